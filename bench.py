@@ -1,0 +1,243 @@
+#!/usr/bin/env python
+"""bench.py -- DSI build + fuse + arg-max throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one stereo batch that is already resident
+in HBM:  for each of the 2 cameras  evaluateDSI past the pose lookup (per-packet
+homography, z0 warp, reset, voting; mapper_emvs_stereo.cpp:108-146), then camera fusion
+(harmonic mean, process1.cpp:126-141), then arg-max + depth (cartesian3dgrid.cpp:115-137,
+mapper_emvs_stereo.cpp:302-313).  At N = 1 this is BASELINE.json configs[1]:
+"Stereo (2-cam) DSEC, 10 M events/cam, 346x260x100 DSI, harmonic fusion, 1xMI355X".
+
+N > 1 (one process per GPU, launched by torch.distributed.run): every rank owns an
+independent time slice of the same size (weak scaling, configs[3] shape), builds and
+camera-fuses its DSI, then the slices are fused across time with the reference's
+harmonic accumulator (process2.cpp:217-226): local 1/(0.01+v), ONE RCCL all-reduce(sum)
+of the 36 MB volume over xGMI, local n/acc, arg-max.  value = events voted by all ranks
+/ max-over-ranks time.
+
+Prints ONE JSON line (rank 0).  Data: synthetic (dvs_mcemvs_amd/synthetic.py).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--events", type=int, default=10_000_000, help="events per camera per GPU")
+    ap.add_argument("--dims", type=int, nargs=3, default=[346, 260, 100])
+    ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 global atomics, 2 LDS bands")
+    ap.add_argument("--band", type=int, nargs=3, default=[0, 0, 0], help="band_rows chunks block")
+    ap.add_argument("--cpu-sample", type=int, default=2_000_000,
+                    help="events of camera 0 the CPU oracle is timed on (0 = skip)")
+    ap.add_argument("--no-cpu", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    torch = None
+    if world > 1:
+        # torch first: libdsi_engine.so then binds to the HIP runtime torch already loaded,
+        # so that RCCL (torch.distributed "nccl") and the engine share one runtime.
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0:
+        print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world),
+              file=sys.stderr)
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if dist is not None:
+        dist.barrier()
+    import dvs_mcemvs_amd as d
+    from dvs_mcemvs_amd import synthetic as syn
+
+    nx, ny, nz = args.dims
+    ctx = d.Context(local_rank)
+
+    # ---- inputs: one stereo time slice per rank, generated and uploaded before timing ----
+    t_gen = time.time()
+    rig = syn.stereo_rig(args.events, width=nx, height=ny, t0=10.0 + 0.5 * rank, duration=0.5,
+                         seed=1234 + 100 * rank)
+    shape = d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0)  # cfg/DSEC/zurich_04_a_full/dsec.conf:11-12,17
+    mappers, batches, voted = [], [], 0
+    for c in range(2):
+        m = d.MapperEMVS(ctx, rig["cam"], shape)
+        m.set_vote_algo(args.algo)
+        m.set_band_params(*args.band)
+        first, Rt = d.packetize(rig["events"][c][2], rig["trajectories"][c], rig["T_rv_w"])
+        batches.append(d.EventBatch(ctx, rig["events"][c][0], rig["events"][c][1], Rt, first))
+        voted += first.shape[0] * d.PACKET_SIZE
+        mappers.append(m)
+    fused = d.Grid3D(ctx, nx, ny, nz)
+    t_gen = time.time() - t_gen
+
+    tfuse = None
+    if world > 1:
+        tfuse = torch.empty((nz, ny, nx), dtype=torch.float32, device="cuda")
+        acc = d.Grid3D(ctx, nx, ny, nz, device_ptr=tfuse.data_ptr())
+
+    def step():
+        for c in range(2):
+            mappers[c].evaluateDSI_batch(batches[c])
+        fused.resetGrid()                     # process1.cpp:126-127: copy-by-add
+        fused.addTwoGrids(mappers[0].dsi_)
+        fused.harmonicMeanTwoGrids(mappers[1].dsi_)
+        if world == 1:
+            mappers[0].computeDepthMap(fused)
+        else:
+            acc.resetGrid()
+            acc.addInverseOfTwoGrids(fused)   # process2.cpp:220
+            ctx.synchronize()                 # engine stream -> torch stream hand-off
+            dist.all_reduce(tfuse)            # RCCL sum over xGMI
+            torch.cuda.current_stream().synchronize()
+            acc.computeHMfromSumOfInv(world)  # process2.cpp:222-225
+            mappers[0].computeDepthMap(acc)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+        ctx.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    for m in mappers:
+        m.set_kernel_timing(True)
+        m.vote_kernel_time()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for _ in range(args.steps):
+        step()
+    gpu_ms = ctx.timer_stop()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kt_ms, kt_n = 0.0, 0
+    for m in mappers:
+        ms, n = m.vote_kernel_time()
+        kt_ms += ms
+        kt_n += n
+        m.set_kernel_timing(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        v = torch.tensor([float(voted)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(v)
+        voted_all = float(v.item())
+    else:
+        voted_all = float(voted)
+
+    # ---- fusion + arg-max kernels on their own (DSI-fuse GB/s, 12 B/voxel algorithmic) ----
+    reps = 50
+    ctx.timer_start()
+    for _ in range(reps):
+        fused.harmonicMeanTwoGrids(mappers[1].dsi_)
+    fuse_ms = ctx.timer_stop() / reps
+    ctx.timer_start()
+    for _ in range(reps):
+        mappers[0].computeDepthMap(fused)
+    argmax_ms = ctx.timer_stop() / reps
+    nvox = nx * ny * nz
+    fuse_gbps = 12.0 * nvox / (fuse_ms * 1e-3) / 1e9
+    argmax_gbps = (4.0 * nz + 9.0) * nx * ny / (argmax_ms * 1e-3) / 1e9
+
+    info = mappers[0].last_vote_info()
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = voted_all * args.steps / elapsed / 1e6  # Mevents/s, whole job
+
+    # ---- roofline of the dominant kernel (the voting kernel) ----
+    # algorithmic bytes per event = Nz * 4 voxels * 8 B (fp32 read+write) + 8 B (x0,y0)
+    # (SURVEY.md 8d); one launch votes one camera's events of this rank.
+    bytes_per_event = 32.0 * nz + 8.0
+    ev_per_launch = voted / 2.0
+    kern_ms = kt_ms / max(1, kt_n)
+    achieved = bytes_per_event * ev_per_launch / (kern_ms * 1e-3) / 1e9 if kt_n else None
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
+                "kernel": "k_vote_bands" if info["algo"] == 2 else "k_vote_global",
+                "kernel_avg_ms": kern_ms, "kernel_launches": kt_n,
+                "algorithmic_bytes_per_launch": bytes_per_event * ev_per_launch,
+                "kernel_Mevents_per_s": ev_per_launch / (kern_ms * 1e-3) / 1e6 if kt_n else None}
+
+    # ---- CPU baseline: the oracle (a port of the reference's CPU path) on a bounded sample ----
+    cpu = None
+    if rank == 0 and not args.no_cpu and args.cpu_sample >= 2048:
+        from oracle import oracle as orc
+        from oracle_pipeline import OracleMapper
+        n_s = min(args.cpu_sample, rig["events"][0][0].shape[0])
+        x, y, ts = (a[:n_s] for a in rig["events"][0])
+        r = OracleMapper(rig["cam"], dimZ=nz, min_depth=4.0, max_depth=200.0)
+        first, Rt = d.packetize(ts, rig["trajectories"][0], rig["T_rv_w"])
+        first = first.astype(np.int64)
+        r.evaluate_packets(x, y, first[:8], Rt[:8])  # warm-up (page in, spin up OpenMP)
+        tc = time.perf_counter()
+        r.evaluate_packets(x, y, first, Rt)          # stage A + reset + fillVoxelGrid
+        tc = time.perf_counter() - tc
+        cpu = {"value": first.shape[0] * 1024 / tc / 1e6, "unit": "Mevents/s",
+               "cores": orc.num_threads(), "kind": "port",
+               "sample": "camera 0, first %d events (%d packets) of the same workload, %dx%dx%d DSI; "
+                         "oracle stage A + fillVoxelGrid, OpenMP over planes, -O3 no -march=native; %.1f s"
+                         % (n_s, first.shape[0], nx, ny, nz, tc)}
+
+    if rank == 0:
+        out = {
+            "metric": "Mevents/s into DSI (346x260x100) + DSI-fuse GB/s",
+            "value": value, "unit": "Mevents/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "stereo (2-cam) synthetic DSEC-like rig, %d events/cam per GPU, %dx%dx%d DSI, "
+                            "harmonic camera fusion + arg-max%s" % (
+                                args.events, nx, ny, nz,
+                                "" if world == 1 else
+                                ", %d time slices (one per GPU) fused by RCCL all-reduce of inverse sums" % world),
+                "events_voted_per_step": voted_all, "vote_algo": info["algo"], "bands": info["bands"],
+                "band_rows": info["band_rows"], "chunks": info["chunks"],
+                "block_threads": info["block_threads"], "lds_bytes": info["lds_bytes"],
+                "parallelism": "1 GPU" if world == 1 else "time-slice x%d" % world},
+            "dsi_fuse_GBps": fuse_gbps, "dsi_fuse_ms": fuse_ms, "dsi_fuse_frac_of_hbm_peak": fuse_gbps / HBM_PEAK_GBPS,
+            "argmax_GBps": argmax_gbps, "argmax_ms": argmax_ms,
+            "gpu_ms_per_step_hip_events": gpu_ms / args.steps,
+            "roofline": roofline, "cpu_baseline": cpu, "input_gen_s": t_gen,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

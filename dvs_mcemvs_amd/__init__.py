@@ -1,0 +1,41 @@
+"""dvs_mcemvs_amd -- MI355X-native DSI construction / fusion / arg-max engine.
+
+Thin ctypes binding over the C ABI in include/dsi_engine.h (libdsi_engine.so,
+hand-written HIP for gfx950).  Class and method names follow the reference
+(tub-rip/dvs_mcemvs): ``Grid3D`` (cartesian3dgrid.h) and ``MapperEMVS``
+(mapper_emvs_stereo.hpp).  There is no CPU or PyTorch fallback anywhere in this
+package: if the shared library is missing or no gfx950 GPU is visible, the
+constructors raise.
+"""
+from .engine import (  # noqa: F401
+    ACC_INV_SUM,
+    ACC_SUM,
+    FUSE_AM,
+    FUSE_GM,
+    FUSE_HM,
+    FUSE_MAX,
+    FUSE_MIN,
+    FUSE_RMS,
+    PACKET_SIZE,
+    VOTE_AUTO,
+    VOTE_GLOBAL_ATOMIC,
+    VOTE_LDS_BANDS,
+    Context,
+    DsiError,
+    EventBatch,
+    Grid3D,
+    MapperEMVS,
+    ShapeDSI,
+    device_count,
+    library_path,
+    load_library,
+    packetize,
+    pose_at,
+)
+
+__all__ = [
+    "Context", "Grid3D", "MapperEMVS", "ShapeDSI", "EventBatch", "DsiError", "device_count",
+    "library_path", "load_library", "packetize", "pose_at", "PACKET_SIZE",
+    "FUSE_MIN", "FUSE_HM", "FUSE_GM", "FUSE_AM", "FUSE_RMS", "FUSE_MAX", "ACC_SUM", "ACC_INV_SUM",
+    "VOTE_AUTO", "VOTE_GLOBAL_ATOMIC", "VOTE_LDS_BANDS",
+]

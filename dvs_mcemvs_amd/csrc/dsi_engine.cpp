@@ -1,0 +1,940 @@
+// dsi_engine.cpp -- C ABI (include/dsi_engine.h) over the gfx950 kernels.
+// Host-side mirror of the reference objects on the hot path:
+//   dsi_grid_t    <-> Grid3D        (cartesian3dgrid.h / cartesian3dgrid.cpp)
+//   dsi_mapper_t  <-> MapperEMVS    (mapper_emvs_stereo.hpp / .cpp)
+//   dsi_batch_t   <-> the (events, per-packet pose) pairs evaluateDSI iterates over
+// There is no CPU implementation behind this ABI: without a gfx950 device every
+// constructor fails with DSI_ERR_NO_DEVICE.
+#include "../../include/dsi_engine.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "dsi_host.hpp"
+#include "dsi_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(DSI_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
+                        __FILE__, __LINE__);                                                 \
+    } while (0)
+
+#define REQUIRE(cond, code, ...)                  \
+    do {                                          \
+        if (!(cond)) return fail(code, __VA_ARGS__); \
+    } while (0)
+
+// device buffer that only ever grows
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) {
+            hipError_t e = hipFree(p);  // implicit device sync
+            p = nullptr;
+            cap = 0;
+            if (e != hipSuccess) return e;
+        }
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), n * sizeof(T));
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+}  // namespace
+
+struct dsi_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    double* ms_accum = nullptr;  // device scalar for mean-square
+};
+
+struct dsi_grid {
+    dsi_context* ctx = nullptr;
+    int nx = 0, ny = 0, nz = 0;
+    size_t n = 0;
+    float* data = nullptr;
+    bool owned = false;
+};
+
+struct dsi_batch {
+    dsi_context* ctx = nullptr;
+    uint16_t *x = nullptr, *y = nullptr;
+    uint32_t* first = nullptr;
+    float* Rt = nullptr;
+    size_t n_events = 0, n_packets = 0;
+};
+
+struct dsi_mapper {
+    dsi_context* ctx = nullptr;
+    int sensor_w = 0, sensor_h = 0;
+    dsi::Geom geom{};
+    std::vector<float> planes;  // raw_depths_vec_
+    float* planes_dev = nullptr;
+    float2* lut_dev = nullptr;
+    dsi_grid* grid = nullptr;
+    int algo = DSI_VOTE_AUTO;
+    int want_band_rows = 0, want_chunks = 0, want_block = 0;
+    dsi_vote_info_t info{};
+    // scratch
+    DevBuf<float> centers, H, partials, Rt_tmp, conf, depth;
+    DevBuf<float2> xy, sxy;
+    DevBuf<uint32_t> nvalid, cuts;
+    DevBuf<dsi::PlaneCoef> coef;
+    DevBuf<uint8_t> idx;
+    bool depth_valid = false;
+    // HIP-event stopwatch around the dominant (voting) kernel, for bench.py's roofline
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_pairs;  // recorded, not yet read
+    std::vector<hipEvent_t> timing_pool;
+};
+
+namespace {
+
+int set_device(const dsi_context* ctx)
+{
+    HIP_TRY(hipSetDevice(ctx->device));
+    return DSI_OK;
+}
+
+// ShapeDSI + setupDSI (mapper_emvs_stereo.cpp:208-241), depth_vector.hpp:76-163
+void make_planes(float min_depth, float max_depth, int nz, bool inverse, std::vector<float>* out)
+{
+    if (min_depth > max_depth) std::swap(min_depth, max_depth);  // depth_vector.hpp:33-36
+    out->resize(nz);
+    if (!inverse) {
+        const float mult = (float)nz / (max_depth - min_depth);  // :88
+        for (int i = 0; i < nz; ++i) (*out)[i] = min_depth + (float)i / mult;  // :93
+    } else {
+        const float inv_min = 1.f / min_depth, inv_max = 1.f / max_depth;  // :131-132
+        const float mult = (float)nz / (inv_min - inv_max);
+        for (int i = 0; i < nz; ++i) {
+            const float rho = inv_max + (float)i / mult;  // :138
+            (*out)[i] = 1.f / rho;                        // :145-148
+        }
+    }
+}
+
+float virtual_focal(float cam_fx, float fov_deg, int dim_x)
+{
+    if (fov_deg < 10.f) return cam_fx;  // mapper_emvs_stereo.cpp:220-224
+    const float fov_rad = (float)((double)fov_deg * 3.1415926535897932384626433832795 / 180.0);
+    return (float)(0.5 * (double)(float)dim_x / std::tan(0.5 * (double)fov_rad));  // :227-228
+}
+
+// Choose the LDS band decomposition for a grid and a packet count.
+bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
+{
+    const dsi::Geom& g = m->geom;
+    const size_t row_bytes = (size_t)g.nx * sizeof(float);
+    const long max_rows_total = (long)(dsi::max_dynamic_lds() / row_bytes);
+    if (max_rows_total < 3 || g.nx < 2 || g.ny < 2) return false;
+    long max_owned = max_rows_total - 2;
+    if (m->want_band_rows > 0) max_owned = std::min<long>(max_owned, m->want_band_rows);
+    int bands = (int)((g.ny + max_owned - 1) / max_owned);
+    int band_rows = (g.ny + bands - 1) / bands;  // balanced
+    if (m->want_band_rows > 0) band_rows = (int)std::min<long>(m->want_band_rows, max_owned);
+    bands = (g.ny + band_rows - 1) / band_rows;
+    bp->bands = bands;
+    bp->band_rows = band_rows;
+    bp->lds_bytes = (size_t)(band_rows + 2) * row_bytes;
+    bp->block_threads = m->want_block > 0 ? m->want_block : 1024;
+    int chunks = m->want_chunks;
+    if (chunks <= 0) {
+        const long items_target = 8L * 256;  // ~8 work items per CU
+        chunks = (int)std::max<long>(1, (items_target + (long)bands * g.nz - 1) / ((long)bands * g.nz));
+        // keep (chunks * bands) a multiple of 8 so that all XCDs get the same number of pairs
+        int step = 8;
+        for (int f = 2; f <= 8; f *= 2)
+            if (bands % f == 0) step = 8 / f;
+        if (chunks > 1 || (bands % 8) != 0) chunks = ((chunks + step - 1) / step) * step;
+        chunks = (int)std::min<size_t>((size_t)chunks, std::max<size_t>(1, n_packets));
+        const size_t vol_bytes = (size_t)g.nx * g.ny * g.nz * sizeof(float);
+        const size_t budget = (size_t)16 << 30;  // partial DSIs may use up to 16 GiB of HBM
+        while (chunks > 1 && (size_t)chunks * vol_bytes > budget) --chunks;
+    }
+    bp->chunks = std::max(1, chunks);
+    return true;
+}
+
+int upload_async(dsi_context* ctx, void* dst, const void* src, size_t bytes)
+{
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return DSI_OK;
+}
+
+hipEvent_t timing_event(dsi_mapper* m)
+{
+    if (!m->timing_pool.empty()) {
+        hipEvent_t e = m->timing_pool.back();
+        m->timing_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+struct VoteTimer {  // records an event pair around the voting kernel when timing is on
+    dsi_mapper* m;
+    hipEvent_t a = nullptr, b = nullptr;
+    explicit VoteTimer(dsi_mapper* m_) : m(m_)
+    {
+        if (!m->timing) return;
+        a = timing_event(m);
+        b = timing_event(m);
+        if (a && b) (void)hipEventRecord(a, m->ctx->stream);
+    }
+    void stop()
+    {
+        if (!a || !b) return;
+        (void)hipEventRecord(b, m->ctx->stream);
+        m->timing_pairs.emplace_back(a, b);
+        a = b = nullptr;
+    }
+};
+
+// fillVoxelGrid on device data.  xy: np*1024 z0 locations (reference order);
+// centers: np*3.  accumulate != 0: add to the grid's current contents.
+int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np, bool accumulate)
+{
+    dsi_context* ctx = m->ctx;
+    dsi_grid* g = m->grid;
+    const dsi::Geom& geom = m->geom;
+    dsi::BandPlan bp{};
+    int algo = m->algo;
+    const bool can_band = plan_bands(m, np, &bp);
+    if (algo == DSI_VOTE_AUTO) algo = can_band ? DSI_VOTE_LDS_BANDS : DSI_VOTE_GLOBAL_ATOMIC;
+    if (algo == DSI_VOTE_LDS_BANDS && !can_band)
+        return fail(DSI_ERR_INVALID, "grid rows of %d floats do not fit the LDS band kernel", geom.nx);
+
+    m->info = dsi_vote_info_t{};
+    m->info.algo = algo;
+    m->info.n_packets = np;
+    m->depth_valid = false;
+
+    if (algo == DSI_VOTE_GLOBAL_ATOMIC) {
+        if (!accumulate) HIP_TRY(hipMemsetAsync(g->data, 0, g->n * sizeof(float), ctx->stream));
+        VoteTimer vt(m);
+        HIP_TRY(dsi::launch_vote_global(ctx->stream, xy, centers, (int)np, m->planes_dev, geom, g->data));
+        vt.stop();
+        return DSI_OK;
+    }
+
+    m->info.bands = bp.bands;
+    m->info.band_rows = bp.band_rows;
+    m->info.chunks = bp.chunks;
+    m->info.block_threads = bp.block_threads;
+    m->info.lds_bytes = bp.lds_bytes;
+    if (np == 0) {
+        if (!accumulate) HIP_TRY(hipMemsetAsync(g->data, 0, g->n * sizeof(float), ctx->stream));
+        return DSI_OK;
+    }
+    HIP_TRY(m->sxy.reserve(np * dsi::kPacket));
+    HIP_TRY(m->nvalid.reserve(np));
+    HIP_TRY(m->coef.reserve(np * geom.nz));
+    HIP_TRY(m->cuts.reserve(np * geom.nz * bp.bands));
+    const bool direct = (bp.chunks == 1 && !accumulate);
+    if (!direct) HIP_TRY(m->partials.reserve((size_t)bp.chunks * g->n));
+
+    HIP_TRY(dsi::launch_sort_packets(ctx->stream, xy, (int)np, m->sxy.p, m->nvalid.p));
+    HIP_TRY(dsi::launch_plane_coef(ctx->stream, centers, m->planes_dev, m->sxy.p, m->nvalid.p, (int)np,
+                                   geom, bp, m->coef.p, m->cuts.p));
+    VoteTimer vt(m);
+    HIP_TRY(dsi::launch_vote_bands(ctx->stream, m->sxy.p, m->coef.p, m->cuts.p, (int)np, geom, bp,
+                                   direct ? g->data : m->partials.p));
+    vt.stop();
+    if (!direct)
+        HIP_TRY(dsi::launch_reduce_partials(ctx->stream, m->partials.p, bp.chunks, g->n, g->data,
+                                            accumulate ? 1 : 0));
+    return DSI_OK;
+}
+
+bool same_shape(const dsi_grid* a, const dsi_grid* b)
+{
+    return a->nx == b->nx && a->ny == b->ny && a->nz == b->nz;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dsi_last_error(void) { return g_last_error.c_str(); }
+int dsi_abi_version(void) { return DSI_ENGINE_ABI_VERSION; }
+
+int dsi_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+/* ------------------------------------------------------------------ context */
+int dsi_context_create(int device_id, dsi_context_t** out)
+{
+    REQUIRE(out, DSI_ERR_INVALID, "out is null");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(DSI_ERR_NO_DEVICE, "no HIP device visible (this engine has no CPU fallback)");
+    REQUIRE(device_id >= 0 && device_id < n, DSI_ERR_NO_DEVICE, "device %d out of range (%d devices)",
+            device_id, n);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(DSI_ERR_NO_DEVICE, "device %d is %s; the kernels are built for gfx950 only", device_id,
+                    prop.gcnArchName);
+    HIP_TRY(hipSetDevice(device_id));
+    dsi_context* ctx = new (std::nothrow) dsi_context();
+    REQUIRE(ctx, DSI_ERR_INVALID, "out of host memory");
+    ctx->device = device_id;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->t0);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->t1);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->ms_accum), sizeof(double));
+    if (e != hipSuccess) {
+        dsi_context_destroy(ctx);
+        return fail(DSI_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
+    }
+    *out = ctx;
+    return DSI_OK;
+}
+
+int dsi_context_destroy(dsi_context_t* ctx)
+{
+    if (!ctx) return DSI_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ms_accum) (void)hipFree(ctx->ms_accum);
+    if (ctx->t0) (void)hipEventDestroy(ctx->t0);
+    if (ctx->t1) (void)hipEventDestroy(ctx->t1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return DSI_OK;
+}
+
+int dsi_context_synchronize(dsi_context_t* ctx)
+{
+    REQUIRE(ctx, DSI_ERR_INVALID, "ctx is null");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return DSI_OK;
+}
+
+void* dsi_context_stream(dsi_context_t* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+int dsi_context_device(dsi_context_t* ctx) { return ctx ? ctx->device : -1; }
+
+int dsi_context_timer_start(dsi_context_t* ctx)
+{
+    REQUIRE(ctx, DSI_ERR_INVALID, "ctx is null");
+    HIP_TRY(hipEventRecord(ctx->t0, ctx->stream));
+    return DSI_OK;
+}
+
+int dsi_context_timer_stop(dsi_context_t* ctx, float* elapsed_ms)
+{
+    REQUIRE(ctx && elapsed_ms, DSI_ERR_INVALID, "null argument");
+    HIP_TRY(hipEventRecord(ctx->t1, ctx->stream));
+    HIP_TRY(hipEventSynchronize(ctx->t1));
+    HIP_TRY(hipEventElapsedTime(elapsed_ms, ctx->t0, ctx->t1));
+    return DSI_OK;
+}
+
+/* ------------------------------------------------------------------- Grid3D */
+static int grid_make(dsi_context_t* ctx, int nx, int ny, int nz, void* wrap, dsi_grid_t** out)
+{
+    REQUIRE(ctx && out, DSI_ERR_INVALID, "null argument");
+    *out = nullptr;
+    REQUIRE(nx > 0 && ny > 0 && nz > 0, DSI_ERR_INVALID, "grid dimensions must be positive (%d,%d,%d)", nx,
+            ny, nz);
+    if (int rc = set_device(ctx)) return rc;
+    dsi_grid* g = new (std::nothrow) dsi_grid();
+    REQUIRE(g, DSI_ERR_INVALID, "out of host memory");
+    g->ctx = ctx;
+    g->nx = nx;
+    g->ny = ny;
+    g->nz = nz;
+    g->n = (size_t)nx * ny * nz;
+    if (wrap) {
+        g->data = static_cast<float*>(wrap);
+        g->owned = false;
+    } else {
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&g->data), g->n * sizeof(float));
+        if (e == hipSuccess) e = hipMemsetAsync(g->data, 0, g->n * sizeof(float), ctx->stream);
+        if (e != hipSuccess) {
+            if (g->data) (void)hipFree(g->data);
+            delete g;
+            return fail(DSI_ERR_HIP, "grid allocation of %zu bytes failed: %s", g->n * sizeof(float),
+                        hipGetErrorString(e));
+        }
+        g->owned = true;
+    }
+    *out = g;
+    return DSI_OK;
+}
+
+int dsi_grid_create(dsi_context_t* ctx, int nx, int ny, int nz, dsi_grid_t** out)
+{
+    return grid_make(ctx, nx, ny, nz, nullptr, out);
+}
+
+int dsi_grid_wrap(dsi_context_t* ctx, int nx, int ny, int nz, void* data_dev, dsi_grid_t** out)
+{
+    REQUIRE(data_dev, DSI_ERR_INVALID, "data_dev is null");
+    return grid_make(ctx, nx, ny, nz, data_dev, out);
+}
+
+int dsi_grid_destroy(dsi_grid_t* g)
+{
+    if (!g) return DSI_OK;
+    (void)hipSetDevice(g->ctx->device);
+    (void)hipStreamSynchronize(g->ctx->stream);
+    if (g->owned && g->data) (void)hipFree(g->data);
+    delete g;
+    return DSI_OK;
+}
+
+int dsi_grid_dims(const dsi_grid_t* g, int* nx, int* ny, int* nz)
+{
+    REQUIRE(g, DSI_ERR_INVALID, "grid is null");
+    if (nx) *nx = g->nx;
+    if (ny) *ny = g->ny;
+    if (nz) *nz = g->nz;
+    return DSI_OK;
+}
+
+int dsi_grid_reset(dsi_grid_t* g)
+{
+    REQUIRE(g, DSI_ERR_INVALID, "grid is null");
+    if (int rc = set_device(g->ctx)) return rc;
+    HIP_TRY(hipMemsetAsync(g->data, 0, g->n * sizeof(float), g->ctx->stream));
+    return DSI_OK;
+}
+
+void* dsi_grid_device_ptr(dsi_grid_t* g) { return g ? g->data : nullptr; }
+
+int dsi_grid_upload(dsi_grid_t* g, const float* host)
+{
+    REQUIRE(g && host, DSI_ERR_INVALID, "null argument");
+    if (int rc = set_device(g->ctx)) return rc;
+    HIP_TRY(hipMemcpyAsync(g->data, host, g->n * sizeof(float), hipMemcpyHostToDevice, g->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(g->ctx->stream));
+    return DSI_OK;
+}
+
+int dsi_grid_download(dsi_grid_t* g, float* host)
+{
+    REQUIRE(g && host, DSI_ERR_INVALID, "null argument");
+    if (int rc = set_device(g->ctx)) return rc;
+    HIP_TRY(hipMemcpyAsync(host, g->data, g->n * sizeof(float), hipMemcpyDeviceToHost, g->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(g->ctx->stream));
+    return DSI_OK;
+}
+
+static int check_pair(const dsi_grid_t* dst, const dsi_grid_t* src)
+{
+    REQUIRE(dst && src, DSI_ERR_INVALID, "null grid");
+    REQUIRE(dst->ctx == src->ctx, DSI_ERR_CONTEXT, "grids belong to different contexts");
+    REQUIRE(same_shape(dst, src), DSI_ERR_SHAPE, "grid shapes differ: (%d,%d,%d) vs (%d,%d,%d)", dst->nx,
+            dst->ny, dst->nz, src->nx, src->ny, src->nz);
+    return set_device(dst->ctx);
+}
+
+int dsi_grid_fuse2(dsi_grid_t* dst, const dsi_grid_t* src, int op)
+{
+    if (int rc = check_pair(dst, src)) return rc;
+    REQUIRE(op >= 1 && op <= 6, DSI_ERR_BAD_OP, "improper fusion method %d (expected 1..6)", op);
+    HIP_TRY(dsi::launch_fuse2(dst->ctx->stream, dst->data, src->data, dst->n, op));
+    return DSI_OK;
+}
+
+int dsi_grid_fuse_hm_n(dsi_grid_t* dst, const dsi_grid_t* src, int n)
+{
+    if (int rc = check_pair(dst, src)) return rc;
+    REQUIRE(n >= 2, DSI_ERR_INVALID, "n-ary harmonic mean needs n >= 2 (got %d)", n);
+    HIP_TRY(dsi::launch_fuse_hm_n(dst->ctx->stream, dst->data, src->data, dst->n, n));
+    return DSI_OK;
+}
+
+int dsi_grid_accumulate(dsi_grid_t* dst, const dsi_grid_t* src, int mode)
+{
+    if (int rc = check_pair(dst, src)) return rc;
+    REQUIRE(mode == DSI_ACC_SUM || mode == DSI_ACC_INV_SUM, DSI_ERR_BAD_OP, "bad accumulate mode %d", mode);
+    HIP_TRY(dsi::launch_accumulate(dst->ctx->stream, dst->data, src->data, dst->n, mode));
+    return DSI_OK;
+}
+
+int dsi_grid_finalize(dsi_grid_t* dst, int mode, int n)
+{
+    REQUIRE(dst, DSI_ERR_INVALID, "grid is null");
+    REQUIRE(mode == DSI_ACC_SUM || mode == DSI_ACC_INV_SUM, DSI_ERR_BAD_OP, "bad finalize mode %d", mode);
+    if (int rc = set_device(dst->ctx)) return rc;
+    HIP_TRY(dsi::launch_finalize(dst->ctx->stream, dst->data, dst->n, mode, n));
+    return DSI_OK;
+}
+
+int dsi_grid_collapse_max_z_dev(dsi_grid_t* g, float* conf_dev, uint8_t* idx_dev, const float* planes_dev,
+                                float* depth_dev)
+{
+    REQUIRE(g && conf_dev && idx_dev, DSI_ERR_INVALID, "null argument");
+    REQUIRE(g->nz <= 256, DSI_ERR_INVALID, "arg-max indices are u8: dimZ must be <= 256 (got %d)", g->nz);
+    REQUIRE(!depth_dev || planes_dev, DSI_ERR_INVALID, "depth output needs the plane depths");
+    if (int rc = set_device(g->ctx)) return rc;
+    HIP_TRY(dsi::launch_collapse_max_z(g->ctx->stream, g->data, g->nx, g->ny, g->nz, conf_dev, idx_dev,
+                                       planes_dev, depth_dev));
+    return DSI_OK;
+}
+
+int dsi_grid_collapse_max_z(dsi_grid_t* g, float* conf_host, uint8_t* idx_host)
+{
+    REQUIRE(g && conf_host && idx_host, DSI_ERR_INVALID, "null argument");
+    if (int rc = set_device(g->ctx)) return rc;
+    const size_t npix = (size_t)g->nx * g->ny;
+    float* conf = nullptr;
+    uint8_t* idx = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&conf), npix * sizeof(float)));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&idx), npix);
+    int rc = DSI_OK;
+    if (e != hipSuccess) {
+        rc = fail(DSI_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+    } else {
+        rc = dsi_grid_collapse_max_z_dev(g, conf, idx, nullptr, nullptr);
+        if (rc == DSI_OK) {
+            e = hipMemcpyAsync(conf_host, conf, npix * sizeof(float), hipMemcpyDeviceToHost, g->ctx->stream);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(idx_host, idx, npix, hipMemcpyDeviceToHost, g->ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(g->ctx->stream);
+            if (e != hipSuccess) rc = fail(DSI_ERR_HIP, "copy back failed: %s", hipGetErrorString(e));
+        }
+    }
+    (void)hipStreamSynchronize(g->ctx->stream);
+    if (conf) (void)hipFree(conf);
+    if (idx) (void)hipFree(idx);
+    return rc;
+}
+
+int dsi_grid_mean_square(dsi_grid_t* g, double* out)
+{
+    REQUIRE(g && out, DSI_ERR_INVALID, "null argument");
+    dsi_context* ctx = g->ctx;
+    if (int rc = set_device(ctx)) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->ms_accum, 0, sizeof(double), ctx->stream));
+    HIP_TRY(dsi::launch_mean_square(ctx->stream, g->data, g->n, ctx->ms_accum));
+    double sum = 0;
+    HIP_TRY(hipMemcpyAsync(&sum, ctx->ms_accum, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *out = sum / (double)g->n;  // cartesian3dgrid.cpp:173
+    return DSI_OK;
+}
+
+/* --------------------------------------------------------------- MapperEMVS */
+int dsi_mapper_create(dsi_context_t* ctx, const dsi_mapper_config_t* cfg, dsi_mapper_t** out)
+{
+    REQUIRE(ctx && cfg && out, DSI_ERR_INVALID, "null argument");
+    *out = nullptr;
+    REQUIRE(cfg->sensor_width > 0 && cfg->sensor_height > 0, DSI_ERR_INVALID, "sensor size must be positive");
+    REQUIRE(cfg->sensor_width <= 65536 && cfg->sensor_height <= 65536, DSI_ERR_INVALID,
+            "event coordinates are u16");
+    // glog CHECKs of setupDSI (mapper_emvs_stereo.cpp:210-211) and PinholeCamera
+    // (geometry_utils.hpp:36-41) become error codes
+    REQUIRE(cfg->min_depth > 0.f, DSI_ERR_INVALID, "min_depth must be > 0");
+    REQUIRE(cfg->max_depth > cfg->min_depth, DSI_ERR_INVALID, "max_depth must be > min_depth");
+    REQUIRE(cfg->dim_z >= 1 && cfg->dim_z <= 256, DSI_ERR_INVALID, "dimZ must be in 1..256 (main.cpp:156)");
+    REQUIRE(cfg->dim_x >= 0 && cfg->dim_y >= 0, DSI_ERR_INVALID, "dimX/dimY must be >= 0");
+    REQUIRE(cfg->K[0] > 0.f && cfg->K[1] > 0.f && cfg->K[2] > 0.f && cfg->K[3] > 0.f, DSI_ERR_INVALID,
+            "camera fx, fy, cx, cy must be > 0");
+    if (int rc = set_device(ctx)) return rc;
+
+    dsi_mapper* m = new (std::nothrow) dsi_mapper();
+    REQUIRE(m, DSI_ERR_INVALID, "out of host memory");
+    m->ctx = ctx;
+    m->sensor_w = cfg->sensor_width;
+    m->sensor_h = cfg->sensor_height;
+    dsi::Geom& g = m->geom;
+    g.nx = cfg->dim_x > 0 ? cfg->dim_x : cfg->sensor_width;   // :216
+    g.ny = cfg->dim_y > 0 ? cfg->dim_y : cfg->sensor_height;  // :217
+    g.nz = cfg->dim_z;
+    g.kfx = cfg->K[0];
+    g.kfy = cfg->K[1];
+    g.kcx = cfg->K[2];
+    g.kcy = cfg->K[3];
+    const float f = virtual_focal(cfg->K[0], cfg->fov_deg, g.nx);
+    g.vfx = f;  // :236-239: PinholeCamera(dimX, dimY, f, f, cam.cx(), cam.cy())
+    g.vfy = f;
+    g.vcx = cfg->K[2];
+    g.vcy = cfg->K[3];
+    make_planes(cfg->min_depth, cfg->max_depth, g.nz, cfg->inverse_depth != 0, &m->planes);
+    g.z0 = m->planes[0];  // :111, :163
+
+    int rc = DSI_OK;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&m->planes_dev), g.nz * sizeof(float));
+    if (e == hipSuccess)
+        e = hipMemcpy(m->planes_dev, m->planes.data(), g.nz * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && cfg->lut) {
+        const size_t bytes = (size_t)cfg->sensor_width * cfg->sensor_height * sizeof(float2);
+        e = hipMalloc(reinterpret_cast<void**>(&m->lut_dev), bytes);
+        if (e == hipSuccess) e = hipMemcpy(m->lut_dev, cfg->lut, bytes, hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) rc = fail(DSI_ERR_HIP, "mapper setup failed: %s", hipGetErrorString(e));
+    if (rc == DSI_OK) rc = dsi_grid_create(ctx, g.nx, g.ny, g.nz, &m->grid);  // :240
+    if (rc != DSI_OK) {
+        std::string keep = g_last_error;
+        dsi_mapper_destroy(m);
+        g_last_error = keep;
+        return rc;
+    }
+    *out = m;
+    return DSI_OK;
+}
+
+int dsi_mapper_destroy(dsi_mapper_t* m)
+{
+    if (!m) return DSI_OK;
+    (void)hipSetDevice(m->ctx->device);
+    (void)hipStreamSynchronize(m->ctx->stream);
+    if (m->grid) dsi_grid_destroy(m->grid);
+    if (m->planes_dev) (void)hipFree(m->planes_dev);
+    if (m->lut_dev) (void)hipFree(m->lut_dev);
+    m->centers.release();
+    m->H.release();
+    m->partials.release();
+    m->Rt_tmp.release();
+    m->conf.release();
+    m->depth.release();
+    m->xy.release();
+    m->sxy.release();
+    m->nvalid.release();
+    m->cuts.release();
+    m->coef.release();
+    m->idx.release();
+    for (auto& pr : m->timing_pairs) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    for (hipEvent_t e : m->timing_pool) (void)hipEventDestroy(e);
+    delete m;
+    return DSI_OK;
+}
+
+dsi_grid_t* dsi_mapper_grid(dsi_mapper_t* m) { return m ? m->grid : nullptr; }
+
+int dsi_mapper_geometry(const dsi_mapper_t* m, float* Kv, float* raw_depths, int* nx, int* ny, int* nz)
+{
+    REQUIRE(m, DSI_ERR_INVALID, "mapper is null");
+    if (Kv) {
+        Kv[0] = m->geom.vfx;
+        Kv[1] = m->geom.vfy;
+        Kv[2] = m->geom.vcx;
+        Kv[3] = m->geom.vcy;
+    }
+    if (raw_depths) std::memcpy(raw_depths, m->planes.data(), m->planes.size() * sizeof(float));
+    if (nx) *nx = m->geom.nx;
+    if (ny) *ny = m->geom.ny;
+    if (nz) *nz = m->geom.nz;
+    return DSI_OK;
+}
+
+int dsi_mapper_set_vote_algo(dsi_mapper_t* m, int algo)
+{
+    REQUIRE(m, DSI_ERR_INVALID, "mapper is null");
+    REQUIRE(algo >= DSI_VOTE_AUTO && algo <= DSI_VOTE_LDS_BANDS, DSI_ERR_INVALID, "unknown vote algorithm %d",
+            algo);
+    m->algo = algo;
+    return DSI_OK;
+}
+
+int dsi_mapper_set_band_params(dsi_mapper_t* m, int band_rows, int chunks, int block_threads)
+{
+    REQUIRE(m, DSI_ERR_INVALID, "mapper is null");
+    REQUIRE(band_rows >= 0 && chunks >= 0, DSI_ERR_INVALID, "band_rows and chunks must be >= 0");
+    REQUIRE(block_threads == 0 || block_threads == 256 || block_threads == 512 || block_threads == 1024,
+            DSI_ERR_INVALID, "block_threads must be 0, 256, 512 or 1024");
+    m->want_band_rows = band_rows;
+    m->want_chunks = chunks;
+    m->want_block = block_threads;
+    return DSI_OK;
+}
+
+int dsi_mapper_fill_voxel_grid(dsi_mapper_t* m, const float* xy_z0, const float* centers, size_t n_packets)
+{
+    REQUIRE(m, DSI_ERR_INVALID, "mapper is null");
+    REQUIRE(n_packets == 0 || (xy_z0 && centers), DSI_ERR_INVALID, "null input");
+    REQUIRE(n_packets < ((size_t)1 << 21), DSI_ERR_INVALID, "too many packets in one call");
+    dsi_context* ctx = m->ctx;
+    if (int rc = set_device(ctx)) return rc;
+    if (n_packets == 0) return DSI_OK;
+    HIP_TRY(m->xy.reserve(n_packets * dsi::kPacket));
+    HIP_TRY(m->centers.reserve(n_packets * 3));
+    if (int rc = upload_async(ctx, m->xy.p, xy_z0, n_packets * dsi::kPacket * sizeof(float2))) return rc;
+    if (int rc = upload_async(ctx, m->centers.p, centers, n_packets * 3 * sizeof(float))) return rc;
+    int rc = vote_device(m, m->xy.p, m->centers.p, n_packets, /*accumulate=*/true);
+    // the host buffers are pageable: do not return before the copies have read them
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return rc;
+}
+
+int dsi_batch_create(dsi_context_t* ctx, const uint16_t* x, const uint16_t* y, size_t n_events,
+                     const uint32_t* packet_first, const float* Rt, size_t n_packets, dsi_batch_t** out)
+{
+    REQUIRE(ctx && out, DSI_ERR_INVALID, "null argument");
+    *out = nullptr;
+    REQUIRE(n_events == 0 || (x && y), DSI_ERR_INVALID, "null event arrays");
+    REQUIRE(n_packets == 0 || Rt, DSI_ERR_INVALID, "null pose array");
+    REQUIRE(n_events < ((size_t)1 << 32), DSI_ERR_INVALID, "at most 2^32-1 events per batch");
+    REQUIRE(n_packets < ((size_t)1 << 21), DSI_ERR_INVALID, "too many packets in one batch");
+    for (size_t k = 0; k < n_packets; ++k) {
+        const size_t first = packet_first ? packet_first[k] : k * dsi::kPacket;
+        REQUIRE(first + dsi::kPacket <= n_events, DSI_ERR_INVALID,
+                "packet %zu [%zu, %zu) exceeds the %zu events given", k, first, first + dsi::kPacket, n_events);
+    }
+    if (int rc = set_device(ctx)) return rc;
+    dsi_batch* b = new (std::nothrow) dsi_batch();
+    REQUIRE(b, DSI_ERR_INVALID, "out of host memory");
+    b->ctx = ctx;
+    b->n_events = n_events;
+    b->n_packets = n_packets;
+    hipError_t e = hipSuccess;
+    const size_t ev_bytes = std::max<size_t>(n_events, 1) * sizeof(uint16_t);
+    e = hipMalloc(reinterpret_cast<void**>(&b->x), ev_bytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&b->y), ev_bytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&b->Rt), std::max<size_t>(n_packets, 1) * 12 * sizeof(float));
+    if (e == hipSuccess && packet_first)
+        e = hipMalloc(reinterpret_cast<void**>(&b->first), std::max<size_t>(n_packets, 1) * sizeof(uint32_t));
+    if (e == hipSuccess && n_events) e = hipMemcpy(b->x, x, n_events * sizeof(uint16_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_events) e = hipMemcpy(b->y, y, n_events * sizeof(uint16_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_packets) e = hipMemcpy(b->Rt, Rt, n_packets * 12 * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && n_packets && packet_first)
+        e = hipMemcpy(b->first, packet_first, n_packets * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        dsi_batch_destroy(b);
+        return fail(DSI_ERR_HIP, "batch upload failed: %s", hipGetErrorString(e));
+    }
+    *out = b;
+    return DSI_OK;
+}
+
+int dsi_batch_destroy(dsi_batch_t* b)
+{
+    if (!b) return DSI_OK;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    if (b->x) (void)hipFree(b->x);
+    if (b->y) (void)hipFree(b->y);
+    if (b->Rt) (void)hipFree(b->Rt);
+    if (b->first) (void)hipFree(b->first);
+    delete b;
+    return DSI_OK;
+}
+
+size_t dsi_batch_num_packets(const dsi_batch_t* b) { return b ? b->n_packets : 0; }
+
+int dsi_mapper_evaluate_batch(dsi_mapper_t* m, const dsi_batch_t* batch)
+{
+    REQUIRE(m && batch, DSI_ERR_INVALID, "null argument");
+    REQUIRE(m->ctx == batch->ctx, DSI_ERR_CONTEXT, "mapper and batch belong to different contexts");
+    dsi_context* ctx = m->ctx;
+    if (int rc = set_device(ctx)) return rc;
+    const size_t np = batch->n_packets;
+    if (np) {
+        HIP_TRY(m->centers.reserve(np * 3));
+        HIP_TRY(m->H.reserve(np * 9));
+        HIP_TRY(m->xy.reserve(np * dsi::kPacket));
+        HIP_TRY(dsi::launch_packet_geometry(ctx->stream, batch->Rt, (int)np, m->geom, m->centers.p, m->H.p));
+        HIP_TRY(dsi::launch_warp_z0(ctx->stream, batch->x, batch->y, batch->first, (int)np, m->H.p,
+                                    m->lut_dev, m->sensor_w, m->xy.p));
+    }
+    // resetGrid (:145) is folded into the vote: accumulate = false
+    return vote_device(m, m->xy.p, m->centers.p, np, /*accumulate=*/false);
+}
+
+int dsi_pose_at(const double* traj_times, const double* traj_poses, size_t n_poses, double t, double* out)
+{
+    REQUIRE(traj_times && traj_poses && out, DSI_ERR_INVALID, "null argument");
+    dsi::host::Pose T;
+    if (!dsi::host::pose_at(traj_times, traj_poses, n_poses, t, &T))
+        return fail(DSI_ERR_INVALID, "cannot extrapolate the trajectory to t=%.9f", t);
+    T.to7(out);
+    return DSI_OK;
+}
+
+int dsi_packetize(const double* ts, size_t n_events, const double* traj_times, const double* traj_poses,
+                  size_t n_poses, const double* T_rv_w, uint32_t* packet_first, float* Rt, size_t* n_packets)
+{
+    REQUIRE(n_packets && T_rv_w && traj_times && traj_poses, DSI_ERR_INVALID, "null argument");
+    REQUIRE(n_events == 0 || ts, DSI_ERR_INVALID, "null timestamps");
+    REQUIRE(n_events < ((size_t)1 << 32), DSI_ERR_INVALID, "at most 2^32-1 events");
+    *n_packets = 0;
+    std::vector<uint32_t> first;
+    std::vector<float> rt;
+    if (!dsi::host::packetize(ts, n_events, traj_times, traj_poses, n_poses, dsi::host::Pose::from7(T_rv_w),
+                              &first, &rt))
+        return fail(DSI_ERR_TOO_FEW_EVENTS, "number of events (%zu) < packet size (%d)", n_events,
+                    DSI_PACKET_SIZE);
+    *n_packets = first.size();
+    if (packet_first && !first.empty()) std::memcpy(packet_first, first.data(), first.size() * sizeof(uint32_t));
+    if (Rt && !rt.empty()) std::memcpy(Rt, rt.data(), rt.size() * sizeof(float));
+    return DSI_OK;
+}
+
+int dsi_mapper_evaluate(dsi_mapper_t* m, const uint16_t* x, const uint16_t* y, const double* ts,
+                        size_t n_events, const double* traj_times, const double* traj_poses, size_t n_poses,
+                        const double* T_rv_w, size_t* n_voted)
+{
+    REQUIRE(m && traj_times && traj_poses && T_rv_w, DSI_ERR_INVALID, "null argument");
+    REQUIRE(n_events == 0 || (x && y && ts), DSI_ERR_INVALID, "null event arrays");
+    REQUIRE(n_events < ((size_t)1 << 32), DSI_ERR_INVALID, "at most 2^32-1 events");
+    if (n_voted) *n_voted = 0;
+    std::vector<uint32_t> first;
+    std::vector<float> rt;
+    if (!dsi::host::packetize(ts, n_events, traj_times, traj_poses, n_poses, dsi::host::Pose::from7(T_rv_w),
+                              &first, &rt))
+        return fail(DSI_ERR_TOO_FEW_EVENTS, "number of events (%zu) < packet size (%d)", n_events,
+                    DSI_PACKET_SIZE);
+    dsi_batch_t* b = nullptr;
+    int rc = dsi_batch_create(m->ctx, x, y, n_events, first.data(), rt.data(), first.size(), &b);
+    if (rc != DSI_OK) return rc;
+    rc = dsi_mapper_evaluate_batch(m, b);
+    std::string keep = g_last_error;
+    dsi_batch_destroy(b);  // synchronises the stream
+    g_last_error = keep;
+    if (rc == DSI_OK && n_voted) *n_voted = first.size() * (size_t)DSI_PACKET_SIZE;
+    return rc;
+}
+
+int dsi_mapper_depth_map_of(dsi_mapper_t* m, dsi_grid_t* g)
+{
+    REQUIRE(m && g, DSI_ERR_INVALID, "null argument");
+    REQUIRE(m->ctx == g->ctx, DSI_ERR_CONTEXT, "mapper and grid belong to different contexts");
+    REQUIRE(same_shape(m->grid, g), DSI_ERR_SHAPE, "grid shape differs from the mapper's DSI");
+    if (int rc = set_device(m->ctx)) return rc;
+    const size_t npix = (size_t)g->nx * g->ny;
+    HIP_TRY(m->conf.reserve(npix));
+    HIP_TRY(m->depth.reserve(npix));
+    HIP_TRY(m->idx.reserve(npix));
+    int rc = dsi_grid_collapse_max_z_dev(g, m->conf.p, m->idx.p, m->planes_dev, m->depth.p);
+    m->depth_valid = (rc == DSI_OK);
+    return rc;
+}
+
+int dsi_mapper_fetch_depth_map(dsi_mapper_t* m, float* depth_host, float* conf_host, uint8_t* idx_host)
+{
+    REQUIRE(m, DSI_ERR_INVALID, "mapper is null");
+    REQUIRE(m->depth_valid, DSI_ERR_INVALID, "no depth map has been computed since the last vote");
+    dsi_context* ctx = m->ctx;
+    if (int rc = set_device(ctx)) return rc;
+    const size_t npix = (size_t)m->geom.nx * m->geom.ny;
+    if (depth_host)
+        HIP_TRY(hipMemcpyAsync(depth_host, m->depth.p, npix * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (conf_host)
+        HIP_TRY(hipMemcpyAsync(conf_host, m->conf.p, npix * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (idx_host) HIP_TRY(hipMemcpyAsync(idx_host, m->idx.p, npix, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return DSI_OK;
+}
+
+int dsi_mapper_depth_map(dsi_mapper_t* m, float* depth_host, float* conf_host, uint8_t* idx_host)
+{
+    REQUIRE(m, DSI_ERR_INVALID, "mapper is null");
+    if (int rc = dsi_mapper_depth_map_of(m, m->grid)) return rc;
+    return dsi_mapper_fetch_depth_map(m, depth_host, conf_host, idx_host);
+}
+
+int dsi_mapper_set_kernel_timing(dsi_mapper_t* m, int enable)
+{
+    REQUIRE(m, DSI_ERR_INVALID, "mapper is null");
+    m->timing = enable != 0;
+    return DSI_OK;
+}
+
+int dsi_mapper_vote_kernel_time(dsi_mapper_t* m, float* total_ms, int* launches)
+{
+    REQUIRE(m && total_ms && launches, DSI_ERR_INVALID, "null argument");
+    if (int rc = set_device(m->ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+    float total = 0.f;
+    int n = 0;
+    for (auto& pr : m->timing_pairs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+            total += ms;
+            ++n;
+        }
+        m->timing_pool.push_back(pr.first);
+        m->timing_pool.push_back(pr.second);
+    }
+    m->timing_pairs.clear();
+    *total_ms = total;
+    *launches = n;
+    return DSI_OK;
+}
+
+int dsi_mapper_last_vote_info(const dsi_mapper_t* m, dsi_vote_info_t* info)
+{
+    REQUIRE(m && info, DSI_ERR_INVALID, "null argument");
+    *info = m->info;
+    return DSI_OK;
+}
+
+/* test hook (not in the public header): residual-corrected division vs IEEE divide */
+DSI_API int dsi_test_div_probe(dsi_context_t* ctx, const float* n, const float* d, size_t count, float* q, float* ref)
+{
+    REQUIRE(ctx && n && d && q && ref, DSI_ERR_INVALID, "null argument");
+    if (int rc = set_device(ctx)) return rc;
+    float *dn = nullptr, *dd = nullptr, *dq = nullptr, *dr = nullptr;
+    const size_t bytes = count * sizeof(float);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&dn), bytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dd), bytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dq), bytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&dr), bytes);
+    if (e == hipSuccess) e = hipMemcpy(dn, n, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dd, d, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = dsi::launch_div_probe(ctx->stream, dn, dd, count, dq, dr);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(q, dq, bytes, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(ref, dr, bytes, hipMemcpyDeviceToHost);
+    if (dn) (void)hipFree(dn);
+    if (dd) (void)hipFree(dd);
+    if (dq) (void)hipFree(dq);
+    if (dr) (void)hipFree(dr);
+    if (e != hipSuccess) return fail(DSI_ERR_HIP, "div probe failed: %s", hipGetErrorString(e));
+    return DSI_OK;
+}
+
+}  // extern "C"

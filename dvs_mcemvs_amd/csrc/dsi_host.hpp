@@ -1,0 +1,159 @@
+// dsi_host.hpp -- host-side (CPU, double precision) part of MapperEMVS::evaluateDSI
+// that stays in front of the device boundary: packetisation and the per-packet
+// pose lookup.
+//
+//   packetisation            mapper_emvs_stereo.cpp:67-99, :131
+//   LinearTrajectory         trajectory.hpp:81-128
+//   T_ev_rv -> R, t (float)  mapper_emvs_stereo.cpp:101-105
+//
+// The SE(3) arithmetic of the reference lives in minkindr (un-vendored,
+// dependencies.yaml:18-21, "version: master"); its published semantics are
+// followed: a transformation is (unit quaternion q, translation t),
+// T1*T2 = (q1 q2, t1 + q1.rotate(t2)), inverse = (q^-1, -q^-1.rotate(t)),
+// log/exp treat the translation linearly and the rotation through the SO(3)
+// exponential (QuatTransformation::log / ::exp).
+#pragma once
+
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+namespace dsi {
+namespace host {
+
+struct Vec3 {
+    double x = 0, y = 0, z = 0;
+    Vec3() = default;
+    Vec3(double x_, double y_, double z_) : x(x_), y(y_), z(z_) {}
+    Vec3 operator+(const Vec3& o) const { return {x + o.x, y + o.y, z + o.z}; }
+    Vec3 operator-() const { return {-x, -y, -z}; }
+    Vec3 operator*(double s) const { return {x * s, y * s, z * s}; }
+    Vec3 cross(const Vec3& o) const { return {y * o.z - z * o.y, z * o.x - x * o.z, x * o.y - y * o.x}; }
+    double norm() const { return std::sqrt(x * x + y * y + z * z); }
+};
+
+struct Quat {
+    double w = 1, x = 0, y = 0, z = 0;
+    Vec3 vec() const { return {x, y, z}; }
+    Quat conjugate() const { return {w, -x, -y, -z}; }
+    // Hamilton product (Eigen quat_product)
+    Quat operator*(const Quat& b) const
+    {
+        return {w * b.w - x * b.x - y * b.y - z * b.z, w * b.x + x * b.w + y * b.z - z * b.y,
+                w * b.y + y * b.w + z * b.x - x * b.z, w * b.z + z * b.w + x * b.y - y * b.x};
+    }
+    // Eigen QuaternionBase::_transformVector
+    Vec3 rotate(const Vec3& v) const
+    {
+        Vec3 uv = vec().cross(v);
+        uv = uv + uv;
+        return v + uv * w + vec().cross(uv);
+    }
+    // minkindr RotationQuaternion::log -> rotation vector
+    Vec3 log() const
+    {
+        const double na = vec().norm();
+        const double eta = w;
+        double scale;
+        if (std::fabs(eta) < na) {
+            scale = (eta >= 0) ? std::acos(eta) / na : -std::acos(-eta) / na;
+        } else {
+            const double s = (std::fabs(na) < kEps4) ? 1.0 + na * na / 6.0 : std::asin(na) / na;
+            scale = (eta > 0) ? s : -s;
+        }
+        return vec() * (2.0 * scale);
+    }
+    // minkindr RotationQuaternion::exp (Grassia 1998)
+    static Quat exp(const Vec3& dx)
+    {
+        const double theta = dx.norm();
+        const double na = (theta < kEps4) ? 0.5 + theta * theta / 48.0 : std::sin(theta * 0.5) / theta;
+        return {std::cos(theta * 0.5), dx.x * na, dx.y * na, dx.z * na};
+    }
+    static constexpr double kEps4 = 1.220703125e-4;  // ~ eps^(1/4)
+};
+
+struct Pose {  // T_A_B
+    Quat q;
+    Vec3 t;
+    static Pose from7(const double* p) { return {{p[3], p[4], p[5], p[6]}, {p[0], p[1], p[2]}}; }
+    void to7(double* p) const
+    {
+        p[0] = t.x; p[1] = t.y; p[2] = t.z;
+        p[3] = q.w; p[4] = q.x; p[5] = q.y; p[6] = q.z;
+    }
+    Pose operator*(const Pose& b) const { return {q * b.q, t + q.rotate(b.t)}; }
+    Pose inverse() const
+    {
+        const Quat qi = q.conjugate();
+        return {qi, -qi.rotate(t)};
+    }
+};
+
+// LinearTrajectory::getPoseAt (trajectory.hpp:92-126).  times ascending.
+inline bool pose_at(const double* times, const double* poses, size_t n, double t, Pose* out)
+{
+    // std::map::upper_bound(t): first control pose strictly later than t
+    size_t lo = 0, hi = n;
+    while (lo < hi) {
+        const size_t mid = (lo + hi) / 2;
+        if (t < times[mid])
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    if (lo == 0 || lo == n) return false;  // no extrapolation (:99-112)
+    const Pose T0 = Pose::from7(poses + 7 * (lo - 1)), T1 = Pose::from7(poses + 7 * lo);
+    const Pose rel = T0.inverse() * T1;  // :123
+    const double delta = (t - times[lo - 1]) / (times[lo] - times[lo - 1]);  // :124
+    const Pose inc{Quat::exp(rel.q.log() * delta), rel.t * delta};  // exp(delta * log(rel)), :125
+    *out = T0 * inc;
+    return true;
+}
+
+// mapper_emvs_stereo.cpp:101-105: (T_rv_w * T_w_ev)^-1 -> R (row-major), t as float
+inline void event_pose_Rt(const Pose& T_rv_w, const Pose& T_w_ev, float* Rt)
+{
+    const Pose T = (T_rv_w * T_w_ev).inverse();
+    const Quat& q = T.q;
+    // Eigen QuaternionBase::toRotationMatrix
+    const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+    const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+    const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+    const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    const double R[9] = {1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz),
+                         tyz - twx,       txz - twy, tyz + twx, 1 - (txx + tyy)};
+    for (int i = 0; i < 9; ++i) Rt[i] = (float)R[i];
+    Rt[9] = (float)T.t.x;
+    Rt[10] = (float)T.t.y;
+    Rt[11] = (float)T.t.z;
+}
+
+// The while-loop of mapper_emvs_stereo.cpp:88-99: returns false when the reference
+// returns false (fewer events than one packet, :71-75).
+inline bool packetize(const double* ts, size_t n_events, const double* times, const double* poses,
+                      size_t n_poses, const Pose& T_rv_w, std::vector<uint32_t>* first,
+                      std::vector<float>* Rt)
+{
+    constexpr size_t kPacket = 1024;
+    first->clear();
+    Rt->clear();
+    if (n_events < kPacket) return false;
+    size_t cur = 0;
+    while (cur + kPacket < n_events) {  // strict '<': a final exactly-full packet is dropped
+        Pose T_w_ev;
+        if (!pose_at(times, poses, n_poses, ts[cur + kPacket / 2], &T_w_ev)) {
+            ++cur;  // :95-99 slide by one event and retry
+            continue;
+        }
+        first->push_back((uint32_t)cur);
+        Rt->resize(Rt->size() + 12);
+        event_pose_Rt(T_rv_w, T_w_ev, Rt->data() + Rt->size() - 12);
+        cur += kPacket;
+    }
+    return true;
+}
+
+}  // namespace host
+}  // namespace dsi

@@ -1,0 +1,75 @@
+// dsi_kernels.h -- internal launch interface between the C-ABI host layer
+// (dsi_engine.cpp) and the gfx950 kernels (dsi_kernels.hip).  Not installed.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace dsi {
+
+constexpr int kPacket = 1024;  // mapper_emvs_stereo.hpp:152
+
+// Per (packet, plane) transfer coefficients of mapper_emvs_stereo.cpp:177-182,
+// plus what the banded kernel needs to divide quickly.  32 bytes so that one
+// s_load_dwordx8 fetches it.
+struct PlaneCoef {
+    float a, bx, by, d;
+    float r;         // RN(1/d) for the residual-corrected division
+    uint32_t flags;  // kCoefSkip / kCoefSlow
+    uint32_t pad0, pad1;
+};
+constexpr uint32_t kCoefSkip = 1u;  // no event of this (packet, plane) can be accepted
+constexpr uint32_t kCoefSlow = 2u;  // use the IEEE divide and the whole packet
+
+struct Geom {
+    int nx, ny, nz;
+    float vfx, vfy, vcx, vcy;  // virtual camera (geometry_utils.hpp:30-47)
+    float kfx, kfy, kcx, kcy;  // sensor projection intrinsics K_ (mapper_emvs_stereo.cpp:46-48)
+    float z0;                  // raw_depths_vec_[0]
+};
+
+struct BandPlan {
+    int bands;          // row bands per plane
+    int band_rows;      // owned rows per band (last band may own fewer)
+    int chunks;         // packet chunks; each writes its own partial DSI when > 1
+    int block_threads;  // 256 / 512 / 1024
+    size_t lds_bytes;   // (band_rows + 2) * nx * 4
+};
+
+// ---- stage A ---------------------------------------------------------------
+hipError_t launch_packet_geometry(hipStream_t s, const float* Rt, int np, const Geom& g,
+                                  float* centers, float* H);
+hipError_t launch_warp_z0(hipStream_t s, const uint16_t* ex, const uint16_t* ey,
+                          const uint32_t* packet_first, int np, const float* H,
+                          const float2* lut, int sensor_w, float2* xy);
+// ---- stage B, global-atomic form ------------------------------------------
+hipError_t launch_vote_global(hipStream_t s, const float2* xy, const float* centers, int np,
+                              const float* planes, const Geom& g, float* dsi);
+// ---- stage B, LDS row-band form -------------------------------------------
+hipError_t launch_sort_packets(hipStream_t s, const float2* xy, int np, float2* sxy,
+                               uint32_t* nvalid);
+hipError_t launch_plane_coef(hipStream_t s, const float* centers, const float* planes,
+                             const float2* sxy, const uint32_t* nvalid, int np, const Geom& g,
+                             const BandPlan& bp, PlaneCoef* coef, uint32_t* cuts);
+hipError_t launch_vote_bands(hipStream_t s, const float2* sxy, const PlaneCoef* coef,
+                             const uint32_t* cuts, int np, const Geom& g, const BandPlan& bp,
+                             float* out);
+hipError_t launch_reduce_partials(hipStream_t s, const float* partials, int chunks, size_t n,
+                                  float* dsi, int accumulate);
+// ---- Grid3D ops ------------------------------------------------------------
+hipError_t launch_fuse2(hipStream_t s, float* a, const float* g, size_t n, int op);
+hipError_t launch_fuse_hm_n(hipStream_t s, float* a, const float* g, size_t n, int n_maps);
+hipError_t launch_accumulate(hipStream_t s, float* acc, const float* g, size_t n, int mode);
+hipError_t launch_finalize(hipStream_t s, float* acc, size_t n, int mode, int n_maps);
+hipError_t launch_collapse_max_z(hipStream_t s, const float* dsi, int nx, int ny, int nz,
+                                 float* conf, uint8_t* idx, const float* planes, float* depth);
+hipError_t launch_mean_square(hipStream_t s, const float* dsi, size_t n, double* accum);
+
+// test hook: q[i] = residual-corrected division, ref[i] = n[i] / d[i]
+hipError_t launch_div_probe(hipStream_t s, const float* n, const float* d, size_t count,
+                            float* q, float* ref);
+
+size_t max_dynamic_lds();
+
+}  // namespace dsi

@@ -1,0 +1,766 @@
+// dsi_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the DSI engine.
+//
+// Replaces, on the GPU, the reference CPU code
+//   MapperEMVS::evaluateDSI stage A   mapper_emvs_stereo.cpp:101-142
+//   MapperEMVS::fillVoxelGrid         mapper_emvs_stereo.cpp:151-205
+//   Grid3D::accumulateGridValueAt     cartesian3dgrid.h:253-273
+//   Grid3D fusion ops                 cartesian3dgrid.h:64-192
+//   Grid3D::collapseMaxZSlice         cartesian3dgrid.cpp:115-137
+//   Grid3D::computeMeanSquare         cartesian3dgrid.cpp:164-174
+//
+// Numerics: the reference is an SSE2 build without FMA.  Every coordinate is
+// computed with the same operations in the same order (separate multiply, add,
+// IEEE divide); only the order in which votes are summed into a voxel differs.
+// This file must be compiled with -ffp-contract=off (the pragma below restates
+// it); explicit fmaf() calls are the only fused operations.
+#include "dsi_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace dsi {
+
+namespace {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ bool finitef(float v) { return __builtin_isfinite(v); }
+
+// Eigen 3.3 fixed-size length-3 dot: x0 + (x1 + x2) (redux_novec_unroller).
+__device__ __forceinline__ float dot3(float a0, float b0, float a1, float b1, float a2, float b2)
+{
+    const float x0 = a0 * b0, x1 = a1 * b1, x2 = a2 * b2;
+    return x0 + (x1 + x2);
+}
+
+__device__ __forceinline__ float cof3(const float* m, int i, int j)
+{
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    return m[3 * i1 + j1] * m[3 * i2 + j2] - m[3 * i1 + j2] * m[3 * i2 + j1];
+}
+
+// Eigen compute_inverse<Matrix3f> (cofactors; first column drives the determinant).
+__device__ void inverse3x3(const float* m, float* out)
+{
+    const float c0 = cof3(m, 0, 0), c1 = cof3(m, 1, 0), c2 = cof3(m, 2, 0);
+    const float det = dot3(c0, m[0], c1, m[3], c2, m[6]);
+    const float invdet = 1.f / det;
+    out[0] = c0 * invdet;
+    out[1] = c1 * invdet;
+    out[2] = c2 * invdet;
+    out[3] = cof3(m, 0, 1) * invdet;
+    out[4] = cof3(m, 1, 1) * invdet;
+    out[5] = cof3(m, 2, 1) * invdet;
+    out[6] = cof3(m, 0, 2) * invdet;
+    out[7] = cof3(m, 1, 2) * invdet;
+    out[8] = cof3(m, 2, 2) * invdet;
+}
+
+__device__ void mul3x3(const float* a, const float* b, float* c)
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            c[3 * i + j] = dot3(a[3 * i], b[j], a[3 * i + 1], b[3 + j], a[3 * i + 2], b[6 + j]);
+}
+
+// n / d, correctly rounded, given r = RN(1/d): two residual corrections, the same
+// recurrence the gfx950 IEEE-divide expansion runs after v_rcp_f32, without its
+// v_div_scale / v_div_fixup range handling (callers guarantee 2^-40 <= |d| <= 2^40;
+// a non-finite or overflowing n gives NaN/inf, which the vote rejects either way).
+__device__ __forceinline__ float div_rc(float n, float d, float r)
+{
+    float q = n * r;
+    float e = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(-d, q, n);
+    return __builtin_fmaf(e, r, q);
+}
+
+// mapper_emvs_stereo.cpp:177-182
+__device__ __forceinline__ void plane_coefficients(float cx_, float cy_, float cz_, float zi,
+                                                   const Geom& g, float& a, float& bx, float& by,
+                                                   float& d)
+{
+    a = g.z0 * (zi - cz_);
+    bx = (g.z0 - zi) * (cx_ * g.vfx + cz_ * g.vcx);
+    by = (g.z0 - zi) * (cy_ * g.vfy + cz_ * g.vcy);
+    d = zi * (g.z0 - cz_);
+}
+
+// ---------------------------------------------------------------- stage A --
+// mapper_emvs_stereo.cpp:101-126: one thread per packet.
+__global__ void k_packet_geometry(const float* __restrict__ Rt, int np, Geom g,
+                                  float* __restrict__ centers, float* __restrict__ H)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= np) return;
+    float R[9], t[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = Rt[12 * k + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = Rt[12 * k + 9 + i];
+
+    // :108  C = -R^T t
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        centers[3 * k + i] = dot3(-R[i], t[0], -R[3 + i], t[1], -R[6 + i], t[2]);
+
+    // :114-116
+    float Hinv[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Hinv[i] = R[i] * g.z0;
+    Hinv[2] += t[0];
+    Hinv[5] += t[1];
+    Hinv[8] += t[2];
+
+    const float Km[9] = {g.kfx, 0.f, g.kcx, 0.f, g.kfy, g.kcy, 0.f, 0.f, 1.f};
+    const float Kvm[9] = {g.vfx, 0.f, g.vcx, 0.f, g.vfy, g.vcy, 0.f, 0.f, 1.f};
+    float Kvinv[9], M1[9], M[9], Hk[9];
+    inverse3x3(Kvm, Kvinv);  // geometry_utils.hpp:47
+    mul3x3(Km, Hinv, M1);    // :119, left to right
+    mul3x3(M1, Kvinv, M);
+    inverse3x3(M, Hk);       // :120
+#pragma unroll
+    for (int i = 0; i < 9; ++i) H[9 * k + i] = Hk[i];
+}
+
+// mapper_emvs_stereo.cpp:129-142: one thread per event slot of a packet.
+__global__ void k_warp_z0(const uint16_t* __restrict__ ex, const uint16_t* __restrict__ ey,
+                          const uint32_t* __restrict__ packet_first, int np,
+                          const float* __restrict__ H, const float2* __restrict__ lut,
+                          int sensor_w, float2* __restrict__ xy)
+{
+    const int k = blockIdx.x;  // packet
+    const size_t first = packet_first ? (size_t)packet_first[k] : (size_t)k * kPacket;
+    const float* h = H + 9 * (size_t)k;
+    const float h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3], h4 = h[4], h5 = h[5], h6 = h[6],
+                h7 = h[7], h8 = h[8];
+    for (int j = threadIdx.x; j < kPacket; j += blockDim.x) {
+        const unsigned x = ex[first + j], y = ey[first + j];
+        float u, v;
+        if (lut) {
+            const float2 p = lut[(size_t)y * sensor_w + x];  // :134
+            u = p.x;
+            v = p.y;
+        } else {
+            u = (float)x;
+            v = (float)y;
+        }
+        // :138 4x4 packet product ((c0*u + c1*v) + c2*1) + c3*0 ; :139 p /= p[2]
+        const float px = ((h0 * u + h1 * v) + h2 * 1.f) + 0.f;
+        const float py = ((h3 * u + h4 * v) + h5 * 1.f) + 0.f;
+        const float pz = ((h6 * u + h7 * v) + h8 * 1.f) + 0.f;
+        xy[(size_t)k * kPacket + j] = make_float2(px / pz, py / pz);
+    }
+}
+
+// ------------------------------------------------- stage B: global atomics --
+// cartesian3dgrid.h:253-273 with the int-conversion guard expressed in float
+// (x+1 < Nx  <=>  x_f < Nx-1 for x_f >= 0), so that inf/huge/NaN are rejected
+// exactly like the x86 build rejects them.
+__device__ __forceinline__ void vote_global(float X, float Y, float* __restrict__ plane, int nx,
+                                            float xmax, float ymax)
+{
+    if (X >= 0.f && Y >= 0.f && X < xmax && Y < ymax) {
+        const int xi = (int)X, yi = (int)Y;
+        const float fx = X - (float)xi, fy = Y - (float)yi, fx1 = 1.f - fx, fy1 = 1.f - fy;
+        float* gptr = plane + (size_t)yi * nx + xi;
+        unsafeAtomicAdd(gptr, fx1 * fy1);
+        unsafeAtomicAdd(gptr + 1, fx * fy1);
+        unsafeAtomicAdd(gptr + nx, fx1 * fy);
+        unsafeAtomicAdd(gptr + nx + 1, fx * fy);
+    }
+}
+
+constexpr int kVgPlanes = 8;  // planes per block of the global-atomic kernel
+
+// block = (packet, group of planes); thread t owns events t, t+256, ... of the packet
+__global__ __launch_bounds__(256) void k_vote_global(const float2* __restrict__ xy,
+                                                     const float* __restrict__ centers,
+                                                     const float* __restrict__ planes, Geom g,
+                                                     float* __restrict__ dsi)
+{
+    const int k = blockIdx.x;
+    const int zbeg = blockIdx.y * kVgPlanes;
+    const int zend = min(g.nz, zbeg + kVgPlanes);
+    const float cx_ = centers[3 * k], cy_ = centers[3 * k + 1], cz_ = centers[3 * k + 2];
+    float2 e[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = xy[(size_t)k * kPacket + threadIdx.x + 256 * i];
+    const float xmax = (float)(g.nx - 1), ymax = (float)(g.ny - 1);
+    const size_t plane_sz = (size_t)g.nx * g.ny;
+    for (int z = zbeg; z < zend; ++z) {
+        float a, bx, by, d;
+        plane_coefficients(cx_, cy_, cz_, planes[z], g, a, bx, by, d);
+        float* plane = dsi + (size_t)z * plane_sz;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float X = (e[i].x * a + bx) / d;  // :194
+            const float Y = (e[i].y * a + by) / d;  // :195
+            vote_global(X, Y, plane, g.nx, xmax, ymax);
+        }
+    }
+}
+
+// ------------------------------------------------ stage B: LDS row bands ---
+// (1) per packet: drop events that no plane can accept (non-finite z0 location),
+//     sort the rest by y0.  For one (packet, plane) the map y0 -> Y is monotone
+//     (each of *a, +by, /d rounds monotonically), so the events landing in a band
+//     of output rows are one contiguous run of the sorted packet.
+__global__ __launch_bounds__(256) void k_sort_packets(const float2* __restrict__ xy,
+                                                      float2* __restrict__ sxy,
+                                                      uint32_t* __restrict__ nvalid)
+{
+    __shared__ float ky[kPacket];
+    __shared__ float kx[kPacket];
+    __shared__ uint32_t count;
+    const int k = blockIdx.x;
+    if (threadIdx.x == 0) count = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (int j = threadIdx.x; j < kPacket; j += 256) {
+        const float2 p = xy[(size_t)k * kPacket + j];
+        const bool ok = finitef(p.x) && finitef(p.y);
+        ky[j] = ok ? p.y : __builtin_inff();
+        kx[j] = p.x;
+        mine += ok ? 1u : 0u;
+    }
+    atomicAdd(&count, mine);
+    __syncthreads();
+    // bitonic network, 512 compare-exchanges per stage, two per thread
+    for (int kk = 2; kk <= kPacket; kk <<= 1) {
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int t = threadIdx.x + 256 * h;
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const bool up = (i & kk) == 0;
+                const float yi = ky[i], yl = ky[l];
+                if ((yi > yl) == up) {
+                    ky[i] = yl;
+                    ky[l] = yi;
+                    const float xi = kx[i];
+                    kx[i] = kx[l];
+                    kx[l] = xi;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int j = threadIdx.x; j < kPacket; j += 256)
+        sxy[(size_t)k * kPacket + j] = make_float2(kx[j], ky[j]);
+    if (threadIdx.x == 0) nvalid[k] = count;
+}
+
+// (2) per (packet, plane): coefficients + for every band the run [lo,hi) of the
+//     sorted packet whose Y can fall into the band.  The run is a superset (margin
+//     of a few ulps); the voting kernel re-tests every event exactly.
+__device__ __forceinline__ float y_of(float y0, float a, float by, float d)
+{
+    return (y0 * a + by) / d;  // IEEE divide: +-inf stay ordered, no NaN for finite inputs
+}
+
+// first index i in [0,n) with Y_i >= v (increasing map) / Y_i < v (decreasing map)
+__device__ int first_reaching(const float2* __restrict__ ev, int n, float a, float by, float d,
+                              bool increasing, float v)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const float Y = y_of(ev[mid].y, a, by, d);
+        const bool reached = increasing ? (Y >= v) : (Y < v);
+        if (reached)
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void k_plane_coef(const float* __restrict__ centers,
+                                                    const float* __restrict__ planes,
+                                                    const float2* __restrict__ sxy,
+                                                    const uint32_t* __restrict__ nvalid, int np,
+                                                    Geom g, BandPlan bp,
+                                                    PlaneCoef* __restrict__ coef,
+                                                    uint32_t* __restrict__ cuts)
+{
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= (size_t)np * g.nz) return;
+    const int k = (int)(tid / g.nz), z = (int)(tid % g.nz);
+    PlaneCoef c;
+    plane_coefficients(centers[3 * k], centers[3 * k + 1], centers[3 * k + 2], planes[z], g, c.a,
+                       c.bx, c.by, c.d);
+    c.r = 1.f / c.d;
+    c.pad0 = c.pad1 = 0;
+    const int nv = (int)nvalid[k];
+    // Which (packet, plane) pairs can vote at all?  NaN anywhere, d == 0, or an
+    // infinite a / bx / by make X or Y non-finite for every event.
+    const bool dead = !(c.a == c.a) || !(c.bx == c.bx) || !(c.by == c.by) || !(c.d == c.d) ||
+                      c.d == 0.f || !finitef(c.a) || !finitef(c.bx) || !finitef(c.by) || nv == 0;
+    const float ad = fabsf(c.d);
+    const bool slow = !dead && !(ad >= 0x1p-40f && ad <= 0x1p40f);  // incl. d = +-inf
+    c.flags = dead ? kCoefSkip : (slow ? kCoefSlow : 0u);
+    coef[tid] = c;
+
+    uint32_t* out = cuts + tid * bp.bands;
+    const float2* ev = sxy + (size_t)k * kPacket;
+    const bool increasing = (c.a > 0.f) == (c.d > 0.f);
+    for (int j = 0; j < bp.bands; ++j) {
+        uint32_t lo = 0, hi = 0;
+        if (slow) {
+            hi = (uint32_t)nv;
+        } else if (!dead) {
+            const int r0 = j * bp.band_rows;
+            const int r1 = min(g.ny, r0 + bp.band_rows);
+            // accepted iff 0 <= Y < ny-1; the band needs floor(Y) in [r0-1, r1-1]
+            float L = (float)max(r0 - 1, 0), U = (float)min(r1, g.ny - 1);
+            L -= 1e-3f * fmaxf(1.f, L);  // superset margin, >> a few ulps
+            U += 1e-3f * fmaxf(1.f, U);
+            if (increasing) {
+                lo = first_reaching(ev, nv, c.a, c.by, c.d, true, L);
+                hi = first_reaching(ev, nv, c.a, c.by, c.d, true, U);
+            } else {
+                lo = first_reaching(ev, nv, c.a, c.by, c.d, false, U);
+                hi = first_reaching(ev, nv, c.a, c.by, c.d, false, L);
+            }
+            if (hi < lo) hi = lo;
+        }
+        out[j] = lo | (hi << 16);  // hi <= 1024 fits in 16 bits
+    }
+}
+
+// (3) the voting kernel.  Work item = (packet chunk c, band j, plane z): the band's
+//     rows [r0-1, r1] of plane z live in LDS (two halo rows, so a bilinear vote never
+//     needs a row test), every wave walks packets of the chunk with the packet's
+//     coefficients in SGPRs, votes with ds_add_f32, and the owned rows [r0, r1) are
+//     written back with plain coalesced stores -- no global atomics, no memset.
+//     Block b runs on XCD b % 8 (observed dispatch rule): the blocks of one XCD walk
+//     the planes of ONE (chunk, band) pair at a time, so its events stream through
+//     that XCD's L2 once instead of once per plane.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_vote_bands(const float2* __restrict__ sxy,
+                                                      const PlaneCoef* __restrict__ coef,
+                                                      const uint32_t* __restrict__ cuts, int np,
+                                                      Geom g, BandPlan bp,
+                                                      float* __restrict__ out)
+{
+    extern __shared__ float lds[];
+    const int b = blockIdx.x;
+    const int xcd = b & 7, s = b >> 3;
+    const int q = (s / g.nz) * 8 + xcd;
+    const int z = s % g.nz;
+    if (q >= bp.chunks * bp.bands) return;
+    const int c = q / bp.bands, j = q % bp.bands;
+    const int r0 = j * bp.band_rows;
+    const int r1 = min(g.ny, r0 + bp.band_rows);
+    const int nx = g.nx;
+    const int lds_elems = (r1 - r0 + 2) * nx;
+
+    for (int i = threadIdx.x; i < lds_elems; i += BLOCK) lds[i] = 0.f;
+    __syncthreads();
+
+    const int p_begin = (int)(((long long)np * c) / bp.chunks);
+    const int p_end = (int)(((long long)np * (c + 1)) / bp.chunks);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int lane = threadIdx.x & (kWave - 1);
+    const float L = (float)max(r0 - 1, 0), U = (float)min(r1, g.ny - 1);
+    const float xmax = (float)(nx - 1);
+    const int row_base = r0 - 1;
+
+    for (int p = p_begin + wave; p < p_end; p += BLOCK / kWave) {
+        const size_t pz = (size_t)p * g.nz + z;
+        const PlaneCoef k = coef[pz];
+        if (k.flags & kCoefSkip) continue;
+        const uint32_t cu = cuts[pz * bp.bands + j];
+        const int lo = (int)(cu & 0xffffu), hi = (int)(cu >> 16);
+        const float2* __restrict__ ev = sxy + (size_t)p * kPacket;
+        const bool slow = (k.flags & kCoefSlow) != 0;
+        for (int i = lo + lane; i < hi; i += kWave) {
+            const float2 e = ev[i];
+            const float nxv = e.x * k.a + k.bx;  // mapper_emvs_stereo.cpp:194-195
+            const float nyv = e.y * k.a + k.by;
+            float X, Y;
+            if (slow) {
+                X = nxv / k.d;
+                Y = nyv / k.d;
+            } else {
+                X = div_rc(nxv, k.d, k.r);
+                Y = div_rc(nyv, k.d, k.r);
+            }
+            // cartesian3dgrid.h:255-259 restricted to this band's rows
+            if (X >= 0.f && X < xmax && Y >= L && Y < U) {
+                const float xf = __builtin_floorf(X), yf = __builtin_floorf(Y);
+                const float fx = X - xf, fy = Y - yf, fx1 = 1.f - fx, fy1 = 1.f - fy;
+                const int idx = ((int)yf - row_base) * nx + (int)xf;
+                __hip_atomic_fetch_add(&lds[idx], fx1 * fy1, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&lds[idx + 1], fx * fy1, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&lds[idx + nx], fx1 * fy, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&lds[idx + nx + 1], fx * fy, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    __syncthreads();
+
+    // owned rows are contiguous in the [z][y][x] volume: a linear coalesced copy
+    const size_t vol = (size_t)g.nx * g.ny * g.nz;
+    float* __restrict__ dst = out + (size_t)c * vol + ((size_t)z * g.ny + r0) * nx;
+    const float* src = lds + nx;  // skip the top halo row
+    const int n_out = (r1 - r0) * nx;
+    for (int i = threadIdx.x; i < n_out; i += BLOCK) dst[i] = src[i];
+}
+
+// (4) DSI = sum of the chunk partials (fixed order => deterministic given partials)
+__global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ partials,
+                                                         int chunks, size_t n,
+                                                         float* __restrict__ dsi, int accumulate)
+{
+    const size_t n4 = n / 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 acc = accumulate ? reinterpret_cast<const float4*>(dsi)[i]
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = 0; c < chunks; ++c) {
+            const float4 v = reinterpret_cast<const float4*>(partials + (size_t)c * n)[i];
+            acc.x += v.x;
+            acc.y += v.y;
+            acc.z += v.z;
+            acc.w += v.w;
+        }
+        reinterpret_cast<float4*>(dsi)[i] = acc;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = n4 * 4 + threadIdx.x;
+        float acc = accumulate ? dsi[i] : 0.f;
+        for (int c = 0; c < chunks; ++c) acc += partials[(size_t)c * n + i];
+        dsi[i] = acc;
+    }
+}
+
+// ------------------------------------------------------------ Grid3D ops ---
+template <int OP>
+__device__ __forceinline__ float fuse_op(float a, float g)
+{
+    if (OP == 1) return (g < a) ? g : a;  // std::min, cartesian3dgrid.h:115
+    if (OP == 2) {                        // :119-127, eps = 1e-1f in the denominator
+        const float prod = a * g, sum = a + g;
+        return 2.f * prod / (sum + 0.1f);
+    }
+    if (OP == 3) return __builtin_sqrtf(a * g);  // :154
+    if (OP == 4) return 0.5f * (a + g);  // :162, double 0.5 * float sum: exact halving
+    if (OP == 5) {                       // :145-146, pow() and 0.5 in double
+        const double ad = (double)a, gd = (double)g;
+        const float ms = (float)(0.5 * (ad * ad + gd * gd));
+        return __builtin_sqrtf(ms);  // == (float)sqrt((double)ms): 53 >= 2*24+2
+    }
+    return (a < g) ? g : a;  // std::max, :188
+}
+
+template <int OP>
+__global__ __launch_bounds__(256) void k_fuse2(float* __restrict__ a, const float* __restrict__ g,
+                                               size_t n)
+{
+    const size_t n4 = n / 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 va = reinterpret_cast<float4*>(a)[i];
+        const float4 vg = reinterpret_cast<const float4*>(g)[i];
+        va.x = fuse_op<OP>(va.x, vg.x);
+        va.y = fuse_op<OP>(va.y, vg.y);
+        va.z = fuse_op<OP>(va.z, vg.z);
+        va.w = fuse_op<OP>(va.w, vg.w);
+        reinterpret_cast<float4*>(a)[i] = va;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = n4 * 4 + threadIdx.x;
+        a[i] = fuse_op<OP>(a[i], g[i]);
+    }
+}
+
+// generic element-wise driver for the remaining ops
+enum { EW_HM_N = 0, EW_ADD = 1, EW_ADD_INV = 2, EW_FIN_AM = 3, EW_FIN_HM = 4 };
+
+template <int KIND>
+__device__ __forceinline__ float ew_op(float a, float g, float fn, float fn1)
+{
+    if (KIND == EW_HM_N) {  // cartesian3dgrid.h:130-139
+        const float av = a / fn1;
+        const float prod = av * g, sum = av + g;
+        return fn * prod / (sum + 0.1f);
+    }
+    if (KIND == EW_ADD) return a + g;                       // :68
+    if (KIND == EW_ADD_INV) return a + 1.0f / (0.01f + g);  // :76, eps = 1e-2f
+    if (KIND == EW_FIN_AM) return a / fn;                   // :91
+    return fn / a;                                          // :84
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k_elementwise(float* __restrict__ a,
+                                                     const float* __restrict__ g, size_t n,
+                                                     float fn, float fn1)
+{
+    constexpr bool has_g = (KIND == EW_HM_N || KIND == EW_ADD || KIND == EW_ADD_INV);
+    const size_t n4 = n / 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 va = reinterpret_cast<float4*>(a)[i];
+        float4 vg = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (has_g) vg = reinterpret_cast<const float4*>(g)[i];
+        va.x = ew_op<KIND>(va.x, vg.x, fn, fn1);
+        va.y = ew_op<KIND>(va.y, vg.y, fn, fn1);
+        va.z = ew_op<KIND>(va.z, vg.z, fn, fn1);
+        va.w = ew_op<KIND>(va.w, vg.w, fn, fn1);
+        reinterpret_cast<float4*>(a)[i] = va;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = n4 * 4 + threadIdx.x;
+        a[i] = ew_op<KIND>(a[i], has_g ? g[i] : 0.f, fn, fn1);
+    }
+}
+
+// cartesian3dgrid.cpp:115-137: thread = pixel, planes walked in order, strict '<'
+// keeps the first maximum (std::max_element).  Lanes of a wave read consecutive x
+// of one plane row: coalesced 256-B segments.
+__global__ __launch_bounds__(256) void k_collapse_max_z(const float* __restrict__ dsi, int npix,
+                                                        int nz, float* __restrict__ conf,
+                                                        uint8_t* __restrict__ idx,
+                                                        const float* __restrict__ planes,
+                                                        float* __restrict__ depth)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    const float* col = dsi + p;
+    float best = col[0];
+    int best_k = 0;
+    int k = 1;
+    for (; k + 8 <= nz; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = col[(size_t)(k + u) * npix];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (best < v[u]) {
+                best = v[u];
+                best_k = k + u;
+            }
+    }
+    for (; k < nz; ++k) {
+        const float v = col[(size_t)k * npix];
+        if (best < v) {
+            best = v;
+            best_k = k;
+        }
+    }
+    conf[p] = best;
+    idx[p] = (uint8_t)best_k;
+    if (depth) depth[p] = planes[best_k];  // mapper_emvs_stereo.cpp:302-313
+}
+
+// cartesian3dgrid.cpp:164-174: sum of squares in double (order differs from the
+// sequential loop; relative difference ~1e-16 * log n)
+__global__ __launch_bounds__(256) void k_mean_square(const float* __restrict__ dsi, size_t n,
+                                                     double* __restrict__ accum)
+{
+    __shared__ double part[4];
+    double acc = 0.0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double v = (double)dsi[i];
+        acc += v * v;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double t = (part[0] + part[1]) + (part[2] + part[3]);
+        unsafeAtomicAdd(accum, t);
+    }
+}
+
+__global__ void k_div_probe(const float* __restrict__ n, const float* __restrict__ d,
+                            size_t count, float* __restrict__ q, float* __restrict__ ref)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const float r = 1.f / d[i];
+    q[i] = div_rc(n[i], d[i], r);
+    ref[i] = n[i] / d[i];
+}
+
+int grid_for(size_t work_items, int block, int max_blocks = 256 * 8)
+{
+    size_t b = (work_items + block - 1) / block;
+    if (b < 1) b = 1;
+    if (b > (size_t)max_blocks) b = max_blocks;
+    return (int)b;
+}
+
+}  // namespace
+
+size_t max_dynamic_lds() { return 160 * 1024; }
+
+hipError_t launch_packet_geometry(hipStream_t s, const float* Rt, int np, const Geom& g,
+                                  float* centers, float* H)
+{
+    if (np <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_packet_geometry, dim3((np + 63) / 64), dim3(64), 0, s, Rt, np, g,
+                       centers, H);
+    return hipGetLastError();
+}
+
+hipError_t launch_warp_z0(hipStream_t s, const uint16_t* ex, const uint16_t* ey,
+                          const uint32_t* packet_first, int np, const float* H,
+                          const float2* lut, int sensor_w, float2* xy)
+{
+    if (np <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_warp_z0, dim3(np), dim3(256), 0, s, ex, ey, packet_first, np, H, lut,
+                       sensor_w, xy);
+    return hipGetLastError();
+}
+
+hipError_t launch_vote_global(hipStream_t s, const float2* xy, const float* centers, int np,
+                              const float* planes, const Geom& g, float* dsi)
+{
+    if (np <= 0) return hipSuccess;
+    const int zgroups = (g.nz + kVgPlanes - 1) / kVgPlanes;
+    // gridDim.y is limited to 65535; x carries the packets
+    hipLaunchKernelGGL(k_vote_global, dim3(np, zgroups), dim3(256), 0, s, xy, centers, planes, g,
+                       dsi);
+    return hipGetLastError();
+}
+
+hipError_t launch_sort_packets(hipStream_t s, const float2* xy, int np, float2* sxy,
+                               uint32_t* nvalid)
+{
+    if (np <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_sort_packets, dim3(np), dim3(256), 0, s, xy, sxy, nvalid);
+    return hipGetLastError();
+}
+
+hipError_t launch_plane_coef(hipStream_t s, const float* centers, const float* planes,
+                             const float2* sxy, const uint32_t* nvalid, int np, const Geom& g,
+                             const BandPlan& bp, PlaneCoef* coef, uint32_t* cuts)
+{
+    if (np <= 0) return hipSuccess;
+    const size_t total = (size_t)np * g.nz;
+    hipLaunchKernelGGL(k_plane_coef, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                       centers, planes, sxy, nvalid, np, g, bp, coef, cuts);
+    return hipGetLastError();
+}
+
+template <int BLOCK>
+static hipError_t launch_vote_bands_t(hipStream_t s, const float2* sxy, const PlaneCoef* coef,
+                                      const uint32_t* cuts, int np, const Geom& g,
+                                      const BandPlan& bp, float* out)
+{
+    static size_t configured = 0;
+    if (bp.lds_bytes > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vote_bands<BLOCK>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)bp.lds_bytes);
+        if (e != hipSuccess) return e;
+        configured = bp.lds_bytes;
+    }
+    const int pairs = bp.chunks * bp.bands;
+    const unsigned blocks = 8u * (unsigned)((pairs + 7) / 8) * (unsigned)g.nz;
+    hipLaunchKernelGGL(k_vote_bands<BLOCK>, dim3(blocks), dim3(BLOCK), bp.lds_bytes, s, sxy, coef,
+                       cuts, np, g, bp, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_vote_bands(hipStream_t s, const float2* sxy, const PlaneCoef* coef,
+                             const uint32_t* cuts, int np, const Geom& g, const BandPlan& bp,
+                             float* out)
+{
+    if (np <= 0) return hipSuccess;
+    switch (bp.block_threads) {
+    case 256: return launch_vote_bands_t<256>(s, sxy, coef, cuts, np, g, bp, out);
+    case 512: return launch_vote_bands_t<512>(s, sxy, coef, cuts, np, g, bp, out);
+    case 1024: return launch_vote_bands_t<1024>(s, sxy, coef, cuts, np, g, bp, out);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_reduce_partials(hipStream_t s, const float* partials, int chunks, size_t n,
+                                  float* dsi, int accumulate)
+{
+    hipLaunchKernelGGL(k_reduce_partials, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, s,
+                       partials, chunks, n, dsi, accumulate);
+    return hipGetLastError();
+}
+
+hipError_t launch_fuse2(hipStream_t s, float* a, const float* g, size_t n, int op)
+{
+    const dim3 grid(grid_for(n / 4 + 1, 256)), block(256);
+    switch (op) {
+    case 1: hipLaunchKernelGGL(k_fuse2<1>, grid, block, 0, s, a, g, n); break;
+    case 2: hipLaunchKernelGGL(k_fuse2<2>, grid, block, 0, s, a, g, n); break;
+    case 3: hipLaunchKernelGGL(k_fuse2<3>, grid, block, 0, s, a, g, n); break;
+    case 4: hipLaunchKernelGGL(k_fuse2<4>, grid, block, 0, s, a, g, n); break;
+    case 5: hipLaunchKernelGGL(k_fuse2<5>, grid, block, 0, s, a, g, n); break;
+    case 6: hipLaunchKernelGGL(k_fuse2<6>, grid, block, 0, s, a, g, n); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_fuse_hm_n(hipStream_t s, float* a, const float* g, size_t n, int n_maps)
+{
+    hipLaunchKernelGGL(k_elementwise<EW_HM_N>, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, s, a,
+                       g, n, (float)n_maps, (float)(n_maps - 1));
+    return hipGetLastError();
+}
+
+hipError_t launch_accumulate(hipStream_t s, float* acc, const float* g, size_t n, int mode)
+{
+    const dim3 grid(grid_for(n / 4 + 1, 256)), block(256);
+    if (mode == 0)
+        hipLaunchKernelGGL(k_elementwise<EW_ADD>, grid, block, 0, s, acc, g, n, 0.f, 0.f);
+    else
+        hipLaunchKernelGGL(k_elementwise<EW_ADD_INV>, grid, block, 0, s, acc, g, n, 0.f, 0.f);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize(hipStream_t s, float* acc, size_t n, int mode, int n_maps)
+{
+    const dim3 grid(grid_for(n / 4 + 1, 256)), block(256);
+    if (mode == 0)
+        hipLaunchKernelGGL(k_elementwise<EW_FIN_AM>, grid, block, 0, s, acc, (const float*)nullptr,
+                           n, (float)n_maps, 0.f);
+    else
+        hipLaunchKernelGGL(k_elementwise<EW_FIN_HM>, grid, block, 0, s, acc, (const float*)nullptr,
+                           n, (float)n_maps, 0.f);
+    return hipGetLastError();
+}
+
+hipError_t launch_collapse_max_z(hipStream_t s, const float* dsi, int nx, int ny, int nz,
+                                 float* conf, uint8_t* idx, const float* planes, float* depth)
+{
+    const int npix = nx * ny;
+    hipLaunchKernelGGL(k_collapse_max_z, dim3((npix + 255) / 256), dim3(256), 0, s, dsi, npix, nz,
+                       conf, idx, planes, depth);
+    return hipGetLastError();
+}
+
+hipError_t launch_mean_square(hipStream_t s, const float* dsi, size_t n, double* accum)
+{
+    hipLaunchKernelGGL(k_mean_square, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, dsi, n,
+                       accum);
+    return hipGetLastError();
+}
+
+hipError_t launch_div_probe(hipStream_t s, const float* n, const float* d, size_t count, float* q,
+                            float* ref)
+{
+    hipLaunchKernelGGL(k_div_probe, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, n, d,
+                       count, q, ref);
+    return hipGetLastError();
+}
+
+}  // namespace dsi

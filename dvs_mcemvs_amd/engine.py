@@ -1,0 +1,507 @@
+"""ctypes binding of include/dsi_engine.h.  Host-side mirror of the reference's
+operator interface on the hot path:
+
+    Grid3D       cartesian3dgrid/include/cartesian3dgrid/cartesian3dgrid.h:22-247
+    MapperEMVS   mapper_emvs_stereo/include/mapper_emvs_stereo/mapper_emvs_stereo.hpp:94-155
+    ShapeDSI     mapper_emvs_stereo.hpp:40-65
+
+Method names, argument meaning and error behaviour follow the reference; where the
+reference aborts (glog CHECK) or throws std::out_of_range this binding raises
+DsiError carrying the C status code.  numpy arrays cross the boundary as plain
+pointers; nothing here computes on the CPU.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+PACKET_SIZE = 1024
+
+FUSE_MIN, FUSE_HM, FUSE_GM, FUSE_AM, FUSE_RMS, FUSE_MAX = 1, 2, 3, 4, 5, 6
+ACC_SUM, ACC_INV_SUM = 0, 1
+VOTE_AUTO, VOTE_GLOBAL_ATOMIC, VOTE_LDS_BANDS = 0, 1, 2
+
+(OK, ERR_INVALID, ERR_TOO_FEW_EVENTS, ERR_HIP, ERR_SHAPE, ERR_BAD_OP, ERR_NO_DEVICE,
+ ERR_CONTEXT) = range(8)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class DsiError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("dsi_engine error %d: %s" % (code, message))
+        self.code = code
+
+
+class _MapperConfig(C.Structure):
+    _fields_ = [("sensor_width", C.c_int), ("sensor_height", C.c_int), ("K", C.c_float * 4),
+                ("dim_x", C.c_int), ("dim_y", C.c_int), ("dim_z", C.c_int),
+                ("min_depth", C.c_float), ("max_depth", C.c_float), ("fov_deg", C.c_float),
+                ("inverse_depth", C.c_int), ("lut", C.POINTER(C.c_float))]
+
+
+class _VoteInfo(C.Structure):
+    _fields_ = [("algo", C.c_int), ("bands", C.c_int), ("band_rows", C.c_int),
+                ("chunks", C.c_int), ("block_threads", C.c_int), ("lds_bytes", C.c_size_t),
+                ("n_packets", C.c_size_t)]
+
+
+def library_path():
+    return os.path.join(_HERE, "libdsi_engine.so")
+
+
+def load_library():
+    """Load libdsi_engine.so (building it is __graft_entry__.build()'s job).
+    Raises when it is absent -- there is no fallback implementation."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            "%s is missing: build the HIP engine first (python -m dvs_mcemvs_amd.build). "
+            "dvs_mcemvs_amd has no CPU fallback." % path)
+    L = C.CDLL(path)
+    vp, f32p, u8p, u16p, u32p, f64p = (C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint8),
+                                       C.POINTER(C.c_uint16), C.POINTER(C.c_uint32),
+                                       C.POINTER(C.c_double))
+    intp, szp = C.POINTER(C.c_int), C.POINTER(C.c_size_t)
+    sig = {
+        "dsi_last_error": (C.c_char_p, []),
+        "dsi_abi_version": (C.c_int, []),
+        "dsi_device_count": (C.c_int, []),
+        "dsi_context_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+        "dsi_context_destroy": (C.c_int, [vp]),
+        "dsi_context_synchronize": (C.c_int, [vp]),
+        "dsi_context_stream": (vp, [vp]),
+        "dsi_context_device": (C.c_int, [vp]),
+        "dsi_context_timer_start": (C.c_int, [vp]),
+        "dsi_context_timer_stop": (C.c_int, [vp, f32p]),
+        "dsi_grid_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+        "dsi_grid_wrap": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp)]),
+        "dsi_grid_destroy": (C.c_int, [vp]),
+        "dsi_grid_dims": (C.c_int, [vp, intp, intp, intp]),
+        "dsi_grid_reset": (C.c_int, [vp]),
+        "dsi_grid_device_ptr": (vp, [vp]),
+        "dsi_grid_upload": (C.c_int, [vp, f32p]),
+        "dsi_grid_download": (C.c_int, [vp, f32p]),
+        "dsi_grid_fuse2": (C.c_int, [vp, vp, C.c_int]),
+        "dsi_grid_fuse_hm_n": (C.c_int, [vp, vp, C.c_int]),
+        "dsi_grid_accumulate": (C.c_int, [vp, vp, C.c_int]),
+        "dsi_grid_finalize": (C.c_int, [vp, C.c_int, C.c_int]),
+        "dsi_grid_collapse_max_z": (C.c_int, [vp, f32p, u8p]),
+        "dsi_grid_collapse_max_z_dev": (C.c_int, [vp, vp, vp, vp, vp]),
+        "dsi_grid_mean_square": (C.c_int, [vp, f64p]),
+        "dsi_mapper_create": (C.c_int, [vp, C.POINTER(_MapperConfig), C.POINTER(vp)]),
+        "dsi_mapper_destroy": (C.c_int, [vp]),
+        "dsi_mapper_grid": (vp, [vp]),
+        "dsi_mapper_geometry": (C.c_int, [vp, f32p, f32p, intp, intp, intp]),
+        "dsi_mapper_set_vote_algo": (C.c_int, [vp, C.c_int]),
+        "dsi_mapper_set_band_params": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
+        "dsi_mapper_fill_voxel_grid": (C.c_int, [vp, f32p, f32p, C.c_size_t]),
+        "dsi_batch_create": (C.c_int, [vp, u16p, u16p, C.c_size_t, u32p, f32p, C.c_size_t,
+                                       C.POINTER(vp)]),
+        "dsi_batch_destroy": (C.c_int, [vp]),
+        "dsi_batch_num_packets": (C.c_size_t, [vp]),
+        "dsi_mapper_evaluate_batch": (C.c_int, [vp, vp]),
+        "dsi_mapper_evaluate": (C.c_int, [vp, u16p, u16p, f64p, C.c_size_t, f64p, f64p,
+                                          C.c_size_t, f64p, szp]),
+        "dsi_packetize": (C.c_int, [f64p, C.c_size_t, f64p, f64p, C.c_size_t, f64p, u32p, f32p,
+                                    szp]),
+        "dsi_pose_at": (C.c_int, [f64p, f64p, C.c_size_t, C.c_double, f64p]),
+        "dsi_mapper_depth_map": (C.c_int, [vp, f32p, f32p, u8p]),
+        "dsi_mapper_depth_map_of": (C.c_int, [vp, vp]),
+        "dsi_mapper_fetch_depth_map": (C.c_int, [vp, f32p, f32p, u8p]),
+        "dsi_mapper_last_vote_info": (C.c_int, [vp, C.POINTER(_VoteInfo)]),
+        "dsi_mapper_set_kernel_timing": (C.c_int, [vp, C.c_int]),
+        "dsi_mapper_vote_kernel_time": (C.c_int, [vp, f32p, intp]),
+        "dsi_test_div_probe": (C.c_int, [vp, f32p, f32p, C.c_size_t, f32p, f32p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError here = the .so does not export the ABI
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = L
+    return L
+
+
+EXPORTED_SYMBOLS = None  # filled by tests from include/dsi_engine.h
+
+
+def _check(rc):
+    if rc != OK:
+        msg = load_library().dsi_last_error()
+        raise DsiError(rc, msg.decode() if msg else "")
+
+
+def _ptr(a, ct):
+    return a.ctypes.data_as(C.POINTER(ct))
+
+
+def _arr(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def device_count():
+    return load_library().dsi_device_count()
+
+
+class Context:
+    """One GPU + one HIP stream.  All objects created from a context share its stream."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _check(load_library().dsi_context_create(int(device), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            load_library().dsi_context_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(load_library().dsi_context_synchronize(self._h))
+
+    @property
+    def stream(self):
+        return load_library().dsi_context_stream(self._h)
+
+    @property
+    def device(self):
+        return load_library().dsi_context_device(self._h)
+
+    def timer_start(self):
+        _check(load_library().dsi_context_timer_start(self._h))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        _check(load_library().dsi_context_timer_stop(self._h, C.byref(ms)))
+        return ms.value
+
+
+class Grid3D:
+    """Device-resident counterpart of the reference's Grid3D (cartesian3dgrid.h:22-247).
+
+    Layout volume[x + dimX*(y + dimY*z)]; host views are numpy [dimZ][dimY][dimX].
+    Fusion methods keep the reference's names and in-place semantics.
+    """
+
+    def __init__(self, ctx, dimX, dimY, dimZ, _handle=None, _owner=None, device_ptr=None):
+        self.ctx = ctx
+        self._owner = _owner
+        self._keep = None
+        L = load_library()
+        if _handle is not None:
+            self._h = _handle
+            self._owned = False
+        elif device_ptr is not None:
+            self._h = C.c_void_p()
+            _check(L.dsi_grid_wrap(ctx._h, dimX, dimY, dimZ, C.c_void_p(device_ptr),
+                                   C.byref(self._h)))
+            self._owned = True
+        else:
+            self._h = C.c_void_p()
+            _check(L.dsi_grid_create(ctx._h, dimX, dimY, dimZ, C.byref(self._h)))
+            self._owned = True
+
+    def close(self):
+        if getattr(self, "_owned", False) and self._h:
+            load_library().dsi_grid_destroy(self._h)
+        self._h = C.c_void_p()
+        self._owned = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def getDimensions(self):
+        nx, ny, nz = C.c_int(), C.c_int(), C.c_int()
+        _check(load_library().dsi_grid_dims(self._h, C.byref(nx), C.byref(ny), C.byref(nz)))
+        return nx.value, ny.value, nz.value
+
+    @property
+    def shape(self):
+        nx, ny, nz = self.getDimensions()
+        return nz, ny, nx
+
+    @property
+    def device_ptr(self):
+        return load_library().dsi_grid_device_ptr(self._h)
+
+    def resetGrid(self):
+        _check(load_library().dsi_grid_reset(self._h))
+
+    def upload(self, host):
+        host = _arr(host, np.float32)
+        if host.shape != self.shape:
+            raise DsiError(ERR_SHAPE, "host array shape %s != grid shape %s" % (host.shape, self.shape))
+        _check(load_library().dsi_grid_upload(self._h, _ptr(host, C.c_float)))
+
+    def download(self):
+        out = np.empty(self.shape, np.float32)
+        _check(load_library().dsi_grid_download(self._h, _ptr(out, C.c_float)))
+        return out
+
+    # -- voxel-wise fusion, cartesian3dgrid.h:64-192 --------------------------------
+    def _fuse(self, other, op):
+        _check(load_library().dsi_grid_fuse2(self._h, other._h, op))
+
+    def minTwoGrids(self, grid2):
+        self._fuse(grid2, FUSE_MIN)
+
+    def harmonicMeanTwoGrids(self, grid2, n=None):
+        if n is None:
+            self._fuse(grid2, FUSE_HM)
+        else:
+            _check(load_library().dsi_grid_fuse_hm_n(self._h, grid2._h, int(n)))
+
+    def geometricMeanTwoGrids(self, grid2):
+        self._fuse(grid2, FUSE_GM)
+
+    def arithmeticMeanTwoGrids(self, grid2):
+        self._fuse(grid2, FUSE_AM)
+
+    def rmsTwoGrids(self, grid2):
+        self._fuse(grid2, FUSE_RMS)
+
+    def maxTwoGrids(self, grid2):
+        self._fuse(grid2, FUSE_MAX)
+
+    def fuseTwoGrids(self, grid2, fusion_method):
+        """The switch(fusion_method) of process1.cpp:136-158."""
+        self._fuse(grid2, int(fusion_method))
+
+    def addTwoGrids(self, grid2):
+        _check(load_library().dsi_grid_accumulate(self._h, grid2._h, ACC_SUM))
+
+    def addInverseOfTwoGrids(self, grid2):
+        _check(load_library().dsi_grid_accumulate(self._h, grid2._h, ACC_INV_SUM))
+
+    def computeAMfromSum(self, n):
+        _check(load_library().dsi_grid_finalize(self._h, ACC_SUM, int(n)))
+
+    def computeHMfromSumOfInv(self, n):
+        _check(load_library().dsi_grid_finalize(self._h, ACC_INV_SUM, int(n)))
+
+    # -- cartesian3dgrid.cpp:115-137, :164-174 --------------------------------------
+    def collapseMaxZSlice(self):
+        """Returns (max_val float32 [dimY][dimX], max_pos uint8 [dimY][dimX])."""
+        nz, ny, nx = self.shape
+        conf = np.empty((ny, nx), np.float32)
+        idx = np.empty((ny, nx), np.uint8)
+        _check(load_library().dsi_grid_collapse_max_z(self._h, _ptr(conf, C.c_float),
+                                                      _ptr(idx, C.c_uint8)))
+        return conf, idx
+
+    def computeMeanSquare(self):
+        out = C.c_double()
+        _check(load_library().dsi_grid_mean_square(self._h, C.byref(out)))
+        return out.value
+
+
+class ShapeDSI:
+    """mapper_emvs_stereo.hpp:40-65"""
+
+    def __init__(self, dimX=0, dimY=0, dimZ=100, min_depth=0.3, max_depth=5.0, fov=0.0):
+        self.dimX_, self.dimY_, self.dimZ_ = int(dimX), int(dimY), int(dimZ)
+        self.min_depth_, self.max_depth_, self.fov_ = float(min_depth), float(max_depth), float(fov)
+
+
+class EventBatch:
+    """Device-resident events of one evaluateDSI call + their packetisation
+    (mapper_emvs_stereo.cpp:88-105)."""
+
+    def __init__(self, ctx, x, y, Rt, packet_first=None):
+        x = _arr(x, np.uint16)
+        y = _arr(y, np.uint16)
+        Rt = _arr(Rt, np.float32).reshape(-1, 12)
+        pf = None
+        if packet_first is not None:
+            packet_first = _arr(packet_first, np.uint32)
+            pf = _ptr(packet_first, C.c_uint32)
+        self.ctx = ctx
+        self.n_packets = Rt.shape[0]
+        self.n_events = x.shape[0]
+        self._h = C.c_void_p()
+        _check(load_library().dsi_batch_create(ctx._h, _ptr(x, C.c_uint16), _ptr(y, C.c_uint16),
+                                               x.shape[0], pf, _ptr(Rt, C.c_float), Rt.shape[0],
+                                               C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            load_library().dsi_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MapperEMVS:
+    """Device-resident counterpart of EMVS::MapperEMVS (mapper_emvs_stereo.hpp:94-155).
+
+    cam = (width, height, fx, fy, cx, cy): full resolution and the projection-matrix
+    intrinsics the reference reads from image_geometry::PinholeCameraModel
+    (mapper_emvs_stereo.cpp:34-48).  lut = undistortion table of
+    precomputeRectifiedPoints (mapper_emvs_stereo.cpp:256-299), shape [H*W][2] or None.
+    """
+
+    def __init__(self, ctx, cam, dsi_shape, lut=None, inverse_depth=False):
+        w, h, fx, fy, cx, cy = cam
+        cfg = _MapperConfig()
+        cfg.sensor_width, cfg.sensor_height = int(w), int(h)
+        cfg.K = (C.c_float * 4)(fx, fy, cx, cy)
+        cfg.dim_x, cfg.dim_y, cfg.dim_z = dsi_shape.dimX_, dsi_shape.dimY_, dsi_shape.dimZ_
+        cfg.min_depth, cfg.max_depth, cfg.fov_deg = (dsi_shape.min_depth_, dsi_shape.max_depth_,
+                                                     dsi_shape.fov_)
+        cfg.inverse_depth = 1 if inverse_depth else 0
+        self._lut = None
+        if lut is not None:
+            self._lut = _arr(lut, np.float32).reshape(int(w) * int(h), 2)
+            cfg.lut = _ptr(self._lut, C.c_float)
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        L = load_library()
+        _check(L.dsi_mapper_create(ctx._h, C.byref(cfg), C.byref(self._h)))
+        nx, ny, nz = C.c_int(), C.c_int(), C.c_int()
+        kv = (C.c_float * 4)()
+        _check(L.dsi_mapper_geometry(self._h, kv, None, C.byref(nx), C.byref(ny), C.byref(nz)))
+        self.dimX, self.dimY, self.dimZ = nx.value, ny.value, nz.value
+        planes = np.empty(self.dimZ, np.float32)
+        _check(L.dsi_mapper_geometry(self._h, None, _ptr(planes, C.c_float), None, None, None))
+        self.raw_depths_vec_ = planes
+        self.virtual_cam_ = tuple(float(v) for v in kv)  # fx, fy, cx, cy
+        # public member dsi_ (mapper_emvs_stereo.hpp:116)
+        self.dsi_ = Grid3D(ctx, 0, 0, 0, _handle=C.c_void_p(L.dsi_mapper_grid(self._h)), _owner=self)
+        self.name = ""
+
+    def close(self):
+        if self._h:
+            load_library().dsi_mapper_destroy(self._h)
+            self._h = C.c_void_p()
+            self.dsi_._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_vote_algo(self, algo):
+        _check(load_library().dsi_mapper_set_vote_algo(self._h, int(algo)))
+
+    def set_band_params(self, band_rows=0, chunks=0, block_threads=0):
+        _check(load_library().dsi_mapper_set_band_params(self._h, int(band_rows), int(chunks),
+                                                         int(block_threads)))
+
+    def last_vote_info(self):
+        info = _VoteInfo()
+        _check(load_library().dsi_mapper_last_vote_info(self._h, C.byref(info)))
+        return {k: getattr(info, k) for k, _ in _VoteInfo._fields_}
+
+    def set_kernel_timing(self, enable=True):
+        _check(load_library().dsi_mapper_set_kernel_timing(self._h, 1 if enable else 0))
+
+    def vote_kernel_time(self):
+        """(total ms, launches) of the voting kernel since the last call (HIP events)."""
+        ms, n = C.c_float(), C.c_int()
+        _check(load_library().dsi_mapper_vote_kernel_time(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def evaluateDSI(self, events, trajectory, T_rv_w):
+        """mapper_emvs_stereo.cpp:67-148.  events = (x uint16[n], y uint16[n], ts float64[n]);
+        trajectory = (times float64[m], poses float64[m][7] as tx,ty,tz,qw,qx,qy,qz);
+        T_rv_w = 7 doubles.  Returns False where the reference returns false."""
+        x, y, ts = events
+        x, y, ts = _arr(x, np.uint16), _arr(y, np.uint16), _arr(ts, np.float64)
+        times, poses = trajectory
+        times, poses = _arr(times, np.float64), _arr(poses, np.float64).reshape(-1, 7)
+        T = _arr(T_rv_w, np.float64)
+        voted = C.c_size_t()
+        rc = load_library().dsi_mapper_evaluate(
+            self._h, _ptr(x, C.c_uint16), _ptr(y, C.c_uint16), _ptr(ts, C.c_double), x.shape[0],
+            _ptr(times, C.c_double), _ptr(poses, C.c_double), times.shape[0], _ptr(T, C.c_double),
+            C.byref(voted))
+        if rc == ERR_TOO_FEW_EVENTS:
+            return False
+        _check(rc)
+        self.n_voted = voted.value
+        return True
+
+    def evaluateDSI_batch(self, batch):
+        """evaluateDSI past the pose lookup, on a device-resident EventBatch (asynchronous)."""
+        _check(load_library().dsi_mapper_evaluate_batch(self._h, batch._h))
+
+    def fillVoxelGrid(self, event_locations_z0, camera_centers):
+        """mapper_emvs_stereo.cpp:151-205 (private in the reference; the parity test point).
+        Accumulates into dsi_ without resetting it."""
+        xy = _arr(event_locations_z0, np.float32).reshape(-1, 2)
+        cc = _arr(camera_centers, np.float32).reshape(-1, 3)
+        if xy.shape[0] != cc.shape[0] * PACKET_SIZE:
+            raise DsiError(ERR_INVALID, "need 1024 event locations per camera centre")
+        _check(load_library().dsi_mapper_fill_voxel_grid(self._h, _ptr(xy, C.c_float),
+                                                         _ptr(cc, C.c_float), cc.shape[0]))
+
+    def getDepthMapFromDSI(self, grid=None):
+        """The device part of getDepthMapFromDSI (mapper_emvs_stereo.cpp:339-437):
+        collapseMaxZSlice (:368) + convertDepthIndicesToValues (:302-313) on the raw
+        arg-max indices.  Returns (depth, confidence, indices)."""
+        L = load_library()
+        _check(L.dsi_mapper_depth_map_of(self._h, (grid or self.dsi_)._h))
+        return self.fetchDepthMap()
+
+    def computeDepthMap(self, grid=None):
+        """Asynchronous half of getDepthMapFromDSI; pair with fetchDepthMap()."""
+        _check(load_library().dsi_mapper_depth_map_of(self._h, (grid or self.dsi_)._h))
+
+    def fetchDepthMap(self):
+        depth = np.empty((self.dimY, self.dimX), np.float32)
+        conf = np.empty((self.dimY, self.dimX), np.float32)
+        idx = np.empty((self.dimY, self.dimX), np.uint8)
+        _check(load_library().dsi_mapper_fetch_depth_map(self._h, _ptr(depth, C.c_float),
+                                                         _ptr(conf, C.c_float), _ptr(idx, C.c_uint8)))
+        return depth, conf, idx
+
+
+def packetize(ts, trajectory, T_rv_w):
+    """Host packetisation + pose pipeline of evaluateDSI (mapper_emvs_stereo.cpp:67-105).
+    Returns (packet_first uint32[np], Rt float32[np][12]) or None when the reference
+    would return false."""
+    ts = _arr(ts, np.float64)
+    times, poses = trajectory
+    times, poses = _arr(times, np.float64), _arr(poses, np.float64).reshape(-1, 7)
+    T = _arr(T_rv_w, np.float64)
+    cap = ts.shape[0] // PACKET_SIZE + 1
+    first = np.empty(cap, np.uint32)
+    Rt = np.empty((cap, 12), np.float32)
+    n = C.c_size_t()
+    rc = load_library().dsi_packetize(_ptr(ts, C.c_double), ts.shape[0], _ptr(times, C.c_double),
+                                      _ptr(poses, C.c_double), times.shape[0], _ptr(T, C.c_double),
+                                      _ptr(first, C.c_uint32), _ptr(Rt, C.c_float), C.byref(n))
+    if rc == ERR_TOO_FEW_EVENTS:
+        return None
+    _check(rc)
+    return first[:n.value].copy(), Rt[:n.value].copy()
+
+
+def pose_at(trajectory, t):
+    """LinearTrajectory::getPoseAt (trajectory.hpp:92-126); None when it returns false."""
+    times, poses = trajectory
+    times, poses = _arr(times, np.float64), _arr(poses, np.float64).reshape(-1, 7)
+    out = np.empty(7, np.float64)
+    rc = load_library().dsi_pose_at(_ptr(times, C.c_double), _ptr(poses, C.c_double), times.shape[0],
+                                    float(t), _ptr(out, C.c_double))
+    if rc == ERR_INVALID:
+        return None
+    _check(rc)
+    return out

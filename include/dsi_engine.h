@@ -1,0 +1,236 @@
+/*
+ * dsi_engine.h -- C ABI of the MI355X-native DSI construction / fusion / arg-max
+ * engine (libdsi_engine.so, hand-written HIP for gfx950).
+ *
+ * This is the drop-in boundary for the hot path of tub-rip/dvs_mcemvs:
+ *     MapperEMVS::evaluateDSI -> fillVoxelGrid -> Grid3D::accumulateGridValueAt,
+ *     Grid3D voxel-wise fusion, Grid3D::collapseMaxZSlice.
+ * The reference has no FFI layer (it is one C++ process); each entry point below
+ * names the reference C++ member it replaces (file:line relative to the
+ * reference checkout).  include/dsi_engine.hpp re-creates the reference's class
+ * and method names (Grid3D, EMVS::MapperEMVS, ...) on top of this ABI.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every function returns a dsi_status_t
+ *    (0 = ok) and never aborts or throws (the reference glog-CHECK-aborts);
+ *    dsi_last_error() gives a thread-local message for the last failure.
+ *  - volumes are fp32, layout volume[x + Nx*(y + Ny*z)] (cartesian3dgrid.h:34-35).
+ *  - "host" pointers are ordinary CPU memory; "_dev" pointers are HIP device
+ *    memory on the context's GPU.
+ *  - all work of one context is issued on that context's HIP stream, in call
+ *    order; functions that return host data synchronise, the others are
+ *    asynchronous.  Distinct contexts may be used from distinct threads.
+ *  - there is NO CPU fallback: creating a context fails when no gfx950 device
+ *    (or no HIP device at all) is present.
+ */
+#ifndef DSI_ENGINE_H
+#define DSI_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define DSI_API __attribute__((visibility("default")))
+#else
+#define DSI_API
+#endif
+
+#define DSI_ENGINE_ABI_VERSION 1
+#define DSI_PACKET_SIZE 1024 /* mapper_emvs_stereo.hpp:152 packet_size_ */
+
+typedef enum {
+    DSI_OK = 0,
+    DSI_ERR_INVALID = 1,       /* bad argument (null pointer, non-positive size, ...) */
+    DSI_ERR_TOO_FEW_EVENTS = 2,/* evaluateDSI returns false: events.size() < 1024 (mapper_emvs_stereo.cpp:71-75) */
+    DSI_ERR_HIP = 3,           /* a HIP runtime call failed */
+    DSI_ERR_SHAPE = 4,         /* grids of different dimensions (reference: std::out_of_range from .at()) */
+    DSI_ERR_BAD_OP = 5,        /* "Improper fusion method selected" (process1.cpp:155-157) */
+    DSI_ERR_NO_DEVICE = 6,     /* no usable gfx950 GPU */
+    DSI_ERR_CONTEXT = 7        /* objects belong to different contexts */
+} dsi_status_t;
+
+/* camera-fusion op codes = --stereo_fusion values (main.cpp:89, process1.cpp:136-158) */
+typedef enum {
+    DSI_FUSE_MIN = 1,  /* Grid3D::minTwoGrids            cartesian3dgrid.h:111-117 */
+    DSI_FUSE_HM = 2,   /* Grid3D::harmonicMeanTwoGrids   cartesian3dgrid.h:119-127 */
+    DSI_FUSE_GM = 3,   /* Grid3D::geometricMeanTwoGrids  cartesian3dgrid.h:150-156 */
+    DSI_FUSE_AM = 4,   /* Grid3D::arithmeticMeanTwoGrids cartesian3dgrid.h:158-164 */
+    DSI_FUSE_RMS = 5,  /* Grid3D::rmsTwoGrids            cartesian3dgrid.h:141-148 */
+    DSI_FUSE_MAX = 6   /* Grid3D::maxTwoGrids            cartesian3dgrid.h:184-190 */
+} dsi_fuse_op_t;
+
+typedef enum {
+    DSI_ACC_SUM = 0,    /* addTwoGrids / computeAMfromSum            cartesian3dgrid.h:64-70, 87-93 */
+    DSI_ACC_INV_SUM = 1 /* addInverseOfTwoGrids / computeHMfromSumOfInv cartesian3dgrid.h:72-86 */
+} dsi_acc_mode_t;
+
+/* which voting kernel MapperEMVS::fillVoxelGrid is replaced by */
+typedef enum {
+    DSI_VOTE_AUTO = 0,
+    DSI_VOTE_GLOBAL_ATOMIC = 1, /* thread = event, global_atomic_add_f32 into the DSI */
+    DSI_VOTE_LDS_BANDS = 2      /* plane x row-band privatised in LDS, ds_add_f32, coalesced flush */
+} dsi_vote_algo_t;
+
+typedef struct dsi_context dsi_context_t; /* one GPU + one HIP stream + scratch */
+typedef struct dsi_grid dsi_grid_t;       /* device-resident Grid3D */
+typedef struct dsi_mapper dsi_mapper_t;   /* device-resident MapperEMVS */
+typedef struct dsi_batch dsi_batch_t;     /* device-resident, packetised events of one evaluateDSI call */
+
+DSI_API const char *dsi_last_error(void);
+DSI_API int dsi_abi_version(void);
+/* number of HIP devices visible, or 0 (never fails) */
+DSI_API int dsi_device_count(void);
+
+/* ------------------------------------------------------------------ context */
+DSI_API int dsi_context_create(int device_id, dsi_context_t **out);
+DSI_API int dsi_context_destroy(dsi_context_t *ctx);
+DSI_API int dsi_context_synchronize(dsi_context_t *ctx);
+/* the hipStream_t all work of this context is issued on */
+DSI_API void *dsi_context_stream(dsi_context_t *ctx);
+DSI_API int dsi_context_device(dsi_context_t *ctx);
+/* HIP-event stopwatch on the context's stream (bench.py: the replacement of the
+ * std::chrono timers at process1.cpp:72-85,132-166). stop synchronises. */
+DSI_API int dsi_context_timer_start(dsi_context_t *ctx);
+DSI_API int dsi_context_timer_stop(dsi_context_t *ctx, float *elapsed_ms);
+
+/* ------------------------------------------------------------------- Grid3D */
+/* Grid3D::Grid3D(dimX,dimY,dimZ) + allocate + resetGrid (cartesian3dgrid.cpp:30-46) */
+DSI_API int dsi_grid_create(dsi_context_t *ctx, int nx, int ny, int nz, dsi_grid_t **out);
+/* same, over caller-owned device memory of nx*ny*nz floats (not zeroed, not freed) */
+DSI_API int dsi_grid_wrap(dsi_context_t *ctx, int nx, int ny, int nz, void *data_dev, dsi_grid_t **out);
+DSI_API int dsi_grid_destroy(dsi_grid_t *g);
+/* Grid3D::getDimensions (cartesian3dgrid.h:230-235) */
+DSI_API int dsi_grid_dims(const dsi_grid_t *g, int *nx, int *ny, int *nz);
+/* Grid3D::resetGrid (cartesian3dgrid.cpp:67-70) */
+DSI_API int dsi_grid_reset(dsi_grid_t *g);
+/* Grid3D::getPointerToSlice(0) (cartesian3dgrid.h:237-240), as a device pointer */
+DSI_API void *dsi_grid_device_ptr(dsi_grid_t *g);
+DSI_API int dsi_grid_upload(dsi_grid_t *g, const float *host);
+DSI_API int dsi_grid_download(dsi_grid_t *g, float *host);
+/* dst = op(dst, src), in place, op in 1..6 (cartesian3dgrid.h:111-190) */
+DSI_API int dsi_grid_fuse2(dsi_grid_t *dst, const dsi_grid_t *src, int op);
+/* Grid3D::harmonicMeanTwoGrids(grid2, n) (cartesian3dgrid.h:130-139) */
+DSI_API int dsi_grid_fuse_hm_n(dsi_grid_t *dst, const dsi_grid_t *src, int n);
+/* Grid3D::addTwoGrids / addInverseOfTwoGrids (cartesian3dgrid.h:64-78) */
+DSI_API int dsi_grid_accumulate(dsi_grid_t *dst, const dsi_grid_t *src, int mode);
+/* Grid3D::computeAMfromSum / computeHMfromSumOfInv (cartesian3dgrid.h:80-93) */
+DSI_API int dsi_grid_finalize(dsi_grid_t *dst, int mode, int n);
+/* Grid3D::collapseMaxZSlice (cartesian3dgrid.cpp:115-137): conf[ny*nx] f32,
+ * idx[ny*nx] u8, first maximum wins.  Host outputs; synchronises. */
+DSI_API int dsi_grid_collapse_max_z(dsi_grid_t *g, float *conf_host, uint8_t *idx_host);
+/* same, device outputs, asynchronous.  planes_dev (nz floats) + depth_dev may be
+ * NULL; when given, depth_dev[p] = planes_dev[idx[p]]
+ * (MapperEMVS::convertDepthIndicesToValues, mapper_emvs_stereo.cpp:302-313). */
+DSI_API int dsi_grid_collapse_max_z_dev(dsi_grid_t *g, float *conf_dev, uint8_t *idx_dev,
+                                const float *planes_dev, float *depth_dev);
+/* Grid3D::computeMeanSquare (cartesian3dgrid.cpp:164-174), accumulated in double */
+DSI_API int dsi_grid_mean_square(dsi_grid_t *g, double *out);
+
+/* --------------------------------------------------------------- MapperEMVS */
+typedef struct {
+    int sensor_width;   /* cam.fullResolution() (mapper_emvs_stereo.cpp:34-36) */
+    int sensor_height;
+    float K[4];         /* fx, fy, cx, cy of the projection matrix (mapper_emvs_stereo.cpp:46-48) */
+    int dim_x;          /* ShapeDSI (mapper_emvs_stereo.hpp:40-65); 0 = sensor size (:216-217) */
+    int dim_y;
+    int dim_z;          /* <= 256 (main.cpp:156) */
+    float min_depth;
+    float max_depth;
+    float fov_deg;      /* < 10: use the camera focal length (mapper_emvs_stereo.cpp:219-229) */
+    int inverse_depth;  /* 0: LinearDepthVector (CMake default), 1: -DUSE_INVERSE_DEPTH */
+    const float *lut;   /* host, 2*W*H floats, entry y*W+x = undistorted (u,v)
+                           (precomputeRectifiedPoints, mapper_emvs_stereo.cpp:256-299); NULL = identity */
+} dsi_mapper_config_t;
+
+/* MapperEMVS::MapperEMVS(cam, dsi_shape) (mapper_emvs_stereo.cpp:29-64, setupDSI :208-241) */
+DSI_API int dsi_mapper_create(dsi_context_t *ctx, const dsi_mapper_config_t *cfg, dsi_mapper_t **out);
+DSI_API int dsi_mapper_destroy(dsi_mapper_t *m);
+/* public member MapperEMVS::dsi_ (mapper_emvs_stereo.hpp:116); owned by the mapper */
+DSI_API dsi_grid_t *dsi_mapper_grid(dsi_mapper_t *m);
+/* virtual camera {fx,fy,cx,cy} (:231-239), plane depths raw_depths_vec_ (:213-214;
+ * raw_depths needs dim_z floats) and the resolved dimensions; any pointer may be NULL */
+DSI_API int dsi_mapper_geometry(const dsi_mapper_t *m, float *Kv, float *raw_depths, int *nx, int *ny, int *nz);
+DSI_API int dsi_mapper_set_vote_algo(dsi_mapper_t *m, int algo);
+/* tuning knobs of DSI_VOTE_LDS_BANDS; 0 = automatic */
+DSI_API int dsi_mapper_set_band_params(dsi_mapper_t *m, int band_rows, int chunks, int block_threads);
+
+/* MapperEMVS::fillVoxelGrid(event_locations_z0, camera_centers)
+ * (mapper_emvs_stereo.cpp:151-205) -- the exact-parity test point.  xy_z0: 2 floats
+ * per event (elements [0],[1] of each Vector4f), n_packets*1024 events; centers: 3
+ * floats per packet.  Host inputs.  Accumulates into the mapper's grid WITHOUT
+ * resetting it (the reset is evaluateDSI's, :145). */
+DSI_API int dsi_mapper_fill_voxel_grid(dsi_mapper_t *m, const float *xy_z0, const float *centers, size_t n_packets);
+
+/* Device-resident input of one evaluateDSI call: raw events (pixel x,y; polarity and
+ * timestamps are not needed past packetisation) plus the packetisation done by
+ * mapper_emvs_stereo.cpp:88-105: packet k covers events
+ * [packet_first[k], packet_first[k]+1024) (packet_first == NULL: k*1024) and has
+ * pose Rt[12k..12k+11] = R (row-major 3x3) then t of T_ev_rv, already cast to float. */
+DSI_API int dsi_batch_create(dsi_context_t *ctx, const uint16_t *x, const uint16_t *y, size_t n_events,
+                     const uint32_t *packet_first, const float *Rt, size_t n_packets, dsi_batch_t **out);
+DSI_API int dsi_batch_destroy(dsi_batch_t *b);
+DSI_API size_t dsi_batch_num_packets(const dsi_batch_t *b);
+
+/* MapperEMVS::evaluateDSI past the pose lookup: per-packet camera centre and H_z0
+ * (:108-126), per-event LUT + z0 warp (:129-142), resetGrid (:145), fillVoxelGrid
+ * (:146).  Asynchronous on the context's stream. */
+DSI_API int dsi_mapper_evaluate_batch(dsi_mapper_t *m, const dsi_batch_t *batch);
+
+/* MapperEMVS::evaluateDSI(events, trajectory, T_rv_w) (mapper_emvs_stereo.cpp:67-148),
+ * host inputs.  Events: pixel coordinates and timestamps in seconds, time-sorted.
+ * Trajectory: n_poses control poses T_w_c as {tx,ty,tz,qw,qx,qy,qz} at ascending
+ * times (LinearTrajectory, trajectory.hpp:81-128; SE(3) interpolation with
+ * minkindr semantics).  T_rv_w: same 7-double layout.  Returns
+ * DSI_ERR_TOO_FEW_EVENTS where the reference returns false.  n_voted (optional)
+ * receives the number of events actually voted (packets * 1024). */
+DSI_API int dsi_mapper_evaluate(dsi_mapper_t *m, const uint16_t *x, const uint16_t *y, const double *ts,
+                        size_t n_events, const double *traj_times, const double *traj_poses,
+                        size_t n_poses, const double *T_rv_w, size_t *n_voted);
+
+/* host-side packetisation + pose pipeline of evaluateDSI, exposed so that callers can
+ * build a dsi_batch_t once and keep it resident.  packet_first (capacity
+ * n_events/1024+1) and Rt (12 floats per packet) are outputs; *n_packets the count.
+ * Returns DSI_ERR_TOO_FEW_EVENTS for n_events < 1024. */
+DSI_API int dsi_packetize(const double *ts, size_t n_events, const double *traj_times,
+                  const double *traj_poses, size_t n_poses, const double *T_rv_w,
+                  uint32_t *packet_first, float *Rt, size_t *n_packets);
+/* LinearTrajectory::getPoseAt (trajectory.hpp:92-126); returns DSI_ERR_INVALID when
+ * the reference returns false (no extrapolation). out = 7 doubles. */
+DSI_API int dsi_pose_at(const double *traj_times, const double *traj_poses, size_t n_poses, double t, double *out);
+
+/* arg-max + depth of the mapper's own grid: collapseMaxZSlice (cartesian3dgrid.cpp:115-137)
+ * + convertDepthIndicesToValues (mapper_emvs_stereo.cpp:302-313) applied to the raw
+ * (pre-filter) indices.  Host outputs (any may be NULL); synchronises. */
+DSI_API int dsi_mapper_depth_map(dsi_mapper_t *m, float *depth_host, float *conf_host, uint8_t *idx_host);
+/* the same for any grid of the mapper's shape (e.g. a fused DSI); asynchronous variant
+ * keeps results in the mapper's device buffers until dsi_mapper_fetch_depth_map */
+DSI_API int dsi_mapper_depth_map_of(dsi_mapper_t *m, dsi_grid_t *g);
+DSI_API int dsi_mapper_fetch_depth_map(dsi_mapper_t *m, float *depth_host, float *conf_host, uint8_t *idx_host);
+
+/* HIP-event stopwatch around the voting kernel (the replacement of fillVoxelGrid's hot
+ * loop, mapper_emvs_stereo.cpp:168-203) on the context's stream: enable, run any number of
+ * evaluate/fill calls, then read the summed kernel time and launch count (synchronises and
+ * clears).  bench.py derives the roofline figure of the dominant kernel from this. */
+DSI_API int dsi_mapper_set_kernel_timing(dsi_mapper_t *m, int enable);
+DSI_API int dsi_mapper_vote_kernel_time(dsi_mapper_t *m, float *total_ms, int *launches);
+
+/* diagnostics of the last evaluate/fill call: which kernel ran, bands, chunks */
+typedef struct {
+    int algo;          /* dsi_vote_algo_t actually used */
+    int bands;         /* row bands per plane (LDS algo) */
+    int band_rows;     /* owned rows per band */
+    int chunks;        /* packet chunks (partial DSIs) */
+    int block_threads;
+    size_t lds_bytes;
+    size_t n_packets;
+} dsi_vote_info_t;
+DSI_API int dsi_mapper_last_vote_info(const dsi_mapper_t *m, dsi_vote_info_t *info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSI_ENGINE_H */

@@ -1,0 +1,509 @@
+/*
+ * dsi_oracle.c -- CPU ORACLE (test infrastructure only; PARITY UNPINNED, see
+ * dsi_oracle.h).  Plain C, fp32 arithmetic written operation by operation so
+ * that, built with -ffp-contract=off and without -ffast-math, every rounding
+ * happens where the reference's SSE2 build rounds.
+ */
+#include "dsi_oracle.h"
+
+#include <math.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ---- depth planes: depth_vector.hpp:76-163 ------------------------------ */
+void orc_depth_planes(float min_depth, float max_depth, int nz, int inverse,
+                      float *raw_depths)
+{
+    /* depth_vector.hpp:33-36: swap when given in the wrong order */
+    if (min_depth > max_depth) {
+        float tmp = min_depth;
+        min_depth = max_depth;
+        max_depth = tmp;
+    }
+    if (!inverse) {
+        /* :88  mult = (float)(N / (max-min)), size_t/float -> float */
+        const float mult = (float)nz / (max_depth - min_depth);
+        for (int i = 0; i < nz; ++i) /* :93 ; cellIndexToDepth :100-103 */
+            raw_depths[i] = min_depth + (float)i / mult;
+    } else {
+        /* :131-140 */
+        const float inv_min = 1.f / min_depth;
+        const float inv_max = 1.f / max_depth;
+        const float mult = (float)nz / (inv_min - inv_max);
+        for (int i = 0; i < nz; ++i) {
+            const float rho = inv_max + (float)i / mult;
+            raw_depths[i] = 1.f / rho; /* :145-148 */
+        }
+    }
+}
+
+/* ---- virtual camera focal: mapper_emvs_stereo.cpp:219-229 --------------- */
+float orc_virtual_focal(float cam_fx, float fov_deg, int dim_x)
+{
+    if (fov_deg < 10.f)
+        return cam_fx;
+    /* const float dsi_fov_rad = fov * CV_PI / 180.0 (double math, float store) */
+    const float dsi_fov_rad = (float)((double)fov_deg * 3.1415926535897932384626433832795 / 180.0);
+    /* f = 0.5 * (float)dimX / std::tan(0.5 * dsi_fov_rad)  (double, float store) */
+    return (float)(0.5 * (double)(float)dim_x / tan(0.5 * (double)dsi_fov_rad));
+}
+
+/* ---- Eigen 3.3 fixed-size helpers (restated; see header) ---------------- */
+static inline float dot3_eigen(float a0, float b0, float a1, float b1, float a2, float b2)
+{
+    /* redux_novec_unroller<.,.,0,3>: x0 + (x1 + x2) */
+    const float x0 = a0 * b0, x1 = a1 * b1, x2 = a2 * b2;
+    return x0 + (x1 + x2);
+}
+
+static void mul3x3_eigen(const float *a, const float *b, float *c)
+{
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            c[3 * i + j] = dot3_eigen(a[3 * i + 0], b[0 + j], a[3 * i + 1], b[3 + j],
+                                      a[3 * i + 2], b[6 + j]);
+}
+
+static inline float cof3(const float *m, int i, int j)
+{
+    /* Eigen cofactor_3x3<i,j> */
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    return m[3 * i1 + j1] * m[3 * i2 + j2] - m[3 * i1 + j2] * m[3 * i2 + j1];
+}
+
+void orc_inverse3x3(const float *m, float *out)
+{
+    /* Eigen compute_inverse<Matrix3f,3> / compute_inverse_size3_helper */
+    const float c0 = cof3(m, 0, 0), c1 = cof3(m, 1, 0), c2 = cof3(m, 2, 0);
+    const float det = dot3_eigen(c0, m[0], c1, m[3], c2, m[6]);
+    const float invdet = 1.f / det;
+    out[0] = c0 * invdet;
+    out[1] = c1 * invdet;
+    out[2] = c2 * invdet;
+    out[3] = cof3(m, 0, 1) * invdet;
+    out[4] = cof3(m, 1, 1) * invdet;
+    out[5] = cof3(m, 2, 1) * invdet;
+    out[6] = cof3(m, 0, 2) * invdet;
+    out[7] = cof3(m, 1, 2) * invdet;
+    out[8] = cof3(m, 2, 2) * invdet;
+}
+
+/* ---- per-packet geometry: mapper_emvs_stereo.cpp:101-126 ---------------- */
+void orc_packet_geometry(const float *Rt, const float *K, const float *Kv, float z0,
+                         float *center, float *H)
+{
+    const float *R = Rt, *t = Rt + 9;
+    /* :108  camera_centers.push_back(-R.transpose() * t) */
+    for (int i = 0; i < 3; ++i)
+        center[i] = dot3_eigen(-R[0 + i], t[0], -R[3 + i], t[1], -R[6 + i], t[2]);
+
+    /* :114-116  H_z0_inv = R; H_z0_inv *= z0; H_z0_inv.col(2) += t */
+    float Hinv[9];
+    for (int k = 0; k < 9; ++k)
+        Hinv[k] = R[k] * z0;
+    Hinv[2] += t[0];
+    Hinv[5] += t[1];
+    Hinv[8] += t[2];
+
+    /* :46-48 K_ ; geometry_utils.hpp:43-47 virtual K and Kinv_ = K_.inverse() */
+    const float Km[9] = {K[0], 0.f, K[2], 0.f, K[1], K[3], 0.f, 0.f, 1.f};
+    const float Kvm[9] = {Kv[0], 0.f, Kv[2], 0.f, Kv[1], Kv[3], 0.f, 0.f, 1.f};
+    float Kvinv[9];
+    orc_inverse3x3(Kvm, Kvinv);
+
+    /* :119  H_z0_inv_px = K_ * H_z0_inv * Kinv_  (left to right) */
+    float M1[9], M[9];
+    mul3x3_eigen(Km, Hinv, M1);
+    mul3x3_eigen(M1, Kvinv, M);
+    /* :120  H_z0_px = H_z0_inv_px.inverse() */
+    orc_inverse3x3(M, H);
+}
+
+/* ---- per-event z0 warp: mapper_emvs_stereo.cpp:129-142 ------------------ */
+void orc_warp_z0(const uint16_t *ex, const uint16_t *ey, size_t n_events, const float *H,
+                 const float *lut, int W, float *xy_z0)
+{
+    for (size_t i = 0; i < n_events; ++i) {
+        const float *h = H + 9 * (i / ORC_PACKET_SIZE);
+        float u, v;
+        if (lut) {
+            const size_t c = (size_t)ey[i] * (size_t)W + ex[i]; /* :134 */
+            u = lut[2 * c];
+            v = lut[2 * c + 1];
+        } else {
+            u = (float)ex[i];
+            v = (float)ey[i];
+        }
+        /* 4x4 * (u,v,1,0): packet product ((c0*u + c1*v) + c2*1) + c3*0, :138 */
+        const float px = ((h[0] * u + h[1] * v) + h[2] * 1.f) + 0.f * 0.f;
+        const float py = ((h[3] * u + h[4] * v) + h[5] * 1.f) + 0.f * 0.f;
+        const float pz = ((h[6] * u + h[7] * v) + h[8] * 1.f) + 0.f * 0.f;
+        xy_z0[2 * i] = px / pz; /* :139  p /= p[2] (true division, Eigen >= 3.3) */
+        xy_z0[2 * i + 1] = py / pz;
+    }
+}
+
+/* ---- bilinear vote: cartesian3dgrid.h:253-273 --------------------------- */
+void orc_vote(float x_f, float y_f, float *grid, int nx, int ny)
+{
+    if (x_f >= 0.f && y_f >= 0.f) {
+        /* :257 `const int x = x_f` is UB beyond INT range; x86 cvttss2si yields
+         * INT_MIN there and the unsigned compare at :258 then rejects.  With
+         * x_f >= 0, x+1 < size_[0]  <=>  x_f < size_[0]-1, tested in float so
+         * that huge/inf coordinates are rejected the same way. */
+        if (x_f < (float)(nx - 1) && y_f < (float)(ny - 1)) {
+            const int x = (int)x_f, y = (int)y_f;
+            float *g = grid + x + (size_t)y * nx;
+            const float fx = x_f - x, fy = y_f - y, fx1 = 1.f - fx, fy1 = 1.f - fy;
+            g[0] += fx1 * fy1;
+            g[1] += fx * fy1;
+            g[nx] += fx1 * fy;
+            g[nx + 1] += fx * fy;
+        }
+    }
+}
+
+/* ---- fillVoxelGrid: mapper_emvs_stereo.cpp:151-205 ---------------------- */
+void orc_fill_voxel_grid(const float *xy_z0, const float *centers, size_t n_packets,
+                         const float *raw_depths, int nz, const float *Kv, int nx, int ny,
+                         float *dsi)
+{
+    enum { N = 128 }; /* :159 */
+    const float z0 = raw_depths[0]; /* :163 */
+    const float vfx = Kv[0], vfy = Kv[1], vcx = Kv[2], vcy = Kv[3];
+    const size_t n_events = n_packets * ORC_PACKET_SIZE;
+
+#pragma omp parallel for if (n_events >= 20000) /* :168 */
+    for (int depth_plane = 0; depth_plane < nz; ++depth_plane) {
+        const float *pe = xy_z0;
+        float *pgrid = dsi + (size_t)depth_plane * nx * ny; /* :172 */
+        for (size_t packet = 0; packet < n_packets; ++packet) {
+            const float *C = centers + 3 * packet;
+            /* :177-182 */
+            const float zi = raw_depths[depth_plane];
+            const float a = z0 * (zi - C[2]);
+            const float bx = (z0 - zi) * (C[0] * vfx + C[2] * vcx);
+            const float by = (z0 - zi) * (C[1] * vfy + C[2] * vcy);
+            const float d = zi * (z0 - C[2]);
+            for (int batch = 0; batch < ORC_PACKET_SIZE / N; ++batch, pe += 2 * N) {
+                float X[N], Y[N];
+                for (int i = 0; i < N; ++i) { /* :194-195, element-wise *, +, / */
+                    X[i] = (pe[2 * i] * a + bx) / d;
+                    Y[i] = (pe[2 * i + 1] * a + by) / d;
+                }
+                for (int i = 0; i < N; ++i) /* :197-201 */
+                    orc_vote(X[i], Y[i], pgrid, nx, ny);
+            }
+        }
+    }
+}
+
+/* ---- packetisation: mapper_emvs_stereo.cpp:67-99 ------------------------ */
+long orc_packetize(size_t n_events, const uint8_t *pose_ok, size_t *first_event,
+                   size_t *mid_event)
+{
+    if (n_events < ORC_PACKET_SIZE) /* :71-75 */
+        return -1;
+    long np = 0;
+    size_t cur = 0;
+    while (cur + ORC_PACKET_SIZE < n_events) { /* :88 strict < */
+        const size_t mid = cur + ORC_PACKET_SIZE / 2; /* :91 */
+        if (pose_ok && !pose_ok[mid]) { /* :95-99 */
+            cur++;
+            continue;
+        }
+        first_event[np] = cur;
+        mid_event[np] = mid;
+        np++;
+        cur += ORC_PACKET_SIZE; /* :131 current_event_++ x1024 */
+    }
+    return np;
+}
+
+/* ---- fusion: cartesian3dgrid.h:64-192 ----------------------------------- */
+int orc_fuse2(float *a, const float *g, size_t n, int op)
+{
+    switch (op) {
+    case 1: /* minTwoGrids :111-117, std::min(a,b) = (b<a)?b:a */
+        for (size_t p = 0; p < n; ++p)
+            a[p] = (g[p] < a[p]) ? g[p] : a[p];
+        return 0;
+    case 2: { /* harmonicMeanTwoGrids :119-127, eps = 1e-1 */
+        const float eps = 1e-1;
+        for (size_t p = 0; p < n; ++p) {
+            const float prod = a[p] * g[p];
+            const float sum = a[p] + g[p];
+            a[p] = 2 * prod / (sum + eps);
+        }
+        return 0;
+    }
+    case 3: /* geometricMeanTwoGrids :150-156 */
+        for (size_t p = 0; p < n; ++p)
+            a[p] = sqrtf(a[p] * g[p]);
+        return 0;
+    case 4: /* arithmeticMeanTwoGrids :158-164: 0.5 is a double literal */
+        for (size_t p = 0; p < n; ++p)
+            a[p] = (float)(0.5 * (double)(a[p] + g[p]));
+        return 0;
+    case 5: /* rmsTwoGrids :141-148: pow(float,int) and 0.5 in double, sqrt of float ms */
+        for (size_t p = 0; p < n; ++p) {
+            const float ms = (float)(0.5 * (pow((double)a[p], 2) + pow((double)g[p], 2)));
+            a[p] = (float)sqrt((double)ms);
+        }
+        return 0;
+    case 6: /* maxTwoGrids :184-190, std::max(a,b) = (a<b)?b:a */
+        for (size_t p = 0; p < n; ++p)
+            a[p] = (a[p] < g[p]) ? g[p] : a[p];
+        return 0;
+    default:
+        return -1; /* process1.cpp:155-157 "Improper fusion method selected" */
+    }
+}
+
+void orc_fuse_hm_n(float *a, const float *g, size_t n, int n_maps)
+{
+    /* cartesian3dgrid.h:130-139 */
+    const float eps = 1e-1;
+    for (size_t p = 0; p < n; ++p) {
+        const float av = a[p] / (float)(n_maps - 1);
+        const float prod = av * g[p];
+        const float sum = av + g[p];
+        a[p] = n_maps * prod / (sum + eps);
+    }
+}
+
+void orc_accumulate(float *acc, const float *g, size_t n, int mode)
+{
+    if (mode == 0) { /* addTwoGrids :64-70 */
+        for (size_t p = 0; p < n; ++p)
+            acc[p] += g[p];
+    } else { /* addInverseOfTwoGrids :72-78, eps = 1e-2 */
+        const float eps = 1e-2;
+        for (size_t p = 0; p < n; ++p)
+            acc[p] = acc[p] + 1.0f / (eps + g[p]);
+    }
+}
+
+void orc_finalize(float *acc, size_t n, int mode, int n_maps)
+{
+    if (mode == 0) { /* computeAMfromSum :87-93 */
+        for (size_t p = 0; p < n; ++p)
+            acc[p] = acc[p] / (float)n_maps;
+    } else { /* computeHMfromSumOfInv :80-86 */
+        for (size_t p = 0; p < n; ++p)
+            acc[p] = (float)n_maps / acc[p];
+    }
+}
+
+/* ---- arg-max over Z: cartesian3dgrid.cpp:115-137 ------------------------ */
+void orc_collapse_max_z(const float *dsi, int nx, int ny, int nz, float *conf, uint8_t *idx)
+{
+    const size_t plane = (size_t)nx * ny;
+    for (int v = 0; v < ny; ++v) {
+        for (int u = 0; u < nx; ++u) {
+            const float *col = dsi + (size_t)v * nx + u;
+            /* std::max_element: keeps the first of equal maxima; uses operator< */
+            float best = col[0];
+            int best_k = 0;
+            for (int k = 1; k < nz; ++k) {
+                const float val = col[(size_t)k * plane];
+                if (best < val) {
+                    best = val;
+                    best_k = k;
+                }
+            }
+            conf[(size_t)v * nx + u] = best;
+            idx[(size_t)v * nx + u] = (uint8_t)best_k; /* CV_8U, :120 */
+        }
+    }
+}
+
+void orc_indices_to_depth(const uint8_t *idx, size_t n, const float *raw_depths, float *depth)
+{
+    for (size_t i = 0; i < n; ++i) /* mapper_emvs_stereo.cpp:302-313 */
+        depth[i] = raw_depths[idx[i]];
+}
+
+double orc_mean_square(const float *dsi, size_t n)
+{
+    double result = 0.; /* cartesian3dgrid.cpp:164-174 */
+    for (size_t i = 0; i < n; ++i) {
+        const double tmp = (double)dsi[i];
+        result += tmp * tmp;
+    }
+    return result / (double)n;
+}
+
+/* ---- SE(3) helpers with minkindr / Eigen semantics (double) ------------- */
+typedef struct {
+    double t[3];
+    double q[4]; /* w,x,y,z */
+} pose_t;
+
+static pose_t pose_load(const double *p)
+{
+    pose_t r;
+    memcpy(r.t, p, 3 * sizeof(double));
+    memcpy(r.q, p + 3, 4 * sizeof(double));
+    return r;
+}
+
+static void pose_store(const pose_t *p, double *out)
+{
+    memcpy(out, p->t, 3 * sizeof(double));
+    memcpy(out + 3, p->q, 4 * sizeof(double));
+}
+
+static void quat_mul(const double *a, const double *b, double *o)
+{
+    /* Eigen quat_product<.,.,double> */
+    o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    o[2] = a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3];
+    o[3] = a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1];
+}
+
+static void quat_rotate(const double *q, const double *v, double *o)
+{
+    /* Eigen QuaternionBase::_transformVector: uv = 2*cross(qv,v); v + w*uv + cross(qv,uv) */
+    const double qv[3] = {q[1], q[2], q[3]};
+    double uv[3] = {qv[1] * v[2] - qv[2] * v[1], qv[2] * v[0] - qv[0] * v[2],
+                    qv[0] * v[1] - qv[1] * v[0]};
+    uv[0] += uv[0];
+    uv[1] += uv[1];
+    uv[2] += uv[2];
+    const double c[3] = {qv[1] * uv[2] - qv[2] * uv[1], qv[2] * uv[0] - qv[0] * uv[2],
+                         qv[0] * uv[1] - qv[1] * uv[0]};
+    for (int i = 0; i < 3; ++i)
+        o[i] = v[i] + q[0] * uv[i] + c[i];
+}
+
+static pose_t pose_mul(const pose_t *a, const pose_t *b)
+{
+    /* minkindr QuatTransformation::operator*: q = qa*qb ; t = ta + qa.rotate(tb) */
+    pose_t r;
+    double rt[3];
+    quat_mul(a->q, b->q, r.q);
+    quat_rotate(a->q, b->t, rt);
+    for (int i = 0; i < 3; ++i)
+        r.t[i] = a->t[i] + rt[i];
+    return r;
+}
+
+static pose_t pose_inv(const pose_t *a)
+{
+    /* minkindr inverse(): q^-1 (conjugate of a unit quaternion), t = -(q^-1).rotate(t) */
+    pose_t r;
+    double rt[3];
+    r.q[0] = a->q[0];
+    r.q[1] = -a->q[1];
+    r.q[2] = -a->q[2];
+    r.q[3] = -a->q[3];
+    quat_rotate(r.q, a->t, rt);
+    for (int i = 0; i < 3; ++i)
+        r.t[i] = -rt[i];
+    return r;
+}
+
+static double arcsin_x_over_x(double x)
+{
+    /* minkindr arcSinXOverX */
+    if (fabs(x) < 1.220703125e-4 /* ~ eps^(1/4) */)
+        return 1.0 + x * x * (1.0 / 6.0);
+    return asin(x) / x;
+}
+
+static void quat_log(const double *q, double *o)
+{
+    /* minkindr RotationQuaternion::log */
+    const double na = sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const double eta = q[0];
+    double scale;
+    if (fabs(eta) < na) {
+        scale = (eta >= 0) ? acos(eta) / na : -acos(-eta) / na;
+    } else {
+        scale = (eta > 0) ? arcsin_x_over_x(na) : -arcsin_x_over_x(na);
+    }
+    for (int i = 0; i < 3; ++i)
+        o[i] = q[1 + i] * (2.0 * scale);
+}
+
+static void quat_exp(const double *dx, double *q)
+{
+    /* minkindr RotationQuaternion::exp (Grassia 1998) */
+    const double theta = sqrt(dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2]);
+    double na;
+    if (theta < 1.220703125e-4)
+        na = 0.5 + (theta * theta) * (1.0 / 48.0);
+    else
+        na = sin(theta * 0.5) / theta;
+    q[0] = cos(theta * 0.5);
+    q[1] = dx[0] * na;
+    q[2] = dx[1] * na;
+    q[3] = dx[2] * na;
+}
+
+int orc_pose_at(const double *times, const double *poses, size_t n_poses, double t, double *out)
+{
+    /* trajectory.hpp:98-113: it1 = upper_bound(t) */
+    size_t i1 = 0;
+    while (i1 < n_poses && !(t < times[i1]))
+        ++i1;
+    if (i1 == 0 || i1 == n_poses)
+        return 0;
+    const size_t i0 = i1 - 1;
+    const pose_t T0 = pose_load(poses + 7 * i0), T1 = pose_load(poses + 7 * i1);
+    /* :123-125 */
+    const pose_t T0inv = pose_inv(&T0);
+    const pose_t Trel = pose_mul(&T0inv, &T1);
+    const double delta_t = (t - times[i0]) / (times[i1] - times[i0]);
+    /* minkindr log(): [translation ; rotation log]; exp(): same split */
+    double rl[3];
+    quat_log(Trel.q, rl);
+    pose_t inc;
+    for (int i = 0; i < 3; ++i) {
+        inc.t[i] = delta_t * Trel.t[i];
+        rl[i] = delta_t * rl[i];
+    }
+    quat_exp(rl, inc.q);
+    const pose_t T = pose_mul(&T0, &inc);
+    pose_store(&T, out);
+    return 1;
+}
+
+void orc_event_pose_Rt(const double *T_rv_w, const double *T_w_ev, float *Rt)
+{
+    /* mapper_emvs_stereo.cpp:101-105 */
+    const pose_t a = pose_load(T_rv_w), b = pose_load(T_w_ev);
+    const pose_t T_rv_ev = pose_mul(&a, &b);
+    const pose_t T = pose_inv(&T_rv_ev);
+    /* Eigen Quaternion::toRotationMatrix */
+    const double w = T.q[0], x = T.q[1], y = T.q[2], z = T.q[3];
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w;
+    const double txx = tx * x, txy = ty * x, txz = tz * x;
+    const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    Rt[0] = (float)(1 - (tyy + tzz));
+    Rt[1] = (float)(txy - twz);
+    Rt[2] = (float)(txz + twy);
+    Rt[3] = (float)(txy + twz);
+    Rt[4] = (float)(1 - (txx + tzz));
+    Rt[5] = (float)(tyz - twx);
+    Rt[6] = (float)(txz - twy);
+    Rt[7] = (float)(tyz + twx);
+    Rt[8] = (float)(1 - (txx + tyy));
+    Rt[9] = (float)T.t[0];
+    Rt[10] = (float)T.t[1];
+    Rt[11] = (float)T.t[2];
+}

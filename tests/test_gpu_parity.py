@@ -1,0 +1,350 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Run on a real MI355X with `pytest -m gpu`.
+
+Stated tolerances
+  * coordinates are computed with the reference's operations in the reference's order
+    (no FMA), so the ONLY difference between GPU and oracle DSIs is the order in which
+    votes are summed into a voxel:  |gpu - cpu| <= 1e-4 * max(1, |cpu|)  for EVERY voxel
+    (observed ~1e-6).
+  * fusion ops, arg-max, index->depth: bit-exact on identical inputs.
+  * mean square (double accumulation, different order): rel 1e-12.
+"""
+import numpy as np
+import pytest
+
+import dvs_mcemvs_amd as d
+from dvs_mcemvs_amd import synthetic as syn
+from oracle import oracle as orc
+from oracle_pipeline import OracleMapper
+
+pytestmark = pytest.mark.gpu
+
+DSI_TOL = 1e-4
+
+
+def assert_dsi_close(got, ref, tol=DSI_TOL):
+    err = np.abs(got.astype(np.float64) - ref) / np.maximum(1.0, np.abs(ref))
+    assert err.max() <= tol, "max rel err %g at %s (gpu %g cpu %g)" % (
+        err.max(), np.unravel_index(err.argmax(), err.shape), got.flat[err.argmax()],
+        ref.flat[err.argmax()])
+
+
+def random_packets(rng, n_packets, nx, ny, spread=0.3, cz_spread=0.5):
+    """z0 locations + camera centres as fillVoxelGrid receives them."""
+    xy = np.empty((n_packets * 1024, 2), np.float32)
+    xy[:, 0] = rng.uniform(-0.1 * nx, 1.1 * nx, xy.shape[0])
+    xy[:, 1] = rng.uniform(-0.1 * ny, 1.1 * ny, xy.shape[0])
+    centers = rng.normal(0, spread, (n_packets, 3)).astype(np.float32)
+    centers[:, 2] = rng.normal(0, cz_spread, n_packets)
+    return xy, centers
+
+
+def make_mapper(ctx, cam, nz, dmin, dmax, algo, dimX=0, dimY=0, fov=0.0, lut=None, inverse=False,
+                band=None):
+    m = d.MapperEMVS(ctx, cam, d.ShapeDSI(dimX, dimY, nz, dmin, dmax, fov), lut=lut,
+                     inverse_depth=inverse)
+    m.set_vote_algo(algo)
+    if band:
+        m.set_band_params(*band)
+    return m
+
+
+ALGOS = [d.VOTE_GLOBAL_ATOMIC, d.VOTE_LDS_BANDS]
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("shape", [(64, 48, 16), (96, 72, 32), (346, 260, 20), (130, 97, 7)])
+def test_fill_voxel_grid_matches_oracle(ctx, algo, shape):
+    nx, ny, nz = shape
+    rng = np.random.default_rng(100 + nx)
+    cam = (nx, ny, 0.8 * nx, 0.8 * nx, 0.5 * nx, 0.5 * ny)
+    m = make_mapper(ctx, cam, nz, 1.0, 6.5, algo)
+    xy, centers = random_packets(rng, 9, nx, ny)
+    ref = orc.fill_voxel_grid(xy, centers, m.raw_depths_vec_, np.array(m.virtual_cam_, np.float32),
+                              nx, ny)
+    m.dsi_.resetGrid()
+    m.fillVoxelGrid(xy, centers)
+    assert_dsi_close(m.dsi_.download(), ref)
+    # fillVoxelGrid accumulates (the reset belongs to evaluateDSI): voting twice doubles
+    m.fillVoxelGrid(xy, centers)
+    assert_dsi_close(m.dsi_.download(), 2 * ref, tol=2 * DSI_TOL)
+    m.close()
+
+
+@pytest.mark.parametrize("band", [(5, 1, 256), (7, 3, 512), (16, 8, 1024), (48, 2, 256)])
+def test_lds_band_decompositions_agree(ctx, band):
+    """Every band height / chunk count / block size gives the same DSI (ragged last band,
+    bands of different sizes, more chunks than packets)."""
+    nx, ny, nz = 70, 48, 9
+    rng = np.random.default_rng(5)
+    cam = (nx, ny, 60.0, 60.0, 35.0, 24.0)
+    xy, centers = random_packets(rng, 5, nx, ny)
+    m = make_mapper(ctx, cam, nz, 0.5, 4.0, d.VOTE_LDS_BANDS, band=band)
+    ref = orc.fill_voxel_grid(xy, centers, m.raw_depths_vec_, np.array(m.virtual_cam_, np.float32),
+                              nx, ny)
+    m.fillVoxelGrid(xy, centers)
+    info = m.last_vote_info()
+    assert info["algo"] == d.VOTE_LDS_BANDS and info["band_rows"] == band[0]
+    assert_dsi_close(m.dsi_.download(), ref)
+    m.close()
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_vote_edge_cases(ctx, algo):
+    """Border drop (x+1 < Nx), negative / NaN / inf coordinates, camera centre at or beyond a
+    plane (d = 0, negative alpha), all rejected or accepted exactly like the oracle."""
+    nx, ny, nz = 40, 30, 6
+    cam = (nx, ny, 30.0, 30.0, 20.0, 15.0)
+    m = make_mapper(ctx, cam, nz, 1.0, 4.0, algo, band=(9, 2, 256))
+    planes = m.raw_depths_vec_
+    rng = np.random.default_rng(11)
+    xy, centers = random_packets(rng, 6, nx, ny)
+    special = np.array([[0.0, 0.0], [nx - 1.0, 3.0], [nx - 1.0001, 3.0], [3.0, ny - 1.0],
+                        [-0.0, 5.0], [-1e-7, 5.0], [np.nan, 1.0], [1.0, np.nan], [np.inf, 2.0],
+                        [2.0, -np.inf], [1e30, 1.0], [nx - 2.0, ny - 2.0], [3.4e38, 3.4e38]],
+                       np.float32)
+    for k in range(6):
+        xy[k * 1024:k * 1024 + special.shape[0]] = special
+    centers[0] = (0, 0, 0)                       # identity pose: every plane gets the z0 vote
+    centers[1] = (0.2, -0.1, planes[2])          # zi - Cz = 0 on plane 2 -> a = 0
+    centers[2] = (0.1, 0.1, planes[0])           # z0 - Cz = 0 -> d = 0 on every plane
+    centers[3] = (0.0, 0.0, planes[3] + 0.01)    # camera between planes: negative alpha on some
+    centers[4] = (5.0, -7.0, 100.0)              # far behind everything
+    centers[5] = (np.nan, 0.0, 0.0)
+    ref = orc.fill_voxel_grid(xy, centers, planes, np.array(m.virtual_cam_, np.float32), nx, ny)
+    m.fillVoxelGrid(xy, centers)
+    assert_dsi_close(m.dsi_.download(), ref)
+    m.close()
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+def test_identity_pose_known_answer(ctx, algo):
+    """Identity pose => X_i = x0, Y_i = y0 on every plane (SURVEY 8c KAT)."""
+    nx, ny, nz = 32, 24, 5
+    m = make_mapper(ctx, (nx, ny, 25.0, 25.0, 16.0, 12.0), nz, 1.0, 3.0, algo)
+    xy = np.zeros((1024, 2), np.float32)
+    xy[:] = (2.25, 3.5)
+    m.fillVoxelGrid(xy, np.zeros((1, 3), np.float32))
+    got = m.dsi_.download()
+    for z in range(nz):
+        assert got[z, 3, 2] == pytest.approx(1024 * 0.375, rel=1e-6)
+        assert got[z, 3, 3] == pytest.approx(1024 * 0.125, rel=1e-6)
+        assert got[z, 4, 2] == pytest.approx(1024 * 0.375, rel=1e-6)
+        assert got[z, 4, 3] == pytest.approx(1024 * 0.125, rel=1e-6)
+        assert got[z].sum() == pytest.approx(1024.0, rel=1e-6)
+    m.close()
+
+
+@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("variant", ["plain", "lut", "inverse_depth", "fov_dims"])
+def test_evaluate_dsi_matches_oracle(ctx, algo, variant):
+    """Full evaluateDSI (host packetisation + pose interpolation, device stage A + B)."""
+    rig = syn.stereo_rig(30000, width=96, height=72, duration=0.3, seed=21)
+    cam = rig["cam"]
+    kw = dict(dimZ=24, min_depth=4.0, max_depth=200.0)
+    lut, inverse, dimX, dimY, fov = None, False, 0, 0, 0.0
+    if variant == "lut":
+        lut = syn.radial_lut(cam)
+    elif variant == "inverse_depth":
+        inverse = True
+    elif variant == "fov_dims":
+        dimX, dimY, fov = 80, 64, 60.0
+    for c in range(2):
+        m = make_mapper(ctx, cam, 24, 4.0, 200.0, algo, dimX=dimX, dimY=dimY, fov=fov, lut=lut,
+                        inverse=inverse)
+        r = OracleMapper(cam, dimX=dimX, dimY=dimY, fov=fov, lut=lut, inverse_depth=inverse, **kw)
+        assert np.array_equal(m.raw_depths_vec_, r.planes)
+        assert np.array_equal(np.array(m.virtual_cam_, np.float32), r.Kv)
+        assert m.evaluateDSI(rig["events"][c], rig["trajectories"][c], rig["T_rv_w"])
+        assert r.evaluateDSI(rig["events"][c], rig["trajectories"][c], rig["T_rv_w"])
+        assert m.n_voted == r.n_voted
+        assert_dsi_close(m.dsi_.download(), r.dsi)
+        # evaluateDSI resets the grid first (:145): a second call gives the same DSI
+        assert m.evaluateDSI(rig["events"][c], rig["trajectories"][c], rig["T_rv_w"])
+        assert_dsi_close(m.dsi_.download(), r.dsi)
+        m.close()
+
+
+def test_evaluate_dsi_packet_counts(ctx):
+    """mapper_emvs_stereo.cpp:71-75, :88: 1023 -> false, 1024 -> true with 0 packets,
+    1025 -> 1 packet, 2048 -> 1, 2049 -> 2."""
+    rig = syn.stereo_rig(4096, width=64, height=48, duration=0.2, seed=3)
+    m = make_mapper(ctx, rig["cam"], 8, 4.0, 100.0, d.VOTE_AUTO)
+    x, y, ts = rig["events"][0]
+    for n, expect in [(1023, None), (1024, 0), (1025, 1), (2048, 1), (2049, 2)]:
+        ok = m.evaluateDSI((x[:n], y[:n], ts[:n]), rig["trajectories"][0], rig["T_rv_w"])
+        if expect is None:
+            assert ok is False
+        else:
+            assert ok is True and m.n_voted == expect * 1024
+            if expect == 0:
+                assert not m.dsi_.download().any()
+    m.close()
+
+
+def test_pose_lookup_failure_shifts_packets(ctx):
+    """mapper_emvs_stereo.cpp:95-99: a failed pose lookup slides the packet start by one event."""
+    rig = syn.stereo_rig(6000, width=64, height=48, duration=0.2, seed=4)
+    x, y, ts = rig["events"][0]
+    times, poses = rig["trajectories"][0]
+    late = ts[700]  # trajectory starts after the mid-timestamp of the first candidates
+    keep = times > late
+    traj = (times[keep], poses[keep])
+    m = make_mapper(ctx, rig["cam"], 8, 4.0, 100.0, d.VOTE_AUTO)
+    r = OracleMapper(rig["cam"], dimZ=8, min_depth=4.0, max_depth=100.0)
+    assert m.evaluateDSI((x, y, ts), traj, rig["T_rv_w"])
+    assert r.evaluateDSI((x, y, ts), traj, rig["T_rv_w"])
+    assert m.n_voted == r.n_voted and m.n_voted > 0
+    first, _ = r.packetize(ts, traj, rig["T_rv_w"])
+    assert first[0] % 1024 != 0  # genuinely misaligned
+    assert_dsi_close(m.dsi_.download(), r.dsi)
+    m.close()
+
+
+@pytest.mark.parametrize("n", [1, 5, 4096 + 3, 64 * 48 * 16])
+def test_fusion_ops_bit_exact(ctx, n):
+    rng = np.random.default_rng(n)
+    nx, ny, nz = (n, 1, 1) if n < 4096 + 4 else (64, 48, 16)
+    a = rng.gamma(2.0, 8.0, (nz, ny, nx)).astype(np.float32)
+    g = rng.gamma(2.0, 8.0, (nz, ny, nx)).astype(np.float32)
+    a.flat[::7] = 0.0  # empty voxels are the common case
+    g.flat[::5] = 0.0
+    A, G = d.Grid3D(ctx, nx, ny, nz), d.Grid3D(ctx, nx, ny, nz)
+    G.upload(g)
+    for op in range(1, 7):
+        A.upload(a)
+        A.fuseTwoGrids(G, op)
+        assert np.array_equal(A.download(), orc.fuse2(a, g, op)), "op %d" % op
+    for nmaps in (3, 4):
+        A.upload(a)
+        A.harmonicMeanTwoGrids(G, nmaps)
+        assert np.array_equal(A.download(), orc.fuse_hm_n(a, g, nmaps))
+    for mode, fin in ((d.ACC_SUM, A.computeAMfromSum), (d.ACC_INV_SUM, A.computeHMfromSumOfInv)):
+        A.upload(a)
+        ref = a
+        for _ in range(3):
+            (A.addTwoGrids if mode == d.ACC_SUM else A.addInverseOfTwoGrids)(G)
+            ref = orc.accumulate(ref, g, mode)
+        assert np.array_equal(A.download(), ref)
+        fin(4)
+        assert np.array_equal(A.download(), orc.finalize(ref, mode, 4))
+    A.close()
+    G.close()
+
+
+def test_fusion_errors(ctx):
+    A, B = d.Grid3D(ctx, 8, 8, 4), d.Grid3D(ctx, 8, 8, 5)
+    with pytest.raises(d.DsiError) as e:
+        A.addTwoGrids(B)
+    assert e.value.code == 4  # DSI_ERR_SHAPE (reference: std::out_of_range)
+    C_ = d.Grid3D(ctx, 8, 8, 4)
+    for bad in (0, 7, -1):
+        with pytest.raises(d.DsiError) as e:
+            A.fuseTwoGrids(C_, bad)
+        assert e.value.code == 5  # "Improper fusion method selected"
+
+
+@pytest.mark.parametrize("shape", [(33, 17, 1), (64, 48, 16), (50, 40, 100), (31, 9, 256)])
+def test_collapse_max_z_exact(ctx, shape):
+    nx, ny, nz = shape
+    rng = np.random.default_rng(nz)
+    v = rng.integers(0, 6, (nz, ny, nx)).astype(np.float32)  # many ties: first max must win
+    v[:, 0, 0] = 0.0                                         # empty column -> conf 0, index 0
+    if nz > 2:
+        v[:, 1, 1] = 3.0                                     # all equal -> index 0
+        v[nz - 1, 2, 2] = 99.0                               # max on the last plane
+    G = d.Grid3D(ctx, nx, ny, nz)
+    G.upload(v)
+    conf, idx = G.collapseMaxZSlice()
+    rconf, ridx = orc.collapse_max_z(v)
+    assert np.array_equal(conf, rconf) and np.array_equal(idx, ridx)
+    assert idx[0, 0] == 0 and conf[0, 0] == 0
+    ms = G.computeMeanSquare()
+    assert ms == pytest.approx(orc.mean_square(v), rel=1e-12)
+    G.close()
+
+
+def test_depth_map_of_fused_grid(ctx):
+    rig = syn.stereo_rig(20000, width=80, height=60, duration=0.2, seed=9)
+    ms = [make_mapper(ctx, rig["cam"], 20, 4.0, 200.0, d.VOTE_AUTO) for _ in range(2)]
+    for c in range(2):
+        assert ms[c].evaluateDSI(rig["events"][c], rig["trajectories"][c], rig["T_rv_w"])
+    fused = d.Grid3D(ctx, *ms[0].dsi_.getDimensions())
+    fused.addTwoGrids(ms[0].dsi_)
+    fused.harmonicMeanTwoGrids(ms[1].dsi_)
+    vol = fused.download()
+    depth, conf, idx = ms[0].getDepthMapFromDSI(fused)
+    rconf, ridx = orc.collapse_max_z(vol)
+    assert np.array_equal(idx, ridx) and np.array_equal(conf, rconf)
+    assert np.array_equal(depth, orc.indices_to_depth(ridx, ms[0].raw_depths_vec_))
+    assert np.abs(depth - orc.indices_to_depth(ridx, ms[0].raw_depths_vec_)).max() <= 1e-4
+
+
+def test_residual_corrected_division_is_ieee(ctx):
+    """The banded kernel's 5-op division must equal the IEEE divide bit for bit wherever it
+    is used (2^-40 <= |d| <= 2^40), otherwise its coordinates would not be the oracle's."""
+    import ctypes as C
+    rng = np.random.default_rng(77)
+    n = 1 << 22
+    num = (rng.uniform(-1, 1, n) * np.exp2(rng.uniform(-30, 30, n))).astype(np.float32)
+    den = (rng.choice([-1.0, 1.0], n) * rng.uniform(1, 2, n) * np.exp2(rng.integers(-40, 40, n))).astype(np.float32)
+    num[:8] = [0.0, -0.0, 1.0, 3.0, 1e-38, 16777215.0, 0.1, 346.0]
+    q = np.empty(n, np.float32)
+    ref = np.empty(n, np.float32)
+    L = d.load_library()
+    rc = L.dsi_test_div_probe(ctx._h, num.ctypes.data_as(C.POINTER(C.c_float)),
+                              den.ctypes.data_as(C.POINTER(C.c_float)), n,
+                              q.ctypes.data_as(C.POINTER(C.c_float)),
+                              ref.ctypes.data_as(C.POINTER(C.c_float)))
+    assert rc == 0
+    assert np.array_equal(ref, num / den)          # the GPU's '/' is IEEE
+    same = (q == ref) | ((q == 0) & (ref == 0))    # sign of zero may differ; votes identical
+    assert same.all(), "%d mismatches" % (~same).sum()
+
+
+def test_full_size_properties(ctx):
+    """346x260x100 at 1M events/camera: size-independent checks (the oracle is too slow to be
+    the checker at BASELINE sizes beyond this)."""
+    rig = syn.stereo_rig(1_000_000, seed=1234)
+    cam = rig["cam"]
+    tot = []
+    vols = []
+    for algo in ALGOS:
+        m = make_mapper(ctx, cam, 100, 4.0, 200.0, algo)
+        assert m.evaluateDSI(rig["events"][0], rig["trajectories"][0], rig["T_rv_w"])
+        v = m.dsi_.download()
+        vols.append(v)
+        assert (v >= 0).all()
+        # each accepted vote adds exactly 1 to its plane: plane sums are integers <= events voted
+        sums = v.reshape(100, -1).sum(axis=1, dtype=np.float64)
+        assert (sums <= m.n_voted + 1).all()
+        assert np.abs(sums - np.rint(sums)).max() < 0.5
+        tot.append(sums)
+        assert m.dsi_.computeMeanSquare() == pytest.approx(float((v.astype(np.float64) ** 2).mean()), rel=1e-10)
+        m.close()
+    # the two kernels agree voxel for voxel
+    assert_dsi_close(vols[1], vols[0].astype(np.float64))
+    assert np.abs(tot[0] - tot[1]).max() < 0.5
+    # linearity: DSI(first half) + DSI(second half) == DSI(all) when the halves are packet aligned
+    x, y, ts = rig["events"][0]
+    h = 488 * 1024 + 1  # 488 packets + the dropped tail event
+    m = make_mapper(ctx, cam, 100, 4.0, 200.0, d.VOTE_LDS_BANDS)
+    assert m.evaluateDSI((x[:h], y[:h], ts[:h]), rig["trajectories"][0], rig["T_rv_w"])
+    va = m.dsi_.download()
+    x2, y2, t2 = x[h - 1:], y[h - 1:], ts[h - 1:]
+    assert m.evaluateDSI((x2, y2, t2), rig["trajectories"][0], rig["T_rv_w"])
+    vb = m.dsi_.download()
+    assert_dsi_close(va + vb, vols[1].astype(np.float64), tol=2e-4)
+    m.close()
+    # oracle on the full-size case (8 host threads: a few seconds)
+    r = OracleMapper(cam, dimZ=100, min_depth=4.0, max_depth=200.0)
+    assert r.evaluateDSI(rig["events"][0], rig["trajectories"][0], rig["T_rv_w"])
+    assert_dsi_close(vols[1], r.dsi)
+    d1, c1, i1 = r.depth_map()
+    conf, idx = orc.collapse_max_z(vols[1])
+    # arg-max index equal wherever the CPU top-2 gap exceeds the DSI tolerance
+    srt = np.sort(r.dsi, axis=0)
+    gap = srt[-1] - srt[-2]
+    safe = gap > 2 * DSI_TOL * np.maximum(1.0, srt[-1])
+    assert np.array_equal(idx[safe], i1[safe])
+    assert (np.abs(orc.indices_to_depth(idx, r.planes) - d1)[safe] <= 1e-4).all()
