@@ -164,7 +164,7 @@ float virtual_focal(float cam_fx, float fov_deg, int dim_x)
 bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
 {
     const dsi::Geom& g = m->geom;
-    const size_t row_bytes = (size_t)g.nx * sizeof(float);
+    const size_t row_bytes = (size_t)g.nx * sizeof(unsigned long long);  // Q33.31 LDS accumulators
     const long max_rows_total = (long)(dsi::max_dynamic_lds() / row_bytes);
     if (max_rows_total < 3 || g.nx < 2 || g.ny < 2) return false;
     long max_owned = max_rows_total - 2;

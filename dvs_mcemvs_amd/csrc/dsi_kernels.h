@@ -34,7 +34,7 @@ struct BandPlan {
     int band_rows;      // owned rows per band (last band may own fewer)
     int chunks;         // packet chunks; each writes its own partial DSI when > 1
     int block_threads;  // 256 / 512 / 1024
-    size_t lds_bytes;   // (band_rows + 2) * nx * 4
+    size_t lds_bytes;   // (band_rows + 2) * nx * 8 (u64 fixed-point accumulators)
 };
 
 // ---- stage A ---------------------------------------------------------------

@@ -335,11 +335,31 @@ __global__ __launch_bounds__(256) void k_plane_coef(const float* __restrict__ ce
 // (3) the voting kernel.  Work item = (packet chunk c, band j, plane z): the band's
 //     rows [r0-1, r1] of plane z live in LDS (two halo rows, so a bilinear vote never
 //     needs a row test), every wave walks packets of the chunk with the packet's
-//     coefficients in SGPRs, votes with ds_add_f32, and the owned rows [r0, r1) are
-//     written back with plain coalesced stores -- no global atomics, no memset.
+//     coefficients in SGPRs, and the owned rows [r0, r1) are written back with plain
+//     coalesced stores -- no global atomics, no memset.
+//
+//     LDS accumulators are 64-bit fixed point (Q33.31), voted with ds_add_u64.
+//     Measured on gfx950 (tools/lds_atomic_bench.hip): ds_add_f32 takes ~194 cycles per
+//     wave instruction for distinct addresses (lanes serialised), ds_add_u64 ~12-15.
+//     A weight w = fl(fx*fy) in [0,1] is added as trunc(w * 2^31): exact for
+//     w >= 2^-8, off by < 2^-31 below, so a voxel holds the EXACT sum of its fp32
+//     weights (to 5e-10 per vote), independent of vote order, and is rounded to fp32
+//     once at write-back.  (The CPU reference rounds after every += instead.)
+//
 //     Block b runs on XCD b % 8 (observed dispatch rule): the blocks of one XCD walk
 //     the planes of ONE (chunk, band) pair at a time, so its events stream through
 //     that XCD's L2 once instead of once per plane.
+using acc_t = unsigned long long;
+constexpr float kFixScale = 2147483648.f;      // 2^31
+constexpr double kFixInv = 1.0 / 2147483648.0;  // 2^-31
+
+__device__ __forceinline__ void lds_vote(acc_t* cell, float w_scaled)
+{
+    // w_scaled = w * 2^31 <= 2^31 fits u32; the high dword of the addend is 0
+    const acc_t v = (acc_t)(unsigned int)w_scaled;
+    __hip_atomic_fetch_add(cell, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_vote_bands(const float2* __restrict__ sxy,
                                                       const PlaneCoef* __restrict__ coef,
@@ -347,7 +367,7 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands(const float2* __restrict__
                                                       Geom g, BandPlan bp,
                                                       float* __restrict__ out)
 {
-    extern __shared__ float lds[];
+    extern __shared__ acc_t lds[];
     const int b = blockIdx.x;
     const int xcd = b & 7, s = b >> 3;
     const int q = (s / g.nz) * 8 + xcd;
@@ -359,7 +379,7 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands(const float2* __restrict__
     const int nx = g.nx;
     const int lds_elems = (r1 - r0 + 2) * nx;
 
-    for (int i = threadIdx.x; i < lds_elems; i += BLOCK) lds[i] = 0.f;
+    for (int i = threadIdx.x; i < lds_elems; i += BLOCK) lds[i] = 0;
     __syncthreads();
 
     const int p_begin = (int)(((long long)np * c) / bp.chunks);
@@ -376,34 +396,44 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands(const float2* __restrict__
         if (k.flags & kCoefSkip) continue;
         const uint32_t cu = cuts[pz * bp.bands + j];
         const int lo = (int)(cu & 0xffffu), hi = (int)(cu >> 16);
+        if (lo >= hi) continue;
         const float2* __restrict__ ev = sxy + (size_t)p * kPacket;
         const bool slow = (k.flags & kCoefSlow) != 0;
-        for (int i = lo + lane; i < hi; i += kWave) {
-            const float2 e = ev[i];
-            const float nxv = e.x * k.a + k.bx;  // mapper_emvs_stereo.cpp:194-195
-            const float nyv = e.y * k.a + k.by;
-            float X, Y;
-            if (slow) {
-                X = nxv / k.d;
-                Y = nyv / k.d;
-            } else {
-                X = div_rc(nxv, k.d, k.r);
-                Y = div_rc(nyv, k.d, k.r);
+        int i = lo + lane;
+        float2 e = make_float2(0.f, 0.f);
+        if (i < hi) e = ev[i];
+        for (int base = lo; base < hi; base += kWave) {
+            // prefetch the next 64 events of the run while this batch is voted
+            const int inext = i + kWave;
+            float2 en = e;
+            if (inext < hi) en = ev[inext];
+            if (i < hi) {
+                const float nxv = e.x * k.a + k.bx;  // mapper_emvs_stereo.cpp:194-195
+                const float nyv = e.y * k.a + k.by;
+                float X, Y;
+                if (slow) {
+                    X = nxv / k.d;
+                    Y = nyv / k.d;
+                } else {
+                    X = div_rc(nxv, k.d, k.r);
+                    Y = div_rc(nyv, k.d, k.r);
+                }
+                // cartesian3dgrid.h:255-259 restricted to this band's rows
+                if (X >= 0.f && X < xmax && Y >= L && Y < U) {
+                    const float xf = __builtin_floorf(X), yf = __builtin_floorf(Y);
+                    const float fx = X - xf, fy = Y - yf, fx1 = 1.f - fx, fy1 = 1.f - fy;
+                    // scaling one factor by 2^31 scales the rounded product exactly
+                    const float fxs = fx * kFixScale, fx1s = fx1 * kFixScale;
+                    const int idx = __mul24((int)yf - row_base, nx) + (int)xf;
+                    acc_t* cell = lds + idx;
+                    lds_vote(cell, fx1s * fy1);         // g[0]      += fx1*fy1  (:267)
+                    lds_vote(cell + 1, fxs * fy1);      // g[1]      += fx*fy1
+                    lds_vote(cell + nx, fx1s * fy);     // g[Nx]     += fx1*fy
+                    lds_vote(cell + nx + 1, fxs * fy);  // g[Nx+1]   += fx*fy
+                }
             }
-            // cartesian3dgrid.h:255-259 restricted to this band's rows
-            if (X >= 0.f && X < xmax && Y >= L && Y < U) {
-                const float xf = __builtin_floorf(X), yf = __builtin_floorf(Y);
-                const float fx = X - xf, fy = Y - yf, fx1 = 1.f - fx, fy1 = 1.f - fy;
-                const int idx = ((int)yf - row_base) * nx + (int)xf;
-                __hip_atomic_fetch_add(&lds[idx], fx1 * fy1, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(&lds[idx + 1], fx * fy1, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(&lds[idx + nx], fx1 * fy, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(&lds[idx + nx + 1], fx * fy, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+            e = en;
+            i = inext;
         }
     }
     __syncthreads();
@@ -411,9 +441,10 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands(const float2* __restrict__
     // owned rows are contiguous in the [z][y][x] volume: a linear coalesced copy
     const size_t vol = (size_t)g.nx * g.ny * g.nz;
     float* __restrict__ dst = out + (size_t)c * vol + ((size_t)z * g.ny + r0) * nx;
-    const float* src = lds + nx;  // skip the top halo row
+    const acc_t* src = lds + nx;  // skip the top halo row
     const int n_out = (r1 - r0) * nx;
-    for (int i = threadIdx.x; i < n_out; i += BLOCK) dst[i] = src[i];
+    for (int i = threadIdx.x; i < n_out; i += BLOCK)
+        dst[i] = (float)((double)src[i] * kFixInv);  // < 2^53: exact in f64, one rounding to f32
 }
 
 // (4) DSI = sum of the chunk partials (fixed order => deterministic given partials)

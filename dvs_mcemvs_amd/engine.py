@@ -10,8 +10,11 @@ reference aborts (glog CHECK) or throws std::out_of_range this binding raises
 DsiError carrying the C status code.  numpy arrays cross the boundary as plain
 pointers; nothing here computes on the CPU.
 """
+import atexit
 import ctypes as C
 import os
+import sys
+import weakref
 
 import numpy as np
 
@@ -129,6 +132,42 @@ def load_library():
 EXPORTED_SYMBOLS = None  # filled by tests from include/dsi_engine.h
 
 
+# Device objects must be released while the HIP runtime is still alive: close whatever is
+# still open at interpreter exit (children before contexts), and never touch the runtime
+# from __del__ once the interpreter is finalizing.
+_LIVE = weakref.WeakSet()
+
+
+def _track(obj):
+    _LIVE.add(obj)
+
+
+@atexit.register
+def _close_all():
+    objs = list(_LIVE)
+    for o in objs:
+        if not isinstance(o, Context):
+            try:
+                o.close()
+            except Exception:
+                pass
+    for o in objs:
+        if isinstance(o, Context):
+            try:
+                o.close()
+            except Exception:
+                pass
+
+
+def _safe_del(obj):
+    if sys is None or sys.is_finalizing():
+        return
+    try:
+        obj.close()
+    except Exception:
+        pass
+
+
 def _check(rc):
     if rc != OK:
         msg = load_library().dsi_last_error()
@@ -153,6 +192,7 @@ class Context:
     def __init__(self, device=0):
         self._h = C.c_void_p()
         _check(load_library().dsi_context_create(int(device), C.byref(self._h)))
+        _track(self)
 
     def close(self):
         if self._h:
@@ -160,10 +200,7 @@ class Context:
             self._h = C.c_void_p()
 
     def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+        _safe_del(self)
 
     def synchronize(self):
         _check(load_library().dsi_context_synchronize(self._h))
@@ -209,6 +246,8 @@ class Grid3D:
             self._h = C.c_void_p()
             _check(L.dsi_grid_create(ctx._h, dimX, dimY, dimZ, C.byref(self._h)))
             self._owned = True
+        if self._owned:
+            _track(self)
 
     def close(self):
         if getattr(self, "_owned", False) and self._h:
@@ -217,10 +256,7 @@ class Grid3D:
         self._owned = False
 
     def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+        _safe_del(self)
 
     def getDimensions(self):
         nx, ny, nz = C.c_int(), C.c_int(), C.c_int()
@@ -334,6 +370,7 @@ class EventBatch:
         _check(load_library().dsi_batch_create(ctx._h, _ptr(x, C.c_uint16), _ptr(y, C.c_uint16),
                                                x.shape[0], pf, _ptr(Rt, C.c_float), Rt.shape[0],
                                                C.byref(self._h)))
+        _track(self)
 
     def close(self):
         if self._h:
@@ -341,10 +378,7 @@ class EventBatch:
             self._h = C.c_void_p()
 
     def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+        _safe_del(self)
 
 
 class MapperEMVS:
@@ -373,6 +407,7 @@ class MapperEMVS:
         self._h = C.c_void_p()
         L = load_library()
         _check(L.dsi_mapper_create(ctx._h, C.byref(cfg), C.byref(self._h)))
+        _track(self)
         nx, ny, nz = C.c_int(), C.c_int(), C.c_int()
         kv = (C.c_float * 4)()
         _check(L.dsi_mapper_geometry(self._h, kv, None, C.byref(nx), C.byref(ny), C.byref(nz)))
@@ -392,10 +427,7 @@ class MapperEMVS:
             self.dsi_._h = C.c_void_p()
 
     def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+        _safe_del(self)
 
     def set_vote_algo(self, algo):
         _check(load_library().dsi_mapper_set_vote_algo(self._h, int(algo)))
