@@ -56,12 +56,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     torch = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("DSI_BENCH_FORCE_DIST") == "1"  # the env knob lets a
+    # 1-GPU box exercise the torch.distributed/RCCL code path (world_size 1)
+    if use_dist:
         # torch first: libdsi_engine.so then binds to the HIP runtime torch already loaded,
         # so that RCCL (torch.distributed "nccl") and the engine share one runtime.
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
     if args.gpus != world and rank == 0:
@@ -97,9 +101,11 @@ def main():
     t_gen = time.time() - t_gen
 
     tfuse = None
-    if world > 1:
+    if use_dist:
+        from dvs_mcemvs_amd import distributed as dd
         tfuse = torch.empty((nz, ny, nx), dtype=torch.float32, device="cuda")
         acc = d.Grid3D(ctx, nx, ny, nz, device_ptr=tfuse.data_ptr())
+        temporal = dd.TemporalFusion(ctx, acc, tfuse, d.ACC_INV_SUM, world)
 
     def step():
         for c in range(2):
@@ -107,15 +113,12 @@ def main():
         fused.resetGrid()                     # process1.cpp:126-127: copy-by-add
         fused.addTwoGrids(mappers[0].dsi_)
         fused.harmonicMeanTwoGrids(mappers[1].dsi_)
-        if world == 1:
+        if not use_dist:
             mappers[0].computeDepthMap(fused)
         else:
-            acc.resetGrid()
-            acc.addInverseOfTwoGrids(fused)   # process2.cpp:220
-            ctx.synchronize()                 # engine stream -> torch stream hand-off
-            dist.all_reduce(tfuse)            # RCCL sum over xGMI
-            torch.cuda.current_stream().synchronize()
-            acc.computeHMfromSumOfInv(world)  # process2.cpp:222-225
+            temporal.reset()
+            temporal.add(fused)               # process2.cpp:220: acc += 1/(0.01 + fused)
+            temporal.finish()                 # ONE RCCL all-reduce(sum) over xGMI, then n/acc
             mappers[0].computeDepthMap(acc)
 
     def barrier():
@@ -235,15 +238,25 @@ def main():
             "gpu_ms_per_step_hip_events": gpu_ms / args.steps,
             "roofline": roofline, "cpu_baseline": cpu, "input_gen_s": t_gen,
         }
-        print(json.dumps(out))
     for o in mappers + batches + [fused]:
         o.close()
-    if world > 1:
+    if use_dist:
         acc.close()
     ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio; push it out first so that the JSON
+        # line is the last line on stdout
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out))
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":

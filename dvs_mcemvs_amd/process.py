@@ -1,0 +1,118 @@
+"""Orchestration of the reference's process_1 / process_2 (Alg. 1 / Alg. 2) over the GPU
+engine: which mapper gets which events, where the reference view sits, the fusion order and
+op codes, and the temporal accumulators.  Pure call sequencing -- every voxel operation is an
+engine kernel.
+
+    process_1   mapper_emvs_stereo/src/process1.cpp:28-224
+    process_2   mapper_emvs_stereo/src/process2.cpp:28-302
+"""
+import numpy as np
+
+from . import engine as E
+from . import synthetic as _q  # quaternion helpers only (numpy)
+
+
+def pose_mul(a, b):
+    """T_a * T_b for 7-vector poses (tx,ty,tz,qw,qx,qy,qz)."""
+    qa, qb = np.asarray(a[3:], np.float64), np.asarray(b[3:], np.float64)
+    w = qa[0] * qb[0] - qa[1] * qb[1] - qa[2] * qb[2] - qa[3] * qb[3]
+    x = qa[0] * qb[1] + qa[1] * qb[0] + qa[2] * qb[3] - qa[3] * qb[2]
+    y = qa[0] * qb[2] + qa[2] * qb[0] + qa[3] * qb[1] - qa[1] * qb[3]
+    z = qa[0] * qb[3] + qa[3] * qb[0] + qa[1] * qb[2] - qa[2] * qb[1]
+    t = np.asarray(a[:3], np.float64) + _q.quat_rotate(qa, np.asarray(b[:3], np.float64))
+    return np.concatenate([t, [w, x, y, z]])
+
+
+def reference_view_process1(trajectory_left, ts, rv_pos=0.0):
+    """process1.cpp:56-68: T_w_rv = T_w_l(ts) * baseline(rv_pos along x); returns T_rv_w."""
+    T_w_l = E.pose_at(trajectory_left, ts)
+    if T_w_l is None:
+        raise E.DsiError(E.ERR_INVALID, "no pose at the reference timestamp %r" % ts)
+    baseline = np.array([rv_pos, 0, 0, 1, 0, 0, 0], np.float64)
+    return _q.pose_inverse(pose_mul(T_w_l, baseline))
+
+
+def reference_view_process2(trajectory_left, ts):
+    """process2.cpp:79-81: T_rv_w = T_w_l(ts)^-1."""
+    T = E.pose_at(trajectory_left, ts)
+    if T is None:
+        raise E.DsiError(E.ERR_INVALID, "no pose at the reference timestamp %r" % ts)
+    return _q.pose_inverse(T)
+
+
+def _fuse_cameras(fused, other, method):
+    if method not in (1, 2, 3, 4, 5, 6):
+        raise E.DsiError(E.ERR_BAD_OP, "Improper fusion method selected")
+    fused.fuseTwoGrids(other, method)
+
+
+def process_1(mappers, events, trajectories, mapper_fused, ts, fusion_method, rv_pos=0.0):
+    """Alg. 1: one DSI per camera, fused across cameras (process1.cpp:54-191).
+    mappers/events/trajectories: lists of 2 or 3 (a third camera is the EVIMO2 case).
+    Returns T_rv_w; the fused DSI is mapper_fused.dsi_."""
+    T_rv_w = reference_view_process1(trajectories[0], ts, rv_pos)
+    for m, ev, tr in zip(mappers, events, trajectories):
+        m.evaluateDSI(ev, tr, T_rv_w)                      # :76, :94, :110
+    mapper_fused.dsi_.resetGrid()                          # :126
+    mapper_fused.dsi_.addTwoGrids(mappers[0].dsi_)         # :127
+    _fuse_cameras(mapper_fused.dsi_, mappers[1].dsi_, fusion_method)   # :136-158
+    if len(mappers) > 2 and events[2][0].shape[0] > 0:     # :169-191
+        g = mappers[2].dsi_
+        if fusion_method == 1:
+            mapper_fused.dsi_.minTwoGrids(g)
+        elif fusion_method == 2:
+            mapper_fused.dsi_.harmonicMeanTwoGrids(g, 3)
+        elif fusion_method == 6:
+            mapper_fused.dsi_.maxTwoGrids(g)
+        # 3, 4, 5: the reference silently ignores the third camera
+    return T_rv_w
+
+
+def process_2(ctx, cams, dsi_shape, events, trajectories, num_subintervals, mapper_fused,
+              mapper_fused_camera_time, ts, stereo_fusion, temporal_fusion, luts=(None, None),
+              inverse_depth=False):
+    """Alg. 2: per sub-interval camera fusion, then temporal fusion; and the converse order
+    (process2.cpp:46-289).  Returns dict with the left / right temporal DSIs (Grid3D)."""
+    mapper0 = E.MapperEMVS(ctx, cams[0], dsi_shape, lut=luts[0], inverse_depth=inverse_depth)
+    mapper1 = E.MapperEMVS(ctx, cams[1], dsi_shape, lut=luts[1], inverse_depth=inverse_depth)
+    dims = mapper0.dsi_.getDimensions()
+    sub = E.Grid3D(ctx, *dims)     # mapper_fused_subinterval.dsi_
+    left = E.Grid3D(ctx, *dims)    # mapper_fused_left.dsi_
+    right = E.Grid3D(ctx, *dims)   # mapper_fused_right.dsi_
+    T_rv_w = reference_view_process2(trajectories[0], ts)
+    per = [int(events[c][0].shape[0]) // int(num_subintervals) for c in range(2)]   # :46-47
+    mapper_fused.dsi_.resetGrid()                                                    # :90
+    for k in range(num_subintervals):
+        for c, m in ((0, mapper0), (1, mapper1)):
+            sl = slice(k * per[c], (k + 1) * per[c])                                 # :105-107, :132-134
+            m.dsi_.resetGrid()
+            m.evaluateDSI(tuple(a[sl] for a in events[c]), trajectories[c], T_rv_w)  # :119, :146
+        sub.resetGrid()                                                              # :159
+        sub.addTwoGrids(mapper0.dsi_)                                                # :160
+        _fuse_cameras(sub, mapper1.dsi_, stereo_fusion)                              # :168-189
+        if temporal_fusion == 2:                                                     # :216-226
+            left.addInverseOfTwoGrids(mapper0.dsi_)
+            right.addInverseOfTwoGrids(mapper1.dsi_)
+            mapper_fused.dsi_.addInverseOfTwoGrids(sub)
+            if k == num_subintervals - 1:
+                for g in (left, right, mapper_fused.dsi_):
+                    g.computeHMfromSumOfInv(num_subintervals)
+        elif temporal_fusion == 4:                                                   # :229-239
+            left.addTwoGrids(mapper0.dsi_)
+            right.addTwoGrids(mapper1.dsi_)
+            mapper_fused.dsi_.addTwoGrids(sub)
+            if k == num_subintervals - 1:
+                for g in (left, right, mapper_fused.dsi_):
+                    g.computeAMfromSum(num_subintervals)
+        # temporal_fusion 1, 3, 5, 6: nothing happens (:213, :227, :240-243)
+    # converse order: time first, cameras second (:266-289).  NOTE the reference swaps cases 3
+    # and 4 here (3 -> arithmetic, 4 -> geometric, process2.cpp:274-279); kept as is.
+    mapper_fused_camera_time.dsi_.addTwoGrids(left)                                  # :266
+    converse = {1: 1, 2: 2, 3: 4, 4: 3, 5: 5, 6: 6}
+    if stereo_fusion not in converse:
+        raise E.DsiError(E.ERR_BAD_OP, "Improper stereo fusion method selected")
+    mapper_fused_camera_time.dsi_.fuseTwoGrids(right, converse[stereo_fusion])
+    mapper0.close()
+    mapper1.close()
+    sub.close()
+    return {"left": left, "right": right, "T_rv_w": T_rv_w}

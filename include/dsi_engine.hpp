@@ -1,0 +1,322 @@
+// dsi_engine.hpp -- header-only C++ adapter over the C ABI (dsi_engine.h) that re-creates
+// the reference's class and method names on the hot path, so that the reference's
+// process_1 / process_2 orchestration (process1.cpp, process2.cpp) can call the GPU engine
+// with the code it already has:
+//
+//   Grid3D                       cartesian3dgrid/include/cartesian3dgrid/cartesian3dgrid.h:22-247
+//   EMVS::ShapeDSI               mapper_emvs_stereo/include/mapper_emvs_stereo/mapper_emvs_stereo.hpp:40-65
+//   EMVS::MapperEMVS             mapper_emvs_stereo.hpp:94-155
+//   LinearTrajectory             mapper_emvs_stereo/include/mapper_emvs_stereo/trajectory.hpp:81-128
+//
+// Types the reference takes from third-party packages are replaced by plain structs:
+//   dvs_msgs::Event                      -> dsi::Event {x, y, ts (seconds), polarity}
+//   geometry_utils::Transformation       -> dsi::Transformation {t[3], q[4] = w,x,y,z}
+//   image_geometry::PinholeCameraModel   -> dsi::PinholeCameraModel {width,height,fx,fy,cx,cy,lut}
+//   cv::Mat (CV_32F / CV_8U)             -> dsi::Image<float> / dsi::Image<uint8_t>
+// Where the reference glog-CHECK-aborts or throws std::out_of_range this adapter throws
+// dsi::Error (carrying the C status code).
+#pragma once
+
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "dsi_engine.h"
+
+namespace dsi {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+inline void check(int rc)
+{
+    if (rc != DSI_OK) throw Error(rc, dsi_last_error());
+}
+
+struct Event {  // fields MapperEMVS reads from dvs_msgs::Event (mapper_emvs_stereo.cpp:91,131,134)
+    uint16_t x = 0, y = 0;
+    double ts = 0;  // seconds
+    bool polarity = false;
+};
+
+struct Transformation {  // T_A_B as translation + unit quaternion (w,x,y,z)
+    double t[3] = {0, 0, 0};
+    double q[4] = {1, 0, 0, 0};
+    void to7(double* p) const
+    {
+        p[0] = t[0]; p[1] = t[1]; p[2] = t[2];
+        p[3] = q[0]; p[4] = q[1]; p[5] = q[2]; p[6] = q[3];
+    }
+    static Transformation from7(const double* p)
+    {
+        Transformation T;
+        T.t[0] = p[0]; T.t[1] = p[1]; T.t[2] = p[2];
+        T.q[0] = p[3]; T.q[1] = p[4]; T.q[2] = p[5]; T.q[3] = p[6];
+        return T;
+    }
+};
+
+struct PinholeCameraModel {
+    int width = 0, height = 0;      // fullResolution()
+    float fx = 0, fy = 0, cx = 0, cy = 0;  // projection-matrix intrinsics (mapper_emvs_stereo.cpp:46-48)
+    std::vector<float> rectified_points;   // optional LUT, 2*W*H, entry y*W+x (precomputeRectifiedPoints)
+};
+
+template <typename T>
+struct Image {  // stands in for a single-channel cv::Mat
+    int rows = 0, cols = 0;
+    std::vector<T> data;
+    Image() = default;
+    Image(int r, int c) : rows(r), cols(c), data((size_t)r * c) {}
+    T& at(int y, int x) { return data[(size_t)y * cols + x]; }
+    const T& at(int y, int x) const { return data[(size_t)y * cols + x]; }
+};
+
+// One GPU + one stream; shared by every Grid3D / MapperEMVS created from it.
+class Context {
+public:
+    explicit Context(int device = 0) { check(dsi_context_create(device, &h_)); }
+    ~Context() { dsi_context_destroy(h_); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    dsi_context_t* handle() const { return h_; }
+    void synchronize() { check(dsi_context_synchronize(h_)); }
+
+private:
+    dsi_context_t* h_ = nullptr;
+};
+
+}  // namespace dsi
+
+// trajectory.hpp:81-128
+class LinearTrajectory {
+public:
+    typedef std::map<double, dsi::Transformation> PoseMap;
+    LinearTrajectory() = default;
+    explicit LinearTrajectory(const PoseMap& poses)
+    {
+        if (poses.size() < 2) throw dsi::Error(DSI_ERR_INVALID, "At least two poses need to be provided");
+        for (const auto& kv : poses) {
+            times_.push_back(kv.first);
+            double p[7];
+            kv.second.to7(p);
+            poses_.insert(poses_.end(), p, p + 7);
+        }
+    }
+    // Returns T_W_C; false when t cannot be interpolated (trajectory.hpp:98-113)
+    bool getPoseAt(double t, dsi::Transformation& T) const
+    {
+        double out[7];
+        if (dsi_pose_at(times_.data(), poses_.data(), times_.size(), t, out) != DSI_OK) return false;
+        T = dsi::Transformation::from7(out);
+        return true;
+    }
+    size_t getNumControlPoses() const { return times_.size(); }
+    const std::vector<double>& times() const { return times_; }
+    const std::vector<double>& poses7() const { return poses_; }
+
+private:
+    std::vector<double> times_, poses_;
+};
+
+// cartesian3dgrid.h:22-247, device resident.
+class Grid3D {
+public:
+    Grid3D() = default;
+    Grid3D(dsi::Context& ctx, unsigned dimX, unsigned dimY, unsigned dimZ) { allocate(ctx, dimX, dimY, dimZ); }
+    ~Grid3D() { deallocate(); }
+    Grid3D(const Grid3D&) = delete;
+    Grid3D& operator=(const Grid3D&) = delete;
+    Grid3D(Grid3D&& o) noexcept : h_(o.h_), owned_(o.owned_) { o.h_ = nullptr; }
+    Grid3D& operator=(Grid3D&& o) noexcept
+    {
+        if (this != &o) {
+            deallocate();
+            h_ = o.h_;
+            owned_ = o.owned_;
+            o.h_ = nullptr;
+        }
+        return *this;
+    }
+
+    void allocate(dsi::Context& ctx, unsigned dimX, unsigned dimY, unsigned dimZ)
+    {
+        deallocate();
+        dsi::check(dsi_grid_create(ctx.handle(), (int)dimX, (int)dimY, (int)dimZ, &h_));
+        owned_ = true;
+    }
+    void deallocate()
+    {
+        if (h_ && owned_) dsi_grid_destroy(h_);
+        h_ = nullptr;
+    }
+    // non-owning view of a grid that belongs to a mapper (MapperEMVS::dsi_)
+    static Grid3D view(dsi_grid_t* h)
+    {
+        Grid3D g;
+        g.h_ = h;
+        g.owned_ = false;
+        return g;
+    }
+    dsi_grid_t* handle() const { return h_; }
+
+    void getDimensions(int* dimX, int* dimY, int* dimZ) const { dsi::check(dsi_grid_dims(h_, dimX, dimY, dimZ)); }
+    void resetGrid() { dsi::check(dsi_grid_reset(h_)); }
+
+    // voxel-wise operations, same names and in-place semantics as cartesian3dgrid.h:64-192
+    void addTwoGrids(const Grid3D& grid2) { dsi::check(dsi_grid_accumulate(h_, grid2.h_, DSI_ACC_SUM)); }
+    void addInverseOfTwoGrids(const Grid3D& grid2) { dsi::check(dsi_grid_accumulate(h_, grid2.h_, DSI_ACC_INV_SUM)); }
+    void computeHMfromSumOfInv(int n) { dsi::check(dsi_grid_finalize(h_, DSI_ACC_INV_SUM, n)); }
+    void computeAMfromSum(int n) { dsi::check(dsi_grid_finalize(h_, DSI_ACC_SUM, n)); }
+    void minTwoGrids(const Grid3D& grid2) { dsi::check(dsi_grid_fuse2(h_, grid2.h_, DSI_FUSE_MIN)); }
+    void harmonicMeanTwoGrids(const Grid3D& grid2) { dsi::check(dsi_grid_fuse2(h_, grid2.h_, DSI_FUSE_HM)); }
+    void harmonicMeanTwoGrids(const Grid3D& grid2, int n) { dsi::check(dsi_grid_fuse_hm_n(h_, grid2.h_, n)); }
+    void rmsTwoGrids(const Grid3D& grid2) { dsi::check(dsi_grid_fuse2(h_, grid2.h_, DSI_FUSE_RMS)); }
+    void geometricMeanTwoGrids(const Grid3D& grid2) { dsi::check(dsi_grid_fuse2(h_, grid2.h_, DSI_FUSE_GM)); }
+    void arithmeticMeanTwoGrids(const Grid3D& grid2) { dsi::check(dsi_grid_fuse2(h_, grid2.h_, DSI_FUSE_AM)); }
+    void maxTwoGrids(const Grid3D& grid2) { dsi::check(dsi_grid_fuse2(h_, grid2.h_, DSI_FUSE_MAX)); }
+
+    // cartesian3dgrid.cpp:115-137
+    void collapseMaxZSlice(dsi::Image<float>* max_val, dsi::Image<uint8_t>* max_pos) const
+    {
+        int nx, ny, nz;
+        getDimensions(&nx, &ny, &nz);
+        *max_val = dsi::Image<float>(ny, nx);
+        *max_pos = dsi::Image<uint8_t>(ny, nx);
+        dsi::check(dsi_grid_collapse_max_z(h_, max_val->data.data(), max_pos->data.data()));
+    }
+    // cartesian3dgrid.cpp:164-174
+    double computeMeanSquare() const
+    {
+        double v = 0;
+        dsi::check(dsi_grid_mean_square(h_, &v));
+        return v;
+    }
+    // host copies (the reference exposes raw pointers via getPointerToSlice; device memory
+    // cannot be handed out like that, dsi_grid_device_ptr() is the device-side equivalent)
+    std::vector<float> download() const
+    {
+        int nx, ny, nz;
+        getDimensions(&nx, &ny, &nz);
+        std::vector<float> v((size_t)nx * ny * nz);
+        dsi::check(dsi_grid_download(h_, v.data()));
+        return v;
+    }
+    void upload(const std::vector<float>& v) { dsi::check(dsi_grid_upload(h_, v.data())); }
+
+private:
+    dsi_grid_t* h_ = nullptr;
+    bool owned_ = false;
+};
+
+namespace EMVS {
+
+struct ShapeDSI {  // mapper_emvs_stereo.hpp:40-65
+    ShapeDSI() = default;
+    ShapeDSI(size_t dimX, size_t dimY, size_t dimZ, float min_depth, float max_depth, float fov)
+        : dimX_(dimX), dimY_(dimY), dimZ_(dimZ), min_depth_(min_depth), max_depth_(max_depth), fov_(fov)
+    {
+    }
+    size_t dimX_ = 0, dimY_ = 0, dimZ_ = 100;
+    float min_depth_ = 0.3f, max_depth_ = 5.f;
+    float fov_ = 0.f;
+};
+
+typedef LinearTrajectory TrajectoryType;
+
+class MapperEMVS {  // mapper_emvs_stereo.hpp:94-155
+public:
+    MapperEMVS(dsi::Context& ctx, const dsi::PinholeCameraModel& cam, const ShapeDSI& dsi_shape,
+               bool inverse_depth = false)
+    {
+        dsi_mapper_config_t cfg{};
+        cfg.sensor_width = cam.width;
+        cfg.sensor_height = cam.height;
+        cfg.K[0] = cam.fx; cfg.K[1] = cam.fy; cfg.K[2] = cam.cx; cfg.K[3] = cam.cy;
+        cfg.dim_x = (int)dsi_shape.dimX_;
+        cfg.dim_y = (int)dsi_shape.dimY_;
+        cfg.dim_z = (int)dsi_shape.dimZ_;
+        cfg.min_depth = dsi_shape.min_depth_;
+        cfg.max_depth = dsi_shape.max_depth_;
+        cfg.fov_deg = dsi_shape.fov_;
+        cfg.inverse_depth = inverse_depth ? 1 : 0;
+        cfg.lut = cam.rectified_points.empty() ? nullptr : cam.rectified_points.data();
+        dsi::check(dsi_mapper_create(ctx.handle(), &cfg, &h_));
+        dsi_ = Grid3D::view(dsi_mapper_grid(h_));
+    }
+    ~MapperEMVS()
+    {
+        dsi_.deallocate();
+        dsi_mapper_destroy(h_);
+    }
+    MapperEMVS(const MapperEMVS&) = delete;
+    MapperEMVS& operator=(const MapperEMVS&) = delete;
+
+    // mapper_emvs_stereo.cpp:67-148.  Returns false when events.size() < 1024.
+    bool evaluateDSI(const std::vector<dsi::Event>& events, const TrajectoryType& trajectory,
+                     const dsi::Transformation& T_rv_w)
+    {
+        const size_t n = events.size();
+        xs_.resize(n);
+        ys_.resize(n);
+        ts_.resize(n);
+        for (size_t i = 0; i < n; ++i) {
+            xs_[i] = events[i].x;
+            ys_[i] = events[i].y;
+            ts_[i] = events[i].ts;
+        }
+        double T7[7];
+        T_rv_w.to7(T7);
+        size_t voted = 0;
+        const int rc = dsi_mapper_evaluate(h_, xs_.data(), ys_.data(), ts_.data(), n, trajectory.times().data(),
+                                           trajectory.poses7().data(), trajectory.times().size(), T7, &voted);
+        if (rc == DSI_ERR_TOO_FEW_EVENTS) return false;
+        dsi::check(rc);
+        events_voted_ = voted;
+        return true;
+    }
+
+    // The device part of getDepthMapFromDSI (mapper_emvs_stereo.cpp:339-437): arg-max over Z
+    // (:368) and convertDepthIndicesToValues (:302-313) on the raw indices.  The adaptive
+    // threshold / median / inpaint post-filters stay on the host (OpenCV) and are fed from
+    // confidence_map and depth_cell_indices exactly as in the reference.
+    void getDepthMapFromDSI(dsi::Image<float>& depth_map, dsi::Image<float>& confidence_map,
+                            dsi::Image<uint8_t>& depth_cell_indices)
+    {
+        int nx, ny, nz;
+        dsi_.getDimensions(&nx, &ny, &nz);
+        depth_map = dsi::Image<float>(ny, nx);
+        confidence_map = dsi::Image<float>(ny, nx);
+        depth_cell_indices = dsi::Image<uint8_t>(ny, nx);
+        dsi::check(dsi_mapper_depth_map(h_, depth_map.data.data(), confidence_map.data.data(),
+                                        depth_cell_indices.data.data()));
+    }
+
+    std::vector<float> depthPlanes() const
+    {
+        int nz = 0;
+        dsi::check(dsi_mapper_geometry(h_, nullptr, nullptr, nullptr, nullptr, &nz));
+        std::vector<float> z(nz);
+        dsi::check(dsi_mapper_geometry(h_, nullptr, z.data(), nullptr, nullptr, nullptr));
+        return z;
+    }
+    size_t eventsVoted() const { return events_voted_; }
+    dsi_mapper_t* handle() const { return h_; }
+
+    Grid3D dsi_;       // public member, as in the reference (mapper_emvs_stereo.hpp:116)
+    std::string name;  // mapper_emvs_stereo.hpp:117
+
+private:
+    dsi_mapper_t* h_ = nullptr;
+    std::vector<uint16_t> xs_, ys_;
+    std::vector<double> ts_;
+    size_t events_voted_ = 0;
+};
+
+}  // namespace EMVS

@@ -1,0 +1,209 @@
+// C++ drop-in test: the reference's process_1 flow (process1.cpp:54-222) written against
+// include/dsi_engine.hpp, i.e. with the reference's own class and method names, checked
+// against the CPU oracle (oracle/dsi_oracle.h).  Built and run by tests/test_cpp_adapter.py.
+//
+//   exit 0: parity ok      exit 3: no GPU (adapter threw DSI_ERR_NO_DEVICE)      else: failure
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "dsi_engine.hpp"
+#include "dsi_oracle.h"
+
+namespace {
+
+struct Lcg {
+    uint64_t s;
+    explicit Lcg(uint64_t seed) : s(seed) {}
+    double uni()
+    {
+        s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+        return (double)(s >> 11) / 9007199254740992.0;
+    }
+};
+
+// a small rig: camera translating along x, looking down +z; events = projections of points
+void make_events(int n, double x_off, const dsi::PinholeCameraModel& cam, uint64_t seed,
+                 std::vector<dsi::Event>* ev, LinearTrajectory::PoseMap* poses)
+{
+    Lcg rng(seed);
+    const int npts = 200;
+    std::vector<double> P(3 * npts);
+    for (int i = 0; i < npts; ++i) {
+        const double z = 1.5 + 3.0 * rng.uni();
+        P[3 * i] = (rng.uni() - 0.5) * 1.2 * z;
+        P[3 * i + 1] = (rng.uni() - 0.5) * 0.9 * z;
+        P[3 * i + 2] = z;
+    }
+    for (int k = 0; k <= 12; ++k) {  // control poses every 0.1 s: x = 0.4 t
+        dsi::Transformation T;
+        T.t[0] = 0.4 * (0.1 * k - 0.1) + x_off;
+        (*poses)[0.1 * k - 0.1] = T;
+    }
+    ev->clear();
+    while ((int)ev->size() < n) {
+        const double t = 1.0 * ev->size() / n;  // increasing timestamps in [0,1)
+        const int i = (int)(rng.uni() * npts) % npts;
+        const double cx = 0.4 * t + x_off;
+        const double u = cam.fx * (P[3 * i] - cx) / P[3 * i + 2] + cam.cx;
+        const double v = cam.fy * P[3 * i + 1] / P[3 * i + 2] + cam.cy;
+        dsi::Event e;
+        e.ts = t;
+        if (u < 0 || v < 0 || u >= cam.width - 1 || v >= cam.height - 1) {
+            e.x = (uint16_t)(rng.uni() * cam.width);  // noise event
+            e.y = (uint16_t)(rng.uni() * cam.height);
+        } else {
+            e.x = (uint16_t)std::lround(u);
+            e.y = (uint16_t)std::lround(v);
+        }
+        ev->push_back(e);
+    }
+}
+
+// oracle evaluateDSI for the same inputs
+std::vector<float> oracle_dsi(const std::vector<dsi::Event>& ev, const LinearTrajectory& traj,
+                              const dsi::Transformation& T_rv_w, const dsi::PinholeCameraModel& cam,
+                              const EMVS::ShapeDSI& shape, std::vector<float>* planes_out)
+{
+    const int nx = cam.width, ny = cam.height, nz = (int)shape.dimZ_;
+    std::vector<float> planes(nz);
+    orc_depth_planes(shape.min_depth_, shape.max_depth_, nz, 0, planes.data());
+    *planes_out = planes;
+    const float K[4] = {cam.fx, cam.fy, cam.cx, cam.cy};
+    const float f = orc_virtual_focal(cam.fx, shape.fov_, nx);
+    const float Kv[4] = {f, f, cam.cx, cam.cy};
+    std::vector<uint16_t> x, y;
+    std::vector<float> centers, H;
+    double T7[7];
+    T_rv_w.to7(T7);
+    size_t cur = 0, np = 0;
+    while (cur + 1024 < ev.size()) {
+        double Tw[7];
+        if (!orc_pose_at(traj.times().data(), traj.poses7().data(), traj.times().size(), ev[cur + 512].ts, Tw)) {
+            ++cur;
+            continue;
+        }
+        float Rt[12];
+        orc_event_pose_Rt(T7, Tw, Rt);
+        centers.resize(3 * (np + 1));
+        H.resize(9 * (np + 1));
+        orc_packet_geometry(Rt, K, Kv, planes[0], &centers[3 * np], &H[9 * np]);
+        for (int i = 0; i < 1024; ++i, ++cur) {
+            x.push_back(ev[cur].x);
+            y.push_back(ev[cur].y);
+        }
+        ++np;
+    }
+    std::vector<float> xy(2 * x.size());
+    orc_warp_z0(x.data(), y.data(), x.size(), H.data(), nullptr, cam.width, xy.data());
+    std::vector<float> dsi((size_t)nx * ny * nz, 0.f);
+    orc_fill_voxel_grid(xy.data(), centers.data(), np, planes.data(), nz, Kv, nx, ny, dsi.data());
+    return dsi;
+}
+
+double max_rel_err(const std::vector<float>& a, const std::vector<float>& b)
+{
+    double m = 0;
+    for (size_t i = 0; i < a.size(); ++i) {
+        const double e = std::fabs((double)a[i] - b[i]) / std::fmax(1.0, std::fabs((double)b[i]));
+        if (e > m) m = e;
+    }
+    return m;
+}
+
+}  // namespace
+
+int main()
+{
+    try {
+        dsi::Context ctx(0);
+        dsi::PinholeCameraModel cam;
+        cam.width = 80;
+        cam.height = 60;
+        cam.fx = cam.fy = 70.f;
+        cam.cx = 40.f;
+        cam.cy = 30.f;
+        const EMVS::ShapeDSI dsi_shape(0, 0, 24, 1.0f, 5.0f, 0.f);
+
+        std::vector<dsi::Event> events0, events1;
+        LinearTrajectory::PoseMap p0, p1;
+        make_events(9000, 0.0, cam, 11, &events0, &p0);
+        make_events(9000, 0.2, cam, 12, &events1, &p1);
+        const LinearTrajectory trajectory0(p0), trajectory1(p1);
+
+        // process1.cpp:56-68: reference view = left camera pose at t_mid (rv_pos = 0)
+        dsi::Transformation T_w_rv;
+        if (!trajectory0.getPoseAt(0.5, T_w_rv)) return 10;
+        dsi::Transformation T_rv_w;  // inverse of a pure translation
+        for (int i = 0; i < 3; ++i) T_rv_w.t[i] = -T_w_rv.t[i];
+
+        EMVS::MapperEMVS mapper0(ctx, cam, dsi_shape), mapper1(ctx, cam, dsi_shape), mapper_fused(ctx, cam, dsi_shape);
+        if (!mapper0.evaluateDSI(events0, trajectory0, T_rv_w)) return 11;  // process1.cpp:76
+        if (!mapper1.evaluateDSI(events1, trajectory1, T_rv_w)) return 12;  // process1.cpp:94
+        if (mapper0.evaluateDSI(std::vector<dsi::Event>(events0.begin(), events0.begin() + 1023), trajectory0, T_rv_w))
+            return 13;                                                       // < 1024 events -> false
+        if (!mapper0.evaluateDSI(events0, trajectory0, T_rv_w)) return 14;
+
+        std::vector<float> planes;
+        const std::vector<float> ref0 = oracle_dsi(events0, trajectory0, T_rv_w, cam, dsi_shape, &planes);
+        const std::vector<float> ref1 = oracle_dsi(events1, trajectory1, T_rv_w, cam, dsi_shape, &planes);
+        const double e0 = max_rel_err(mapper0.dsi_.download(), ref0);
+        const double e1 = max_rel_err(mapper1.dsi_.download(), ref1);
+        std::printf("dsi0 max rel err %.3g, dsi1 max rel err %.3g, mean square %.6f\n", e0, e1,
+                    mapper0.dsi_.computeMeanSquare());
+        if (e0 > 1e-4 || e1 > 1e-4) return 20;
+        if (mapper0.depthPlanes() != planes) return 21;
+
+        for (int fusion_method = 1; fusion_method <= 6; ++fusion_method) {
+            // process1.cpp:126-158
+            mapper_fused.dsi_.resetGrid();
+            mapper_fused.dsi_.addTwoGrids(mapper0.dsi_);
+            switch (fusion_method) {
+            case 1: mapper_fused.dsi_.minTwoGrids(mapper1.dsi_); break;
+            case 2: mapper_fused.dsi_.harmonicMeanTwoGrids(mapper1.dsi_); break;
+            case 3: mapper_fused.dsi_.geometricMeanTwoGrids(mapper1.dsi_); break;
+            case 4: mapper_fused.dsi_.arithmeticMeanTwoGrids(mapper1.dsi_); break;
+            case 5: mapper_fused.dsi_.rmsTwoGrids(mapper1.dsi_); break;
+            case 6: mapper_fused.dsi_.maxTwoGrids(mapper1.dsi_); break;
+            }
+            std::vector<float> a = mapper0.dsi_.download();
+            const std::vector<float> g = mapper1.dsi_.download();
+            orc_fuse2(a.data(), g.data(), a.size(), fusion_method);
+            if (mapper_fused.dsi_.download() != a) {  // bit exact on identical inputs
+                std::printf("fusion %d differs\n", fusion_method);
+                return 30 + fusion_method;
+            }
+        }
+        // process1.cpp:222 -> mapper_emvs_stereo.cpp:368 (+ :302-313)
+        mapper_fused.dsi_.resetGrid();
+        mapper_fused.dsi_.addTwoGrids(mapper0.dsi_);
+        mapper_fused.dsi_.harmonicMeanTwoGrids(mapper1.dsi_);
+        dsi::Image<float> depth, conf;
+        dsi::Image<uint8_t> idx;
+        mapper_fused.getDepthMapFromDSI(depth, conf, idx);
+        const std::vector<float> vol = mapper_fused.dsi_.download();
+        std::vector<float> rconf(conf.data.size()), rdepth(conf.data.size());
+        std::vector<uint8_t> ridx(conf.data.size());
+        orc_collapse_max_z(vol.data(), cam.width, cam.height, (int)dsi_shape.dimZ_, rconf.data(), ridx.data());
+        orc_indices_to_depth(ridx.data(), ridx.size(), planes.data(), rdepth.data());
+        if (conf.data != rconf || idx.data != ridx || depth.data != rdepth) return 40;
+        dsi::Image<float> c2;
+        dsi::Image<uint8_t> i2;
+        mapper_fused.dsi_.collapseMaxZSlice(&c2, &i2);
+        if (c2.data != rconf || i2.data != ridx) return 41;
+        // mismatched grids: the reference throws std::out_of_range from .at()
+        Grid3D other(ctx, 8, 8, 8);
+        try {
+            mapper_fused.dsi_.addTwoGrids(other);
+            return 50;
+        } catch (const dsi::Error& e) {
+            if (e.code != DSI_ERR_SHAPE) return 51;
+        }
+        std::printf("process_1 flow through the C++ adapter: OK\n");
+        return 0;
+    } catch (const dsi::Error& e) {
+        std::printf("dsi::Error %d: %s\n", e.code, e.what());
+        return e.code == DSI_ERR_NO_DEVICE ? 3 : 2;
+    }
+}

@@ -1,0 +1,84 @@
+"""world_size-2 gloo test (CPU) of the multi-GPU orchestration: slice partitioning +
+the single all-reduce(sum) that implements the reference's temporal fusion
+(process2.cpp:211-242).  Per-slice DSIs come from the CPU oracle here (tests may use it);
+on GPUs they come from the engine and the tensor aliases a Grid3D."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, mode, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from dvs_mcemvs_amd import distributed as dd, synthetic as syn
+    from oracle import oracle as orc
+    from oracle_pipeline import OracleMapper
+
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    rig = syn.stereo_rig(9000, width=40, height=30, duration=0.3, seed=17)
+    x, y, ts = rig["events"][0]
+    n_slices = 4
+    bounds = dd.subinterval_bounds(x.shape[0], n_slices)
+    acc = np.zeros((8, 30, 40), np.float32)
+    for k in dd.slices_of_rank(n_slices, world, rank):
+        a, b = bounds[k]
+        m = OracleMapper(rig["cam"], dimZ=8, min_depth=4.0, max_depth=100.0)
+        assert m.evaluateDSI((x[a:b], y[a:b], ts[a:b]), rig["trajectories"][0], rig["T_rv_w"])
+        acc = orc.accumulate(acc, m.dsi, mode)
+    t = torch.from_numpy(acc)
+    dd.allreduce_sum_(t)
+    fused = orc.finalize(t.numpy(), mode, n_slices)
+    tmax = dd.allreduce_max_scalar(1.0 + rank)
+    assert tmax == float(world)
+    np.save(os.path.join(out_dir, "fused_rank%d.npy" % rank), fused)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_two_rank_temporal_fusion_equals_single_process(tmp_path, mode):
+    import torch.multiprocessing as mp
+    from dvs_mcemvs_amd import distributed as dd, synthetic as syn
+    from oracle import oracle as orc
+    from oracle_pipeline import OracleMapper
+
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, mode, str(tmp_path)), nprocs=2, join=True)
+    # single-process reference: all 4 slices in order (process2.cpp:98-242)
+    rig = syn.stereo_rig(9000, width=40, height=30, duration=0.3, seed=17)
+    x, y, ts = rig["events"][0]
+    acc = np.zeros((8, 30, 40), np.float32)
+    for a, b in dd.subinterval_bounds(x.shape[0], 4):
+        m = OracleMapper(rig["cam"], dimZ=8, min_depth=4.0, max_depth=100.0)
+        assert m.evaluateDSI((x[a:b], y[a:b], ts[a:b]), rig["trajectories"][0], rig["T_rv_w"])
+        acc = orc.accumulate(acc, m.dsi, mode)
+    ref = orc.finalize(acc, mode, 4)
+    r0 = np.load(tmp_path / "fused_rank0.npy")
+    r1 = np.load(tmp_path / "fused_rank1.npy")
+    assert np.array_equal(r0, r1)                   # every rank holds the same fused DSI
+    # summation order differs (slices 0,2 | 1,3 vs 0,1,2,3): equal to rounding
+    assert np.allclose(r0, ref, rtol=1e-6, atol=1e-6)
+    assert r0.any()
+
+
+def test_partitioning():
+    from dvs_mcemvs_amd import distributed as dd
+    assert dd.subinterval_bounds(10, 4) == [(0, 2), (2, 4), (4, 6), (6, 8)]  # remainder dropped
+    assert dd.slices_of_rank(8, 8, 3) == [3]
+    assert dd.slices_of_rank(8, 2, 1) == [1, 3, 5, 7]
+    owned = sorted(k for r in range(3) for k in dd.slices_of_rank(7, 3, r))
+    assert owned == list(range(7))

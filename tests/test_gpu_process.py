@@ -1,0 +1,62 @@
+"""process_1 / process_2 orchestration (process1.cpp, process2.cpp) on the GPU engine vs the
+same orchestration assembled from oracle pieces."""
+import numpy as np
+import pytest
+
+import dvs_mcemvs_amd as d
+from dvs_mcemvs_amd import process, synthetic as syn
+from oracle_pipeline import OracleMapper, oracle_process_1, oracle_process_2
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+
+
+def close(got, ref, tol=TOL):
+    err = np.abs(got.astype(np.float64) - ref) / np.maximum(1.0, np.abs(ref))
+    assert err.max() <= tol, "max rel err %g" % err.max()
+
+
+@pytest.mark.parametrize("fusion_method", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("n_cams", [2, 3])
+def test_process_1(ctx, fusion_method, n_cams):
+    rig = syn.stereo_rig(12000, width=72, height=54, duration=0.25, n_cams=n_cams, baseline=0.4, seed=31)
+    shape = d.ShapeDSI(0, 0, 16, 4.0, 150.0, 0.0)
+    mappers = [d.MapperEMVS(ctx, rig["cam"], shape) for _ in range(n_cams)]
+    fused = d.MapperEMVS(ctx, rig["cam"], shape)
+    ts = rig["t0"] + 0.2
+    process.process_1(mappers, rig["events"], rig["trajectories"], fused, ts, fusion_method, rv_pos=0.1)
+    dsis, ref = oracle_process_1(lambda: OracleMapper(rig["cam"], dimZ=16, min_depth=4.0, max_depth=150.0),
+                                 rig["events"], rig["trajectories"], ts, fusion_method, rv_pos=0.1)
+    for m, r in zip(mappers, dsis):
+        close(m.dsi_.download(), r, 1e-4)
+    close(fused.dsi_.download(), ref)
+    for m in mappers + [fused]:
+        m.close()
+
+
+def test_process_1_bad_method(ctx):
+    rig = syn.stereo_rig(3000, width=40, height=30, duration=0.2, seed=2)
+    shape = d.ShapeDSI(0, 0, 6, 4.0, 150.0, 0.0)
+    ms = [d.MapperEMVS(ctx, rig["cam"], shape) for _ in range(3)]
+    with pytest.raises(d.DsiError) as e:
+        process.process_1(ms[:2], rig["events"], rig["trajectories"], ms[2], rig["t0"] + 0.1, 9)
+    assert e.value.code == 5
+
+
+@pytest.mark.parametrize("stereo_fusion,temporal_fusion", [(2, 2), (2, 4), (3, 2), (4, 4), (1, 2), (5, 3)])
+def test_process_2(ctx, stereo_fusion, temporal_fusion):
+    rig = syn.stereo_rig(18000, width=64, height=48, duration=0.3, seed=41)
+    shape = d.ShapeDSI(0, 0, 12, 4.0, 150.0, 0.0)
+    fused = d.MapperEMVS(ctx, rig["cam"], shape)
+    cam_time = d.MapperEMVS(ctx, rig["cam"], shape)
+    ts = rig["t0"] + 0.15
+    out = process.process_2(ctx, [rig["cam"]] * 2, shape, rig["events"], rig["trajectories"], 4, fused,
+                            cam_time, ts, stereo_fusion, temporal_fusion)
+    ref = oracle_process_2(lambda: OracleMapper(rig["cam"], dimZ=12, min_depth=4.0, max_depth=150.0),
+                           rig["events"], rig["trajectories"], 4, ts, stereo_fusion, temporal_fusion)
+    close(out["left"].download(), ref["left"])
+    close(out["right"].download(), ref["right"])
+    close(fused.dsi_.download(), ref["fused"])
+    close(cam_time.dsi_.download(), ref["camera_time"], 4e-4)
+    fused.close()
+    cam_time.close()

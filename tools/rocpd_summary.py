@@ -20,7 +20,7 @@ def main():
             print("no kernel stats:", e)
         try:
             q = ("select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection "
-                 "group by kernel_name, counter_name")
+                 "where kernel_name like '%dsi::%' group by kernel_name, counter_name")
             rows = list(cur.execute(q))
             if rows:
                 print("%-40s %-24s %6s %18s %12s" % ("kernel", "counter", "n", "avg_value", "avg_dur_us"))
