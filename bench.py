@@ -170,6 +170,22 @@ def main():
     fuse_gbps = 12.0 * nvox / (fuse_ms * 1e-3) / 1e9
     argmax_gbps = (4.0 * nz + 9.0) * nx * ny / (argmax_ms * 1e-3) / 1e9
 
+    # ---- host-buffer (PCIe-inclusive) rate, reported beside `value`, never as it: upload the raw
+    # events + poses of camera 0 from pageable host memory, evaluate, wait
+    h2d_rate = None
+    if rank == 0:
+        ev0 = rig["events"][0]
+        first0, Rt0 = d.packetize(ev0[2], rig["trajectories"][0], rig["T_rv_w"])
+        best = float("inf")
+        for _ in range(3):
+            t1 = time.perf_counter()
+            bt = d.EventBatch(ctx, ev0[0], ev0[1], Rt0, first0)
+            mappers[0].evaluateDSI_batch(bt)
+            ctx.synchronize()
+            best = min(best, time.perf_counter() - t1)
+            bt.close()
+        h2d_rate = first0.shape[0] * d.PACKET_SIZE / best / 1e6
+
     info = mappers[0].last_vote_info()
     ms_per_step = 1e3 * elapsed / args.steps
     value = voted_all * args.steps / elapsed / 1e6  # Mevents/s, whole job
@@ -236,6 +252,7 @@ def main():
             "dsi_fuse_GBps": fuse_gbps, "dsi_fuse_ms": fuse_ms, "dsi_fuse_frac_of_hbm_peak": fuse_gbps / HBM_PEAK_GBPS,
             "argmax_GBps": argmax_gbps, "argmax_ms": argmax_ms,
             "gpu_ms_per_step_hip_events": gpu_ms / args.steps,
+            "h2d_inclusive_Mevents_per_s": h2d_rate,
             "roofline": roofline, "cpu_baseline": cpu, "input_gen_s": t_gen,
         }
     for o in mappers + batches + [fused]:
