@@ -168,7 +168,15 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
     const long max_rows_total = (long)(dsi::max_dynamic_lds() / row_bytes);
     if (max_rows_total < 3 || g.nx < 2 || g.ny < 2) return false;
     long max_owned = max_rows_total - 2;
-    if (m->want_band_rows > 0) max_owned = std::min<long>(max_owned, m->want_band_rows);
+    if (m->want_band_rows > 0) {
+        max_owned = std::min<long>(max_owned, m->want_band_rows);
+    } else {
+        // Two 1024-thread workgroups per CU (32 waves) hide latency better than one, if half the
+        // LDS still gives runs of >= ~96 events per (packet, band): rows+1 of Ny rows see
+        // 1024*(rows+1)/Ny events of a packet.
+        const long half_rows = (long)(dsi::max_dynamic_lds() / 2 / row_bytes) - 2;
+        if (half_rows >= 4 && 1024L * (half_rows + 1) / g.ny >= 96) max_owned = half_rows;
+    }
     int bands = (int)((g.ny + max_owned - 1) / max_owned);
     int band_rows = (g.ny + bands - 1) / bands;  // balanced
     if (m->want_band_rows > 0) band_rows = (int)std::min<long>(m->want_band_rows, max_owned);

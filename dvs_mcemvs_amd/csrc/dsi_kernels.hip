@@ -390,51 +390,80 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands(const float2* __restrict__
     const float xmax = (float)(nx - 1);
     const int row_base = r0 - 1;
 
-    for (int p = p_begin + wave; p < p_end; p += BLOCK / kWave) {
-        const size_t pz = (size_t)p * g.nz + z;
-        const PlaneCoef k = coef[pz];
-        if (k.flags & kCoefSkip) continue;
-        const uint32_t cu = cuts[pz * bp.bands + j];
+    // Per-packet metadata (coefficients + this band's run) is fetched with VECTOR loads whose
+    // address is the same in every lane, one packet ahead of its use: scalar loads would
+    // share lgkmcnt with the LDS atomics and serialise flags -> cuts -> coefficients.
+    constexpr int kStride = BLOCK / kWave;
+    const uint4* __restrict__ coef4 = reinterpret_cast<const uint4*>(coef);
+    auto fetch_meta = [&](int p, uint4& m0, uint2& m1, uint32_t& cu) {
+        size_t pz = (size_t)p * g.nz + z;
+        asm volatile("" : "+v"(pz));  // keep the address in VGPRs => global_load, counted by vmcnt
+        m0 = coef4[2 * pz];
+        m1 = *reinterpret_cast<const uint2*>(coef4 + 2 * pz + 1);
+        cu = cuts[pz * bp.bands + j];
+    };
+    int p = p_begin + wave;
+    uint4 m0 = make_uint4(0, 0, 0, 0), n0 = m0;
+    uint2 m1 = make_uint2(0, kCoefSkip), n1 = m1;
+    uint32_t mcu = 0, ncu = 0;
+    if (p < p_end) fetch_meta(p, m0, m1, mcu);
+    for (; p < p_end; p += kStride) {
+        // unpack the current packet first (this is where its loads are waited for), THEN put
+        // the next packet's metadata in flight so that it overlaps this packet's votes
+        const float ka = __uint_as_float(__builtin_amdgcn_readfirstlane(m0.x));
+        const float kbx = __uint_as_float(__builtin_amdgcn_readfirstlane(m0.y));
+        const float kby = __uint_as_float(__builtin_amdgcn_readfirstlane(m0.z));
+        const float kd = __uint_as_float(__builtin_amdgcn_readfirstlane(m0.w));
+        const float kr = __uint_as_float(__builtin_amdgcn_readfirstlane(m1.x));
+        const uint32_t flags = __builtin_amdgcn_readfirstlane(m1.y);
+        const uint32_t cu = __builtin_amdgcn_readfirstlane(mcu);
         const int lo = (int)(cu & 0xffffu), hi = (int)(cu >> 16);
-        if (lo >= hi) continue;
-        const float2* __restrict__ ev = sxy + (size_t)p * kPacket;
-        const bool slow = (k.flags & kCoefSlow) != 0;
-        int i = lo + lane;
-        float2 e = make_float2(0.f, 0.f);
-        if (i < hi) e = ev[i];
-        for (int base = lo; base < hi; base += kWave) {
-            // prefetch the next 64 events of the run while this batch is voted
-            const int inext = i + kWave;
-            float2 en = e;
-            if (inext < hi) en = ev[inext];
-            if (i < hi) {
-                const float nxv = e.x * k.a + k.bx;  // mapper_emvs_stereo.cpp:194-195
-                const float nyv = e.y * k.a + k.by;
-                float X, Y;
-                if (slow) {
-                    X = nxv / k.d;
-                    Y = nyv / k.d;
-                } else {
-                    X = div_rc(nxv, k.d, k.r);
-                    Y = div_rc(nyv, k.d, k.r);
+        const int pn = p + kStride;
+        n1 = make_uint2(0, kCoefSkip);
+        if (pn < p_end) fetch_meta(pn, n0, n1, ncu);
+        if (!(flags & kCoefSkip) && lo < hi) {
+            const float2* __restrict__ ev = sxy + (size_t)p * kPacket;
+            const bool slow = (flags & kCoefSlow) != 0;
+            int i = lo + lane;
+            float2 e = make_float2(0.f, 0.f);
+            if (i < hi) e = ev[i];
+            for (int base = lo; base < hi; base += kWave) {
+                // prefetch the next 64 events of the run while this batch is voted
+                const int inext = i + kWave;
+                float2 en = e;
+                if (inext < hi) en = ev[inext];
+                if (i < hi) {
+                    const float nxv = e.x * ka + kbx;  // mapper_emvs_stereo.cpp:194-195
+                    const float nyv = e.y * ka + kby;
+                    float X, Y;
+                    if (slow) {
+                        X = nxv / kd;
+                        Y = nyv / kd;
+                    } else {
+                        X = div_rc(nxv, kd, kr);
+                        Y = div_rc(nyv, kd, kr);
+                    }
+                    // cartesian3dgrid.h:255-259 restricted to this band's rows
+                    if (X >= 0.f && X < xmax && Y >= L && Y < U) {
+                        const float xf = __builtin_floorf(X), yf = __builtin_floorf(Y);
+                        const float fx = X - xf, fy = Y - yf, fx1 = 1.f - fx, fy1 = 1.f - fy;
+                        // scaling one factor by 2^31 scales the rounded product exactly
+                        const float fxs = fx * kFixScale, fx1s = fx1 * kFixScale;
+                        const int idx = __mul24((int)yf - row_base, nx) + (int)xf;
+                        acc_t* cell = lds + idx;
+                        lds_vote(cell, fx1s * fy1);         // g[0]      += fx1*fy1  (:267)
+                        lds_vote(cell + 1, fxs * fy1);      // g[1]      += fx*fy1
+                        lds_vote(cell + nx, fx1s * fy);     // g[Nx]     += fx1*fy
+                        lds_vote(cell + nx + 1, fxs * fy);  // g[Nx+1]   += fx*fy
+                    }
                 }
-                // cartesian3dgrid.h:255-259 restricted to this band's rows
-                if (X >= 0.f && X < xmax && Y >= L && Y < U) {
-                    const float xf = __builtin_floorf(X), yf = __builtin_floorf(Y);
-                    const float fx = X - xf, fy = Y - yf, fx1 = 1.f - fx, fy1 = 1.f - fy;
-                    // scaling one factor by 2^31 scales the rounded product exactly
-                    const float fxs = fx * kFixScale, fx1s = fx1 * kFixScale;
-                    const int idx = __mul24((int)yf - row_base, nx) + (int)xf;
-                    acc_t* cell = lds + idx;
-                    lds_vote(cell, fx1s * fy1);         // g[0]      += fx1*fy1  (:267)
-                    lds_vote(cell + 1, fxs * fy1);      // g[1]      += fx*fy1
-                    lds_vote(cell + nx, fx1s * fy);     // g[Nx]     += fx1*fy
-                    lds_vote(cell + nx + 1, fxs * fy);  // g[Nx+1]   += fx*fy
-                }
+                e = en;
+                i = inext;
             }
-            e = en;
-            i = inext;
         }
+        m0 = n0;
+        m1 = n1;
+        mcu = ncu;
     }
     __syncthreads();
 

@@ -348,3 +348,23 @@ def test_full_size_properties(ctx):
     safe = gap > 2 * DSI_TOL * np.maximum(1.0, srt[-1])
     assert np.array_equal(idx[safe], i1[safe])
     assert (np.abs(orc.indices_to_depth(idx, r.planes) - d1)[safe] <= 1e-4).all()
+
+
+@pytest.mark.parametrize("dims", [(512, 512, 200), (1024, 1024, 256)])
+def test_baseline_large_grids(ctx, dims):
+    """BASELINE.json configs[2] (512x512x200) and configs[4] (1024x1024x256) grid shapes at a
+    small event count: many narrow bands, rows of 4-8 KB in LDS, 1 GiB volume."""
+    nx, ny, nz = dims
+    rig = syn.stereo_rig(6 * 1024 + 1, width=nx, height=ny, duration=0.2, seed=77)
+    m = make_mapper(ctx, rig["cam"], nz, 4.0, 200.0, d.VOTE_LDS_BANDS)
+    r = OracleMapper(rig["cam"], dimZ=nz, min_depth=4.0, max_depth=200.0)
+    assert m.evaluateDSI(rig["events"][0], rig["trajectories"][0], rig["T_rv_w"])
+    assert r.evaluateDSI(rig["events"][0], rig["trajectories"][0], rig["T_rv_w"])
+    info = m.last_vote_info()
+    assert info["algo"] == d.VOTE_LDS_BANDS and info["bands"] >= 10
+    got = m.dsi_.download()
+    assert_dsi_close(got, r.dsi)
+    depth, conf, idx = m.getDepthMapFromDSI()
+    rconf, ridx = orc.collapse_max_z(got)
+    assert np.array_equal(conf, rconf) and np.array_equal(idx, ridx)
+    m.close()
