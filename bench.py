@@ -110,9 +110,8 @@ def main():
     def step():
         for c in range(2):
             mappers[c].evaluateDSI_batch(batches[c])
-        fused.resetGrid()                     # process1.cpp:126-127: copy-by-add
-        fused.addTwoGrids(mappers[0].dsi_)
-        fused.harmonicMeanTwoGrids(mappers[1].dsi_)
+        # process1.cpp:126-141 (resetGrid; addTwoGrids(dsi0); harmonicMeanTwoGrids(dsi1)) in one pass
+        fused.setToFusionOf(mappers[0].dsi_, mappers[1].dsi_, d.FUSE_HM)
         if not use_dist:
             mappers[0].computeDepthMap(fused)
         else:

@@ -193,7 +193,7 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
         int step = 8;
         for (int f = 2; f <= 8; f *= 2)
             if (bands % f == 0) step = 8 / f;
-        if (chunks > 1 || (bands % 8) != 0) chunks = ((chunks + step - 1) / step) * step;
+        if (chunks > 1) chunks = ((chunks + step - 1) / step) * step;  // whole groups of 8 pairs
         chunks = (int)std::min<size_t>((size_t)chunks, std::max<size_t>(1, n_packets));
         const size_t vol_bytes = (size_t)g.nx * g.ny * g.nz * sizeof(float);
         const size_t budget = (size_t)16 << 30;  // partial DSIs may use up to 16 GiB of HBM
@@ -490,6 +490,16 @@ int dsi_grid_fuse2(dsi_grid_t* dst, const dsi_grid_t* src, int op)
     if (int rc = check_pair(dst, src)) return rc;
     REQUIRE(op >= 1 && op <= 6, DSI_ERR_BAD_OP, "improper fusion method %d (expected 1..6)", op);
     HIP_TRY(dsi::launch_fuse2(dst->ctx->stream, dst->data, src->data, dst->n, op));
+    return DSI_OK;
+}
+
+int dsi_grid_fuse2_into(dsi_grid_t* dst, const dsi_grid_t* a, const dsi_grid_t* b, int op)
+{
+    if (int rc = check_pair(dst, a)) return rc;
+    if (int rc = check_pair(dst, b)) return rc;
+    REQUIRE(op >= 1 && op <= 6, DSI_ERR_BAD_OP, "improper fusion method %d (expected 1..6)", op);
+    REQUIRE(dst != a && dst != b, DSI_ERR_INVALID, "dst must differ from the operands (use dsi_grid_fuse2 in place)");
+    HIP_TRY(dsi::launch_fuse2_into(dst->ctx->stream, dst->data, a->data, b->data, dst->n, op));
     return DSI_OK;
 }
 

@@ -59,6 +59,8 @@ hipError_t launch_reduce_partials(hipStream_t s, const float* partials, int chun
                                   float* dsi, int accumulate);
 // ---- Grid3D ops ------------------------------------------------------------
 hipError_t launch_fuse2(hipStream_t s, float* a, const float* g, size_t n, int op);
+hipError_t launch_fuse2_into(hipStream_t s, float* dst, const float* a, const float* g, size_t n,
+                             int op);
 hipError_t launch_fuse_hm_n(hipStream_t s, float* a, const float* g, size_t n, int n_maps);
 hipError_t launch_accumulate(hipStream_t s, float* acc, const float* g, size_t n, int mode);
 hipError_t launch_finalize(hipStream_t s, float* acc, size_t n, int mode, int n_maps);

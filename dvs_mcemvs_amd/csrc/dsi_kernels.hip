@@ -368,11 +368,22 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands(const float2* __restrict__
                                                       float* __restrict__ out)
 {
     extern __shared__ acc_t lds[];
+    // block -> (pair q = (chunk, band), plane z).  Groups of 8 pairs: XCD x (= block % 8) walks
+    // the planes of pair 8k + x.  The last (pairs % 8) pairs are dealt plane by plane over all
+    // XCDs so that no XCD idles (their events then stream through every L2).
     const int b = blockIdx.x;
-    const int xcd = b & 7, s = b >> 3;
-    const int q = (s / g.nz) * 8 + xcd;
-    const int z = s % g.nz;
-    if (q >= bp.chunks * bp.bands) return;
+    const int pairs = bp.chunks * bp.bands;
+    const int full = (pairs / 8) * 8 * g.nz;
+    int q, z;
+    if (b < full) {
+        const int xcd = b & 7, s = b >> 3;
+        q = (s / g.nz) * 8 + xcd;
+        z = s % g.nz;
+    } else {
+        const int r = b - full;
+        q = (pairs / 8) * 8 + r / g.nz;
+        z = r % g.nz;
+    }
     const int c = q / bp.bands, j = q % bp.bands;
     const int r0 = j * bp.band_rows;
     const int r1 = min(g.ny, r0 + bp.band_rows);
@@ -540,6 +551,31 @@ __global__ __launch_bounds__(256) void k_fuse2(float* __restrict__ a, const floa
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const size_t i = n4 * 4 + threadIdx.x;
         a[i] = fuse_op<OP>(a[i], g[i]);
+    }
+}
+
+// dst = op(a, g): what "dst.resetGrid(); dst.addTwoGrids(a); dst.<op>TwoGrids(g)"
+// (process1.cpp:126-158) leaves in dst, in one pass (0 + a == a exactly for a >= 0)
+template <int OP>
+__global__ __launch_bounds__(256) void k_fuse2_into(float* __restrict__ dst,
+                                                    const float* __restrict__ a,
+                                                    const float* __restrict__ g, size_t n)
+{
+    const size_t n4 = n / 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 va = reinterpret_cast<const float4*>(a)[i];
+        const float4 vg = reinterpret_cast<const float4*>(g)[i];
+        float4 r;
+        r.x = fuse_op<OP>(0.f + va.x, vg.x);
+        r.y = fuse_op<OP>(0.f + va.y, vg.y);
+        r.z = fuse_op<OP>(0.f + va.z, vg.z);
+        r.w = fuse_op<OP>(0.f + va.w, vg.w);
+        reinterpret_cast<float4*>(dst)[i] = r;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = n4 * 4 + threadIdx.x;
+        dst[i] = fuse_op<OP>(0.f + a[i], g[i]);
     }
 }
 
@@ -727,8 +763,7 @@ static hipError_t launch_vote_bands_t(hipStream_t s, const float2* sxy, const Pl
         if (e != hipSuccess) return e;
         configured = bp.lds_bytes;
     }
-    const int pairs = bp.chunks * bp.bands;
-    const unsigned blocks = 8u * (unsigned)((pairs + 7) / 8) * (unsigned)g.nz;
+    const unsigned blocks = (unsigned)(bp.chunks * bp.bands) * (unsigned)g.nz;
     hipLaunchKernelGGL(k_vote_bands<BLOCK>, dim3(blocks), dim3(BLOCK), bp.lds_bytes, s, sxy, coef,
                        cuts, np, g, bp, out);
     return hipGetLastError();
@@ -765,6 +800,21 @@ hipError_t launch_fuse2(hipStream_t s, float* a, const float* g, size_t n, int o
     case 4: hipLaunchKernelGGL(k_fuse2<4>, grid, block, 0, s, a, g, n); break;
     case 5: hipLaunchKernelGGL(k_fuse2<5>, grid, block, 0, s, a, g, n); break;
     case 6: hipLaunchKernelGGL(k_fuse2<6>, grid, block, 0, s, a, g, n); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_fuse2_into(hipStream_t s, float* dst, const float* a, const float* g, size_t n, int op)
+{
+    const dim3 grid(grid_for(n / 4 + 1, 256)), block(256);
+    switch (op) {
+    case 1: hipLaunchKernelGGL(k_fuse2_into<1>, grid, block, 0, s, dst, a, g, n); break;
+    case 2: hipLaunchKernelGGL(k_fuse2_into<2>, grid, block, 0, s, dst, a, g, n); break;
+    case 3: hipLaunchKernelGGL(k_fuse2_into<3>, grid, block, 0, s, dst, a, g, n); break;
+    case 4: hipLaunchKernelGGL(k_fuse2_into<4>, grid, block, 0, s, dst, a, g, n); break;
+    case 5: hipLaunchKernelGGL(k_fuse2_into<5>, grid, block, 0, s, dst, a, g, n); break;
+    case 6: hipLaunchKernelGGL(k_fuse2_into<6>, grid, block, 0, s, dst, a, g, n); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -90,6 +90,7 @@ def load_library():
         "dsi_grid_upload": (C.c_int, [vp, f32p]),
         "dsi_grid_download": (C.c_int, [vp, f32p]),
         "dsi_grid_fuse2": (C.c_int, [vp, vp, C.c_int]),
+        "dsi_grid_fuse2_into": (C.c_int, [vp, vp, vp, C.c_int]),
         "dsi_grid_fuse_hm_n": (C.c_int, [vp, vp, C.c_int]),
         "dsi_grid_accumulate": (C.c_int, [vp, vp, C.c_int]),
         "dsi_grid_finalize": (C.c_int, [vp, C.c_int, C.c_int]),
@@ -314,6 +315,11 @@ class Grid3D:
     def fuseTwoGrids(self, grid2, fusion_method):
         """The switch(fusion_method) of process1.cpp:136-158."""
         self._fuse(grid2, int(fusion_method))
+
+    def setToFusionOf(self, grid_a, grid_b, fusion_method):
+        """self = op(grid_a, grid_b): the result of the reference's
+        `resetGrid(); addTwoGrids(a); <op>TwoGrids(b)` (process1.cpp:126-158) in one pass."""
+        _check(load_library().dsi_grid_fuse2_into(self._h, grid_a._h, grid_b._h, int(fusion_method)))
 
     def addTwoGrids(self, grid2):
         _check(load_library().dsi_grid_accumulate(self._h, grid2._h, ACC_SUM))

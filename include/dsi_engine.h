@@ -113,6 +113,10 @@ DSI_API int dsi_grid_upload(dsi_grid_t *g, const float *host);
 DSI_API int dsi_grid_download(dsi_grid_t *g, float *host);
 /* dst = op(dst, src), in place, op in 1..6 (cartesian3dgrid.h:111-190) */
 DSI_API int dsi_grid_fuse2(dsi_grid_t *dst, const dsi_grid_t *src, int op);
+/* dst = op(a, b) in one pass: exactly what the reference's sequence
+ * "dst.resetGrid(); dst.addTwoGrids(a); dst.<op>TwoGrids(b)" (process1.cpp:126-158,
+ * process2.cpp:159-189) leaves in dst, without the two extra sweeps over the volume */
+DSI_API int dsi_grid_fuse2_into(dsi_grid_t *dst, const dsi_grid_t *a, const dsi_grid_t *b, int op);
 /* Grid3D::harmonicMeanTwoGrids(grid2, n) (cartesian3dgrid.h:130-139) */
 DSI_API int dsi_grid_fuse_hm_n(dsi_grid_t *dst, const dsi_grid_t *src, int n);
 /* Grid3D::addTwoGrids / addInverseOfTwoGrids (cartesian3dgrid.h:64-78) */

@@ -368,3 +368,24 @@ def test_baseline_large_grids(ctx, dims):
     rconf, ridx = orc.collapse_max_z(got)
     assert np.array_equal(conf, rconf) and np.array_equal(idx, ridx)
     m.close()
+
+
+def test_fuse_into_equals_reference_sequence(ctx):
+    """dsi_grid_fuse2_into == resetGrid + addTwoGrids + <op>TwoGrids (process1.cpp:126-158)."""
+    rng = np.random.default_rng(12)
+    a = rng.gamma(2.0, 8.0, (6, 10, 13)).astype(np.float32)
+    g = rng.gamma(2.0, 8.0, (6, 10, 13)).astype(np.float32)
+    a.flat[::3] = 0.0
+    A, G, F, R = (d.Grid3D(ctx, 13, 10, 6) for _ in range(4))
+    A.upload(a)
+    G.upload(g)
+    for op in range(1, 7):
+        R.upload(rng.random((6, 10, 13)).astype(np.float32))  # stale contents must not matter
+        R.setToFusionOf(A, G, op)
+        F.resetGrid()
+        F.addTwoGrids(A)
+        F.fuseTwoGrids(G, op)
+        assert np.array_equal(R.download(), F.download())
+        assert np.array_equal(R.download(), orc.fuse2(a, g, op))
+    with pytest.raises(d.DsiError):
+        A.setToFusionOf(A, G, 2)
