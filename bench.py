@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--dims", type=int, nargs=3, default=[346, 260, 100])
     ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 global atomics, 2 LDS bands")
     ap.add_argument("--band", type=int, nargs=3, default=[0, 0, 0], help="band_rows chunks block")
+    ap.add_argument("--packed", type=int, default=-1, help="-1 auto, 0 per-packet waves, 1 packed lanes")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000,
                     help="events of camera 0 the CPU oracle is timed on (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -93,6 +94,7 @@ def main():
         m = d.MapperEMVS(ctx, rig["cam"], shape)
         m.set_vote_algo(args.algo)
         m.set_band_params(*args.band)
+        m.set_packed_lanes(args.packed)
         first, Rt = d.packetize(rig["events"][c][2], rig["trajectories"][c], rig["T_rv_w"])
         batches.append(d.EventBatch(ctx, rig["events"][c][0], rig["events"][c][1], Rt, first))
         voted += first.shape[0] * d.PACKET_SIZE
@@ -246,7 +248,7 @@ def main():
                                 ", %d time slices (one per GPU) fused by RCCL all-reduce of inverse sums" % world),
                 "events_voted_per_step": voted_all, "vote_algo": info["algo"], "bands": info["bands"],
                 "band_rows": info["band_rows"], "chunks": info["chunks"],
-                "block_threads": info["block_threads"], "lds_bytes": info["lds_bytes"],
+                "block_threads": info["block_threads"], "lds_bytes": info["lds_bytes"], "packed_lanes": info["packed"],
                 "parallelism": "1 GPU" if world == 1 else "time-slice x%d" % world},
             "dsi_fuse_GBps": fuse_gbps, "dsi_fuse_ms": fuse_ms, "dsi_fuse_frac_of_hbm_peak": fuse_gbps / HBM_PEAK_GBPS,
             "argmax_GBps": argmax_gbps, "argmax_ms": argmax_ms,

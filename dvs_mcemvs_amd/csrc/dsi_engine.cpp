@@ -113,11 +113,13 @@ struct dsi_mapper {
     dsi_grid* grid = nullptr;
     int algo = DSI_VOTE_AUTO;
     int want_band_rows = 0, want_chunks = 0, want_block = 0;
+    int want_packed = -1;  // -1 automatic, 0 per-packet waves, 1 packed lanes
     dsi_vote_info_t info{};
     // scratch
     DevBuf<float> centers, H, partials, Rt_tmp, conf, depth;
     DevBuf<float2> xy, sxy;
     DevBuf<uint32_t> nvalid, cuts;
+    DevBuf<uint16_t> rowstart;
     DevBuf<dsi::PlaneCoef> coef;
     DevBuf<uint8_t> idx;
     bool depth_valid = false;
@@ -166,7 +168,7 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
     const dsi::Geom& g = m->geom;
     const size_t row_bytes = (size_t)g.nx * sizeof(unsigned long long);  // Q33.31 LDS accumulators
     const long max_rows_total = (long)(dsi::max_dynamic_lds() / row_bytes);
-    if (max_rows_total < 3 || g.nx < 2 || g.ny < 2) return false;
+    if (max_rows_total < 3 || g.nx < 2 || g.ny < 2 || g.ny > 16000) return false;
     long max_owned = max_rows_total - 2;
     if (m->want_band_rows > 0) {
         max_owned = std::min<long>(max_owned, m->want_band_rows);
@@ -185,6 +187,10 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
     bp->band_rows = band_rows;
     bp->lds_bytes = (size_t)(band_rows + 2) * row_bytes;
     bp->block_threads = m->want_block > 0 ? m->want_block : 1024;
+    bp->row_pad = std::min(g.ny, 4096);  // z0 locations spill up to ~ny rows outside the grid
+    // expected events of one packet in one band; short runs waste lanes in the per-packet kernel
+    const long run = 1024L * (band_rows + 1) / g.ny;
+    bp->packed = m->want_packed >= 0 ? m->want_packed : (run < 512 ? 1 : 0);
     int chunks = m->want_chunks;
     if (chunks <= 0) {
         const long items_target = 8L * 256;  // ~8 work items per CU
@@ -272,19 +278,21 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
     m->info.chunks = bp.chunks;
     m->info.block_threads = bp.block_threads;
     m->info.lds_bytes = bp.lds_bytes;
+    m->info.packed = bp.packed;
     if (np == 0) {
         if (!accumulate) HIP_TRY(hipMemsetAsync(g->data, 0, g->n * sizeof(float), ctx->stream));
         return DSI_OK;
     }
     HIP_TRY(m->sxy.reserve(np * dsi::kPacket));
     HIP_TRY(m->nvalid.reserve(np));
+    HIP_TRY(m->rowstart.reserve(np * (size_t)(geom.ny + 2 * bp.row_pad + 3)));
     HIP_TRY(m->coef.reserve(np * geom.nz));
     HIP_TRY(m->cuts.reserve(np * geom.nz * bp.bands));
     const bool direct = (bp.chunks == 1 && !accumulate);
     if (!direct) HIP_TRY(m->partials.reserve((size_t)bp.chunks * g->n));
 
-    HIP_TRY(dsi::launch_sort_packets(ctx->stream, xy, (int)np, m->sxy.p, m->nvalid.p));
-    HIP_TRY(dsi::launch_plane_coef(ctx->stream, centers, m->planes_dev, m->sxy.p, m->nvalid.p, (int)np,
+    HIP_TRY(dsi::launch_sort_packets(ctx->stream, xy, (int)np, geom.ny, bp.row_pad, m->sxy.p, m->nvalid.p, m->rowstart.p));
+    HIP_TRY(dsi::launch_plane_coef(ctx->stream, centers, m->planes_dev, m->rowstart.p, m->nvalid.p, (int)np,
                                    geom, bp, m->coef.p, m->cuts.p));
     VoteTimer vt(m);
     HIP_TRY(dsi::launch_vote_bands(ctx->stream, m->sxy.p, m->coef.p, m->cuts.p, (int)np, geom, bp,
@@ -659,6 +667,7 @@ int dsi_mapper_destroy(dsi_mapper_t* m)
     m->xy.release();
     m->sxy.release();
     m->nvalid.release();
+    m->rowstart.release();
     m->cuts.release();
     m->coef.release();
     m->idx.release();
@@ -707,6 +716,14 @@ int dsi_mapper_set_band_params(dsi_mapper_t* m, int band_rows, int chunks, int b
     m->want_band_rows = band_rows;
     m->want_chunks = chunks;
     m->want_block = block_threads;
+    return DSI_OK;
+}
+
+int dsi_mapper_set_packed_lanes(dsi_mapper_t* m, int mode)
+{
+    REQUIRE(m, DSI_ERR_INVALID, "mapper is null");
+    REQUIRE(mode >= -1 && mode <= 1, DSI_ERR_INVALID, "mode must be -1 (auto), 0 or 1");
+    m->want_packed = mode;
     return DSI_OK;
 }
 
@@ -927,6 +944,23 @@ int dsi_mapper_last_vote_info(const dsi_mapper_t* m, dsi_vote_info_t* info)
 {
     REQUIRE(m && info, DSI_ERR_INVALID, "null argument");
     *info = m->info;
+    return DSI_OK;
+}
+
+/* test hook (not in the public header): total length of all runs [lo,hi) of the last banded
+ * vote, i.e. the number of event-planes the voting kernel looked at (>= the number accepted) */
+DSI_API int dsi_test_run_length_total(dsi_mapper_t* m, unsigned long long* total, unsigned long long* entries)
+{
+    REQUIRE(m && total && entries, DSI_ERR_INVALID, "null argument");
+    if (int rc = set_device(m->ctx)) return rc;
+    const size_t n = m->info.n_packets * (size_t)m->geom.nz * (size_t)m->info.bands;
+    std::vector<uint32_t> h(n);
+    HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+    if (n) HIP_TRY(hipMemcpy(h.data(), m->cuts.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    unsigned long long t = 0;
+    for (uint32_t c : h) t += (c >> 16) - (c & 0xffffu);
+    *total = t;
+    *entries = n;
     return DSI_OK;
 }
 

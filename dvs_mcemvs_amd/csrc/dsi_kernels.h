@@ -34,6 +34,8 @@ struct BandPlan {
     int band_rows;      // owned rows per band (last band may own fewer)
     int chunks;         // packet chunks; each writes its own partial DSI when > 1
     int block_threads;  // 256 / 512 / 1024
+    int packed;         // 1: k_vote_bands_packed (short runs), 0: k_vote_bands
+    int row_pad;        // z0 rows binned over [-row_pad, ny + row_pad) by k_sort_packets
     size_t lds_bytes;   // (band_rows + 2) * nx * 8 (u64 fixed-point accumulators)
 };
 
@@ -47,11 +49,11 @@ hipError_t launch_warp_z0(hipStream_t s, const uint16_t* ex, const uint16_t* ey,
 hipError_t launch_vote_global(hipStream_t s, const float2* xy, const float* centers, int np,
                               const float* planes, const Geom& g, float* dsi);
 // ---- stage B, LDS row-band form -------------------------------------------
-hipError_t launch_sort_packets(hipStream_t s, const float2* xy, int np, float2* sxy,
-                               uint32_t* nvalid);
+hipError_t launch_sort_packets(hipStream_t s, const float2* xy, int np, int ny, int pad,
+                               float2* sxy, uint32_t* nvalid, uint16_t* rowstart);
 hipError_t launch_plane_coef(hipStream_t s, const float* centers, const float* planes,
-                             const float2* sxy, const uint32_t* nvalid, int np, const Geom& g,
-                             const BandPlan& bp, PlaneCoef* coef, uint32_t* cuts);
+                             const uint16_t* rowstart, const uint32_t* nvalid, int np,
+                             const Geom& g, const BandPlan& bp, PlaneCoef* coef, uint32_t* cuts);
 hipError_t launch_vote_bands(hipStream_t s, const float2* sxy, const PlaneCoef* coef,
                              const uint32_t* cuts, int np, const Geom& g, const BandPlan& bp,
                              float* out);

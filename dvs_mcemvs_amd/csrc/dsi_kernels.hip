@@ -204,84 +204,84 @@ __global__ __launch_bounds__(256) void k_vote_global(const float2* __restrict__ 
 }
 
 // ------------------------------------------------ stage B: LDS row bands ---
-// (1) per packet: drop events that no plane can accept (non-finite z0 location),
-//     sort the rest by y0.  For one (packet, plane) the map y0 -> Y is monotone
-//     (each of *a, +by, /d rounds monotonically), so the events landing in a band
-//     of output rows are one contiguous run of the sorted packet.
-__global__ __launch_bounds__(256) void k_sort_packets(const float2* __restrict__ xy,
-                                                      float2* __restrict__ sxy,
-                                                      uint32_t* __restrict__ nvalid)
+// (1) per packet: drop events that no plane can accept (non-finite z0 location) and group
+//     the rest by the row floor(y0) they fall in at z0 (counting sort in LDS; the order inside
+//     a row does not matter).  For one (packet, plane) the map y0 -> Y is monotone (each of
+//     *a, +by, /d rounds monotonically), so the events landing in a band of output rows come
+//     from a contiguous range of z0 rows = one contiguous run of the grouped packet.
+//     Rows are binned over [-pad, ny+pad) (events warped to z0 spill well outside the grid
+//     when the camera is far from the reference view, and other planes pull them back in);
+//     bin 0 holds everything below, the last bin everything above:
+//     bin(y0) = clamp(floor(y0), -pad-1, ny+pad) + pad + 1, nb = ny + 2*pad + 2 bins,
+//     rowstart[p][b] = number of kept events in bins < b, b = 0..nb.
+__device__ __forceinline__ int row_bin(float y0, int ny, int pad)
 {
-    __shared__ float ky[kPacket];
-    __shared__ float kx[kPacket];
-    __shared__ uint32_t count;
+    const float f = fminf(fmaxf(__builtin_floorf(y0), (float)(-pad - 1)), (float)(ny + pad));
+    return (int)f + pad + 1;  // finite y0 only
+}
+
+__global__ __launch_bounds__(256) void k_sort_packets(const float2* __restrict__ xy, int ny,
+                                                      int pad, float2* __restrict__ sxy,
+                                                      uint32_t* __restrict__ nvalid,
+                                                      uint16_t* __restrict__ rowstart)
+{
+    extern __shared__ uint32_t hist[];  // nb + 1 counters, then scanned in place
+    __shared__ uint32_t wave_tot[4];
+    const int nb = ny + 2 * pad + 2;
     const int k = blockIdx.x;
-    if (threadIdx.x == 0) count = 0;
+    for (int i = threadIdx.x; i <= nb; i += 256) hist[i] = 0;
     __syncthreads();
-    uint32_t mine = 0;
-    for (int j = threadIdx.x; j < kPacket; j += 256) {
-        const float2 p = xy[(size_t)k * kPacket + j];
-        const bool ok = finitef(p.x) && finitef(p.y);
-        ky[j] = ok ? p.y : __builtin_inff();
-        kx[j] = p.x;
-        mine += ok ? 1u : 0u;
-    }
-    atomicAdd(&count, mine);
-    __syncthreads();
-    // bitonic network, 512 compare-exchanges per stage, two per thread
-    for (int kk = 2; kk <= kPacket; kk <<= 1) {
-        for (int j = kk >> 1; j > 0; j >>= 1) {
+    float2 ev[4];
+    int bin[4];
+    uint32_t rank[4];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int t = threadIdx.x + 256 * h;
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const int l = i | j;
-                const bool up = (i & kk) == 0;
-                const float yi = ky[i], yl = ky[l];
-                if ((yi > yl) == up) {
-                    ky[i] = yl;
-                    ky[l] = yi;
-                    const float xi = kx[i];
-                    kx[i] = kx[l];
-                    kx[l] = xi;
-                }
-            }
-            __syncthreads();
-        }
+    for (int h = 0; h < 4; ++h) {
+        ev[h] = xy[(size_t)k * kPacket + threadIdx.x + 256 * h];
+        const bool ok = finitef(ev[h].x) && finitef(ev[h].y);
+        bin[h] = ok ? row_bin(ev[h].y, ny, pad) : -1;
+        rank[h] = 0;
+        if (ok) rank[h] = atomicAdd(&hist[bin[h]], 1u);
     }
-    for (int j = threadIdx.x; j < kPacket; j += 256)
-        sxy[(size_t)k * kPacket + j] = make_float2(kx[j], ky[j]);
-    if (threadIdx.x == 0) nvalid[k] = count;
-}
-
-// (2) per (packet, plane): coefficients + for every band the run [lo,hi) of the
-//     sorted packet whose Y can fall into the band.  The run is a superset (margin
-//     of a few ulps); the voting kernel re-tests every event exactly.
-__device__ __forceinline__ float y_of(float y0, float a, float by, float d)
-{
-    return (y0 * a + by) / d;  // IEEE divide: +-inf stay ordered, no NaN for finite inputs
-}
-
-// first index i in [0,n) with Y_i >= v (increasing map) / Y_i < v (decreasing map)
-__device__ int first_reaching(const float2* __restrict__ ev, int n, float a, float by, float d,
-                              bool increasing, float v)
-{
-    int lo = 0, hi = n;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        const float Y = y_of(ev[mid].y, a, by, d);
-        const bool reached = increasing ? (Y >= v) : (Y < v);
-        if (reached)
-            hi = mid;
-        else
-            lo = mid + 1;
+    __syncthreads();
+    // exclusive scan of hist[0..nb): each thread owns a contiguous slice
+    const int per = (nb + 255) / 256;
+    const int b0 = threadIdx.x * per, b1 = min(nb, b0 + per);
+    uint32_t local = 0;
+    for (int i = b0; i < b1; ++i) local += hist[i];
+    uint32_t incl = local;
+    const int lane = threadIdx.x & 63;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
     }
-    return lo;
+    if (lane == 63) wave_tot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t base = incl - local;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wave_tot[w];
+    const uint32_t total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    __syncthreads();
+    for (int i = b0; i < b1; ++i) {
+        const uint32_t c = hist[i];
+        hist[i] = base;
+        base += c;
+    }
+    if (threadIdx.x == 0) hist[nb] = total;
+    __syncthreads();
+    uint16_t* rs = rowstart + (size_t)k * (nb + 1);
+    for (int i = threadIdx.x; i <= nb; i += 256) rs[i] = (uint16_t)hist[i];
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+        if (bin[h] >= 0) sxy[(size_t)k * kPacket + hist[bin[h]] + rank[h]] = ev[h];
+    if (threadIdx.x == 0) nvalid[k] = total;
 }
 
+// (2) per (packet, plane): coefficients + for every band the run [lo,hi) of the grouped
+//     packet whose Y can fall into the band.  The band's Y interval is mapped back to z0 rows
+//     (in double, widened by one row on each side), and the run is read off the packet's
+//     rowstart table.  The run is a superset; the voting kernel re-tests every event exactly.
 __global__ __launch_bounds__(256) void k_plane_coef(const float* __restrict__ centers,
                                                     const float* __restrict__ planes,
-                                                    const float2* __restrict__ sxy,
+                                                    const uint16_t* __restrict__ rowstart,
                                                     const uint32_t* __restrict__ nvalid, int np,
                                                     Geom g, BandPlan bp,
                                                     PlaneCoef* __restrict__ coef,
@@ -289,7 +289,9 @@ __global__ __launch_bounds__(256) void k_plane_coef(const float* __restrict__ ce
 {
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= (size_t)np * g.nz) return;
-    const int k = (int)(tid / g.nz), z = (int)(tid % g.nz);
+    // packet index fastest: the plane-major tables (coef[z][p], cuts[band][z][p]) are written
+    // coalesced, and a voting workgroup (fixed z, band) later streams through them
+    const int z = (int)(tid / np), k = (int)(tid % np);
     PlaneCoef c;
     plane_coefficients(centers[3 * k], centers[3 * k + 1], centers[3 * k + 2], planes[z], g, c.a,
                        c.bx, c.by, c.d);
@@ -305,30 +307,39 @@ __global__ __launch_bounds__(256) void k_plane_coef(const float* __restrict__ ce
     c.flags = dead ? kCoefSkip : (slow ? kCoefSlow : 0u);
     coef[tid] = c;
 
-    uint32_t* out = cuts + tid * bp.bands;
-    const float2* ev = sxy + (size_t)k * kPacket;
-    const bool increasing = (c.a > 0.f) == (c.d > 0.f);
+    const int pad = bp.row_pad;
+    const int nb = g.ny + 2 * pad + 2;
+    const uint16_t* rs = rowstart + (size_t)k * (nb + 1);
+    // y0 = (Y*d - by)/a inverts the transfer; unusable when the map is (nearly) constant or
+    // the inversion is ill-conditioned -- then the whole packet is the (superset) run
+    const double a = (double)c.a, d = (double)c.d, by = (double)c.by;
+    const bool invertible = !dead && !slow && fabs(a) > 1e-3 * fabs(d);
     for (int j = 0; j < bp.bands; ++j) {
         uint32_t lo = 0, hi = 0;
-        if (slow) {
+        if (!dead) {
             hi = (uint32_t)nv;
-        } else if (!dead) {
-            const int r0 = j * bp.band_rows;
-            const int r1 = min(g.ny, r0 + bp.band_rows);
-            // accepted iff 0 <= Y < ny-1; the band needs floor(Y) in [r0-1, r1-1]
-            float L = (float)max(r0 - 1, 0), U = (float)min(r1, g.ny - 1);
-            L -= 1e-3f * fmaxf(1.f, L);  // superset margin, >> a few ulps
-            U += 1e-3f * fmaxf(1.f, U);
-            if (increasing) {
-                lo = first_reaching(ev, nv, c.a, c.by, c.d, true, L);
-                hi = first_reaching(ev, nv, c.a, c.by, c.d, true, U);
-            } else {
-                lo = first_reaching(ev, nv, c.a, c.by, c.d, false, U);
-                hi = first_reaching(ev, nv, c.a, c.by, c.d, false, L);
+            if (invertible) {
+                const int r0 = j * bp.band_rows;
+                const int r1 = min(g.ny, r0 + bp.band_rows);
+                // accepted iff 0 <= Y < ny-1; the band needs floor(Y) in [r0-1, r1-1]
+                const double L = (double)max(r0 - 1, 0) - 0.01, U = (double)min(r1, g.ny - 1) + 0.01;
+                const double ya = (L * d - by) / a, yb = (U * d - by) / a;
+                double ymin = fmin(ya, yb), ymax = fmax(ya, yb);
+                if (ymin == ymin && ymax == ymax) {  // not NaN
+                    // the fp32 forward map (mul, add, divide) is within a few ulps of the real
+                    // one: in y0 units that is ~2^-22 * (|y0| + |by/a|); widen by 40x that
+                    const double m = 1e-5 * (fmax(fabs(ymin), fabs(ymax)) + fabs(by / a));
+                    ymin -= m;
+                    ymax += m;
+                    const double fa = fmin(fmax(floor(ymin), (double)(-pad - 1)), (double)(g.ny + pad));
+                    const double fb = fmin(fmax(floor(ymax), (double)(-pad - 1)), (double)(g.ny + pad));
+                    lo = rs[(int)fa + pad + 1];   // events in bins below bin(fa)
+                    hi = rs[(int)fb + pad + 2];   // events in bins up to and including bin(fb)
+                }
             }
             if (hi < lo) hi = lo;
         }
-        out[j] = lo | (hi << 16);  // hi <= 1024 fits in 16 bits
+        cuts[((size_t)j * g.nz + z) * np + k] = lo | (hi << 16);  // hi <= 1024 fits in 16 bits
     }
 }
 
@@ -406,12 +417,14 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands(const float2* __restrict__
     // share lgkmcnt with the LDS atomics and serialise flags -> cuts -> coefficients.
     constexpr int kStride = BLOCK / kWave;
     const uint4* __restrict__ coef4 = reinterpret_cast<const uint4*>(coef);
+    const size_t coef_base = (size_t)z * np;                 // coef[z][p]
+    const size_t cuts_base = ((size_t)j * g.nz + z) * np;    // cuts[band][z][p]
     auto fetch_meta = [&](int p, uint4& m0, uint2& m1, uint32_t& cu) {
-        size_t pz = (size_t)p * g.nz + z;
+        size_t pz = coef_base + p;
         asm volatile("" : "+v"(pz));  // keep the address in VGPRs => global_load, counted by vmcnt
         m0 = coef4[2 * pz];
         m1 = *reinterpret_cast<const uint2*>(coef4 + 2 * pz + 1);
-        cu = cuts[pz * bp.bands + j];
+        cu = cuts[cuts_base + (pz - coef_base)];
     };
     int p = p_begin + wave;
     uint4 m0 = make_uint4(0, 0, 0, 0), n0 = m0;
@@ -485,6 +498,128 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands(const float2* __restrict__
     const int n_out = (r1 - r0) * nx;
     for (int i = threadIdx.x; i < n_out; i += BLOCK)
         dst[i] = (float)((double)src[i] * kFixInv);  // < 2^53: exact in f64, one rounding to f32
+}
+
+// (3b) the same work item decomposition for SHORT runs (tall or wide grids: a band of a
+//     1024-wide plane sees ~20 events of a packet).  A wave takes 64 packets at a time,
+//     appends their runs back to back into its 64 lanes and votes whenever the lanes are
+//     full, so lane utilisation no longer depends on the run length.  Coefficients are then
+//     per lane (gathered from the plane-major table), not per wave.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const float2* __restrict__ sxy,
+                                                             const PlaneCoef* __restrict__ coef,
+                                                             const uint32_t* __restrict__ cuts,
+                                                             int np, Geom g, BandPlan bp,
+                                                             float* __restrict__ out)
+{
+    extern __shared__ acc_t lds[];
+    const int b = blockIdx.x;
+    const int pairs = bp.chunks * bp.bands;
+    const int full = (pairs / 8) * 8 * g.nz;
+    int q, z;
+    if (b < full) {
+        const int xcd = b & 7, s = b >> 3;
+        q = (s / g.nz) * 8 + xcd;
+        z = s % g.nz;
+    } else {
+        const int r = b - full;
+        q = (pairs / 8) * 8 + r / g.nz;
+        z = r % g.nz;
+    }
+    const int c = q / bp.bands, j = q % bp.bands;
+    const int r0 = j * bp.band_rows;
+    const int r1 = min(g.ny, r0 + bp.band_rows);
+    const int nx = g.nx;
+    const int lds_elems = (r1 - r0 + 2) * nx;
+    for (int i = threadIdx.x; i < lds_elems; i += BLOCK) lds[i] = 0;
+    __syncthreads();
+
+    const int p_begin = (int)(((long long)np * c) / bp.chunks);
+    const int p_end = (int)(((long long)np * (c + 1)) / bp.chunks);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int lane = threadIdx.x & (kWave - 1);
+    const float L = (float)max(r0 - 1, 0), U = (float)min(r1, g.ny - 1);
+    const float xmax = (float)(nx - 1);
+    const int row_base = r0 - 1;
+    // packets a wave takes per pass: 64 when the chunk is long, fewer (>= 4) when it is short so
+    // that every wave of the workgroup gets some
+    constexpr int kWaves = BLOCK / kWave;
+    int group = kWave;
+    while (group > 4 && (p_end - p_begin) < group * kWaves) group >>= 1;
+    const int stride = kWaves * group;
+    const uint4* __restrict__ coef4 = reinterpret_cast<const uint4*>(coef) + 2 * (size_t)z * np;
+    const uint32_t* __restrict__ cutz = cuts + ((size_t)j * g.nz + z) * np;
+
+    // lane state of the batch being filled
+    float2 e = make_float2(0.f, 0.f);
+    uint4 ca = make_uint4(0, 0, 0, 0);  // a, bx, by, d
+    uint2 cb = make_uint2(0, 0);        // r, flags
+    int fill = 0;
+
+    auto vote_batch = [&](int n_active) {
+        if (lane < n_active) {
+            const float ka = __uint_as_float(ca.x), kbx = __uint_as_float(ca.y);
+            const float kby = __uint_as_float(ca.z), kd = __uint_as_float(ca.w);
+            const float kr = __uint_as_float(cb.x);
+            const float nxv = e.x * ka + kbx;  // mapper_emvs_stereo.cpp:194-195
+            const float nyv = e.y * ka + kby;
+            float X, Y;
+            if (cb.y & kCoefSlow) {  // rare; per lane
+                X = nxv / kd;
+                Y = nyv / kd;
+            } else {
+                X = div_rc(nxv, kd, kr);
+                Y = div_rc(nyv, kd, kr);
+            }
+            if (X >= 0.f && X < xmax && Y >= L && Y < U) {
+                const float xf = __builtin_floorf(X), yf = __builtin_floorf(Y);
+                const float fx = X - xf, fy = Y - yf, fx1 = 1.f - fx, fy1 = 1.f - fy;
+                const float fxs = fx * kFixScale, fx1s = fx1 * kFixScale;
+                const int idx = __mul24((int)yf - row_base, nx) + (int)xf;
+                acc_t* cell = lds + idx;
+                lds_vote(cell, fx1s * fy1);
+                lds_vote(cell + 1, fxs * fy1);
+                lds_vote(cell + nx, fx1s * fy);
+                lds_vote(cell + nx + 1, fxs * fy);
+            }
+        }
+    };
+
+    for (int pg = p_begin + wave * group; pg < p_end; pg += stride) {
+        const int pl = pg + lane;
+        uint32_t mycu = 0;
+        if (lane < group && pl < p_end) mycu = cutz[pl];  // consecutive packets: one coalesced load
+        const int ng = min(group, p_end - pg);
+        for (int k = 0; k < ng; ++k) {
+            const uint32_t cu = __builtin_amdgcn_readlane(mycu, k);
+            int off = (int)(cu & 0xffffu);
+            const int hi = (int)(cu >> 16);
+            const int p = pg + k;
+            while (off < hi) {
+                const int take = min(kWave - fill, hi - off);
+                const int rel = lane - fill;
+                if ((unsigned)rel < (unsigned)take) {
+                    e = sxy[(size_t)p * kPacket + off + rel];
+                    ca = coef4[2 * (size_t)p];
+                    cb = *reinterpret_cast<const uint2*>(coef4 + 2 * (size_t)p + 1);
+                }
+                fill += take;
+                off += take;
+                if (fill == kWave) {
+                    vote_batch(kWave);
+                    fill = 0;
+                }
+            }
+        }
+    }
+    if (fill > 0) vote_batch(fill);
+    __syncthreads();
+
+    const size_t vol = (size_t)g.nx * g.ny * g.nz;
+    float* __restrict__ dst = out + (size_t)c * vol + ((size_t)z * g.ny + r0) * nx;
+    const acc_t* src = lds + nx;
+    const int n_out = (r1 - r0) * nx;
+    for (int i = threadIdx.x; i < n_out; i += BLOCK) dst[i] = (float)((double)src[i] * kFixInv);
 }
 
 // (4) DSI = sum of the chunk partials (fixed order => deterministic given partials)
@@ -731,41 +866,44 @@ hipError_t launch_vote_global(hipStream_t s, const float2* xy, const float* cent
     return hipGetLastError();
 }
 
-hipError_t launch_sort_packets(hipStream_t s, const float2* xy, int np, float2* sxy,
-                               uint32_t* nvalid)
+hipError_t launch_sort_packets(hipStream_t s, const float2* xy, int np, int ny, int pad,
+                               float2* sxy, uint32_t* nvalid, uint16_t* rowstart)
 {
     if (np <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_sort_packets, dim3(np), dim3(256), 0, s, xy, sxy, nvalid);
+    const size_t lds = (size_t)(ny + 2 * pad + 3) * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_sort_packets, dim3(np), dim3(256), lds, s, xy, ny, pad, sxy, nvalid,
+                       rowstart);
     return hipGetLastError();
 }
 
 hipError_t launch_plane_coef(hipStream_t s, const float* centers, const float* planes,
-                             const float2* sxy, const uint32_t* nvalid, int np, const Geom& g,
-                             const BandPlan& bp, PlaneCoef* coef, uint32_t* cuts)
+                             const uint16_t* rowstart, const uint32_t* nvalid, int np,
+                             const Geom& g, const BandPlan& bp, PlaneCoef* coef, uint32_t* cuts)
 {
     if (np <= 0) return hipSuccess;
     const size_t total = (size_t)np * g.nz;
     hipLaunchKernelGGL(k_plane_coef, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
-                       centers, planes, sxy, nvalid, np, g, bp, coef, cuts);
+                       centers, planes, rowstart, nvalid, np, g, bp, coef, cuts);
     return hipGetLastError();
 }
 
-template <int BLOCK>
+template <int BLOCK, bool PACKED>
 static hipError_t launch_vote_bands_t(hipStream_t s, const float2* sxy, const PlaneCoef* coef,
                                       const uint32_t* cuts, int np, const Geom& g,
                                       const BandPlan& bp, float* out)
 {
     static size_t configured = 0;
+    auto kern = PACKED ? &k_vote_bands_packed<BLOCK> : &k_vote_bands<BLOCK>;
     if (bp.lds_bytes > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vote_bands<BLOCK>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)bp.lds_bytes);
         if (e != hipSuccess) return e;
         configured = bp.lds_bytes;
     }
     const unsigned blocks = (unsigned)(bp.chunks * bp.bands) * (unsigned)g.nz;
-    hipLaunchKernelGGL(k_vote_bands<BLOCK>, dim3(blocks), dim3(BLOCK), bp.lds_bytes, s, sxy, coef,
-                       cuts, np, g, bp, out);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(BLOCK), bp.lds_bytes, s, sxy, coef, cuts, np, g, bp,
+                       out);
     return hipGetLastError();
 }
 
@@ -774,10 +912,18 @@ hipError_t launch_vote_bands(hipStream_t s, const float2* sxy, const PlaneCoef* 
                              float* out)
 {
     if (np <= 0) return hipSuccess;
+    if (bp.packed) {
+        switch (bp.block_threads) {
+        case 256: return launch_vote_bands_t<256, true>(s, sxy, coef, cuts, np, g, bp, out);
+        case 512: return launch_vote_bands_t<512, true>(s, sxy, coef, cuts, np, g, bp, out);
+        case 1024: return launch_vote_bands_t<1024, true>(s, sxy, coef, cuts, np, g, bp, out);
+        default: return hipErrorInvalidValue;
+        }
+    }
     switch (bp.block_threads) {
-    case 256: return launch_vote_bands_t<256>(s, sxy, coef, cuts, np, g, bp, out);
-    case 512: return launch_vote_bands_t<512>(s, sxy, coef, cuts, np, g, bp, out);
-    case 1024: return launch_vote_bands_t<1024>(s, sxy, coef, cuts, np, g, bp, out);
+    case 256: return launch_vote_bands_t<256, false>(s, sxy, coef, cuts, np, g, bp, out);
+    case 512: return launch_vote_bands_t<512, false>(s, sxy, coef, cuts, np, g, bp, out);
+    case 1024: return launch_vote_bands_t<1024, false>(s, sxy, coef, cuts, np, g, bp, out);
     default: return hipErrorInvalidValue;
     }
 }

@@ -47,7 +47,7 @@ class _MapperConfig(C.Structure):
 class _VoteInfo(C.Structure):
     _fields_ = [("algo", C.c_int), ("bands", C.c_int), ("band_rows", C.c_int),
                 ("chunks", C.c_int), ("block_threads", C.c_int), ("lds_bytes", C.c_size_t),
-                ("n_packets", C.c_size_t)]
+                ("n_packets", C.c_size_t), ("packed", C.c_int)]
 
 
 def library_path():
@@ -103,6 +103,7 @@ def load_library():
         "dsi_mapper_geometry": (C.c_int, [vp, f32p, f32p, intp, intp, intp]),
         "dsi_mapper_set_vote_algo": (C.c_int, [vp, C.c_int]),
         "dsi_mapper_set_band_params": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
+        "dsi_mapper_set_packed_lanes": (C.c_int, [vp, C.c_int]),
         "dsi_mapper_fill_voxel_grid": (C.c_int, [vp, f32p, f32p, C.c_size_t]),
         "dsi_batch_create": (C.c_int, [vp, u16p, u16p, C.c_size_t, u32p, f32p, C.c_size_t,
                                        C.POINTER(vp)]),
@@ -441,6 +442,9 @@ class MapperEMVS:
     def set_band_params(self, band_rows=0, chunks=0, block_threads=0):
         _check(load_library().dsi_mapper_set_band_params(self._h, int(band_rows), int(chunks),
                                                          int(block_threads)))
+
+    def set_packed_lanes(self, mode=-1):
+        _check(load_library().dsi_mapper_set_packed_lanes(self._h, int(mode)))
 
     def last_vote_info(self):
         info = _VoteInfo()

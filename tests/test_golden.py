@@ -79,9 +79,11 @@ def _close(got, ref, tol=DSI_TOL):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("algo", [1, 2])
+@pytest.mark.parametrize("algo", [1, 2, 3])
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p) for p in CASES])
 def test_hip_matches_golden(ctx, path, algo):
+    packed = 1 if algo == 3 else 0   # 3 = LDS bands with the packed lane mapping
+    algo = min(algo, 2)
     import dvs_mcemvs_amd as d
     g = load(path)
     shape = d.ShapeDSI(int(g["dimX"]), int(g["dimY"]), int(g["nz"]), float(g["dmin"]), float(g["dmax"]),
@@ -90,6 +92,7 @@ def test_hip_matches_golden(ctx, path, algo):
     for c in range(2):
         m = d.MapperEMVS(ctx, g["cam_t"], shape, lut=g["lut_arr"], inverse_depth=bool(g["inverse"]))
         m.set_vote_algo(algo)
+        m.set_packed_lanes(packed)
         assert np.array_equal(m.raw_depths_vec_, g["planes"])
         assert np.array_equal(np.array(m.virtual_cam_, np.float32), g["Kv"])
         x, y = g["x%d" % c].astype(np.uint16), g["y%d" % c].astype(np.uint16)

@@ -40,12 +40,14 @@ def random_packets(rng, n_packets, nx, ny, spread=0.3, cz_spread=0.5):
 
 
 def make_mapper(ctx, cam, nz, dmin, dmax, algo, dimX=0, dimY=0, fov=0.0, lut=None, inverse=False,
-                band=None):
+                band=None, packed=None):
     m = d.MapperEMVS(ctx, cam, d.ShapeDSI(dimX, dimY, nz, dmin, dmax, fov), lut=lut,
                      inverse_depth=inverse)
     m.set_vote_algo(algo)
     if band:
         m.set_band_params(*band)
+    if packed is not None:
+        m.set_packed_lanes(packed)
     return m
 
 
@@ -389,3 +391,26 @@ def test_fuse_into_equals_reference_sequence(ctx):
         assert np.array_equal(R.download(), orc.fuse2(a, g, op))
     with pytest.raises(d.DsiError):
         A.setToFusionOf(A, G, 2)
+
+
+@pytest.mark.parametrize("packed", [0, 1])
+@pytest.mark.parametrize("shape,band", [((64, 48, 16), None), ((346, 260, 12), (26, 4, 1024)),
+                                        ((130, 97, 7), (5, 3, 256)), ((70, 48, 9), (48, 2, 512)),
+                                        ((40, 30, 6), (9, 2, 256))])
+def test_both_lane_mappings_match_oracle(ctx, shape, band, packed):
+    """The per-packet and the packed-lane voting kernels are two mappings of the same work."""
+    nx, ny, nz = shape
+    rng = np.random.default_rng(300 + nx)
+    cam = (nx, ny, 0.8 * nx, 0.8 * nx, 0.5 * nx, 0.5 * ny)
+    m = make_mapper(ctx, cam, nz, 1.0, 6.5, d.VOTE_LDS_BANDS, band=band, packed=packed)
+    xy, centers = random_packets(rng, 70, nx, ny)     # > 64 packets: more than one wave group
+    xy[5 * 1024:6 * 1024] = np.nan                    # an entirely dead packet (run length 0)
+    xy[7 * 1024:8 * 1024, 1] = 3.25                   # one row: the whole packet in one band
+    centers[9] = (0.1, 0.1, m.raw_depths_vec_[0])     # d = 0 on every plane
+    centers[11] = (0.0, 0.0, 1e30)                    # |d| huge -> IEEE-divide path
+    ref = orc.fill_voxel_grid(xy, centers, m.raw_depths_vec_, np.array(m.virtual_cam_, np.float32),
+                              nx, ny)
+    m.fillVoxelGrid(xy, centers)
+    assert m.last_vote_info()["packed"] == packed
+    assert_dsi_close(m.dsi_.download(), ref)
+    m.close()
