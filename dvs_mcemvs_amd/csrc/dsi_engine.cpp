@@ -169,7 +169,7 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
     const size_t row_bytes = (size_t)g.nx * sizeof(unsigned long long);  // Q33.31 LDS accumulators
     const long max_rows_total = (long)(dsi::max_dynamic_lds() / row_bytes);
     if (max_rows_total < 3 || g.nx < 2 || g.ny < 2 || g.ny > 16000) return false;
-    long max_owned = max_rows_total - 2;
+    long max_owned = max_rows_total - 2;  // two halo rows
     if (m->want_band_rows > 0) {
         max_owned = std::min<long>(max_owned, m->want_band_rows);
     } else {

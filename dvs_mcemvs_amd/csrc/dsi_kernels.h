@@ -36,7 +36,7 @@ struct BandPlan {
     int block_threads;  // 256 / 512 / 1024
     int packed;         // 1: k_vote_bands_packed (short runs), 0: k_vote_bands
     int row_pad;        // z0 rows binned over [-row_pad, ny + row_pad) by k_sort_packets
-    size_t lds_bytes;   // (band_rows + 2) * nx * 8 (u64 fixed-point accumulators)
+    size_t lds_bytes;   // (band_rows + 2) * nx * 8 (u64 fixed-point accumulators, 2 halo rows)
 };
 
 // ---- stage A ---------------------------------------------------------------

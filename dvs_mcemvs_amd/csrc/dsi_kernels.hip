@@ -287,11 +287,14 @@ __global__ __launch_bounds__(256) void k_plane_coef(const float* __restrict__ ce
                                                     PlaneCoef* __restrict__ coef,
                                                     uint32_t* __restrict__ cuts)
 {
-    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= (size_t)np * g.nz) return;
-    // packet index fastest: the plane-major tables (coef[z][p], cuts[band][z][p]) are written
-    // coalesced, and a voting workgroup (fixed z, band) later streams through them
-    const int z = (int)(tid / np), k = (int)(tid % np);
+    // a block covers a tile of 16 packets x 16 planes: 16 consecutive packets per plane make
+    // the plane-major tables (coef[z][p], cuts[band][z][p]) 64-byte coalesced writes, and the 16
+    // planes of a packet re-read the same rowstart table out of cache
+    const int tiles_p = (np + 15) / 16;
+    const int k = (int)(blockIdx.x % tiles_p) * 16 + (threadIdx.x & 15);
+    const int z = (int)(blockIdx.x / tiles_p) * 16 + (threadIdx.x >> 4);
+    if (k >= np || z >= g.nz) return;
+    const size_t tid = (size_t)z * np + k;
     PlaneCoef c;
     plane_coefficients(centers[3 * k], centers[3 * k + 1], centers[3 * k + 2], planes[z], g, c.a,
                        c.bx, c.by, c.d);
@@ -314,6 +317,7 @@ __global__ __launch_bounds__(256) void k_plane_coef(const float* __restrict__ ce
     // the inversion is ill-conditioned -- then the whole packet is the (superset) run
     const double a = (double)c.a, d = (double)c.d, by = (double)c.by;
     const bool invertible = !dead && !slow && fabs(a) > 1e-3 * fabs(d);
+    const double inv_a = 1.0 / a, by_a = by * inv_a, d_a = d * inv_a;  // y0 = Y * d_a - by_a
     for (int j = 0; j < bp.bands; ++j) {
         uint32_t lo = 0, hi = 0;
         if (!dead) {
@@ -323,12 +327,12 @@ __global__ __launch_bounds__(256) void k_plane_coef(const float* __restrict__ ce
                 const int r1 = min(g.ny, r0 + bp.band_rows);
                 // accepted iff 0 <= Y < ny-1; the band needs floor(Y) in [r0-1, r1-1]
                 const double L = (double)max(r0 - 1, 0) - 0.01, U = (double)min(r1, g.ny - 1) + 0.01;
-                const double ya = (L * d - by) / a, yb = (U * d - by) / a;
+                const double ya = L * d_a - by_a, yb = U * d_a - by_a;
                 double ymin = fmin(ya, yb), ymax = fmax(ya, yb);
                 if (ymin == ymin && ymax == ymax) {  // not NaN
                     // the fp32 forward map (mul, add, divide) is within a few ulps of the real
                     // one: in y0 units that is ~2^-22 * (|y0| + |by/a|); widen by 40x that
-                    const double m = 1e-5 * (fmax(fabs(ymin), fabs(ymax)) + fabs(by / a));
+                    const double m = 1e-5 * (fmax(fabs(ymin), fabs(ymax)) + fabs(by_a));
                     ymin -= m;
                     ymax += m;
                     const double fa = fmin(fmax(floor(ymin), (double)(-pad - 1)), (double)(g.ny + pad));
@@ -349,26 +353,44 @@ __global__ __launch_bounds__(256) void k_plane_coef(const float* __restrict__ ce
 //     coefficients in SGPRs, and the owned rows [r0, r1) are written back with plain
 //     coalesced stores -- no global atomics, no memset.
 //
-//     LDS accumulators are 64-bit fixed point (Q33.31), voted with ds_add_u64.
-//     Measured on gfx950 (tools/lds_atomic_bench.hip): ds_add_f32 takes ~194 cycles per
-//     wave instruction for distinct addresses (lanes serialised), ds_add_u64 ~12-15.
-//     A weight w = fl(fx*fy) in [0,1] is added as trunc(w * 2^31): exact for
-//     w >= 2^-8, off by < 2^-31 below, so a voxel holds the EXACT sum of its fp32
-//     weights (to 5e-10 per vote), independent of vote order, and is rounded to fp32
-//     once at write-back.  (The CPU reference rounds after every += instead.)
-//
 //     Block b runs on XCD b % 8 (observed dispatch rule): the blocks of one XCD walk
 //     the planes of ONE (chunk, band) pair at a time, so its events stream through
 //     that XCD's L2 once instead of once per plane.
+// LDS accumulators are 64-bit fixed point (Q33.31), voted with ds_add_u64 (no return).
+// Measured on gfx950 (tools/lds_atomic_bench2.hip, cycles per wave instruction, random band
+// addresses): ds_add_f32 ~185 (lanes serialised), ds_add_u64 ~11, ds_add_u32 ~6.5.  A 32-bit
+// Q8.24 word + carry counter was tried (needs the returning form to detect wraps): the wait
+// for the returned value cost more than the cheaper atomic saved (3.5 vs 4.3 Gev/s).
+// A weight w = fl(fx*fy) in [0,1] is added as trunc(w * 2^31): exact for w >= 2^-8, off by
+// < 2^-31 below, so a voxel holds the EXACT sum of its fp32 weights (to 5e-10 per vote),
+// independent of vote order, and is rounded to fp32 once at write-back.  (The CPU reference
+// rounds after every += instead.)
 using acc_t = unsigned long long;
 constexpr float kFixScale = 2147483648.f;      // 2^31
 constexpr double kFixInv = 1.0 / 2147483648.0;  // 2^-31
 
-__device__ __forceinline__ void lds_vote(acc_t* cell, float w_scaled)
+// the four bilinear votes of one event (cartesian3dgrid.h:261-270) into the band
+__device__ __forceinline__ void vote4(acc_t* __restrict__ band, int idx, int nx, float fx, float fy)
 {
-    // w_scaled = w * 2^31 <= 2^31 fits u32; the high dword of the addend is 0
-    const acc_t v = (acc_t)(unsigned int)w_scaled;
-    __hip_atomic_fetch_add(cell, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const float fx1 = 1.f - fx, fy1 = 1.f - fy;
+    // scaling one factor by 2^31 scales the rounded product exactly; w * 2^31 <= 2^31 fits u32,
+    // the high dword of the addend is 0
+    const float fxs = fx * kFixScale, fx1s = fx1 * kFixScale;
+    acc_t* cell = band + idx;
+    __hip_atomic_fetch_add(cell, (acc_t)(unsigned int)(fx1s * fy1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(cell + 1, (acc_t)(unsigned int)(fxs * fy1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(cell + nx, (acc_t)(unsigned int)(fx1s * fy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(cell + nx + 1, (acc_t)(unsigned int)(fxs * fy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// owned rows of the band -> fp32 volume (a linear, coalesced copy)
+template <int BLOCK>
+__device__ __forceinline__ void flush_band(const acc_t* __restrict__ band, int nx, int n_out,
+                                           float* __restrict__ dst)
+{
+    const acc_t* src = band + nx;  // skip the top halo row
+    for (int i = threadIdx.x; i < n_out; i += BLOCK)
+        dst[i] = (float)((double)src[i] * kFixInv);  // < 2^53: exact in f64, one rounding to f32
 }
 
 template <int BLOCK>
@@ -378,7 +400,7 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands(const float2* __restrict__
                                                       Geom g, BandPlan bp,
                                                       float* __restrict__ out)
 {
-    extern __shared__ acc_t lds[];
+    extern __shared__ acc_t band[];
     // block -> (pair q = (chunk, band), plane z).  Groups of 8 pairs: XCD x (= block % 8) walks
     // the planes of pair 8k + x.  The last (pairs % 8) pairs are dealt plane by plane over all
     // XCDs so that no XCD idles (their events then stream through every L2).
@@ -399,9 +421,8 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands(const float2* __restrict__
     const int r0 = j * bp.band_rows;
     const int r1 = min(g.ny, r0 + bp.band_rows);
     const int nx = g.nx;
-    const int lds_elems = (r1 - r0 + 2) * nx;
-
-    for (int i = threadIdx.x; i < lds_elems; i += BLOCK) lds[i] = 0;
+    const int cells = (r1 - r0 + 2) * nx;
+    for (int i = threadIdx.x; i < cells; i += BLOCK) band[i] = 0;
     __syncthreads();
 
     const int p_begin = (int)(((long long)np * c) / bp.chunks);
@@ -467,18 +488,12 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands(const float2* __restrict__
                         X = div_rc(nxv, kd, kr);
                         Y = div_rc(nyv, kd, kr);
                     }
-                    // cartesian3dgrid.h:255-259 restricted to this band's rows
+                    // cartesian3dgrid.h:255-259 restricted to this band's rows.  (Voting rejected
+                    // events into a spare cell instead of branching was tried: 12 % slower.)
                     if (X >= 0.f && X < xmax && Y >= L && Y < U) {
                         const float xf = __builtin_floorf(X), yf = __builtin_floorf(Y);
-                        const float fx = X - xf, fy = Y - yf, fx1 = 1.f - fx, fy1 = 1.f - fy;
-                        // scaling one factor by 2^31 scales the rounded product exactly
-                        const float fxs = fx * kFixScale, fx1s = fx1 * kFixScale;
                         const int idx = __mul24((int)yf - row_base, nx) + (int)xf;
-                        acc_t* cell = lds + idx;
-                        lds_vote(cell, fx1s * fy1);         // g[0]      += fx1*fy1  (:267)
-                        lds_vote(cell + 1, fxs * fy1);      // g[1]      += fx*fy1
-                        lds_vote(cell + nx, fx1s * fy);     // g[Nx]     += fx1*fy
-                        lds_vote(cell + nx + 1, fxs * fy);  // g[Nx+1]   += fx*fy
+                        vote4(band, idx, nx, X - xf, Y - yf);  // cartesian3dgrid.h:261-270
                     }
                 }
                 e = en;
@@ -494,10 +509,7 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands(const float2* __restrict__
     // owned rows are contiguous in the [z][y][x] volume: a linear coalesced copy
     const size_t vol = (size_t)g.nx * g.ny * g.nz;
     float* __restrict__ dst = out + (size_t)c * vol + ((size_t)z * g.ny + r0) * nx;
-    const acc_t* src = lds + nx;  // skip the top halo row
-    const int n_out = (r1 - r0) * nx;
-    for (int i = threadIdx.x; i < n_out; i += BLOCK)
-        dst[i] = (float)((double)src[i] * kFixInv);  // < 2^53: exact in f64, one rounding to f32
+    flush_band<BLOCK>(band, nx, (r1 - r0) * nx, dst);
 }
 
 // (3b) the same work item decomposition for SHORT runs (tall or wide grids: a band of a
@@ -512,7 +524,7 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const float2* __res
                                                              int np, Geom g, BandPlan bp,
                                                              float* __restrict__ out)
 {
-    extern __shared__ acc_t lds[];
+    extern __shared__ acc_t band[];
     const int b = blockIdx.x;
     const int pairs = bp.chunks * bp.bands;
     const int full = (pairs / 8) * 8 * g.nz;
@@ -530,8 +542,8 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const float2* __res
     const int r0 = j * bp.band_rows;
     const int r1 = min(g.ny, r0 + bp.band_rows);
     const int nx = g.nx;
-    const int lds_elems = (r1 - r0 + 2) * nx;
-    for (int i = threadIdx.x; i < lds_elems; i += BLOCK) lds[i] = 0;
+    const int cells = (r1 - r0 + 2) * nx;
+    for (int i = threadIdx.x; i < cells; i += BLOCK) band[i] = 0;
     __syncthreads();
 
     const int p_begin = (int)(((long long)np * c) / bp.chunks);
@@ -550,39 +562,60 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const float2* __res
     const uint4* __restrict__ coef4 = reinterpret_cast<const uint4*>(coef) + 2 * (size_t)z * np;
     const uint32_t* __restrict__ cutz = cuts + ((size_t)j * g.nz + z) * np;
 
-    // lane state of the batch being filled
-    float2 e = make_float2(0.f, 0.f);
-    uint4 ca = make_uint4(0, 0, 0, 0);  // a, bx, by, d
-    uint2 cb = make_uint2(0, 0);        // r, flags
+    // Lane state.  While a batch is being FILLED a lane only records which event it will take
+    // (packet index + position in the grouped packet).  When the 64 lanes are full the wave
+    // issues the three gathers of that batch (event, coefficients) and, while they are in
+    // flight, votes the PREVIOUS batch whose data was requested one batch earlier.
+    int f_pk = 0, f_ev = 0;  // batch being filled: packet, event slot
+    // two register sets that alternate between "in flight" and "being voted" (no copies)
+    float2 eA = make_float2(0.f, 0.f), eB = eA;        // event location at z0
+    uint4 caA = make_uint4(0, 0, 0, 0), caB = caA;     // a, bx, by, d
+    uint2 cbA = make_uint2(0, 0), cbB = cbA;           // r, flags
+    int inflight = 0;  // lanes of the batch in flight (0 = none)
+    int phase = 0;     // 0: next gathers go to set A, the batch in flight sits in set B
     int fill = 0;
 
-    auto vote_batch = [&](int n_active) {
-        if (lane < n_active) {
-            const float ka = __uint_as_float(ca.x), kbx = __uint_as_float(ca.y);
-            const float kby = __uint_as_float(ca.z), kd = __uint_as_float(ca.w);
-            const float kr = __uint_as_float(cb.x);
-            const float nxv = e.x * ka + kbx;  // mapper_emvs_stereo.cpp:194-195
-            const float nyv = e.y * ka + kby;
-            float X, Y;
-            if (cb.y & kCoefSlow) {  // rare; per lane
-                X = nxv / kd;
-                Y = nyv / kd;
-            } else {
-                X = div_rc(nxv, kd, kr);
-                Y = div_rc(nyv, kd, kr);
-            }
-            if (X >= 0.f && X < xmax && Y >= L && Y < U) {
-                const float xf = __builtin_floorf(X), yf = __builtin_floorf(Y);
-                const float fx = X - xf, fy = Y - yf, fx1 = 1.f - fx, fy1 = 1.f - fy;
-                const float fxs = fx * kFixScale, fx1s = fx1 * kFixScale;
-                const int idx = __mul24((int)yf - row_base, nx) + (int)xf;
-                acc_t* cell = lds + idx;
-                lds_vote(cell, fx1s * fy1);
-                lds_vote(cell + 1, fxs * fy1);
-                lds_vote(cell + nx, fx1s * fy);
-                lds_vote(cell + nx + 1, fxs * fy);
-            }
+    auto vote_batch = [&](int n_active, float2 ev, uint4 va, uint2 vb) {
+        const float ka = __uint_as_float(va.x), kbx = __uint_as_float(va.y);
+        const float kby = __uint_as_float(va.z), kd = __uint_as_float(va.w);
+        const float kr = __uint_as_float(vb.x);
+        const float nxv = ev.x * ka + kbx;  // mapper_emvs_stereo.cpp:194-195
+        const float nyv = ev.y * ka + kby;
+        float X, Y;
+        // |d| outside [2^-40, 2^40] somewhere in the wave (rare): everybody takes the IEEE
+        // divide, which equals the residual-corrected one wherever that is valid
+        if (__builtin_amdgcn_ballot_w64((vb.y & kCoefSlow) != 0 && lane < n_active) != 0) {
+            X = nxv / kd;
+            Y = nyv / kd;
+        } else {
+            X = div_rc(nxv, kd, kr);
+            Y = div_rc(nyv, kd, kr);
         }
+        // cartesian3dgrid.h:255-259 restricted to this band's rows
+        if (lane < n_active && X >= 0.f && X < xmax && Y >= L && Y < U) {
+            const float xf = __builtin_floorf(X), yf = __builtin_floorf(Y);
+            const int idx = __mul24((int)yf - row_base, nx) + (int)xf;
+            vote4(band, idx, nx, X - xf, Y - yf);  // cartesian3dgrid.h:261-270
+        }
+    };
+    // the filled batch becomes the batch in flight; the previous one is voted meanwhile
+    auto gather = [&](int n_new, float2& ev, uint4& va, uint2& vb) {
+        if (lane < n_new) {
+            ev = sxy[(size_t)f_pk * kPacket + f_ev];
+            va = coef4[2 * (size_t)f_pk];
+            vb = *reinterpret_cast<const uint2*>(coef4 + 2 * (size_t)f_pk + 1);
+        }
+    };
+    auto rotate = [&](int n_new) {
+        if (phase == 0) {
+            gather(n_new, eA, caA, cbA);
+            if (inflight > 0) vote_batch(inflight, eB, caB, cbB);
+        } else {
+            gather(n_new, eB, caB, cbB);
+            if (inflight > 0) vote_batch(inflight, eA, caA, cbA);
+        }
+        inflight = n_new;
+        phase ^= 1;
     };
 
     for (int pg = p_begin + wave * group; pg < p_end; pg += stride) {
@@ -599,27 +632,30 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const float2* __res
                 const int take = min(kWave - fill, hi - off);
                 const int rel = lane - fill;
                 if ((unsigned)rel < (unsigned)take) {
-                    e = sxy[(size_t)p * kPacket + off + rel];
-                    ca = coef4[2 * (size_t)p];
-                    cb = *reinterpret_cast<const uint2*>(coef4 + 2 * (size_t)p + 1);
+                    f_pk = p;
+                    f_ev = off + rel;
                 }
                 fill += take;
                 off += take;
                 if (fill == kWave) {
-                    vote_batch(kWave);
+                    rotate(kWave);
                     fill = 0;
                 }
             }
         }
     }
-    if (fill > 0) vote_batch(fill);
+    if (fill > 0) rotate(fill);
+    if (inflight > 0) {
+        if (phase == 0)
+            vote_batch(inflight, eB, caB, cbB);
+        else
+            vote_batch(inflight, eA, caA, cbA);
+    }
     __syncthreads();
 
     const size_t vol = (size_t)g.nx * g.ny * g.nz;
     float* __restrict__ dst = out + (size_t)c * vol + ((size_t)z * g.ny + r0) * nx;
-    const acc_t* src = lds + nx;
-    const int n_out = (r1 - r0) * nx;
-    for (int i = threadIdx.x; i < n_out; i += BLOCK) dst[i] = (float)((double)src[i] * kFixInv);
+    flush_band<BLOCK>(band, nx, (r1 - r0) * nx, dst);
 }
 
 // (4) DSI = sum of the chunk partials (fixed order => deterministic given partials)
@@ -881,9 +917,9 @@ hipError_t launch_plane_coef(hipStream_t s, const float* centers, const float* p
                              const Geom& g, const BandPlan& bp, PlaneCoef* coef, uint32_t* cuts)
 {
     if (np <= 0) return hipSuccess;
-    const size_t total = (size_t)np * g.nz;
-    hipLaunchKernelGGL(k_plane_coef, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
-                       centers, planes, rowstart, nvalid, np, g, bp, coef, cuts);
+    const unsigned tiles = (unsigned)((np + 15) / 16) * (unsigned)((g.nz + 15) / 16);
+    hipLaunchKernelGGL(k_plane_coef, dim3(tiles), dim3(256), 0, s, centers, planes, rowstart, nvalid,
+                       np, g, bp, coef, cuts);
     return hipGetLastError();
 }
 
