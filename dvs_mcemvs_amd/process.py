@@ -5,6 +5,8 @@ engine kernel.
 
     process_1   mapper_emvs_stereo/src/process1.cpp:28-224
     process_2   mapper_emvs_stereo/src/process2.cpp:28-302
+    process_5   mapper_emvs_stereo/src/process5.cpp:28-260  (process_2 with the right camera's
+                sub-intervals circularly shifted by num_subintervals/2)
 """
 import numpy as np
 
@@ -68,11 +70,30 @@ def process_1(mappers, events, trajectories, mapper_fused, ts, fusion_method, rv
     return T_rv_w
 
 
+def shuffled_subintervals(n_events, num_subintervals):
+    """Index arrays of the right camera's sub-intervals in process_5 (process5.cpp:89-93,
+    :136-150): start at shift*per with shift = n/2, wrap around the END OF THE EVENT VECTOR
+    (not per*n), so a wrapped sub-interval is the tail followed by the head."""
+    per = int(n_events) // int(num_subintervals)
+    idx = (int(num_subintervals) // 2) * per
+    out = []
+    for _ in range(int(num_subintervals)):
+        if idx + per >= n_events:
+            sel = np.concatenate([np.arange(idx, n_events), np.arange(0, idx + per - n_events)])
+            idx = idx + per - n_events
+        else:
+            sel = np.arange(idx, idx + per)
+            idx += per
+        out.append(sel)
+    return out
+
+
 def process_2(ctx, cams, dsi_shape, events, trajectories, num_subintervals, mapper_fused,
               mapper_fused_camera_time, ts, stereo_fusion, temporal_fusion, luts=(None, None),
-              inverse_depth=False):
+              inverse_depth=False, shuffle_right=False):
     """Alg. 2: per sub-interval camera fusion, then temporal fusion; and the converse order
-    (process2.cpp:46-289).  Returns dict with the left / right temporal DSIs (Grid3D)."""
+    (process2.cpp:46-289).  shuffle_right=True is process_5.  Returns dict with the left / right
+    temporal DSIs (Grid3D)."""
     mapper0 = E.MapperEMVS(ctx, cams[0], dsi_shape, lut=luts[0], inverse_depth=inverse_depth)
     mapper1 = E.MapperEMVS(ctx, cams[1], dsi_shape, lut=luts[1], inverse_depth=inverse_depth)
     dims = mapper0.dsi_.getDimensions()
@@ -82,9 +103,12 @@ def process_2(ctx, cams, dsi_shape, events, trajectories, num_subintervals, mapp
     T_rv_w = reference_view_process2(trajectories[0], ts)
     per = [int(events[c][0].shape[0]) // int(num_subintervals) for c in range(2)]   # :46-47
     mapper_fused.dsi_.resetGrid()                                                    # :90
+    right_sel = shuffled_subintervals(events[1][0].shape[0], num_subintervals) if shuffle_right else None
     for k in range(num_subintervals):
         for c, m in ((0, mapper0), (1, mapper1)):
             sl = slice(k * per[c], (k + 1) * per[c])                                 # :105-107, :132-134
+            if c == 1 and right_sel is not None:
+                sl = right_sel[k]                                                    # process5.cpp:136-150
             m.dsi_.resetGrid()
             m.evaluateDSI(tuple(a[sl] for a in events[c]), trajectories[c], T_rv_w)  # :119, :146
         sub.resetGrid()                                                              # :159
@@ -116,3 +140,9 @@ def process_2(ctx, cams, dsi_shape, events, trajectories, num_subintervals, mapp
     mapper1.close()
     sub.close()
     return {"left": left, "right": right, "T_rv_w": T_rv_w}
+
+
+def process_5(*args, **kw):
+    """process5.cpp:28-260: process_2 with the right camera's sub-intervals circularly shifted."""
+    kw["shuffle_right"] = True
+    return process_2(*args, **kw)

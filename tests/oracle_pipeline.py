@@ -101,17 +101,30 @@ def oracle_process_1(make_mapper, events, trajectories, ts, fusion_method, rv_po
     return dsis, fused
 
 
-def oracle_process_2(make_mapper, events, trajectories, n_sub, ts, stereo_fusion, temporal_fusion):
-    """process2.cpp:46-289 -> dict(left, right, fused, camera_time)."""
+def oracle_process_2(make_mapper, events, trajectories, n_sub, ts, stereo_fusion, temporal_fusion,
+                     shuffle_right=False):
+    """process2.cpp:46-289 (process5.cpp when shuffle_right) -> dict(left, right, fused, camera_time)."""
     from dvs_mcemvs_amd import synthetic as syn
     T_rv_w = syn.pose_inverse(orc.pose_at(trajectories[0][0], trajectories[0][1], ts))
     per = [events[c][0].shape[0] // n_sub for c in range(2)]
     zero = np.zeros_like(make_mapper().dsi)
     left, right, fused = zero.copy(), zero.copy(), zero.copy()
+    right_sel = None
+    if shuffle_right:  # process5.cpp:89-93, :136-150
+        n1, idx, right_sel = events[1][0].shape[0], (n_sub // 2) * per[1], []
+        for _ in range(n_sub):
+            if idx + per[1] >= n1:
+                right_sel.append(np.concatenate([np.arange(idx, n1), np.arange(0, idx + per[1] - n1)]))
+                idx = idx + per[1] - n1
+            else:
+                right_sel.append(np.arange(idx, idx + per[1]))
+                idx += per[1]
     for k in range(n_sub):
         d = []
         for c in range(2):
             sl = slice(k * per[c], (k + 1) * per[c])
+            if c == 1 and right_sel is not None:
+                sl = right_sel[k]
             m = make_mapper()
             m.evaluateDSI(tuple(a[sl] for a in events[c]), trajectories[c], T_rv_w)
             d.append(m.dsi.copy())

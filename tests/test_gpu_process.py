@@ -60,3 +60,26 @@ def test_process_2(ctx, stereo_fusion, temporal_fusion):
     close(cam_time.dsi_.download(), ref["camera_time"], 4e-4)
     fused.close()
     cam_time.close()
+
+
+def test_process_5_shuffled_right_camera(ctx):
+    """process5.cpp: right-camera sub-intervals start at n/2 and wrap around the event vector."""
+    rig = syn.stereo_rig(18000 + 37, width=64, height=48, duration=0.3, seed=43)   # remainder != 0
+    shape = d.ShapeDSI(0, 0, 12, 4.0, 150.0, 0.0)
+    fused = d.MapperEMVS(ctx, rig["cam"], shape)
+    cam_time = d.MapperEMVS(ctx, rig["cam"], shape)
+    ts = rig["t0"] + 0.15
+    out = process.process_5(ctx, [rig["cam"]] * 2, shape, rig["events"], rig["trajectories"], 4, fused,
+                            cam_time, ts, 2, 2)
+    ref = oracle_process_2(lambda: OracleMapper(rig["cam"], dimZ=12, min_depth=4.0, max_depth=150.0),
+                           rig["events"], rig["trajectories"], 4, ts, 2, 2, shuffle_right=True)
+    plain = oracle_process_2(lambda: OracleMapper(rig["cam"], dimZ=12, min_depth=4.0, max_depth=150.0),
+                             rig["events"], rig["trajectories"], 4, ts, 2, 2)
+    close(out["right"].download(), ref["right"])
+    close(fused.dsi_.download(), ref["fused"])
+    assert np.abs(ref["fused"] - plain["fused"]).max() > 1e-3   # the shuffle really changes the result
+    sel = process.shuffled_subintervals(18037, 4)
+    assert sel[0][0] == 2 * (18037 // 4) and len(sel[1]) == 18037 // 4
+    assert any(s[-1] < s[0] for s in sel)                       # one sub-interval wraps: tail then head
+    fused.close()
+    cam_time.close()

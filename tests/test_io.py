@@ -1,0 +1,61 @@
+"""On-disk formats: .npy DSI dump, depth-points text, ROSBAG v2 pose reader."""
+import os
+
+import numpy as np
+import pytest
+
+from dvs_mcemvs_amd import io
+
+REF_BAG = "/root/reference/data/DSEC/zurich_city_04-odometry/pose.bag"
+
+
+def test_grid_npy_layout(tmp_path):
+    vol = np.arange(2 * 3 * 4, dtype=np.float32).reshape(2, 3, 4)   # [Z][Y][X]
+    shape = io.write_grid_npy(tmp_path / "dsi.npy", vol)
+    assert shape == (2, 3, 4)                       # cartesian3dgrid_IO.cpp:33: {size_[2], size_[1], size_[0]}
+    back = np.load(tmp_path / "dsi.npy")
+    assert back.dtype == np.float32 and back.flags["C_CONTIGUOUS"] and np.array_equal(back, vol)
+    # the reference's viewers index dsi[z, y, x] (scripts/visualize_dsi_*.py)
+    assert back[1, 2, 3] == vol.reshape(-1)[3 + 4 * (2 + 3 * 1)]   # volume[x + dimX*(y + dimY*z)]
+
+
+def test_depth_points_text(tmp_path):
+    depth = np.array([[1.5, 2.25, 0.0], [123.456789, 0.0, 7.0]], np.float32)
+    mask = np.array([[1, 0, 0], [1, 0, 1]], np.uint8)
+    n = io.save_depth_points(tmp_path / "pts.txt", depth, mask)
+    assert n == 3
+    lines = open(tmp_path / "pts.txt").read().splitlines()
+    assert lines == ["0 0 1.5", "0 1 123.457", "2 1 7"]   # "col row depth", 6 significant digits
+
+
+def test_pose_bag_round_trip(tmp_path):
+    rng = np.random.default_rng(0)
+    times = 100.0 + np.sort(rng.uniform(0, 5, 40))
+    q = rng.normal(size=(40, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    poses = np.concatenate([rng.normal(size=(40, 3)), q], axis=1)
+    io.write_pose_bag(tmp_path / "pose.bag", times, poses, topic="/pose")
+    t, p = io.read_pose_bag(tmp_path / "pose.bag", topic="/pose")
+    assert np.allclose(t, times, atol=1e-9) and np.allclose(p, poses, atol=0)
+    t2, _ = io.read_pose_bag(tmp_path / "pose.bag", topic="/other")
+    assert t2.shape[0] == 0
+    with pytest.raises(ValueError):
+        open(tmp_path / "junk.bag", "wb").write(b"not a bag")
+        io.read_pose_bag(tmp_path / "junk.bag")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BAG), reason="reference checkout not present on this box")
+def test_reads_the_reference_dsec_odometry_bag():
+    """The only real data in the reference repo: LiDAR-IMU odometry of
+    DSEC zurich_city_04, 6205 PoseStamped at ~9.92 Hz over 625.7 s, median speed 3.6 m/s."""
+    t, p = io.read_pose_bag(REF_BAG, topic="/pose")
+    assert t.shape[0] == 6205
+    assert t[-1] - t[0] == pytest.approx(625.7, abs=0.1)
+    assert np.median(np.diff(t)) == pytest.approx(1 / 9.92, rel=0.02)
+    assert np.abs(np.linalg.norm(p[:, 3:], axis=1) - 1).max() < 1e-5
+    speed = np.linalg.norm(np.diff(p[:, :3], axis=0), axis=1) / np.diff(t)
+    assert np.median(speed) == pytest.approx(3.6, abs=0.1)
+    # the engine's trajectory interpolation accepts it (cfg/DSEC/zurich_04_a_full/dsec.conf:13-14 window)
+    import dvs_mcemvs_amd as d
+    T = d.pose_at((t - t[0], p), 12.5)
+    assert T is not None and abs(np.linalg.norm(T[3:]) - 1) < 1e-5
