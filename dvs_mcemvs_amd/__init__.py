@@ -25,6 +25,7 @@ from .engine import (  # noqa: F401
     EventBatch,
     Grid3D,
     MapperEMVS,
+    OptionsDepthMap,
     ShapeDSI,
     device_count,
     library_path,
@@ -34,7 +35,7 @@ from .engine import (  # noqa: F401
 )
 
 __all__ = [
-    "Context", "Grid3D", "MapperEMVS", "ShapeDSI", "EventBatch", "DsiError", "device_count",
+    "Context", "Grid3D", "MapperEMVS", "ShapeDSI", "OptionsDepthMap", "EventBatch", "DsiError", "device_count",
     "library_path", "load_library", "packetize", "pose_at", "PACKET_SIZE",
     "FUSE_MIN", "FUSE_HM", "FUSE_GM", "FUSE_AM", "FUSE_RMS", "FUSE_MAX", "ACC_SUM", "ACC_INV_SUM",
     "VOTE_AUTO", "VOTE_GLOBAL_ATOMIC", "VOTE_LDS_BANDS",

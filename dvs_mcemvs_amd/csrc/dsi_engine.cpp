@@ -121,7 +121,8 @@ struct dsi_mapper {
     DevBuf<uint32_t> nvalid, cuts;
     DevBuf<uint16_t> rowstart;
     DevBuf<dsi::PlaneCoef> coef;
-    DevBuf<uint8_t> idx;
+    DevBuf<uint8_t> idx, conf8, mask, idx_filtered;
+    DevBuf<uint32_t> minmax;
     bool depth_valid = false;
     // HIP-event stopwatch around the dominant (voting) kernel, for bench.py's roofline
     bool timing = false;
@@ -671,6 +672,10 @@ int dsi_mapper_destroy(dsi_mapper_t* m)
     m->cuts.release();
     m->coef.release();
     m->idx.release();
+    m->conf8.release();
+    m->mask.release();
+    m->idx_filtered.release();
+    m->minmax.release();
     for (auto& pr : m->timing_pairs) {
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
@@ -937,6 +942,41 @@ int dsi_mapper_vote_kernel_time(dsi_mapper_t* m, float* total_ms, int* launches)
     m->timing_pairs.clear();
     *total_ms = total;
     *launches = n;
+    return DSI_OK;
+}
+
+int dsi_mapper_get_depth_map_from_dsi(dsi_mapper_t* m, dsi_grid_t* g, const dsi_depthmap_options_t* opts,
+                                      float* depth_host, float* conf_host, uint8_t* mask_host,
+                                      uint8_t* idx_filtered_host)
+{
+    REQUIRE(m && opts, DSI_ERR_INVALID, "null argument");
+    REQUIRE(opts->adaptive_threshold_kernel_size >= 1 && (opts->adaptive_threshold_kernel_size & 1) &&
+                opts->adaptive_threshold_kernel_size <= 63,
+            DSI_ERR_INVALID, "adaptive_threshold_kernel_size must be odd and in 1..63");
+    REQUIRE(opts->median_filter_size >= 1 && (opts->median_filter_size & 1) && opts->median_filter_size <= 31,
+            DSI_ERR_INVALID, "median_filter_size must be odd and in 1..31 (median_filtering.cpp:44)");
+    if (!g) g = m->grid;
+    if (int rc = dsi_mapper_depth_map_of(m, g)) return rc;  // collapseMaxZSlice, :368
+    dsi_context* ctx = m->ctx;
+    const int nx = m->geom.nx, ny = m->geom.ny;
+    const size_t npix = (size_t)nx * ny;
+    HIP_TRY(m->conf8.reserve(npix));
+    HIP_TRY(m->mask.reserve(npix));
+    HIP_TRY(m->idx_filtered.reserve(npix));
+    HIP_TRY(m->minmax.reserve(2));
+    HIP_TRY(dsi::launch_depth_map_filters(ctx->stream, m->conf.p, m->idx.p, nx, ny,
+                                          opts->adaptive_threshold_kernel_size, opts->adaptive_threshold_c,
+                                          opts->median_filter_size, opts->max_confidence, m->planes_dev,
+                                          m->minmax.p, m->conf8.p, m->mask.p, m->idx_filtered.p, m->depth.p));
+    if (depth_host)
+        HIP_TRY(hipMemcpyAsync(depth_host, m->depth.p, npix * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (conf_host)
+        HIP_TRY(hipMemcpyAsync(conf_host, m->conf.p, npix * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (mask_host) HIP_TRY(hipMemcpyAsync(mask_host, m->mask.p, npix, hipMemcpyDeviceToHost, ctx->stream));
+    if (idx_filtered_host)
+        HIP_TRY(hipMemcpyAsync(idx_filtered_host, m->idx_filtered.p, npix, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    m->depth_valid = false;  // m->depth now holds the filtered map, m->conf has (0,0) overwritten
     return DSI_OK;
 }
 

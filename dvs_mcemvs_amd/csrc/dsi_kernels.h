@@ -68,6 +68,10 @@ hipError_t launch_accumulate(hipStream_t s, float* acc, const float* g, size_t n
 hipError_t launch_finalize(hipStream_t s, float* acc, size_t n, int mode, int n_maps);
 hipError_t launch_collapse_max_z(hipStream_t s, const float* dsi, int nx, int ny, int nz,
                                  float* conf, uint8_t* idx, const float* planes, float* depth);
+hipError_t launch_depth_map_filters(hipStream_t s, float* conf, const uint8_t* idx, int nx, int ny,
+                                    int ksize, double C, int median_size, double max_confidence,
+                                    const float* planes, uint32_t* minmax_scratch, uint8_t* conf8,
+                                    uint8_t* mask, uint8_t* idx_filtered, float* depth);
 hipError_t launch_mean_square(hipStream_t s, const float* dsi, size_t n, double* accum);
 
 // test hook: q[i] = residual-corrected division, ref[i] = n[i] / d[i]

@@ -15,6 +15,8 @@
 // it); explicit fmaf() calls are the only fused operations.
 #include "dsi_kernels.h"
 
+#include <cmath>
+
 #pragma clang fp contract(off)
 
 namespace dsi {
@@ -850,6 +852,138 @@ __global__ __launch_bounds__(256) void k_mean_square(const float* __restrict__ d
     }
 }
 
+// --------------------------------------------------- post-arg-max filters ---
+// Device side of MapperEMVS::getDepthMapFromDSI after the arg-max
+// (mapper_emvs_stereo.cpp:390-436; the Telea inpainting of the dense map stays out).
+// All of it is integer / exactly representable float work on a W x H image.
+__device__ __forceinline__ uint32_t float_key(float v)
+{
+    const uint32_t b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);  // monotone float -> uint
+}
+__device__ __forceinline__ float key_float(uint32_t k)
+{
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// :393 conf(0,0) = max_confidence, then min / max for cv::normalize(NORM_MINMAX)
+__global__ __launch_bounds__(256) void k_conf_minmax(float* __restrict__ conf, int n,
+                                                     float max_confidence,
+                                                     uint32_t* __restrict__ mm /* [min,max] keys */)
+{
+    uint32_t lo = 0xffffffffu, hi = 0u;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float v = conf[i];
+        if (i == 0) {
+            v = max_confidence;
+            conf[0] = v;
+        }
+        const uint32_t k = float_key(v);
+        lo = min(lo, k);
+        hi = max(hi, k);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_down((int)lo, off, 64));
+        hi = max(hi, (uint32_t)__shfl_down((int)hi, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&mm[0], lo);
+        atomicMax(&mm[1], hi);
+    }
+}
+
+__device__ __forceinline__ uint8_t saturate_u8(float v)
+{
+    const float r = __builtin_rintf(v);  // cvRound: half to even
+    return (uint8_t)(r < 0.f ? 0 : (r > 255.f ? 255 : (int)r));
+}
+
+// :394-397 normalize to [0,255] (scale/shift in double, applied in float), (0,0) = 0, to u8
+__global__ __launch_bounds__(256) void k_conf8(const float* __restrict__ conf, int n,
+                                               const uint32_t* __restrict__ mm,
+                                               uint8_t* __restrict__ conf8)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double smin = (double)key_float(mm[0]), smax = (double)key_float(mm[1]);
+    const double range = smax - smin;
+    const double scale = 255.0 * (range > 2.220446049250313e-16 ? 1. / range : 0.);
+    const double shift = 0.0 - smin * scale;
+    const float a = (float)scale, b = (float)shift;
+    float v = conf[i] * a + b;
+    if (i == 0) v = 0.f;
+    conf8[i] = saturate_u8(v);
+}
+
+struct GaussK {
+    float w[64];
+};
+
+// :403-409 cv::adaptiveThreshold(ADAPTIVE_THRESH_GAUSSIAN_C, THRESH_BINARY, ksize, delta = -C)
+__global__ __launch_bounds__(256) void k_adaptive_mask(const uint8_t* __restrict__ conf8, int nx,
+                                                       int ny, int ksize, GaussK kern, int idelta,
+                                                       uint8_t* __restrict__ mask)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= nx || y >= ny) return;
+    const int r = ksize / 2;
+    float acc = 0.f;
+    for (int ty = -r; ty <= r; ++ty) {  // column pass over row-pass results, BORDER_REPLICATE
+        const int yy = min(max(y + ty, 0), ny - 1);
+        float row = 0.f;
+        for (int tx = -r; tx <= r; ++tx)
+            row += kern.w[tx + r] * (float)conf8[(size_t)yy * nx + min(max(x + tx, 0), nx - 1)];
+        acc += kern.w[ty + r] * row;
+    }
+    const int mean = saturate_u8(acc);
+    mask[(size_t)y * nx + x] = ((int)conf8[(size_t)y * nx + x] - mean > -idelta) ? 1 : 0;
+}
+
+// :420-423 huangMedianFilter (median_filtering.cpp:33-158): for every pixel the median
+// (compute_median_histogram: smallest v whose cumulative count reaches (num+1)/2) of the
+// masked in-image values of its window; 0 when the window holds none
+__global__ __launch_bounds__(256) void k_masked_median(const uint8_t* __restrict__ idx,
+                                                       const uint8_t* __restrict__ mask, int nx,
+                                                       int ny, int p, uint8_t* __restrict__ out)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= nx || y >= ny) return;
+    const int y0 = max(y - p, 0), y1 = min(y + p, ny - 1), x0 = max(x - p, 0), x1 = min(x + p, nx - 1);
+    int num = 0;
+    for (int yy = y0; yy <= y1; ++yy)
+        for (int xx = x0; xx <= x1; ++xx) num += mask[(size_t)yy * nx + xx] > 0 ? 1 : 0;
+    const int middle = (num + 1) / 2;
+    int best = 256;
+    for (int yy = y0; yy <= y1; ++yy)
+        for (int xx = x0; xx <= x1; ++xx) {
+            if (!(mask[(size_t)yy * nx + xx] > 0)) continue;
+            const int v = idx[(size_t)yy * nx + xx];
+            if (v >= best) continue;
+            int c = 0;  // values <= v in the window
+            for (int y2 = y0; y2 <= y1; ++y2)
+                for (int x2 = x0; x2 <= x1; ++x2)
+                    c += (mask[(size_t)y2 * nx + x2] > 0 && idx[(size_t)y2 * nx + x2] <= v) ? 1 : 0;
+            if (c >= middle) best = v;
+        }
+    out[(size_t)y * nx + x] = (uint8_t)(num == 0 ? 0 : best);
+}
+
+// :426-427 removeMaskBoundary (:316-329) and :435 convertDepthIndicesToValues
+__global__ __launch_bounds__(256) void k_finish_depth(uint8_t* __restrict__ mask,
+                                                      const uint8_t* __restrict__ idxf, int nx,
+                                                      int ny, int border,
+                                                      const float* __restrict__ planes,
+                                                      float* __restrict__ depth)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nx * ny) return;
+    const int x = i % nx, y = i / nx;
+    if (x <= border || x >= nx - border || y <= border || y >= ny - border) mask[i] = 0;
+    depth[i] = planes[idxf[i]];
+}
+
 __global__ void k_div_probe(const float* __restrict__ n, const float* __restrict__ d,
                             size_t count, float* __restrict__ q, float* __restrict__ ref)
 {
@@ -1044,6 +1178,50 @@ hipError_t launch_mean_square(hipStream_t s, const float* dsi, size_t n, double*
 {
     hipLaunchKernelGGL(k_mean_square, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, dsi, n,
                        accum);
+    return hipGetLastError();
+}
+
+hipError_t launch_depth_map_filters(hipStream_t s, float* conf, const uint8_t* idx, int nx, int ny,
+                                    int ksize, double C, int median_size, double max_confidence,
+                                    const float* planes, uint32_t* minmax_scratch, uint8_t* conf8,
+                                    uint8_t* mask, uint8_t* idx_filtered, float* depth)
+{
+    const int n = nx * ny;
+    const uint32_t init[2] = {0xffffffffu, 0u};
+    hipError_t e = hipMemcpyAsync(minmax_scratch, init, sizeof init, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_conf_minmax, dim3(grid_for(n, 256, 512)), dim3(256), 0, s, conf, n,
+                       (float)max_confidence, minmax_scratch);
+    hipLaunchKernelGGL(k_conf8, dim3((n + 255) / 256), dim3(256), 0, s, conf, n, minmax_scratch, conf8);
+    GaussK kern{};
+    if (ksize > 63) ksize = 63;
+    // cv::getGaussianKernel, sigma <= 0: fixed tables up to 7, else sigma from the size
+    static const float k1[] = {1.f};
+    static const float k3[] = {0.25f, 0.5f, 0.25f};
+    static const float k5[] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};
+    static const float k7[] = {0.03125f, 0.109375f, 0.21875f, 0.28125f, 0.21875f, 0.109375f, 0.03125f};
+    const float* fixed = ksize == 1 ? k1 : ksize == 3 ? k3 : ksize == 5 ? k5 : ksize == 7 ? k7 : nullptr;
+    if (fixed) {
+        for (int i = 0; i < ksize; ++i) kern.w[i] = fixed[i];
+    } else {
+        const double sigma = ((ksize - 1) * 0.5 - 1) * 0.3 + 0.8;
+        const double scale2x = -0.5 / (sigma * sigma);
+        double sum = 0, t[64];
+        for (int i = 0; i < ksize; ++i) {
+            const double x = i - (ksize - 1) * 0.5;
+            t[i] = exp(scale2x * x * x);
+            sum += t[i];
+        }
+        for (int i = 0; i < ksize; ++i) kern.w[i] = (float)(t[i] * (1. / sum));
+    }
+    const dim3 grid2((nx + 63) / 64, (ny + 3) / 4);
+    hipLaunchKernelGGL(k_adaptive_mask, grid2, dim3(256), 0, s, conf8, nx, ny, ksize, kern,
+                       (int)ceil(-C), mask);
+    hipLaunchKernelGGL(k_masked_median, grid2, dim3(256), 0, s, idx, mask, nx, ny, median_size / 2,
+                       idx_filtered);
+    const int border = ksize / 2 > 1 ? ksize / 2 : 1;
+    hipLaunchKernelGGL(k_finish_depth, dim3((n + 255) / 256), dim3(256), 0, s, mask, idx_filtered, nx,
+                       ny, border, planes, depth);
     return hipGetLastError();
 }
 

@@ -44,6 +44,11 @@ class _MapperConfig(C.Structure):
                 ("inverse_depth", C.c_int), ("lut", C.POINTER(C.c_float))]
 
 
+class _DepthMapOptions(C.Structure):
+    _fields_ = [("adaptive_threshold_kernel_size", C.c_int), ("adaptive_threshold_c", C.c_double),
+                ("median_filter_size", C.c_int), ("max_confidence", C.c_double)]
+
+
 class _VoteInfo(C.Structure):
     _fields_ = [("algo", C.c_int), ("bands", C.c_int), ("band_rows", C.c_int),
                 ("chunks", C.c_int), ("block_threads", C.c_int), ("lds_bytes", C.c_size_t),
@@ -118,6 +123,8 @@ def load_library():
         "dsi_mapper_depth_map": (C.c_int, [vp, f32p, f32p, u8p]),
         "dsi_mapper_depth_map_of": (C.c_int, [vp, vp]),
         "dsi_mapper_fetch_depth_map": (C.c_int, [vp, f32p, f32p, u8p]),
+        "dsi_mapper_get_depth_map_from_dsi": (C.c_int, [vp, vp, C.POINTER(_DepthMapOptions), f32p, f32p,
+                                                       u8p, u8p]),
         "dsi_mapper_last_vote_info": (C.c_int, [vp, C.POINTER(_VoteInfo)]),
         "dsi_mapper_set_kernel_timing": (C.c_int, [vp, C.c_int]),
         "dsi_mapper_vote_kernel_time": (C.c_int, [vp, f32p, intp]),
@@ -358,6 +365,17 @@ class ShapeDSI:
         self.min_depth_, self.max_depth_, self.fov_ = float(min_depth), float(max_depth), float(fov)
 
 
+class OptionsDepthMap:
+    """mapper_emvs_stereo.hpp:68-82 (the fields getDepthMapFromDSI reads; defaults of main.cpp:73-75,97)."""
+
+    def __init__(self, adaptive_threshold_kernel_size=5, adaptive_threshold_c=5.0, median_filter_size=5,
+                 max_confidence=0.0):
+        self.adaptive_threshold_kernel_size_ = int(adaptive_threshold_kernel_size)
+        self.adaptive_threshold_c_ = float(adaptive_threshold_c)
+        self.median_filter_size_ = int(median_filter_size)
+        self.max_confidence = float(max_confidence)
+
+
 class EventBatch:
     """Device-resident events of one evaluateDSI call + their packetisation
     (mapper_emvs_stereo.cpp:88-105)."""
@@ -494,11 +512,25 @@ class MapperEMVS:
         _check(load_library().dsi_mapper_fill_voxel_grid(self._h, _ptr(xy, C.c_float),
                                                          _ptr(cc, C.c_float), cc.shape[0]))
 
-    def getDepthMapFromDSI(self, grid=None):
-        """The device part of getDepthMapFromDSI (mapper_emvs_stereo.cpp:339-437):
-        collapseMaxZSlice (:368) + convertDepthIndicesToValues (:302-313) on the raw
-        arg-max indices.  Returns (depth, confidence, indices)."""
+    def getDepthMapFromDSI(self, grid=None, options_depth_map=None):
+        """mapper_emvs_stereo.cpp:339-437.  With options_depth_map (OptionsDepthMap): the full
+        extraction -- arg-max, confidence normalisation, Gaussian adaptive threshold, masked
+        median, border removal -- returning (depth_map, confidence_map, mask) like the
+        reference's signature (dense inpainted map excluded).  Without: the raw arg-max
+        (:368) + convertDepthIndicesToValues (:302-313), returning (depth, confidence, indices)."""
         L = load_library()
+        if options_depth_map is not None:
+            o = options_depth_map
+            opts = _DepthMapOptions(o.adaptive_threshold_kernel_size_, o.adaptive_threshold_c_,
+                                    o.median_filter_size_, o.max_confidence)
+            depth = np.empty((self.dimY, self.dimX), np.float32)
+            conf = np.empty((self.dimY, self.dimX), np.float32)
+            mask = np.empty((self.dimY, self.dimX), np.uint8)
+            self.depth_cell_indices_filtered = np.empty((self.dimY, self.dimX), np.uint8)
+            _check(L.dsi_mapper_get_depth_map_from_dsi(
+                self._h, (grid or self.dsi_)._h, C.byref(opts), _ptr(depth, C.c_float), _ptr(conf, C.c_float),
+                _ptr(mask, C.c_uint8), _ptr(self.depth_cell_indices_filtered, C.c_uint8)))
+            return depth, conf, mask
         _check(L.dsi_mapper_depth_map_of(self._h, (grid or self.dsi_)._h))
         return self.fetchDepthMap()
 

@@ -219,6 +219,27 @@ DSI_API int dsi_mapper_depth_map(dsi_mapper_t *m, float *depth_host, float *conf
 DSI_API int dsi_mapper_depth_map_of(dsi_mapper_t *m, dsi_grid_t *g);
 DSI_API int dsi_mapper_fetch_depth_map(dsi_mapper_t *m, float *depth_host, float *conf_host, uint8_t *idx_host);
 
+/* OptionsDepthMap (mapper_emvs_stereo.hpp:68-82), the fields the depth-map extraction reads */
+typedef struct {
+    int adaptive_threshold_kernel_size; /* --adaptive_threshold_kernel_size, default 5 (main.cpp:73) */
+    double adaptive_threshold_c;        /* --adaptive_threshold_c, default 5 (main.cpp:74) */
+    int median_filter_size;             /* --median_filter_size, default 5 (main.cpp:75) */
+    double max_confidence;              /* --max_confidence (main.cpp:97); written to conf(0,0) */
+} dsi_depthmap_options_t;
+
+/* MapperEMVS::getDepthMapFromDSI(depth_map, confidence_map, mask, options)
+ * (mapper_emvs_stereo.cpp:339-437) for grid g (NULL = the mapper's own DSI), entirely on the
+ * device: collapseMaxZSlice (:368), conf(0,0) = max_confidence + cv::normalize to 8 bit
+ * (:393-397), Gaussian adaptive threshold (:403-409), masked Huang median of the depth indices
+ * (:420-423, median_filtering.cpp), removeMaskBoundary (:426-427) and
+ * convertDepthIndicesToValues of the filtered indices (:435).  The Telea inpainting of
+ * depth_map_dense (:430-436) is not reproduced.  Host outputs (any may be NULL): depth f32,
+ * confidence f32 (element (0,0) overwritten like the reference does), mask u8 in {0,1},
+ * filtered indices u8.  Synchronises. */
+DSI_API int dsi_mapper_get_depth_map_from_dsi(dsi_mapper_t *m, dsi_grid_t *g, const dsi_depthmap_options_t *opts,
+                                      float *depth_host, float *conf_host, uint8_t *mask_host,
+                                      uint8_t *idx_filtered_host);
+
 /* HIP-event stopwatch around the voting kernel (the replacement of fillVoxelGrid's hot
  * loop, mapper_emvs_stereo.cpp:168-203) on the context's stream: enable, run any number of
  * evaluate/fill calls, then read the summed kernel time and launch count (synchronises and

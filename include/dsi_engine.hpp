@@ -228,6 +228,13 @@ struct ShapeDSI {  // mapper_emvs_stereo.hpp:40-65
     float fov_ = 0.f;
 };
 
+struct OptionsDepthMap {  // mapper_emvs_stereo.hpp:68-82 (fields the extraction reads)
+    int adaptive_threshold_kernel_size_ = 5;
+    double adaptive_threshold_c_ = 5.;
+    double max_confidence = 0.;
+    int median_filter_size_ = 5;
+};
+
 typedef LinearTrajectory TrajectoryType;
 
 class MapperEMVS {  // mapper_emvs_stereo.hpp:94-155
@@ -296,6 +303,28 @@ public:
         depth_cell_indices = dsi::Image<uint8_t>(ny, nx);
         dsi::check(dsi_mapper_depth_map(h_, depth_map.data.data(), confidence_map.data.data(),
                                         depth_cell_indices.data.data()));
+    }
+
+    // getDepthMapFromDSI(depth_map, confidence_map, mask, options) (mapper_emvs_stereo.cpp:339-437)
+    // on the device: arg-max, conf(0,0) = max_confidence + normalisation, Gaussian adaptive
+    // threshold, masked Huang median, removeMaskBoundary, index -> depth (inpainting excluded).
+    // grid: the DSI to extract from (the reference calls this on whichever mapper holds it).
+    void getDepthMapFromDSI(dsi::Image<float>& depth_map, dsi::Image<float>& confidence_map,
+                            dsi::Image<uint8_t>& mask, const OptionsDepthMap& options_depth_map,
+                            const Grid3D* grid = nullptr)
+    {
+        int nx, ny, nz;
+        dsi_.getDimensions(&nx, &ny, &nz);
+        depth_map = dsi::Image<float>(ny, nx);
+        confidence_map = dsi::Image<float>(ny, nx);
+        mask = dsi::Image<uint8_t>(ny, nx);
+        dsi_depthmap_options_t o{};
+        o.adaptive_threshold_kernel_size = options_depth_map.adaptive_threshold_kernel_size_;
+        o.adaptive_threshold_c = options_depth_map.adaptive_threshold_c_;
+        o.median_filter_size = options_depth_map.median_filter_size_;
+        o.max_confidence = options_depth_map.max_confidence;
+        dsi::check(dsi_mapper_get_depth_map_from_dsi(h_, grid ? grid->handle() : nullptr, &o, depth_map.data.data(),
+                                                     confidence_map.data.data(), mask.data.data(), nullptr));
     }
 
     std::vector<float> depthPlanes() const

@@ -7,6 +7,7 @@
 #include "dsi_oracle.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
@@ -506,4 +507,118 @@ void orc_event_pose_Rt(const double *T_rv_w, const double *T_w_ev, float *Rt)
     Rt[9] = (float)T.t[0];
     Rt[10] = (float)T.t[1];
     Rt[11] = (float)T.t[2];
+}
+
+
+/* ---- post-arg-max filters: mapper_emvs_stereo.cpp:390-436 ---------------- */
+static void gaussian_kernel(int ksize, float *k)
+{
+    /* cv::getGaussianKernel with sigma <= 0: fixed tables for ksize <= 7, else
+     * sigma = ((ksize-1)*0.5 - 1)*0.3 + 0.8 and a normalised exp() in double */
+    static const float k1[] = {1.f};
+    static const float k3[] = {0.25f, 0.5f, 0.25f};
+    static const float k5[] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};
+    static const float k7[] = {0.03125f, 0.109375f, 0.21875f, 0.28125f, 0.21875f, 0.109375f, 0.03125f};
+    const float *fixed = ksize == 1 ? k1 : ksize == 3 ? k3 : ksize == 5 ? k5 : ksize == 7 ? k7 : 0;
+    if (fixed) {
+        memcpy(k, fixed, ksize * sizeof(float));
+        return;
+    }
+    const double sigma = ((ksize - 1) * 0.5 - 1) * 0.3 + 0.8;
+    const double scale2x = -0.5 / (sigma * sigma);
+    double sum = 0, t[64];
+    for (int i = 0; i < ksize; ++i) {
+        const double x = i - (ksize - 1) * 0.5;
+        t[i] = exp(scale2x * x * x);
+        sum += t[i];
+    }
+    for (int i = 0; i < ksize; ++i)
+        k[i] = (float)(t[i] * (1. / sum));
+}
+
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+static inline uint8_t saturate_u8(float v)
+{
+    /* cv::saturate_cast<uchar>(float): cvRound (round half to even), clamped */
+    const int i = (int)lrintf(v);
+    return (uint8_t)(i < 0 ? 0 : (i > 255 ? 255 : i));
+}
+
+void orc_depth_map_filters(float *conf, const uint8_t *idx, int nx, int ny, int ksize, double C,
+                           int median_size, double max_confidence, const float *raw_depths,
+                           uint8_t *conf8, uint8_t *mask, uint8_t *idx_filtered, float *depth)
+{
+    const size_t n = (size_t)nx * ny;
+    /* :393 */
+    conf[0] = (float)max_confidence;
+    /* :394 cv::normalize(src, dst, 0, 255, NORM_MINMAX): scale/shift in double, applied in float */
+    float smin = conf[0], smax = conf[0];
+    for (size_t i = 1; i < n; ++i) {
+        if (conf[i] < smin) smin = conf[i];
+        if (conf[i] > smax) smax = conf[i];
+    }
+    const double range = (double)smax - (double)smin;
+    const double scale = 255.0 * (range > 2.220446049250313e-16 ? 1. / range : 0.);
+    const double shift = 0.0 - (double)smin * scale;
+    const float a = (float)scale, b = (float)shift;
+    for (size_t i = 0; i < n; ++i) {
+        float v = conf[i] * a + b;
+        if (i == 0) v = 0.f; /* :396 */
+        conf8[i] = saturate_u8(v); /* :397 */
+    }
+    /* :403-409 adaptiveThreshold: Gaussian mean on the float image, BORDER_REPLICATE, rounded
+     * back to uchar; dst = 1 where src - mean > -cvCeil(-C) */
+    float kern[64];
+    if (ksize > 63) ksize = 63;
+    gaussian_kernel(ksize, kern);
+    const int r = ksize / 2;
+    float *tmp = (float *)malloc(n * sizeof(float));
+    for (int y = 0; y < ny; ++y)
+        for (int x = 0; x < nx; ++x) { /* row pass */
+            float acc = 0.f;
+            for (int t = -r; t <= r; ++t)
+                acc += kern[t + r] * (float)conf8[(size_t)y * nx + clampi(x + t, 0, nx - 1)];
+            tmp[(size_t)y * nx + x] = acc;
+        }
+    const int idelta = (int)ceil(-C);
+    for (int y = 0; y < ny; ++y)
+        for (int x = 0; x < nx; ++x) { /* column pass */
+            float acc = 0.f;
+            for (int t = -r; t <= r; ++t)
+                acc += kern[t + r] * tmp[(size_t)clampi(y + t, 0, ny - 1) * nx + x];
+            const int mean = saturate_u8(acc);
+            mask[(size_t)y * nx + x] = ((int)conf8[(size_t)y * nx + x] - mean > -idelta) ? 1 : 0;
+        }
+    free(tmp);
+    /* :420-423 huangMedianFilter: median of the masked, in-image window values; the histogram
+     * walk of median_filtering.cpp:33-158 visits every pixel with exactly its window */
+    const int p = median_size / 2;
+    for (int y = 0; y < ny; ++y)
+        for (int x = 0; x < nx; ++x) {
+            int h[256] = {0}, num = 0;
+            for (int yy = y - p; yy <= y + p; ++yy)
+                for (int xx = x - p; xx <= x + p; ++xx)
+                    if (yy >= 0 && xx >= 0 && yy < ny && xx < nx && mask[(size_t)yy * nx + xx] > 0) {
+                        h[idx[(size_t)yy * nx + xx]]++;
+                        num++;
+                    }
+            /* compute_median_histogram, median_filtering.cpp:7-18 */
+            const int middle = (num + 1) / 2;
+            int m = 0, v = 0;
+            for (v = 0; v < 256; ++v) {
+                m += h[v];
+                if (m >= middle) break;
+            }
+            idx_filtered[(size_t)y * nx + x] = (uint8_t)v;
+        }
+    /* :426-427 removeMaskBoundary(mask, max(ksize/2, 1)) (:316-329) */
+    const int border = ksize / 2 > 1 ? ksize / 2 : 1;
+    for (int y = 0; y < ny; ++y)
+        for (int x = 0; x < nx; ++x)
+            if (x <= border || x >= nx - border || y <= border || y >= ny - border)
+                mask[(size_t)y * nx + x] = 0;
+    /* :435 */
+    for (size_t i = 0; i < n; ++i)
+        depth[i] = raw_depths[idx_filtered[i]];
 }

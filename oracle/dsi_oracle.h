@@ -119,6 +119,21 @@ int orc_pose_at(const double *times, const double *poses, size_t n_poses,
  * float.  Inputs are 7-double poses; Rt gets 12 floats. */
 void orc_event_pose_Rt(const double *T_rv_w, const double *T_w_ev, float *Rt);
 
+/* Host post-filters of MapperEMVS::getDepthMapFromDSI after the arg-max
+ * (mapper_emvs_stereo.cpp:390-436), inpainting excluded:
+ *   conf(0,0) = max_confidence (:393); cv::normalize NORM_MINMAX to [0,255] float (:394);
+ *   conf8(0,0) = 0, convertTo CV_8U (:396-397); cv::adaptiveThreshold(GAUSSIAN_C, BINARY,
+ *   ksize, -C) with maxValue 1 (:403-409); huangMedianFilter on the indices under the mask
+ *   (:420-423, median_filtering.cpp:33-158); removeMaskBoundary (:426-427, :316-329);
+ *   convertDepthIndicesToValues of the FILTERED indices (:435).
+ * OpenCV arithmetic (normalize, GaussianBlur, saturate_cast) is restated from its
+ * documentation / published source; for ksize 3, 5, 7 the blur is exact in float (dyadic
+ * weights), so only round-half-even of saturate_cast<uchar> matters.
+ * conf is modified in place like the reference does (element (0,0)). */
+void orc_depth_map_filters(float *conf, const uint8_t *idx, int nx, int ny, int ksize, double C,
+                           int median_size, double max_confidence, const float *raw_depths,
+                           uint8_t *conf8, uint8_t *mask, uint8_t *idx_filtered, float *depth);
+
 int orc_num_threads(void);
 
 #ifdef __cplusplus

@@ -53,6 +53,8 @@ def lib():
         L.orc_pose_at.argtypes = [f64p, f64p, C.c_size_t, C.c_double, f64p]
         L.orc_pose_at.restype = C.c_int
         L.orc_event_pose_Rt.argtypes = [f64p, f64p, f32p]
+        L.orc_depth_map_filters.argtypes = [f32p, u8p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
+                                            C.c_double, f32p, u8p, u8p, u8p, f32p]
         L.orc_num_threads.restype = C.c_int
         _LIB = L
     return _LIB
@@ -219,3 +221,21 @@ def event_pose_Rt(T_rv_w, T_w_ev):
 
 def num_threads():
     return lib().orc_num_threads()
+
+
+def depth_map_filters(conf, idx, raw_depths, ksize=5, C_=5.0, median_size=5, max_confidence=0.0):
+    """Post-arg-max filters of getDepthMapFromDSI (mapper_emvs_stereo.cpp:390-436).
+    Returns dict(depth, confidence (with (0,0) overwritten), mask, conf8, idx_filtered)."""
+    conf = _f32(conf).copy()
+    idx = np.ascontiguousarray(idx, np.uint8)
+    raw_depths = _f32(raw_depths)
+    ny, nx = conf.shape
+    conf8 = np.empty((ny, nx), np.uint8)
+    mask = np.empty((ny, nx), np.uint8)
+    filt = np.empty((ny, nx), np.uint8)
+    depth = np.empty((ny, nx), np.float32)
+    lib().orc_depth_map_filters(_p(conf, C.c_float), _p(idx, C.c_uint8), nx, ny, ksize, float(C_),
+                                median_size, float(max_confidence), _p(raw_depths, C.c_float),
+                                _p(conf8, C.c_uint8), _p(mask, C.c_uint8), _p(filt, C.c_uint8),
+                                _p(depth, C.c_float))
+    return {"depth": depth, "confidence": conf, "mask": mask, "conf8": conf8, "idx_filtered": filt}

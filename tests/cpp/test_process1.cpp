@@ -192,6 +192,20 @@ int main()
         dsi::Image<uint8_t> i2;
         mapper_fused.dsi_.collapseMaxZSlice(&c2, &i2);
         if (c2.data != rconf || i2.data != ridx) return 41;
+        // the full extraction with the reference's signature (adaptive threshold, median, border)
+        {
+            EMVS::OptionsDepthMap opts;
+            opts.adaptive_threshold_c_ = 4.;
+            opts.max_confidence = 50.;
+            dsi::Image<float> dm, cm;
+            dsi::Image<uint8_t> mk;
+            mapper_fused.getDepthMapFromDSI(dm, cm, mk, opts);
+            std::vector<float> oc = rconf, od(rconf.size());
+            std::vector<uint8_t> c8(rconf.size()), om(rconf.size()), of(rconf.size());
+            orc_depth_map_filters(oc.data(), ridx.data(), cam.width, cam.height, 5, 4., 5, 50., planes.data(),
+                                  c8.data(), om.data(), of.data(), od.data());
+            if (dm.data != od || cm.data != oc || mk.data != om) return 42;
+        }
         // mismatched grids: the reference throws std::out_of_range from .at()
         Grid3D other(ctx, 8, 8, 8);
         try {
