@@ -552,8 +552,7 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const float2* __res
     const int p_end = (int)(((long long)np * (c + 1)) / bp.chunks);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int lane = threadIdx.x & (kWave - 1);
-    const float L = (float)max(r0 - 1, 0), U = (float)min(r1, g.ny - 1);
-    const float xmax = (float)(nx - 1);
+    const int Li = max(r0 - 1, 0), Ui = min(r1, g.ny - 1);
     const int row_base = r0 - 1;
     // packets a wave takes per pass: 64 when the chunk is long, fewer (>= 4) when it is short so
     // that every wave of the workgroup gets some
@@ -583,20 +582,34 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const float2* __res
         const float kr = __uint_as_float(vb.x);
         const float nxv = ev.x * ka + kbx;  // mapper_emvs_stereo.cpp:194-195
         const float nyv = ev.y * ka + kby;
-        float X, Y;
+        float X, Y, nmax;
         // |d| outside [2^-40, 2^40] somewhere in the wave (rare): everybody takes the IEEE
-        // divide, which equals the residual-corrected one wherever that is valid
+        // divide, which equals the residual-corrected one wherever that is valid.  nmax: the
+        // largest |numerator| for which the quotient cannot be NaN (IEEE: any finite one;
+        // div_rc: no intermediate overflow below 1e30, and beyond it X > nx anyway)
         if (__builtin_amdgcn_ballot_w64((vb.y & kCoefSlow) != 0 && lane < n_active) != 0) {
             X = nxv / kd;
             Y = nyv / kd;
+            nmax = __builtin_inff();
         } else {
             X = div_rc(nxv, kd, kr);
             Y = div_rc(nyv, kd, kr);
+            nmax = 1e30f;
         }
-        // cartesian3dgrid.h:255-259 restricted to this band's rows
-        if (lane < n_active && X >= 0.f && X < xmax && Y >= L && Y < U) {
-            const float xf = __builtin_floorf(X), yf = __builtin_floorf(Y);
-            const int idx = __mul24((int)yf - row_base, nx) + (int)xf;
+        // cartesian3dgrid.h:255-259 restricted to this band's rows, as ONE integer test (each
+        // float compare + mask AND costs scalar-unit slots, the kernel's scarce resource):
+        // with xi = floor(X), yi = floor(Y) (the conversion saturates, NaN -> 0)
+        //   0 <= X < nx-1  <=>  xi >= 0 and nx-2-xi >= 0        (X = -0.0 -> 0, accepted like >= 0.f)
+        //   L <= Y < U     <=>  yi-Li >= 0 and Ui-1-yi >= 0     (L, U are integers)
+        // all four hold iff the OR of the four values has a clear sign bit.  NaN cannot occur:
+        // events and coefficients are finite, d != 0, and an overflowing numerator gives
+        // a non-finite quotient only through an overflowing numerator -- excluded by nmax.
+        const float xf = __builtin_floorf(X), yf = __builtin_floorf(Y);
+        const int xi = (int)xf, yi = (int)yf;
+        int sgn = xi | (nx - 2 - xi) | (yi - Li) | (Ui - 1 - yi);
+        sgn |= (lane < n_active && fabsf(nxv) < nmax && fabsf(nyv) < nmax) ? 0 : -1;
+        if (sgn >= 0) {
+            const int idx = __mul24(yi - row_base, nx) + xi;
             vote4(band, idx, nx, X - xf, Y - yf);  // cartesian3dgrid.h:261-270
         }
     };
