@@ -113,12 +113,13 @@ struct dsi_mapper {
     dsi_grid* grid = nullptr;
     int algo = DSI_VOTE_AUTO;
     int want_band_rows = 0, want_chunks = 0, want_block = 0;
-    int want_packed = -1;  // -1 automatic, 0 per-packet waves, 1 packed lanes
+    int want_packed = -1;  // -1 automatic, 0 per-packet waves, 1 packed lanes, 2 packet groups
     dsi_vote_info_t info{};
     // scratch
     DevBuf<float> centers, H, partials, Rt_tmp, conf, depth;
     DevBuf<float2> xy, sxy;
-    DevBuf<uint32_t> nvalid, cuts;
+    DevBuf<uint32_t> nvalid, cuts, gcuts;
+    DevBuf<uint8_t> spk;
     DevBuf<uint16_t> rowstart;
     DevBuf<dsi::PlaneCoef> coef;
     DevBuf<uint8_t> idx, conf8, mask, idx_filtered;
@@ -192,6 +193,10 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
     // expected events of one packet in one band; short runs waste lanes in the per-packet kernel
     const long run = 1024L * (band_rows + 1) / g.ny;
     bp->packed = m->want_packed >= 0 ? m->want_packed : (run < 512 ? 1 : 0);
+    // mapping 2 sorts S consecutive packets together so that a run holds >= ~512 events
+    int S = 1;
+    while (S < 32 && (long)S * std::max<long>(run, 1) < 512) S <<= 1;
+    bp->group_packets = S;
     int chunks = m->want_chunks;
     if (chunks <= 0) {
         const long items_target = 8L * 256;  // ~8 work items per CU
@@ -280,6 +285,7 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
     m->info.block_threads = bp.block_threads;
     m->info.lds_bytes = bp.lds_bytes;
     m->info.packed = bp.packed;
+    m->info.group_packets = bp.group_packets;
     if (np == 0) {
         if (!accumulate) HIP_TRY(hipMemsetAsync(g->data, 0, g->n * sizeof(float), ctx->stream));
         return DSI_OK;
@@ -292,6 +298,23 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
     const bool direct = (bp.chunks == 1 && !accumulate);
     if (!direct) HIP_TRY(m->partials.reserve((size_t)bp.chunks * g->n));
 
+    if (bp.packed == 2) {
+        const int S = bp.group_packets;
+        const size_t ngroups = (np + S - 1) / S;
+        HIP_TRY(m->spk.reserve(np * dsi::kPacket));
+        HIP_TRY(m->gcuts.reserve(ngroups * geom.nz * bp.bands));
+        HIP_TRY(m->rowstart.reserve(ngroups * (size_t)(geom.ny + 2 * bp.row_pad + 3)));
+        HIP_TRY(dsi::launch_sort_groups(ctx->stream, xy, (int)np, S, geom.ny, bp.row_pad, m->sxy.p, m->spk.p,
+                                        m->nvalid.p, m->rowstart.p));
+        // per-packet coefficients + row-bin ranges (cuts buffer), then the per-group runs
+        HIP_TRY(dsi::launch_plane_coef(ctx->stream, centers, m->planes_dev, m->rowstart.p, m->nvalid.p, (int)np,
+                                       geom, bp, m->coef.p, m->cuts.p));
+        HIP_TRY(dsi::launch_group_cuts(ctx->stream, m->cuts.p, m->rowstart.p, (int)np, S, geom, bp, m->gcuts.p));
+        VoteTimer vt(m);
+        HIP_TRY(dsi::launch_vote_groups(ctx->stream, m->sxy.p, m->spk.p, m->coef.p, m->gcuts.p, (int)np, S, geom,
+                                        bp, direct ? g->data : m->partials.p));
+        vt.stop();
+    } else {
     HIP_TRY(dsi::launch_sort_packets(ctx->stream, xy, (int)np, geom.ny, bp.row_pad, m->sxy.p, m->nvalid.p, m->rowstart.p));
     HIP_TRY(dsi::launch_plane_coef(ctx->stream, centers, m->planes_dev, m->rowstart.p, m->nvalid.p, (int)np,
                                    geom, bp, m->coef.p, m->cuts.p));
@@ -299,6 +322,7 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
     HIP_TRY(dsi::launch_vote_bands(ctx->stream, m->sxy.p, m->coef.p, m->cuts.p, (int)np, geom, bp,
                                    direct ? g->data : m->partials.p));
     vt.stop();
+    }
     if (!direct)
         HIP_TRY(dsi::launch_reduce_partials(ctx->stream, m->partials.p, bp.chunks, g->n, g->data,
                                             accumulate ? 1 : 0));
@@ -668,6 +692,8 @@ int dsi_mapper_destroy(dsi_mapper_t* m)
     m->xy.release();
     m->sxy.release();
     m->nvalid.release();
+    m->gcuts.release();
+    m->spk.release();
     m->rowstart.release();
     m->cuts.release();
     m->coef.release();
@@ -727,7 +753,7 @@ int dsi_mapper_set_band_params(dsi_mapper_t* m, int band_rows, int chunks, int b
 int dsi_mapper_set_packed_lanes(dsi_mapper_t* m, int mode)
 {
     REQUIRE(m, DSI_ERR_INVALID, "mapper is null");
-    REQUIRE(mode >= -1 && mode <= 1, DSI_ERR_INVALID, "mode must be -1 (auto), 0 or 1");
+    REQUIRE(mode >= -1 && mode <= 2, DSI_ERR_INVALID, "mode must be -1 (auto), 0, 1 or 2");
     m->want_packed = mode;
     return DSI_OK;
 }
@@ -993,10 +1019,16 @@ DSI_API int dsi_test_run_length_total(dsi_mapper_t* m, unsigned long long* total
 {
     REQUIRE(m && total && entries, DSI_ERR_INVALID, "null argument");
     if (int rc = set_device(m->ctx)) return rc;
-    const size_t n = m->info.n_packets * (size_t)m->geom.nz * (size_t)m->info.bands;
+    size_t units = m->info.n_packets;
+    const uint32_t* src = m->cuts.p;
+    if (m->info.packed == 2) {  // grouped mapping: one run per group of packets
+        units = (m->info.n_packets + m->info.group_packets - 1) / m->info.group_packets;
+        src = m->gcuts.p;
+    }
+    const size_t n = units * (size_t)m->geom.nz * (size_t)m->info.bands;
     std::vector<uint32_t> h(n);
     HIP_TRY(hipStreamSynchronize(m->ctx->stream));
-    if (n) HIP_TRY(hipMemcpy(h.data(), m->cuts.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (n) HIP_TRY(hipMemcpy(h.data(), src, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     unsigned long long t = 0;
     for (uint32_t c : h) t += (c >> 16) - (c & 0xffffu);
     *total = t;

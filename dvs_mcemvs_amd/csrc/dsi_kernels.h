@@ -34,7 +34,8 @@ struct BandPlan {
     int band_rows;      // owned rows per band (last band may own fewer)
     int chunks;         // packet chunks; each writes its own partial DSI when > 1
     int block_threads;  // 256 / 512 / 1024
-    int packed;         // 1: k_vote_bands_packed (short runs), 0: k_vote_bands
+    int packed;         // lane mapping: 0 k_vote_bands, 1 k_vote_bands_packed, 2 k_vote_groups
+    int group_packets;  // mapping 2: packets sorted together (power of two <= 32)
     int row_pad;        // z0 rows binned over [-row_pad, ny + row_pad) by k_sort_packets
     size_t lds_bytes;   // (band_rows + 2) * nx * 8 (u64 fixed-point accumulators, 2 halo rows)
 };
@@ -57,6 +58,13 @@ hipError_t launch_plane_coef(hipStream_t s, const float* centers, const float* p
 hipError_t launch_vote_bands(hipStream_t s, const float2* sxy, const PlaneCoef* coef,
                              const uint32_t* cuts, int np, const Geom& g, const BandPlan& bp,
                              float* out);
+hipError_t launch_sort_groups(hipStream_t s, const float2* xy, int np, int S, int ny, int pad,
+                              float2* sxy, uint8_t* spk, uint32_t* nvalid, uint16_t* rowstart);
+hipError_t launch_group_cuts(hipStream_t s, const uint32_t* prow, const uint16_t* rowstart, int np,
+                             int S, const Geom& g, const BandPlan& bp, uint32_t* gcuts);
+hipError_t launch_vote_groups(hipStream_t s, const float2* sxy, const uint8_t* spk,
+                              const PlaneCoef* coef, const uint32_t* gcuts, int np, int S,
+                              const Geom& g, const BandPlan& bp, float* out);
 hipError_t launch_reduce_partials(hipStream_t s, const float* partials, int chunks, size_t n,
                                   float* dsi, int accumulate);
 // ---- Grid3D ops ------------------------------------------------------------

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void k_plane_coef(const float* __restrict__ ce
                        c.bx, c.by, c.d);
     c.r = 1.f / c.d;
     c.pad0 = c.pad1 = 0;
-    const int nv = (int)nvalid[k];
+    const int nv = bp.packed == 2 ? 1 : (int)nvalid[k];
     // Which (packet, plane) pairs can vote at all?  NaN anywhere, d == 0, or an
     // infinite a / bx / by make X or Y non-finite for every event.
     const bool dead = !(c.a == c.a) || !(c.bx == c.bx) || !(c.by == c.by) || !(c.d == c.d) ||
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void k_plane_coef(const float* __restrict__ ce
 
     const int pad = bp.row_pad;
     const int nb = g.ny + 2 * pad + 2;
-    const uint16_t* rs = rowstart + (size_t)k * (nb + 1);
+    const uint16_t* rs = rowstart + (bp.packed == 2 ? 0 : (size_t)k * (nb + 1));
     // y0 = (Y*d - by)/a inverts the transfer; unusable when the map is (nearly) constant or
     // the inversion is ill-conditioned -- then the whole packet is the (superset) run
     const double a = (double)c.a, d = (double)c.d, by = (double)c.by;
@@ -339,13 +339,27 @@ __global__ __launch_bounds__(256) void k_plane_coef(const float* __restrict__ ce
                     ymax += m;
                     const double fa = fmin(fmax(floor(ymin), (double)(-pad - 1)), (double)(g.ny + pad));
                     const double fb = fmin(fmax(floor(ymax), (double)(-pad - 1)), (double)(g.ny + pad));
-                    lo = rs[(int)fa + pad + 1];   // events in bins below bin(fa)
-                    hi = rs[(int)fb + pad + 2];   // events in bins up to and including bin(fb)
+                    if (bp.packed == 2) {  // grouped mapping: row bins, resolved per group later
+                        lo = (uint32_t)((int)fa + pad + 1);
+                        hi = (uint32_t)((int)fb + pad + 2);
+                    } else {
+                        lo = rs[(int)fa + pad + 1];   // events in bins below bin(fa)
+                        hi = rs[(int)fb + pad + 2];   // events in bins up to and including bin(fb)
+                    }
+                } else if (bp.packed == 2) {
+                    lo = 0;
+                    hi = (uint32_t)nb;
                 }
+            } else if (bp.packed == 2) {
+                lo = 0;
+                hi = (uint32_t)nb;  // whole packet = all row bins
             }
             if (hi < lo) hi = lo;
+        } else if (bp.packed == 2) {
+            lo = 0xffffu;  // dead packet: contributes no rows
+            hi = 0;
         }
-        cuts[((size_t)j * g.nz + z) * np + k] = lo | (hi << 16);  // hi <= 1024 fits in 16 bits
+        cuts[((size_t)j * g.nz + z) * np + k] = lo | (hi << 16);  // 16 bits each
     }
 }
 
@@ -668,6 +682,211 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const float2* __res
     }
     __syncthreads();
 
+    const size_t vol = (size_t)g.nx * g.ny * g.nz;
+    float* __restrict__ dst = out + (size_t)c * vol + ((size_t)z * g.ny + r0) * nx;
+    flush_band<BLOCK>(band, nx, (r1 - r0) * nx, dst);
+}
+
+// (3c) GROUPED mapping: S consecutive packets (a "group"; their poses are microseconds apart)
+//     are sorted TOGETHER by z0 row, every event keeping its packet's index within the group.
+//     The events a band needs from the whole group are then one long contiguous run (the
+//     union of the S packets' row ranges), so a wave walks a few hundred events per run with
+//     a plain loop -- almost no scalar bookkeeping per batch (the CU's one-per-clock scalar
+//     unit is what limits the packed mapping) -- and fetches each lane's coefficients with a
+//     gather that stays inside a 32*S-byte window of the plane-major table.
+__global__ __launch_bounds__(256) void k_sort_groups(const float2* __restrict__ xy, int np, int S,
+                                                     int ny, int pad, float2* __restrict__ sxy,
+                                                     uint8_t* __restrict__ spk,
+                                                     uint32_t* __restrict__ nvalid,
+                                                     uint16_t* __restrict__ rowstart)
+{
+    extern __shared__ uint32_t hist[];  // nb + 1 counters -> exclusive offsets -> running cursors
+    __shared__ uint32_t wave_tot[4];
+    const int nb = ny + 2 * pad + 2;
+    const int gidx = blockIdx.x;
+    const int p0 = gidx * S;
+    const int n_ev = min(S, np - p0) * kPacket;
+    const float2* __restrict__ src = xy + (size_t)p0 * kPacket;
+    for (int i = threadIdx.x; i <= nb; i += 256) hist[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_ev; i += 256) {
+        const float2 e = src[i];
+        if (finitef(e.x) && finitef(e.y)) atomicAdd(&hist[row_bin(e.y, ny, pad)], 1u);
+    }
+    __syncthreads();
+    const int per = (nb + 255) / 256;
+    const int b0 = threadIdx.x * per, b1 = min(nb, b0 + per);
+    uint32_t local = 0;
+    for (int i = b0; i < b1; ++i) local += hist[i];
+    uint32_t incl = local;
+    const int lane = threadIdx.x & 63;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wave_tot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t base = incl - local;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wave_tot[w];
+    const uint32_t total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    __syncthreads();
+    for (int i = b0; i < b1; ++i) {
+        const uint32_t c = hist[i];
+        hist[i] = base;
+        base += c;
+    }
+    if (threadIdx.x == 0) hist[nb] = total;
+    __syncthreads();
+    uint16_t* rs = rowstart + (size_t)gidx * (nb + 1);
+    for (int i = threadIdx.x; i <= nb; i += 256) rs[i] = (uint16_t)hist[i];  // S*1024 <= 32768
+    __syncthreads();
+    float2* __restrict__ dst = sxy + (size_t)p0 * kPacket;
+    uint8_t* __restrict__ dpk = spk + (size_t)p0 * kPacket;
+    for (int i = threadIdx.x; i < n_ev; i += 256) {
+        const float2 e = src[i];
+        if (finitef(e.x) && finitef(e.y)) {
+            const uint32_t pos = atomicAdd(&hist[row_bin(e.y, ny, pad)], 1u);
+            dst[pos] = e;
+            dpk[pos] = (uint8_t)(i >> 10);  // packet index within the group
+        }
+    }
+    if (threadIdx.x == 0) nvalid[gidx] = total;
+}
+
+// union of the row-bin ranges of a group's packets -> the run [lo, hi) of the group
+__global__ __launch_bounds__(256) void k_group_cuts(const uint32_t* __restrict__ prow,
+                                                    const uint16_t* __restrict__ rowstart, int np,
+                                                    int ngroups, int S, int nz, int bands, int nb,
+                                                    uint32_t* __restrict__ gcuts)
+{
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)ngroups * nz * bands;
+    if (tid >= total) return;
+    const int gidx = (int)(tid % ngroups);  // group fastest: coalesced writes
+    const size_t jz = tid / ngroups;        // = band * nz + z
+    const int p0 = gidx * S, p1 = min(np, p0 + S);
+    uint32_t blo = 0xffffu, bhi = 0;
+    const uint32_t* __restrict__ row = prow + jz * np;
+    for (int p = p0; p < p1; ++p) {
+        const uint32_t w = row[p];
+        const uint32_t l = w & 0xffffu, h = w >> 16;
+        if (l <= h && !(l == 0xffffu)) {
+            blo = min(blo, l);
+            bhi = max(bhi, h);
+        }
+    }
+    uint32_t lo = 0, hi = 0;
+    if (blo <= bhi && blo != 0xffffu) {
+        const uint16_t* rs = rowstart + (size_t)gidx * (nb + 1);
+        lo = rs[blo];
+        hi = rs[bhi];
+    }
+    gcuts[jz * ngroups + gidx] = lo | (hi << 16);
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_vote_groups(const float2* __restrict__ sxy,
+                                                       const uint8_t* __restrict__ spk,
+                                                       const PlaneCoef* __restrict__ coef,
+                                                       const uint32_t* __restrict__ gcuts, int np,
+                                                       int ngroups, int S, Geom g, BandPlan bp,
+                                                       float* __restrict__ out)
+{
+    extern __shared__ acc_t band[];
+    const int b = blockIdx.x;
+    const int pairs = bp.chunks * bp.bands;
+    const int full = (pairs / 8) * 8 * g.nz;
+    int q, z;
+    if (b < full) {
+        const int xcd = b & 7, s = b >> 3;
+        q = (s / g.nz) * 8 + xcd;
+        z = s % g.nz;
+    } else {
+        const int r = b - full;
+        q = (pairs / 8) * 8 + r / g.nz;
+        z = r % g.nz;
+    }
+    const int c = q / bp.bands, j = q % bp.bands;
+    const int r0 = j * bp.band_rows;
+    const int r1 = min(g.ny, r0 + bp.band_rows);
+    const int nx = g.nx;
+    const int cells = (r1 - r0 + 2) * nx;
+    for (int i = threadIdx.x; i < cells; i += BLOCK) band[i] = 0;
+    __syncthreads();
+
+    const int g_begin = (int)(((long long)ngroups * c) / bp.chunks);
+    const int g_end = (int)(((long long)ngroups * (c + 1)) / bp.chunks);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int Li = max(r0 - 1, 0), Ui = min(r1, g.ny - 1);
+    const int row_base = r0 - 1;
+    const uint4* __restrict__ coef4 = reinterpret_cast<const uint4*>(coef) + 2 * (size_t)z * np;
+    const uint32_t* __restrict__ cutz = gcuts + ((size_t)j * g.nz + z) * ngroups;
+
+    for (int gi = g_begin + wave; gi < g_end; gi += BLOCK / kWave) {
+        const uint32_t cu = cutz[gi];
+        const int lo = (int)(cu & 0xffffu), hi = (int)(cu >> 16);
+        if (lo >= hi) continue;
+        const size_t ev0 = (size_t)gi * S * kPacket;
+        const float2* __restrict__ ev = sxy + ev0;
+        const uint8_t* __restrict__ pk = spk + ev0;
+        const uint4* __restrict__ cg = coef4 + 2 * (size_t)gi * S;  // the group's coefficient window
+        // Two batches per trip with two register sets (A, B): the gathers of batch b+1 (event +
+        // coefficients, which need that batch's packet indices) and the packet indices of
+        // batch b+2 are in flight while batch b is voted.  All loads are straight-line with
+        // indices clamped into the run, so the compiler counts outstanding loads exactly and no
+        // register copy waits for a load.
+        auto vote_one = [&](float2 e, uint4 va, uint2 vb, bool act) {
+            const float ka = __uint_as_float(va.x), kbx = __uint_as_float(va.y);
+            const float kby = __uint_as_float(va.z), kd = __uint_as_float(va.w);
+            const float kr = __uint_as_float(vb.x);
+            const float nxv = e.x * ka + kbx;  // mapper_emvs_stereo.cpp:194-195
+            const float nyv = e.y * ka + kby;
+            float X, Y, nmax;
+            if (__builtin_amdgcn_ballot_w64((vb.y & kCoefSlow) != 0) != 0) {  // rare, whole wave
+                X = nxv / kd;
+                Y = nyv / kd;
+                nmax = __builtin_inff();
+            } else {
+                X = div_rc(nxv, kd, kr);
+                Y = div_rc(nyv, kd, kr);
+                nmax = 1e30f;
+            }
+            // cartesian3dgrid.h:255-259 restricted to this band's rows as one integer test
+            // (see k_vote_bands_packed); dead packets of the group carry kCoefSkip
+            const float xf = __builtin_floorf(X), yf = __builtin_floorf(Y);
+            const int xi = (int)xf, yi = (int)yf;
+            int sgn = xi | (nx - 2 - xi) | (yi - Li) | (Ui - 1 - yi);
+            sgn |= (act && !(vb.y & kCoefSkip) && fabsf(nxv) < nmax && fabsf(nyv) < nmax) ? 0 : -1;
+            if (sgn >= 0) {
+                const int idx = __mul24(yi - row_base, nx) + xi;
+                vote4(band, idx, nx, X - xf, Y - yf);  // cartesian3dgrid.h:261-270
+            }
+        };
+        const int last = hi - 1;
+        int i0 = lo + lane, i1 = i0 + kWave;
+        int k0 = pk[min(i0, last)], k1 = pk[min(i1, last)];
+        float2 eA = ev[min(i0, last)], eB;
+        uint4 vaA = cg[2 * k0], vaB;
+        uint2 vbA = *reinterpret_cast<const uint2*>(cg + 2 * k0 + 1), vbB;
+        for (int base = lo; base < hi; base += 2 * kWave) {
+            // set B <- batch b+1, packet indices of b+2; vote batch b (set A)
+            eB = ev[min(i1, last)];
+            vaB = cg[2 * k1];
+            vbB = *reinterpret_cast<const uint2*>(cg + 2 * k1 + 1);
+            k0 = pk[min(i0 + 2 * kWave, last)];
+            vote_one(eA, vaA, vbA, i0 < hi);
+            // set A <- batch b+2, packet indices of b+3; vote batch b+1 (set B)
+            eA = ev[min(i0 + 2 * kWave, last)];
+            vaA = cg[2 * k0];
+            vbA = *reinterpret_cast<const uint2*>(cg + 2 * k0 + 1);
+            k1 = pk[min(i1 + 2 * kWave, last)];
+            vote_one(eB, vaB, vbB, i1 < hi);
+            i0 += 2 * kWave;
+            i1 += 2 * kWave;
+        }
+    }
+    __syncthreads();
     const size_t vol = (size_t)g.nx * g.ny * g.nz;
     float* __restrict__ dst = out + (size_t)c * vol + ((size_t)z * g.ny + r0) * nx;
     flush_band<BLOCK>(band, nx, (r1 - r0) * nx, dst);
@@ -1107,6 +1326,61 @@ hipError_t launch_vote_bands(hipStream_t s, const float2* sxy, const PlaneCoef* 
     case 256: return launch_vote_bands_t<256, false>(s, sxy, coef, cuts, np, g, bp, out);
     case 512: return launch_vote_bands_t<512, false>(s, sxy, coef, cuts, np, g, bp, out);
     case 1024: return launch_vote_bands_t<1024, false>(s, sxy, coef, cuts, np, g, bp, out);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_sort_groups(hipStream_t s, const float2* xy, int np, int S, int ny, int pad,
+                              float2* sxy, uint8_t* spk, uint32_t* nvalid, uint16_t* rowstart)
+{
+    if (np <= 0) return hipSuccess;
+    const int ngroups = (np + S - 1) / S;
+    const size_t lds = (size_t)(ny + 2 * pad + 3) * sizeof(uint32_t);
+    hipLaunchKernelGGL(k_sort_groups, dim3(ngroups), dim3(256), lds, s, xy, np, S, ny, pad, sxy, spk,
+                       nvalid, rowstart);
+    return hipGetLastError();
+}
+
+hipError_t launch_group_cuts(hipStream_t s, const uint32_t* prow, const uint16_t* rowstart, int np,
+                             int S, const Geom& g, const BandPlan& bp, uint32_t* gcuts)
+{
+    if (np <= 0) return hipSuccess;
+    const int ngroups = (np + S - 1) / S;
+    const size_t total = (size_t)ngroups * g.nz * bp.bands;
+    hipLaunchKernelGGL(k_group_cuts, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, prow,
+                       rowstart, np, ngroups, S, g.nz, bp.bands, g.ny + 2 * bp.row_pad + 2, gcuts);
+    return hipGetLastError();
+}
+
+template <int BLOCK>
+static hipError_t launch_vote_groups_t(hipStream_t s, const float2* sxy, const uint8_t* spk,
+                                       const PlaneCoef* coef, const uint32_t* gcuts, int np, int S,
+                                       const Geom& g, const BandPlan& bp, float* out)
+{
+    static size_t configured = 0;
+    if (bp.lds_bytes > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vote_groups<BLOCK>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)bp.lds_bytes);
+        if (e != hipSuccess) return e;
+        configured = bp.lds_bytes;
+    }
+    const int ngroups = (np + S - 1) / S;
+    const unsigned blocks = (unsigned)(bp.chunks * bp.bands) * (unsigned)g.nz;
+    hipLaunchKernelGGL(k_vote_groups<BLOCK>, dim3(blocks), dim3(BLOCK), bp.lds_bytes, s, sxy, spk,
+                       coef, gcuts, np, ngroups, S, g, bp, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_vote_groups(hipStream_t s, const float2* sxy, const uint8_t* spk,
+                              const PlaneCoef* coef, const uint32_t* gcuts, int np, int S,
+                              const Geom& g, const BandPlan& bp, float* out)
+{
+    if (np <= 0) return hipSuccess;
+    switch (bp.block_threads) {
+    case 256: return launch_vote_groups_t<256>(s, sxy, spk, coef, gcuts, np, S, g, bp, out);
+    case 512: return launch_vote_groups_t<512>(s, sxy, spk, coef, gcuts, np, S, g, bp, out);
+    case 1024: return launch_vote_groups_t<1024>(s, sxy, spk, coef, gcuts, np, S, g, bp, out);
     default: return hipErrorInvalidValue;
     }
 }

@@ -52,7 +52,7 @@ class _DepthMapOptions(C.Structure):
 class _VoteInfo(C.Structure):
     _fields_ = [("algo", C.c_int), ("bands", C.c_int), ("band_rows", C.c_int),
                 ("chunks", C.c_int), ("block_threads", C.c_int), ("lds_bytes", C.c_size_t),
-                ("n_packets", C.c_size_t), ("packed", C.c_int)]
+                ("n_packets", C.c_size_t), ("packed", C.c_int), ("group_packets", C.c_int)]
 
 
 def library_path():

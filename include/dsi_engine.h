@@ -163,7 +163,8 @@ DSI_API int dsi_mapper_set_vote_algo(dsi_mapper_t *m, int algo);
 DSI_API int dsi_mapper_set_band_params(dsi_mapper_t *m, int band_rows, int chunks, int block_threads);
 /* DSI_VOTE_LDS_BANDS has two lane mappings: one packet's run per wave pass (long runs) or the
  * runs of 64 packets packed back to back into the lanes (short runs: wide / tall grids).
- * mode -1 = automatic (by expected run length), 0 = per packet, 1 = packed. */
+ * mode -1 = automatic (by expected run length), 0 = per packet, 1 = packed,
+ * 2 = groups of consecutive packets sorted together (one long run per group). */
 DSI_API int dsi_mapper_set_packed_lanes(dsi_mapper_t *m, int mode);
 
 /* MapperEMVS::fillVoxelGrid(event_locations_z0, camera_centers)
@@ -256,7 +257,8 @@ typedef struct {
     int block_threads;
     size_t lds_bytes;
     size_t n_packets;
-    int packed;        /* 1 when the packed-lane kernel ran */
+    int packed;        /* lane mapping that ran: 0 per packet, 1 packed lanes, 2 packet groups */
+    int group_packets; /* packets sorted together by mapping 2 */
 } dsi_vote_info_t;
 DSI_API int dsi_mapper_last_vote_info(const dsi_mapper_t *m, dsi_vote_info_t *info);
 

@@ -79,10 +79,10 @@ def _close(got, ref, tol=DSI_TOL):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("algo", [1, 2, 3])
+@pytest.mark.parametrize("algo", [1, 2, 3, 4])
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p) for p in CASES])
 def test_hip_matches_golden(ctx, path, algo):
-    packed = 1 if algo == 3 else 0   # 3 = LDS bands with the packed lane mapping
+    packed = {3: 1, 4: 2}.get(algo, 0)   # 3 / 4 = LDS bands with the packed / grouped lane mapping
     algo = min(algo, 2)
     import dvs_mcemvs_amd as d
     g = load(path)

@@ -393,12 +393,13 @@ def test_fuse_into_equals_reference_sequence(ctx):
         A.setToFusionOf(A, G, 2)
 
 
-@pytest.mark.parametrize("packed", [0, 1])
+@pytest.mark.parametrize("packed", [0, 1, 2])
 @pytest.mark.parametrize("shape,band", [((64, 48, 16), None), ((346, 260, 12), (26, 4, 1024)),
                                         ((130, 97, 7), (5, 3, 256)), ((70, 48, 9), (48, 2, 512)),
                                         ((40, 30, 6), (9, 2, 256))])
 def test_both_lane_mappings_match_oracle(ctx, shape, band, packed):
-    """The per-packet and the packed-lane voting kernels are two mappings of the same work."""
+    """The per-packet, packed-lane and packet-group voting kernels are three lane mappings of
+    the same work."""
     nx, ny, nz = shape
     rng = np.random.default_rng(300 + nx)
     cam = (nx, ny, 0.8 * nx, 0.8 * nx, 0.5 * nx, 0.5 * ny)
