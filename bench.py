@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--dims", type=int, nargs=3, default=[346, 260, 100])
     ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 global atomics, 2 LDS bands")
     ap.add_argument("--band", type=int, nargs=3, default=[0, 0, 0], help="band_rows chunks block")
+    ap.add_argument("--points", type=int, default=5000, help="scene points of the synthetic rig (SURVEY 8d: 2000-20000)")
     ap.add_argument("--packed", type=int, default=-1, help="-1 auto, 0 per-packet waves, 1 packed lanes")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000,
                     help="events of camera 0 the CPU oracle is timed on (0 = skip)")
@@ -87,7 +88,7 @@ def main():
     # ---- inputs: one stereo time slice per rank, generated and uploaded before timing ----
     t_gen = time.time()
     rig = syn.stereo_rig(args.events, width=nx, height=ny, t0=10.0 + 0.5 * rank, duration=0.5,
-                         seed=1234 + 100 * rank)
+                         seed=1234 + 100 * rank, n_points=args.points)
     shape = d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0)  # cfg/DSEC/zurich_04_a_full/dsec.conf:11-12,17
     mappers, batches, voted = [], [], 0
     for c in range(2):

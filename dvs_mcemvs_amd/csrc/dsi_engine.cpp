@@ -117,7 +117,8 @@ struct dsi_mapper {
     dsi_vote_info_t info{};
     // scratch
     DevBuf<float> centers, H, partials, Rt_tmp, conf, depth;
-    DevBuf<float2> xy, sxy;
+    DevBuf<float2> xy;
+    DevBuf<dsi::EvRec> sxy;
     DevBuf<uint32_t> nvalid, cuts, gcuts;
     DevBuf<uint8_t> spk;
     DevBuf<uint16_t> rowstart;

@@ -22,6 +22,14 @@ struct PlaneCoef {
 constexpr uint32_t kCoefSkip = 1u;  // no event of this (packet, plane) can be accepted
 constexpr uint32_t kCoefSlow = 2u;  // use the IEEE divide and the whole packet
 
+// One entry of a grouped packet: an event's z0 location and how many events of the packet
+// share exactly that location (identical raw pixel in one 1024-event packet: hot pixels,
+// bursts).  Voting m identical events = one vote of m times the fixed-point weight, exactly.
+struct EvRec {
+    float x, y;
+    uint32_t m;
+};
+
 struct Geom {
     int nx, ny, nz;
     float vfx, vfy, vcx, vcy;  // virtual camera (geometry_utils.hpp:30-47)
@@ -51,18 +59,18 @@ hipError_t launch_vote_global(hipStream_t s, const float2* xy, const float* cent
                               const float* planes, const Geom& g, float* dsi);
 // ---- stage B, LDS row-band form -------------------------------------------
 hipError_t launch_sort_packets(hipStream_t s, const float2* xy, int np, int ny, int pad,
-                               float2* sxy, uint32_t* nvalid, uint16_t* rowstart);
+                               EvRec* sxy, uint32_t* nvalid, uint16_t* rowstart);
 hipError_t launch_plane_coef(hipStream_t s, const float* centers, const float* planes,
                              const uint16_t* rowstart, const uint32_t* nvalid, int np,
                              const Geom& g, const BandPlan& bp, PlaneCoef* coef, uint32_t* cuts);
-hipError_t launch_vote_bands(hipStream_t s, const float2* sxy, const PlaneCoef* coef,
+hipError_t launch_vote_bands(hipStream_t s, const EvRec* sxy, const PlaneCoef* coef,
                              const uint32_t* cuts, int np, const Geom& g, const BandPlan& bp,
                              float* out);
 hipError_t launch_sort_groups(hipStream_t s, const float2* xy, int np, int S, int ny, int pad,
-                              float2* sxy, uint8_t* spk, uint32_t* nvalid, uint16_t* rowstart);
+                              EvRec* sxy, uint8_t* spk, uint32_t* nvalid, uint16_t* rowstart);
 hipError_t launch_group_cuts(hipStream_t s, const uint32_t* prow, const uint16_t* rowstart, int np,
                              int S, const Geom& g, const BandPlan& bp, uint32_t* gcuts);
-hipError_t launch_vote_groups(hipStream_t s, const float2* sxy, const uint8_t* spk,
+hipError_t launch_vote_groups(hipStream_t s, const EvRec* sxy, const uint8_t* spk,
                               const PlaneCoef* coef, const uint32_t* gcuts, int np, int S,
                               const Geom& g, const BandPlan& bp, float* out);
 hipError_t launch_reduce_partials(hipStream_t s, const float* partials, int chunks, size_t n,

@@ -222,28 +222,55 @@ __device__ __forceinline__ int row_bin(float y0, int ny, int pad)
     return (int)f + pad + 1;  // finite y0 only
 }
 
+// Events of one packet with bit-identical z0 locations (same raw pixel fired again within the
+// packet) are merged into one record with a multiplicity: an open-addressing hash set in LDS
+// keyed by the 64 bits of (x0, y0); the first event to arrive in a slot represents the rest.
+constexpr int kHashSlots = 2048;  // >= 2 * kPacket
+constexpr unsigned long long kHashEmpty = ~0ull;  // a NaN pair: never a finite location
+
 __global__ __launch_bounds__(256) void k_sort_packets(const float2* __restrict__ xy, int ny,
-                                                      int pad, float2* __restrict__ sxy,
+                                                      int pad, EvRec* __restrict__ sxy,
                                                       uint32_t* __restrict__ nvalid,
                                                       uint16_t* __restrict__ rowstart)
 {
     extern __shared__ uint32_t hist[];  // nb + 1 counters, then scanned in place
+    __shared__ unsigned long long hkey[kHashSlots];
+    __shared__ uint32_t hcnt[kHashSlots];
     __shared__ uint32_t wave_tot[4];
     const int nb = ny + 2 * pad + 2;
     const int k = blockIdx.x;
     for (int i = threadIdx.x; i <= nb; i += 256) hist[i] = 0;
+    for (int i = threadIdx.x; i < kHashSlots; i += 256) {
+        hkey[i] = kHashEmpty;
+        hcnt[i] = 0;
+    }
     __syncthreads();
     float2 ev[4];
-    int bin[4];
+    int bin[4], slot[4];
     uint32_t rank[4];
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
         ev[h] = xy[(size_t)k * kPacket + threadIdx.x + 256 * h];
-        const bool ok = finitef(ev[h].x) && finitef(ev[h].y);
-        bin[h] = ok ? row_bin(ev[h].y, ny, pad) : -1;
+        bin[h] = -1;
+        slot[h] = 0;
         rank[h] = 0;
-        if (ok) rank[h] = atomicAdd(&hist[bin[h]], 1u);
+        if (finitef(ev[h].x) && finitef(ev[h].y)) {
+            const unsigned long long key =
+                ((unsigned long long)__float_as_uint(ev[h].y) << 32) | __float_as_uint(ev[h].x);
+            uint32_t hs = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 53);  // 11 bits
+            for (;;) {
+                const unsigned long long old = atomicCAS(&hkey[hs], kHashEmpty, key);
+                if (old == kHashEmpty || old == key) break;
+                hs = (hs + 1) & (kHashSlots - 1);
+            }
+            slot[h] = (int)hs;
+            if (atomicAdd(&hcnt[hs], 1u) == 0u) bin[h] = row_bin(ev[h].y, ny, pad);  // representative
+        }
     }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+        if (bin[h] >= 0) rank[h] = atomicAdd(&hist[bin[h]], 1u);
     __syncthreads();
     // exclusive scan of hist[0..nb): each thread owns a contiguous slice
     const int per = (nb + 255) / 256;
@@ -273,7 +300,13 @@ __global__ __launch_bounds__(256) void k_sort_packets(const float2* __restrict__
     for (int i = threadIdx.x; i <= nb; i += 256) rs[i] = (uint16_t)hist[i];
 #pragma unroll
     for (int h = 0; h < 4; ++h)
-        if (bin[h] >= 0) sxy[(size_t)k * kPacket + hist[bin[h]] + rank[h]] = ev[h];
+        if (bin[h] >= 0) {
+            EvRec r;
+            r.x = ev[h].x;
+            r.y = ev[h].y;
+            r.m = hcnt[slot[h]];
+            sxy[(size_t)k * kPacket + hist[bin[h]] + rank[h]] = r;
+        }
     if (threadIdx.x == 0) nvalid[k] = total;
 }
 
@@ -385,18 +418,19 @@ using acc_t = unsigned long long;
 constexpr float kFixScale = 2147483648.f;      // 2^31
 constexpr double kFixInv = 1.0 / 2147483648.0;  // 2^-31
 
-// the four bilinear votes of one event (cartesian3dgrid.h:261-270) into the band
-__device__ __forceinline__ void vote4(acc_t* __restrict__ band, int idx, int nx, float fx, float fy)
+// the four bilinear votes of m identical events (cartesian3dgrid.h:261-270) into the band
+__device__ __forceinline__ void vote4(acc_t* __restrict__ band, int idx, int nx, float fx, float fy,
+                                      uint32_t m)
 {
     const float fx1 = 1.f - fx, fy1 = 1.f - fy;
-    // scaling one factor by 2^31 scales the rounded product exactly; w * 2^31 <= 2^31 fits u32,
-    // the high dword of the addend is 0
+    // scaling one factor by 2^31 scales the rounded product exactly; w * 2^31 <= 2^31 fits u32;
+    // m votes of trunc(w * 2^31) are one vote of m * trunc(w * 2^31) (v_mad_u64_u32), exactly
     const float fxs = fx * kFixScale, fx1s = fx1 * kFixScale;
     acc_t* cell = band + idx;
-    __hip_atomic_fetch_add(cell, (acc_t)(unsigned int)(fx1s * fy1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_fetch_add(cell + 1, (acc_t)(unsigned int)(fxs * fy1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_fetch_add(cell + nx, (acc_t)(unsigned int)(fx1s * fy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_fetch_add(cell + nx + 1, (acc_t)(unsigned int)(fxs * fy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(cell, (acc_t)(unsigned int)(fx1s * fy1) * m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(cell + 1, (acc_t)(unsigned int)(fxs * fy1) * m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(cell + nx, (acc_t)(unsigned int)(fx1s * fy) * m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(cell + nx + 1, (acc_t)(unsigned int)(fxs * fy) * m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // owned rows of the band -> fp32 volume (a linear, coalesced copy)
@@ -410,7 +444,7 @@ __device__ __forceinline__ void flush_band(const acc_t* __restrict__ band, int n
 }
 
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_vote_bands(const float2* __restrict__ sxy,
+__global__ __launch_bounds__(BLOCK) void k_vote_bands(const EvRec* __restrict__ sxy,
                                                       const PlaneCoef* __restrict__ coef,
                                                       const uint32_t* __restrict__ cuts, int np,
                                                       Geom g, BandPlan bp,
@@ -483,15 +517,15 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands(const float2* __restrict__
         n1 = make_uint2(0, kCoefSkip);
         if (pn < p_end) fetch_meta(pn, n0, n1, ncu);
         if (!(flags & kCoefSkip) && lo < hi) {
-            const float2* __restrict__ ev = sxy + (size_t)p * kPacket;
+            const EvRec* __restrict__ ev = sxy + (size_t)p * kPacket;
             const bool slow = (flags & kCoefSlow) != 0;
             int i = lo + lane;
-            float2 e = make_float2(0.f, 0.f);
+            EvRec e = {0.f, 0.f, 0u};
             if (i < hi) e = ev[i];
             for (int base = lo; base < hi; base += kWave) {
                 // prefetch the next 64 events of the run while this batch is voted
                 const int inext = i + kWave;
-                float2 en = e;
+                EvRec en = e;
                 if (inext < hi) en = ev[inext];
                 if (i < hi) {
                     const float nxv = e.x * ka + kbx;  // mapper_emvs_stereo.cpp:194-195
@@ -509,7 +543,7 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands(const float2* __restrict__
                     if (X >= 0.f && X < xmax && Y >= L && Y < U) {
                         const float xf = __builtin_floorf(X), yf = __builtin_floorf(Y);
                         const int idx = __mul24((int)yf - row_base, nx) + (int)xf;
-                        vote4(band, idx, nx, X - xf, Y - yf);  // cartesian3dgrid.h:261-270
+                        vote4(band, idx, nx, X - xf, Y - yf, e.m);  // cartesian3dgrid.h:261-270
                     }
                 }
                 e = en;
@@ -534,7 +568,7 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands(const float2* __restrict__
 //     full, so lane utilisation no longer depends on the run length.  Coefficients are then
 //     per lane (gathered from the plane-major table), not per wave.
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const float2* __restrict__ sxy,
+__global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const EvRec* __restrict__ sxy,
                                                              const PlaneCoef* __restrict__ coef,
                                                              const uint32_t* __restrict__ cuts,
                                                              int np, Geom g, BandPlan bp,
@@ -583,14 +617,14 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const float2* __res
     // flight, votes the PREVIOUS batch whose data was requested one batch earlier.
     int f_pk = 0, f_ev = 0;  // batch being filled: packet, event slot
     // two register sets that alternate between "in flight" and "being voted" (no copies)
-    float2 eA = make_float2(0.f, 0.f), eB = eA;        // event location at z0
+    EvRec eA = {0.f, 0.f, 0u}, eB = eA;                // event location at z0 + multiplicity
     uint4 caA = make_uint4(0, 0, 0, 0), caB = caA;     // a, bx, by, d
     uint2 cbA = make_uint2(0, 0), cbB = cbA;           // r, flags
     int inflight = 0;  // lanes of the batch in flight (0 = none)
     int phase = 0;     // 0: next gathers go to set A, the batch in flight sits in set B
     int fill = 0;
 
-    auto vote_batch = [&](int n_active, float2 ev, uint4 va, uint2 vb) {
+    auto vote_batch = [&](int n_active, EvRec ev, uint4 va, uint2 vb) {
         const float ka = __uint_as_float(va.x), kbx = __uint_as_float(va.y);
         const float kby = __uint_as_float(va.z), kd = __uint_as_float(va.w);
         const float kr = __uint_as_float(vb.x);
@@ -624,15 +658,18 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const float2* __res
         sgn |= (lane < n_active && fabsf(nxv) < nmax && fabsf(nyv) < nmax) ? 0 : -1;
         if (sgn >= 0) {
             const int idx = __mul24(yi - row_base, nx) + xi;
-            vote4(band, idx, nx, X - xf, Y - yf);  // cartesian3dgrid.h:261-270
+            vote4(band, idx, nx, X - xf, Y - yf, ev.m);  // cartesian3dgrid.h:261-270
         }
     };
     // the filled batch becomes the batch in flight; the previous one is voted meanwhile
-    auto gather = [&](int n_new, float2& ev, uint4& va, uint2& vb) {
+    auto gather = [&](int n_new, EvRec& ev, uint4& va, uint2& vb) {
         if (lane < n_new) {
-            ev = sxy[(size_t)f_pk * kPacket + f_ev];
-            va = coef4[2 * (size_t)f_pk];
-            vb = *reinterpret_cast<const uint2*>(coef4 + 2 * (size_t)f_pk + 1);
+            // 32-bit element offsets from uniform bases (scalar base + vector offset addressing)
+            const uint32_t eo = (uint32_t)f_pk * (uint32_t)kPacket + (uint32_t)f_ev;
+            const uint32_t co = 2u * (uint32_t)f_pk;
+            ev = sxy[eo];
+            va = coef4[co];
+            vb = *reinterpret_cast<const uint2*>(coef4 + co + 1u);
         }
     };
     auto rotate = [&](int n_new) {
@@ -695,7 +732,7 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const float2* __res
 //     unit is what limits the packed mapping) -- and fetches each lane's coefficients with a
 //     gather that stays inside a 32*S-byte window of the plane-major table.
 __global__ __launch_bounds__(256) void k_sort_groups(const float2* __restrict__ xy, int np, int S,
-                                                     int ny, int pad, float2* __restrict__ sxy,
+                                                     int ny, int pad, EvRec* __restrict__ sxy,
                                                      uint8_t* __restrict__ spk,
                                                      uint32_t* __restrict__ nvalid,
                                                      uint16_t* __restrict__ rowstart)
@@ -740,13 +777,14 @@ __global__ __launch_bounds__(256) void k_sort_groups(const float2* __restrict__ 
     uint16_t* rs = rowstart + (size_t)gidx * (nb + 1);
     for (int i = threadIdx.x; i <= nb; i += 256) rs[i] = (uint16_t)hist[i];  // S*1024 <= 32768
     __syncthreads();
-    float2* __restrict__ dst = sxy + (size_t)p0 * kPacket;
+    EvRec* __restrict__ dst = sxy + (size_t)p0 * kPacket;
     uint8_t* __restrict__ dpk = spk + (size_t)p0 * kPacket;
     for (int i = threadIdx.x; i < n_ev; i += 256) {
         const float2 e = src[i];
         if (finitef(e.x) && finitef(e.y)) {
             const uint32_t pos = atomicAdd(&hist[row_bin(e.y, ny, pad)], 1u);
-            dst[pos] = e;
+            const EvRec r = {e.x, e.y, 1u};
+            dst[pos] = r;
             dpk[pos] = (uint8_t)(i >> 10);  // packet index within the group
         }
     }
@@ -785,7 +823,7 @@ __global__ __launch_bounds__(256) void k_group_cuts(const uint32_t* __restrict__
 }
 
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_vote_groups(const float2* __restrict__ sxy,
+__global__ __launch_bounds__(BLOCK) void k_vote_groups(const EvRec* __restrict__ sxy,
                                                        const uint8_t* __restrict__ spk,
                                                        const PlaneCoef* __restrict__ coef,
                                                        const uint32_t* __restrict__ gcuts, int np,
@@ -828,7 +866,7 @@ __global__ __launch_bounds__(BLOCK) void k_vote_groups(const float2* __restrict_
         const int lo = (int)(cu & 0xffffu), hi = (int)(cu >> 16);
         if (lo >= hi) continue;
         const size_t ev0 = (size_t)gi * S * kPacket;
-        const float2* __restrict__ ev = sxy + ev0;
+        const EvRec* __restrict__ ev = sxy + ev0;
         const uint8_t* __restrict__ pk = spk + ev0;
         const uint4* __restrict__ cg = coef4 + 2 * (size_t)gi * S;  // the group's coefficient window
         // Two batches per trip with two register sets (A, B): the gathers of batch b+1 (event +
@@ -836,7 +874,7 @@ __global__ __launch_bounds__(BLOCK) void k_vote_groups(const float2* __restrict_
         // batch b+2 are in flight while batch b is voted.  All loads are straight-line with
         // indices clamped into the run, so the compiler counts outstanding loads exactly and no
         // register copy waits for a load.
-        auto vote_one = [&](float2 e, uint4 va, uint2 vb, bool act) {
+        auto vote_one = [&](EvRec e, uint4 va, uint2 vb, bool act) {
             const float ka = __uint_as_float(va.x), kbx = __uint_as_float(va.y);
             const float kby = __uint_as_float(va.z), kd = __uint_as_float(va.w);
             const float kr = __uint_as_float(vb.x);
@@ -860,13 +898,13 @@ __global__ __launch_bounds__(BLOCK) void k_vote_groups(const float2* __restrict_
             sgn |= (act && !(vb.y & kCoefSkip) && fabsf(nxv) < nmax && fabsf(nyv) < nmax) ? 0 : -1;
             if (sgn >= 0) {
                 const int idx = __mul24(yi - row_base, nx) + xi;
-                vote4(band, idx, nx, X - xf, Y - yf);  // cartesian3dgrid.h:261-270
+                vote4(band, idx, nx, X - xf, Y - yf, e.m);  // cartesian3dgrid.h:261-270
             }
         };
         const int last = hi - 1;
         int i0 = lo + lane, i1 = i0 + kWave;
         int k0 = pk[min(i0, last)], k1 = pk[min(i1, last)];
-        float2 eA = ev[min(i0, last)], eB;
+        EvRec eA = ev[min(i0, last)], eB;
         uint4 vaA = cg[2 * k0], vaB;
         uint2 vbA = *reinterpret_cast<const uint2*>(cg + 2 * k0 + 1), vbB;
         for (int base = lo; base < hi; base += 2 * kWave) {
@@ -1269,7 +1307,7 @@ hipError_t launch_vote_global(hipStream_t s, const float2* xy, const float* cent
 }
 
 hipError_t launch_sort_packets(hipStream_t s, const float2* xy, int np, int ny, int pad,
-                               float2* sxy, uint32_t* nvalid, uint16_t* rowstart)
+                               EvRec* sxy, uint32_t* nvalid, uint16_t* rowstart)
 {
     if (np <= 0) return hipSuccess;
     const size_t lds = (size_t)(ny + 2 * pad + 3) * sizeof(uint32_t);
@@ -1290,7 +1328,7 @@ hipError_t launch_plane_coef(hipStream_t s, const float* centers, const float* p
 }
 
 template <int BLOCK, bool PACKED>
-static hipError_t launch_vote_bands_t(hipStream_t s, const float2* sxy, const PlaneCoef* coef,
+static hipError_t launch_vote_bands_t(hipStream_t s, const EvRec* sxy, const PlaneCoef* coef,
                                       const uint32_t* cuts, int np, const Geom& g,
                                       const BandPlan& bp, float* out)
 {
@@ -1309,7 +1347,7 @@ static hipError_t launch_vote_bands_t(hipStream_t s, const float2* sxy, const Pl
     return hipGetLastError();
 }
 
-hipError_t launch_vote_bands(hipStream_t s, const float2* sxy, const PlaneCoef* coef,
+hipError_t launch_vote_bands(hipStream_t s, const EvRec* sxy, const PlaneCoef* coef,
                              const uint32_t* cuts, int np, const Geom& g, const BandPlan& bp,
                              float* out)
 {
@@ -1331,7 +1369,7 @@ hipError_t launch_vote_bands(hipStream_t s, const float2* sxy, const PlaneCoef* 
 }
 
 hipError_t launch_sort_groups(hipStream_t s, const float2* xy, int np, int S, int ny, int pad,
-                              float2* sxy, uint8_t* spk, uint32_t* nvalid, uint16_t* rowstart)
+                              EvRec* sxy, uint8_t* spk, uint32_t* nvalid, uint16_t* rowstart)
 {
     if (np <= 0) return hipSuccess;
     const int ngroups = (np + S - 1) / S;
@@ -1353,7 +1391,7 @@ hipError_t launch_group_cuts(hipStream_t s, const uint32_t* prow, const uint16_t
 }
 
 template <int BLOCK>
-static hipError_t launch_vote_groups_t(hipStream_t s, const float2* sxy, const uint8_t* spk,
+static hipError_t launch_vote_groups_t(hipStream_t s, const EvRec* sxy, const uint8_t* spk,
                                        const PlaneCoef* coef, const uint32_t* gcuts, int np, int S,
                                        const Geom& g, const BandPlan& bp, float* out)
 {
@@ -1372,7 +1410,7 @@ static hipError_t launch_vote_groups_t(hipStream_t s, const float2* sxy, const u
     return hipGetLastError();
 }
 
-hipError_t launch_vote_groups(hipStream_t s, const float2* sxy, const uint8_t* spk,
+hipError_t launch_vote_groups(hipStream_t s, const EvRec* sxy, const uint8_t* spk,
                               const PlaneCoef* coef, const uint32_t* gcuts, int np, int S,
                               const Geom& g, const BandPlan& bp, float* out)
 {

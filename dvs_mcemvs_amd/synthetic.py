@@ -137,7 +137,7 @@ def radial_lut(cam, k1=-0.09, k2=0.19):
 
 
 def stereo_rig(n_events_per_cam, width=346, height=260, t0=10.0, duration=0.5, baseline=0.6,
-               n_cams=2, seed=1234, **kw):
+               n_cams=2, seed=1234, n_points=5000, noise_frac=0.10, **kw):
     """A synthetic multi-camera recording: dict with cam, per-camera events and
     trajectories, and the reference-view pose T_rv_w (left camera at the END of the
     interval, i.e. --forward_looking=true as in cfg/DSEC/zurich_04_a_full/dsec.conf)."""
@@ -146,7 +146,8 @@ def stereo_rig(n_events_per_cam, width=346, height=260, t0=10.0, duration=0.5, b
     offsets = [baseline * i / max(1, n_cams - 1) for i in range(n_cams)] if n_cams > 1 else [0.0]
     events, trajs = [], []
     for i, off in enumerate(offsets):
-        events.append(make_events(n_events_per_cam, cam, t0, t1, seed + i, cam_offset_x=off, **kw))
+        events.append(make_events(n_events_per_cam, cam, t0, t1, seed + i, cam_offset_x=off,
+                                  n_points=n_points, noise_frac=noise_frac, **kw))
         trajs.append(trajectory(t0, t1, cam_offset_x=off, **kw))
     pos, q = rig_pose(np.array(t1), **kw)
     T_w_rv = np.concatenate([pos, q])

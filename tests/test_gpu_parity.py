@@ -415,3 +415,34 @@ def test_both_lane_mappings_match_oracle(ctx, shape, band, packed):
     assert m.last_vote_info()["packed"] == packed
     assert_dsi_close(m.dsi_.download(), ref)
     m.close()
+
+
+@pytest.mark.parametrize("packed", [0, 1, 2])
+@pytest.mark.parametrize("n_pixels", [1, 7, 300, 5000])
+def test_duplicate_events_in_a_packet(ctx, packed, n_pixels):
+    """Events of a packet drawn from a few pixels (hot pixels, bursts): the packet sort merges
+    bit-identical z0 locations into one record with a multiplicity (k_sort_packets); the DSI
+    must be what voting every event separately gives.  -0.0 / +0.0 and NaN keys included."""
+    nx, ny, nz = 96, 64, 10
+    cam = (nx, ny, 70.0, 70.0, 48.0, 32.0)
+    rng = np.random.default_rng(700 + n_pixels)
+    n_packets = 6
+    pool = np.empty((n_pixels, 2), np.float32)
+    pool[:, 0] = rng.uniform(-0.05 * nx, 1.05 * nx, n_pixels)
+    pool[:, 1] = rng.uniform(-0.05 * ny, 1.05 * ny, n_pixels)
+    xy = pool[rng.integers(0, n_pixels, n_packets * 1024)].copy()
+    xy[5] = (0.0, 4.0)
+    xy[6] = (-0.0, 4.0)
+    xy[7] = (np.nan, 4.0)
+    xy[8] = (np.nan, 4.0)
+    centers = rng.normal(0, 0.2, (n_packets, 3)).astype(np.float32)
+    m = make_mapper(ctx, cam, nz, 1.0, 5.0, d.VOTE_LDS_BANDS, packed=packed)
+    ref = orc.fill_voxel_grid(xy, centers, m.raw_depths_vec_, np.array(m.virtual_cam_, np.float32),
+                              nx, ny)
+    m.fillVoxelGrid(xy, centers)
+    assert_dsi_close(m.dsi_.download(), ref)
+    m.set_vote_algo(d.VOTE_GLOBAL_ATOMIC)
+    m.dsi_.resetGrid()
+    m.fillVoxelGrid(xy, centers)
+    assert_dsi_close(m.dsi_.download(), ref)
+    m.close()
