@@ -292,7 +292,7 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
         return DSI_OK;
     }
     HIP_TRY(m->sxy.reserve(np * dsi::kPacket));
-    HIP_TRY(m->nvalid.reserve(np));
+    HIP_TRY(m->nvalid.reserve(np + (size_t)geom.nz));  // + one "needs IEEE divide" word per plane
     HIP_TRY(m->rowstart.reserve(np * (size_t)(geom.ny + 2 * bp.row_pad + 3)));
     HIP_TRY(m->coef.reserve(np * geom.nz));
     HIP_TRY(m->cuts.reserve(np * geom.nz * bp.bands));
@@ -305,7 +305,7 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
         HIP_TRY(m->spk.reserve(np * dsi::kPacket));
         HIP_TRY(m->gcuts.reserve(ngroups * geom.nz * bp.bands));
         HIP_TRY(m->rowstart.reserve(ngroups * (size_t)(geom.ny + 2 * bp.row_pad + 3)));
-        HIP_TRY(dsi::launch_sort_groups(ctx->stream, xy, (int)np, S, geom.ny, bp.row_pad, m->sxy.p, m->spk.p,
+        HIP_TRY(dsi::launch_sort_groups(ctx->stream, xy, (int)np, S, geom.ny, geom.nz, bp.row_pad, m->sxy.p, m->spk.p,
                                         m->nvalid.p, m->rowstart.p));
         // per-packet coefficients + row-bin ranges (cuts buffer), then the per-group runs
         HIP_TRY(dsi::launch_plane_coef(ctx->stream, centers, m->planes_dev, m->rowstart.p, m->nvalid.p, (int)np,
@@ -316,11 +316,11 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
                                         bp, direct ? g->data : m->partials.p));
         vt.stop();
     } else {
-    HIP_TRY(dsi::launch_sort_packets(ctx->stream, xy, (int)np, geom.ny, bp.row_pad, m->sxy.p, m->nvalid.p, m->rowstart.p));
+    HIP_TRY(dsi::launch_sort_packets(ctx->stream, xy, (int)np, geom.ny, geom.nz, bp.row_pad, m->sxy.p, m->nvalid.p, m->rowstart.p));
     HIP_TRY(dsi::launch_plane_coef(ctx->stream, centers, m->planes_dev, m->rowstart.p, m->nvalid.p, (int)np,
                                    geom, bp, m->coef.p, m->cuts.p));
     VoteTimer vt(m);
-    HIP_TRY(dsi::launch_vote_bands(ctx->stream, m->sxy.p, m->coef.p, m->cuts.p, (int)np, geom, bp,
+    HIP_TRY(dsi::launch_vote_bands(ctx->stream, m->sxy.p, m->coef.p, m->cuts.p, m->nvalid.p + np, (int)np, geom, bp,
                                    direct ? g->data : m->partials.p));
     vt.stop();
     }

@@ -58,15 +58,15 @@ hipError_t launch_warp_z0(hipStream_t s, const uint16_t* ex, const uint16_t* ey,
 hipError_t launch_vote_global(hipStream_t s, const float2* xy, const float* centers, int np,
                               const float* planes, const Geom& g, float* dsi);
 // ---- stage B, LDS row-band form -------------------------------------------
-hipError_t launch_sort_packets(hipStream_t s, const float2* xy, int np, int ny, int pad,
+hipError_t launch_sort_packets(hipStream_t s, const float2* xy, int np, int ny, int nz, int pad,
                                EvRec* sxy, uint32_t* nvalid, uint16_t* rowstart);
 hipError_t launch_plane_coef(hipStream_t s, const float* centers, const float* planes,
-                             const uint16_t* rowstart, const uint32_t* nvalid, int np,
+                             const uint16_t* rowstart, uint32_t* nvalid, int np,
                              const Geom& g, const BandPlan& bp, PlaneCoef* coef, uint32_t* cuts);
 hipError_t launch_vote_bands(hipStream_t s, const EvRec* sxy, const PlaneCoef* coef,
-                             const uint32_t* cuts, int np, const Geom& g, const BandPlan& bp,
-                             float* out);
-hipError_t launch_sort_groups(hipStream_t s, const float2* xy, int np, int S, int ny, int pad,
+                             const uint32_t* cuts, const uint32_t* slow_any, int np, const Geom& g,
+                             const BandPlan& bp, float* out);
+hipError_t launch_sort_groups(hipStream_t s, const float2* xy, int np, int S, int ny, int nz, int pad,
                               EvRec* sxy, uint8_t* spk, uint32_t* nvalid, uint16_t* rowstart);
 hipError_t launch_group_cuts(hipStream_t s, const uint32_t* prow, const uint16_t* rowstart, int np,
                              int S, const Geom& g, const BandPlan& bp, uint32_t* gcuts);

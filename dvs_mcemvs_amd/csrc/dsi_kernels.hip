@@ -228,8 +228,8 @@ __device__ __forceinline__ int row_bin(float y0, int ny, int pad)
 constexpr int kHashSlots = 2048;  // >= 2 * kPacket
 constexpr unsigned long long kHashEmpty = ~0ull;  // a NaN pair: never a finite location
 
-__global__ __launch_bounds__(256) void k_sort_packets(const float2* __restrict__ xy, int ny,
-                                                      int pad, EvRec* __restrict__ sxy,
+__global__ __launch_bounds__(256) void k_sort_packets(const float2* __restrict__ xy, int np, int ny,
+                                                      int nz, int pad, EvRec* __restrict__ sxy,
                                                       uint32_t* __restrict__ nvalid,
                                                       uint16_t* __restrict__ rowstart)
 {
@@ -237,8 +237,14 @@ __global__ __launch_bounds__(256) void k_sort_packets(const float2* __restrict__
     __shared__ unsigned long long hkey[kHashSlots];
     __shared__ uint32_t hcnt[kHashSlots];
     __shared__ uint32_t wave_tot[4];
+    __shared__ uint32_t big;  // some |x0| or |y0| above 2^40 (never a real pixel)
     const int nb = ny + 2 * pad + 2;
     const int k = blockIdx.x;
+    // nvalid[np + z]: "plane z has a coefficient set that needs the IEEE divide", set by
+    // k_plane_coef (next kernel on the stream), read by the packed voting kernel
+    if (k == 0)
+        for (int i = threadIdx.x; i < nz; i += 256) nvalid[np + i] = 0;
+    if (threadIdx.x == 0) big = 0;
     for (int i = threadIdx.x; i <= nb; i += 256) hist[i] = 0;
     for (int i = threadIdx.x; i < kHashSlots; i += 256) {
         hkey[i] = kHashEmpty;
@@ -265,6 +271,7 @@ __global__ __launch_bounds__(256) void k_sort_packets(const float2* __restrict__
             }
             slot[h] = (int)hs;
             if (atomicAdd(&hcnt[hs], 1u) == 0u) bin[h] = row_bin(ev[h].y, ny, pad);  // representative
+            if (!(fabsf(ev[h].x) <= 0x1p40f && fabsf(ev[h].y) <= 0x1p40f)) big = 1u;
         }
     }
     __syncthreads();
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(256) void k_sort_packets(const float2* __restrict__
             r.m = hcnt[slot[h]];
             sxy[(size_t)k * kPacket + hist[bin[h]] + rank[h]] = r;
         }
-    if (threadIdx.x == 0) nvalid[k] = total;
+    if (threadIdx.x == 0) nvalid[k] = total | (big << 31);  // total <= 1024
 }
 
 // (2) per (packet, plane): coefficients + for every band the run [lo,hi) of the grouped
@@ -317,7 +324,7 @@ __global__ __launch_bounds__(256) void k_sort_packets(const float2* __restrict__
 __global__ __launch_bounds__(256) void k_plane_coef(const float* __restrict__ centers,
                                                     const float* __restrict__ planes,
                                                     const uint16_t* __restrict__ rowstart,
-                                                    const uint32_t* __restrict__ nvalid, int np,
+                                                    uint32_t* __restrict__ nvalid, int np,
                                                     Geom g, BandPlan bp,
                                                     PlaneCoef* __restrict__ coef,
                                                     uint32_t* __restrict__ cuts)
@@ -335,15 +342,23 @@ __global__ __launch_bounds__(256) void k_plane_coef(const float* __restrict__ ce
                        c.bx, c.by, c.d);
     c.r = 1.f / c.d;
     c.pad0 = c.pad1 = 0;
-    const int nv = bp.packed == 2 ? 1 : (int)nvalid[k];
+    const uint32_t nvraw = bp.packed == 2 ? 1u : nvalid[k];
+    const int nv = (int)(nvraw & 0x7fffffffu);
+    const bool big_events = (nvraw >> 31) != 0;
     // Which (packet, plane) pairs can vote at all?  NaN anywhere, d == 0, or an
     // infinite a / bx / by make X or Y non-finite for every event.
     const bool dead = !(c.a == c.a) || !(c.bx == c.bx) || !(c.by == c.by) || !(c.d == c.d) ||
                       c.d == 0.f || !finitef(c.a) || !finitef(c.bx) || !finitef(c.by) || nv == 0;
     const float ad = fabsf(c.d);
-    const bool slow = !dead && !(ad >= 0x1p-40f && ad <= 0x1p40f);  // incl. d = +-inf
+    // "slow": the residual-corrected division is only proven for 2^-40 <= |d| <= 2^40; with
+    // |x0|, |y0|, |a|, |bx|, |by| <= 2^40 as well, no intermediate of the fast path can overflow,
+    // so X and Y are finite there and the voting kernel needs no NaN / overflow guards
+    const bool slow = !dead && (!(ad >= 0x1p-40f && ad <= 0x1p40f) /* incl. d = +-inf */ ||
+                                big_events || fabsf(c.a) > 0x1p40f || fabsf(c.bx) > 0x1p40f ||
+                                fabsf(c.by) > 0x1p40f);
     c.flags = dead ? kCoefSkip : (slow ? kCoefSlow : 0u);
     coef[tid] = c;
+    if (slow) atomicOr(&nvalid[np + z], 1u);
 
     const int pad = bp.row_pad;
     const int nb = g.ny + 2 * pad + 2;
@@ -567,10 +582,123 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands(const EvRec* __restrict__ 
 //     appends their runs back to back into its 64 lanes and votes whenever the lanes are
 //     full, so lane utilisation no longer depends on the run length.  Coefficients are then
 //     per lane (gathered from the plane-major table), not per wave.
+// The stream of one wave.  SLOW = the plane has coefficient sets outside the range where the
+// residual-corrected division is proven (or events / coefficients above 2^40): every lane then
+// takes the IEEE divide and the accept test also guards against inf / inf.
+template <bool SLOW>
+__device__ __forceinline__ void packed_stream(const EvRec* __restrict__ sxy,
+                                              const uint4* __restrict__ coef4,
+                                              const uint32_t* __restrict__ cutz,
+                                              acc_t* __restrict__ band, int p_first, int p_end,
+                                              int group, int stride, int lane, int nx, int Li,
+                                              int Ui, int row_base)
+{
+    // ---- the run stream (all wave-uniform): packets pg .. pg+ng of the current pass, packet k
+    //      of it contributes events [off, hi) of its grouped storage
+    int pg = p_first - stride, ng = 0, k = 0;
+    int off = 0, hi = 0, p = 0;
+    uint32_t mycu = 0, nextcu = 0;  // lane l holds the cut word of packet pg + l (this / next pass)
+    if (lane < group && p_first + lane < p_end) nextcu = cutz[p_first + lane];
+    int f_pk = 0, f_ev = 0;  // per lane: the event the lane takes in the batch being filled
+
+    // append runs to the lanes until 64 are taken or the stream ends; returns the lanes taken
+    auto fill_batch = [&]() -> int {
+        int fill = 0;
+        for (;;) {
+            if (off >= hi) {  // next packet
+                if (++k >= ng) {
+                    pg += stride;
+                    if (pg >= p_end) break;
+                    mycu = nextcu;
+                    const int pl = pg + stride + lane;  // one pass ahead, one coalesced load
+                    nextcu = 0;
+                    if (lane < group && pl < p_end) nextcu = cutz[pl];
+                    ng = min(group, p_end - pg);
+                    k = 0;
+                }
+                const uint32_t cu = __builtin_amdgcn_readlane(mycu, k);
+                off = (int)(cu & 0xffffu);
+                hi = (int)(cu >> 16);
+                p = pg + k;
+                continue;
+            }
+            const int take = min(kWave - fill, hi - off);
+            const int rel = lane - fill;
+            if ((unsigned)rel < (unsigned)take) {
+                f_pk = p;
+                f_ev = off + rel;
+            }
+            fill += take;
+            off += take;
+            if (fill == kWave) break;
+        }
+        return fill;
+    };
+    // issue the gathers of the filled batch.  EVERY lane loads: a lane the batch did not reach
+    // re-reads the (valid) record it took last time and is voted with multiplicity 0.
+    auto gather = [&](EvRec& ev, uint4& va, uint2& vb) {
+        const uint32_t eo = (uint32_t)f_pk * (uint32_t)kPacket + (uint32_t)f_ev;
+        const uint32_t co = 2u * (uint32_t)f_pk;
+        ev = sxy[eo];
+        va = coef4[co];
+        vb = *reinterpret_cast<const uint2*>(coef4 + co + 1u);
+    };
+    auto vote = [&](int n, const EvRec& ev, const uint4& va, const uint2& vb) {
+        const float ka = __uint_as_float(va.x), kbx = __uint_as_float(va.y);
+        const float kby = __uint_as_float(va.z), kd = __uint_as_float(va.w);
+        const float nxv = ev.x * ka + kbx;  // mapper_emvs_stereo.cpp:194-195
+        const float nyv = ev.y * ka + kby;
+        float X, Y;
+        if (SLOW) {
+            X = nxv / kd;
+            Y = nyv / kd;
+        } else {
+            const float kr = __uint_as_float(vb.x);
+            X = div_rc(nxv, kd, kr);
+            Y = div_rc(nyv, kd, kr);
+        }
+        // cartesian3dgrid.h:255-259 restricted to this band's rows, as ONE integer test (each
+        // float compare + mask AND costs scalar-unit slots, the kernel's scarce resource):
+        // with xi = floor(X), yi = floor(Y) (the conversion saturates, NaN -> 0)
+        //   0 <= X < nx-1  <=>  xi >= 0 and nx-2-xi >= 0        (X = -0.0 -> 0, accepted like >= 0.f)
+        //   L <= Y < U     <=>  yi-Li >= 0 and Ui-1-yi >= 0     (L, U are integers)
+        // all four hold iff the OR of the four values has a clear sign bit.  On the fast path X
+        // and Y are finite by construction (k_plane_coef); on the slow path the only NaN source
+        // is inf / inf, excluded by asking for finite numerators.
+        const float xf = __builtin_floorf(X), yf = __builtin_floorf(Y);
+        const int xi = (int)xf, yi = (int)yf;
+        int sgn = xi | (nx - 2 - xi) | (yi - Li) | (Ui - 1 - yi);
+        if (SLOW)
+            sgn |= (fabsf(nxv) < __builtin_inff() && fabsf(nyv) < __builtin_inff()) ? 0 : -1;
+        const uint32_t m = lane < n ? ev.m : 0u;  // lanes beyond a short last batch add zero
+        if (sgn >= 0) {
+            const int idx = __mul24(yi - row_base, nx) + xi;
+            vote4(band, idx, nx, X - xf, Y - yf, m);  // cartesian3dgrid.h:261-270
+        }
+    };
+
+    // two register sets: while the votes of one batch run, the gathers of the next are in flight
+    EvRec eA = {0.f, 0.f, 0u}, eB = eA;
+    uint4 caA = make_uint4(0, 0, 0, 0), caB = caA;
+    uint2 cbA = make_uint2(0, 0), cbB = cbA;
+    int nA = fill_batch();
+    if (nA > 0) gather(eA, caA, cbA);
+    while (nA > 0) {
+        const int nB = fill_batch();
+        if (nB > 0) gather(eB, caB, cbB);
+        vote(nA, eA, caA, cbA);
+        if (nB == 0) break;
+        nA = fill_batch();
+        if (nA > 0) gather(eA, caA, cbA);
+        vote(nB, eB, caB, cbB);
+    }
+}
+
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const EvRec* __restrict__ sxy,
                                                              const PlaneCoef* __restrict__ coef,
                                                              const uint32_t* __restrict__ cuts,
+                                                             const uint32_t* __restrict__ slow_any,
                                                              int np, Geom g, BandPlan bp,
                                                              float* __restrict__ out)
 {
@@ -601,122 +729,19 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const EvRec* __rest
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int lane = threadIdx.x & (kWave - 1);
     const int Li = max(r0 - 1, 0), Ui = min(r1, g.ny - 1);
-    const int row_base = r0 - 1;
     // packets a wave takes per pass: 64 when the chunk is long, fewer (>= 4) when it is short so
     // that every wave of the workgroup gets some
     constexpr int kWaves = BLOCK / kWave;
     int group = kWave;
     while (group > 4 && (p_end - p_begin) < group * kWaves) group >>= 1;
-    const int stride = kWaves * group;
     const uint4* __restrict__ coef4 = reinterpret_cast<const uint4*>(coef) + 2 * (size_t)z * np;
     const uint32_t* __restrict__ cutz = cuts + ((size_t)j * g.nz + z) * np;
-
-    // Lane state.  While a batch is being FILLED a lane only records which event it will take
-    // (packet index + position in the grouped packet).  When the 64 lanes are full the wave
-    // issues the three gathers of that batch (event, coefficients) and, while they are in
-    // flight, votes the PREVIOUS batch whose data was requested one batch earlier.
-    int f_pk = 0, f_ev = 0;  // batch being filled: packet, event slot
-    // two register sets that alternate between "in flight" and "being voted" (no copies)
-    EvRec eA = {0.f, 0.f, 0u}, eB = eA;                // event location at z0 + multiplicity
-    uint4 caA = make_uint4(0, 0, 0, 0), caB = caA;     // a, bx, by, d
-    uint2 cbA = make_uint2(0, 0), cbB = cbA;           // r, flags
-    int inflight = 0;  // lanes of the batch in flight (0 = none)
-    int phase = 0;     // 0: next gathers go to set A, the batch in flight sits in set B
-    int fill = 0;
-
-    auto vote_batch = [&](int n_active, EvRec ev, uint4 va, uint2 vb) {
-        const float ka = __uint_as_float(va.x), kbx = __uint_as_float(va.y);
-        const float kby = __uint_as_float(va.z), kd = __uint_as_float(va.w);
-        const float kr = __uint_as_float(vb.x);
-        const float nxv = ev.x * ka + kbx;  // mapper_emvs_stereo.cpp:194-195
-        const float nyv = ev.y * ka + kby;
-        float X, Y, nmax;
-        // |d| outside [2^-40, 2^40] somewhere in the wave (rare): everybody takes the IEEE
-        // divide, which equals the residual-corrected one wherever that is valid.  nmax: the
-        // largest |numerator| for which the quotient cannot be NaN (IEEE: any finite one;
-        // div_rc: no intermediate overflow below 1e30, and beyond it X > nx anyway)
-        if (__builtin_amdgcn_ballot_w64((vb.y & kCoefSlow) != 0 && lane < n_active) != 0) {
-            X = nxv / kd;
-            Y = nyv / kd;
-            nmax = __builtin_inff();
-        } else {
-            X = div_rc(nxv, kd, kr);
-            Y = div_rc(nyv, kd, kr);
-            nmax = 1e30f;
-        }
-        // cartesian3dgrid.h:255-259 restricted to this band's rows, as ONE integer test (each
-        // float compare + mask AND costs scalar-unit slots, the kernel's scarce resource):
-        // with xi = floor(X), yi = floor(Y) (the conversion saturates, NaN -> 0)
-        //   0 <= X < nx-1  <=>  xi >= 0 and nx-2-xi >= 0        (X = -0.0 -> 0, accepted like >= 0.f)
-        //   L <= Y < U     <=>  yi-Li >= 0 and Ui-1-yi >= 0     (L, U are integers)
-        // all four hold iff the OR of the four values has a clear sign bit.  NaN cannot occur:
-        // events and coefficients are finite, d != 0, and an overflowing numerator gives
-        // a non-finite quotient only through an overflowing numerator -- excluded by nmax.
-        const float xf = __builtin_floorf(X), yf = __builtin_floorf(Y);
-        const int xi = (int)xf, yi = (int)yf;
-        int sgn = xi | (nx - 2 - xi) | (yi - Li) | (Ui - 1 - yi);
-        sgn |= (lane < n_active && fabsf(nxv) < nmax && fabsf(nyv) < nmax) ? 0 : -1;
-        if (sgn >= 0) {
-            const int idx = __mul24(yi - row_base, nx) + xi;
-            vote4(band, idx, nx, X - xf, Y - yf, ev.m);  // cartesian3dgrid.h:261-270
-        }
-    };
-    // the filled batch becomes the batch in flight; the previous one is voted meanwhile
-    auto gather = [&](int n_new, EvRec& ev, uint4& va, uint2& vb) {
-        if (lane < n_new) {
-            // 32-bit element offsets from uniform bases (scalar base + vector offset addressing)
-            const uint32_t eo = (uint32_t)f_pk * (uint32_t)kPacket + (uint32_t)f_ev;
-            const uint32_t co = 2u * (uint32_t)f_pk;
-            ev = sxy[eo];
-            va = coef4[co];
-            vb = *reinterpret_cast<const uint2*>(coef4 + co + 1u);
-        }
-    };
-    auto rotate = [&](int n_new) {
-        if (phase == 0) {
-            gather(n_new, eA, caA, cbA);
-            if (inflight > 0) vote_batch(inflight, eB, caB, cbB);
-        } else {
-            gather(n_new, eB, caB, cbB);
-            if (inflight > 0) vote_batch(inflight, eA, caA, cbA);
-        }
-        inflight = n_new;
-        phase ^= 1;
-    };
-
-    for (int pg = p_begin + wave * group; pg < p_end; pg += stride) {
-        const int pl = pg + lane;
-        uint32_t mycu = 0;
-        if (lane < group && pl < p_end) mycu = cutz[pl];  // consecutive packets: one coalesced load
-        const int ng = min(group, p_end - pg);
-        for (int k = 0; k < ng; ++k) {
-            const uint32_t cu = __builtin_amdgcn_readlane(mycu, k);
-            int off = (int)(cu & 0xffffu);
-            const int hi = (int)(cu >> 16);
-            const int p = pg + k;
-            while (off < hi) {
-                const int take = min(kWave - fill, hi - off);
-                const int rel = lane - fill;
-                if ((unsigned)rel < (unsigned)take) {
-                    f_pk = p;
-                    f_ev = off + rel;
-                }
-                fill += take;
-                off += take;
-                if (fill == kWave) {
-                    rotate(kWave);
-                    fill = 0;
-                }
-            }
-        }
-    }
-    if (fill > 0) rotate(fill);
-    if (inflight > 0) {
-        if (phase == 0)
-            vote_batch(inflight, eB, caB, cbB);
-        else
-            vote_batch(inflight, eA, caA, cbA);
-    }
+    if (slow_any[z] != 0)
+        packed_stream<true>(sxy, coef4, cutz, band, p_begin + wave * group, p_end, group,
+                            kWaves * group, lane, nx, Li, Ui, r0 - 1);
+    else
+        packed_stream<false>(sxy, coef4, cutz, band, p_begin + wave * group, p_end, group,
+                             kWaves * group, lane, nx, Li, Ui, r0 - 1);
     __syncthreads();
 
     const size_t vol = (size_t)g.nx * g.ny * g.nz;
@@ -732,7 +757,7 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const EvRec* __rest
 //     unit is what limits the packed mapping) -- and fetches each lane's coefficients with a
 //     gather that stays inside a 32*S-byte window of the plane-major table.
 __global__ __launch_bounds__(256) void k_sort_groups(const float2* __restrict__ xy, int np, int S,
-                                                     int ny, int pad, EvRec* __restrict__ sxy,
+                                                     int ny, int nz, int pad, EvRec* __restrict__ sxy,
                                                      uint8_t* __restrict__ spk,
                                                      uint32_t* __restrict__ nvalid,
                                                      uint16_t* __restrict__ rowstart)
@@ -744,6 +769,8 @@ __global__ __launch_bounds__(256) void k_sort_groups(const float2* __restrict__ 
     const int p0 = gidx * S;
     const int n_ev = min(S, np - p0) * kPacket;
     const float2* __restrict__ src = xy + (size_t)p0 * kPacket;
+    if (gidx == 0)
+        for (int i = threadIdx.x; i < nz; i += 256) nvalid[np + i] = 0;  // see k_sort_packets
     for (int i = threadIdx.x; i <= nb; i += 256) hist[i] = 0;
     __syncthreads();
     for (int i = threadIdx.x; i < n_ev; i += 256) {
@@ -1306,18 +1333,18 @@ hipError_t launch_vote_global(hipStream_t s, const float2* xy, const float* cent
     return hipGetLastError();
 }
 
-hipError_t launch_sort_packets(hipStream_t s, const float2* xy, int np, int ny, int pad,
+hipError_t launch_sort_packets(hipStream_t s, const float2* xy, int np, int ny, int nz, int pad,
                                EvRec* sxy, uint32_t* nvalid, uint16_t* rowstart)
 {
     if (np <= 0) return hipSuccess;
     const size_t lds = (size_t)(ny + 2 * pad + 3) * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_sort_packets, dim3(np), dim3(256), lds, s, xy, ny, pad, sxy, nvalid,
+    hipLaunchKernelGGL(k_sort_packets, dim3(np), dim3(256), lds, s, xy, np, ny, nz, pad, sxy, nvalid,
                        rowstart);
     return hipGetLastError();
 }
 
 hipError_t launch_plane_coef(hipStream_t s, const float* centers, const float* planes,
-                             const uint16_t* rowstart, const uint32_t* nvalid, int np,
+                             const uint16_t* rowstart, uint32_t* nvalid, int np,
                              const Geom& g, const BandPlan& bp, PlaneCoef* coef, uint32_t* cuts)
 {
     if (np <= 0) return hipSuccess;
@@ -1329,52 +1356,56 @@ hipError_t launch_plane_coef(hipStream_t s, const float* centers, const float* p
 
 template <int BLOCK, bool PACKED>
 static hipError_t launch_vote_bands_t(hipStream_t s, const EvRec* sxy, const PlaneCoef* coef,
-                                      const uint32_t* cuts, int np, const Geom& g,
-                                      const BandPlan& bp, float* out)
+                                      const uint32_t* cuts, const uint32_t* slow_any, int np,
+                                      const Geom& g, const BandPlan& bp, float* out)
 {
     static size_t configured = 0;
-    auto kern = PACKED ? &k_vote_bands_packed<BLOCK> : &k_vote_bands<BLOCK>;
+    const void* kern = PACKED ? reinterpret_cast<const void*>(&k_vote_bands_packed<BLOCK>)
+                              : reinterpret_cast<const void*>(&k_vote_bands<BLOCK>);
     if (bp.lds_bytes > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)bp.lds_bytes);
         if (e != hipSuccess) return e;
         configured = bp.lds_bytes;
     }
     const unsigned blocks = (unsigned)(bp.chunks * bp.bands) * (unsigned)g.nz;
-    hipLaunchKernelGGL(kern, dim3(blocks), dim3(BLOCK), bp.lds_bytes, s, sxy, coef, cuts, np, g, bp,
-                       out);
+    if (PACKED)
+        hipLaunchKernelGGL(k_vote_bands_packed<BLOCK>, dim3(blocks), dim3(BLOCK), bp.lds_bytes, s,
+                           sxy, coef, cuts, slow_any, np, g, bp, out);
+    else
+        hipLaunchKernelGGL(k_vote_bands<BLOCK>, dim3(blocks), dim3(BLOCK), bp.lds_bytes, s, sxy, coef,
+                           cuts, np, g, bp, out);
     return hipGetLastError();
 }
 
 hipError_t launch_vote_bands(hipStream_t s, const EvRec* sxy, const PlaneCoef* coef,
-                             const uint32_t* cuts, int np, const Geom& g, const BandPlan& bp,
-                             float* out)
+                             const uint32_t* cuts, const uint32_t* slow_any, int np, const Geom& g,
+                             const BandPlan& bp, float* out)
 {
     if (np <= 0) return hipSuccess;
     if (bp.packed) {
         switch (bp.block_threads) {
-        case 256: return launch_vote_bands_t<256, true>(s, sxy, coef, cuts, np, g, bp, out);
-        case 512: return launch_vote_bands_t<512, true>(s, sxy, coef, cuts, np, g, bp, out);
-        case 1024: return launch_vote_bands_t<1024, true>(s, sxy, coef, cuts, np, g, bp, out);
+        case 256: return launch_vote_bands_t<256, true>(s, sxy, coef, cuts, slow_any, np, g, bp, out);
+        case 512: return launch_vote_bands_t<512, true>(s, sxy, coef, cuts, slow_any, np, g, bp, out);
+        case 1024: return launch_vote_bands_t<1024, true>(s, sxy, coef, cuts, slow_any, np, g, bp, out);
         default: return hipErrorInvalidValue;
         }
     }
     switch (bp.block_threads) {
-    case 256: return launch_vote_bands_t<256, false>(s, sxy, coef, cuts, np, g, bp, out);
-    case 512: return launch_vote_bands_t<512, false>(s, sxy, coef, cuts, np, g, bp, out);
-    case 1024: return launch_vote_bands_t<1024, false>(s, sxy, coef, cuts, np, g, bp, out);
+    case 256: return launch_vote_bands_t<256, false>(s, sxy, coef, cuts, slow_any, np, g, bp, out);
+    case 512: return launch_vote_bands_t<512, false>(s, sxy, coef, cuts, slow_any, np, g, bp, out);
+    case 1024: return launch_vote_bands_t<1024, false>(s, sxy, coef, cuts, slow_any, np, g, bp, out);
     default: return hipErrorInvalidValue;
     }
 }
 
-hipError_t launch_sort_groups(hipStream_t s, const float2* xy, int np, int S, int ny, int pad,
+hipError_t launch_sort_groups(hipStream_t s, const float2* xy, int np, int S, int ny, int nz, int pad,
                               EvRec* sxy, uint8_t* spk, uint32_t* nvalid, uint16_t* rowstart)
 {
     if (np <= 0) return hipSuccess;
     const int ngroups = (np + S - 1) / S;
     const size_t lds = (size_t)(ny + 2 * pad + 3) * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_sort_groups, dim3(ngroups), dim3(256), lds, s, xy, np, S, ny, pad, sxy, spk,
+    hipLaunchKernelGGL(k_sort_groups, dim3(ngroups), dim3(256), lds, s, xy, np, S, ny, nz, pad, sxy, spk,
                        nvalid, rowstart);
     return hipGetLastError();
 }
