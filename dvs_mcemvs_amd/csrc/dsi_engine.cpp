@@ -291,10 +291,10 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
         if (!accumulate) HIP_TRY(hipMemsetAsync(g->data, 0, g->n * sizeof(float), ctx->stream));
         return DSI_OK;
     }
-    HIP_TRY(m->sxy.reserve(np * dsi::kPacket));
+    HIP_TRY(m->sxy.reserve(np * dsi::kPacket + 1));  // + the multiplicity-0 dummy record
     HIP_TRY(m->nvalid.reserve(np + (size_t)geom.nz));  // + one "needs IEEE divide" word per plane
     HIP_TRY(m->rowstart.reserve(np * (size_t)(geom.ny + 2 * bp.row_pad + 3)));
-    HIP_TRY(m->coef.reserve(np * geom.nz));
+    HIP_TRY(m->coef.reserve(np * geom.nz + 1));       // + the dummy record's "coefficients"
     HIP_TRY(m->cuts.reserve(np * geom.nz * bp.bands));
     const bool direct = (bp.chunks == 1 && !accumulate);
     if (!direct) HIP_TRY(m->partials.reserve((size_t)bp.chunks * g->n));
@@ -754,7 +754,7 @@ int dsi_mapper_set_band_params(dsi_mapper_t* m, int band_rows, int chunks, int b
 int dsi_mapper_set_packed_lanes(dsi_mapper_t* m, int mode)
 {
     REQUIRE(m, DSI_ERR_INVALID, "mapper is null");
-    REQUIRE(mode >= -1 && mode <= 2, DSI_ERR_INVALID, "mode must be -1 (auto), 0, 1 or 2");
+    REQUIRE(mode >= -1 && mode <= 3, DSI_ERR_INVALID, "mode must be -1 (auto), 0, 1, 2 or 3");
     m->want_packed = mode;
     return DSI_OK;
 }

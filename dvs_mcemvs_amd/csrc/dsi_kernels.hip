@@ -242,8 +242,13 @@ __global__ __launch_bounds__(256) void k_sort_packets(const float2* __restrict__
     const int k = blockIdx.x;
     // nvalid[np + z]: "plane z has a coefficient set that needs the IEEE divide", set by
     // k_plane_coef (next kernel on the stream), read by the packed voting kernel
-    if (k == 0)
+    if (k == 0) {
         for (int i = threadIdx.x; i < nz; i += 256) nvalid[np + i] = 0;
+        if (threadIdx.x == 0) {  // the multiplicity-0 record behind the last packet
+            const EvRec none = {0.f, 0.f, 0u};
+            sxy[(size_t)np * kPacket] = none;
+        }
+    }
     if (threadIdx.x == 0) big = 0;
     for (int i = threadIdx.x; i <= nb; i += 256) hist[i] = 0;
     for (int i = threadIdx.x; i < kHashSlots; i += 256) {
@@ -582,68 +587,151 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands(const EvRec* __restrict__ 
 //     appends their runs back to back into its 64 lanes and votes whenever the lanes are
 //     full, so lane utilisation no longer depends on the run length.  Coefficients are then
 //     per lane (gathered from the plane-major table), not per wave.
+// floor(X) as an integer in one instruction (saturating, NaN -> 0), instead of floor + convert
+__device__ __forceinline__ int floor_to_int(float x)
+{
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 // The stream of one wave.  SLOW = the plane has coefficient sets outside the range where the
 // residual-corrected division is proven (or events / coefficients above 2^40): every lane then
 // takes the IEEE divide and the accept test also guards against inf / inf.
+//
+// Issue rates measured on gfx950 (tools/valu_rate_bench.hip, wave-instructions / clk / CU):
+// fp32 add/mul/fma and plain integer add/sub/logic/shift ~1.6-2, everything else (conversions,
+// floor/fract, three-operand integer ops, compares, v_cndmask, 24-bit and 64-bit multiplies)
+// ~0.95, and v_pk_*_f32 0.95 (no gain over two scalar ops).  The loop below is bound by VALU
+// issue, so it is written to need few instructions of the second kind.
 template <bool SLOW>
 __device__ __forceinline__ void packed_stream(const EvRec* __restrict__ sxy,
                                               const uint4* __restrict__ coef4,
                                               const uint32_t* __restrict__ cutz,
-                                              acc_t* __restrict__ band, int p_first, int p_end,
-                                              int group, int stride, int lane, int nx, int Li,
-                                              int Ui, int row_base)
+                                              char* __restrict__ band_bytes, int p_first,
+                                              int p_end, int lg_group, int stride, int lane,
+                                              int nx, int Li, int Ui, int row_base,
+                                              uint32_t dummy_eo)
 {
-    // ---- the run stream (all wave-uniform): packets pg .. pg+ng of the current pass, packet k
-    //      of it contributes events [off, hi) of its grouped storage
-    int pg = p_first - stride, ng = 0, k = 0;
-    int off = 0, hi = 0, p = 0;
-    uint32_t mycu = 0, nextcu = 0;  // lane l holds the cut word of packet pg + l (this / next pass)
-    if (lane < group && p_first + lane < p_end) nextcu = cutz[p_first + lane];
-    int f_pk = 0, f_ev = 0;  // per lane: the event the lane takes in the batch being filled
+    // ---- the run stream (all wave-uniform).  The wave owns packets i = 0 .. n_my-1:
+    //      packet i is p_first + (i >> lg_group) * stride + (i & (group-1)); it contributes the
+    //      records [off, hi) of its grouped storage.
+    const int group = 1 << lg_group;
+    int n_my = 0;
+    if (p_first < p_end) {
+        const int passes = (p_end - p_first + stride - 1) / stride;         // >= 1
+        const int last = p_first + (passes - 1) * stride;
+        n_my = (passes - 1) * group + min(group, p_end - last);
+    }
+    n_my = __builtin_amdgcn_readfirstlane(n_my);  // (the division runs on the vector unit)
+    int i = -1;
+    int cur = 0, end = 0;  // absolute record indices (packet * 1024 + slot) of the current run
+    int pbase = 0;         // current packet * 1024
+    uint32_t mycu = 0;     // lane l: cut word of packet l of the current pass
+    uint32_t eo = 0;       // per lane: the record the lane takes next
+    const int gmask = __builtin_amdgcn_readfirstlane(group - 1);
 
-    // append runs to the lanes until 64 are taken or the stream ends; returns the lanes taken
+    // Append runs to the lanes until 64 are taken or the stream ends; returns the lanes taken.
+    // The bookkeeping is scalar work, and the CU issues ONE scalar instruction per clock (for
+    // all its waves): compiled from C++ this loop cost ~60 scalar instructions per batch and
+    // bounded the kernel (PMC: SQ_INSTS_SALU ~ SQ_INSTS_VALU).  Hand-scheduled: 11 per run
+    // piece + 13 per packet, and the lane update is one VALU add under a shifted exec mask
+    // (lanes [fill, 64) take consecutive records; those beyond the run are overwritten by the
+    // next piece, or retired to the multiplicity-0 record when the stream ends).
     auto fill_batch = [&]() -> int {
         int fill = 0;
         for (;;) {
-            if (off >= hi) {  // next packet
-                if (++k >= ng) {
-                    pg += stride;
-                    if (pg >= p_end) break;
-                    mycu = nextcu;
-                    const int pl = pg + stride + lane;  // one pass ahead, one coalesced load
-                    nextcu = 0;
-                    if (lane < group && pl < p_end) nextcu = cutz[pl];
-                    ng = min(group, p_end - pg);
-                    k = 0;
-                }
-                const uint32_t cu = __builtin_amdgcn_readlane(mycu, k);
-                off = (int)(cu & 0xffffu);
-                hi = (int)(cu >> 16);
-                p = pg + k;
-                continue;
+            int status, t0, t1;
+            // (all wave-uniform already; the readfirstlanes only pin them to scalar registers)
+            cur = __builtin_amdgcn_readfirstlane(cur);
+            end = __builtin_amdgcn_readfirstlane(end);
+            i = __builtin_amdgcn_readfirstlane(i);
+            pbase = __builtin_amdgcn_readfirstlane(pbase);
+            fill = __builtin_amdgcn_readfirstlane(fill);
+            asm volatile(
+                "Ltop%=:\n\t"
+                "s_cmp_ge_i32 %0, %1\n\t"
+                "s_cbranch_scc1 Lnext%=\n\t"
+                "s_sub_i32 %7, 64, %4\n\t"        // room in the batch
+                "s_sub_i32 %8, %1, %0\n\t"        // records left in the run
+                "s_min_i32 %7, %7, %8\n\t"        // take
+                "s_sub_i32 %8, %0, %4\n\t"        // record of lane 0 if the run started there
+                "s_lshl_b64 exec, -1, %4\n\t"     // lanes >= fill
+                "v_add_u32 %5, %8, %11\n\t"
+                "s_mov_b64 exec, -1\n\t"
+                "s_add_i32 %4, %4, %7\n\t"
+                "s_add_i32 %0, %0, %7\n\t"
+                "s_cmp_lt_u32 %4, 64\n\t"
+                "s_cbranch_scc0 Lfull%=\n"        // not full => the run is exhausted
+                "Lnext%=:\n\t"
+                "s_add_i32 %2, %2, 1\n\t"
+                "s_cmp_ge_i32 %2, %9\n\t"
+                "s_cbranch_scc1 Leos%=\n\t"
+                "s_and_b32 %7, %2, %10\n\t"       // packet within the pass
+                "s_cmp_eq_u32 %7, 0\n\t"
+                "s_cbranch_scc1 Lreload%=\n\t"
+                "v_readlane_b32 %8, %12, %7\n\t"  // its cut word
+                "s_addk_i32 %3, 0x400\n\t"
+                "s_and_b32 %7, %8, 0xffff\n\t"
+                "s_lshr_b32 %8, %8, 16\n\t"
+                "s_add_i32 %0, %3, %7\n\t"
+                "s_add_i32 %1, %3, %8\n\t"
+                "s_branch Ltop%=\n"
+                "Lfull%=:\n\t"
+                "s_mov_b32 %6, 0\n\t"
+                "s_branch Ldone%=\n"
+                "Lreload%=:\n\t"
+                "s_mov_b32 %6, 1\n\t"
+                "s_branch Ldone%=\n"
+                "Leos%=:\n\t"
+                "s_mov_b32 %6, 2\n"
+                "Ldone%=:"
+                : "+s"(cur), "+s"(end), "+s"(i), "+s"(pbase), "+s"(fill), "+v"(eo), "=&s"(status),
+                  "=&s"(t0), "=&s"(t1)
+                : "s"(n_my), "s"(gmask), "v"(lane), "v"(mycu)
+                : "scc");
+            if (status == 0) break;  // 64 lanes taken
+            if (status == 2) {       // end of the stream
+                if (fill > 0) eo = lane >= fill ? dummy_eo : eo;
+                break;
             }
-            const int take = min(kWave - fill, hi - off);
-            const int rel = lane - fill;
-            if ((unsigned)rel < (unsigned)take) {
-                f_pk = p;
-                f_ev = off + rel;
-            }
-            fill += take;
-            off += take;
-            if (fill == kWave) break;
+            // first packet of a pass: one coalesced load of the pass's cut words, waited for
+            // HERE (a compiler-visible load still pending later would make its next wait a wait
+            // for everything in flight)
+            const int pp = __builtin_amdgcn_readfirstlane(p_first + (i >> lg_group) * stride);
+            mycu = cutz[min(pp + lane, p_end - 1)];
+            const uint32_t cu = __builtin_amdgcn_readfirstlane(mycu);
+            pbase = pp << 10;
+            cur = pbase + (int)(cu & 0xffffu);
+            end = pbase + (int)(cu >> 16);
         }
         return fill;
     };
-    // issue the gathers of the filled batch.  EVERY lane loads: a lane the batch did not reach
-    // re-reads the (valid) record it took last time and is voted with multiplicity 0.
-    auto gather = [&](EvRec& ev, uint4& va, uint2& vb) {
-        const uint32_t eo = (uint32_t)f_pk * (uint32_t)kPacket + (uint32_t)f_ev;
-        const uint32_t co = 2u * (uint32_t)f_pk;
-        ev = sxy[eo];
-        va = coef4[co];
-        vb = *reinterpret_cast<const uint2*>(coef4 + co + 1u);
+    // Issue the gathers of the filled batch.  The three loads and the wait for them are inline
+    // assembly: with compiler-visible loads the register allocator reuses destination registers
+    // of the set in flight as temporaries of fill_batch and the waitcnt pass then waits for ALL
+    // outstanding loads there (vmcnt(0)), which undoes the prefetch.  The compiler only sees
+    // opaque values defined by `gather` and redefined by `arrived`; nothing touches them between.
+    typedef float v3f __attribute__((ext_vector_type(3)));
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    const uint4* coef_r = reinterpret_cast<const uint4*>(coef4);
+    auto gather = [&](v3f& ev, v4u& va, uint32_t& vr) {
+        const uint32_t eo12 = eo * 12u;                 // byte offset of the record (< 2^32)
+        const uint32_t co = (eo >> 5) & ~31u;           // byte offset of the packet's coefficients
+        asm volatile("global_load_dwordx3 %0, %3, %5\n\t"
+                     "global_load_dwordx4 %1, %4, %6\n\t"
+                     "global_load_dword %2, %4, %6 offset:16"
+                     : "=&v"(ev), "=&v"(va), "=&v"(vr)
+                     : "v"(eo12), "v"(co), "s"(sxy), "s"(coef_r)
+                     : "memory");
     };
-    auto vote = [&](int n, const EvRec& ev, const uint4& va, const uint2& vb) {
+    // all loads but the three newest (the next batch's) have arrived
+    auto arrived = [&](v3f& ev, v4u& va, uint32_t& vr) {
+        asm volatile("s_waitcnt vmcnt(3)" : "+v"(ev), "+v"(va), "+v"(vr) : : "memory");
+    };
+    const int nx8 = nx * 8;
+    const int cbase = -row_base * nx8;
+    auto vote = [&](const v3f& ev, const v4u& va, uint32_t vr) {
         const float ka = __uint_as_float(va.x), kbx = __uint_as_float(va.y);
         const float kby = __uint_as_float(va.z), kd = __uint_as_float(va.w);
         const float nxv = ev.x * ka + kbx;  // mapper_emvs_stereo.cpp:194-195
@@ -653,45 +741,240 @@ __device__ __forceinline__ void packed_stream(const EvRec* __restrict__ sxy,
             X = nxv / kd;
             Y = nyv / kd;
         } else {
-            const float kr = __uint_as_float(vb.x);
+            const float kr = __uint_as_float(vr);
             X = div_rc(nxv, kd, kr);
             Y = div_rc(nyv, kd, kr);
         }
-        // cartesian3dgrid.h:255-259 restricted to this band's rows, as ONE integer test (each
-        // float compare + mask AND costs scalar-unit slots, the kernel's scarce resource):
+        // cartesian3dgrid.h:255-259 restricted to this band's rows, as ONE integer test:
         // with xi = floor(X), yi = floor(Y) (the conversion saturates, NaN -> 0)
         //   0 <= X < nx-1  <=>  xi >= 0 and nx-2-xi >= 0        (X = -0.0 -> 0, accepted like >= 0.f)
         //   L <= Y < U     <=>  yi-Li >= 0 and Ui-1-yi >= 0     (L, U are integers)
         // all four hold iff the OR of the four values has a clear sign bit.  On the fast path X
         // and Y are finite by construction (k_plane_coef); on the slow path the only NaN source
         // is inf / inf, excluded by asking for finite numerators.
-        const float xf = __builtin_floorf(X), yf = __builtin_floorf(Y);
-        const int xi = (int)xf, yi = (int)yf;
+        const int xi = floor_to_int(X), yi = floor_to_int(Y);
         int sgn = xi | (nx - 2 - xi) | (yi - Li) | (Ui - 1 - yi);
         if (SLOW)
             sgn |= (fabsf(nxv) < __builtin_inff() && fabsf(nyv) < __builtin_inff()) ? 0 : -1;
-        const uint32_t m = lane < n ? ev.m : 0u;  // lanes beyond a short last batch add zero
         if (sgn >= 0) {
-            const int idx = __mul24(yi - row_base, nx) + xi;
-            vote4(band, idx, nx, X - xf, Y - yf, m);  // cartesian3dgrid.h:261-270
+            // accepted => X, Y >= 0, where v_fract is exactly X - floor(X)
+            const float fx = __builtin_amdgcn_fractf(X), fy = __builtin_amdgcn_fractf(Y);
+            acc_t* cell = reinterpret_cast<acc_t*>(band_bytes + (__mul24(yi, nx8) + ((xi << 3) + cbase)));
+            vote4(cell, 0, nx, fx, fy, __float_as_uint(ev.z));  // cartesian3dgrid.h:261-270
         }
     };
 
     // two register sets: while the votes of one batch run, the gathers of the next are in flight
-    EvRec eA = {0.f, 0.f, 0u}, eB = eA;
-    uint4 caA = make_uint4(0, 0, 0, 0), caB = caA;
-    uint2 cbA = make_uint2(0, 0), cbB = cbA;
+    // (the gathers are issued unconditionally -- an empty batch re-reads valid stale records --
+    //  so that exactly three loads are newer than the ones a vote waits for)
+    v3f eA, eB;
+    v4u caA, caB;
+    uint32_t crA, crB;
     int nA = fill_batch();
-    if (nA > 0) gather(eA, caA, cbA);
+    gather(eA, caA, crA);
     while (nA > 0) {
         const int nB = fill_batch();
-        if (nB > 0) gather(eB, caB, cbB);
-        vote(nA, eA, caA, cbA);
+        gather(eB, caB, crB);
+        arrived(eA, caA, crA);
+        vote(eA, caA, crA);
         if (nB == 0) break;
         nA = fill_batch();
-        if (nA > 0) gather(eA, caA, cbA);
-        vote(nB, eB, caB, cbB);
+        gather(eA, caA, crA);
+        arrived(eB, caB, crB);
+        vote(eB, caB, crB);
     }
+    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");  // the last (empty) batch's loads
+}
+
+// The same stream, fast path only (no IEEE-divide planes), written in gfx950 assembly.
+//
+// Why: PMC counters of the compiled stream (10 M events x 100 planes) show ~61 scalar and ~63
+// vector instructions per 64-lane batch at ~78 CU-clocks per batch: the scalar unit (one
+// instruction per clock per CU, shared by all its waves) is ~80 % busy, mostly with compiler
+// glue around the run bookkeeping, and the prefetch registers get shuffled.  Written by hand
+// the batch costs ~34 scalar + ~46 vector instructions + 4 ds_add_u64, which leaves the LDS
+// atomic unit (~11 clocks per ds_add_u64 wave instruction) as the next bound.
+//
+// Register map (all listed as clobbers; the operands are read-only):
+//   s40 cur  s41 end  s42 packet counter i  s43 packet*1024  s44 fill  s45,s46 temporaries
+//   s47 lanes of the batch in set A, s48 of set B
+//   v40 record index per lane (eo)   v41 cut words of the pass
+//   set A: v[42:44] record (x0,y0,m)  v45 r  v[46:49] a,bx,by,d      set B: v[50:52] v53 v[54:57]
+//   (register tuples must be even-aligned on gfx950)
+//   v36-v39, v58-v63 temporaries
+// The arithmetic of VOTE is instruction for instruction what packed_stream<false> compiles to
+// (mapper_emvs_stereo.cpp:194-195, div_rc, cartesian3dgrid.h:255-270), so both give the same bits.
+#define DSI_ASM_FILL(NOUT, L)                                                                      \
+    "s_mov_b32 s44, 0\n"                                                                            \
+    "Ltop" L "%=:\n\t"                                                                              \
+    "s_cmp_ge_i32 s40, s41\n\t"                                                                     \
+    "s_cbranch_scc1 Lnext" L "%=\n\t"                                                               \
+    "s_sub_i32 s45, 64, s44\n\t"          /* room in the batch */                                   \
+    "s_sub_i32 s46, s41, s40\n\t"         /* records left in the run */                             \
+    "s_min_i32 s45, s45, s46\n\t"         /* take */                                                \
+    "s_sub_i32 s46, s40, s44\n\t"         /* record of lane 0 if the run started there */           \
+    "s_lshl_b64 exec, -1, s44\n\t"        /* lanes >= fill */                                       \
+    "v_add_u32 v40, s46, %15\n\t"                                                                   \
+    "s_mov_b64 exec, -1\n\t"                                                                        \
+    "s_add_i32 s44, s44, s45\n\t"                                                                   \
+    "s_add_i32 s40, s40, s45\n\t"                                                                   \
+    "s_cmp_lt_u32 s44, 64\n\t"                                                                      \
+    "s_cbranch_scc0 Ldone" L "%=\n"       /* not full => the run is exhausted */                    \
+    "Lnext" L "%=:\n\t"                                                                             \
+    "s_add_i32 s42, s42, 1\n\t"                                                                     \
+    "s_cmp_ge_i32 s42, %3\n\t"                                                                      \
+    "s_cbranch_scc1 Leos" L "%=\n\t"                                                                \
+    "s_and_b32 s45, s42, %4\n\t"          /* packet within the pass */                              \
+    "s_cmp_eq_u32 s45, 0\n\t"                                                                       \
+    "s_cbranch_scc1 Lreload" L "%=\n\t"                                                             \
+    "v_readlane_b32 s46, v41, s45\n\t"    /* its cut word */                                        \
+    "s_addk_i32 s43, 0x400\n"                                                                       \
+    "Lhave" L "%=:\n\t"                                                                             \
+    "s_and_b32 s45, s46, 0xffff\n\t"                                                                \
+    "s_lshr_b32 s46, s46, 16\n\t"                                                                   \
+    "s_add_i32 s40, s43, s45\n\t"                                                                   \
+    "s_add_i32 s41, s43, s46\n\t"                                                                   \
+    "s_branch Ltop" L "%=\n"                                                                        \
+    "Lreload" L "%=:\n\t"                 /* first packet of a pass: load the pass's cut words */   \
+    "s_lshr_b32 s45, s42, %7\n\t"                                                                   \
+    "s_mul_i32 s45, s45, %6\n\t"                                                                    \
+    "s_add_i32 s45, s45, %5\n\t"          /* first packet of the pass */                            \
+    "s_lshl_b32 s43, s45, 10\n\t"                                                                   \
+    "v_add_u32 v58, s45, %15\n\t"                                                                   \
+    "v_min_i32 v58, %8, v58\n\t"                                                                    \
+    "v_lshlrev_b32 v58, 2, v58\n\t"                                                                 \
+    "global_load_dword v41, v58, %2\n\t"                                                            \
+    "s_waitcnt vmcnt(0)\n\t"                                                                        \
+    "v_readfirstlane_b32 s46, v41\n\t"                                                              \
+    "s_branch Lhave" L "%=\n"                                                                       \
+    "Leos" L "%=:\n\t"                    /* stream over: unreached lanes -> multiplicity-0 record */ \
+    "s_cmp_eq_u32 s44, 0\n\t"                                                                       \
+    "s_cbranch_scc1 Ldone" L "%=\n\t"                                                               \
+    "s_lshl_b64 exec, -1, s44\n\t"                                                                  \
+    "v_mov_b32 v40, %14\n\t"                                                                        \
+    "s_mov_b64 exec, -1\n"                                                                          \
+    "Ldone" L "%=:\n\t"                                                                             \
+    "s_mov_b32 " NOUT ", s44\n\t"
+
+#define DSI_ASM_GATHER(EV, CA, CR)                                                                 \
+    "v_mul_lo_u32 v58, v40, 12\n\t"       /* byte offset of the record */                           \
+    "v_lshrrev_b32 v59, 5, v40\n\t"                                                                 \
+    "v_and_b32 v59, 0x7ffffe0, v59\n\t"   /* byte offset of the packet's coefficients */            \
+    "global_load_dwordx3 " EV ", v58, %0\n\t"                                                       \
+    "global_load_dwordx4 " CA ", v59, %1\n\t"                                                       \
+    "global_load_dword " CR ", v59, %1 offset:16\n\t"
+
+#define DSI_ASM_VOTE(EX, EY, EM, KA, KBX, KBY, KD, KR)                                             \
+    "v_mul_f32 v58, " EX ", " KA "\n\t"                                                             \
+    "v_mul_f32 v59, " EY ", " KA "\n\t"                                                             \
+    "v_add_f32 v58, v58, " KBX "\n\t"     /* x0*a + bx */                                           \
+    "v_add_f32 v59, v59, " KBY "\n\t"     /* y0*a + by */                                           \
+    "v_mul_f32 v60, v58, " KR "\n\t"      /* div_rc: q = n*r */                                     \
+    "v_mul_f32 v61, v59, " KR "\n\t"                                                                \
+    "v_fma_f32 v62, -" KD ", v60, v58\n\t"                                                          \
+    "v_fma_f32 v63, -" KD ", v61, v59\n\t"                                                          \
+    "v_fma_f32 v60, v62, " KR ", v60\n\t"                                                           \
+    "v_fma_f32 v61, v63, " KR ", v61\n\t"                                                           \
+    "v_fma_f32 v62, -" KD ", v60, v58\n\t"                                                          \
+    "v_fma_f32 v63, -" KD ", v61, v59\n\t"                                                          \
+    "v_fma_f32 v60, v62, " KR ", v60\n\t" /* X */                                                   \
+    "v_fma_f32 v61, v63, " KR ", v61\n\t" /* Y */                                                   \
+    "v_cvt_flr_i32_f32 v58, v60\n\t"      /* xi */                                                  \
+    "v_cvt_flr_i32_f32 v59, v61\n\t"      /* yi */                                                  \
+    "v_sub_u32 v62, %11, v58\n\t"         /* nx-2-xi */                                             \
+    "v_subrev_u32 v63, %12, v59\n\t"      /* yi-Li */                                               \
+    "v_sub_u32 v36, %13, v59\n\t"         /* Ui-1-yi */                                             \
+    "v_or3_b32 v62, v62, v63, v36\n\t"                                                              \
+    "v_or_b32 v62, v62, v58\n\t"                                                                    \
+    "v_cmpx_lt_i32 vcc, -1, v62\n\t"      /* exec = lanes whose four values are all >= 0 */         \
+    "v_fract_f32 v60, v60\n\t"            /* fx (X >= 0 here) */                                    \
+    "v_fract_f32 v61, v61\n\t"            /* fy */                                                  \
+    "v_lshl_add_u32 v58, v58, 3, %10\n\t"                                                           \
+    "v_mad_i32_i24 v59, v59, %9, v58\n\t" /* LDS byte address of voxel (xi, yi) */                  \
+    "v_sub_f32 v62, 1.0, v60\n\t"         /* 1-fx */                                                \
+    "v_sub_f32 v63, 1.0, v61\n\t"         /* 1-fy */                                                \
+    "v_mul_f32 v60, 0x4f000000, v60\n\t"  /* fx * 2^31 */                                           \
+    "v_mul_f32 v62, 0x4f000000, v62\n\t"  /* (1-fx) * 2^31 */                                       \
+    "v_mul_f32 v36, v62, v63\n\t"                                                                   \
+    "v_mul_f32 v37, v60, v63\n\t"                                                                   \
+    "v_mul_f32 v38, v62, v61\n\t"                                                                   \
+    "v_mul_f32 v39, v60, v61\n\t"                                                                   \
+    "v_cvt_u32_f32 v36, v36\n\t"                                                                    \
+    "v_cvt_u32_f32 v37, v37\n\t"                                                                    \
+    "v_cvt_u32_f32 v38, v38\n\t"                                                                    \
+    "v_cvt_u32_f32 v39, v39\n\t"                                                                    \
+    "v_add_u32 v58, %9, v59\n\t"          /* next row */                                            \
+    "v_mad_u64_u32 v[62:63], vcc, v36, " EM ", 0\n\t"                                               \
+    "ds_add_u64 v59, v[62:63]\n\t"                                                                  \
+    "v_mad_u64_u32 v[60:61], vcc, v37, " EM ", 0\n\t"                                               \
+    "ds_add_u64 v59, v[60:61] offset:8\n\t"                                                         \
+    "v_mad_u64_u32 v[62:63], vcc, v38, " EM ", 0\n\t"                                               \
+    "ds_add_u64 v58, v[62:63]\n\t"                                                                  \
+    "v_mad_u64_u32 v[60:61], vcc, v39, " EM ", 0\n\t"                                               \
+    "ds_add_u64 v58, v[60:61] offset:8\n\t"                                                         \
+    "s_mov_b64 exec, -1\n\t"
+
+__device__ __forceinline__ void packed_stream_asm(const EvRec* sxy, const uint4* coef4,
+                                                  const uint32_t* cutz, char* band_bytes,
+                                                  int p_first, int p_end, int lg_group, int stride,
+                                                  int lane, int nx, int Li, int Ui, int row_base,
+                                                  uint32_t dummy_eo)
+{
+    const int group = 1 << lg_group;
+    int n_my = 0;
+    if (p_first < p_end) {
+        const int passes = (p_end - p_first + stride - 1) / stride;
+        const int last = p_first + (passes - 1) * stride;
+        n_my = (passes - 1) * group + min(group, p_end - last);
+    }
+    // every operand is wave-uniform; the readfirstlanes pin them to scalar registers
+    const int s_n_my = __builtin_amdgcn_readfirstlane(n_my);
+    const int s_gmask = __builtin_amdgcn_readfirstlane(group - 1);
+    const int s_p_first = __builtin_amdgcn_readfirstlane(p_first);
+    const int s_stride = __builtin_amdgcn_readfirstlane(stride);
+    const int s_lg = __builtin_amdgcn_readfirstlane(lg_group);
+    const int s_p_last = __builtin_amdgcn_readfirstlane(p_end - 1);
+    const int s_nx8 = __builtin_amdgcn_readfirstlane(nx * 8);
+    const int lds_base = (int)(uintptr_t)band_bytes;  // LDS byte offset of the band
+    const int s_cbase = __builtin_amdgcn_readfirstlane(lds_base - row_base * nx * 8);
+    const int s_nxm2 = __builtin_amdgcn_readfirstlane(nx - 2);
+    const int s_Li = __builtin_amdgcn_readfirstlane(Li);
+    const int s_Uim1 = __builtin_amdgcn_readfirstlane(Ui - 1);
+    const uint32_t s_dummy = __builtin_amdgcn_readfirstlane(dummy_eo);
+    asm volatile(
+        "s_mov_b32 s42, -1\n\t"
+        "s_mov_b32 s40, 0\n\t"
+        "s_mov_b32 s41, 0\n\t"
+        "s_mov_b32 s43, 0\n\t"
+        "v_mov_b32 v40, 0\n\t"
+        "v_mov_b32 v41, 0\n\t"
+        DSI_ASM_FILL("s47", "a")
+        DSI_ASM_GATHER("v[42:44]", "v[46:49]", "v45")
+        "s_cmp_eq_u32 s47, 0\n\t"
+        "s_cbranch_scc1 Lend%=\n"
+        "Lloop%=:\n\t"
+        DSI_ASM_FILL("s48", "b")
+        DSI_ASM_GATHER("v[50:52]", "v[54:57]", "v53")
+        "s_waitcnt vmcnt(3)\n\t"
+        DSI_ASM_VOTE("v42", "v43", "v44", "v46", "v47", "v48", "v49", "v45")
+        "s_cmp_eq_u32 s48, 0\n\t"
+        "s_cbranch_scc1 Lend%=\n\t"
+        DSI_ASM_FILL("s47", "c")
+        DSI_ASM_GATHER("v[42:44]", "v[46:49]", "v45")
+        "s_waitcnt vmcnt(3)\n\t"
+        DSI_ASM_VOTE("v50", "v51", "v52", "v54", "v55", "v56", "v57", "v53")
+        "s_cmp_lg_u32 s47, 0\n\t"
+        "s_cbranch_scc1 Lloop%=\n"
+        "Lend%=:\n\t"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)"
+        :
+        : "s"(sxy), "s"(coef4), "s"(cutz), "s"(s_n_my), "s"(s_gmask), "s"(s_p_first), "s"(s_stride),
+          "s"(s_lg), "s"(s_p_last), "s"(s_nx8), "s"(s_cbase), "s"(s_nxm2), "s"(s_Li), "s"(s_Uim1),
+          "s"(s_dummy), "v"(lane)
+        : "memory", "scc", "vcc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48",
+          "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48",
+          "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61",
+          "v62", "v63");
 }
 
 template <int BLOCK>
@@ -732,16 +1015,25 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const EvRec* __rest
     // packets a wave takes per pass: 64 when the chunk is long, fewer (>= 4) when it is short so
     // that every wave of the workgroup gets some
     constexpr int kWaves = BLOCK / kWave;
-    int group = kWave;
-    while (group > 4 && (p_end - p_begin) < group * kWaves) group >>= 1;
+    int lg_group = 6;
+    while (lg_group > 2 && (p_end - p_begin) < (kWaves << lg_group)) --lg_group;
+    const int group = 1 << lg_group;
     const uint4* __restrict__ coef4 = reinterpret_cast<const uint4*>(coef) + 2 * (size_t)z * np;
     const uint32_t* __restrict__ cutz = cuts + ((size_t)j * g.nz + z) * np;
+    // record np * 1024 is a dummy with multiplicity 0 (k_sort_packets) for the lanes a short last
+    // batch does not reach; "its" coefficients are whatever follows the plane's table
+    const uint32_t dummy_eo = (uint32_t)np * (uint32_t)kPacket;
+    char* band_bytes = reinterpret_cast<char*>(band);
+    // bp.packed == 3 selects the compiled stream on the fast path too (A/B testing)
     if (slow_any[z] != 0)
-        packed_stream<true>(sxy, coef4, cutz, band, p_begin + wave * group, p_end, group,
-                            kWaves * group, lane, nx, Li, Ui, r0 - 1);
+        packed_stream<true>(sxy, coef4, cutz, band_bytes, p_begin + wave * group, p_end, lg_group,
+                            kWaves * group, lane, nx, Li, Ui, r0 - 1, dummy_eo);
+    else if (bp.packed == 3)
+        packed_stream<false>(sxy, coef4, cutz, band_bytes, p_begin + wave * group, p_end, lg_group,
+                             kWaves * group, lane, nx, Li, Ui, r0 - 1, dummy_eo);
     else
-        packed_stream<false>(sxy, coef4, cutz, band, p_begin + wave * group, p_end, group,
-                             kWaves * group, lane, nx, Li, Ui, r0 - 1);
+        packed_stream_asm(sxy, coef4, cutz, band_bytes, p_begin + wave * group, p_end, lg_group,
+                          kWaves * group, lane, nx, Li, Ui, r0 - 1, dummy_eo);
     __syncthreads();
 
     const size_t vol = (size_t)g.nx * g.ny * g.nz;
