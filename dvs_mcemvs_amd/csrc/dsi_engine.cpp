@@ -191,9 +191,11 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
     bp->lds_bytes = (size_t)(band_rows + 2) * row_bytes;
     bp->block_threads = m->want_block > 0 ? m->want_block : 1024;
     bp->row_pad = std::min(g.ny, 4096);  // z0 locations spill up to ~ny rows outside the grid
-    // expected events of one packet in one band; short runs waste lanes in the per-packet kernel
+    // expected events of one packet in one band.  The packed mapping (hand-scheduled wave loop)
+    // is the default at every run length: measured 1.1x (240x180) to 3x (1024x1024) faster than
+    // the per-packet mapping.
     const long run = 1024L * (band_rows + 1) / g.ny;
-    bp->packed = m->want_packed >= 0 ? m->want_packed : (run < 512 ? 1 : 0);
+    bp->packed = m->want_packed >= 0 ? m->want_packed : 1;
     // mapping 2 sorts S consecutive packets together so that a run holds >= ~512 events
     int S = 1;
     while (S < 32 && (long)S * std::max<long>(run, 1) < 512) S <<= 1;

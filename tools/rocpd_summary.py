@@ -1,12 +1,14 @@
 #!/usr/bin/env python
 """Summarise a rocprofv3 (rocpd sqlite) result: per-kernel stats and, when present,
-per-kernel PMC counter averages.  Usage: rocpd_summary.py results.db [more.db ...]"""
+per-kernel PMC counter averages.  Usage: rocpd_summary.py [--all] results.db [more.db ...]"""
 import sqlite3
 import sys
 
 
 def main():
-    for db in sys.argv[1:]:
+    args = [a for a in sys.argv[1:] if a != "--all"]
+    like = "%" if "--all" in sys.argv else "%dsi::%"   # --all: counters of every kernel (microbenchmarks)
+    for db in args:
         con = sqlite3.connect(db)
         cur = con.cursor()
         print("## %s" % db)
@@ -20,7 +22,7 @@ def main():
             print("no kernel stats:", e)
         try:
             q = ("select kernel_name, counter_name, count(*), avg(value), avg(duration) from counters_collection "
-                 "where kernel_name like '%dsi::%' group by kernel_name, counter_name")
+                 "where kernel_name like '" + like + "' group by kernel_name, counter_name")
             rows = list(cur.execute(q))
             if rows:
                 print("%-40s %-24s %6s %18s %12s" % ("kernel", "counter", "n", "avg_value", "avg_dur_us"))
