@@ -4,11 +4,13 @@ trajectories can be replayed without ROS:
 
   write_grid_npy        Grid3D::writeGridNpy           cartesian3dgrid_IO.cpp:30-36   (.npy, shape {Z,Y,X} f32)
   save_depth_points     saveDepthMaps (txt part)        utils.cpp:31-46                ("col row depth" lines)
-  read_pose_bag         parse of geometry_msgs/PoseStamped bags   data_loading.cpp:221-302 (ROSBAG v2.0, uncompressed)
-  write_pose_bag        test helper: minimal writer of the same subset of the format
+  read_pose_bag         parse of geometry_msgs/PoseStamped bags   data_loading.cpp:221-302 (ROSBAG v2.0; none / bz2 chunks)
+  read_event_bag        parse of dvs_msgs/EventArray bags         data_loading.cpp:31-107, 211-216
+  write_pose_bag, write_event_bag   test helpers: minimal writers of the same subset of the format
 
 Host-side file I/O only; nothing here touches voxels.
 """
+import bz2
 import struct
 
 import numpy as np
@@ -65,22 +67,13 @@ def _records(buf, start=0, end=None):
         i += 4 + dl
 
 
-def _parse_pose_stamped(data):
-    """std_msgs/Header (seq, stamp.sec, stamp.nsec, frame_id) + geometry_msgs/Pose."""
-    seq, sec, nsec, n = struct.unpack_from("<IIII", data, 0)
-    off = 16 + n
-    px, py, pz, qx, qy, qz, qw = struct.unpack_from("<7d", data, off)
-    return sec + 1e-9 * nsec, (px, py, pz, qw, qx, qy, qz)
-
-
-def read_pose_bag(path, topic=None):
-    """Reads geometry_msgs/PoseStamped messages of an uncompressed ROSBAG v2.0 file.
-    Returns (times float64[n] by header stamp, poses float64[n][7] = tx,ty,tz,qw,qx,qy,qz),
-    sorted by time like the reference's std::map<ros::Time, Transformation>."""
+def _scan_bag(path, on_message):
+    """Walks every message record of a ROSBAG v2.0 file (chunks with compression none or bz2) in
+    file order and calls on_message(topic, type, data)."""
     buf = open(path, "rb").read()
     if not buf.startswith(_MAGIC):
         raise ValueError("%s is not a ROSBAG V2.0 file" % path)
-    conns, out = {}, []
+    conns = {}
 
     def handle(header, data):
         op = header["op"][0]
@@ -91,18 +84,44 @@ def read_pose_bag(path, topic=None):
         elif op == _OP_MSG:
             conn = struct.unpack("<I", header["conn"])[0]
             tpc, typ = conns.get(conn, ("", ""))
-            if (topic is None or tpc == topic) and typ == "geometry_msgs/PoseStamped":
-                out.append(_parse_pose_stamped(data))
+            return on_message(tpc, typ, data)
+        return True
 
     for header, data in _records(buf, len(_MAGIC)):
         op = header["op"][0]
         if op == _OP_CHUNK:
-            if header.get("compression", b"none") != b"none":
-                raise ValueError("compressed chunks (%r) are not supported" % header["compression"])
+            comp = header.get("compression", b"none")
+            if comp == b"bz2":
+                data = bz2.decompress(data)
+            elif comp != b"none":
+                raise ValueError("chunk compression %r is not supported (none, bz2)" % comp)
             for h2, d2 in _records(data):
-                handle(h2, d2)
-        else:
-            handle(header, data)
+                if handle(h2, d2) is False:
+                    return
+        elif handle(header, data) is False:
+            return
+
+
+def _parse_pose_stamped(data):
+    """std_msgs/Header (seq, stamp.sec, stamp.nsec, frame_id) + geometry_msgs/Pose."""
+    seq, sec, nsec, n = struct.unpack_from("<IIII", data, 0)
+    off = 16 + n
+    px, py, pz, qx, qy, qz, qw = struct.unpack_from("<7d", data, off)
+    return sec + 1e-9 * nsec, (px, py, pz, qw, qx, qy, qz)
+
+
+def read_pose_bag(path, topic=None):
+    """Reads geometry_msgs/PoseStamped messages of a ROSBAG v2.0 file.
+    Returns (times float64[n] by header stamp, poses float64[n][7] = tx,ty,tz,qw,qx,qy,qz),
+    sorted by time like the reference's std::map<ros::Time, Transformation>."""
+    out = []
+
+    def on_message(tpc, typ, data):
+        if (topic is None or tpc == topic) and typ == "geometry_msgs/PoseStamped":
+            out.append(_parse_pose_stamped(data))
+        return True
+
+    _scan_bag(path, on_message)
     out.sort(key=lambda tp: tp[0])
     times = np.array([t for t, _ in out], np.float64)
     poses = np.array([p for _, p in out], np.float64).reshape(-1, 7)
@@ -147,3 +166,108 @@ def write_pose_bag(path, times, poses, topic="/pose", frame_id="world"):
         f.write(_MAGIC + bag_header)
         f.write(_record((("op", bytes([_OP_CHUNK])), ("compression", b"none"),
                          ("size", struct.pack("<I", len(chunk)))), chunk))
+
+
+# dvs_msgs/Event as serialised by ROS: uint16 x, uint16 y, time ts (u32 sec, u32 nsec), bool polarity
+_EVENT_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("sec", "<u4"), ("nsec", "<u4"), ("p", "u1")])
+
+
+def _parse_event_array(data):
+    """std_msgs/Header, uint32 height, uint32 width, dvs_msgs/Event[] events."""
+    (n,) = struct.unpack_from("<I", data, 12)
+    off = 16 + n
+    height, width, count = struct.unpack_from("<III", data, off)
+    ev = np.frombuffer(data, _EVENT_DTYPE, count, off + 12)
+    return height, width, ev
+
+
+def read_event_bag(path, topic, tmin=0.0, tmax=float("inf"), events_offset=0.0):
+    """parse_rosbag's event branch (data_loading.cpp:66-104) + the final sort (:211-216).
+    The first event of the first non-empty message defines the initial stamp; an event is kept
+    iff its stamp relative to that is >= tmin; the message in which a relative stamp exceeds tmax
+    is still taken whole (the reference only stops reading AFTER it); timestamps become
+    ts - initial - events_offset (seconds, double); events are sorted by timestamp.
+    Returns dict(x u16[n], y u16[n], ts f64[n], polarity u8[n], height, width, initial_stamp)."""
+    xs, ys, tss, ps = [], [], [], []
+    state = {"t0": None, "h": 0, "w": 0}
+
+    def on_message(tpc, typ, data):
+        if tpc != topic or typ != "dvs_msgs/EventArray":
+            return True
+        h, w, ev = _parse_event_array(data)
+        if ev.shape[0] == 0:
+            return True
+        state["h"], state["w"] = h, w
+        if state["t0"] is None:
+            state["t0"] = (int(ev["sec"][0]), int(ev["nsec"][0]))
+        s0, n0 = state["t0"]
+        # (ts - initial).toSec() on ros::Duration: exact integer nanoseconds -> double
+        rel_ns = (ev["sec"].astype(np.int64) - s0) * 1000000000 + (ev["nsec"].astype(np.int64) - n0)
+        rel = rel_ns.astype(np.float64) * 1e-9
+        keep = rel >= tmin
+        # ev.ts.toSec() - initial.toSec() - offset, each toSec() = sec + 1e-9 * nsec in double
+        t_abs = ev["sec"].astype(np.float64) + 1e-9 * ev["nsec"].astype(np.float64)
+        t_new = t_abs - (float(s0) + 1e-9 * float(n0)) - events_offset
+        xs.append(ev["x"][keep])
+        ys.append(ev["y"][keep])
+        tss.append(t_new[keep])
+        ps.append(ev["p"][keep])
+        return not bool(np.any(rel > tmax))   # stop after this message
+
+    _scan_bag(path, on_message)
+    if not xs:
+        z = np.empty(0)
+        return {"x": z.astype(np.uint16), "y": z.astype(np.uint16), "ts": z.astype(np.float64),
+                "polarity": z.astype(np.uint8), "height": 0, "width": 0, "initial_stamp": None}
+    x = np.concatenate(xs)
+    y = np.concatenate(ys)
+    ts = np.concatenate(tss)
+    p = np.concatenate(ps)
+    order = np.argsort(ts, kind="stable")
+    t0 = state["t0"]
+    return {"x": x[order], "y": y[order], "ts": ts[order], "polarity": p[order],
+            "height": state["h"], "width": state["w"], "initial_stamp": t0[0] + 1e-9 * t0[1]}
+
+
+def write_event_bag(path, x, y, ts, polarity=None, topic="/dvs/events", height=260, width=346,
+                    events_per_message=5000, compression="none"):
+    """Minimal ROSBAG v2.0 with dvs_msgs/EventArray messages (one chunk per message, optional
+    bz2).  ts: absolute seconds (float64), written as (sec, nsec).  Test helper."""
+    x = np.asarray(x, np.uint16)
+    y = np.asarray(y, np.uint16)
+    ts = np.asarray(ts, np.float64)
+    pol = np.ones(x.shape[0], np.uint8) if polarity is None else np.asarray(polarity, np.uint8)
+    sec = np.floor(ts).astype(np.int64)
+    nsec = np.rint((ts - sec) * 1e9).astype(np.int64)
+    carry = nsec >= 1000000000
+    sec, nsec = sec + carry, nsec - carry * 1000000000
+    conn = struct.pack("<I", 0)
+    conn_data = b"".join(_field(k, v) for k, v in (
+        ("topic", topic.encode()), ("type", b"dvs_msgs/EventArray"),
+        ("md5sum", b"5e8beee5a6c107e504c2e78903c224b8"), ("message_definition", b"")))
+    conn_rec = _record((("op", bytes([_OP_CONN])), ("conn", conn), ("topic", topic.encode())), conn_data)
+    chunks = []
+    n = x.shape[0]
+    for seq, a in enumerate(range(0, max(n, 1), events_per_message)):
+        b = min(n, a + events_per_message)
+        ev = np.empty(b - a, _EVENT_DTYPE)
+        ev["x"], ev["y"], ev["sec"], ev["nsec"], ev["p"] = x[a:b], y[a:b], sec[a:b], nsec[a:b], pol[a:b]
+        hs, hn = (int(sec[a]), int(nsec[a])) if b > a else (0, 0)
+        msg = struct.pack("<IIII", seq, hs, hn, 0) + struct.pack("<III", height, width, b - a) + ev.tobytes()
+        rec = _record((("op", bytes([_OP_MSG])), ("conn", conn), ("time", struct.pack("<II", hs, hn))), msg)
+        body = (conn_rec if seq == 0 else b"") + rec
+        raw_len = len(body)
+        if compression == "bz2":
+            body = bz2.compress(body)
+        chunks.append(_record((("op", bytes([_OP_CHUNK])), ("compression", compression.encode()),
+                               ("size", struct.pack("<I", raw_len))), body))
+    bag_header = _record((("op", bytes([_OP_BAG_HEADER])), ("index_pos", struct.pack("<Q", 0)),
+                          ("conn_count", struct.pack("<I", 1)),
+                          ("chunk_count", struct.pack("<I", len(chunks)))), b"")
+    pad = 4096 - len(_MAGIC) - len(bag_header)
+    if pad > 0:
+        bag_header = bag_header[:-4] + struct.pack("<I", pad) + b" " * pad
+    with open(path, "wb") as f:
+        f.write(_MAGIC + bag_header)
+        for c in chunks:
+            f.write(c)

@@ -59,3 +59,42 @@ def test_reads_the_reference_dsec_odometry_bag():
     import dvs_mcemvs_amd as d
     T = d.pose_at((t - t[0], p), 12.5)
     assert T is not None and abs(np.linalg.norm(T[3:]) - 1) < 1e-5
+
+
+@pytest.mark.parametrize("compression", ["none", "bz2"])
+def test_event_bag_reader_follows_parse_rosbag(tmp_path, compression):
+    """data_loading.cpp:66-104, 211-216: the first event defines the initial stamp; events with
+    relative stamp < tmin are skipped; the message in which tmax is exceeded is still taken whole
+    and is the last one read; stamps become ts - initial - events_offset; sorted by stamp."""
+    rng = np.random.default_rng(3)
+    n = 1000
+    t_abs = 1000.25 + np.sort(rng.uniform(0.0, 1.0, n))
+    t_abs[0] = 1000.25
+    # unsorted inside a message (the final sort fixes it)
+    t_abs[[10, 11]] = t_abs[[11, 10]]
+    x = rng.integers(0, 346, n).astype(np.uint16)
+    y = rng.integers(0, 260, n).astype(np.uint16)
+    pol = rng.integers(0, 2, n).astype(np.uint8)
+    path = tmp_path / "ev.bag"
+    io.write_event_bag(path, x, y, t_abs, pol, topic="/dvs/left/events", events_per_message=100,
+                       compression=compression)
+    ev = io.read_event_bag(path, "/dvs/left/events")
+    assert ev["x"].shape[0] == n and ev["height"] == 260 and ev["width"] == 346
+    assert ev["initial_stamp"] == pytest.approx(1000.25, abs=1e-9)
+    assert np.all(np.diff(ev["ts"]) >= 0) and ev["ts"][0] == pytest.approx(0.0, abs=1e-9)
+    order = np.argsort(t_abs, kind="stable")
+    assert np.array_equal(ev["x"], x[order]) and np.array_equal(ev["polarity"], pol[order])
+    assert np.allclose(ev["ts"], t_abs[order] - 1000.25, atol=2e-9)
+
+    tmin, tmax, off = 0.2, 0.5, 0.05
+    ev = io.read_event_bag(path, "/dvs/left/events", tmin, tmax, off)
+    rel = np.rint((t_abs - 1000.25) * 1e9) * 1e-9
+    msg = np.arange(n) // 100
+    last_msg = msg[np.nonzero(rel > tmax)[0][0]]          # read up to and including this message
+    keep = (rel >= tmin) & (msg <= last_msg)
+    assert ev["x"].shape[0] == keep.sum()
+    assert ev["ts"].max() > tmax - off                     # events beyond tmax of that message stay
+    ko = np.nonzero(keep)[0][np.argsort(t_abs[keep], kind="stable")]
+    assert np.array_equal(ev["x"], x[ko]) and np.array_equal(ev["y"], y[ko])
+    assert np.allclose(ev["ts"], t_abs[ko] - 1000.25 - off, atol=2e-9)
+    assert io.read_event_bag(path, "/nope")["x"].shape[0] == 0
