@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 global atomics, 2 LDS bands")
     ap.add_argument("--band", type=int, nargs=3, default=[0, 0, 0], help="band_rows chunks block")
     ap.add_argument("--points", type=int, default=5000, help="scene points of the synthetic rig (SURVEY 8d: 2000-20000)")
-    ap.add_argument("--packed", type=int, default=-1, help="-1 auto, 0 per-packet waves, 1 packed lanes")
+    ap.add_argument("--packed", type=int, default=-1, help="-1 auto (= 1), 0 per-packet waves, 1 packed lanes (hand-scheduled), 2 packet groups, 3 packed (compiled loop)")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000,
                     help="events of camera 0 the CPU oracle is timed on (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -208,10 +208,24 @@ def main():
             traffic = None
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
-                "kernel": ("k_vote_bands_packed" if info["packed"] else "k_vote_bands") if info["algo"] == 2 else "k_vote_global",
+                "kernel": {0: "k_vote_bands", 1: "k_vote_bands_packed", 2: "k_vote_groups",
+                           3: "k_vote_bands_packed"}[info["packed"]] if info["algo"] == 2 else "k_vote_global",
                 "kernel_avg_ms": kern_ms, "kernel_launches": kt_n,
                 "algorithmic_bytes_per_launch": bytes_per_event * ev_per_launch,
                 "kernel_Mevents_per_s": ev_per_launch / (kern_ms * 1e-3) / 1e6 if kt_n else None}
+
+    # ---- what actually bounds the voting kernel: 64-bit LDS atomic adds (4 per accepted event-plane;
+    # the sum of a DSI = accepted event-planes because the 4 bilinear weights of a vote sum to 1).
+    # Rates per wave instruction measured with tools/lds_atomic_bench2.hip on this chip (16 waves/CU
+    # issuing back to back): 6.2 clk conflict-free, 11.2 clk with random cells of a band.
+    accepted = float(np.sum(mappers[0].dsi_.download(), dtype=np.float64))
+    adds = 4.0 * accepted / (kern_ms * 1e-3) if kt_n else None
+    cu_lane_rate = 256 * 64 * 2.4e9
+    lds_atomics = {"adds_per_s": adds, "unit": "64-bit LDS atomic adds/s (one camera launch)",
+                   "accepted_event_planes_per_launch": accepted,
+                   "peak_conflict_free": cu_lane_rate / 6.2, "rate_random_cells": cu_lane_rate / 11.2,
+                   "frac_of_conflict_free_peak": adds / (cu_lane_rate / 6.2) if adds else None,
+                   "frac_of_random_cell_rate": adds / (cu_lane_rate / 11.2) if adds else None}
 
     # ---- CPU baseline: the oracle (a port of the reference's CPU path) on a bounded sample ----
     cpu = None
@@ -255,7 +269,7 @@ def main():
             "argmax_GBps": argmax_gbps, "argmax_ms": argmax_ms,
             "gpu_ms_per_step_hip_events": gpu_ms / args.steps,
             "h2d_inclusive_Mevents_per_s": h2d_rate,
-            "roofline": roofline, "cpu_baseline": cpu, "input_gen_s": t_gen,
+            "roofline": roofline, "lds_atomics": lds_atomics, "cpu_baseline": cpu, "input_gen_s": t_gen,
         }
     for o in mappers + batches + [fused]:
         o.close()
