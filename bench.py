@@ -14,8 +14,9 @@ N > 1 (one process per GPU, launched by torch.distributed.run): every rank owns 
 independent time slice of the same size (weak scaling, configs[3] shape), builds and
 camera-fuses its DSI, then the slices are fused across time with the reference's
 harmonic accumulator (process2.cpp:217-226): local 1/(0.01+v), ONE RCCL all-reduce(sum)
-of the 36 MB volume over xGMI, local n/acc, arg-max.  value = events voted by all ranks
-/ max-over-ranks time.
+of the 36 MB volume over xGMI, local n/acc, arg-max -- issued on a second HIP stream so that it
+overlaps the next step's voting (every step's fusion is complete before the closing barrier).
+value = events voted by all ranks / max-over-ranks time.
 
 Prints ONE JSON line (rank 0).  Data: synthetic (dvs_mcemvs_amd/synthetic.py).
 """
@@ -103,31 +104,36 @@ def main():
     fused = d.Grid3D(ctx, nx, ny, nz)
     t_gen = time.time() - t_gen
 
-    tfuse = None
+    temporal = None
     if use_dist:
+        # temporal fusion across ranks, pipelined: round k's all-reduce + finalize + arg-max run on
+        # a second HIP stream (its own context + the reference's "mapper_fused") while the main
+        # stream already votes round k+1
         from dvs_mcemvs_amd import distributed as dd
-        tfuse = torch.empty((nz, ny, nx), dtype=torch.float32, device="cuda")
-        acc = d.Grid3D(ctx, nx, ny, nz, device_ptr=tfuse.data_ptr())
-        temporal = dd.TemporalFusion(ctx, acc, tfuse, d.ACC_INV_SUM, world)
+        ctx_side = d.Context(local_rank)
+        mapper_fused = d.MapperEMVS(ctx_side, rig["cam"], shape)
+        temporal = dd.PipelinedTemporalFusion.on_gpu(ctx, ctx_side, (nx, ny, nz), d.ACC_INV_SUM, world,
+                                                     extract=mapper_fused.computeDepthMap)
 
     def step():
         for c in range(2):
             mappers[c].evaluateDSI_batch(batches[c])
         # process1.cpp:126-141 (resetGrid; addTwoGrids(dsi0); harmonicMeanTwoGrids(dsi1)) in one pass
         fused.setToFusionOf(mappers[0].dsi_, mappers[1].dsi_, d.FUSE_HM)
-        if not use_dist:
+        if temporal is None:
             mappers[0].computeDepthMap(fused)
         else:
-            temporal.reset()
-            temporal.add(fused)               # process2.cpp:220: acc += 1/(0.01 + fused)
-            temporal.finish()                 # ONE RCCL all-reduce(sum) over xGMI, then n/acc
-            mappers[0].computeDepthMap(acc)
+            # process2.cpp:220: acc += 1/(0.01 + fused); ONE RCCL all-reduce(sum) over xGMI; n/acc; arg-max
+            temporal.submit(fused)
 
     def barrier():
+        ctx.synchronize()
+        if temporal is not None:
+            temporal.drain()
         if dist is not None:
+            torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
-        ctx.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -273,8 +279,10 @@ def main():
         }
     for o in mappers + batches + [fused]:
         o.close()
-    if use_dist:
-        acc.close()
+    if temporal is not None:
+        temporal.close()
+        mapper_fused.close()
+        ctx_side.close()
     ctx.close()
     if dist is not None:
         dist.barrier()

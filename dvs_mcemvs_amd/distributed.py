@@ -72,14 +72,108 @@ class TemporalFusion:
             self.acc.addTwoGrids(dsi)            # process2.cpp:231-233
 
     def finish(self):
-        """all-reduce the accumulator and finalize (process2.cpp:221-225 / :234-238)."""
-        import torch
-        self.ctx.synchronize()                   # engine stream -> torch stream
-        allreduce_sum_(self.tensor, self.group)
-        if self.tensor.is_cuda:
-            torch.cuda.current_stream().synchronize()
+        """all-reduce the accumulator and finalize (process2.cpp:221-225 / :234-238).
+        On a GPU the collective is issued with the engine's HIP stream as torch's current stream,
+        so it is ordered after the accumulate kernels and before the finalize kernel on the
+        device; the host does not wait."""
+        if getattr(self.tensor, "is_cuda", False):
+            import torch
+            with torch.cuda.stream(torch.cuda.ExternalStream(self.ctx.stream)):
+                allreduce_sum_(self.tensor, self.group)
+        else:
+            allreduce_sum_(self.tensor, self.group)
         if self.mode == 1:
             self.acc.computeHMfromSumOfInv(self.n)
         else:
             self.acc.computeAMfromSum(self.n)
         return self.acc
+
+
+class PipelinedTemporalFusion:
+    """TemporalFusion for a STREAM of fusion rounds (sliding windows, main.cpp:177; bench steps):
+    round k's all-reduce + finalize + depth-map extraction run on a second HIP stream while the
+    main stream already votes round k+1.  The volume accumulator is double-buffered.
+
+        main stream :  ... vote, camera-fuse(k) | acc[k%2] = f(fused)      | vote, camera-fuse(k+1) ...
+        side stream :                            wait | all-reduce(acc[k%2]), finalize, arg-max |
+
+    Device-side ordering only (events); the host never blocks in submit().
+
+    slots   : list of dicts {"tensor": torch tensor [Nz][Ny][Nx], "acc_main": Grid3D aliasing it in
+              the main context, "acc_side": Grid3D aliasing it in the side context}
+    streams : (main, side) torch streams wrapping the two contexts' HIP streams, or None to run
+              everything in program order (CPU tests)
+    extract : optional callable(acc_side_grid) run on the side stream after finalize
+              (e.g. mapper_fused.computeDepthMap)
+    """
+
+    def __init__(self, slots, mode, num_slices, streams=None, extract=None, group=None):
+        self.slots, self.mode, self.n = slots, int(mode), int(num_slices)
+        self.streams, self.extract, self.group = streams, extract, group
+        self.k = 0
+        for s in self.slots:
+            s["used"] = False
+            if streams is not None:
+                import torch
+                s["filled"], s["free"] = torch.cuda.Event(), torch.cuda.Event()
+
+    @classmethod
+    def on_gpu(cls, ctx_main, ctx_side, dims, mode, num_slices, extract=None, depth=2, group=None):
+        import torch
+        from .engine import Grid3D
+        nx, ny, nz = dims
+        slots = []
+        for _ in range(depth):
+            t = torch.empty((nz, ny, nx), dtype=torch.float32, device="cuda")
+            slots.append({"tensor": t,
+                          "acc_main": Grid3D(ctx_main, nx, ny, nz, device_ptr=t.data_ptr()),
+                          "acc_side": Grid3D(ctx_side, nx, ny, nz, device_ptr=t.data_ptr())})
+        streams = (torch.cuda.ExternalStream(ctx_main.stream), torch.cuda.ExternalStream(ctx_side.stream))
+        obj = cls(slots, mode, num_slices, streams, extract, group)
+        obj._ctxs = (ctx_main, ctx_side)
+        return obj
+
+    def submit(self, fused):
+        """Round k: accumulate `fused` (main stream), then all-reduce / finalize / extract on the
+        side stream.  Returns the slot's side-context grid (valid after drain() or after the
+        slot's "free" event)."""
+        s = self.slots[self.k % len(self.slots)]
+        main, side = self.streams if self.streams is not None else (None, None)
+        if main is not None and s["used"]:
+            main.wait_event(s["free"])            # round k - depth has left this buffer
+        s["acc_main"].resetGrid()
+        if self.mode == 1:
+            s["acc_main"].addInverseOfTwoGrids(fused)   # process2.cpp:218-220
+        else:
+            s["acc_main"].addTwoGrids(fused)            # process2.cpp:231-233
+        if main is not None:
+            import torch
+            s["filled"].record(main)
+            side.wait_event(s["filled"])
+            with torch.cuda.stream(side):
+                allreduce_sum_(s["tensor"], self.group)
+        else:
+            allreduce_sum_(s["tensor"], self.group)
+        if self.mode == 1:
+            s["acc_side"].computeHMfromSumOfInv(self.n)
+        else:
+            s["acc_side"].computeAMfromSum(self.n)
+        if self.extract is not None:
+            self.extract(s["acc_side"])
+        if main is not None:
+            s["free"].record(side)
+        s["used"] = True
+        self.k += 1
+        return s["acc_side"]
+
+    def drain(self):
+        """Host waits for both streams."""
+        if self.streams is not None:
+            for c in self._ctxs:
+                c.synchronize()
+
+    def close(self):
+        for s in self.slots:
+            for key in ("acc_main", "acc_side"):
+                if hasattr(s[key], "close"):
+                    s[key].close()

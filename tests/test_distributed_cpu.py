@@ -82,3 +82,75 @@ def test_partitioning():
     assert dd.slices_of_rank(8, 2, 1) == [1, 3, 5, 7]
     owned = sorted(k for r in range(3) for k in dd.slices_of_rank(7, 3, r))
     assert owned == list(range(7))
+
+
+class _NumpyGrid:
+    """Stand-in for an engine Grid3D that aliases a torch CPU tensor (oracle arithmetic)."""
+
+    def __init__(self, tensor):
+        self.a = tensor.numpy()
+
+    def resetGrid(self):
+        self.a[...] = 0
+
+    def addInverseOfTwoGrids(self, g):
+        from oracle import oracle as orc
+        self.a[...] = orc.accumulate(self.a.copy(), g, 1)
+
+    def addTwoGrids(self, g):
+        from oracle import oracle as orc
+        self.a[...] = orc.accumulate(self.a.copy(), g, 0)
+
+    def computeHMfromSumOfInv(self, n):
+        from oracle import oracle as orc
+        self.a[...] = orc.finalize(self.a.copy(), 1, n)
+
+    def computeAMfromSum(self, n):
+        from oracle import oracle as orc
+        self.a[...] = orc.finalize(self.a.copy(), 0, n)
+
+
+def _pipelined_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from dvs_mcemvs_amd import distributed as dd
+
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    rng = np.random.default_rng(5)                      # same stream on every rank
+    rounds = [rng.uniform(0, 3, (world, 4, 6, 5)).astype(np.float32) for _ in range(5)]
+    slots = []
+    for _ in range(2):
+        t = torch.zeros((4, 6, 5), dtype=torch.float32)
+        g = _NumpyGrid(t)
+        slots.append({"tensor": t, "acc_main": g, "acc_side": g})
+    seen = []
+    pipe = dd.PipelinedTemporalFusion(slots, 1, world, streams=None,
+                                      extract=lambda grid: seen.append(grid.a.copy()))
+    for r in rounds:
+        pipe.submit(r[rank])                            # this rank's slice of the round
+    pipe.drain()
+    assert len(seen) == 5 and pipe.k == 5
+    np.save(os.path.join(out_dir, "pipe_rank%d.npy" % rank), np.stack(seen))
+    dist.destroy_process_group()
+
+
+def test_pipelined_temporal_fusion_rounds(tmp_path):
+    """Five fusion rounds through the double-buffered PipelinedTemporalFusion (program-order mode
+    on CPU): every round equals the single-process harmonic fusion of that round's slices."""
+    import torch.multiprocessing as mp
+    from oracle import oracle as orc
+
+    port = _free_port()
+    mp.spawn(_pipelined_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(tmp_path / "pipe_rank0.npy")
+    r1 = np.load(tmp_path / "pipe_rank1.npy")
+    assert np.array_equal(r0, r1)
+    rng = np.random.default_rng(5)
+    for k in range(5):
+        slices = rng.uniform(0, 3, (2, 4, 6, 5)).astype(np.float32)
+        acc = np.zeros((4, 6, 5), np.float32)
+        for s in slices:
+            acc = orc.accumulate(acc, s, 1)
+        assert np.allclose(r0[k], orc.finalize(acc, 1, 2), rtol=1e-6, atol=1e-7)
