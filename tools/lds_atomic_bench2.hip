@@ -26,7 +26,20 @@ __global__ __launch_bounds__(1024) void k(int iters, float* out)
         if (PAT == 0) a[j] = (j * 64 + lane) % kCells;                 // linear
         else if (PAT == 1) a[j] = lcg(s) % (kCells - 8);               // random cell in band
         else if (PAT == 2) a[j] = ((lcg(s) % 3) + (lane / 8)) * kNx + lcg(s) % (kNx - 8);  // sorted-ish rows, random x
-        else a[j] = (lcg(s) % kRows) * kNx + ((lane & 15) * 21 + (lcg(s) % 16) * 16) % (kNx - 8);  // distinct x mod 16 per 16-lane group
+        else if (PAT == 3) a[j] = (lcg(s) % kRows) * kNx + ((lane & 15) * 21 + (lcg(s) % 16) * 16) % (kNx - 8);  // distinct x mod 16 per 16-lane group
+        else {
+            // "bank-aware order": the 32 lanes of a half-wave sit in ONE row (same for the half-wave:
+            // seeded by wave id, half and j) and have distinct x mod 32; PAT 5 adds the distortion of
+            // a plane transfer X = 1.02 * x0 (up to 7 cells across the row), PAT 6 a random +-3
+            uint32_t hs = (threadIdx.x >> 5) * 7919u + j * 104729u + blockIdx.x * 31u + 17u;
+            const int row = lcg(hs) % kRows;
+            int x = (lane & 31) + 32 * (int)(lcg(s) % 10);             // 0..319, residue = lane & 31
+            if (PAT == 5) x = (int)(1.02f * (float)x);
+            if (PAT == 6) x += (int)(lcg(s) % 7) - 3;
+            if (PAT == 7) x = (int)(1.005f * (float)x);
+            x = x < 0 ? 0 : (x > kNx - 10 ? kNx - 10 : x);
+            a[j] = row * kNx + x;
+        }
     }
     uint32_t acc = 0;
     for (int it = 0; it < iters; ++it) {
@@ -63,7 +76,7 @@ void run(const char* name, float* d_out, int threads)
     hipError_t e = hipGetLastError(); if (e != hipSuccess) printf("ERR %s\n", hipGetErrorString(e));
     float ms; (void)hipEventElapsedTime(&ms, a, b);
     const double cyc = ms * 1e-3 * 2.3e9;            // ~clock under load
-    const double winstr = iters * 8.0 * 32.0;          // wave instructions per CU (2048 threads = 32 waves)
+    const double winstr = iters * 8.0 * 16.0;          // wave instructions per CU (256 blocks of 1024 threads = 16 waves per CU)
     printf("%-40s %8.3f ms  %6.2f cyc/wave-instr/CU\n", name, ms, cyc / winstr);
 }
 
@@ -72,13 +85,14 @@ int main()
     float* d_out; (void)hipMalloc(&d_out, 64);
 #define RUNALL(OP, label) \
     run<OP, 0>(label " linear", d_out, 1024); run<OP, 1>(label " random-in-band", d_out, 1024); \
-    run<OP, 2>(label " rows-sorted", d_out, 1024); run<OP, 3>(label " x-mod16-distinct", d_out, 1024);
+    run<OP, 2>(label " rows-sorted", d_out, 1024); run<OP, 3>(label " x-mod16-distinct", d_out, 1024); \
+    run<OP, 4>(label " halfwave-row x-mod32-distinct", d_out, 1024); run<OP, 5>(label " ... scaled 1.02", d_out, 1024); \
+    run<OP, 6>(label " ... jitter +-3", d_out, 1024); run<OP, 7>(label " ... scaled 1.005", d_out, 1024);
     RUNALL(0, "ds_add_u64")
     RUNALL(1, "ds_add_u32")
     RUNALL(2, "ds_add_rtn_u32")
-    RUNALL(3, "ds_add_f32")
+    run<3, 1>("ds_add_f32 random-in-band", d_out, 1024);
     RUNALL(4, "ds_write_b32")
-    RUNALL(5, "ds_read_b32")
     RUNALL(6, "ds_write_b64")
     return 0;
 }
