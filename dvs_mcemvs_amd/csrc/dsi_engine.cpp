@@ -107,7 +107,8 @@ struct dsi_mapper {
     dsi_context* ctx = nullptr;
     int sensor_w = 0, sensor_h = 0;
     dsi::Geom geom{};
-    std::vector<float> planes;  // raw_depths_vec_
+    std::vector<float> planes;  // raw_depths_vec_ (of the planes this mapper owns)
+    int plane_begin = 0;        // first owned plane of the full depth vector (plane sharding)
     float* planes_dev = nullptr;
     float2* lut_dev = nullptr;
     dsi_grid* grid = nullptr;
@@ -632,6 +633,9 @@ int dsi_mapper_create(dsi_context_t* ctx, const dsi_mapper_config_t* cfg, dsi_ma
     REQUIRE(cfg->max_depth > cfg->min_depth, DSI_ERR_INVALID, "max_depth must be > min_depth");
     REQUIRE(cfg->dim_z >= 1 && cfg->dim_z <= 256, DSI_ERR_INVALID, "dimZ must be in 1..256 (main.cpp:156)");
     REQUIRE(cfg->dim_x >= 0 && cfg->dim_y >= 0, DSI_ERR_INVALID, "dimX/dimY must be >= 0");
+    REQUIRE(cfg->plane_begin >= 0 && cfg->plane_count >= 0 && cfg->plane_begin < cfg->dim_z &&
+                cfg->plane_begin + cfg->plane_count <= cfg->dim_z,
+            DSI_ERR_INVALID, "plane range must lie inside [0, dimZ)");
     REQUIRE(cfg->K[0] > 0.f && cfg->K[1] > 0.f && cfg->K[2] > 0.f && cfg->K[3] > 0.f, DSI_ERR_INVALID,
             "camera fx, fy, cx, cy must be > 0");
     if (int rc = set_device(ctx)) return rc;
@@ -654,8 +658,11 @@ int dsi_mapper_create(dsi_context_t* ctx, const dsi_mapper_config_t* cfg, dsi_ma
     g.vfy = f;
     g.vcx = cfg->K[2];
     g.vcy = cfg->K[3];
-    make_planes(cfg->min_depth, cfg->max_depth, g.nz, cfg->inverse_depth != 0, &m->planes);
-    g.z0 = m->planes[0];  // :111, :163
+    make_planes(cfg->min_depth, cfg->max_depth, cfg->dim_z, cfg->inverse_depth != 0, &m->planes);
+    g.z0 = m->planes[0];  // :111, :163 -- of the full depth vector, also for a plane shard
+    m->plane_begin = cfg->plane_begin;
+    g.nz = cfg->plane_count > 0 ? cfg->plane_count : cfg->dim_z - cfg->plane_begin;
+    m->planes = std::vector<float>(m->planes.begin() + m->plane_begin, m->planes.begin() + m->plane_begin + g.nz);
 
     int rc = DSI_OK;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&m->planes_dev), g.nz * sizeof(float));
@@ -715,6 +722,8 @@ int dsi_mapper_destroy(dsi_mapper_t* m)
 }
 
 dsi_grid_t* dsi_mapper_grid(dsi_mapper_t* m) { return m ? m->grid : nullptr; }
+
+int dsi_mapper_plane_begin(const dsi_mapper_t* m) { return m ? m->plane_begin : 0; }
 
 int dsi_mapper_geometry(const dsi_mapper_t* m, float* Kv, float* raw_depths, int* nx, int* ny, int* nz)
 {

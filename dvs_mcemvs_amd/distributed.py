@@ -51,6 +51,53 @@ def allreduce_max_scalar(value, device=None, group=None):
     return float(t.item())
 
 
+# ---------------------------------------------------------------- plane sharding (one big DSI)
+def plane_ranges(num_planes, world_size):
+    """Contiguous, balanced plane ranges [(begin, count)] per rank (the reference layout
+    [z][y][x] makes a plane range a contiguous slab of the volume)."""
+    base, extra = divmod(int(num_planes), int(world_size))
+    out, b = [], 0
+    for r in range(int(world_size)):
+        c = base + (1 if r < extra else 0)
+        out.append((b, c))
+        b += c
+    return out
+
+
+def pack_argmax_keys(conf, idx_local, plane_begin):
+    """(confidence, plane index) of a shard's collapseMaxZSlice -> one int64 per pixel whose MAX over
+    shards is the unsharded result: Grid3D::collapseMaxZSlice takes the FIRST maximum
+    (std::max_element, cartesian3dgrid.cpp:115-137), i.e. the larger confidence wins and, on equal
+    confidence, the smaller global plane index.  DSI values are >= 0, so their IEEE bit patterns
+    order like the floats."""
+    conf = np.ascontiguousarray(conf, np.float32)
+    bits = conf.view(np.uint32).astype(np.int64)
+    gidx = np.asarray(idx_local).astype(np.int64) + int(plane_begin)
+    return (bits << 8) | (255 - gidx)
+
+
+def unpack_argmax_keys(keys):
+    keys = np.asarray(keys, np.int64)
+    conf = (keys >> 8).astype(np.uint32).view(np.float32)
+    idx = (255 - (keys & 255)).astype(np.uint8)
+    return conf, idx
+
+
+def allreduce_argmax(conf, idx_local, plane_begin, device=None, group=None):
+    """The one collective of plane sharding: all-reduce(MAX) of the packed (confidence, index)
+    keys (8 B per pixel; 8 MB at 1024x1024).  Returns (conf f32, global idx u8) on every rank."""
+    import torch
+    import torch.distributed as dist
+    keys = pack_argmax_keys(conf, idx_local, plane_begin)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        t = torch.from_numpy(keys)
+        if device is not None:
+            t = t.to(device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        keys = t.cpu().numpy()
+    return unpack_argmax_keys(keys)
+
+
 class TemporalFusion:
     """Temporal fusion of per-slice DSIs across ranks.
 

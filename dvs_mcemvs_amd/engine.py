@@ -41,7 +41,8 @@ class _MapperConfig(C.Structure):
     _fields_ = [("sensor_width", C.c_int), ("sensor_height", C.c_int), ("K", C.c_float * 4),
                 ("dim_x", C.c_int), ("dim_y", C.c_int), ("dim_z", C.c_int),
                 ("min_depth", C.c_float), ("max_depth", C.c_float), ("fov_deg", C.c_float),
-                ("inverse_depth", C.c_int), ("lut", C.POINTER(C.c_float))]
+                ("inverse_depth", C.c_int), ("lut", C.POINTER(C.c_float)),
+                ("plane_begin", C.c_int), ("plane_count", C.c_int)]
 
 
 class _DepthMapOptions(C.Structure):
@@ -78,6 +79,7 @@ def load_library():
     sig = {
         "dsi_last_error": (C.c_char_p, []),
         "dsi_abi_version": (C.c_int, []),
+        "dsi_mapper_plane_begin": (C.c_int, [vp]),
         "dsi_device_count": (C.c_int, []),
         "dsi_context_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
         "dsi_context_destroy": (C.c_int, [vp]),
@@ -415,9 +417,13 @@ class MapperEMVS:
     precomputeRectifiedPoints (mapper_emvs_stereo.cpp:256-299), shape [H*W][2] or None.
     """
 
-    def __init__(self, ctx, cam, dsi_shape, lut=None, inverse_depth=False):
+    def __init__(self, ctx, cam, dsi_shape, lut=None, inverse_depth=False, plane_range=None):
+        """plane_range = (begin, count): own only those planes of dsi_shape's dimZ planes (plane
+        sharding across GPUs; the DSI then has `count` planes and equals that slice of the full one)."""
         w, h, fx, fy, cx, cy = cam
         cfg = _MapperConfig()
+        if plane_range is not None:
+            cfg.plane_begin, cfg.plane_count = int(plane_range[0]), int(plane_range[1])
         cfg.sensor_width, cfg.sensor_height = int(w), int(h)
         cfg.K = (C.c_float * 4)(fx, fy, cx, cy)
         cfg.dim_x, cfg.dim_y, cfg.dim_z = dsi_shape.dimX_, dsi_shape.dimY_, dsi_shape.dimZ_
@@ -440,6 +446,7 @@ class MapperEMVS:
         planes = np.empty(self.dimZ, np.float32)
         _check(L.dsi_mapper_geometry(self._h, None, _ptr(planes, C.c_float), None, None, None))
         self.raw_depths_vec_ = planes
+        self.plane_begin = int(L.dsi_mapper_plane_begin(self._h))
         self.virtual_cam_ = tuple(float(v) for v in kv)  # fx, fy, cx, cy
         # public member dsi_ (mapper_emvs_stereo.hpp:116)
         self.dsi_ = Grid3D(ctx, 0, 0, 0, _handle=C.c_void_p(L.dsi_mapper_grid(self._h)), _owner=self)

@@ -39,7 +39,7 @@ extern "C" {
 #define DSI_API
 #endif
 
-#define DSI_ENGINE_ABI_VERSION 1
+#define DSI_ENGINE_ABI_VERSION 2
 #define DSI_PACKET_SIZE 1024 /* mapper_emvs_stereo.hpp:152 packet_size_ */
 
 typedef enum {
@@ -148,6 +148,13 @@ typedef struct {
     int inverse_depth;  /* 0: LinearDepthVector (CMake default), 1: -DUSE_INVERSE_DEPTH */
     const float *lut;   /* host, 2*W*H floats, entry y*W+x = undistorted (u,v)
                            (precomputeRectifiedPoints, mapper_emvs_stereo.cpp:256-299); NULL = identity */
+    /* Plane sharding (multi-GPU): this mapper owns planes
+     * [plane_begin, plane_begin + plane_count) of the dim_z planes defined above; its DSI has
+     * plane_count planes.  z0 stays plane 0 of the FULL depth vector (mapper_emvs_stereo.cpp:111,163)
+     * and planes are independent in fillVoxelGrid (:168), so the shard's DSI equals those planes of
+     * the unsharded DSI bit for bit.  plane_count == 0: all planes from plane_begin on. */
+    int plane_begin;
+    int plane_count;
 } dsi_mapper_config_t;
 
 /* MapperEMVS::MapperEMVS(cam, dsi_shape) (mapper_emvs_stereo.cpp:29-64, setupDSI :208-241) */
@@ -158,6 +165,8 @@ DSI_API dsi_grid_t *dsi_mapper_grid(dsi_mapper_t *m);
 /* virtual camera {fx,fy,cx,cy} (:231-239), plane depths raw_depths_vec_ (:213-214;
  * raw_depths needs dim_z floats) and the resolved dimensions; any pointer may be NULL */
 DSI_API int dsi_mapper_geometry(const dsi_mapper_t *m, float *Kv, float *raw_depths, int *nx, int *ny, int *nz);
+/* first plane this mapper owns (0 unless plane-sharded); raw_depths / nz above describe the owned planes */
+DSI_API int dsi_mapper_plane_begin(const dsi_mapper_t *m);
 DSI_API int dsi_mapper_set_vote_algo(dsi_mapper_t *m, int algo);
 /* tuning knobs of DSI_VOTE_LDS_BANDS; 0 = automatic */
 DSI_API int dsi_mapper_set_band_params(dsi_mapper_t *m, int band_rows, int chunks, int block_threads);

@@ -239,10 +239,14 @@ typedef LinearTrajectory TrajectoryType;
 
 class MapperEMVS {  // mapper_emvs_stereo.hpp:94-155
 public:
+    // plane_begin / plane_count: own only that range of the dimZ planes (plane sharding over GPUs;
+    // 0, 0 = all planes, the reference behaviour)
     MapperEMVS(dsi::Context& ctx, const dsi::PinholeCameraModel& cam, const ShapeDSI& dsi_shape,
-               bool inverse_depth = false)
+               bool inverse_depth = false, int plane_begin = 0, int plane_count = 0)
     {
         dsi_mapper_config_t cfg{};
+        cfg.plane_begin = plane_begin;
+        cfg.plane_count = plane_count;
         cfg.sensor_width = cam.width;
         cfg.sensor_height = cam.height;
         cfg.K[0] = cam.fx; cfg.K[1] = cam.fy; cfg.K[2] = cam.cx; cfg.K[3] = cam.cy;

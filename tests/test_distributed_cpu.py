@@ -154,3 +154,69 @@ def test_pipelined_temporal_fusion_rounds(tmp_path):
         for s in slices:
             acc = orc.accumulate(acc, s, 1)
         assert np.allclose(r0[k], orc.finalize(acc, 1, 2), rtol=1e-6, atol=1e-7)
+
+
+def test_plane_ranges_and_argmax_keys():
+    from dvs_mcemvs_amd import distributed as dd
+    from oracle import oracle as orc
+    assert dd.plane_ranges(256, 8) == [(32 * r, 32) for r in range(8)]
+    assert dd.plane_ranges(10, 4) == [(0, 3), (3, 3), (6, 2), (8, 2)]
+    rng = np.random.default_rng(9)
+    dsi = rng.integers(0, 4, (37, 9, 11)).astype(np.float32)    # many ties -> "first maximum wins" matters
+    dsi[:, 0, 0] = 0.0                                            # all-zero column -> index 0
+    dsi[5, 1, 1] = dsi[30, 1, 1] = 99.0                           # equal maxima in different shards
+    conf, idx = orc.collapse_max_z(dsi)
+    keys = None
+    for b, c in dd.plane_ranges(37, 5):
+        cl, il = orc.collapse_max_z(dsi[b:b + c])
+        k = dd.pack_argmax_keys(cl, il, b)
+        keys = k if keys is None else np.maximum(keys, k)
+    c2, i2 = dd.unpack_argmax_keys(keys)
+    assert np.array_equal(c2, conf) and np.array_equal(i2, idx) and i2[1, 1] == 5 and i2[0, 0] == 0
+
+
+def _plane_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from dvs_mcemvs_amd import distributed as dd, synthetic as syn
+    from oracle import oracle as orc
+    from oracle_pipeline import OracleMapper
+
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    rig = syn.stereo_rig(6000, width=40, height=30, duration=0.3, seed=23)
+    nz = 13
+    b, c = dd.plane_ranges(nz, world)[rank]
+    fused = None
+    for cam in range(2):                                 # every rank reads ALL events, owns planes [b, b+c)
+        m = OracleMapper(rig["cam"], dimZ=nz, min_depth=4.0, max_depth=100.0)
+        assert m.evaluateDSI(rig["events"][cam], rig["trajectories"][cam], rig["T_rv_w"])
+        shard = m.dsi[b:b + c]                           # planes are independent (mapper_emvs_stereo.cpp:168)
+        fused = shard.copy() if fused is None else orc.fuse2(fused, shard, 3)   # GM, voxel-wise: local
+    conf_l, idx_l = orc.collapse_max_z(fused)
+    conf, idx = dd.allreduce_argmax(conf_l, idx_l, b)    # the only collective
+    np.savez(os.path.join(out_dir, "plane_rank%d.npz" % rank), conf=conf, idx=idx)
+    dist.destroy_process_group()
+
+
+def test_plane_sharded_argmax_equals_single_process(tmp_path):
+    """configs[4]-style sharding (one big DSI, planes split over ranks, voxel-wise camera fusion local,
+    ONE all-reduce(MAX) of packed (confidence, index) keys) gives the unsharded depth-map inputs."""
+    import torch.multiprocessing as mp
+    from dvs_mcemvs_amd import synthetic as syn
+    from oracle import oracle as orc
+    from oracle_pipeline import OracleMapper
+
+    port = _free_port()
+    mp.spawn(_plane_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    rig = syn.stereo_rig(6000, width=40, height=30, duration=0.3, seed=23)
+    fused = None
+    for cam in range(2):
+        m = OracleMapper(rig["cam"], dimZ=13, min_depth=4.0, max_depth=100.0)
+        assert m.evaluateDSI(rig["events"][cam], rig["trajectories"][cam], rig["T_rv_w"])
+        fused = m.dsi.copy() if fused is None else orc.fuse2(fused, m.dsi, 3)
+    conf, idx = orc.collapse_max_z(fused)
+    for r in range(3):
+        z = np.load(tmp_path / ("plane_rank%d.npz" % r))
+        assert np.array_equal(z["conf"], conf) and np.array_equal(z["idx"], idx)
+    assert conf.max() > 0

@@ -446,3 +446,37 @@ def test_duplicate_events_in_a_packet(ctx, packed, n_pixels):
     m.fillVoxelGrid(xy, centers)
     assert_dsi_close(m.dsi_.download(), ref)
     m.close()
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_plane_sharded_mappers_equal_slices_of_the_full_dsi(ctx, inverse):
+    """Plane sharding (SURVEY 8e, configs[4]): a mapper that owns planes [b, b+c) of the depth vector
+    builds exactly those planes of the unsharded DSI (same z0, same kernels per plane), and the packed
+    (confidence, index) keys of the shards combine to the unsharded arg-max and depth."""
+    from dvs_mcemvs_amd import distributed as dd
+    rig = syn.stereo_rig(30000, width=96, height=72, duration=0.3, seed=5)
+    shape = d.ShapeDSI(0, 0, 23, 4.0, 120.0, 0.0)
+    full = d.MapperEMVS(ctx, rig["cam"], shape, inverse_depth=inverse)
+    assert full.evaluateDSI(rig["events"][0], rig["trajectories"][0], rig["T_rv_w"])
+    ref = full.dsi_.download()
+    full.computeDepthMap(full.dsi_)
+    depth_ref, conf_ref, idx_ref = full.fetchDepthMap()
+    keys = None
+    for b, c in dd.plane_ranges(23, 4):
+        m = d.MapperEMVS(ctx, rig["cam"], shape, inverse_depth=inverse, plane_range=(b, c))
+        assert m.plane_begin == b and m.dimZ == c
+        assert np.array_equal(m.raw_depths_vec_, full.raw_depths_vec_[b:b + c])
+        assert m.evaluateDSI(rig["events"][0], rig["trajectories"][0], rig["T_rv_w"])
+        assert np.array_equal(m.dsi_.download(), ref[b:b + c])          # bit for bit
+        m.computeDepthMap(m.dsi_)
+        _, conf_l, idx_l = m.fetchDepthMap()
+        k = dd.pack_argmax_keys(conf_l, idx_l, b)
+        keys = k if keys is None else np.maximum(keys, k)
+        m.close()
+    conf, idx = dd.unpack_argmax_keys(keys)
+    assert np.array_equal(conf, conf_ref) and np.array_equal(idx, idx_ref)
+    # index -> depth with the full depth vector (mapper_emvs_stereo.cpp:302-313)
+    assert np.array_equal(orc.indices_to_depth(idx, full.raw_depths_vec_), depth_ref)
+    with pytest.raises(d.DsiError):
+        d.MapperEMVS(ctx, rig["cam"], shape, plane_range=(20, 9))
+    full.close()
