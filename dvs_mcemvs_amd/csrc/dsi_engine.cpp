@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -198,9 +199,21 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
     const long run = 1024L * (band_rows + 1) / g.ny;
     bp->packed = m->want_packed >= 0 ? m->want_packed : 1;
     // mapping 2 sorts S consecutive packets together so that a run holds >= ~512 events
+    // (mapping 4, the hand-scheduled loop, packs the runs of consecutive groups into the lanes, so
+    //  it only needs runs of a few batches)
+    const long want_run = bp->packed == 4 ? 160 : 512;
     int S = 1;
-    while (S < 32 && (long)S * std::max<long>(run, 1) < 512) S <<= 1;
+    while (S < 32 && (long)S * std::max<long>(run, 1) < want_run) S <<= 1;
+    if (const char* e = std::getenv("DSI_GROUP_PACKETS")) {  // tuning experiments only
+        const int v = std::atoi(e);
+        if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) S = v;
+    }
     bp->group_packets = S;
+    bp->pass_lg = 0;
+    if (const char* e = std::getenv("DSI_PASS_LG")) {  // tuning experiments only
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 6) bp->pass_lg = v;
+    }
     int chunks = m->want_chunks;
     if (chunks <= 0) {
         const long items_target = 8L * 256;  // ~8 work items per CU
@@ -302,7 +315,7 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
     const bool direct = (bp.chunks == 1 && !accumulate);
     if (!direct) HIP_TRY(m->partials.reserve((size_t)bp.chunks * g->n));
 
-    if (bp.packed == 2) {
+    if (bp.packed == 2 || bp.packed == 4) {
         const int S = bp.group_packets;
         const size_t ngroups = (np + S - 1) / S;
         HIP_TRY(m->spk.reserve(np * dsi::kPacket));
@@ -315,7 +328,7 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
                                        geom, bp, m->coef.p, m->cuts.p));
         HIP_TRY(dsi::launch_group_cuts(ctx->stream, m->cuts.p, m->rowstart.p, (int)np, S, geom, bp, m->gcuts.p));
         VoteTimer vt(m);
-        HIP_TRY(dsi::launch_vote_groups(ctx->stream, m->sxy.p, m->spk.p, m->coef.p, m->gcuts.p, (int)np, S, geom,
+        HIP_TRY(dsi::launch_vote_groups(ctx->stream, m->sxy.p, m->spk.p, m->coef.p, m->gcuts.p, m->nvalid.p + np, (int)np, S, geom,
                                         bp, direct ? g->data : m->partials.p));
         vt.stop();
     } else {
@@ -765,7 +778,7 @@ int dsi_mapper_set_band_params(dsi_mapper_t* m, int band_rows, int chunks, int b
 int dsi_mapper_set_packed_lanes(dsi_mapper_t* m, int mode)
 {
     REQUIRE(m, DSI_ERR_INVALID, "mapper is null");
-    REQUIRE(mode >= -1 && mode <= 3, DSI_ERR_INVALID, "mode must be -1 (auto), 0, 1, 2 or 3");
+    REQUIRE(mode >= -1 && mode <= 4, DSI_ERR_INVALID, "mode must be -1 (auto) or 0..4");
     m->want_packed = mode;
     return DSI_OK;
 }
@@ -1033,7 +1046,7 @@ DSI_API int dsi_test_run_length_total(dsi_mapper_t* m, unsigned long long* total
     if (int rc = set_device(m->ctx)) return rc;
     size_t units = m->info.n_packets;
     const uint32_t* src = m->cuts.p;
-    if (m->info.packed == 2) {  // grouped mapping: one run per group of packets
+    if (m->info.packed == 2 || m->info.packed == 4) {  // grouped mapping: one run per group of packets
         units = (m->info.n_packets + m->info.group_packets - 1) / m->info.group_packets;
         src = m->gcuts.p;
     }

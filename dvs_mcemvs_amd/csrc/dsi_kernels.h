@@ -42,9 +42,11 @@ struct BandPlan {
     int band_rows;      // owned rows per band (last band may own fewer)
     int chunks;         // packet chunks; each writes its own partial DSI when > 1
     int block_threads;  // 256 / 512 / 1024
-    int packed;         // lane mapping: 0 k_vote_bands, 1 k_vote_bands_packed, 2 k_vote_groups
+    int packed;         // lane mapping: 0 k_vote_bands, 1 k_vote_bands_packed (asm), 2 k_vote_groups,
+                        // 3 k_vote_bands_packed (compiled loop), 4 k_vote_groups (asm)
     int group_packets;  // mapping 2: packets sorted together (power of two <= 32)
     int row_pad;        // z0 rows binned over [-row_pad, ny + row_pad) by k_sort_packets
+    int pass_lg;        // packed mappings: log2(packets a wave takes per pass); 0 = automatic
     size_t lds_bytes;   // (band_rows + 2) * nx * 8 (u64 fixed-point accumulators, 2 halo rows)
 };
 
@@ -71,8 +73,8 @@ hipError_t launch_sort_groups(hipStream_t s, const float2* xy, int np, int S, in
 hipError_t launch_group_cuts(hipStream_t s, const uint32_t* prow, const uint16_t* rowstart, int np,
                              int S, const Geom& g, const BandPlan& bp, uint32_t* gcuts);
 hipError_t launch_vote_groups(hipStream_t s, const EvRec* sxy, const uint8_t* spk,
-                              const PlaneCoef* coef, const uint32_t* gcuts, int np, int S,
-                              const Geom& g, const BandPlan& bp, float* out);
+                              const PlaneCoef* coef, const uint32_t* gcuts, const uint32_t* slow_any,
+                              int np, int S, const Geom& g, const BandPlan& bp, float* out);
 hipError_t launch_reduce_partials(hipStream_t s, const float* partials, int chunks, size_t n,
                                   float* dsi, int accumulate);
 // ---- Grid3D ops ------------------------------------------------------------

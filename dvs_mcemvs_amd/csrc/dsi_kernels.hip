@@ -322,6 +322,9 @@ __global__ __launch_bounds__(256) void k_sort_packets(const float2* __restrict__
     if (threadIdx.x == 0) nvalid[k] = total | (big << 31);  // total <= 1024
 }
 
+// lane mappings 2 and 4 sort groups of packets together (k_sort_groups)
+__device__ __host__ __forceinline__ bool grouped(int packed) { return packed == 2 || packed == 4; }
+
 // (2) per (packet, plane): coefficients + for every band the run [lo,hi) of the grouped
 //     packet whose Y can fall into the band.  The band's Y interval is mapped back to z0 rows
 //     (in double, widened by one row on each side), and the run is read off the packet's
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(256) void k_plane_coef(const float* __restrict__ ce
                        c.bx, c.by, c.d);
     c.r = 1.f / c.d;
     c.pad0 = c.pad1 = 0;
-    const uint32_t nvraw = bp.packed == 2 ? 1u : nvalid[k];
+    const uint32_t nvraw = grouped(bp.packed) ? 1u : nvalid[k];
     const int nv = (int)(nvraw & 0x7fffffffu);
     const bool big_events = (nvraw >> 31) != 0;
     // Which (packet, plane) pairs can vote at all?  NaN anywhere, d == 0, or an
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(256) void k_plane_coef(const float* __restrict__ ce
 
     const int pad = bp.row_pad;
     const int nb = g.ny + 2 * pad + 2;
-    const uint16_t* rs = rowstart + (bp.packed == 2 ? 0 : (size_t)k * (nb + 1));
+    const uint16_t* rs = rowstart + (grouped(bp.packed) ? 0 : (size_t)k * (nb + 1));
     // y0 = (Y*d - by)/a inverts the transfer; unusable when the map is (nearly) constant or
     // the inversion is ill-conditioned -- then the whole packet is the (superset) run
     const double a = (double)c.a, d = (double)c.d, by = (double)c.by;
@@ -392,23 +395,23 @@ __global__ __launch_bounds__(256) void k_plane_coef(const float* __restrict__ ce
                     ymax += m;
                     const double fa = fmin(fmax(floor(ymin), (double)(-pad - 1)), (double)(g.ny + pad));
                     const double fb = fmin(fmax(floor(ymax), (double)(-pad - 1)), (double)(g.ny + pad));
-                    if (bp.packed == 2) {  // grouped mapping: row bins, resolved per group later
+                    if (grouped(bp.packed)) {  // grouped mapping: row bins, resolved per group later
                         lo = (uint32_t)((int)fa + pad + 1);
                         hi = (uint32_t)((int)fb + pad + 2);
                     } else {
                         lo = rs[(int)fa + pad + 1];   // events in bins below bin(fa)
                         hi = rs[(int)fb + pad + 2];   // events in bins up to and including bin(fb)
                     }
-                } else if (bp.packed == 2) {
+                } else if (grouped(bp.packed)) {
                     lo = 0;
                     hi = (uint32_t)nb;
                 }
-            } else if (bp.packed == 2) {
+            } else if (grouped(bp.packed)) {
                 lo = 0;
                 hi = (uint32_t)nb;  // whole packet = all row bins
             }
             if (hi < lo) hi = lo;
-        } else if (bp.packed == 2) {
+        } else if (grouped(bp.packed)) {
             lo = 0xffffu;  // dead packet: contributes no rows
             hi = 0;
         }
@@ -977,6 +980,157 @@ __device__ __forceinline__ void packed_stream_asm(const EvRec* sxy, const uint4*
           "v62", "v63");
 }
 
+// ---- the same hand-scheduled loop over GROUPS of S packets sorted together (lane mapping 4).
+// A run is then S times longer (wide grids: ~19 records per packet and band at 1024 x 1024, which
+// makes the per-packet stream scalar-bound at 4.4 run pieces per batch).  A record's coefficients
+// now depend on the record (its packet index within the group sits in the high half of m), so
+// the pipeline is three batches deep: records of batch i+2 and coefficients of batch i+1 are in
+// flight while batch i is voted; three register slots, loop unrolled three times.
+//   s47,s48,s49 lanes of the batches in slots 0,1,2      v52 record index per lane   v53 cut words
+//   slot 0: v[20:22] record  v23 group's coefficient base  v[24:27] a,bx,by,d  v28 r
+//   slot 1: v[30:32]         v33                           v[40:43]            v29
+//   slot 2: v[44:46]         v47                           v[48:51]            v34
+//   temporaries v36-v39, v56-v63 (v57 = multiplicity)
+#define DSI_ASM_FILL_G(NOUT, L)                                                                    \
+    "s_mov_b32 s44, 0\n"                                                                            \
+    "Ltop" L "%=:\n\t"                                                                              \
+    "s_cmp_ge_i32 s40, s41\n\t"                                                                     \
+    "s_cbranch_scc1 Lnext" L "%=\n\t"                                                               \
+    "s_sub_i32 s45, 64, s44\n\t"                                                                    \
+    "s_sub_i32 s46, s41, s40\n\t"                                                                   \
+    "s_min_i32 s45, s45, s46\n\t"                                                                   \
+    "s_sub_i32 s46, s40, s44\n\t"                                                                   \
+    "s_lshl_b64 exec, -1, s44\n\t"                                                                  \
+    "v_add_u32 v52, s46, %15\n\t"                                                                   \
+    "s_mov_b64 exec, -1\n\t"                                                                        \
+    "s_add_i32 s44, s44, s45\n\t"                                                                   \
+    "s_add_i32 s40, s40, s45\n\t"                                                                   \
+    "s_cmp_lt_u32 s44, 64\n\t"                                                                      \
+    "s_cbranch_scc0 Ldone" L "%=\n"                                                                 \
+    "Lnext" L "%=:\n\t"                                                                             \
+    "s_add_i32 s42, s42, 1\n\t"                                                                     \
+    "s_cmp_ge_i32 s42, %3\n\t"                                                                      \
+    "s_cbranch_scc1 Leos" L "%=\n\t"                                                                \
+    "s_and_b32 s45, s42, %4\n\t"                                                                    \
+    "s_cmp_eq_u32 s45, 0\n\t"                                                                       \
+    "s_cbranch_scc1 Lreload" L "%=\n\t"                                                             \
+    "v_readlane_b32 s46, v53, s45\n\t"                                                              \
+    "s_add_i32 s43, s43, %16\n"           /* next group: S * 1024 records further */                \
+    "Lhave" L "%=:\n\t"                                                                             \
+    "s_and_b32 s45, s46, 0xffff\n\t"                                                                \
+    "s_lshr_b32 s46, s46, 16\n\t"                                                                   \
+    "s_add_i32 s40, s43, s45\n\t"                                                                   \
+    "s_add_i32 s41, s43, s46\n\t"                                                                   \
+    "s_branch Ltop" L "%=\n"                                                                        \
+    "Lreload" L "%=:\n\t"                                                                           \
+    "s_lshr_b32 s45, s42, %7\n\t"                                                                   \
+    "s_mul_i32 s45, s45, %6\n\t"                                                                    \
+    "s_add_i32 s45, s45, %5\n\t"          /* first group of the pass */                             \
+    "s_mul_i32 s43, s45, %16\n\t"                                                                   \
+    "v_add_u32 v58, s45, %15\n\t"                                                                   \
+    "v_min_i32 v58, %8, v58\n\t"                                                                    \
+    "v_lshlrev_b32 v58, 2, v58\n\t"                                                                 \
+    "global_load_dword v53, v58, %2\n\t"                                                            \
+    "s_waitcnt vmcnt(0)\n\t"                                                                        \
+    "v_readfirstlane_b32 s46, v53\n\t"                                                              \
+    "s_branch Lhave" L "%=\n"                                                                       \
+    "Leos" L "%=:\n\t"                                                                              \
+    "s_cmp_eq_u32 s44, 0\n\t"                                                                       \
+    "s_cbranch_scc1 Ldone" L "%=\n\t"                                                               \
+    "s_lshl_b64 exec, -1, s44\n\t"                                                                  \
+    "v_mov_b32 v52, %14\n\t"                                                                        \
+    "s_mov_b64 exec, -1\n"                                                                          \
+    "Ldone" L "%=:\n\t"                                                                             \
+    "s_mov_b32 " NOUT ", s44\n\t"
+
+// request the records of the batch just filled; keep the byte offset of its group's coefficients
+#define DSI_ASM_GREC(REC, GB)                                                                      \
+    "v_mul_lo_u32 v56, v52, 12\n\t"                                                                 \
+    "v_lshrrev_b32 " GB ", 10, v52\n\t"   /* packet of the record, if groups were single packets */ \
+    "v_and_b32 " GB ", %17, " GB "\n\t"   /* first packet of the group */                           \
+    "v_lshlrev_b32 " GB ", 5, " GB "\n\t" /* 32 bytes per coefficient set */                        \
+    "global_load_dwordx3 " REC ", v56, %0\n\t"
+
+// the records have arrived: request each lane's coefficients (packet index = high half of m)
+#define DSI_ASM_GCOEF(M, GB, CA, CR)                                                               \
+    "v_lshrrev_b32 v56, 16, " M "\n\t"                                                              \
+    "v_lshl_add_u32 v56, v56, 5, " GB "\n\t"                                                        \
+    "global_load_dwordx4 " CA ", v56, %1\n\t"                                                       \
+    "global_load_dword " CR ", v56, %1 offset:16\n\t"
+
+#define DSI_ASM_GITER(NJ, RECJ2, GBJ2, NJ2, MJ1, GBJ1, CAJ1, CRJ1, EX, EY, EM, KA, KBX, KBY, KD, KR, L) \
+    DSI_ASM_FILL_G(NJ2, L)                                                                         \
+    DSI_ASM_GREC(RECJ2, GBJ2)                                                                      \
+    "s_waitcnt vmcnt(3)\n\t"              /* records of the next batch are here */                  \
+    DSI_ASM_GCOEF(MJ1, GBJ1, CAJ1, CRJ1)                                                           \
+    "s_waitcnt vmcnt(3)\n\t"              /* coefficients of this batch are here */                 \
+    "s_cmp_eq_u32 " NJ ", 0\n\t"                                                                    \
+    "s_cbranch_scc1 Lend%=\n\t"                                                                     \
+    "v_and_b32 v57, 0xffff, " EM "\n\t"   /* multiplicity */                                        \
+    DSI_ASM_VOTE(EX, EY, "v57", KA, KBX, KBY, KD, KR)
+
+__device__ __forceinline__ void group_stream_asm(const EvRec* sxy, const uint4* coef4,
+                                                 const uint32_t* cutz, char* band_bytes,
+                                                 int g_first, int g_end, int lg_pass, int stride,
+                                                 int lane, int nx, int Li, int Ui, int row_base,
+                                                 uint32_t dummy_eo, int S)
+{
+    const int pass = 1 << lg_pass;
+    int n_my = 0;
+    if (g_first < g_end) {
+        const int passes = (g_end - g_first + stride - 1) / stride;
+        const int last = g_first + (passes - 1) * stride;
+        n_my = (passes - 1) * pass + min(pass, g_end - last);
+    }
+    const int s_n_my = __builtin_amdgcn_readfirstlane(n_my);
+    const int s_gmask = __builtin_amdgcn_readfirstlane(pass - 1);
+    const int s_g_first = __builtin_amdgcn_readfirstlane(g_first);
+    const int s_stride = __builtin_amdgcn_readfirstlane(stride);
+    const int s_lg = __builtin_amdgcn_readfirstlane(lg_pass);
+    const int s_g_last = __builtin_amdgcn_readfirstlane(g_end - 1);
+    const int s_nx8 = __builtin_amdgcn_readfirstlane(nx * 8);
+    const int lds_base = (int)(uintptr_t)band_bytes;
+    const int s_cbase = __builtin_amdgcn_readfirstlane(lds_base - row_base * nx * 8);
+    const int s_nxm2 = __builtin_amdgcn_readfirstlane(nx - 2);
+    const int s_Li = __builtin_amdgcn_readfirstlane(Li);
+    const int s_Uim1 = __builtin_amdgcn_readfirstlane(Ui - 1);
+    const uint32_t s_dummy = __builtin_amdgcn_readfirstlane(dummy_eo);
+    const int s_gs = __builtin_amdgcn_readfirstlane(S * kPacket);
+    const int s_pkmask = __builtin_amdgcn_readfirstlane(~(S - 1));
+    asm volatile(
+        "s_mov_b32 s42, -1\n\t"
+        "s_mov_b32 s40, 0\n\t"
+        "s_mov_b32 s41, 0\n\t"
+        "s_mov_b32 s43, 0\n\t"
+        "v_mov_b32 v52, 0\n\t"
+        "v_mov_b32 v53, 0\n\t"
+        DSI_ASM_FILL_G("s47", "p")
+        DSI_ASM_GREC("v[20:22]", "v23")
+        DSI_ASM_FILL_G("s48", "q")
+        DSI_ASM_GREC("v[30:32]", "v33")
+        "s_waitcnt vmcnt(1)\n\t"
+        DSI_ASM_GCOEF("v22", "v23", "v[24:27]", "v28")
+        "Lloop%=:\n\t"
+        DSI_ASM_GITER("s47", "v[44:46]", "v47", "s49", "v32", "v33", "v[40:43]", "v29",
+                      "v20", "v21", "v22", "v24", "v25", "v26", "v27", "v28", "a")
+        DSI_ASM_GITER("s48", "v[20:22]", "v23", "s47", "v46", "v47", "v[48:51]", "v34",
+                      "v30", "v31", "v32", "v40", "v41", "v42", "v43", "v29", "b")
+        DSI_ASM_GITER("s49", "v[30:32]", "v33", "s48", "v22", "v23", "v[24:27]", "v28",
+                      "v44", "v45", "v46", "v48", "v49", "v50", "v51", "v34", "c")
+        "s_branch Lloop%=\n"
+        "Lend%=:\n\t"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)"
+        :
+        : "s"(sxy), "s"(coef4), "s"(cutz), "s"(s_n_my), "s"(s_gmask), "s"(s_g_first), "s"(s_stride),
+          "s"(s_lg), "s"(s_g_last), "s"(s_nx8), "s"(s_cbase), "s"(s_nxm2), "s"(s_Li), "s"(s_Uim1),
+          "s"(s_dummy), "v"(lane), "s"(s_gs), "s"(s_pkmask)
+        : "memory", "scc", "vcc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49",
+          "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32",
+          "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45",
+          "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58",
+          "v59", "v60", "v61", "v62", "v63");
+}
+
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const EvRec* __restrict__ sxy,
                                                              const PlaneCoef* __restrict__ coef,
@@ -1012,11 +1166,13 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const EvRec* __rest
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int lane = threadIdx.x & (kWave - 1);
     const int Li = max(r0 - 1, 0), Ui = min(r1, g.ny - 1);
-    // packets a wave takes per pass: 64 when the chunk is long, fewer (>= 4) when it is short so
-    // that every wave of the workgroup gets some
+    // packets a wave takes per pass:
     constexpr int kWaves = BLOCK / kWave;
+    // as many as possible (fewer reloads of cut words), but every wave should get >= 4 passes so
+    // that the waves of the workgroup finish together (measured: 2 % at 346x260, 6 % at 512x512)
     int lg_group = 6;
-    while (lg_group > 2 && (p_end - p_begin) < (kWaves << lg_group)) --lg_group;
+    while (lg_group > 2 && (p_end - p_begin) < ((kWaves * 4) << lg_group)) --lg_group;
+    if (bp.pass_lg > 0) lg_group = bp.pass_lg;
     const int group = 1 << lg_group;
     const uint4* __restrict__ coef4 = reinterpret_cast<const uint4*>(coef) + 2 * (size_t)z * np;
     const uint32_t* __restrict__ cutz = cuts + ((size_t)j * g.nz + z) * np;
@@ -1061,8 +1217,13 @@ __global__ __launch_bounds__(256) void k_sort_groups(const float2* __restrict__ 
     const int p0 = gidx * S;
     const int n_ev = min(S, np - p0) * kPacket;
     const float2* __restrict__ src = xy + (size_t)p0 * kPacket;
-    if (gidx == 0)
+    if (gidx == 0) {
         for (int i = threadIdx.x; i < nz; i += 256) nvalid[np + i] = 0;  // see k_sort_packets
+        if (threadIdx.x == 0) {
+            const EvRec none = {0.f, 0.f, 0u};
+            sxy[(size_t)np * kPacket] = none;  // the multiplicity-0 record
+        }
+    }
     for (int i = threadIdx.x; i <= nb; i += 256) hist[i] = 0;
     __syncthreads();
     for (int i = threadIdx.x; i < n_ev; i += 256) {
@@ -1102,7 +1263,9 @@ __global__ __launch_bounds__(256) void k_sort_groups(const float2* __restrict__ 
         const float2 e = src[i];
         if (finitef(e.x) && finitef(e.y)) {
             const uint32_t pos = atomicAdd(&hist[row_bin(e.y, ny, pad)], 1u);
-            const EvRec r = {e.x, e.y, 1u};
+            // multiplicity 1 in the low half, packet index within the group in the high half (the
+            // hand-scheduled loop finds the record's coefficients through it)
+            const EvRec r = {e.x, e.y, 1u | ((uint32_t)(i >> 10) << 16)};
             dst[pos] = r;
             dpk[pos] = (uint8_t)(i >> 10);  // packet index within the group
         }
@@ -1145,7 +1308,8 @@ template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_vote_groups(const EvRec* __restrict__ sxy,
                                                        const uint8_t* __restrict__ spk,
                                                        const PlaneCoef* __restrict__ coef,
-                                                       const uint32_t* __restrict__ gcuts, int np,
+                                                       const uint32_t* __restrict__ gcuts,
+                                                       const uint32_t* __restrict__ slow_any, int np,
                                                        int ngroups, int S, Geom g, BandPlan bp,
                                                        float* __restrict__ out)
 {
@@ -1180,6 +1344,18 @@ __global__ __launch_bounds__(BLOCK) void k_vote_groups(const EvRec* __restrict__
     const uint4* __restrict__ coef4 = reinterpret_cast<const uint4*>(coef) + 2 * (size_t)z * np;
     const uint32_t* __restrict__ cutz = gcuts + ((size_t)j * g.nz + z) * ngroups;
 
+    if (bp.packed == 4 && slow_any[z] == 0) {
+        // lane mapping 4: the hand-scheduled stream over groups (runs of all the wave's groups
+        // packed back to back into the lanes); planes that need the IEEE divide take the loop below
+        constexpr int kWaves = BLOCK / kWave;
+        int lg_pass = 6;
+        while (lg_pass > 0 && (g_end - g_begin) < ((kWaves * 4) << lg_pass)) --lg_pass;
+        if (bp.pass_lg > 0) lg_pass = bp.pass_lg;
+        const int pass = 1 << lg_pass;
+        group_stream_asm(sxy, coef4, cutz, reinterpret_cast<char*>(band), g_begin + wave * pass, g_end,
+                         lg_pass, kWaves * pass, lane, nx, Li, Ui, row_base,
+                         (uint32_t)np * (uint32_t)kPacket, S);
+    } else
     for (int gi = g_begin + wave; gi < g_end; gi += BLOCK / kWave) {
         const uint32_t cu = cutz[gi];
         const int lo = (int)(cu & 0xffffu), hi = (int)(cu >> 16);
@@ -1217,7 +1393,7 @@ __global__ __launch_bounds__(BLOCK) void k_vote_groups(const EvRec* __restrict__
             sgn |= (act && !(vb.y & kCoefSkip) && fabsf(nxv) < nmax && fabsf(nyv) < nmax) ? 0 : -1;
             if (sgn >= 0) {
                 const int idx = __mul24(yi - row_base, nx) + xi;
-                vote4(band, idx, nx, X - xf, Y - yf, e.m);  // cartesian3dgrid.h:261-270
+                vote4(band, idx, nx, X - xf, Y - yf, e.m & 0xffffu);  // cartesian3dgrid.h:261-270
             }
         };
         const int last = hi - 1;
@@ -1715,8 +1891,9 @@ hipError_t launch_group_cuts(hipStream_t s, const uint32_t* prow, const uint16_t
 
 template <int BLOCK>
 static hipError_t launch_vote_groups_t(hipStream_t s, const EvRec* sxy, const uint8_t* spk,
-                                       const PlaneCoef* coef, const uint32_t* gcuts, int np, int S,
-                                       const Geom& g, const BandPlan& bp, float* out)
+                                       const PlaneCoef* coef, const uint32_t* gcuts,
+                                       const uint32_t* slow_any, int np, int S, const Geom& g,
+                                       const BandPlan& bp, float* out)
 {
     static size_t configured = 0;
     if (bp.lds_bytes > configured) {
@@ -1729,19 +1906,19 @@ static hipError_t launch_vote_groups_t(hipStream_t s, const EvRec* sxy, const ui
     const int ngroups = (np + S - 1) / S;
     const unsigned blocks = (unsigned)(bp.chunks * bp.bands) * (unsigned)g.nz;
     hipLaunchKernelGGL(k_vote_groups<BLOCK>, dim3(blocks), dim3(BLOCK), bp.lds_bytes, s, sxy, spk,
-                       coef, gcuts, np, ngroups, S, g, bp, out);
+                       coef, gcuts, slow_any, np, ngroups, S, g, bp, out);
     return hipGetLastError();
 }
 
 hipError_t launch_vote_groups(hipStream_t s, const EvRec* sxy, const uint8_t* spk,
-                              const PlaneCoef* coef, const uint32_t* gcuts, int np, int S,
-                              const Geom& g, const BandPlan& bp, float* out)
+                              const PlaneCoef* coef, const uint32_t* gcuts, const uint32_t* slow_any,
+                              int np, int S, const Geom& g, const BandPlan& bp, float* out)
 {
     if (np <= 0) return hipSuccess;
     switch (bp.block_threads) {
-    case 256: return launch_vote_groups_t<256>(s, sxy, spk, coef, gcuts, np, S, g, bp, out);
-    case 512: return launch_vote_groups_t<512>(s, sxy, spk, coef, gcuts, np, S, g, bp, out);
-    case 1024: return launch_vote_groups_t<1024>(s, sxy, spk, coef, gcuts, np, S, g, bp, out);
+    case 256: return launch_vote_groups_t<256>(s, sxy, spk, coef, gcuts, slow_any, np, S, g, bp, out);
+    case 512: return launch_vote_groups_t<512>(s, sxy, spk, coef, gcuts, slow_any, np, S, g, bp, out);
+    case 1024: return launch_vote_groups_t<1024>(s, sxy, spk, coef, gcuts, slow_any, np, S, g, bp, out);
     default: return hipErrorInvalidValue;
     }
 }

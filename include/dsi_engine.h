@@ -174,7 +174,8 @@ DSI_API int dsi_mapper_set_band_params(dsi_mapper_t *m, int band_rows, int chunk
  * runs of 64 packets packed back to back into the lanes (short runs: wide / tall grids).
  * mode -1 = automatic (by expected run length), 0 = per packet, 1 = packed,
  * 2 = groups of consecutive packets sorted together (one long run per group),
- * 3 = packed with the compiled (not hand-scheduled) wave loop, for A/B tests. */
+ * 3 = packed with the compiled (not hand-scheduled) wave loop, for A/B tests,
+ * 4 = groups with the hand-scheduled wave loop (long runs for wide grids). */
 DSI_API int dsi_mapper_set_packed_lanes(dsi_mapper_t *m, int mode);
 
 /* MapperEMVS::fillVoxelGrid(event_locations_z0, camera_centers)

@@ -79,10 +79,11 @@ def _close(got, ref, tol=DSI_TOL):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("algo", [1, 2, 3, 4])
+@pytest.mark.parametrize("algo", [1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p) for p in CASES])
 def test_hip_matches_golden(ctx, path, algo):
-    packed = {3: 1, 4: 2}.get(algo, 0)   # 3 / 4 = LDS bands with the packed / grouped lane mapping
+    # 3..6 = LDS bands with the packed (asm) / grouped / packed (compiled) / grouped (asm) lane mapping
+    packed = {3: 1, 4: 2, 5: 3, 6: 4}.get(algo, 0)
     algo = min(algo, 2)
     import dvs_mcemvs_amd as d
     g = load(path)

@@ -393,7 +393,7 @@ def test_fuse_into_equals_reference_sequence(ctx):
         A.setToFusionOf(A, G, 2)
 
 
-@pytest.mark.parametrize("packed", [0, 1, 2, 3])
+@pytest.mark.parametrize("packed", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("shape,band", [((64, 48, 16), None), ((346, 260, 12), (26, 4, 1024)),
                                         ((130, 97, 7), (5, 3, 256)), ((70, 48, 9), (48, 2, 512)),
                                         ((40, 30, 6), (9, 2, 256))])
@@ -417,7 +417,7 @@ def test_both_lane_mappings_match_oracle(ctx, shape, band, packed):
     m.close()
 
 
-@pytest.mark.parametrize("packed", [0, 1, 2, 3])
+@pytest.mark.parametrize("packed", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("n_pixels", [1, 7, 300, 5000])
 def test_duplicate_events_in_a_packet(ctx, packed, n_pixels):
     """Events of a packet drawn from a few pixels (hot pixels, bursts): the packet sort merges
