@@ -480,3 +480,49 @@ def test_plane_sharded_mappers_equal_slices_of_the_full_dsi(ctx, inverse):
     with pytest.raises(d.DsiError):
         d.MapperEMVS(ctx, rig["cam"], shape, plane_range=(20, 9))
     full.close()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_hand_scheduled_loops_equal_the_compiled_loop_bit_for_bit(ctx, seed):
+    """The assembly wave loops (lane mappings 1 and 4) do the compiled loop's arithmetic instruction
+    for instruction and accumulate in exact fixed point, so on ANY input -- random grid sizes, band
+    heights, chunk counts, block sizes, poses that push most events off the grid, planes behind the
+    camera -- their DSIs must equal mapping 3's bit for bit (and mapping 0's, the per-packet loop)."""
+    rng = np.random.default_rng(9000 + seed)
+    nx = int(rng.integers(8, 400))
+    ny = int(rng.integers(8, 300))
+    nz = int(rng.integers(1, 40))
+    n_packets = int(rng.integers(1, 70))
+    cam = (nx, ny, float(rng.uniform(0.5, 2.0) * nx), float(rng.uniform(0.5, 2.0) * nx),
+           0.5 * nx, 0.5 * ny)
+    xy, centers = random_packets(rng, n_packets, nx, ny, spread=float(rng.uniform(0.01, 2.0)),
+                                 cz_spread=float(rng.uniform(0.01, 3.0)))
+    if seed % 2:
+        pool = xy[rng.integers(0, xy.shape[0], 200)]                  # heavy duplicates
+        xy[: xy.shape[0] // 2] = pool[rng.integers(0, 200, xy.shape[0] // 2)]
+    xy[rng.integers(0, xy.shape[0], 20)] = np.nan
+    xy[rng.integers(0, xy.shape[0], 20)] = np.inf
+    xy[rng.integers(0, xy.shape[0], 5)] = 3.0e38
+    band = (int(rng.integers(1, 12)), int(rng.integers(1, 6)), int(rng.choice([256, 512, 1024])))
+    m_max = float(rng.uniform(2.0, 9.0))
+    ref = {}
+    # (3, 1, 0) chunk the packets identically, (2, 4) chunk the groups identically: within each
+    # family the fp32 partial DSIs of the chunks are the same numbers, so the results are bit-equal
+    import os
+    for packed in (3, 1, 0, 2, 4):
+        m = make_mapper(ctx, cam, nz, 0.8, m_max, d.VOTE_LDS_BANDS, band=band, packed=packed)
+        os.environ["DSI_GROUP_PACKETS"] = "8"      # same groups (hence chunk boundaries) for 2 and 4
+        try:
+            m.fillVoxelGrid(xy, centers)
+        finally:
+            del os.environ["DSI_GROUP_PACKETS"]
+        got = m.dsi_.download()
+        m.close()
+        family = 0 if packed in (3, 1, 0) else 1
+        if family not in ref:
+            ref[family] = got
+            orc_ref = orc.fill_voxel_grid(xy, centers, m.raw_depths_vec_, np.array(m.virtual_cam_, np.float32), nx, ny)
+            assert_dsi_close(got, orc_ref)
+        else:
+            assert np.array_equal(got, ref[family]), "lane mapping %d differs from its compiled twin: max %g" % (
+                packed, np.abs(got.astype(np.float64) - ref[family]).max())
