@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=10_000_000,
                     help="events of camera 0 the CPU oracle is timed on (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="2: each camera's mapper on its own HIP stream (context), meeting at the fusion")
     return ap.parse_args()
 
 
@@ -92,13 +94,15 @@ def main():
                          seed=1234 + 100 * rank, n_points=args.points)
     shape = d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0)  # cfg/DSEC/zurich_04_a_full/dsec.conf:11-12,17
     mappers, batches, voted = [], [], 0
+    ctx_cam1 = d.Context(local_rank) if args.streams == 2 else ctx
+    cam_ctx = [ctx, ctx_cam1]
     for c in range(2):
-        m = d.MapperEMVS(ctx, rig["cam"], shape)
+        m = d.MapperEMVS(cam_ctx[c], rig["cam"], shape)
         m.set_vote_algo(args.algo)
         m.set_band_params(*args.band)
         m.set_packed_lanes(args.packed)
         first, Rt = d.packetize(rig["events"][c][2], rig["trajectories"][c], rig["T_rv_w"])
-        batches.append(d.EventBatch(ctx, rig["events"][c][0], rig["events"][c][1], Rt, first))
+        batches.append(d.EventBatch(cam_ctx[c], rig["events"][c][0], rig["events"][c][1], Rt, first))
         voted += first.shape[0] * d.PACKET_SIZE
         mappers.append(m)
     fused = d.Grid3D(ctx, nx, ny, nz)
@@ -116,8 +120,12 @@ def main():
                                                      extract=mapper_fused.computeDepthMap)
 
     def step():
+        if ctx_cam1 is not ctx:
+            ctx_cam1.wait_for(ctx)        # the previous step's fusion has read camera 1's DSI
         for c in range(2):
             mappers[c].evaluateDSI_batch(batches[c])
+        if ctx_cam1 is not ctx:
+            ctx.wait_for(ctx_cam1)        # fusion after both cameras
         # process1.cpp:126-141 (resetGrid; addTwoGrids(dsi0); harmonicMeanTwoGrids(dsi1)) in one pass
         fused.setToFusionOf(mappers[0].dsi_, mappers[1].dsi_, d.FUSE_HM)
         if temporal is None:
@@ -128,6 +136,7 @@ def main():
 
     def barrier():
         ctx.synchronize()
+        ctx_cam1.synchronize()
         if temporal is not None:
             temporal.drain()
         if dist is not None:
@@ -283,6 +292,8 @@ def main():
         temporal.close()
         mapper_fused.close()
         ctx_side.close()
+    if ctx_cam1 is not ctx:
+        ctx_cam1.close()
     ctx.close()
     if dist is not None:
         dist.barrier()

@@ -85,7 +85,8 @@ struct dsi_context {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr;
-    double* ms_accum = nullptr;  // device scalar for mean-square
+    hipEvent_t sync_ev = nullptr;  // dsi_context_wait_for: "everything queued on this stream so far"
+    double* ms_accum = nullptr;    // device scalar for mean-square
 };
 
 struct dsi_grid {
@@ -404,6 +405,7 @@ int dsi_context_destroy(dsi_context_t* ctx)
     if (ctx->ms_accum) (void)hipFree(ctx->ms_accum);
     if (ctx->t0) (void)hipEventDestroy(ctx->t0);
     if (ctx->t1) (void)hipEventDestroy(ctx->t1);
+    if (ctx->sync_ev) (void)hipEventDestroy(ctx->sync_ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return DSI_OK;
@@ -413,6 +415,18 @@ int dsi_context_synchronize(dsi_context_t* ctx)
 {
     REQUIRE(ctx, DSI_ERR_INVALID, "ctx is null");
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return DSI_OK;
+}
+
+int dsi_context_wait_for(dsi_context_t* ctx, dsi_context_t* other)
+{
+    REQUIRE(ctx && other, DSI_ERR_INVALID, "ctx is null");
+    REQUIRE(ctx->device == other->device, DSI_ERR_INVALID, "contexts are on different devices");
+    if (ctx == other) return DSI_OK;
+    if (int rc = set_device(ctx)) return rc;
+    if (!other->sync_ev) HIP_TRY(hipEventCreateWithFlags(&other->sync_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(other->sync_ev, other->stream));
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, other->sync_ev, 0));
     return DSI_OK;
 }
 
@@ -529,7 +543,9 @@ int dsi_grid_download(dsi_grid_t* g, float* host)
 static int check_pair(const dsi_grid_t* dst, const dsi_grid_t* src)
 {
     REQUIRE(dst && src, DSI_ERR_INVALID, "null grid");
-    REQUIRE(dst->ctx == src->ctx, DSI_ERR_CONTEXT, "grids belong to different contexts");
+    // grids of two contexts (streams) of one device may be combined: the op runs on dst's stream and
+    // the caller orders the streams (dsi_context_wait_for)
+    REQUIRE(dst->ctx->device == src->ctx->device, DSI_ERR_CONTEXT, "grids live on different devices");
     REQUIRE(same_shape(dst, src), DSI_ERR_SHAPE, "grid shapes differ: (%d,%d,%d) vs (%d,%d,%d)", dst->nx,
             dst->ny, dst->nz, src->nx, src->ny, src->nz);
     return set_device(dst->ctx);
@@ -932,7 +948,7 @@ int dsi_mapper_evaluate(dsi_mapper_t* m, const uint16_t* x, const uint16_t* y, c
 int dsi_mapper_depth_map_of(dsi_mapper_t* m, dsi_grid_t* g)
 {
     REQUIRE(m && g, DSI_ERR_INVALID, "null argument");
-    REQUIRE(m->ctx == g->ctx, DSI_ERR_CONTEXT, "mapper and grid belong to different contexts");
+    REQUIRE(m->ctx->device == g->ctx->device, DSI_ERR_CONTEXT, "mapper and grid live on different devices");
     REQUIRE(same_shape(m->grid, g), DSI_ERR_SHAPE, "grid shape differs from the mapper's DSI");
     if (int rc = set_device(m->ctx)) return rc;
     const size_t npix = (size_t)g->nx * g->ny;

@@ -85,6 +85,7 @@ def load_library():
         "dsi_context_destroy": (C.c_int, [vp]),
         "dsi_context_synchronize": (C.c_int, [vp]),
         "dsi_context_stream": (vp, [vp]),
+        "dsi_context_wait_for": (C.c_int, [vp, vp]),
         "dsi_context_device": (C.c_int, [vp]),
         "dsi_context_timer_start": (C.c_int, [vp]),
         "dsi_context_timer_stop": (C.c_int, [vp, f32p]),
@@ -219,6 +220,11 @@ class Context:
     @property
     def stream(self):
         return load_library().dsi_context_stream(self._h)
+
+    def wait_for(self, other):
+        """Device-side: work queued on this context from now on starts after everything already
+        queued on `other` (no host wait)."""
+        _check(load_library().dsi_context_wait_for(self._h, other._h))
 
     @property
     def device(self):

@@ -50,7 +50,7 @@ typedef enum {
     DSI_ERR_SHAPE = 4,         /* grids of different dimensions (reference: std::out_of_range from .at()) */
     DSI_ERR_BAD_OP = 5,        /* "Improper fusion method selected" (process1.cpp:155-157) */
     DSI_ERR_NO_DEVICE = 6,     /* no usable gfx950 GPU */
-    DSI_ERR_CONTEXT = 7        /* objects belong to different contexts */
+    DSI_ERR_CONTEXT = 7        /* objects belong to different devices (or a batch to another context) */
 } dsi_status_t;
 
 /* camera-fusion op codes = --stereo_fusion values (main.cpp:89, process1.cpp:136-158) */
@@ -92,6 +92,11 @@ DSI_API int dsi_context_synchronize(dsi_context_t *ctx);
 /* the hipStream_t all work of this context is issued on */
 DSI_API void *dsi_context_stream(dsi_context_t *ctx);
 DSI_API int dsi_context_device(dsi_context_t *ctx);
+/* device-side ordering between two contexts (streams) of one GPU: work queued on ctx after this call
+ * starts only when everything queued on `other` before this call has finished.  The host does not
+ * wait.  (The reference is single-threaded; this lets each MapperEMVS own a stream, e.g. the two
+ * cameras of process_1, and meet at the fusion.) */
+DSI_API int dsi_context_wait_for(dsi_context_t *ctx, dsi_context_t *other);
 /* HIP-event stopwatch on the context's stream (bench.py: the replacement of the
  * std::chrono timers at process1.cpp:72-85,132-166). stop synchronises. */
 DSI_API int dsi_context_timer_start(dsi_context_t *ctx);

@@ -86,6 +86,7 @@ public:
     Context(const Context&) = delete;
     Context& operator=(const Context&) = delete;
     dsi_context_t* handle() const { return h_; }
+    void wait_for(Context& other) { check(dsi_context_wait_for(h_, other.h_)); }
     void synchronize() { check(dsi_context_synchronize(h_)); }
 
 private:

@@ -526,3 +526,25 @@ def test_hand_scheduled_loops_equal_the_compiled_loop_bit_for_bit(ctx, seed):
         else:
             assert np.array_equal(got, ref[family]), "lane mapping %d differs from its compiled twin: max %g" % (
                 packed, np.abs(got.astype(np.float64) - ref[family]).max())
+
+
+def test_two_contexts_meet_at_the_fusion(ctx):
+    """Each camera's mapper on its own context (HIP stream); dsi_context_wait_for orders the streams on
+    the device; grid ops accept operands of another context of the same device."""
+    rig = syn.stereo_rig(20000, width=80, height=60, duration=0.3, seed=3)
+    shape = d.ShapeDSI(0, 0, 12, 4.0, 100.0, 0.0)
+    ctx2 = d.Context(0)
+    m0 = d.MapperEMVS(ctx, rig["cam"], shape)
+    m1 = d.MapperEMVS(ctx2, rig["cam"], shape)
+    fused = d.Grid3D(ctx, 80, 60, 12)
+    for rep in range(3):
+        ctx2.wait_for(ctx)                      # the previous fusion has read m1.dsi_
+        assert m0.evaluateDSI(rig["events"][0], rig["trajectories"][0], rig["T_rv_w"])
+        assert m1.evaluateDSI(rig["events"][1], rig["trajectories"][1], rig["T_rv_w"])
+        ctx.wait_for(ctx2)
+        fused.setToFusionOf(m0.dsi_, m1.dsi_, d.FUSE_HM)
+    got = fused.download()
+    ref = orc.fuse2(m0.dsi_.download(), m1.dsi_.download(), 2)
+    assert np.array_equal(got, ref)
+    for o in (m0, m1, fused, ctx2):
+        o.close()
