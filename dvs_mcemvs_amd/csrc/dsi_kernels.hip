@@ -710,28 +710,28 @@ __device__ __forceinline__ void packed_stream(const EvRec* __restrict__ sxy,
         }
         return fill;
     };
-    // Issue the gathers of the filled batch.  The three loads and the wait for them are inline
-    // assembly: with compiler-visible loads the register allocator reuses destination registers
-    // of the set in flight as temporaries of fill_batch and the waitcnt pass then waits for ALL
-    // outstanding loads there (vmcnt(0)), which undoes the prefetch.  The compiler only sees
-    // opaque values defined by `gather` and redefined by `arrived`; nothing touches them between.
+    // Issue the gathers of the filled batch: plain loads the compiler counts.  (Its waitcnt pass
+    // then waits for ALL outstanding loads inside fill_batch -- the register allocator reuses
+    // destination registers of the set in flight as temporaries there -- so the prefetch is
+    // only partly effective.  Hiding the loads from the compiler in inline assembly fixes that
+    // but leaves the in-flight registers unprotected against compiler copies; the hand-scheduled
+    // stream below owns its registers instead.)
     typedef float v3f __attribute__((ext_vector_type(3)));
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-    const uint4* coef_r = reinterpret_cast<const uint4*>(coef4);
     auto gather = [&](v3f& ev, v4u& va, uint32_t& vr) {
-        const uint32_t eo12 = eo * 12u;                 // byte offset of the record (< 2^32)
-        const uint32_t co = (eo >> 5) & ~31u;           // byte offset of the packet's coefficients
-        asm volatile("global_load_dwordx3 %0, %3, %5\n\t"
-                     "global_load_dwordx4 %1, %4, %6\n\t"
-                     "global_load_dword %2, %4, %6 offset:16"
-                     : "=&v"(ev), "=&v"(va), "=&v"(vr)
-                     : "v"(eo12), "v"(co), "s"(sxy), "s"(coef_r)
-                     : "memory");
+        const EvRec r = sxy[eo];
+        ev.x = r.x;
+        ev.y = r.y;
+        ev.z = __uint_as_float(r.m);
+        const uint32_t co = (eo >> 9) & ~1u;  // 2 * packet
+        const uint4 c4 = coef4[co];
+        va.x = c4.x;
+        va.y = c4.y;
+        va.z = c4.z;
+        va.w = c4.w;
+        vr = *reinterpret_cast<const uint32_t*>(coef4 + co + 1u);
     };
-    // all loads but the three newest (the next batch's) have arrived
-    auto arrived = [&](v3f& ev, v4u& va, uint32_t& vr) {
-        asm volatile("s_waitcnt vmcnt(3)" : "+v"(ev), "+v"(va), "+v"(vr) : : "memory");
-    };
+    auto arrived = [&](v3f&, v4u&, uint32_t&) {};
     const int nx8 = nx * 8;
     const int cbase = -row_base * nx8;
     auto vote = [&](const v3f& ev, const v4u& va, uint32_t vr) {
@@ -786,7 +786,6 @@ __device__ __forceinline__ void packed_stream(const EvRec* __restrict__ sxy,
         arrived(eB, caB, crB);
         vote(eB, caB, crB);
     }
-    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");  // the last (empty) batch's loads
 }
 
 // The same stream, fast path only (no IEEE-divide planes), written in gfx950 assembly.
