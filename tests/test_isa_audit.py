@@ -1,0 +1,41 @@
+"""Static audit of the compiled gfx950 code of the voting kernels (no GPU needed): the hand-written
+wave loops name physical registers, so the kernels must neither spill nor use scratch, and must stay
+within 64 VGPRs (8 waves per SIMD = two 1024-thread workgroups per CU)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    return None
+
+
+@pytest.mark.skipif(_hipcc() is None, reason="hipcc not available")
+def test_vote_kernels_do_not_spill(tmp_path):
+    out = tmp_path / "dsi_kernels.s"
+    subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-x", "hip",
+                           "-S", "--cuda-device-only", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "dvs_mcemvs_amd", "csrc", "dsi_kernels.hip"), "-o", str(out)],
+                          stderr=subprocess.DEVNULL)
+    text = out.read_text()
+    seen = 0
+    for block in text.split("  - .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block).group(1)
+        if "k_vote_" not in name:
+            continue
+        seen += 1
+        val = lambda key: int(re.search(r"\.%s:\s+(\d+)" % key, block).group(1))
+        assert val("vgpr_spill_count") == 0 and val("sgpr_spill_count") == 0, name
+        assert val("private_segment_fixed_size") == 0, name
+        assert val("vgpr_count") <= 64, name
+    assert seen >= 10
+    # the hand-scheduled loops are in there and keep their waits
+    assert text.count("s_waitcnt vmcnt(3)") >= 6 and "v_cvt_flr_i32_f32" in text and "v_cmpx_lt_i32" in text
