@@ -122,6 +122,7 @@ struct dsi_mapper {
     DevBuf<float> centers, H, partials, Rt_tmp, conf, depth;
     DevBuf<float2> xy;
     DevBuf<dsi::EvRec> sxy;
+    DevBuf<float> carry;  // [chunks][nz][bands][nx]: votes into the row below each band
     DevBuf<uint32_t> nvalid, cuts, gcuts;
     DevBuf<uint8_t> spk;
     DevBuf<uint16_t> rowstart;
@@ -174,15 +175,15 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
     const dsi::Geom& g = m->geom;
     const size_t row_bytes = (size_t)g.nx * sizeof(unsigned long long);  // Q33.31 LDS accumulators
     const long max_rows_total = (long)(dsi::max_dynamic_lds() / row_bytes);
-    if (max_rows_total < 3 || g.nx < 2 || g.ny < 2 || g.ny > 16000) return false;
-    long max_owned = max_rows_total - 2;  // two halo rows
+    if (max_rows_total < 2 || g.nx < 2 || g.ny < 2 || g.ny > 16000) return false;
+    long max_owned = max_rows_total - 1;  // + the carry row
     if (m->want_band_rows > 0) {
         max_owned = std::min<long>(max_owned, m->want_band_rows);
     } else {
         // Two 1024-thread workgroups per CU (32 waves) hide latency better than one, if half the
         // LDS still gives runs of >= ~96 events per (packet, band): rows+1 of Ny rows see
         // 1024*(rows+1)/Ny events of a packet.
-        const long half_rows = (long)(dsi::max_dynamic_lds() / 2 / row_bytes) - 2;
+        const long half_rows = (long)(dsi::max_dynamic_lds() / 2 / row_bytes) - 1;
         if (half_rows >= 4 && 1024L * (half_rows + 1) / g.ny >= 96) max_owned = half_rows;
     }
     int bands = (int)((g.ny + max_owned - 1) / max_owned);
@@ -191,7 +192,7 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
     bands = (g.ny + band_rows - 1) / band_rows;
     bp->bands = bands;
     bp->band_rows = band_rows;
-    bp->lds_bytes = (size_t)(band_rows + 2) * row_bytes;
+    bp->lds_bytes = (size_t)(band_rows + 1) * row_bytes;
     bp->block_threads = m->want_block > 0 ? m->want_block : 1024;
     bp->row_pad = std::min(g.ny, 4096);  // z0 locations spill up to ~ny rows outside the grid
     // expected events of one packet in one band.  The packed mapping (hand-scheduled wave loop)
@@ -313,6 +314,7 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
     HIP_TRY(m->rowstart.reserve(np * (size_t)(geom.ny + 2 * bp.row_pad + 3)));
     HIP_TRY(m->coef.reserve(np * geom.nz + 1));       // + the dummy record's "coefficients"
     HIP_TRY(m->cuts.reserve(np * geom.nz * bp.bands));
+    HIP_TRY(m->carry.reserve((size_t)bp.chunks * geom.nz * bp.bands * geom.nx));
     const bool direct = (bp.chunks == 1 && !accumulate);
     if (!direct) HIP_TRY(m->partials.reserve((size_t)bp.chunks * g->n));
 
@@ -330,7 +332,7 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
         HIP_TRY(dsi::launch_group_cuts(ctx->stream, m->cuts.p, m->rowstart.p, (int)np, S, geom, bp, m->gcuts.p));
         VoteTimer vt(m);
         HIP_TRY(dsi::launch_vote_groups(ctx->stream, m->sxy.p, m->spk.p, m->coef.p, m->gcuts.p, m->nvalid.p + np, (int)np, S, geom,
-                                        bp, direct ? g->data : m->partials.p));
+                                        bp, direct ? g->data : m->partials.p, m->carry.p));
         vt.stop();
     } else {
     HIP_TRY(dsi::launch_sort_packets(ctx->stream, xy, (int)np, geom.ny, geom.nz, bp.row_pad, m->sxy.p, m->nvalid.p, m->rowstart.p));
@@ -338,12 +340,13 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
                                    geom, bp, m->coef.p, m->cuts.p));
     VoteTimer vt(m);
     HIP_TRY(dsi::launch_vote_bands(ctx->stream, m->sxy.p, m->coef.p, m->cuts.p, m->nvalid.p + np, (int)np, geom, bp,
-                                   direct ? g->data : m->partials.p));
+                                   direct ? g->data : m->partials.p, m->carry.p));
     vt.stop();
     }
     if (!direct)
         HIP_TRY(dsi::launch_reduce_partials(ctx->stream, m->partials.p, bp.chunks, g->n, g->data,
                                             accumulate ? 1 : 0));
+    HIP_TRY(dsi::launch_add_carry(ctx->stream, m->carry.p, bp.chunks, geom, bp, g->data));
     return DSI_OK;
 }
 
@@ -730,6 +733,7 @@ int dsi_mapper_destroy(dsi_mapper_t* m)
     m->depth.release();
     m->xy.release();
     m->sxy.release();
+    m->carry.release();
     m->nvalid.release();
     m->gcuts.release();
     m->spk.release();

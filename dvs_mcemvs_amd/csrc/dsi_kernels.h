@@ -47,7 +47,7 @@ struct BandPlan {
     int group_packets;  // mapping 2: packets sorted together (power of two <= 32)
     int row_pad;        // z0 rows binned over [-row_pad, ny + row_pad) by k_sort_packets
     int pass_lg;        // packed mappings: log2(packets a wave takes per pass); 0 = automatic
-    size_t lds_bytes;   // (band_rows + 2) * nx * 8 (u64 fixed-point accumulators, 2 halo rows)
+    size_t lds_bytes;   // (band_rows + 1) * nx * 8 (u64 fixed-point accumulators; +1 = the carry row)
 };
 
 // ---- stage A ---------------------------------------------------------------
@@ -67,14 +67,17 @@ hipError_t launch_plane_coef(hipStream_t s, const float* centers, const float* p
                              const Geom& g, const BandPlan& bp, PlaneCoef* coef, uint32_t* cuts);
 hipError_t launch_vote_bands(hipStream_t s, const EvRec* sxy, const PlaneCoef* coef,
                              const uint32_t* cuts, const uint32_t* slow_any, int np, const Geom& g,
-                             const BandPlan& bp, float* out);
+                             const BandPlan& bp, float* out, float* carry);
+// adds the bands' carry rows (votes of a band's last row into the next band's first row) to the volume
+hipError_t launch_add_carry(hipStream_t s, const float* carry, int chunks, const Geom& g,
+                            const BandPlan& bp, float* dsi);
 hipError_t launch_sort_groups(hipStream_t s, const float2* xy, int np, int S, int ny, int nz, int pad,
                               EvRec* sxy, uint8_t* spk, uint32_t* nvalid, uint16_t* rowstart);
 hipError_t launch_group_cuts(hipStream_t s, const uint32_t* prow, const uint16_t* rowstart, int np,
                              int S, const Geom& g, const BandPlan& bp, uint32_t* gcuts);
 hipError_t launch_vote_groups(hipStream_t s, const EvRec* sxy, const uint8_t* spk,
                               const PlaneCoef* coef, const uint32_t* gcuts, const uint32_t* slow_any,
-                              int np, int S, const Geom& g, const BandPlan& bp, float* out);
+                              int np, int S, const Geom& g, const BandPlan& bp, float* out, float* carry);
 hipError_t launch_reduce_partials(hipStream_t s, const float* partials, int chunks, size_t n,
                                   float* dsi, int accumulate);
 // ---- Grid3D ops ------------------------------------------------------------

@@ -383,8 +383,8 @@ __global__ __launch_bounds__(256) void k_plane_coef(const float* __restrict__ ce
             if (invertible) {
                 const int r0 = j * bp.band_rows;
                 const int r1 = min(g.ny, r0 + bp.band_rows);
-                // accepted iff 0 <= Y < ny-1; the band needs floor(Y) in [r0-1, r1-1]
-                const double L = (double)max(r0 - 1, 0) - 0.01, U = (double)min(r1, g.ny - 1) + 0.01;
+                // accepted iff 0 <= Y < ny-1; the band needs floor(Y) in [r0, r1-1]
+                const double L = (double)r0 - 0.01, U = (double)min(r1, g.ny - 1) + 0.01;
                 const double ya = L * d_a - by_a, yb = U * d_a - by_a;
                 double ymin = fmin(ya, yb), ymax = fmax(ya, yb);
                 if (ymin == ymin && ymax == ymax) {  // not NaN
@@ -456,14 +456,28 @@ __device__ __forceinline__ void vote4(acc_t* __restrict__ band, int idx, int nx,
     __hip_atomic_fetch_add(cell + nx + 1, (acc_t)(unsigned int)(fxs * fy) * m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// owned rows of the band -> fp32 volume (a linear, coalesced copy)
+// owned rows of the band -> fp32 volume (a linear, coalesced copy); the row below the band (votes
+// of this band's last row into the next band's first row) -> the carry buffer, added to the
+// volume afterwards by k_add_carry.  A band therefore processes exactly the events with
+// floor(Y) in its OWNED rows: no event is processed by two bands.
 template <int BLOCK>
 __device__ __forceinline__ void flush_band(const acc_t* __restrict__ band, int nx, int n_out,
-                                           float* __restrict__ dst)
+                                           float* __restrict__ dst, float* __restrict__ carry_dst)
 {
-    const acc_t* src = band + nx;  // skip the top halo row
     for (int i = threadIdx.x; i < n_out; i += BLOCK)
-        dst[i] = (float)((double)src[i] * kFixInv);  // < 2^53: exact in f64, one rounding to f32
+        dst[i] = (float)((double)band[i] * kFixInv);  // < 2^53: exact in f64, one rounding to f32
+    if (carry_dst) {
+        const acc_t* src = band + n_out;
+        for (int i = threadIdx.x; i < nx; i += BLOCK) carry_dst[i] = (float)((double)src[i] * kFixInv);
+    }
+}
+
+// carry[c][z][j][x] of band j (written for j < bands - 1)
+__device__ __forceinline__ float* carry_row(float* carry, int c, int z, int j, const Geom& g,
+                                            const BandPlan& bp)
+{
+    if (j >= bp.bands - 1) return nullptr;
+    return carry + (((size_t)c * g.nz + z) * bp.bands + j) * g.nx;
 }
 
 template <int BLOCK>
@@ -471,7 +485,8 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands(const EvRec* __restrict__ 
                                                       const PlaneCoef* __restrict__ coef,
                                                       const uint32_t* __restrict__ cuts, int np,
                                                       Geom g, BandPlan bp,
-                                                      float* __restrict__ out)
+                                                      float* __restrict__ out,
+                                                      float* __restrict__ carry)
 {
     extern __shared__ acc_t band[];
     // block -> (pair q = (chunk, band), plane z).  Groups of 8 pairs: XCD x (= block % 8) walks
@@ -494,7 +509,7 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands(const EvRec* __restrict__ 
     const int r0 = j * bp.band_rows;
     const int r1 = min(g.ny, r0 + bp.band_rows);
     const int nx = g.nx;
-    const int cells = (r1 - r0 + 2) * nx;
+    const int cells = (r1 - r0 + 1) * nx;  // owned rows + the carry row
     for (int i = threadIdx.x; i < cells; i += BLOCK) band[i] = 0;
     __syncthreads();
 
@@ -502,9 +517,9 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands(const EvRec* __restrict__ 
     const int p_end = (int)(((long long)np * (c + 1)) / bp.chunks);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int lane = threadIdx.x & (kWave - 1);
-    const float L = (float)max(r0 - 1, 0), U = (float)min(r1, g.ny - 1);
+    const float L = (float)r0, U = (float)min(r1, g.ny - 1);
     const float xmax = (float)(nx - 1);
-    const int row_base = r0 - 1;
+    const int row_base = r0;
 
     // Per-packet metadata (coefficients + this band's run) is fetched with VECTOR loads whose
     // address is the same in every lane, one packet ahead of its use: scalar loads would
@@ -582,7 +597,7 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands(const EvRec* __restrict__ 
     // owned rows are contiguous in the [z][y][x] volume: a linear coalesced copy
     const size_t vol = (size_t)g.nx * g.ny * g.nz;
     float* __restrict__ dst = out + (size_t)c * vol + ((size_t)z * g.ny + r0) * nx;
-    flush_band<BLOCK>(band, nx, (r1 - r0) * nx, dst);
+    flush_band<BLOCK>(band, nx, (r1 - r0) * nx, dst, carry_row(carry, c, z, j, g, bp));
 }
 
 // (3b) the same work item decomposition for SHORT runs (tall or wide grids: a band of a
@@ -1136,7 +1151,8 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const EvRec* __rest
                                                              const uint32_t* __restrict__ cuts,
                                                              const uint32_t* __restrict__ slow_any,
                                                              int np, Geom g, BandPlan bp,
-                                                             float* __restrict__ out)
+                                                             float* __restrict__ out,
+                                                             float* __restrict__ carry)
 {
     extern __shared__ acc_t band[];
     const int b = blockIdx.x;
@@ -1156,7 +1172,7 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const EvRec* __rest
     const int r0 = j * bp.band_rows;
     const int r1 = min(g.ny, r0 + bp.band_rows);
     const int nx = g.nx;
-    const int cells = (r1 - r0 + 2) * nx;
+    const int cells = (r1 - r0 + 1) * nx;  // owned rows + the carry row
     for (int i = threadIdx.x; i < cells; i += BLOCK) band[i] = 0;
     __syncthreads();
 
@@ -1164,7 +1180,7 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const EvRec* __rest
     const int p_end = (int)(((long long)np * (c + 1)) / bp.chunks);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int lane = threadIdx.x & (kWave - 1);
-    const int Li = max(r0 - 1, 0), Ui = min(r1, g.ny - 1);
+    const int Li = r0, Ui = min(r1, g.ny - 1);
     // packets a wave takes per pass:
     constexpr int kWaves = BLOCK / kWave;
     // as many as possible (fewer reloads of cut words), but every wave should get >= 4 passes so
@@ -1182,18 +1198,18 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const EvRec* __rest
     // bp.packed == 3 selects the compiled stream on the fast path too (A/B testing)
     if (slow_any[z] != 0)
         packed_stream<true>(sxy, coef4, cutz, band_bytes, p_begin + wave * group, p_end, lg_group,
-                            kWaves * group, lane, nx, Li, Ui, r0 - 1, dummy_eo);
+                            kWaves * group, lane, nx, Li, Ui, r0, dummy_eo);
     else if (bp.packed == 3)
         packed_stream<false>(sxy, coef4, cutz, band_bytes, p_begin + wave * group, p_end, lg_group,
-                             kWaves * group, lane, nx, Li, Ui, r0 - 1, dummy_eo);
+                             kWaves * group, lane, nx, Li, Ui, r0, dummy_eo);
     else
         packed_stream_asm(sxy, coef4, cutz, band_bytes, p_begin + wave * group, p_end, lg_group,
-                          kWaves * group, lane, nx, Li, Ui, r0 - 1, dummy_eo);
+                          kWaves * group, lane, nx, Li, Ui, r0, dummy_eo);
     __syncthreads();
 
     const size_t vol = (size_t)g.nx * g.ny * g.nz;
     float* __restrict__ dst = out + (size_t)c * vol + ((size_t)z * g.ny + r0) * nx;
-    flush_band<BLOCK>(band, nx, (r1 - r0) * nx, dst);
+    flush_band<BLOCK>(band, nx, (r1 - r0) * nx, dst, carry_row(carry, c, z, j, g, bp));
 }
 
 // (3c) GROUPED mapping: S consecutive packets (a "group"; their poses are microseconds apart)
@@ -1310,7 +1326,8 @@ __global__ __launch_bounds__(BLOCK) void k_vote_groups(const EvRec* __restrict__
                                                        const uint32_t* __restrict__ gcuts,
                                                        const uint32_t* __restrict__ slow_any, int np,
                                                        int ngroups, int S, Geom g, BandPlan bp,
-                                                       float* __restrict__ out)
+                                                       float* __restrict__ out,
+                                                       float* __restrict__ carry)
 {
     extern __shared__ acc_t band[];
     const int b = blockIdx.x;
@@ -1330,7 +1347,7 @@ __global__ __launch_bounds__(BLOCK) void k_vote_groups(const EvRec* __restrict__
     const int r0 = j * bp.band_rows;
     const int r1 = min(g.ny, r0 + bp.band_rows);
     const int nx = g.nx;
-    const int cells = (r1 - r0 + 2) * nx;
+    const int cells = (r1 - r0 + 1) * nx;  // owned rows + the carry row
     for (int i = threadIdx.x; i < cells; i += BLOCK) band[i] = 0;
     __syncthreads();
 
@@ -1338,8 +1355,8 @@ __global__ __launch_bounds__(BLOCK) void k_vote_groups(const EvRec* __restrict__
     const int g_end = (int)(((long long)ngroups * (c + 1)) / bp.chunks);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int lane = threadIdx.x & (kWave - 1);
-    const int Li = max(r0 - 1, 0), Ui = min(r1, g.ny - 1);
-    const int row_base = r0 - 1;
+    const int Li = r0, Ui = min(r1, g.ny - 1);
+    const int row_base = r0;
     const uint4* __restrict__ coef4 = reinterpret_cast<const uint4*>(coef) + 2 * (size_t)z * np;
     const uint32_t* __restrict__ cutz = gcuts + ((size_t)j * g.nz + z) * ngroups;
 
@@ -1421,10 +1438,26 @@ __global__ __launch_bounds__(BLOCK) void k_vote_groups(const EvRec* __restrict__
     __syncthreads();
     const size_t vol = (size_t)g.nx * g.ny * g.nz;
     float* __restrict__ dst = out + (size_t)c * vol + ((size_t)z * g.ny + r0) * nx;
-    flush_band<BLOCK>(band, nx, (r1 - r0) * nx, dst);
+    flush_band<BLOCK>(band, nx, (r1 - r0) * nx, dst, carry_row(carry, c, z, j, g, bp));
 }
 
 // (4) DSI = sum of the chunk partials (fixed order => deterministic given partials)
+// dsi[z][first row of band j+1][x] += sum over chunks of carry[c][z][j][x]
+__global__ __launch_bounds__(256) void k_add_carry(const float* __restrict__ carry, int chunks,
+                                                   Geom g, int bands, int band_rows,
+                                                   float* __restrict__ dsi)
+{
+    const size_t n = (size_t)g.nz * (bands - 1) * g.nx;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int x = (int)(i % g.nx);
+    const int j = (int)((i / g.nx) % (bands - 1));
+    const int z = (int)(i / ((size_t)g.nx * (bands - 1)));
+    float acc = 0.f;
+    for (int c = 0; c < chunks; ++c) acc += carry[(((size_t)c * g.nz + z) * bands + j) * g.nx + x];
+    dsi[((size_t)z * g.ny + (size_t)(j + 1) * band_rows) * g.nx + x] += acc;
+}
+
 __global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ partials,
                                                          int chunks, size_t n,
                                                          float* __restrict__ dsi, int accumulate)
@@ -1824,7 +1857,7 @@ hipError_t launch_plane_coef(hipStream_t s, const float* centers, const float* p
 template <int BLOCK, bool PACKED>
 static hipError_t launch_vote_bands_t(hipStream_t s, const EvRec* sxy, const PlaneCoef* coef,
                                       const uint32_t* cuts, const uint32_t* slow_any, int np,
-                                      const Geom& g, const BandPlan& bp, float* out)
+                                      const Geom& g, const BandPlan& bp, float* out, float* carry)
 {
     static size_t configured = 0;
     const void* kern = PACKED ? reinterpret_cast<const void*>(&k_vote_bands_packed<BLOCK>)
@@ -1838,30 +1871,30 @@ static hipError_t launch_vote_bands_t(hipStream_t s, const EvRec* sxy, const Pla
     const unsigned blocks = (unsigned)(bp.chunks * bp.bands) * (unsigned)g.nz;
     if (PACKED)
         hipLaunchKernelGGL(k_vote_bands_packed<BLOCK>, dim3(blocks), dim3(BLOCK), bp.lds_bytes, s,
-                           sxy, coef, cuts, slow_any, np, g, bp, out);
+                           sxy, coef, cuts, slow_any, np, g, bp, out, carry);
     else
         hipLaunchKernelGGL(k_vote_bands<BLOCK>, dim3(blocks), dim3(BLOCK), bp.lds_bytes, s, sxy, coef,
-                           cuts, np, g, bp, out);
+                           cuts, np, g, bp, out, carry);
     return hipGetLastError();
 }
 
 hipError_t launch_vote_bands(hipStream_t s, const EvRec* sxy, const PlaneCoef* coef,
                              const uint32_t* cuts, const uint32_t* slow_any, int np, const Geom& g,
-                             const BandPlan& bp, float* out)
+                             const BandPlan& bp, float* out, float* carry)
 {
     if (np <= 0) return hipSuccess;
     if (bp.packed) {
         switch (bp.block_threads) {
-        case 256: return launch_vote_bands_t<256, true>(s, sxy, coef, cuts, slow_any, np, g, bp, out);
-        case 512: return launch_vote_bands_t<512, true>(s, sxy, coef, cuts, slow_any, np, g, bp, out);
-        case 1024: return launch_vote_bands_t<1024, true>(s, sxy, coef, cuts, slow_any, np, g, bp, out);
+        case 256: return launch_vote_bands_t<256, true>(s, sxy, coef, cuts, slow_any, np, g, bp, out, carry);
+        case 512: return launch_vote_bands_t<512, true>(s, sxy, coef, cuts, slow_any, np, g, bp, out, carry);
+        case 1024: return launch_vote_bands_t<1024, true>(s, sxy, coef, cuts, slow_any, np, g, bp, out, carry);
         default: return hipErrorInvalidValue;
         }
     }
     switch (bp.block_threads) {
-    case 256: return launch_vote_bands_t<256, false>(s, sxy, coef, cuts, slow_any, np, g, bp, out);
-    case 512: return launch_vote_bands_t<512, false>(s, sxy, coef, cuts, slow_any, np, g, bp, out);
-    case 1024: return launch_vote_bands_t<1024, false>(s, sxy, coef, cuts, slow_any, np, g, bp, out);
+    case 256: return launch_vote_bands_t<256, false>(s, sxy, coef, cuts, slow_any, np, g, bp, out, carry);
+    case 512: return launch_vote_bands_t<512, false>(s, sxy, coef, cuts, slow_any, np, g, bp, out, carry);
+    case 1024: return launch_vote_bands_t<1024, false>(s, sxy, coef, cuts, slow_any, np, g, bp, out, carry);
     default: return hipErrorInvalidValue;
     }
 }
@@ -1892,7 +1925,7 @@ template <int BLOCK>
 static hipError_t launch_vote_groups_t(hipStream_t s, const EvRec* sxy, const uint8_t* spk,
                                        const PlaneCoef* coef, const uint32_t* gcuts,
                                        const uint32_t* slow_any, int np, int S, const Geom& g,
-                                       const BandPlan& bp, float* out)
+                                       const BandPlan& bp, float* out, float* carry)
 {
     static size_t configured = 0;
     if (bp.lds_bytes > configured) {
@@ -1905,21 +1938,31 @@ static hipError_t launch_vote_groups_t(hipStream_t s, const EvRec* sxy, const ui
     const int ngroups = (np + S - 1) / S;
     const unsigned blocks = (unsigned)(bp.chunks * bp.bands) * (unsigned)g.nz;
     hipLaunchKernelGGL(k_vote_groups<BLOCK>, dim3(blocks), dim3(BLOCK), bp.lds_bytes, s, sxy, spk,
-                       coef, gcuts, slow_any, np, ngroups, S, g, bp, out);
+                       coef, gcuts, slow_any, np, ngroups, S, g, bp, out, carry);
     return hipGetLastError();
 }
 
 hipError_t launch_vote_groups(hipStream_t s, const EvRec* sxy, const uint8_t* spk,
                               const PlaneCoef* coef, const uint32_t* gcuts, const uint32_t* slow_any,
-                              int np, int S, const Geom& g, const BandPlan& bp, float* out)
+                              int np, int S, const Geom& g, const BandPlan& bp, float* out, float* carry)
 {
     if (np <= 0) return hipSuccess;
     switch (bp.block_threads) {
-    case 256: return launch_vote_groups_t<256>(s, sxy, spk, coef, gcuts, slow_any, np, S, g, bp, out);
-    case 512: return launch_vote_groups_t<512>(s, sxy, spk, coef, gcuts, slow_any, np, S, g, bp, out);
-    case 1024: return launch_vote_groups_t<1024>(s, sxy, spk, coef, gcuts, slow_any, np, S, g, bp, out);
+    case 256: return launch_vote_groups_t<256>(s, sxy, spk, coef, gcuts, slow_any, np, S, g, bp, out, carry);
+    case 512: return launch_vote_groups_t<512>(s, sxy, spk, coef, gcuts, slow_any, np, S, g, bp, out, carry);
+    case 1024: return launch_vote_groups_t<1024>(s, sxy, spk, coef, gcuts, slow_any, np, S, g, bp, out, carry);
     default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t launch_add_carry(hipStream_t s, const float* carry, int chunks, const Geom& g,
+                            const BandPlan& bp, float* dsi)
+{
+    if (bp.bands < 2) return hipSuccess;
+    const size_t n = (size_t)g.nz * (bp.bands - 1) * g.nx;
+    hipLaunchKernelGGL(k_add_carry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, carry, chunks, g,
+                       bp.bands, bp.band_rows, dsi);
+    return hipGetLastError();
 }
 
 hipError_t launch_reduce_partials(hipStream_t s, const float* partials, int chunks, size_t n,
