@@ -298,6 +298,13 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
         return DSI_OK;
     }
 
+    // the hand-scheduled loops address records with 32-bit byte offsets (12 B per record):
+    // beyond 2^32 / 12 records (349,525 packets = 358 M events in ONE call) use the compiled loops
+    if ((np + 1) * dsi::kPacket * sizeof(dsi::EvRec) > 0xffffffffull) {
+        if (bp.packed == 1) bp.packed = 3;
+        if (bp.packed == 4) bp.packed = 2;
+    }
+
     m->info.bands = bp.bands;
     m->info.band_rows = bp.band_rows;
     m->info.chunks = bp.chunks;
