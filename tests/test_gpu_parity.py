@@ -548,3 +548,36 @@ def test_two_contexts_meet_at_the_fusion(ctx):
     assert np.array_equal(got, ref)
     for o in (m0, m1, fused, ctx2):
         o.close()
+
+
+def test_configs1_against_the_oracle_at_full_size(ctx):
+    """BASELINE.json configs[1] exactly (stereo, 10 M events per camera, 346x260x100, harmonic camera
+    fusion, arg-max + depth) against the CPU oracle: every voxel of both DSIs and of the fused DSI
+    within the stated tolerance; depth equal (<= 1e-4) wherever the CPU's arg-max is not a near-tie."""
+    rig = syn.stereo_rig(10_000_000, seed=1234)
+    cam = rig["cam"]
+    gpu, cpu = [], []
+    for c in range(2):
+        m = make_mapper(ctx, cam, 100, 4.0, 200.0, d.VOTE_LDS_BANDS)
+        assert m.evaluateDSI(rig["events"][c], rig["trajectories"][c], rig["T_rv_w"])
+        assert m.n_voted == 9765 * 1024
+        gpu.append(m)
+        r = OracleMapper(cam, dimZ=100, min_depth=4.0, max_depth=200.0)
+        assert r.evaluateDSI(rig["events"][c], rig["trajectories"][c], rig["T_rv_w"])
+        cpu.append(r)
+        assert_dsi_close(m.dsi_.download(), r.dsi)
+    fused = d.Grid3D(ctx, 346, 260, 100)
+    fused.setToFusionOf(gpu[0].dsi_, gpu[1].dsi_, d.FUSE_HM)
+    ref = orc.fuse2(cpu[0].dsi.copy(), cpu[1].dsi, 2)
+    got = fused.download()
+    assert_dsi_close(got, ref, tol=3 * DSI_TOL)      # HM of two values each within DSI_TOL
+    gpu[0].computeDepthMap(fused)
+    depth, conf, idx = gpu[0].fetchDepthMap()
+    rconf, ridx = orc.collapse_max_z(ref)
+    srt = np.sort(ref, axis=0)
+    safe = (srt[-1] - srt[-2]) > 6 * DSI_TOL * np.maximum(1.0, srt[-1])
+    assert safe.mean() > 0.5
+    assert np.array_equal(idx[safe], ridx[safe])
+    assert (np.abs(depth - orc.indices_to_depth(ridx, cpu[0].planes))[safe] <= 1e-4).all()
+    for o in gpu + [fused]:
+        o.close()
