@@ -259,7 +259,7 @@ def main():
             r.evaluate_packets(x, y, first, Rt)       # stage A + reset + fillVoxelGrid
             tc = min(tc, time.perf_counter() - t1)
         cpu = {"value": first.shape[0] * 1024 / tc / 1e6, "unit": "Mevents/s",
-               "cores": orc.num_threads(), "kind": "port",
+               "cores": min(orc.num_threads(), nz), "kind": "port",  # OpenMP over planes: at most nz threads work
                "sample": "camera 0, first %d events (%d packets) of the same workload, %dx%dx%d DSI; "
                          "oracle stage A + fillVoxelGrid, OpenMP over planes (reference strategy: at most dimZ threads busy), -O3 no -march=native; best of 3, %.2f s wall"
                          % (n_s, first.shape[0], nx, ny, nz, tc)}
