@@ -118,6 +118,11 @@ def main():
         mapper_fused = d.MapperEMVS(ctx_side, rig["cam"], shape)
         temporal = dd.PipelinedTemporalFusion.on_gpu(ctx, ctx_side, (nx, ny, nz), d.ACC_INV_SUM, world,
                                                      extract=mapper_fused.computeDepthMap)
+        # one un-timed round now: any problem with the two-stream / RCCL set-up shows up here, on
+        # every rank, before the warm-up
+        fused.resetGrid()
+        temporal.submit(fused)
+        temporal.drain()
 
     def step():
         if ctx_cam1 is not ctx:
