@@ -87,7 +87,43 @@ struct dsi_context {
     hipEvent_t t0 = nullptr, t1 = nullptr;
     hipEvent_t sync_ev = nullptr;  // dsi_context_wait_for: "everything queued on this stream so far"
     double* ms_accum = nullptr;    // device scalar for mean-square
+    // Released event-batch blocks, reused by the next dsi_batch_create on this context: a stream of
+    // windows then costs no hipMalloc / hipFree (hipFree synchronises the device).  Reuse is safe
+    // without waiting: everything that used the block was queued on this context's stream before.
+    std::vector<std::pair<void*, size_t>> batch_pool;
 };
+
+void* pool_take(dsi_context* ctx, size_t bytes, size_t* got)
+{
+    size_t best = (size_t)-1;
+    for (size_t i = 0; i < ctx->batch_pool.size(); ++i) {
+        const size_t sz = ctx->batch_pool[i].second;
+        if (sz >= bytes && sz <= 4 * bytes + 65536 &&
+            (best == (size_t)-1 || sz < ctx->batch_pool[best].second))
+            best = i;
+    }
+    if (best != (size_t)-1) {
+        void* p = ctx->batch_pool[best].first;
+        *got = ctx->batch_pool[best].second;
+        ctx->batch_pool.erase(ctx->batch_pool.begin() + (long)best);
+        return p;
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    *got = bytes;
+    return p;
+}
+
+void pool_give(dsi_context* ctx, void* p, size_t bytes)
+{
+    if (!p) return;
+    ctx->batch_pool.emplace_back(p, bytes);
+    if (ctx->batch_pool.size() > 8) {  // keep a handful; drop the oldest
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(ctx->batch_pool.front().first);
+        ctx->batch_pool.erase(ctx->batch_pool.begin());
+    }
+}
 
 struct dsi_grid {
     dsi_context* ctx = nullptr;
@@ -99,6 +135,8 @@ struct dsi_grid {
 
 struct dsi_batch {
     dsi_context* ctx = nullptr;
+    void* block = nullptr;  // one device allocation holding the four arrays below
+    size_t block_bytes = 0;
     uint16_t *x = nullptr, *y = nullptr;
     uint32_t* first = nullptr;
     float* Rt = nullptr;
@@ -412,6 +450,7 @@ int dsi_context_destroy(dsi_context_t* ctx)
     if (!ctx) return DSI_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto& blk : ctx->batch_pool) (void)hipFree(blk.first);
     if (ctx->ms_accum) (void)hipFree(ctx->ms_accum);
     if (ctx->t0) (void)hipEventDestroy(ctx->t0);
     if (ctx->t1) (void)hipEventDestroy(ctx->t1);
@@ -848,18 +887,31 @@ int dsi_batch_create(dsi_context_t* ctx, const uint16_t* x, const uint16_t* y, s
     b->ctx = ctx;
     b->n_events = n_events;
     b->n_packets = n_packets;
+    // one block: Rt | first | x | y (256-byte aligned parts), uploaded on the context's stream
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t rt_bytes = up(std::max<size_t>(n_packets, 1) * 12 * sizeof(float));
+    const size_t first_bytes = packet_first ? up(std::max<size_t>(n_packets, 1) * sizeof(uint32_t)) : 0;
+    const size_t ev_bytes = up(std::max<size_t>(n_events, 1) * sizeof(uint16_t));
+    b->block = pool_take(ctx, rt_bytes + first_bytes + 2 * ev_bytes, &b->block_bytes);
+    if (!b->block) {
+        delete b;
+        return fail(DSI_ERR_HIP, "batch allocation of %zu bytes failed", rt_bytes + first_bytes + 2 * ev_bytes);
+    }
+    char* base = static_cast<char*>(b->block);
+    b->Rt = reinterpret_cast<float*>(base);
+    b->first = packet_first ? reinterpret_cast<uint32_t*>(base + rt_bytes) : nullptr;
+    b->x = reinterpret_cast<uint16_t*>(base + rt_bytes + first_bytes);
+    b->y = reinterpret_cast<uint16_t*>(base + rt_bytes + first_bytes + ev_bytes);
     hipError_t e = hipSuccess;
-    const size_t ev_bytes = std::max<size_t>(n_events, 1) * sizeof(uint16_t);
-    e = hipMalloc(reinterpret_cast<void**>(&b->x), ev_bytes);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&b->y), ev_bytes);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&b->Rt), std::max<size_t>(n_packets, 1) * 12 * sizeof(float));
-    if (e == hipSuccess && packet_first)
-        e = hipMalloc(reinterpret_cast<void**>(&b->first), std::max<size_t>(n_packets, 1) * sizeof(uint32_t));
-    if (e == hipSuccess && n_events) e = hipMemcpy(b->x, x, n_events * sizeof(uint16_t), hipMemcpyHostToDevice);
-    if (e == hipSuccess && n_events) e = hipMemcpy(b->y, y, n_events * sizeof(uint16_t), hipMemcpyHostToDevice);
-    if (e == hipSuccess && n_packets) e = hipMemcpy(b->Rt, Rt, n_packets * 12 * sizeof(float), hipMemcpyHostToDevice);
+    if (n_events) e = hipMemcpyAsync(b->x, x, n_events * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && n_events)
+        e = hipMemcpyAsync(b->y, y, n_events * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && n_packets)
+        e = hipMemcpyAsync(b->Rt, Rt, n_packets * 12 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && n_packets && packet_first)
-        e = hipMemcpy(b->first, packet_first, n_packets * sizeof(uint32_t), hipMemcpyHostToDevice);
+        e = hipMemcpyAsync(b->first, packet_first, n_packets * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+    // the host arrays are the caller's: they must be consumed before this call returns
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         dsi_batch_destroy(b);
         return fail(DSI_ERR_HIP, "batch upload failed: %s", hipGetErrorString(e));
@@ -872,11 +924,7 @@ int dsi_batch_destroy(dsi_batch_t* b)
 {
     if (!b) return DSI_OK;
     (void)hipSetDevice(b->ctx->device);
-    (void)hipStreamSynchronize(b->ctx->stream);
-    if (b->x) (void)hipFree(b->x);
-    if (b->y) (void)hipFree(b->y);
-    if (b->Rt) (void)hipFree(b->Rt);
-    if (b->first) (void)hipFree(b->first);
+    pool_give(b->ctx, b->block, b->block_bytes);  // no wait: reuse is ordered by the context's stream
     delete b;
     return DSI_OK;
 }
