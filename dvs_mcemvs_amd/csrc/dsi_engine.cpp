@@ -152,6 +152,15 @@ struct dsi_mapper {
     float* planes_dev = nullptr;
     float2* lut_dev = nullptr;
     dsi_grid* grid = nullptr;
+    // Opt-in experiment (DSI_PREP_OVERLAP=1): stage A, the packet sort and the coefficient tables of
+    // evaluateDSI on a second stream, overlapping whatever the context's stream is still doing
+    // (typically the previous camera's voting kernel).  Measured: the voting kernel loses more
+    // (1.21 -> 1.38 ms: wave slots, LDS and L2 taken by the preparation kernels) than the overlap
+    // hides, 2.80 -> 2.92 ms per step, so it is off by default.
+    hipStream_t prep_stream = nullptr;
+    hipEvent_t ev_prep = nullptr, ev_vote_done = nullptr;
+    bool vote_recorded = false;
+    int prep_overlap = 0;
     int algo = DSI_VOTE_AUTO;
     int want_band_rows = 0, want_chunks = 0, want_block = 0;
     int want_packed = -1;  // -1 automatic, 0 per-packet waves, 1 packed lanes, 2 packet groups
@@ -309,9 +318,45 @@ struct VoteTimer {  // records an event pair around the voting kernel when timin
     }
 };
 
+// The stream the preparation kernels of an evaluate call go to: the mapper's own second stream,
+// ordered after this mapper's previous vote (which still reads the scratch tables), or the
+// context's stream when overlapping is off.
+int prep_begin(dsi_mapper* m, hipStream_t* ps)
+{
+    *ps = m->ctx->stream;
+    if (!m->prep_overlap) return DSI_OK;
+    if (!m->prep_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&m->prep_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&m->ev_prep, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&m->ev_vote_done, hipEventDisableTiming));
+    }
+    if (m->vote_recorded) HIP_TRY(hipStreamWaitEvent(m->prep_stream, m->ev_vote_done, 0));
+    *ps = m->prep_stream;
+    return DSI_OK;
+}
+
+// the context's stream continues only after the preparation kernels
+int prep_end(dsi_mapper* m, hipStream_t ps)
+{
+    if (ps == m->ctx->stream) return DSI_OK;
+    HIP_TRY(hipEventRecord(m->ev_prep, ps));
+    HIP_TRY(hipStreamWaitEvent(m->ctx->stream, m->ev_prep, 0));
+    return DSI_OK;
+}
+
+int vote_done(dsi_mapper* m)
+{
+    if (!m->prep_stream) return DSI_OK;
+    HIP_TRY(hipEventRecord(m->ev_vote_done, m->ctx->stream));
+    m->vote_recorded = true;
+    return DSI_OK;
+}
+
 // fillVoxelGrid on device data.  xy: np*1024 z0 locations (reference order);
-// centers: np*3.  accumulate != 0: add to the grid's current contents.
-int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np, bool accumulate)
+// centers: np*3.  accumulate != 0: add to the grid's current contents.  ps: the stream the sort and
+// coefficient kernels go to (see prep_begin); the caller has already put xy / centers on it.
+int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np, bool accumulate,
+                hipStream_t ps)
 {
     dsi_context* ctx = m->ctx;
     dsi_grid* g = m->grid;
@@ -329,11 +374,12 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
     m->depth_valid = false;
 
     if (algo == DSI_VOTE_GLOBAL_ATOMIC) {
+        if (int rc = prep_end(m, ps)) return rc;
         if (!accumulate) HIP_TRY(hipMemsetAsync(g->data, 0, g->n * sizeof(float), ctx->stream));
         VoteTimer vt(m);
         HIP_TRY(dsi::launch_vote_global(ctx->stream, xy, centers, (int)np, m->planes_dev, geom, g->data));
         vt.stop();
-        return DSI_OK;
+        return vote_done(m);
     }
 
     // the hand-scheduled loops address records with 32-bit byte offsets (12 B per record):
@@ -351,8 +397,9 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
     m->info.packed = bp.packed;
     m->info.group_packets = bp.group_packets;
     if (np == 0) {
+        if (int rc = prep_end(m, ps)) return rc;
         if (!accumulate) HIP_TRY(hipMemsetAsync(g->data, 0, g->n * sizeof(float), ctx->stream));
-        return DSI_OK;
+        return vote_done(m);
     }
     HIP_TRY(m->sxy.reserve(np * dsi::kPacket + 1));  // + the multiplicity-0 dummy record
     HIP_TRY(m->nvalid.reserve(np + (size_t)geom.nz));  // + one "needs IEEE divide" word per plane
@@ -369,20 +416,22 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
         HIP_TRY(m->spk.reserve(np * dsi::kPacket));
         HIP_TRY(m->gcuts.reserve(ngroups * geom.nz * bp.bands));
         HIP_TRY(m->rowstart.reserve(ngroups * (size_t)(geom.ny + 2 * bp.row_pad + 3)));
-        HIP_TRY(dsi::launch_sort_groups(ctx->stream, xy, (int)np, S, geom.ny, geom.nz, bp.row_pad, m->sxy.p, m->spk.p,
+        HIP_TRY(dsi::launch_sort_groups(ps, xy, (int)np, S, geom.ny, geom.nz, bp.row_pad, m->sxy.p, m->spk.p,
                                         m->nvalid.p, m->rowstart.p));
         // per-packet coefficients + row-bin ranges (cuts buffer), then the per-group runs
-        HIP_TRY(dsi::launch_plane_coef(ctx->stream, centers, m->planes_dev, m->rowstart.p, m->nvalid.p, (int)np,
+        HIP_TRY(dsi::launch_plane_coef(ps, centers, m->planes_dev, m->rowstart.p, m->nvalid.p, (int)np,
                                        geom, bp, m->coef.p, m->cuts.p));
-        HIP_TRY(dsi::launch_group_cuts(ctx->stream, m->cuts.p, m->rowstart.p, (int)np, S, geom, bp, m->gcuts.p));
+        HIP_TRY(dsi::launch_group_cuts(ps, m->cuts.p, m->rowstart.p, (int)np, S, geom, bp, m->gcuts.p));
+        if (int rc = prep_end(m, ps)) return rc;
         VoteTimer vt(m);
         HIP_TRY(dsi::launch_vote_groups(ctx->stream, m->sxy.p, m->spk.p, m->coef.p, m->gcuts.p, m->nvalid.p + np, (int)np, S, geom,
                                         bp, direct ? g->data : m->partials.p, m->carry.p));
         vt.stop();
     } else {
-    HIP_TRY(dsi::launch_sort_packets(ctx->stream, xy, (int)np, geom.ny, geom.nz, bp.row_pad, m->sxy.p, m->nvalid.p, m->rowstart.p));
-    HIP_TRY(dsi::launch_plane_coef(ctx->stream, centers, m->planes_dev, m->rowstart.p, m->nvalid.p, (int)np,
+    HIP_TRY(dsi::launch_sort_packets(ps, xy, (int)np, geom.ny, geom.nz, bp.row_pad, m->sxy.p, m->nvalid.p, m->rowstart.p));
+    HIP_TRY(dsi::launch_plane_coef(ps, centers, m->planes_dev, m->rowstart.p, m->nvalid.p, (int)np,
                                    geom, bp, m->coef.p, m->cuts.p));
+    if (int rc = prep_end(m, ps)) return rc;
     VoteTimer vt(m);
     HIP_TRY(dsi::launch_vote_bands(ctx->stream, m->sxy.p, m->coef.p, m->cuts.p, m->nvalid.p + np, (int)np, geom, bp,
                                    direct ? g->data : m->partials.p, m->carry.p));
@@ -392,7 +441,7 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
         HIP_TRY(dsi::launch_reduce_partials(ctx->stream, m->partials.p, bp.chunks, g->n, g->data,
                                             accumulate ? 1 : 0));
     HIP_TRY(dsi::launch_add_carry(ctx->stream, m->carry.p, bp.chunks, geom, bp, g->data));
-    return DSI_OK;
+    return vote_done(m);
 }
 
 bool same_shape(const dsi_grid* a, const dsi_grid* b)
@@ -739,6 +788,7 @@ int dsi_mapper_create(dsi_context_t* ctx, const dsi_mapper_config_t* cfg, dsi_ma
     make_planes(cfg->min_depth, cfg->max_depth, cfg->dim_z, cfg->inverse_depth != 0, &m->planes);
     g.z0 = m->planes[0];  // :111, :163 -- of the full depth vector, also for a plane shard
     m->plane_begin = cfg->plane_begin;
+    if (const char* e = std::getenv("DSI_PREP_OVERLAP")) m->prep_overlap = std::atoi(e) != 0;
     g.nz = cfg->plane_count > 0 ? cfg->plane_count : cfg->dim_z - cfg->plane_begin;
     m->planes = std::vector<float>(m->planes.begin() + m->plane_begin, m->planes.begin() + m->plane_begin + g.nz);
 
@@ -768,6 +818,12 @@ int dsi_mapper_destroy(dsi_mapper_t* m)
     if (!m) return DSI_OK;
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
+    if (m->prep_stream) {
+        (void)hipStreamSynchronize(m->prep_stream);
+        (void)hipStreamDestroy(m->prep_stream);
+        (void)hipEventDestroy(m->ev_prep);
+        (void)hipEventDestroy(m->ev_vote_done);
+    }
     if (m->grid) dsi_grid_destroy(m->grid);
     if (m->planes_dev) (void)hipFree(m->planes_dev);
     if (m->lut_dev) (void)hipFree(m->lut_dev);
@@ -861,7 +917,8 @@ int dsi_mapper_fill_voxel_grid(dsi_mapper_t* m, const float* xy_z0, const float*
     HIP_TRY(m->centers.reserve(n_packets * 3));
     if (int rc = upload_async(ctx, m->xy.p, xy_z0, n_packets * dsi::kPacket * sizeof(float2))) return rc;
     if (int rc = upload_async(ctx, m->centers.p, centers, n_packets * 3 * sizeof(float))) return rc;
-    int rc = vote_device(m, m->xy.p, m->centers.p, n_packets, /*accumulate=*/true);
+    // (host inputs were uploaded on the context's stream: no second stream here)
+    int rc = vote_device(m, m->xy.p, m->centers.p, n_packets, /*accumulate=*/true, ctx->stream);
     // the host buffers are pageable: do not return before the copies have read them
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return rc;
@@ -938,16 +995,18 @@ int dsi_mapper_evaluate_batch(dsi_mapper_t* m, const dsi_batch_t* batch)
     dsi_context* ctx = m->ctx;
     if (int rc = set_device(ctx)) return rc;
     const size_t np = batch->n_packets;
+    hipStream_t ps = ctx->stream;
     if (np) {
         HIP_TRY(m->centers.reserve(np * 3));
         HIP_TRY(m->H.reserve(np * 9));
         HIP_TRY(m->xy.reserve(np * dsi::kPacket));
-        HIP_TRY(dsi::launch_packet_geometry(ctx->stream, batch->Rt, (int)np, m->geom, m->centers.p, m->H.p));
-        HIP_TRY(dsi::launch_warp_z0(ctx->stream, batch->x, batch->y, batch->first, (int)np, m->H.p,
+        if (int rc = prep_begin(m, &ps)) return rc;
+        HIP_TRY(dsi::launch_packet_geometry(ps, batch->Rt, (int)np, m->geom, m->centers.p, m->H.p));
+        HIP_TRY(dsi::launch_warp_z0(ps, batch->x, batch->y, batch->first, (int)np, m->H.p,
                                     m->lut_dev, m->sensor_w, m->xy.p));
     }
     // resetGrid (:145) is folded into the vote: accumulate = false
-    return vote_device(m, m->xy.p, m->centers.p, np, /*accumulate=*/false);
+    return vote_device(m, m->xy.p, m->centers.p, np, /*accumulate=*/false, ps);
 }
 
 int dsi_pose_at(const double* traj_times, const double* traj_poses, size_t n_poses, double t, double* out)
