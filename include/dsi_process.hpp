@@ -1,0 +1,198 @@
+// dsi_process.hpp -- host orchestration of the reference's Alg. 1 / Alg. 2 over the engine, in C++,
+// with the reference's function names and argument order (minus ROS / OpenCV types and the file
+// output):
+//
+//   process_1   mapper_emvs_stereo/src/process1.cpp:28-224   one DSI per camera, camera fusion
+//   process_2   mapper_emvs_stereo/src/process2.cpp:28-302   sub-intervals: camera fusion then
+//                                                            temporal fusion, and the converse order
+//   process_5   mapper_emvs_stereo/src/process5.cpp:28-260   process_2 with the right camera's
+//                                                            sub-intervals circularly shifted
+//
+// Pure call sequencing: which mapper gets which events, where the reference view sits, the fusion
+// order and op codes (1 min, 2 HM, 3 GM, 4 AM, 5 RMS, 6 max), the temporal accumulators
+// (2 harmonic, 4 arithmetic; other codes do nothing, like the reference).  Every voxel operation is
+// an engine kernel behind include/dsi_engine.h.
+#ifndef DSI_PROCESS_HPP
+#define DSI_PROCESS_HPP
+
+#include <vector>
+
+#include "dsi_engine.hpp"
+
+namespace dsi {
+
+// T_a * T_b and T^-1 for (translation, unit quaternion w,x,y,z) -- the two minkindr operations the
+// callers need to place the reference view (process1.cpp:56-68, process2.cpp:79-81)
+inline void quat_rotate(const double* q, const double* v, double* out)
+{
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    const double ux = 2 * (y * v[2] - z * v[1]), uy = 2 * (z * v[0] - x * v[2]), uz = 2 * (x * v[1] - y * v[0]);
+    out[0] = v[0] + w * ux + (y * uz - z * uy);
+    out[1] = v[1] + w * uy + (z * ux - x * uz);
+    out[2] = v[2] + w * uz + (x * uy - y * ux);
+}
+
+inline Transformation operator*(const Transformation& a, const Transformation& b)
+{
+    Transformation o;
+    const double *p = a.q, *r = b.q;
+    o.q[0] = p[0] * r[0] - p[1] * r[1] - p[2] * r[2] - p[3] * r[3];
+    o.q[1] = p[0] * r[1] + p[1] * r[0] + p[2] * r[3] - p[3] * r[2];
+    o.q[2] = p[0] * r[2] + p[2] * r[0] + p[3] * r[1] - p[1] * r[3];
+    o.q[3] = p[0] * r[3] + p[3] * r[0] + p[1] * r[2] - p[2] * r[1];
+    double rt[3];
+    quat_rotate(a.q, b.t, rt);
+    for (int i = 0; i < 3; ++i) o.t[i] = a.t[i] + rt[i];
+    return o;
+}
+
+inline Transformation inverse(const Transformation& T)
+{
+    Transformation o;
+    o.q[0] = T.q[0];
+    o.q[1] = -T.q[1];
+    o.q[2] = -T.q[2];
+    o.q[3] = -T.q[3];
+    double rt[3];
+    quat_rotate(o.q, T.t, rt);
+    for (int i = 0; i < 3; ++i) o.t[i] = -rt[i];
+    return o;
+}
+
+inline void fuseTwoGrids(Grid3D& dst, const Grid3D& g, int method, const char* what)
+{
+    switch (method) {  // process1.cpp:136-158
+    case 1: dst.minTwoGrids(g); break;
+    case 2: dst.harmonicMeanTwoGrids(g); break;
+    case 3: dst.geometricMeanTwoGrids(g); break;
+    case 4: dst.arithmeticMeanTwoGrids(g); break;
+    case 5: dst.rmsTwoGrids(g); break;
+    case 6: dst.maxTwoGrids(g); break;
+    default: throw Error(DSI_ERR_BAD_OP, what);
+    }
+}
+
+}  // namespace dsi
+
+// Alg. 1.  A camera with no events (events2.empty(), the stereo case) is skipped like
+// process1.cpp:105.  rv_pos: position of the reference view along the baseline (process1.cpp:58-66;
+// a flag in the reference).  Returns T_rv_w; the fused DSI is mapper_fused.dsi_.
+inline dsi::Transformation process_1(const LinearTrajectory& trajectory0, const LinearTrajectory& trajectory1,
+                                     const LinearTrajectory& trajectory2, const std::vector<dsi::Event>& events0,
+                                     const std::vector<dsi::Event>& events1, const std::vector<dsi::Event>& events2,
+                                     EMVS::MapperEMVS& mapper_fused, EMVS::MapperEMVS& mapper0,
+                                     EMVS::MapperEMVS& mapper1, EMVS::MapperEMVS& mapper2, double ts,
+                                     int fusion_method, double rv_pos = 0.0)
+{
+    dsi::Transformation T_w_l;
+    if (!trajectory0.getPoseAt(ts, T_w_l)) throw dsi::Error(DSI_ERR_INVALID, "no pose at the reference timestamp");
+    dsi::Transformation baseline;
+    baseline.t[0] = rv_pos;
+    const dsi::Transformation T_rv_w = dsi::inverse(T_w_l * baseline);  // :56-68
+    mapper0.evaluateDSI(events0, trajectory0, T_rv_w);                  // :76
+    mapper1.evaluateDSI(events1, trajectory1, T_rv_w);                  // :94
+    if (!events2.empty()) mapper2.evaluateDSI(events2, trajectory2, T_rv_w);  // :105-117
+    mapper_fused.dsi_.resetGrid();                                      // :126
+    mapper_fused.dsi_.addTwoGrids(mapper0.dsi_);                        // :127
+    dsi::fuseTwoGrids(mapper_fused.dsi_, mapper1.dsi_, fusion_method, "Improper fusion method selected");
+    if (!events2.empty()) {                                             // :169-191
+        if (fusion_method == 1) mapper_fused.dsi_.minTwoGrids(mapper2.dsi_);
+        else if (fusion_method == 2) mapper_fused.dsi_.harmonicMeanTwoGrids(mapper2.dsi_, 3);
+        else if (fusion_method == 6) mapper_fused.dsi_.maxTwoGrids(mapper2.dsi_);
+        // 3, 4, 5: the reference silently ignores the third camera
+    }
+    return T_rv_w;
+}
+
+struct Process2Result {
+    dsi::Transformation T_rv_w;
+    Grid3D left, right;  // temporal fusion of the left / right camera's sub-interval DSIs
+};
+
+// Alg. 2 (shuffle_right = false) and process_5 (true).
+inline Process2Result process_2(dsi::Context& ctx, const dsi::PinholeCameraModel& cam0,
+                                const dsi::PinholeCameraModel& cam1, const LinearTrajectory& trajectory0,
+                                const LinearTrajectory& trajectory1, const std::vector<dsi::Event>& events0,
+                                const std::vector<dsi::Event>& events1, const EMVS::ShapeDSI& dsi_shape,
+                                const int num_subintervals, EMVS::MapperEMVS& mapper_fused,
+                                EMVS::MapperEMVS& mapper_fused_camera_time, double ts, int stereo_fusion,
+                                int temporal_fusion, bool shuffle_right = false)
+{
+    EMVS::MapperEMVS mapper0(ctx, cam0, dsi_shape), mapper1(ctx, cam1, dsi_shape);
+    int nx, ny, nz;
+    mapper0.dsi_.getDimensions(&nx, &ny, &nz);
+    Grid3D sub(ctx, nx, ny, nz);  // mapper_fused_subinterval.dsi_
+    Process2Result out;
+    out.left.allocate(ctx, nx, ny, nz);
+    out.right.allocate(ctx, nx, ny, nz);
+    dsi::Transformation T_w_l;
+    if (!trajectory0.getPoseAt(ts, T_w_l)) throw dsi::Error(DSI_ERR_INVALID, "no pose at the reference timestamp");
+    out.T_rv_w = dsi::inverse(T_w_l);  // process2.cpp:79-81
+    const size_t per0 = events0.size() / (size_t)num_subintervals;  // :46-47, integer division
+    const size_t per1 = events1.size() / (size_t)num_subintervals;
+    mapper_fused.dsi_.resetGrid();  // :90
+    size_t idx1 = shuffle_right ? (size_t)(num_subintervals / 2) * per1 : 0;  // process5.cpp:89-93
+    for (int k = 0; k < num_subintervals; ++k) {
+        const std::vector<dsi::Event> ev0(events0.begin() + (long)(k * per0), events0.begin() + (long)((k + 1) * per0));
+        std::vector<dsi::Event> ev1;
+        if (!shuffle_right) {
+            ev1.assign(events1.begin() + (long)(k * per1), events1.begin() + (long)((k + 1) * per1));  // :132-134
+        } else if (idx1 + per1 >= events1.size()) {  // process5.cpp:136-150: tail, then the head
+            ev1.assign(events1.begin() + (long)idx1, events1.end());
+            const size_t rest = idx1 + per1 - events1.size();
+            ev1.insert(ev1.end(), events1.begin(), events1.begin() + (long)rest);
+            idx1 = rest;
+        } else {
+            ev1.assign(events1.begin() + (long)idx1, events1.begin() + (long)(idx1 + per1));
+            idx1 += per1;
+        }
+        mapper0.dsi_.resetGrid();
+        mapper0.evaluateDSI(ev0, trajectory0, out.T_rv_w);  // :119
+        mapper1.dsi_.resetGrid();
+        mapper1.evaluateDSI(ev1, trajectory1, out.T_rv_w);  // :146
+        sub.resetGrid();                                    // :159
+        sub.addTwoGrids(mapper0.dsi_);                      // :160
+        dsi::fuseTwoGrids(sub, mapper1.dsi_, stereo_fusion, "Improper stereo fusion method selected");  // :168-189
+        if (temporal_fusion == 2) {  // :216-226
+            out.left.addInverseOfTwoGrids(mapper0.dsi_);
+            out.right.addInverseOfTwoGrids(mapper1.dsi_);
+            mapper_fused.dsi_.addInverseOfTwoGrids(sub);
+            if (k == num_subintervals - 1) {
+                out.left.computeHMfromSumOfInv(num_subintervals);
+                out.right.computeHMfromSumOfInv(num_subintervals);
+                mapper_fused.dsi_.computeHMfromSumOfInv(num_subintervals);
+            }
+        } else if (temporal_fusion == 4) {  // :229-239
+            out.left.addTwoGrids(mapper0.dsi_);
+            out.right.addTwoGrids(mapper1.dsi_);
+            mapper_fused.dsi_.addTwoGrids(sub);
+            if (k == num_subintervals - 1) {
+                out.left.computeAMfromSum(num_subintervals);
+                out.right.computeAMfromSum(num_subintervals);
+                mapper_fused.dsi_.computeAMfromSum(num_subintervals);
+            }
+        }  // 1, 3, 5, 6: nothing happens (:213, :227, :240-243)
+    }
+    // converse order: time first, cameras second (:266-289).  The reference swaps cases 3 and 4
+    // here (3 -> arithmetic, 4 -> geometric, process2.cpp:274-279); kept as is.
+    mapper_fused_camera_time.dsi_.addTwoGrids(out.left);  // :266
+    static const int converse[7] = {0, 1, 2, 4, 3, 5, 6};
+    if (stereo_fusion < 1 || stereo_fusion > 6) throw dsi::Error(DSI_ERR_BAD_OP, "Improper stereo fusion method selected");
+    dsi::fuseTwoGrids(mapper_fused_camera_time.dsi_, out.right, converse[stereo_fusion],
+                      "Improper stereo fusion method selected");
+    return out;
+}
+
+inline Process2Result process_5(dsi::Context& ctx, const dsi::PinholeCameraModel& cam0,
+                                const dsi::PinholeCameraModel& cam1, const LinearTrajectory& trajectory0,
+                                const LinearTrajectory& trajectory1, const std::vector<dsi::Event>& events0,
+                                const std::vector<dsi::Event>& events1, const EMVS::ShapeDSI& dsi_shape,
+                                const int num_subintervals, EMVS::MapperEMVS& mapper_fused,
+                                EMVS::MapperEMVS& mapper_fused_camera_time, double ts, int stereo_fusion,
+                                int temporal_fusion)
+{
+    return process_2(ctx, cam0, cam1, trajectory0, trajectory1, events0, events1, dsi_shape, num_subintervals,
+                     mapper_fused, mapper_fused_camera_time, ts, stereo_fusion, temporal_fusion, true);
+}
+
+#endif

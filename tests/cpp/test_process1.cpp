@@ -1,4 +1,5 @@
-// C++ drop-in test: the reference's process_1 flow (process1.cpp:54-222) written against
+// C++ drop-in test: the reference's process_1 flow (process1.cpp:54-222) and, through
+// include/dsi_process.hpp, process_1 / process_2 / process_5 as functions, written against
 // include/dsi_engine.hpp, i.e. with the reference's own class and method names, checked
 // against the CPU oracle (oracle/dsi_oracle.h).  Built and run by tests/test_cpp_adapter.py.
 //
@@ -10,6 +11,7 @@
 
 #include "dsi_engine.hpp"
 #include "dsi_oracle.h"
+#include "dsi_process.hpp"
 
 namespace {
 
@@ -214,7 +216,76 @@ int main()
         } catch (const dsi::Error& e) {
             if (e.code != DSI_ERR_SHAPE) return 51;
         }
-        std::printf("process_1 flow through the C++ adapter: OK\n");
+        // ---- process_1 / process_2 / process_5 as functions (include/dsi_process.hpp) against the
+        //      same orchestration done with the oracle
+        {
+            EMVS::MapperEMVS mapper2(ctx, cam, dsi_shape);
+            const std::vector<dsi::Event> none;
+            const dsi::Transformation T1 = process_1(trajectory0, trajectory1, trajectory1, events0, events1, none,
+                                                     mapper_fused, mapper0, mapper1, mapper2, 0.5, 3);
+            if (std::fabs(T1.t[0] - T_rv_w.t[0]) > 1e-12) return 60;
+            std::vector<float> a = ref0;
+            orc_fuse2(a.data(), ref1.data(), a.size(), 3);
+            if (max_rel_err(mapper_fused.dsi_.download(), a) > 3e-4) return 61;
+            try {
+                process_1(trajectory0, trajectory1, trajectory1, events0, events1, none, mapper_fused, mapper0,
+                          mapper1, mapper2, 0.5, 9);
+                return 62;
+            } catch (const dsi::Error& e) {
+                if (e.code != DSI_ERR_BAD_OP) return 63;
+            }
+        }
+        for (int variant = 0; variant < 2; ++variant) {
+            const bool shuffle = variant == 1;
+            const int n_sub = 3, stereo = shuffle ? 3 : 2, temporal = shuffle ? 4 : 2;
+            EMVS::MapperEMVS fused_ct(ctx, cam, dsi_shape);
+            fused_ct.dsi_.resetGrid();
+            Process2Result r = shuffle ? process_5(ctx, cam, cam, trajectory0, trajectory1, events0, events1, dsi_shape,
+                                                   n_sub, mapper_fused, fused_ct, 0.5, stereo, temporal)
+                                       : process_2(ctx, cam, cam, trajectory0, trajectory1, events0, events1, dsi_shape,
+                                                   n_sub, mapper_fused, fused_ct, 0.5, stereo, temporal);
+            // oracle orchestration (process2.cpp:98-289, process5.cpp:89-150)
+            const size_t n = ref0.size();
+            std::vector<float> oleft(n, 0.f), oright(n, 0.f), ofused(n, 0.f);
+            const size_t per0 = events0.size() / n_sub, per1 = events1.size() / n_sub;
+            size_t idx1 = shuffle ? (size_t)(n_sub / 2) * per1 : 0;
+            const int mode = temporal == 2 ? 1 : 0;
+            for (int k = 0; k < n_sub; ++k) {
+                const std::vector<dsi::Event> e0(events0.begin() + k * per0, events0.begin() + (k + 1) * per0);
+                std::vector<dsi::Event> e1;
+                if (!shuffle) {
+                    e1.assign(events1.begin() + k * per1, events1.begin() + (k + 1) * per1);
+                } else if (idx1 + per1 >= events1.size()) {
+                    e1.assign(events1.begin() + idx1, events1.end());
+                    const size_t rest = idx1 + per1 - events1.size();
+                    e1.insert(e1.end(), events1.begin(), events1.begin() + rest);
+                    idx1 = rest;
+                } else {
+                    e1.assign(events1.begin() + idx1, events1.begin() + idx1 + per1);
+                    idx1 += per1;
+                }
+                const std::vector<float> d0 = oracle_dsi(e0, trajectory0, r.T_rv_w, cam, dsi_shape, &planes);
+                const std::vector<float> d1 = oracle_dsi(e1, trajectory1, r.T_rv_w, cam, dsi_shape, &planes);
+                std::vector<float> sub = d0;
+                orc_fuse2(sub.data(), d1.data(), n, stereo);
+                orc_accumulate(oleft.data(), d0.data(), n, mode);
+                orc_accumulate(oright.data(), d1.data(), n, mode);
+                orc_accumulate(ofused.data(), sub.data(), n, mode);
+            }
+            orc_finalize(oleft.data(), n, mode, n_sub);
+            orc_finalize(oright.data(), n, mode, n_sub);
+            orc_finalize(ofused.data(), n, mode, n_sub);
+            std::vector<float> oct = oleft;
+            static const int converse[7] = {0, 1, 2, 4, 3, 5, 6};
+            orc_fuse2(oct.data(), oright.data(), n, converse[stereo]);
+            const double el = max_rel_err(r.left.download(), oleft), er = max_rel_err(r.right.download(), oright);
+            const double ef = max_rel_err(mapper_fused.dsi_.download(), ofused);
+            const double ec = max_rel_err(fused_ct.dsi_.download(), oct);
+            std::printf("%s: left %.3g right %.3g fused %.3g camera-time %.3g\n", shuffle ? "process_5" : "process_2",
+                        el, er, ef, ec);
+            if (el > 3e-4 || er > 3e-4 || ef > 1e-3 || ec > 1e-3) return 70 + variant;
+        }
+        std::printf("process_1 / process_2 / process_5 through the C++ adapter: OK\n");
         return 0;
     } catch (const dsi::Error& e) {
         std::printf("dsi::Error %d: %s\n", e.code, e.what());

@@ -1,6 +1,6 @@
 """The C++ adapter (include/dsi_engine.hpp: Grid3D / EMVS::MapperEMVS / LinearTrajectory with
-the reference's method names) compiles against the C ABI, and a process_1-shaped C++
-program built on it matches the oracle on the GPU."""
+the reference's method names; include/dsi_process.hpp: process_1 / process_2 / process_5) compiles
+against the C ABI, and a C++ program built on it matches the oracle on the GPU."""
 import os
 import subprocess
 
@@ -14,7 +14,8 @@ EXE = os.path.join(ROOT, "tests", "cpp", "test_process1")
 
 def build_exe():
     src = os.path.join(ROOT, "tests", "cpp", "test_process1.cpp")
-    deps = [src, os.path.join(ROOT, "include", "dsi_engine.hpp"), os.path.join(ROOT, "include", "dsi_engine.h")]
+    deps = [src, os.path.join(ROOT, "include", "dsi_engine.hpp"), os.path.join(ROOT, "include", "dsi_engine.h"),
+            os.path.join(ROOT, "include", "dsi_process.hpp")]
     if os.path.exists(EXE) and all(os.path.getmtime(EXE) > os.path.getmtime(p) for p in deps):
         return
     pkg = os.path.join(ROOT, "dvs_mcemvs_amd")
