@@ -194,7 +194,7 @@ def main():
 
     # ---- host-buffer (PCIe-inclusive) rate, reported beside `value`, never as it: upload the raw
     # events + poses of camera 0 from pageable host memory, evaluate, wait
-    h2d_rate = None
+    h2d_rate = h2d_stereo_rate = None
     if rank == 0:
         ev0 = rig["events"][0]
         first0, Rt0 = d.packetize(ev0[2], rig["trajectories"][0], rig["T_rv_w"])
@@ -207,6 +207,25 @@ def main():
             best = min(best, time.perf_counter() - t1)
             bt.close()
         h2d_rate = first0.shape[0] * d.PACKET_SIZE / best / 1e6
+        # the whole stereo step from host memory: camera 1's upload overlaps camera 0's voting
+        # (evaluate returns as soon as its host buffers are consumed), then fusion + arg-max
+        pk = [d.packetize(rig["events"][c][2], rig["trajectories"][c], rig["T_rv_w"]) for c in range(2)]
+        best2 = float("inf")
+        for _ in range(3):
+            t1 = time.perf_counter()
+            bts = []
+            for c in range(2):
+                bts.append(d.EventBatch(cam_ctx[c], rig["events"][c][0], rig["events"][c][1], pk[c][1], pk[c][0]))
+                mappers[c].evaluateDSI_batch(bts[-1])
+            if ctx_cam1 is not ctx:
+                ctx.wait_for(ctx_cam1)
+            fused.setToFusionOf(mappers[0].dsi_, mappers[1].dsi_, d.FUSE_HM)
+            mappers[0].computeDepthMap(fused)
+            ctx.synchronize()
+            best2 = min(best2, time.perf_counter() - t1)
+            for b in bts:
+                b.close()
+        h2d_stereo_rate = sum(p_[0].shape[0] for p_ in pk) * d.PACKET_SIZE / best2 / 1e6
 
     info = mappers[0].last_vote_info()
     ms_per_step = 1e3 * elapsed / args.steps
@@ -288,7 +307,7 @@ def main():
             "dsi_fuse_GBps": fuse_gbps, "dsi_fuse_ms": fuse_ms, "dsi_fuse_frac_of_hbm_peak": fuse_gbps / HBM_PEAK_GBPS,
             "argmax_GBps": argmax_gbps, "argmax_ms": argmax_ms,
             "gpu_ms_per_step_hip_events": gpu_ms / args.steps,
-            "h2d_inclusive_Mevents_per_s": h2d_rate,
+            "h2d_inclusive_Mevents_per_s": h2d_rate, "h2d_inclusive_stereo_step_Mevents_per_s": h2d_stereo_rate,
             "roofline": roofline, "lds_atomics": lds_atomics, "cpu_baseline": cpu, "input_gen_s": t_gen,
         }
     for o in mappers + batches + [fused]:

@@ -87,40 +87,53 @@ struct dsi_context {
     hipEvent_t t0 = nullptr, t1 = nullptr;
     hipEvent_t sync_ev = nullptr;  // dsi_context_wait_for: "everything queued on this stream so far"
     double* ms_accum = nullptr;    // device scalar for mean-square
+    // Event batches are uploaded on their own stream so that the upload of the next batch (camera,
+    // window) overlaps the voting of the current one; "ready" / "freed" events order the two streams.
+    hipStream_t copy_stream = nullptr;
     // Released event-batch blocks, reused by the next dsi_batch_create on this context: a stream of
-    // windows then costs no hipMalloc / hipFree (hipFree synchronises the device).  Reuse is safe
-    // without waiting: everything that used the block was queued on this context's stream before.
-    std::vector<std::pair<void*, size_t>> batch_pool;
+    // windows then costs no hipMalloc / hipFree (hipFree synchronises the device).
+    struct PoolBlock {
+        void* p;
+        size_t bytes;
+        hipEvent_t freed;  // recorded on `stream` when the batch was released: its last reader is done
+    };
+    std::vector<PoolBlock> batch_pool;
 };
 
-void* pool_take(dsi_context* ctx, size_t bytes, size_t* got)
+bool pool_take(dsi_context* ctx, size_t bytes, dsi_context::PoolBlock* out)
 {
     size_t best = (size_t)-1;
     for (size_t i = 0; i < ctx->batch_pool.size(); ++i) {
-        const size_t sz = ctx->batch_pool[i].second;
-        if (sz >= bytes && sz <= 4 * bytes + 65536 &&
-            (best == (size_t)-1 || sz < ctx->batch_pool[best].second))
+        const size_t sz = ctx->batch_pool[i].bytes;
+        if (sz >= bytes && sz <= 4 * bytes + 65536 && (best == (size_t)-1 || sz < ctx->batch_pool[best].bytes))
             best = i;
     }
     if (best != (size_t)-1) {
-        void* p = ctx->batch_pool[best].first;
-        *got = ctx->batch_pool[best].second;
+        *out = ctx->batch_pool[best];
         ctx->batch_pool.erase(ctx->batch_pool.begin() + (long)best);
-        return p;
+        return true;
     }
-    void* p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
-    *got = bytes;
-    return p;
+    out->p = nullptr;
+    out->bytes = bytes;
+    out->freed = nullptr;
+    if (hipMalloc(&out->p, bytes) != hipSuccess) return false;
+    if (hipEventCreateWithFlags(&out->freed, hipEventDisableTiming) != hipSuccess) {
+        (void)hipFree(out->p);
+        return false;
+    }
+    (void)hipEventRecord(out->freed, ctx->stream);
+    return true;
 }
 
-void pool_give(dsi_context* ctx, void* p, size_t bytes)
+void pool_give(dsi_context* ctx, const dsi_context::PoolBlock& blk)
 {
-    if (!p) return;
-    ctx->batch_pool.emplace_back(p, bytes);
+    if (!blk.p) return;
+    (void)hipEventRecord(blk.freed, ctx->stream);  // everything that read the block was queued before
+    ctx->batch_pool.push_back(blk);
     if (ctx->batch_pool.size() > 8) {  // keep a handful; drop the oldest
         (void)hipStreamSynchronize(ctx->stream);
-        (void)hipFree(ctx->batch_pool.front().first);
+        (void)hipFree(ctx->batch_pool.front().p);
+        (void)hipEventDestroy(ctx->batch_pool.front().freed);
         ctx->batch_pool.erase(ctx->batch_pool.begin());
     }
 }
@@ -135,8 +148,8 @@ struct dsi_grid {
 
 struct dsi_batch {
     dsi_context* ctx = nullptr;
-    void* block = nullptr;  // one device allocation holding the four arrays below
-    size_t block_bytes = 0;
+    dsi_context::PoolBlock block{nullptr, 0, nullptr};  // one device allocation holding the four arrays below
+    hipEvent_t ready = nullptr;  // recorded on the copy stream after the upload
     uint16_t *x = nullptr, *y = nullptr;
     uint32_t* first = nullptr;
     float* Rt = nullptr;
@@ -483,6 +496,7 @@ int dsi_context_create(int device_id, dsi_context_t** out)
     REQUIRE(ctx, DSI_ERR_INVALID, "out of host memory");
     ctx->device = device_id;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&ctx->t0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->t1);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->ms_accum), sizeof(double));
@@ -499,7 +513,12 @@ int dsi_context_destroy(dsi_context_t* ctx)
     if (!ctx) return DSI_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (auto& blk : ctx->batch_pool) (void)hipFree(blk.first);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    for (auto& blk : ctx->batch_pool) {
+        (void)hipFree(blk.p);
+        (void)hipEventDestroy(blk.freed);
+    }
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->ms_accum) (void)hipFree(ctx->ms_accum);
     if (ctx->t0) (void)hipEventDestroy(ctx->t0);
     if (ctx->t1) (void)hipEventDestroy(ctx->t1);
@@ -949,26 +968,30 @@ int dsi_batch_create(dsi_context_t* ctx, const uint16_t* x, const uint16_t* y, s
     const size_t rt_bytes = up(std::max<size_t>(n_packets, 1) * 12 * sizeof(float));
     const size_t first_bytes = packet_first ? up(std::max<size_t>(n_packets, 1) * sizeof(uint32_t)) : 0;
     const size_t ev_bytes = up(std::max<size_t>(n_events, 1) * sizeof(uint16_t));
-    b->block = pool_take(ctx, rt_bytes + first_bytes + 2 * ev_bytes, &b->block_bytes);
-    if (!b->block) {
+    if (!pool_take(ctx, rt_bytes + first_bytes + 2 * ev_bytes, &b->block)) {
         delete b;
         return fail(DSI_ERR_HIP, "batch allocation of %zu bytes failed", rt_bytes + first_bytes + 2 * ev_bytes);
     }
-    char* base = static_cast<char*>(b->block);
+    char* base = static_cast<char*>(b->block.p);
     b->Rt = reinterpret_cast<float*>(base);
     b->first = packet_first ? reinterpret_cast<uint32_t*>(base + rt_bytes) : nullptr;
     b->x = reinterpret_cast<uint16_t*>(base + rt_bytes + first_bytes);
     b->y = reinterpret_cast<uint16_t*>(base + rt_bytes + first_bytes + ev_bytes);
-    hipError_t e = hipSuccess;
-    if (n_events) e = hipMemcpyAsync(b->x, x, n_events * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream);
+    hipStream_t cs = ctx->copy_stream;
+    hipError_t e = hipEventCreateWithFlags(&b->ready, hipEventDisableTiming);
+    // the block's previous reader (a kernel on the compute stream) must be done before we overwrite it
+    if (e == hipSuccess) e = hipStreamWaitEvent(cs, b->block.freed, 0);
+    if (e == hipSuccess && n_events) e = hipMemcpyAsync(b->x, x, n_events * sizeof(uint16_t), hipMemcpyHostToDevice, cs);
     if (e == hipSuccess && n_events)
-        e = hipMemcpyAsync(b->y, y, n_events * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream);
+        e = hipMemcpyAsync(b->y, y, n_events * sizeof(uint16_t), hipMemcpyHostToDevice, cs);
     if (e == hipSuccess && n_packets)
-        e = hipMemcpyAsync(b->Rt, Rt, n_packets * 12 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+        e = hipMemcpyAsync(b->Rt, Rt, n_packets * 12 * sizeof(float), hipMemcpyHostToDevice, cs);
     if (e == hipSuccess && n_packets && packet_first)
-        e = hipMemcpyAsync(b->first, packet_first, n_packets * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
-    // the host arrays are the caller's: they must be consumed before this call returns
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        e = hipMemcpyAsync(b->first, packet_first, n_packets * sizeof(uint32_t), hipMemcpyHostToDevice, cs);
+    if (e == hipSuccess) e = hipEventRecord(b->ready, cs);
+    // the host arrays are the caller's: they must be consumed before this call returns (this waits
+    // for the copies only, not for whatever the compute stream is doing)
+    if (e == hipSuccess) e = hipStreamSynchronize(cs);
     if (e != hipSuccess) {
         dsi_batch_destroy(b);
         return fail(DSI_ERR_HIP, "batch upload failed: %s", hipGetErrorString(e));
@@ -981,7 +1004,8 @@ int dsi_batch_destroy(dsi_batch_t* b)
 {
     if (!b) return DSI_OK;
     (void)hipSetDevice(b->ctx->device);
-    pool_give(b->ctx, b->block, b->block_bytes);  // no wait: reuse is ordered by the context's stream
+    pool_give(b->ctx, b->block);  // no wait: the block's "freed" event orders its reuse
+    if (b->ready) (void)hipEventDestroy(b->ready);
     delete b;
     return DSI_OK;
 }
@@ -1001,6 +1025,7 @@ int dsi_mapper_evaluate_batch(dsi_mapper_t* m, const dsi_batch_t* batch)
         HIP_TRY(m->H.reserve(np * 9));
         HIP_TRY(m->xy.reserve(np * dsi::kPacket));
         if (int rc = prep_begin(m, &ps)) return rc;
+        if (batch->ready) HIP_TRY(hipStreamWaitEvent(ps, batch->ready, 0));  // uploaded on the copy stream
         HIP_TRY(dsi::launch_packet_geometry(ps, batch->Rt, (int)np, m->geom, m->centers.p, m->H.p));
         HIP_TRY(dsi::launch_warp_z0(ps, batch->x, batch->y, batch->first, (int)np, m->H.p,
                                     m->lut_dev, m->sensor_w, m->xy.p));
