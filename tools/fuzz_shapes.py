@@ -1,0 +1,43 @@
+"""One-off robustness fuzz of the voting paths on odd shapes (tiny and very wide / tall grids, single
+planes, single packets): every lane mapping against the oracle and against its compiled twin."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import dvs_mcemvs_amd as d
+from oracle import oracle as orc
+import test_gpu_parity as t
+
+ctx = d.Context(0)
+rng = np.random.default_rng(77)
+shapes = [(2, 2, 1), (2, 9, 3), (9, 2, 3), (3, 3, 256), (5000, 3, 2), (6800, 2, 1), (3, 4000, 2), (17, 16000, 1),
+          (1024, 64, 4), (640, 480, 3), (31, 33, 37)]
+bad = 0
+for (nx, ny, nz) in shapes:
+    for n_packets in (1, 3, 40):
+        cam = (nx, ny, 0.9 * max(nx, 4), 0.9 * max(nx, 4), 0.5 * nx, 0.5 * ny)
+        xy, centers = t.random_packets(rng, n_packets, nx, ny)
+        ref = {}
+        for packed in (3, 1, 0, 2, 4):
+            m = t.make_mapper(ctx, cam, nz, 1.0, 6.0, d.VOTE_LDS_BANDS, packed=packed)
+            os.environ["DSI_GROUP_PACKETS"] = "4"
+            try:
+                m.fillVoxelGrid(xy, centers)
+            finally:
+                del os.environ["DSI_GROUP_PACKETS"]
+            got = m.dsi_.download()
+            fam = 0 if packed in (3, 1, 0) else 1
+            if fam not in ref:
+                ref[fam] = got
+                o = orc.fill_voxel_grid(xy, centers, m.raw_depths_vec_, np.array(m.virtual_cam_, np.float32), nx, ny)
+                err = np.abs(got.astype(np.float64) - o) / np.maximum(1.0, np.abs(o))
+                if err.max() > 1e-4:
+                    bad += 1
+                    print("ORACLE MISMATCH", (nx, ny, nz), n_packets, packed, err.max())
+            elif not np.array_equal(got, ref[fam]):
+                bad += 1
+                print("TWIN MISMATCH", (nx, ny, nz), n_packets, packed)
+            info = m.last_vote_info()
+            m.close()
+    print((nx, ny, nz), "ok", info["bands"], info["band_rows"], info["chunks"])
+print("failures:", bad)
