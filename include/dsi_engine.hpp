@@ -18,6 +18,7 @@
 #pragma once
 
 #include <cstdint>
+#include <cstdio>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -210,6 +211,29 @@ public:
         return v;
     }
     void upload(const std::vector<float>& v) { dsi::check(dsi_grid_upload(h_, v.data())); }
+
+    // Grid3D::writeGridNpy (cartesian3dgrid_IO.cpp:30-36): NumPy .npy v1.0, little-endian float32,
+    // C order, shape (dimZ, dimY, dimX) -- what scripts/visualize_dsi_*.py load.  Returns 0 on success.
+    int writeGridNpy(const char* filename) const
+    {
+        int nx, ny, nz;
+        getDimensions(&nx, &ny, &nz);
+        const std::vector<float> v = download();
+        std::string dict = "{'descr': '<f4', 'fortran_order': False, 'shape': (" + std::to_string(nz) + ", " +
+                           std::to_string(ny) + ", " + std::to_string(nx) + "), }";
+        while ((10 + dict.size() + 1) % 64 != 0) dict += ' ';  // header padded to a multiple of 64 bytes
+        dict += '\n';
+        std::FILE* f = std::fopen(filename, "wb");
+        if (!f) return 1;
+        const unsigned char magic[8] = {0x93, 'N', 'U', 'M', 'P', 'Y', 1, 0};
+        const unsigned short hl = (unsigned short)dict.size();
+        const unsigned char hlen[2] = {(unsigned char)(hl & 0xff), (unsigned char)(hl >> 8)};
+        bool ok = std::fwrite(magic, 1, 8, f) == 8 && std::fwrite(hlen, 1, 2, f) == 2 &&
+                  std::fwrite(dict.data(), 1, dict.size(), f) == dict.size() &&
+                  std::fwrite(v.data(), sizeof(float), v.size(), f) == v.size();
+        ok = (std::fclose(f) == 0) && ok;
+        return ok ? 0 : 1;
+    }
 
 private:
     dsi_grid_t* h_ = nullptr;

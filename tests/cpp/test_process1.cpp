@@ -285,6 +285,12 @@ int main()
                         el, er, ef, ec);
             if (el > 3e-4 || er > 3e-4 || ef > 1e-3 || ec > 1e-3) return 70 + variant;
         }
+        if (const char* out = std::getenv("DSI_TEST_NPY")) {  // for tests/test_cpp_adapter.py
+            if (mapper_fused.dsi_.writeGridNpy(out) != 0) return 80;
+            double sum = 0;
+            for (float v : mapper_fused.dsi_.download()) sum += v;
+            std::printf("npy sum %.9e\n", sum);
+        }
         std::printf("process_1 / process_2 / process_5 through the C++ adapter: OK\n");
         return 0;
     } catch (const dsi::Error& e) {

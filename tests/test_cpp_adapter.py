@@ -36,8 +36,16 @@ def test_adapter_compiles_and_fails_loudly_without_gpu(built):
 
 
 @pytest.mark.gpu
-def test_process1_flow_in_cpp(built):
+def test_process1_flow_in_cpp(built, tmp_path):
+    import re
+    import numpy as np
     build_exe()
-    r = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
+    npy = tmp_path / "fused.npy"
+    r = subprocess.run([EXE], capture_output=True, text=True, timeout=300, env=dict(os.environ, DSI_TEST_NPY=str(npy)))
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK" in r.stdout
+    # Grid3D::writeGridNpy of the adapter: numpy reads it back as float32 [Z][Y][X]
+    vol = np.load(npy)
+    assert vol.dtype == np.float32 and vol.shape == (24, 60, 80) and vol.flags["C_CONTIGUOUS"]
+    want = float(re.search(r"npy sum (\S+)", r.stdout).group(1))
+    assert float(vol.sum(dtype=np.float64)) == pytest.approx(want, rel=1e-6)
