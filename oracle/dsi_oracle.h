@@ -135,6 +135,8 @@ void orc_depth_map_filters(float *conf, const uint8_t *idx, int nx, int ny, int 
                            uint8_t *conf8, uint8_t *mask, uint8_t *idx_filtered, float *depth);
 
 int orc_num_threads(void);
+/* bench.py's single-thread baseline: OpenMP threads used by the calls that follow */
+void orc_set_num_threads(int n);
 
 #ifdef __cplusplus
 }

@@ -56,6 +56,8 @@ def lib():
         L.orc_depth_map_filters.argtypes = [f32p, u8p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
                                             C.c_double, f32p, u8p, u8p, u8p, f32p]
         L.orc_num_threads.restype = C.c_int
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        L.orc_set_num_threads.restype = None
         _LIB = L
     return _LIB
 
@@ -221,6 +223,10 @@ def event_pose_Rt(T_rv_w, T_w_ev):
 
 def num_threads():
     return lib().orc_num_threads()
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))
 
 
 def depth_map_filters(conf, idx, raw_depths, ksize=5, C_=5.0, median_size=5, max_confidence=0.0):
