@@ -898,20 +898,16 @@ __device__ __forceinline__ void packed_stream(const EvRec* __restrict__ sxy,
     "v_fma_f32 v61, v63, " KR ", v61\n\t" /* Y */                                                   \
     "v_cvt_flr_i32_f32 v58, v60\n\t"      /* xi */                                                  \
     "v_cvt_flr_i32_f32 v59, v61\n\t"      /* yi */                                                  \
-    "v_sub_u32 v62, %11, v58\n\t"         /* nx-2-xi */                                             \
     "v_subrev_u32 v63, %12, v59\n\t"      /* yi-Li */                                               \
-    "v_sub_u32 v36, %13, v59\n\t"         /* Ui-1-yi */                                             \
-    "v_or3_b32 v62, v62, v63, v36\n\t"                                                              \
-    "v_or_b32 v62, v62, v58\n\t"                                                                    \
-    "v_cmpx_lt_i32 vcc, -1, v62\n\t"      /* exec = lanes whose four values are all >= 0 */         \
+    "v_cmpx_ge_u32 vcc, %11, v58\n\t"     /* exec &= 0 <= xi <= nx-2       (unsigned compare) */    \
+    "v_cmpx_ge_u32 vcc, %13, v63\n\t"     /* exec &= 0 <= yi-Li <= Ui-1-Li (unsigned compare) */    \
     "v_fract_f32 v60, v60\n\t"            /* fx (X >= 0 here) */                                    \
     "v_fract_f32 v61, v61\n\t"            /* fy */                                                  \
     "v_lshl_add_u32 v58, v58, 3, %10\n\t"                                                           \
     "v_mad_i32_i24 v59, v59, %9, v58\n\t" /* LDS byte address of voxel (xi, yi) */                  \
-    "v_sub_f32 v62, 1.0, v60\n\t"         /* 1-fx */                                                \
     "v_sub_f32 v63, 1.0, v61\n\t"         /* 1-fy */                                                \
     "v_mul_f32 v60, 0x4f000000, v60\n\t"  /* fx * 2^31 */                                           \
-    "v_mul_f32 v62, 0x4f000000, v62\n\t"  /* (1-fx) * 2^31 */                                       \
+    "v_sub_f32 v62, 0x4f000000, v60\n\t"  /* 2^31 - fx*2^31 == fl(1-fx) * 2^31 (power-of-two scale) */ \
     "v_mul_f32 v36, v62, v63\n\t"                                                                   \
     "v_mul_f32 v37, v60, v63\n\t"                                                                   \
     "v_mul_f32 v38, v62, v61\n\t"                                                                   \
@@ -944,6 +940,7 @@ __device__ __forceinline__ void packed_stream_asm(const EvRec* sxy, const uint4*
         const int last = p_first + (passes - 1) * stride;
         n_my = (passes - 1) * group + min(group, p_end - last);
     }
+    if (Ui - 1 < Li) n_my = 0;  // no acceptable row (the unsigned range test needs Ui-1-Li >= 0)
     // every operand is wave-uniform; the readfirstlanes pin them to scalar registers
     const int s_n_my = __builtin_amdgcn_readfirstlane(n_my);
     const int s_gmask = __builtin_amdgcn_readfirstlane(group - 1);
@@ -956,7 +953,8 @@ __device__ __forceinline__ void packed_stream_asm(const EvRec* sxy, const uint4*
     const int s_cbase = __builtin_amdgcn_readfirstlane(lds_base - row_base * nx * 8);
     const int s_nxm2 = __builtin_amdgcn_readfirstlane(nx - 2);
     const int s_Li = __builtin_amdgcn_readfirstlane(Li);
-    const int s_Uim1 = __builtin_amdgcn_readfirstlane(Ui - 1);
+    // rows the band accepts: 0 <= yi - Li <= Ui - 1 - Li  (a band with no acceptable row gets no stream)
+    const int s_Uim1 = __builtin_amdgcn_readfirstlane(Ui - 1 - Li);
     const uint32_t s_dummy = __builtin_amdgcn_readfirstlane(dummy_eo);
     asm volatile(
         "s_mov_b32 s42, -1\n\t"
@@ -1096,6 +1094,7 @@ __device__ __forceinline__ void group_stream_asm(const EvRec* sxy, const uint4* 
         const int last = g_first + (passes - 1) * stride;
         n_my = (passes - 1) * pass + min(pass, g_end - last);
     }
+    if (Ui - 1 < Li) n_my = 0;  // no acceptable row (the unsigned range test needs Ui-1-Li >= 0)
     const int s_n_my = __builtin_amdgcn_readfirstlane(n_my);
     const int s_gmask = __builtin_amdgcn_readfirstlane(pass - 1);
     const int s_g_first = __builtin_amdgcn_readfirstlane(g_first);
@@ -1107,7 +1106,8 @@ __device__ __forceinline__ void group_stream_asm(const EvRec* sxy, const uint4* 
     const int s_cbase = __builtin_amdgcn_readfirstlane(lds_base - row_base * nx * 8);
     const int s_nxm2 = __builtin_amdgcn_readfirstlane(nx - 2);
     const int s_Li = __builtin_amdgcn_readfirstlane(Li);
-    const int s_Uim1 = __builtin_amdgcn_readfirstlane(Ui - 1);
+    // rows the band accepts: 0 <= yi - Li <= Ui - 1 - Li  (a band with no acceptable row gets no stream)
+    const int s_Uim1 = __builtin_amdgcn_readfirstlane(Ui - 1 - Li);
     const uint32_t s_dummy = __builtin_amdgcn_readfirstlane(dummy_eo);
     const int s_gs = __builtin_amdgcn_readfirstlane(S * kPacket);
     const int s_pkmask = __builtin_amdgcn_readfirstlane(~(S - 1));
