@@ -38,4 +38,4 @@ def test_vote_kernels_do_not_spill(tmp_path):
         assert val("vgpr_count") <= 64, name
     assert seen >= 10
     # the hand-scheduled loops are in there and keep their waits
-    assert text.count("s_waitcnt vmcnt(3)") >= 6 and "v_cvt_flr_i32_f32" in text and "v_cmpx_lt_i32" in text
+    assert text.count("s_waitcnt vmcnt(3)") >= 6 and "v_cvt_flr_i32_f32" in text and "v_cmpx_ge_u32" in text
