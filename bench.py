@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 global atomics, 2 LDS bands")
     ap.add_argument("--band", type=int, nargs=3, default=[0, 0, 0], help="band_rows chunks block")
     ap.add_argument("--points", type=int, default=5000, help="scene points of the synthetic rig (SURVEY 8d: 2000-20000)")
-    ap.add_argument("--packed", type=int, default=-1, help="-1 auto (= 1), 0 per-packet waves, 1 packed lanes (hand-scheduled), 2 packet groups, 3 packed (compiled loop), 4 packet groups (hand-scheduled)")
+    ap.add_argument("--packed", type=int, default=-1, help="-1 auto (= 1), 0 per-packet waves, 1 packed lanes (hand-scheduled), 2 packet groups, 3 packed (compiled loop), 4 packet groups (hand-scheduled), 5 packed with vector fill")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000,
                     help="events of camera 0 the CPU oracle is timed on (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -248,7 +248,7 @@ def main():
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
                 "kernel": {0: "k_vote_bands", 1: "k_vote_bands_packed", 2: "k_vote_groups",
-                           3: "k_vote_bands_packed", 4: "k_vote_groups"}[info["packed"]] if info["algo"] == 2 else "k_vote_global",
+                           3: "k_vote_bands_packed", 4: "k_vote_groups", 5: "k_vote_bands_packed"}[info["packed"]] if info["algo"] == 2 else "k_vote_global",
                 "kernel_avg_ms": kern_ms, "kernel_launches": kt_n,
                 "algorithmic_bytes_per_launch": bytes_per_event * ev_per_launch,
                 "kernel_Mevents_per_s": ev_per_launch / (kern_ms * 1e-3) / 1e6 if kt_n else None}

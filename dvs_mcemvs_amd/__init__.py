@@ -9,6 +9,10 @@ constructors raise.
 """
 from .engine import (  # noqa: F401
     ACC_INV_SUM,
+    ACC_LOG_SUM,
+    ACC_MAX,
+    ACC_MIN,
+    ACC_SQ_SUM,
     ACC_SUM,
     FUSE_AM,
     FUSE_GM,
@@ -17,6 +21,9 @@ from .engine import (  # noqa: F401
     FUSE_MIN,
     FUSE_RMS,
     PACKET_SIZE,
+    REDUCE_MAX,
+    REDUCE_MIN,
+    REDUCE_SUM,
     VOTE_AUTO,
     VOTE_GLOBAL_ATOMIC,
     VOTE_LDS_BANDS,
@@ -27,6 +34,7 @@ from .engine import (  # noqa: F401
     MapperEMVS,
     OptionsDepthMap,
     ShapeDSI,
+    acc_reduce_op,
     device_count,
     library_path,
     load_library,
@@ -37,6 +45,7 @@ from .engine import (  # noqa: F401
 __all__ = [
     "Context", "Grid3D", "MapperEMVS", "ShapeDSI", "OptionsDepthMap", "EventBatch", "DsiError", "device_count",
     "library_path", "load_library", "packetize", "pose_at", "PACKET_SIZE",
-    "FUSE_MIN", "FUSE_HM", "FUSE_GM", "FUSE_AM", "FUSE_RMS", "FUSE_MAX", "ACC_SUM", "ACC_INV_SUM",
+    "FUSE_MIN", "FUSE_HM", "FUSE_GM", "FUSE_AM", "FUSE_RMS", "FUSE_MAX", "ACC_SUM", "ACC_INV_SUM", "ACC_LOG_SUM", "ACC_SQ_SUM", "ACC_MIN", "ACC_MAX",
+    "REDUCE_SUM", "REDUCE_MIN", "REDUCE_MAX", "acc_reduce_op",
     "VOTE_AUTO", "VOTE_GLOBAL_ATOMIC", "VOTE_LDS_BANDS",
 ]

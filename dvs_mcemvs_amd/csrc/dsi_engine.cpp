@@ -234,7 +234,10 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
 {
     const dsi::Geom& g = m->geom;
     const size_t row_bytes = (size_t)g.nx * sizeof(unsigned long long);  // Q33.31 LDS accumulators
-    const long max_rows_total = (long)(dsi::max_dynamic_lds() / row_bytes);
+    const int block_threads = m->want_block > 0 ? m->want_block : 1024;
+    // lane mapping 5 keeps 64 tail-bit words per wave behind the band
+    const size_t scratch_bytes = m->want_packed == 5 ? (size_t)(block_threads / 64) * 512 : 0;
+    const long max_rows_total = (long)((dsi::max_dynamic_lds() - scratch_bytes) / row_bytes);
     if (max_rows_total < 2 || g.nx < 2 || g.ny < 2 || g.ny > 16000) return false;
     long max_owned = max_rows_total - 1;  // + the carry row
     if (m->want_band_rows > 0) {
@@ -243,7 +246,7 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
         // Two 1024-thread workgroups per CU (32 waves) hide latency better than one, if half the
         // LDS still gives runs of >= ~96 events per (packet, band): rows+1 of Ny rows see
         // 1024*(rows+1)/Ny events of a packet.
-        const long half_rows = (long)(dsi::max_dynamic_lds() / 2 / row_bytes) - 1;
+        const long half_rows = (long)((dsi::max_dynamic_lds() / 2 - scratch_bytes) / row_bytes) - 1;
         if (half_rows >= 4 && 1024L * (half_rows + 1) / g.ny >= 96) max_owned = half_rows;
     }
     int bands = (int)((g.ny + max_owned - 1) / max_owned);
@@ -252,8 +255,9 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
     bands = (g.ny + band_rows - 1) / band_rows;
     bp->bands = bands;
     bp->band_rows = band_rows;
-    bp->lds_bytes = (size_t)(band_rows + 1) * row_bytes;
-    bp->block_threads = m->want_block > 0 ? m->want_block : 1024;
+    bp->scratch_offset = (int)((size_t)(band_rows + 1) * row_bytes);
+    bp->lds_bytes = (size_t)(band_rows + 1) * row_bytes + scratch_bytes;
+    bp->block_threads = block_threads;
     bp->row_pad = std::min(g.ny, 4096);  // z0 locations spill up to ~ny rows outside the grid
     // expected events of one packet in one band.  The packed mapping (hand-scheduled wave loop)
     // is the default at every run length: measured 1.1x (240x180) to 3x (1024x1024) faster than
@@ -698,10 +702,34 @@ int dsi_grid_fuse_hm_n(dsi_grid_t* dst, const dsi_grid_t* src, int n)
     return DSI_OK;
 }
 
+static bool valid_acc_mode(int mode) { return mode >= DSI_ACC_SUM && mode <= DSI_ACC_MAX; }
+
+int dsi_acc_reduce_op(int mode)
+{
+    if (!valid_acc_mode(mode)) return -1;
+    if (mode == DSI_ACC_MIN) return DSI_REDUCE_MIN;
+    if (mode == DSI_ACC_MAX) return DSI_REDUCE_MAX;
+    return DSI_REDUCE_SUM;
+}
+
+int dsi_grid_accumulate_begin(dsi_grid_t* dst, int mode)
+{
+    REQUIRE(dst, DSI_ERR_INVALID, "grid is null");
+    REQUIRE(valid_acc_mode(mode), DSI_ERR_BAD_OP, "bad accumulate mode %d", mode);
+    if (int rc = set_device(dst->ctx)) return rc;
+    if (mode == DSI_ACC_MIN || mode == DSI_ACC_MAX) {
+        const float v = mode == DSI_ACC_MIN ? INFINITY : -INFINITY;
+        HIP_TRY(dsi::launch_fill(dst->ctx->stream, dst->data, dst->n, v));
+    } else {
+        HIP_TRY(hipMemsetAsync(dst->data, 0, dst->n * sizeof(float), dst->ctx->stream));
+    }
+    return DSI_OK;
+}
+
 int dsi_grid_accumulate(dsi_grid_t* dst, const dsi_grid_t* src, int mode)
 {
     if (int rc = check_pair(dst, src)) return rc;
-    REQUIRE(mode == DSI_ACC_SUM || mode == DSI_ACC_INV_SUM, DSI_ERR_BAD_OP, "bad accumulate mode %d", mode);
+    REQUIRE(valid_acc_mode(mode), DSI_ERR_BAD_OP, "bad accumulate mode %d", mode);
     HIP_TRY(dsi::launch_accumulate(dst->ctx->stream, dst->data, src->data, dst->n, mode));
     return DSI_OK;
 }
@@ -709,7 +737,8 @@ int dsi_grid_accumulate(dsi_grid_t* dst, const dsi_grid_t* src, int mode)
 int dsi_grid_finalize(dsi_grid_t* dst, int mode, int n)
 {
     REQUIRE(dst, DSI_ERR_INVALID, "grid is null");
-    REQUIRE(mode == DSI_ACC_SUM || mode == DSI_ACC_INV_SUM, DSI_ERR_BAD_OP, "bad finalize mode %d", mode);
+    REQUIRE(valid_acc_mode(mode), DSI_ERR_BAD_OP, "bad finalize mode %d", mode);
+    REQUIRE(n >= 1, DSI_ERR_INVALID, "number of maps must be >= 1 (got %d)", n);
     if (int rc = set_device(dst->ctx)) return rc;
     HIP_TRY(dsi::launch_finalize(dst->ctx->stream, dst->data, dst->n, mode, n));
     return DSI_OK;
@@ -923,7 +952,7 @@ int dsi_mapper_set_band_params(dsi_mapper_t* m, int band_rows, int chunks, int b
 int dsi_mapper_set_packed_lanes(dsi_mapper_t* m, int mode)
 {
     REQUIRE(m, DSI_ERR_INVALID, "mapper is null");
-    REQUIRE(mode >= -1 && mode <= 4, DSI_ERR_INVALID, "mode must be -1 (auto) or 0..4");
+    REQUIRE(mode >= -1 && mode <= 5, DSI_ERR_INVALID, "mode must be -1 (auto) or 0..5");
     m->want_packed = mode;
     return DSI_OK;
 }
@@ -1102,9 +1131,15 @@ int dsi_mapper_depth_map_of(dsi_mapper_t* m, dsi_grid_t* g)
     HIP_TRY(m->conf.reserve(npix));
     HIP_TRY(m->depth.reserve(npix));
     HIP_TRY(m->idx.reserve(npix));
-    int rc = dsi_grid_collapse_max_z_dev(g, m->conf.p, m->idx.p, m->planes_dev, m->depth.p);
-    m->depth_valid = (rc == DSI_OK);
-    return rc;
+    // The arg-max writes the MAPPER's buffers and the filters / copies that follow run on the mapper's
+    // stream, so the kernel goes to the mapper's stream; a grid that lives in another context (stream)
+    // of the same device is first waited for: everything queued on its stream so far.
+    REQUIRE(g->nz <= 256, DSI_ERR_INVALID, "arg-max indices are u8: dimZ must be <= 256 (got %d)", g->nz);
+    if (int rc = dsi_context_wait_for(m->ctx, g->ctx)) return rc;
+    HIP_TRY(dsi::launch_collapse_max_z(m->ctx->stream, g->data, g->nx, g->ny, g->nz, m->conf.p, m->idx.p,
+                                       m->planes_dev, m->depth.p));
+    m->depth_valid = true;
+    return DSI_OK;
 }
 
 int dsi_mapper_fetch_depth_map(dsi_mapper_t* m, float* depth_host, float* conf_host, uint8_t* idx_host)

@@ -803,6 +803,182 @@ __device__ __forceinline__ void packed_stream(const EvRec* __restrict__ sxy,
     }
 }
 
+// ---- lane mapping 5: VECTOR fill.  The packed streams above append runs to the lanes with
+// scalar bookkeeping (11 scalar instructions per run piece + 13 per packet, ~3 taken branches
+// each); with short runs -- wide grids: ~19 records per (packet, band) at 1024 x 1024, 4.4 run
+// pieces per batch -- a wave then spends ~80 dependent scalar instructions per batch and, with
+// only 16 waves per CU (the band fills the LDS), nothing hides that latency (PMC at
+// 1024x1024x256: scalar unit 67 % busy, LDS 37 %, 123 CU-clocks per batch).  Here the slot ->
+// record mapping of a whole pass of up to 64 packets is computed with vector operations:
+//   lane l = packet l of the pass: run length len_l, inclusive prefix incl_l (wave scan);
+//   the non-empty packets are compacted (ballot + mbcnt + ds_permute) into tables
+//   D_c = first record - first slot, P_c = packet index;
+//   the LAST slot of every run sets one bit in a per-wave LDS bit array (ds_or_b64), read back
+//   as one 64-bit word per batch (lane j = word j);
+//   for batch b, slot lane i belongs to compacted packet  c = #tail bits before slot i
+//   = (tails before the batch, a scalar) + v_mbcnt(word_b), and its record is D_c + slot.
+// Per batch: 3 v_readlane, 2 v_mbcnt, 2 ds_bpermute, a few adds -- no loop over packets.
+// The arithmetic of a vote is the function the other compiled streams use, so all mappings give
+// the same bits.
+template <bool SLOW>
+__device__ __forceinline__ void vote_record(char* __restrict__ band_bytes, float ex, float ey,
+                                            uint32_t em, uint4 va, uint32_t vr, int nx, int nx8,
+                                            int cbase, int Li, int Ui)
+{
+    const float ka = __uint_as_float(va.x), kbx = __uint_as_float(va.y);
+    const float kby = __uint_as_float(va.z), kd = __uint_as_float(va.w);
+    const float nxv = ex * ka + kbx;  // mapper_emvs_stereo.cpp:194-195
+    const float nyv = ey * ka + kby;
+    float X, Y;
+    if (SLOW) {
+        X = nxv / kd;
+        Y = nyv / kd;
+    } else {
+        const float kr = __uint_as_float(vr);
+        X = div_rc(nxv, kd, kr);
+        Y = div_rc(nyv, kd, kr);
+    }
+    // cartesian3dgrid.h:255-259 restricted to the band's rows, as one integer sign test (see
+    // packed_stream)
+    const int xi = floor_to_int(X), yi = floor_to_int(Y);
+    int sgn = xi | (nx - 2 - xi) | (yi - Li) | (Ui - 1 - yi);
+    if (SLOW)
+        sgn |= (fabsf(nxv) < __builtin_inff() && fabsf(nyv) < __builtin_inff()) ? 0 : -1;
+    if (sgn >= 0) {
+        const float fx = __builtin_amdgcn_fractf(X), fy = __builtin_amdgcn_fractf(Y);
+        acc_t* cell = reinterpret_cast<acc_t*>(band_bytes + (__mul24(yi, nx8) + ((xi << 3) + cbase)));
+        vote4(cell, 0, nx, fx, fy, em);  // cartesian3dgrid.h:261-270
+    }
+}
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(v, off, 64);
+        if (lane >= off) v += t;
+    }
+    return v;
+}
+
+template <bool SLOW>
+__device__ __forceinline__ void vfill_stream(const EvRec* __restrict__ sxy,
+                                             const uint4* __restrict__ coef4,
+                                             const uint32_t* __restrict__ cutz,
+                                             char* __restrict__ band_bytes,
+                                             unsigned long long* __restrict__ scratch /* 64 words of this wave */,
+                                             int p_first, int p_end, int lg_pass, int stride,
+                                             int lane, int nx, int Li, int Ui, int row_base,
+                                             uint32_t dummy_eo)
+{
+    if (Ui - 1 < Li) return;  // the band accepts no row
+    const int pass = 1 << lg_pass;
+    const int nx8 = nx * 8;
+    const int cbase = -row_base * nx8;
+    // ---- state of the batch generator (wave-uniform unless noted)
+    int pass_base = p_first - stride;  // advanced before use
+    int T = 0;                          // records of the current pass
+    int rbase = 0;                      // first slot of the current range of 4096 slots
+    int b = 0, nb = 0;                  // batch within the range, batches of the range
+    int Cbase = 0;                      // compacted packets that end before the range
+    int Dc = 0, Pc = 0;                 // per lane c: tables of the c-th non-empty packet
+    int incl = 0, len = 0;              // per lane l: packet l of the pass
+    unsigned long long w = 0;           // per lane j: tail bits of batch j of the range
+    int cbefore = 0;                    // per lane j: tails of the range before batch j
+
+    int rtot = 0;                       // tails of the current range
+    auto build_range = [&]() {
+        scratch[lane] = 0ull;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        const int ts = incl - 1 - rbase;  // tail slot of packet `lane`, relative to the range
+        if (len > 0 && ts >= 0 && ts < 4096)
+            atomicOr(&scratch[ts >> 6], 1ull << (ts & 63));
+        // (same wave: its LDS operations complete in order; the fences only pin the compiler)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        w = scratch[lane];
+        const int pc = __builtin_popcountll(w);
+        const int inc = wave_incl_scan(pc, lane);
+        cbefore = inc - pc;
+        rtot = __builtin_amdgcn_readlane(inc, 63);
+        nb = min(64, (T - rbase + 63) >> 6);
+        b = 0;
+    };
+    // advance to the next batch; false at the end of the stream.  rec: record index per lane,
+    // pk: packet whose coefficients the lane needs
+    auto next_batch = [&](uint32_t& rec, int& pk) -> bool {
+        while (b >= nb) {
+            if (T > 0 && rbase + 4096 < T) {
+                Cbase += rtot;
+                rbase += 4096;
+                build_range();
+                continue;
+            }
+            pass_base += stride;
+            if (pass_base >= p_end) return false;
+            const int p = pass_base + lane;
+            uint32_t cu = 0;
+            if (lane < pass && p < p_end) cu = cutz[p];
+            const int lo = (int)(cu & 0xffffu), hi = (int)(cu >> 16);
+            len = max(hi - lo, 0);
+            incl = wave_incl_scan(len, lane);
+            T = __builtin_amdgcn_readlane(incl, 63);
+            rbase = 0;
+            Cbase = 0;
+            b = nb = 0;
+            if (T == 0) continue;
+            const int D = (p << 10) + lo - (incl - len);
+            const unsigned long long ne = __builtin_amdgcn_ballot_w64(len > 0);
+            const int c = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ne >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)ne, 0u));
+            // push (D, p) of the non-empty packets to lanes 0, 1, 2, ...; empty ones to an unused lane
+            const int dst = len > 0 ? c : 63 - (lane - c);
+            Dc = __builtin_amdgcn_ds_permute(dst << 2, D);
+            Pc = __builtin_amdgcn_ds_permute(dst << 2, p);
+            build_range();
+        }
+        const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)w, b);
+        const uint32_t whi = (uint32_t)__builtin_amdgcn_readlane((int)(w >> 32), b);
+        const int cb = __builtin_amdgcn_readlane(cbefore, b) + Cbase;
+        const int c = cb + (int)__builtin_amdgcn_mbcnt_hi(whi, __builtin_amdgcn_mbcnt_lo(wlo, 0u));
+        const int slot = rbase + (b << 6) + lane;
+        const int Dl = __builtin_amdgcn_ds_bpermute(c << 2, Dc);
+        const int Pl = __builtin_amdgcn_ds_bpermute(c << 2, Pc);
+        const bool live = slot < T;
+        rec = live ? (uint32_t)(Dl + slot) : dummy_eo;
+        pk = live ? Pl : p_first;
+        ++b;
+        return true;
+    };
+    struct Loaded {
+        EvRec e;
+        uint4 va;
+        uint32_t vr;
+    };
+    auto gather = [&](uint32_t rec, int pk, Loaded& L) {
+        L.e = sxy[rec];
+        L.va = coef4[2 * (size_t)pk];
+        L.vr = *reinterpret_cast<const uint32_t*>(coef4 + 2 * (size_t)pk + 1);
+    };
+    auto vote = [&](const Loaded& L) {
+        vote_record<SLOW>(band_bytes, L.e.x, L.e.y, L.e.m, L.va, L.vr, nx, nx8, cbase, Li, Ui);
+    };
+    uint32_t rec;
+    int pk;
+    Loaded A, B;
+    if (!next_batch(rec, pk)) return;
+    gather(rec, pk, A);
+    for (;;) {
+        const bool haveB = next_batch(rec, pk);
+        if (haveB) gather(rec, pk, B);
+        vote(A);
+        if (!haveB) break;
+        const bool haveA = next_batch(rec, pk);
+        if (haveA) gather(rec, pk, A);
+        vote(B);
+        if (!haveA) break;
+    }
+}
+
 // The same stream, fast path only (no IEEE-divide planes), written in gfx950 assembly.
 //
 // Why: PMC counters of the compiled stream (10 M events x 100 planes) show ~61 scalar and ~63
@@ -1195,6 +1371,22 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const EvRec* __rest
     // batch does not reach; "its" coefficients are whatever follows the plane's table
     const uint32_t dummy_eo = (uint32_t)np * (uint32_t)kPacket;
     char* band_bytes = reinterpret_cast<char*>(band);
+    if (bp.packed == 5) {
+        // vector fill (wide grids): passes of up to 64 packets, smaller when the chunk has few
+        // packets so that every wave gets >= 2 passes; 64 words of LDS per wave behind the band
+        int lg_pass = 6;
+        while (lg_pass > 3 && (p_end - p_begin) < ((kWaves * 2) << lg_pass)) --lg_pass;
+        if (bp.pass_lg > 0) lg_pass = bp.pass_lg;
+        const int pass = 1 << lg_pass;
+        unsigned long long* scratch =
+            reinterpret_cast<unsigned long long*>(band_bytes + bp.scratch_offset) + wave * 64;
+        if (slow_any[z] != 0)
+            vfill_stream<true>(sxy, coef4, cutz, band_bytes, scratch, p_begin + wave * pass, p_end, lg_pass,
+                               kWaves * pass, lane, nx, Li, Ui, r0, dummy_eo);
+        else
+            vfill_stream<false>(sxy, coef4, cutz, band_bytes, scratch, p_begin + wave * pass, p_end, lg_pass,
+                                kWaves * pass, lane, nx, Li, Ui, r0, dummy_eo);
+    } else
     // bp.packed == 3 selects the compiled stream on the fast path too (A/B testing)
     if (slow_any[z] != 0)
         packed_stream<true>(sxy, coef4, cutz, band_bytes, p_begin + wave * group, p_end, lg_group,
@@ -1550,7 +1742,66 @@ __global__ __launch_bounds__(256) void k_fuse2_into(float* __restrict__ dst,
 }
 
 // generic element-wise driver for the remaining ops
-enum { EW_HM_N = 0, EW_ADD = 1, EW_ADD_INV = 2, EW_FIN_AM = 3, EW_FIN_HM = 4 };
+enum { EW_HM_N = 0, EW_ADD = 1, EW_ADD_INV = 2, EW_FIN_AM = 3, EW_FIN_HM = 4,
+       EW_ADD_LOG = 5, EW_ADD_SQ = 6, EW_MIN = 7, EW_MAX = 8, EW_FIN_GM = 9, EW_FIN_RMS = 10 };
+
+// ---- n-ary geometric mean: exp(mean(log v)), 0 as soon as one factor is 0 (SURVEY 8d cfg 5).
+// The reference only has the 2-ary sqrt(a*g) (cartesian3dgrid.h:150-156).  log and exp are
+// spelled out in IEEE double operations (+, *, /, floor, bit moves; no libm, no FMA) so that the
+// CPU oracle, which repeats exactly this sequence, gets the same bits.
+__device__ __forceinline__ float det_logf(float v)
+{
+    if (!(v > 0.f)) return v == 0.f ? -__builtin_inff() : __builtin_nanf("");
+    if (!finitef(v)) return v;
+    const double x = (double)v;  // every positive float is a normal double
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    int e = (int)((b >> 52) & 0x7ffull) - 1023;
+    double m = __longlong_as_double((long long)((b & 0x000fffffffffffffull) | 0x3ff0000000000000ull));
+    if (m > 1.4142135623730951) {
+        m = m * 0.5;
+        e += 1;
+    }
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    double p = 0.07692307692307693;          // 1/13
+    p = p * z + 0.09090909090909091;         // 1/11
+    p = p * z + 0.1111111111111111;          // 1/9
+    p = p * z + 0.14285714285714285;         // 1/7
+    p = p * z + 0.2;                         // 1/5
+    p = p * z + 0.3333333333333333;          // 1/3
+    p = p * z + 1.0;
+    const double t1 = (double)e * 0.6931471805599453;
+    const double t2 = 2.0 * s;
+    const double t3 = t2 * p;
+    return (float)(t1 + t3);
+}
+
+__device__ __forceinline__ float det_expf(double y)
+{
+    if (y != y) return __builtin_nanf("");
+    if (y > 89.0) return __builtin_inff();
+    if (y < -104.0) return 0.f;  // includes -inf: one factor was 0
+    const double kd = __builtin_floor(y * 1.4426950408889634 + 0.5);
+    double r = y - kd * 0.6931471803691238;      // ln2 split as in fdlibm (hi part has 32 bits)
+    r = r - kd * 1.9082149292705877e-10;
+    double p = 2.08767569878681e-09;             // 1/12!
+    p = p * r + 2.505210838544172e-08;
+    p = p * r + 2.755731922398589e-07;
+    p = p * r + 2.7557319223985893e-06;
+    p = p * r + 2.48015873015873e-05;
+    p = p * r + 0.0001984126984126984;
+    p = p * r + 0.001388888888888889;
+    p = p * r + 0.008333333333333333;
+    p = p * r + 0.041666666666666664;
+    p = p * r + 0.16666666666666666;
+    p = p * r + 0.5;
+    p = p * r + 1.0;
+    p = p * r + 1.0;
+    const long long k = (long long)kd;           // |k| <= 151: 2^k is a normal double
+    const double sc = __longlong_as_double((k + 1023) << 52);
+    return (float)(p * sc);
+}
 
 template <int KIND>
 __device__ __forceinline__ float ew_op(float a, float g, float fn, float fn1)
@@ -1563,7 +1814,17 @@ __device__ __forceinline__ float ew_op(float a, float g, float fn, float fn1)
     if (KIND == EW_ADD) return a + g;                       // :68
     if (KIND == EW_ADD_INV) return a + 1.0f / (0.01f + g);  // :76, eps = 1e-2f
     if (KIND == EW_FIN_AM) return a / fn;                   // :91
-    return fn / a;                                          // :84
+    if (KIND == EW_FIN_HM) return fn / a;                   // :84
+    // n-ary extensions of the 2-ary camera-fusion ops (cartesian3dgrid.h:111-190) in
+    // accumulate / finalize form; sum-, min- and max-reducible across GPUs
+    if (KIND == EW_ADD_LOG) return a + det_logf(g);         // GM: sum of log v (-inf once a v is 0)
+    if (KIND == EW_ADD_SQ) return a + g * g;                // RMS: sum of v^2
+    if (KIND == EW_MIN) return (g < a) ? g : a;             // std::min, :115
+    if (KIND == EW_MAX) return (a < g) ? g : a;             // std::max, :188
+    if (KIND == EW_FIN_GM) return det_expf((double)a / (double)fn);
+    // EW_FIN_RMS: mean square in double rounded to float, then sqrt like rmsTwoGrids (:145-146)
+    const float ms = (float)((double)a / (double)fn);
+    return __builtin_sqrtf(ms);
 }
 
 template <int KIND>
@@ -1571,7 +1832,8 @@ __global__ __launch_bounds__(256) void k_elementwise(float* __restrict__ a,
                                                      const float* __restrict__ g, size_t n,
                                                      float fn, float fn1)
 {
-    constexpr bool has_g = (KIND == EW_HM_N || KIND == EW_ADD || KIND == EW_ADD_INV);
+    constexpr bool has_g = (KIND == EW_HM_N || KIND == EW_ADD || KIND == EW_ADD_INV ||
+                            KIND == EW_ADD_LOG || KIND == EW_ADD_SQ || KIND == EW_MIN || KIND == EW_MAX);
     const size_t n4 = n / 4;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -2013,22 +2275,45 @@ hipError_t launch_fuse_hm_n(hipStream_t s, float* a, const float* g, size_t n, i
 hipError_t launch_accumulate(hipStream_t s, float* acc, const float* g, size_t n, int mode)
 {
     const dim3 grid(grid_for(n / 4 + 1, 256)), block(256);
-    if (mode == 0)
-        hipLaunchKernelGGL(k_elementwise<EW_ADD>, grid, block, 0, s, acc, g, n, 0.f, 0.f);
-    else
-        hipLaunchKernelGGL(k_elementwise<EW_ADD_INV>, grid, block, 0, s, acc, g, n, 0.f, 0.f);
+    switch (mode) {
+    case 0: hipLaunchKernelGGL(k_elementwise<EW_ADD>, grid, block, 0, s, acc, g, n, 0.f, 0.f); break;
+    case 1: hipLaunchKernelGGL(k_elementwise<EW_ADD_INV>, grid, block, 0, s, acc, g, n, 0.f, 0.f); break;
+    case 2: hipLaunchKernelGGL(k_elementwise<EW_ADD_LOG>, grid, block, 0, s, acc, g, n, 0.f, 0.f); break;
+    case 3: hipLaunchKernelGGL(k_elementwise<EW_ADD_SQ>, grid, block, 0, s, acc, g, n, 0.f, 0.f); break;
+    case 4: hipLaunchKernelGGL(k_elementwise<EW_MIN>, grid, block, 0, s, acc, g, n, 0.f, 0.f); break;
+    case 5: hipLaunchKernelGGL(k_elementwise<EW_MAX>, grid, block, 0, s, acc, g, n, 0.f, 0.f); break;
+    default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 
 hipError_t launch_finalize(hipStream_t s, float* acc, size_t n, int mode, int n_maps)
 {
     const dim3 grid(grid_for(n / 4 + 1, 256)), block(256);
-    if (mode == 0)
-        hipLaunchKernelGGL(k_elementwise<EW_FIN_AM>, grid, block, 0, s, acc, (const float*)nullptr,
-                           n, (float)n_maps, 0.f);
-    else
-        hipLaunchKernelGGL(k_elementwise<EW_FIN_HM>, grid, block, 0, s, acc, (const float*)nullptr,
-                           n, (float)n_maps, 0.f);
+    const float* none = nullptr;
+    const float fn = (float)n_maps;
+    switch (mode) {
+    case 0: hipLaunchKernelGGL(k_elementwise<EW_FIN_AM>, grid, block, 0, s, acc, none, n, fn, 0.f); break;
+    case 1: hipLaunchKernelGGL(k_elementwise<EW_FIN_HM>, grid, block, 0, s, acc, none, n, fn, 0.f); break;
+    case 2: hipLaunchKernelGGL(k_elementwise<EW_FIN_GM>, grid, block, 0, s, acc, none, n, fn, 0.f); break;
+    case 3: hipLaunchKernelGGL(k_elementwise<EW_FIN_RMS>, grid, block, 0, s, acc, none, n, fn, 0.f); break;
+    case 4:
+    case 5: break;  // min / max need no finalisation
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// identity element of an accumulate mode: 0 for the sums, +inf for min, -inf for max
+__global__ __launch_bounds__(256) void k_fill(float* __restrict__ a, size_t n, float v)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) a[i] = v;
+}
+
+hipError_t launch_fill(hipStream_t s, float* a, size_t n, float v)
+{
+    hipLaunchKernelGGL(k_fill, dim3(grid_for(n, 256)), dim3(256), 0, s, a, n, v);
     return hipGetLastError();
 }
 

@@ -21,7 +21,8 @@ import numpy as np
 PACKET_SIZE = 1024
 
 FUSE_MIN, FUSE_HM, FUSE_GM, FUSE_AM, FUSE_RMS, FUSE_MAX = 1, 2, 3, 4, 5, 6
-ACC_SUM, ACC_INV_SUM = 0, 1
+ACC_SUM, ACC_INV_SUM, ACC_LOG_SUM, ACC_SQ_SUM, ACC_MIN, ACC_MAX = 0, 1, 2, 3, 4, 5
+REDUCE_SUM, REDUCE_MIN, REDUCE_MAX = 0, 1, 2
 VOTE_AUTO, VOTE_GLOBAL_ATOMIC, VOTE_LDS_BANDS = 0, 1, 2
 
 (OK, ERR_INVALID, ERR_TOO_FEW_EVENTS, ERR_HIP, ERR_SHAPE, ERR_BAD_OP, ERR_NO_DEVICE,
@@ -102,6 +103,8 @@ def load_library():
         "dsi_grid_fuse_hm_n": (C.c_int, [vp, vp, C.c_int]),
         "dsi_grid_accumulate": (C.c_int, [vp, vp, C.c_int]),
         "dsi_grid_finalize": (C.c_int, [vp, C.c_int, C.c_int]),
+        "dsi_grid_accumulate_begin": (C.c_int, [vp, C.c_int]),
+        "dsi_acc_reduce_op": (C.c_int, [C.c_int]),
         "dsi_grid_collapse_max_z": (C.c_int, [vp, f32p, u8p]),
         "dsi_grid_collapse_max_z_dev": (C.c_int, [vp, vp, vp, vp, vp]),
         "dsi_grid_mean_square": (C.c_int, [vp, f64p]),
@@ -192,6 +195,14 @@ def _ptr(a, ct):
 
 def _arr(a, dtype):
     return np.ascontiguousarray(a, dtype=dtype)
+
+
+def acc_reduce_op(mode):
+    """REDUCE_SUM / REDUCE_MIN / REDUCE_MAX: how an accumulator of `mode` combines across GPUs."""
+    r = load_library().dsi_acc_reduce_op(int(mode))
+    if r < 0:
+        raise DsiError(ERR_BAD_OP, "bad accumulate mode %r" % (mode,))
+    return r
 
 
 def device_count():
@@ -348,6 +359,26 @@ class Grid3D:
 
     def computeHMfromSumOfInv(self, n):
         _check(load_library().dsi_grid_finalize(self._h, ACC_INV_SUM, int(n)))
+
+    # -- n-ary accumulate / finalize (dsi_acc_mode_t): the reference's temporal accumulators
+    #    (modes 0, 1) and the n-ary forms of its 2-ary camera-fusion ops (modes 2..5), which it
+    #    does not have (process1.cpp:169-191 drops camera 3 for GM / AM / RMS)
+    def accumulateBegin(self, mode):
+        _check(load_library().dsi_grid_accumulate_begin(self._h, int(mode)))
+
+    def accumulate(self, grid2, mode):
+        _check(load_library().dsi_grid_accumulate(self._h, grid2._h, int(mode)))
+
+    def finalize(self, mode, n):
+        _check(load_library().dsi_grid_finalize(self._h, int(mode), int(n)))
+
+    def setToFusionOfN(self, grids, mode):
+        """self = n-ary mean of `grids`: ACC_SUM arithmetic, ACC_LOG_SUM geometric (0 where any
+        grid is 0), ACC_SQ_SUM root mean square, ACC_MIN / ACC_MAX."""
+        self.accumulateBegin(mode)
+        for g in grids:
+            self.accumulate(g, mode)
+        self.finalize(mode, len(grids))
 
     # -- cartesian3dgrid.cpp:115-137, :164-174 --------------------------------------
     def collapseMaxZSlice(self):

@@ -39,7 +39,7 @@ extern "C" {
 #define DSI_API
 #endif
 
-#define DSI_ENGINE_ABI_VERSION 2
+#define DSI_ENGINE_ABI_VERSION 3
 #define DSI_PACKET_SIZE 1024 /* mapper_emvs_stereo.hpp:152 packet_size_ */
 
 typedef enum {
@@ -63,16 +63,37 @@ typedef enum {
     DSI_FUSE_MAX = 6   /* Grid3D::maxTwoGrids            cartesian3dgrid.h:184-190 */
 } dsi_fuse_op_t;
 
+/* accumulate / finalize modes.  0 and 1 are the reference's temporal-fusion accumulators.
+ * 2..5 are the n-ary forms of the 2-ary camera-fusion ops, which the reference does not have:
+ * it applies GM / AM / RMS to two cameras only and silently ignores a third one
+ * (process1.cpp:169-191).  They follow SURVEY.md 8(d) cfg 5 / 8(e): each is an accumulation
+ * that is a plain sum, min or max over the maps -- i.e. directly an RCCL ncclSum / ncclMin /
+ * ncclMax all-reduce across GPUs (dsi_acc_reduce_op) -- followed by a local finalize:
+ *   LOG_SUM  acc += log v            finalize exp(acc / n)    geometric mean; 0 if any v is 0
+ *   SQ_SUM   acc += v*v              finalize sqrt(acc / n)   root mean square
+ *   MIN/MAX  acc = min/max(acc, v)   finalize: nothing
+ * For n = 2: MIN / MAX / SUM(AM) equal the reference's 2-ary ops bit for bit; LOG_SUM equals
+ * sqrt(a*g) (geometricMeanTwoGrids) within 16 ulp for values in [2^-20, 2^20] (1e-5 relative
+ * over the whole float range: the accumulator is an fp32 sum of fp32 logarithms) and SQ_SUM
+ * equals rmsTwoGrids within 2 ulp; tests/test_gpu_parity.py states and checks both.  log and exp
+ * are spelled out in IEEE double operations, so GPU and CPU oracle agree bit for bit. */
 typedef enum {
-    DSI_ACC_SUM = 0,    /* addTwoGrids / computeAMfromSum            cartesian3dgrid.h:64-70, 87-93 */
-    DSI_ACC_INV_SUM = 1 /* addInverseOfTwoGrids / computeHMfromSumOfInv cartesian3dgrid.h:72-86 */
+    DSI_ACC_SUM = 0,     /* addTwoGrids / computeAMfromSum            cartesian3dgrid.h:64-70, 87-93 */
+    DSI_ACC_INV_SUM = 1, /* addInverseOfTwoGrids / computeHMfromSumOfInv cartesian3dgrid.h:72-86 */
+    DSI_ACC_LOG_SUM = 2, /* n-ary geometricMeanTwoGrids               cartesian3dgrid.h:150-156 */
+    DSI_ACC_SQ_SUM = 3,  /* n-ary rmsTwoGrids                         cartesian3dgrid.h:141-148 */
+    DSI_ACC_MIN = 4,     /* n-ary minTwoGrids                         cartesian3dgrid.h:111-117 */
+    DSI_ACC_MAX = 5      /* n-ary maxTwoGrids                         cartesian3dgrid.h:184-190 */
 } dsi_acc_mode_t;
+
+/* how an accumulator of a given mode combines across GPUs */
+typedef enum { DSI_REDUCE_SUM = 0, DSI_REDUCE_MIN = 1, DSI_REDUCE_MAX = 2 } dsi_reduce_op_t;
 
 /* which voting kernel MapperEMVS::fillVoxelGrid is replaced by */
 typedef enum {
     DSI_VOTE_AUTO = 0,
     DSI_VOTE_GLOBAL_ATOMIC = 1, /* thread = event, global_atomic_add_f32 into the DSI */
-    DSI_VOTE_LDS_BANDS = 2      /* plane x row-band privatised in LDS, ds_add_f32, coalesced flush */
+    DSI_VOTE_LDS_BANDS = 2      /* plane x row-band privatised in LDS as Q33.31 fixed point (ds_add_u64), coalesced flush */
 } dsi_vote_algo_t;
 
 typedef struct dsi_context dsi_context_t; /* one GPU + one HIP stream + scratch */
@@ -124,10 +145,16 @@ DSI_API int dsi_grid_fuse2(dsi_grid_t *dst, const dsi_grid_t *src, int op);
 DSI_API int dsi_grid_fuse2_into(dsi_grid_t *dst, const dsi_grid_t *a, const dsi_grid_t *b, int op);
 /* Grid3D::harmonicMeanTwoGrids(grid2, n) (cartesian3dgrid.h:130-139) */
 DSI_API int dsi_grid_fuse_hm_n(dsi_grid_t *dst, const dsi_grid_t *src, int n);
-/* Grid3D::addTwoGrids / addInverseOfTwoGrids (cartesian3dgrid.h:64-78) */
+/* dst = identity element of the mode: 0 for the four sums (what the reference's resetGrid()
+ * before the temporal loop does, process2.cpp:203), +inf for MIN, -inf for MAX */
+DSI_API int dsi_grid_accumulate_begin(dsi_grid_t *dst, int mode);
+/* Grid3D::addTwoGrids / addInverseOfTwoGrids (cartesian3dgrid.h:64-78) and the n-ary modes,
+ * mode = dsi_acc_mode_t */
 DSI_API int dsi_grid_accumulate(dsi_grid_t *dst, const dsi_grid_t *src, int mode);
-/* Grid3D::computeAMfromSum / computeHMfromSumOfInv (cartesian3dgrid.h:80-93) */
+/* Grid3D::computeAMfromSum / computeHMfromSumOfInv (cartesian3dgrid.h:80-93) and the n-ary modes */
 DSI_API int dsi_grid_finalize(dsi_grid_t *dst, int mode, int n);
+/* dsi_reduce_op_t of a mode (never fails for a valid mode; -1 otherwise) */
+DSI_API int dsi_acc_reduce_op(int mode);
 /* Grid3D::collapseMaxZSlice (cartesian3dgrid.cpp:115-137): conf[ny*nx] f32,
  * idx[ny*nx] u8, first maximum wins.  Host outputs; synchronises. */
 DSI_API int dsi_grid_collapse_max_z(dsi_grid_t *g, float *conf_host, uint8_t *idx_host);
@@ -180,7 +207,9 @@ DSI_API int dsi_mapper_set_band_params(dsi_mapper_t *m, int band_rows, int chunk
  * mode -1 = automatic (by expected run length), 0 = per packet, 1 = packed,
  * 2 = groups of consecutive packets sorted together (one long run per group),
  * 3 = packed with the compiled (not hand-scheduled) wave loop, for A/B tests,
- * 4 = groups with the hand-scheduled wave loop (long runs for wide grids). */
+ * 4 = groups with the hand-scheduled wave loop (long runs for wide grids),
+ * 5 = packed with a vector (prefix-sum + tail-bit) slot -> record mapping instead of the scalar run
+ *     bookkeeping (short runs: wide grids). */
 DSI_API int dsi_mapper_set_packed_lanes(dsi_mapper_t *m, int mode);
 
 /* MapperEMVS::fillVoxelGrid(event_locations_z0, camera_centers)
@@ -273,7 +302,7 @@ typedef struct {
     int block_threads;
     size_t lds_bytes;
     size_t n_packets;
-    int packed;        /* lane mapping that ran: 0 per packet, 1 packed lanes, 2 packet groups */
+    int packed;        /* lane mapping that ran (see dsi_mapper_set_packed_lanes) */
     int group_packets; /* packets sorted together by mapping 2 */
 } dsi_vote_info_t;
 DSI_API int dsi_mapper_last_vote_info(const dsi_mapper_t *m, dsi_vote_info_t *info);

@@ -293,26 +293,140 @@ void orc_fuse_hm_n(float *a, const float *g, size_t n, int n_maps)
     }
 }
 
+/* ---- n-ary geometric mean helpers: log and exp spelled out in IEEE double operations
+ * (+, *, /, floor, bit moves; no libm, no FMA -- this file is built with -ffp-contract=off).
+ * The n-ary forms are NOT in the reference (it has 2-ary ops only and drops a third camera for
+ * GM / AM / RMS, process1.cpp:169-191); they restate SURVEY.md 8(d) cfg 5:
+ * GM = exp(mean(log v)), 0 if any v is 0. */
+static double bits_to_double(uint64_t b)
+{
+    double d;
+    memcpy(&d, &b, sizeof d);
+    return d;
+}
+
+static float det_logf(float v)
+{
+    if (!(v > 0.f))
+        return v == 0.f ? -INFINITY : NAN;
+    if (isinf(v))
+        return v;
+    const double x = (double)v;
+    uint64_t b;
+    memcpy(&b, &x, sizeof b);
+    int e = (int)((b >> 52) & 0x7ffull) - 1023;
+    double m = bits_to_double((b & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
+    if (m > 1.4142135623730951) {
+        m = m * 0.5;
+        e += 1;
+    }
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    double p = 0.07692307692307693;
+    p = p * z + 0.09090909090909091;
+    p = p * z + 0.1111111111111111;
+    p = p * z + 0.14285714285714285;
+    p = p * z + 0.2;
+    p = p * z + 0.3333333333333333;
+    p = p * z + 1.0;
+    const double t1 = (double)e * 0.6931471805599453;
+    const double t2 = 2.0 * s;
+    const double t3 = t2 * p;
+    return (float)(t1 + t3);
+}
+
+static float det_expf(double y)
+{
+    if (y != y)
+        return NAN;
+    if (y > 89.0)
+        return INFINITY;
+    if (y < -104.0)
+        return 0.f;
+    const double kd = floor(y * 1.4426950408889634 + 0.5);
+    double r = y - kd * 0.6931471803691238;
+    r = r - kd * 1.9082149292705877e-10;
+    double p = 2.08767569878681e-09;
+    p = p * r + 2.505210838544172e-08;
+    p = p * r + 2.755731922398589e-07;
+    p = p * r + 2.7557319223985893e-06;
+    p = p * r + 2.48015873015873e-05;
+    p = p * r + 0.0001984126984126984;
+    p = p * r + 0.001388888888888889;
+    p = p * r + 0.008333333333333333;
+    p = p * r + 0.041666666666666664;
+    p = p * r + 0.16666666666666666;
+    p = p * r + 0.5;
+    p = p * r + 1.0;
+    p = p * r + 1.0;
+    const int64_t k = (int64_t)kd;
+    const double sc = bits_to_double((uint64_t)(k + 1023) << 52);
+    return (float)(p * sc);
+}
+
+void orc_accumulate_begin(float *acc, size_t n, int mode)
+{
+    const float v = mode == 4 ? INFINITY : (mode == 5 ? -INFINITY : 0.f);
+    for (size_t p = 0; p < n; ++p)
+        acc[p] = v;
+}
+
 void orc_accumulate(float *acc, const float *g, size_t n, int mode)
 {
-    if (mode == 0) { /* addTwoGrids :64-70 */
+    switch (mode) {
+    case 0: /* addTwoGrids :64-70 */
         for (size_t p = 0; p < n; ++p)
             acc[p] += g[p];
-    } else { /* addInverseOfTwoGrids :72-78, eps = 1e-2 */
+        break;
+    case 1: { /* addInverseOfTwoGrids :72-78, eps = 1e-2 */
         const float eps = 1e-2;
         for (size_t p = 0; p < n; ++p)
             acc[p] = acc[p] + 1.0f / (eps + g[p]);
+        break;
+    }
+    case 2: /* n-ary GM: sum of log v */
+        for (size_t p = 0; p < n; ++p)
+            acc[p] = acc[p] + det_logf(g[p]);
+        break;
+    case 3: /* n-ary RMS: sum of v^2 */
+        for (size_t p = 0; p < n; ++p)
+            acc[p] = acc[p] + g[p] * g[p];
+        break;
+    case 4: /* n-ary min, std::min as in minTwoGrids :115 */
+        for (size_t p = 0; p < n; ++p)
+            acc[p] = (g[p] < acc[p]) ? g[p] : acc[p];
+        break;
+    default: /* 5: n-ary max, std::max as in maxTwoGrids :188 */
+        for (size_t p = 0; p < n; ++p)
+            acc[p] = (acc[p] < g[p]) ? g[p] : acc[p];
+        break;
     }
 }
 
 void orc_finalize(float *acc, size_t n, int mode, int n_maps)
 {
-    if (mode == 0) { /* computeAMfromSum :87-93 */
+    switch (mode) {
+    case 0: /* computeAMfromSum :87-93 */
         for (size_t p = 0; p < n; ++p)
             acc[p] = acc[p] / (float)n_maps;
-    } else { /* computeHMfromSumOfInv :80-86 */
+        break;
+    case 1: /* computeHMfromSumOfInv :80-86 */
         for (size_t p = 0; p < n; ++p)
             acc[p] = (float)n_maps / acc[p];
+        break;
+    case 2: /* GM = exp(mean(log v)) */
+        for (size_t p = 0; p < n; ++p)
+            acc[p] = det_expf((double)acc[p] / (double)(float)n_maps);
+        break;
+    case 3: /* RMS: mean square in double -> float, sqrt of the float like rmsTwoGrids :145-146 */
+        for (size_t p = 0; p < n; ++p) {
+            const float ms = (float)((double)acc[p] / (double)(float)n_maps);
+            acc[p] = (float)sqrt((double)ms);
+        }
+        break;
+    default: /* min / max: nothing */
+        break;
     }
 }
 

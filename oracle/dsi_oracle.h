@@ -96,9 +96,15 @@ long orc_packetize(size_t n_events, const uint8_t *pose_ok,
 int orc_fuse2(float *a, const float *g, size_t n, int op);
 /* cartesian3dgrid.h:130-139 harmonicMeanTwoGrids(grid2, n). */
 void orc_fuse_hm_n(float *a, const float *g, size_t n, int n_maps);
-/* cartesian3dgrid.h:64-78: mode 0 addTwoGrids, mode 1 addInverseOfTwoGrids. */
+/* cartesian3dgrid.h:64-78: mode 0 addTwoGrids, mode 1 addInverseOfTwoGrids.
+ * Modes 2..5 are the n-ary accumulate forms of the camera-fusion ops (NOT in the reference,
+ * which is 2-ary and drops a third camera for GM/AM/RMS, process1.cpp:169-191; semantics from
+ * SURVEY.md 8(d) cfg 5 / 8(e)): 2 sum of log v (GM), 3 sum of v^2 (RMS), 4 min, 5 max. */
 void orc_accumulate(float *acc, const float *g, size_t n, int mode);
-/* cartesian3dgrid.h:80-93: mode 0 computeAMfromSum, 1 computeHMfromSumOfInv. */
+/* identity of a mode: 0 (sums), +inf (min), -inf (max) */
+void orc_accumulate_begin(float *acc, size_t n, int mode);
+/* cartesian3dgrid.h:80-93: mode 0 computeAMfromSum, 1 computeHMfromSumOfInv;
+ * 2 exp(acc/n) (0 if any factor was 0), 3 sqrt(acc/n), 4/5 nothing. */
 void orc_finalize(float *acc, size_t n, int mode, int n_maps);
 
 /* cartesian3dgrid.cpp:115-137 (std::max_element: first maximum wins). */

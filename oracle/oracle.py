@@ -46,6 +46,7 @@ def lib():
         L.orc_fuse_hm_n.argtypes = [f32p, f32p, C.c_size_t, C.c_int]
         L.orc_accumulate.argtypes = [f32p, f32p, C.c_size_t, C.c_int]
         L.orc_finalize.argtypes = [f32p, C.c_size_t, C.c_int, C.c_int]
+        L.orc_accumulate_begin.argtypes = [f32p, C.c_size_t, C.c_int]
         L.orc_collapse_max_z.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p, u8p]
         L.orc_indices_to_depth.argtypes = [u8p, C.c_size_t, f32p, f32p]
         L.orc_mean_square.argtypes = [f32p, C.c_size_t]
@@ -172,6 +173,20 @@ def accumulate(acc, g, mode):
     g = _f32(g)
     lib().orc_accumulate(_p(acc, C.c_float), _p(g, C.c_float), acc.size, mode)
     return acc
+
+
+def accumulate_begin(shape, mode):
+    acc = np.empty(shape, np.float32)
+    lib().orc_accumulate_begin(_p(acc, C.c_float), acc.size, mode)
+    return acc
+
+
+def fuse_nary(grids, mode):
+    """n-ary camera fusion in accumulate / finalize form (modes 0 AM, 2 GM, 3 RMS, 4 min, 5 max)."""
+    acc = accumulate_begin(np.asarray(grids[0]).shape, mode)
+    for g in grids:
+        acc = accumulate(acc, g, mode)
+    return finalize(acc, mode, len(grids))
 
 
 def finalize(acc, mode, n_maps):

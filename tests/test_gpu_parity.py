@@ -234,6 +234,72 @@ def test_fusion_ops_bit_exact(ctx, n):
     G.close()
 
 
+def _ulp_diff(x, y):
+    xi = x.view(np.int32).astype(np.int64)
+    yi = y.view(np.int32).astype(np.int64)
+    return np.abs(xi - yi)
+
+
+@pytest.mark.parametrize("n_maps", [2, 3, 4, 8])
+def test_nary_fusion_modes_bit_exact(ctx, n_maps):
+    """n-ary camera fusion (accumulate / finalize modes LOG_SUM = GM, SQ_SUM = RMS, MIN, MAX, SUM =
+    AM): the HIP kernels against the oracle, bit for bit, on vote-count-like values with zeros,
+    denormals, huge values and +inf mixed in.  The reference has no n-ary GM / AM / RMS
+    (process1.cpp:169-191 drops camera 3); for n = 2 the relation to its 2-ary ops
+    (cartesian3dgrid.h:111-190) is checked too: min / max / AM equal, RMS within 2 ulp, GM within
+    16 ulp for values in [2^-20, 2^20] (the accumulator is an fp32 sum of logs)."""
+    rng = np.random.default_rng(40 + n_maps)
+    nx, ny, nz = 67, 33, 5   # n % 4 != 0: the scalar tail of the float4 kernels runs too
+    maps = []
+    for k in range(n_maps):
+        v = rng.gamma(2.0, 8.0, (nz, ny, nx)).astype(np.float32)
+        v.flat[k::11] = 0.0                                   # empty voxels
+        v.flat[3 + k::97] = np.float32(1e-41)                 # denormal
+        v.flat[5 + k::101] = np.float32(3e37)
+        v.flat[7 + k::103] = np.float32(2.0 ** -20)
+        maps.append(v)
+    maps[0].flat[50] = np.inf
+    G = [d.Grid3D(ctx, nx, ny, nz) for _ in range(n_maps)]
+    for g, v in zip(G, maps):
+        g.upload(v)
+    A = d.Grid3D(ctx, nx, ny, nz)
+    for mode in (d.ACC_SUM, d.ACC_LOG_SUM, d.ACC_SQ_SUM, d.ACC_MIN, d.ACC_MAX):
+        A.upload(maps[0])          # whatever was there must not matter
+        A.setToFusionOfN(G, mode)
+        got = A.download()
+        ref = orc.fuse_nary(maps, mode)
+        same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
+        assert same.all(), "mode %d: %d voxels differ, first at %s: gpu %r cpu %r" % (
+            mode, (~same).sum(), np.argwhere(~same)[0], got[~same][0], ref[~same][0])
+    # "0 if any factor is 0" and the all-reduce forms
+    gm = orc.fuse_nary(maps, d.ACC_LOG_SUM)
+    anyzero = np.zeros(gm.shape, bool)
+    for v in maps:
+        anyzero |= v == 0
+    assert np.all(gm[anyzero] == 0.0)
+    assert d.acc_reduce_op(d.ACC_LOG_SUM) == d.REDUCE_SUM and d.acc_reduce_op(d.ACC_SQ_SUM) == d.REDUCE_SUM
+    assert d.acc_reduce_op(d.ACC_MIN) == d.REDUCE_MIN and d.acc_reduce_op(d.ACC_MAX) == d.REDUCE_MAX
+    if n_maps == 2:
+        a, g = maps
+        for mode, op in ((d.ACC_MIN, 1), (d.ACC_SUM, 4), (d.ACC_MAX, 6)):
+            A.setToFusionOfN(G, mode)
+            ref2 = orc.fuse2(a, g, op)
+            got = A.download()
+            ok = np.isfinite(ref2)
+            assert np.array_equal(got[ok], ref2[ok]), "mode %d vs 2-ary op %d" % (mode, op)
+        A.setToFusionOfN(G, d.ACC_SQ_SUM)
+        got, ref2 = A.download(), orc.fuse2(a, g, 5)
+        ok = np.isfinite(ref2) & (ref2 > 1e-18) & np.isfinite(a * a + g * g)
+        assert _ulp_diff(got[ok], ref2[ok]).max() <= 2
+        A.setToFusionOfN(G, d.ACC_LOG_SUM)
+        got, ref2 = A.download(), orc.fuse2(a, g, 3)
+        lo, hi = 2.0 ** -20, 2.0 ** 20
+        ok = (a >= lo) & (a <= hi) & (g >= lo) & (g <= hi)
+        assert ok.sum() > 1000 and _ulp_diff(got[ok], ref2[ok]).max() <= 16
+    for o in G + [A]:
+        o.close()
+
+
 def test_fusion_errors(ctx):
     A, B = d.Grid3D(ctx, 8, 8, 4), d.Grid3D(ctx, 8, 8, 5)
     with pytest.raises(d.DsiError) as e:
@@ -393,7 +459,7 @@ def test_fuse_into_equals_reference_sequence(ctx):
         A.setToFusionOf(A, G, 2)
 
 
-@pytest.mark.parametrize("packed", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("packed", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("shape,band", [((64, 48, 16), None), ((346, 260, 12), (26, 4, 1024)),
                                         ((130, 97, 7), (5, 3, 256)), ((70, 48, 9), (48, 2, 512)),
                                         ((40, 30, 6), (9, 2, 256))])
@@ -417,7 +483,7 @@ def test_both_lane_mappings_match_oracle(ctx, shape, band, packed):
     m.close()
 
 
-@pytest.mark.parametrize("packed", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("packed", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("n_pixels", [1, 7, 300, 5000])
 def test_duplicate_events_in_a_packet(ctx, packed, n_pixels):
     """Events of a packet drawn from a few pixels (hot pixels, bursts): the packet sort merges
@@ -506,10 +572,10 @@ def test_hand_scheduled_loops_equal_the_compiled_loop_bit_for_bit(ctx, seed):
     band = (int(rng.integers(1, 12)), int(rng.integers(1, 6)), int(rng.choice([256, 512, 1024])))
     m_max = float(rng.uniform(2.0, 9.0))
     ref = {}
-    # (3, 1, 0) chunk the packets identically, (2, 4) chunk the groups identically: within each
+    # (3, 1, 0, 5) chunk the packets identically, (2, 4) chunk the groups identically: within each
     # family the fp32 partial DSIs of the chunks are the same numbers, so the results are bit-equal
     import os
-    for packed in (3, 1, 0, 2, 4):
+    for packed in (3, 1, 0, 5, 2, 4):
         m = make_mapper(ctx, cam, nz, 0.8, m_max, d.VOTE_LDS_BANDS, band=band, packed=packed)
         os.environ["DSI_GROUP_PACKETS"] = "8"      # same groups (hence chunk boundaries) for 2 and 4
         try:
@@ -518,7 +584,7 @@ def test_hand_scheduled_loops_equal_the_compiled_loop_bit_for_bit(ctx, seed):
             del os.environ["DSI_GROUP_PACKETS"]
         got = m.dsi_.download()
         m.close()
-        family = 0 if packed in (3, 1, 0) else 1
+        family = 0 if packed in (3, 1, 0, 5) else 1
         if family not in ref:
             ref[family] = got
             orc_ref = orc.fill_voxel_grid(xy, centers, m.raw_depths_vec_, np.array(m.virtual_cam_, np.float32), nx, ny)
@@ -547,6 +613,35 @@ def test_two_contexts_meet_at_the_fusion(ctx):
     ref = orc.fuse2(m0.dsi_.download(), m1.dsi_.download(), 2)
     assert np.array_equal(got, ref)
     for o in (m0, m1, fused, ctx2):
+        o.close()
+
+
+def test_depth_map_of_a_grid_in_another_context(ctx):
+    """A mapper in context A extracts the depth map of a grid that context B is still producing
+    (the `mapper_fused` pattern of the pipelined temporal fusion): the arg-max must be ordered
+    after B's queued work on the device, without the host waiting."""
+    nx, ny, nz = 512, 512, 200
+    ctx_b = d.Context(0)
+    cam = (nx, ny, 400.0, 400.0, 256.0, 256.0)
+    m = d.MapperEMVS(ctx, cam, d.ShapeDSI(0, 0, nz, 1.0, 10.0, 0.0))
+    rng = np.random.default_rng(8)
+    vol = rng.gamma(2.0, 3.0, (nz, ny, nx)).astype(np.float32)
+    src = d.Grid3D(ctx_b, nx, ny, nz)
+    src.upload(vol)
+    g = d.Grid3D(ctx_b, nx, ny, nz)
+    for rep in range(3):
+        g.resetGrid()
+        for _ in range(40):                    # ~10 ms of queued work on B's stream
+            g.addTwoGrids(src)
+        g.computeAMfromSum(1)                   # g = 40 * vol, finished only when all of it ran
+        m.computeDepthMap(g)                    # queued on A's stream right away
+        depth, conf, idx = m.fetchDepthMap()
+        got = g.download()
+        rconf, ridx = orc.collapse_max_z(got)
+        assert np.array_equal(idx, ridx) and np.array_equal(conf, rconf)
+        assert conf.max() > 39.0 * vol.max() - 1.0   # not a stale / partial volume
+        ctx_b.wait_for(ctx)                     # B overwrites g only after A has read it
+    for o in (m, src, g, ctx_b):
         o.close()
 
 

@@ -283,3 +283,43 @@ def test_event_pose_Rt_is_inverse_of_relative_pose():
     q = rig["T_rv_w"][3:]
     expect = rig["T_rv_w"][:3] + syn.quat_rotate(q, T_w_ev[:3])
     assert np.allclose(c_rv, expect, atol=1e-5)
+
+
+def _ulp(x, y):
+    return np.abs(x.view(np.int32).astype(np.int64) - y.view(np.int32).astype(np.int64))
+
+
+def test_nary_fusion_modes_against_float64_and_the_two_ary_ops():
+    """The n-ary accumulate / finalize modes (an extension: the reference is 2-ary,
+    cartesian3dgrid.h:111-190, and drops camera 3 for GM/AM/RMS, process1.cpp:169-191) against
+    float64 numpy, and for n = 2 against the restated 2-ary ops."""
+    rng = np.random.default_rng(5)
+    maps = [rng.gamma(2.0, 8.0, 20000).astype(np.float32) for _ in range(4)]
+    for k, v in enumerate(maps):
+        v[k::13] = 0.0
+    st = np.stack(maps).astype(np.float64)
+    gm = orc.fuse_nary(maps, 2)
+    with np.errstate(divide="ignore"):
+        ref = np.exp(np.mean(np.log(st), axis=0))
+    assert np.all(gm[(st == 0).any(axis=0)] == 0.0)
+    nz = ref > 0
+    assert np.max(np.abs(gm[nz] - ref[nz]) / ref[nz]) < 4e-6      # fp32 sum of four fp32 logs
+    rms = orc.fuse_nary(maps, 3)
+    assert np.max(np.abs(rms - np.sqrt(np.mean(st * st, axis=0))) / np.maximum(1.0, rms)) < 1e-6
+    assert np.array_equal(orc.fuse_nary(maps, 4), np.min(np.stack(maps), axis=0))
+    assert np.array_equal(orc.fuse_nary(maps, 5), np.max(np.stack(maps), axis=0))
+    am = orc.fuse_nary(maps, 0)
+    assert np.max(np.abs(am - st.mean(axis=0))) < 1e-4
+    a, g = maps[0], maps[1]
+    assert np.array_equal(orc.fuse_nary([a, g], 0), orc.fuse2(a, g, 4))
+    assert np.array_equal(orc.fuse_nary([a, g], 4), orc.fuse2(a, g, 1))
+    assert np.array_equal(orc.fuse_nary([a, g], 5), orc.fuse2(a, g, 6))
+    r5 = orc.fuse2(a, g, 5)
+    assert _ulp(orc.fuse_nary([a, g], 3), r5).max() <= 2
+    r3 = orc.fuse2(a, g, 3)
+    ok = (a > 2.0 ** -20) & (g > 2.0 ** -20)
+    assert _ulp(orc.fuse_nary([a, g], 2)[ok], r3[ok]).max() <= 16
+    assert np.all(orc.fuse_nary([a, g], 2)[~ok & ((a == 0) | (g == 0))] == 0.0)
+    # identities: a rank that owns no map contributes the identity to the all-reduce
+    for mode, ident in ((0, 0.0), (2, 0.0), (3, 0.0), (4, np.inf), (5, -np.inf)):
+        assert np.all(orc.accumulate_begin((3, 2), mode) == ident)
