@@ -248,7 +248,7 @@ def main():
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
                 "kernel": {0: "k_vote_bands", 1: "k_vote_bands_packed", 2: "k_vote_groups",
-                           3: "k_vote_bands_packed", 4: "k_vote_groups", 5: "k_vote_bands_packed"}[info["packed"]] if info["algo"] == 2 else "k_vote_global",
+                           3: "k_vote_bands_packed", 4: "k_vote_groups", 5: "k_vote_bands_packed", 6: "k_vote_bands_packed"}[info["packed"]] if info["algo"] == 2 else "k_vote_global",
                 "kernel_avg_ms": kern_ms, "kernel_launches": kt_n,
                 "algorithmic_bytes_per_launch": bytes_per_event * ev_per_launch,
                 "kernel_Mevents_per_s": ev_per_launch / (kern_ms * 1e-3) / 1e6 if kt_n else None}

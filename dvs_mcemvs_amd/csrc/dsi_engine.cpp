@@ -8,6 +8,9 @@
 #include "../../include/dsi_engine.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types only: librccl is loaded at run time (load_rccl)
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -15,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <utility>
@@ -161,6 +165,9 @@ struct dsi_mapper {
     int sensor_w = 0, sensor_h = 0;
     dsi::Geom geom{};
     std::vector<float> planes;  // raw_depths_vec_ (of the planes this mapper owns)
+    std::vector<float> planes_full;  // the whole depth vector (plane-sharded arg-max: index -> depth)
+    float* planes_full_dev = nullptr;
+    DevBuf<unsigned long long> argmax_keys;
     int plane_begin = 0;        // first owned plane of the full depth vector (plane sharding)
     float* planes_dev = nullptr;
     float2* lut_dev = nullptr;
@@ -235,8 +242,18 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
     const dsi::Geom& g = m->geom;
     const size_t row_bytes = (size_t)g.nx * sizeof(unsigned long long);  // Q33.31 LDS accumulators
     const int block_threads = m->want_block > 0 ? m->want_block : 1024;
+    // Lane mapping: the packed mapping with the hand-scheduled scalar run bookkeeping (1) is the
+    // default (measured 1.1x (240x180) to 3x faster than the per-packet mapping 0); when a band sees
+    // fewer than ~32 records of a packet (wide grids: 19 at 1024x1024) the scalar bookkeeping per run
+    // dominates and the vector fill (5) takes over (measured at 1024x1024x256, 10 M events:
+    // 7.6 -> 4.9 ms; at 512x512x200 and 640x480x100 mapping 1 still wins).
+    int packed = m->want_packed;
+    if (packed < 0) {
+        const long rows_full = std::max<long>(1, (long)(dsi::max_dynamic_lds() / row_bytes) - 1);
+        packed = 1024L * (rows_full + 1) / g.ny < 32 ? 5 : 1;
+    }
     // lane mapping 5 keeps 64 tail-bit words per wave behind the band
-    const size_t scratch_bytes = m->want_packed == 5 ? (size_t)(block_threads / 64) * 512 : 0;
+    const size_t scratch_bytes = (packed == 5 || packed == 6) ? (size_t)(block_threads / 64) * 512 : 0;
     const long max_rows_total = (long)((dsi::max_dynamic_lds() - scratch_bytes) / row_bytes);
     if (max_rows_total < 2 || g.nx < 2 || g.ny < 2 || g.ny > 16000) return false;
     long max_owned = max_rows_total - 1;  // + the carry row
@@ -259,11 +276,9 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
     bp->lds_bytes = (size_t)(band_rows + 1) * row_bytes + scratch_bytes;
     bp->block_threads = block_threads;
     bp->row_pad = std::min(g.ny, 4096);  // z0 locations spill up to ~ny rows outside the grid
-    // expected events of one packet in one band.  The packed mapping (hand-scheduled wave loop)
-    // is the default at every run length: measured 1.1x (240x180) to 3x (1024x1024) faster than
-    // the per-packet mapping.
+    // expected events of one packet in one band
     const long run = 1024L * (band_rows + 1) / g.ny;
-    bp->packed = m->want_packed >= 0 ? m->want_packed : 1;
+    bp->packed = packed;
     // mapping 2 sorts S consecutive packets together so that a run holds >= ~512 events
     // (mapping 4, the hand-scheduled loop, packs the runs of consecutive groups into the lanes, so
     //  it only needs runs of a few batches)
@@ -408,6 +423,7 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
     if ((np + 1) * dsi::kPacket * sizeof(dsi::EvRec) > 0xffffffffull) {
         if (bp.packed == 1) bp.packed = 3;
         if (bp.packed == 4) bp.packed = 2;
+        if (bp.packed == 5) bp.packed = 6;
     }
 
     m->info.bands = bp.bands;
@@ -839,6 +855,7 @@ int dsi_mapper_create(dsi_context_t* ctx, const dsi_mapper_config_t* cfg, dsi_ma
     g.vcy = cfg->K[3];
     make_planes(cfg->min_depth, cfg->max_depth, cfg->dim_z, cfg->inverse_depth != 0, &m->planes);
     g.z0 = m->planes[0];  // :111, :163 -- of the full depth vector, also for a plane shard
+    m->planes_full = m->planes;
     m->plane_begin = cfg->plane_begin;
     if (const char* e = std::getenv("DSI_PREP_OVERLAP")) m->prep_overlap = std::atoi(e) != 0;
     g.nz = cfg->plane_count > 0 ? cfg->plane_count : cfg->dim_z - cfg->plane_begin;
@@ -878,6 +895,8 @@ int dsi_mapper_destroy(dsi_mapper_t* m)
     }
     if (m->grid) dsi_grid_destroy(m->grid);
     if (m->planes_dev) (void)hipFree(m->planes_dev);
+    if (m->planes_full_dev) (void)hipFree(m->planes_full_dev);
+    m->argmax_keys.release();
     if (m->lut_dev) (void)hipFree(m->lut_dev);
     m->centers.release();
     m->H.release();
@@ -952,7 +971,7 @@ int dsi_mapper_set_band_params(dsi_mapper_t* m, int band_rows, int chunks, int b
 int dsi_mapper_set_packed_lanes(dsi_mapper_t* m, int mode)
 {
     REQUIRE(m, DSI_ERR_INVALID, "mapper is null");
-    REQUIRE(mode >= -1 && mode <= 5, DSI_ERR_INVALID, "mode must be -1 (auto) or 0..5");
+    REQUIRE(mode >= -1 && mode <= 6, DSI_ERR_INVALID, "mode must be -1 (auto) or 0..6");
     m->want_packed = mode;
     return DSI_OK;
 }
@@ -1281,6 +1300,304 @@ DSI_API int dsi_test_div_probe(dsi_context_t* ctx, const float* n, const float* 
     if (dq) (void)hipFree(dq);
     if (dr) (void)hipFree(dr);
     if (e != hipSuccess) return fail(DSI_ERR_HIP, "div probe failed: %s", hipGetErrorString(e));
+    return DSI_OK;
+}
+
+}  // extern "C"
+
+/* ---------------------------------------------------------- multi-GPU (RCCL) */
+namespace {
+
+// librccl entry points, resolved once.  When the process already holds an RCCL (e.g. the one torch
+// ships) dlopen by soname returns that copy; otherwise /opt/rocm's.
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
+                              hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+
+Rccl* load_rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char* n : names) {
+            r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) {
+            r.error = std::string("librccl could not be loaded: ") + (dlerror() ? dlerror() : "?");
+            return;
+        }
+        auto sym = [&](const char* name) -> void* {
+            void* p = dlsym(r.lib, name);
+            if (!p && r.error.empty()) r.error = std::string("librccl lacks ") + name;
+            return p;
+        };
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+        r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+        r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+        r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+        r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    });
+    return &r;
+}
+
+#define RCCL_TRY(R, expr)                                                                          \
+    do {                                                                                           \
+        ncclResult_t e_ = (expr);                                                                  \
+        if (e_ != ncclSuccess)                                                                     \
+            return fail(DSI_ERR_COMM, "%s failed: %s (%s:%d)", #expr, (R)->GetErrorString(e_), __FILE__, \
+                        __LINE__);                                                                 \
+    } while (0)
+
+int rccl_ready(Rccl** out)
+{
+    Rccl* r = load_rccl();
+    if (!r->error.empty()) return fail(DSI_ERR_COMM, "%s", r->error.c_str());
+    *out = r;
+    return DSI_OK;
+}
+
+bool to_nccl_op(int op, ncclRedOp_t* out)
+{
+    switch (op) {
+    case DSI_REDUCE_SUM: *out = ncclSum; return true;
+    case DSI_REDUCE_MIN: *out = ncclMin; return true;
+    case DSI_REDUCE_MAX: *out = ncclMax; return true;
+    default: return false;
+    }
+}
+
+}  // namespace
+
+struct dsi_comm {
+    ncclComm_t comm = nullptr;
+    int device = 0, rank = 0, size = 1;
+};
+
+extern "C" {
+
+int dsi_comm_unique_id(uint8_t id[DSI_COMM_ID_BYTES])
+{
+    REQUIRE(id, DSI_ERR_INVALID, "id is null");
+    static_assert(sizeof(ncclUniqueId) == DSI_COMM_ID_BYTES, "RCCL unique id size");
+    Rccl* r = nullptr;
+    if (int rc = rccl_ready(&r)) return rc;
+    ncclUniqueId u;
+    RCCL_TRY(r, r->GetUniqueId(&u));
+    std::memcpy(id, &u, sizeof u);
+    return DSI_OK;
+}
+
+int dsi_comm_create_rank(dsi_context_t* ctx, const uint8_t id[DSI_COMM_ID_BYTES], int nranks, int rank,
+                         dsi_comm_t** out)
+{
+    REQUIRE(ctx && id && out, DSI_ERR_INVALID, "null argument");
+    *out = nullptr;
+    REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, DSI_ERR_INVALID, "rank %d of %d", rank, nranks);
+    Rccl* r = nullptr;
+    if (int rc = rccl_ready(&r)) return rc;
+    if (int rc = set_device(ctx)) return rc;
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof u);
+    dsi_comm* c = new (std::nothrow) dsi_comm();
+    REQUIRE(c, DSI_ERR_INVALID, "out of host memory");
+    c->device = ctx->device;
+    c->rank = rank;
+    c->size = nranks;
+    const ncclResult_t e = r->CommInitRank(&c->comm, nranks, u, rank);
+    if (e != ncclSuccess) {
+        delete c;
+        return fail(DSI_ERR_COMM, "ncclCommInitRank(rank %d of %d) failed: %s", rank, nranks, r->GetErrorString(e));
+    }
+    *out = c;
+    return DSI_OK;
+}
+
+int dsi_comm_create_all(dsi_context_t* const* contexts, int n, dsi_comm_t** out)
+{
+    REQUIRE(contexts && out && n >= 1, DSI_ERR_INVALID, "bad argument");
+    for (int i = 0; i < n; ++i) out[i] = nullptr;
+    std::vector<int> devs(n);
+    for (int i = 0; i < n; ++i) {
+        REQUIRE(contexts[i], DSI_ERR_INVALID, "context %d is null", i);
+        devs[i] = contexts[i]->device;
+        for (int j = 0; j < i; ++j)
+            REQUIRE(devs[j] != devs[i], DSI_ERR_CONTEXT, "contexts %d and %d share device %d (RCCL: one rank per GPU)",
+                    j, i, devs[i]);
+    }
+    Rccl* r = nullptr;
+    if (int rc = rccl_ready(&r)) return rc;
+    std::vector<ncclComm_t> comms(n, nullptr);
+    RCCL_TRY(r, r->CommInitAll(comms.data(), n, devs.data()));
+    for (int i = 0; i < n; ++i) {
+        dsi_comm* c = new (std::nothrow) dsi_comm();
+        if (!c) {
+            for (int j = 0; j < n; ++j) {
+                if (comms[j]) (void)r->CommDestroy(comms[j]);
+                delete out[j];
+                out[j] = nullptr;
+            }
+            return fail(DSI_ERR_INVALID, "out of host memory");
+        }
+        c->comm = comms[i];
+        c->device = devs[i];
+        c->rank = i;
+        c->size = n;
+        out[i] = c;
+    }
+    return DSI_OK;
+}
+
+int dsi_comm_destroy(dsi_comm_t* c)
+{
+    if (!c) return DSI_OK;
+    Rccl* r = load_rccl();
+    if (c->comm && r->CommDestroy) {
+        (void)hipSetDevice(c->device);
+        (void)r->CommDestroy(c->comm);
+    }
+    delete c;
+    return DSI_OK;
+}
+
+int dsi_comm_rank(const dsi_comm_t* c) { return c ? c->rank : -1; }
+int dsi_comm_size(const dsi_comm_t* c) { return c ? c->size : 0; }
+
+static int allreduce_check(const dsi_comm_t* c, const dsi_grid_t* g)
+{
+    REQUIRE(c && g, DSI_ERR_INVALID, "null argument");
+    REQUIRE(c->device == g->ctx->device, DSI_ERR_CONTEXT, "grid on device %d, communicator rank on device %d",
+            g->ctx->device, c->device);
+    return DSI_OK;
+}
+
+int dsi_grid_allreduce(dsi_comm_t* c, dsi_grid_t* g, int op)
+{
+    if (int rc = allreduce_check(c, g)) return rc;
+    ncclRedOp_t nop;
+    REQUIRE(to_nccl_op(op, &nop), DSI_ERR_BAD_OP, "bad reduce op %d", op);
+    Rccl* r = nullptr;
+    if (int rc = rccl_ready(&r)) return rc;
+    if (int rc = set_device(g->ctx)) return rc;
+    RCCL_TRY(r, r->AllReduce(g->data, g->data, g->n, ncclFloat32, nop, c->comm, g->ctx->stream));
+    return DSI_OK;
+}
+
+int dsi_grid_allreduce_all(dsi_comm_t* const* comms, dsi_grid_t* const* grids, int n, int op)
+{
+    REQUIRE(comms && grids && n >= 1, DSI_ERR_INVALID, "bad argument");
+    ncclRedOp_t nop;
+    REQUIRE(to_nccl_op(op, &nop), DSI_ERR_BAD_OP, "bad reduce op %d", op);
+    for (int i = 0; i < n; ++i) {
+        if (int rc = allreduce_check(comms[i], grids[i])) return rc;
+        REQUIRE(same_shape(grids[0], grids[i]), DSI_ERR_SHAPE, "grid %d has another shape", i);
+    }
+    Rccl* r = nullptr;
+    if (int rc = rccl_ready(&r)) return rc;
+    RCCL_TRY(r, r->GroupStart());
+    ncclResult_t bad = ncclSuccess;
+    for (int i = 0; i < n; ++i) {
+        (void)hipSetDevice(grids[i]->ctx->device);
+        const ncclResult_t e = r->AllReduce(grids[i]->data, grids[i]->data, grids[i]->n, ncclFloat32, nop,
+                                            comms[i]->comm, grids[i]->ctx->stream);
+        if (e != ncclSuccess && bad == ncclSuccess) bad = e;
+    }
+    const ncclResult_t e2 = r->GroupEnd();
+    if (bad != ncclSuccess) return fail(DSI_ERR_COMM, "ncclAllReduce failed: %s", r->GetErrorString(bad));
+    if (e2 != ncclSuccess) return fail(DSI_ERR_COMM, "ncclGroupEnd failed: %s", r->GetErrorString(e2));
+    return DSI_OK;
+}
+
+// local collapse + key packing of one shard (everything on the mapper's stream)
+static int sharded_prepare(dsi_mapper_t* m, dsi_grid_t* g)
+{
+    REQUIRE(m && g, DSI_ERR_INVALID, "null argument");
+    REQUIRE(m->ctx->device == g->ctx->device, DSI_ERR_CONTEXT, "mapper and grid live on different devices");
+    REQUIRE(same_shape(m->grid, g), DSI_ERR_SHAPE, "grid shape differs from the mapper's DSI");
+    REQUIRE(m->planes_full.size() <= 256, DSI_ERR_INVALID, "arg-max indices are u8");
+    if (int rc = set_device(m->ctx)) return rc;
+    const size_t npix = (size_t)g->nx * g->ny;
+    HIP_TRY(m->conf.reserve(npix));
+    HIP_TRY(m->depth.reserve(npix));
+    HIP_TRY(m->idx.reserve(npix));
+    HIP_TRY(m->argmax_keys.reserve(npix));
+    if (!m->planes_full_dev) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->planes_full_dev), m->planes_full.size() * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(m->planes_full_dev, m->planes_full.data(), m->planes_full.size() * sizeof(float),
+                               hipMemcpyHostToDevice, m->ctx->stream));
+        HIP_TRY(hipStreamSynchronize(m->ctx->stream));  // the source is host memory of this object: simplest
+    }
+    if (int rc = dsi_context_wait_for(m->ctx, g->ctx)) return rc;
+    HIP_TRY(dsi::launch_collapse_max_z(m->ctx->stream, g->data, g->nx, g->ny, g->nz, m->conf.p, m->idx.p, nullptr,
+                                       nullptr));
+    HIP_TRY(dsi::launch_pack_argmax(m->ctx->stream, m->conf.p, m->idx.p, (int)npix, m->plane_begin,
+                                    m->argmax_keys.p));
+    return DSI_OK;
+}
+
+static int sharded_finish(dsi_mapper_t* m)
+{
+    const size_t npix = (size_t)m->geom.nx * m->geom.ny;
+    HIP_TRY(hipSetDevice(m->ctx->device));
+    HIP_TRY(dsi::launch_unpack_argmax(m->ctx->stream, m->argmax_keys.p, (int)npix, m->planes_full_dev, m->conf.p,
+                                      m->idx.p, m->depth.p));
+    m->depth_valid = true;
+    return DSI_OK;
+}
+
+int dsi_mapper_depth_map_sharded(dsi_mapper_t* m, dsi_grid_t* g, dsi_comm_t* c)
+{
+    REQUIRE(c, DSI_ERR_INVALID, "communicator is null");
+    if (int rc = sharded_prepare(m, g)) return rc;
+    REQUIRE(c->device == m->ctx->device, DSI_ERR_CONTEXT, "communicator rank on another device");
+    Rccl* r = nullptr;
+    if (int rc = rccl_ready(&r)) return rc;
+    const size_t npix = (size_t)g->nx * g->ny;
+    RCCL_TRY(r, r->AllReduce(m->argmax_keys.p, m->argmax_keys.p, npix, ncclUint64, ncclMax, c->comm,
+                             m->ctx->stream));
+    return sharded_finish(m);
+}
+
+int dsi_mapper_depth_map_sharded_all(dsi_mapper_t* const* ms, dsi_grid_t* const* gs, dsi_comm_t* const* cs, int n)
+{
+    REQUIRE(ms && gs && cs && n >= 1, DSI_ERR_INVALID, "bad argument");
+    for (int i = 0; i < n; ++i) {
+        REQUIRE(cs[i], DSI_ERR_INVALID, "communicator %d is null", i);
+        if (int rc = sharded_prepare(ms[i], gs[i])) return rc;
+        REQUIRE(cs[i]->device == ms[i]->ctx->device, DSI_ERR_CONTEXT, "communicator %d on another device", i);
+        REQUIRE(ms[i]->geom.nx == ms[0]->geom.nx && ms[i]->geom.ny == ms[0]->geom.ny, DSI_ERR_SHAPE,
+                "mapper %d has another image size", i);
+    }
+    Rccl* r = nullptr;
+    if (int rc = rccl_ready(&r)) return rc;
+    const size_t npix = (size_t)ms[0]->geom.nx * ms[0]->geom.ny;
+    RCCL_TRY(r, r->GroupStart());
+    ncclResult_t bad = ncclSuccess;
+    for (int i = 0; i < n; ++i) {
+        (void)hipSetDevice(ms[i]->ctx->device);
+        const ncclResult_t e = r->AllReduce(ms[i]->argmax_keys.p, ms[i]->argmax_keys.p, npix, ncclUint64, ncclMax,
+                                            cs[i]->comm, ms[i]->ctx->stream);
+        if (e != ncclSuccess && bad == ncclSuccess) bad = e;
+    }
+    const ncclResult_t e2 = r->GroupEnd();
+    if (bad != ncclSuccess) return fail(DSI_ERR_COMM, "ncclAllReduce failed: %s", r->GetErrorString(bad));
+    if (e2 != ncclSuccess) return fail(DSI_ERR_COMM, "ncclGroupEnd failed: %s", r->GetErrorString(e2));
+    for (int i = 0; i < n; ++i)
+        if (int rc = sharded_finish(ms[i])) return rc;
     return DSI_OK;
 }
 

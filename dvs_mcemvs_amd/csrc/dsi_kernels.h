@@ -44,7 +44,7 @@ struct BandPlan {
     int block_threads;  // 256 / 512 / 1024
     int packed;         // lane mapping: 0 k_vote_bands, 1 k_vote_bands_packed (asm), 2 k_vote_groups,
                         // 3 k_vote_bands_packed (compiled loop), 4 k_vote_groups (asm),
-                        // 5 k_vote_bands_packed with the vector fill (wide grids)
+                        // 5 k_vote_bands_packed with the vector fill (wide grids), 6 the same all compiled
     int group_packets;  // mapping 2: packets sorted together (power of two <= 32)
     int row_pad;        // z0 rows binned over [-row_pad, ny + row_pad) by k_sort_packets
     int pass_lg;        // packed mappings: log2(packets a wave takes per pass); 0 = automatic
@@ -91,6 +91,10 @@ hipError_t launch_fuse_hm_n(hipStream_t s, float* a, const float* g, size_t n, i
 hipError_t launch_accumulate(hipStream_t s, float* acc, const float* g, size_t n, int mode);
 hipError_t launch_finalize(hipStream_t s, float* acc, size_t n, int mode, int n_maps);
 hipError_t launch_fill(hipStream_t s, float* a, size_t n, float v);
+hipError_t launch_pack_argmax(hipStream_t s, const float* conf, const uint8_t* idx, int n, int plane_begin,
+                              unsigned long long* keys);
+hipError_t launch_unpack_argmax(hipStream_t s, const unsigned long long* keys, int n, const float* planes_full,
+                                float* conf, uint8_t* idx, float* depth);
 hipError_t launch_collapse_max_z(hipStream_t s, const float* dsi, int nx, int ny, int nz,
                                  float* conf, uint8_t* idx, const float* planes, float* depth);
 hipError_t launch_depth_map_filters(hipStream_t s, float* conf, const uint8_t* idx, int nx, int ny,

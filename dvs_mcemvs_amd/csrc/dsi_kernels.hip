@@ -851,14 +851,21 @@ __device__ __forceinline__ void vote_record(char* __restrict__ band_bytes, float
     }
 }
 
-__device__ __forceinline__ int wave_incl_scan(int v, int lane)
+// inclusive prefix sum over the 64 lanes with DPP moves only (no LDS round trips: the per-pass set-up
+// of the vector fill sits on a wave's critical path while the LDS queue is full of votes)
+__device__ __forceinline__ int wave_incl_scan(int v, int /*lane*/)
 {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(v, off, 64);
-        if (lane >= off) v += t;
-    }
-    return v;
+    // row_shr:n = 0x110 + n, row_bcast:15 = 0x142, row_bcast:31 = 0x143; lanes a mask disables
+    // (and reads beyond a row) contribute `old` = 0
+    int s = v;
+    s += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    s += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    s += __builtin_amdgcn_update_dpp(0, v, 0x113, 0xf, 0xf, true);
+    s += __builtin_amdgcn_update_dpp(0, s, 0x114, 0xf, 0xe, true);
+    s += __builtin_amdgcn_update_dpp(0, s, 0x118, 0xf, 0xc, true);
+    s += __builtin_amdgcn_update_dpp(0, s, 0x142, 0xa, 0xf, true);
+    s += __builtin_amdgcn_update_dpp(0, s, 0x143, 0xc, 0xf, true);
+    return s;
 }
 
 template <bool SLOW>
@@ -1168,6 +1175,166 @@ __device__ __forceinline__ void packed_stream_asm(const EvRec* sxy, const uint4*
           "v62", "v63");
 }
 
+// ---- lane mapping 5, hand-scheduled: the batches of one range (<= 64 batches = 4096 slots) of a
+// vector-fill pass (see vfill_stream for the slot -> record mapping; the per-pass tables are built
+// by compiled code and handed over in vector registers).  Per batch: 3 v_readlane + 2 v_mbcnt +
+// 2 ds_bpermute find every lane's record and packet, then the same GATHER / VOTE as the packed
+// stream.  Two batches of gathers are in flight while one is voted: the ds_bpermutes of batch k+2
+// are issued BEFORE the votes of batch k (their latency hides behind ~45 vector instructions),
+// waited for with lgkmcnt(4) (the four ds_add_u64 of batch k are younger), and the gathers of
+// batch k+2 go into the register set batch k has just released.
+//   s42 batch counter k   s45 k+2   s46,s49,s50 tail-bit words / tails before the batch   s51 first slot of batch k+2
+//   v32 slot per lane   v33 coefficient byte offset   v34 D (record - slot)   v35 table index   v40 record index
+//   sets A / B and the temporaries as in packed_stream_asm
+#define DSI_ASM_VPREP1                                                                             \
+    "v_readlane_b32 s46, %5, s45\n\t"     /* tail bits of the batch, low / high half */             \
+    "v_readlane_b32 s49, %6, s45\n\t"                                                               \
+    "v_readlane_b32 s50, %7, s45\n\t"     /* runs that end before the batch */                      \
+    "v_mbcnt_lo_u32_b32 v35, s46, 0\n\t"                                                            \
+    "v_mbcnt_hi_u32_b32 v35, s49, v35\n\t" /* + runs that end before this lane's slot */            \
+    "v_add_lshl_u32 v35, v35, s50, 2\n\t"                                                           \
+    "ds_bpermute_b32 v34, v35, %8\n\t"    /* D of the lane's run */                                 \
+    "ds_bpermute_b32 v33, v35, %16\n\t"   /* byte offset of its packet's coefficients */            \
+    "s_lshl_b32 s51, s45, 6\n\t"                                                                    \
+    "s_add_i32 s51, s51, %3\n\t"          /* first slot of the batch */
+
+#define DSI_ASM_VPREP2(EV, CA, CR)                                                                 \
+    "v_add_u32 v32, s51, %15\n\t"         /* slot */                                                \
+    "v_add_u32 v40, v34, v32\n\t"         /* record */                                              \
+    "v_cmp_gt_i32 vcc, %4, v32\n\t"       /* slot < T */                                            \
+    "v_cndmask_b32 v40, %14, v40, vcc\n\t" /* beyond the pass: the multiplicity-0 record */         \
+    "v_mul_lo_u32 v58, v40, 12\n\t"                                                                 \
+    "global_load_dwordx3 " EV ", v58, %0\n\t"                                                       \
+    "global_load_dwordx4 " CA ", v33, %1\n\t"                                                       \
+    "global_load_dword " CR ", v33, %1 offset:16\n\t"
+
+__device__ __forceinline__ void vfill_range_asm(const EvRec* sxy, const uint4* coef4, int nb, int slot0,
+                                                int T, uint32_t wlo, uint32_t whi, int cb, int Dc,
+                                                int Pc32, char* band_bytes, int lane, int nx, int Li,
+                                                int Ui, int row_base, uint32_t dummy_eo)
+{
+    const int s_nb = __builtin_amdgcn_readfirstlane(nb);
+    const int s_slot0 = __builtin_amdgcn_readfirstlane(slot0);
+    const int s_T = __builtin_amdgcn_readfirstlane(T);
+    const int s_nx8 = __builtin_amdgcn_readfirstlane(nx * 8);
+    const int lds_base = (int)(uintptr_t)band_bytes;
+    const int s_cbase = __builtin_amdgcn_readfirstlane(lds_base - row_base * nx * 8);
+    const int s_nxm2 = __builtin_amdgcn_readfirstlane(nx - 2);
+    const int s_Li = __builtin_amdgcn_readfirstlane(Li);
+    const int s_Uim1 = __builtin_amdgcn_readfirstlane(Ui - 1 - Li);
+    asm volatile(
+        // prologue: batches 0 and 1 (batch 1 may lie beyond the range: all its lanes then take the
+        // multiplicity-0 record only if it is also beyond the pass; it is never voted)
+        "s_mov_b32 s42, 0\n\t"
+        "s_mov_b32 s45, 0\n\t"
+        DSI_ASM_VPREP1
+        "s_waitcnt lgkmcnt(0)\n\t"
+        DSI_ASM_VPREP2("v[42:44]", "v[46:49]", "v45")
+        "s_cmp_lt_i32 1, %2\n\t"
+        "s_cbranch_scc0 Llast1%=\n\t"        // nb == 1
+        "s_mov_b32 s45, 1\n\t"
+        DSI_ASM_VPREP1
+        "s_waitcnt lgkmcnt(0)\n\t"
+        DSI_ASM_VPREP2("v[50:52]", "v[54:57]", "v53")
+        "Lloop%=:\n\t"
+        // ---- batch k in set A
+        "s_add_i32 s45, s42, 2\n\t"
+        "s_cmp_lt_i32 s45, %2\n\t"
+        "s_cbranch_scc0 LtailA%=\n\t"
+        DSI_ASM_VPREP1
+        "s_waitcnt vmcnt(3)\n\t"
+        DSI_ASM_VOTE("v42", "v43", "v44", "v46", "v47", "v48", "v49", "v45")
+        "s_waitcnt lgkmcnt(4)\n\t"
+        DSI_ASM_VPREP2("v[42:44]", "v[46:49]", "v45")
+        "s_add_i32 s42, s42, 1\n\t"
+        // ---- batch k+1 in set B
+        "s_add_i32 s45, s42, 2\n\t"
+        "s_cmp_lt_i32 s45, %2\n\t"
+        "s_cbranch_scc0 LtailB%=\n\t"
+        DSI_ASM_VPREP1
+        "s_waitcnt vmcnt(3)\n\t"
+        DSI_ASM_VOTE("v50", "v51", "v52", "v54", "v55", "v56", "v57", "v53")
+        "s_waitcnt lgkmcnt(4)\n\t"
+        DSI_ASM_VPREP2("v[50:52]", "v[54:57]", "v53")
+        "s_add_i32 s42, s42, 1\n\t"
+        "s_branch Lloop%=\n"
+        "LtailA%=:\n\t"                      // batches k (A) and k+1 (B) remain, both in flight
+        "s_waitcnt vmcnt(3)\n\t"
+        DSI_ASM_VOTE("v42", "v43", "v44", "v46", "v47", "v48", "v49", "v45")
+        "s_waitcnt vmcnt(0)\n\t"
+        DSI_ASM_VOTE("v50", "v51", "v52", "v54", "v55", "v56", "v57", "v53")
+        "s_branch Lend%=\n"
+        "LtailB%=:\n\t"                      // batches k (B) and k+1 (A) remain
+        "s_waitcnt vmcnt(3)\n\t"
+        DSI_ASM_VOTE("v50", "v51", "v52", "v54", "v55", "v56", "v57", "v53")
+        "s_waitcnt vmcnt(0)\n\t"
+        DSI_ASM_VOTE("v42", "v43", "v44", "v46", "v47", "v48", "v49", "v45")
+        "s_branch Lend%=\n"
+        "Llast1%=:\n\t"                      // a single batch
+        "s_waitcnt vmcnt(0)\n\t"
+        DSI_ASM_VOTE("v42", "v43", "v44", "v46", "v47", "v48", "v49", "v45")
+        "Lend%=:\n\t"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)"
+        :
+        : "s"(sxy), "s"(coef4), "s"(s_nb), "s"(s_slot0), "s"(s_T), "v"(wlo), "v"(whi), "v"(cb), "v"(Dc),
+          "s"(s_nx8), "s"(s_cbase), "s"(s_nxm2), "s"(s_Li), "s"(s_Uim1), "v"(dummy_eo), "v"(lane),
+          "v"(Pc32)
+        : "memory", "scc", "vcc", "s42", "s45", "s46", "s49", "s50", "s51", "v32", "v33", "v34", "v35",
+          "v36", "v37", "v38", "v39", "v40", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50",
+          "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+}
+
+// the passes of a wave: per-pass tables by compiled code, the batches by vfill_range_asm
+__device__ __forceinline__ void vfill_stream_asm(const EvRec* __restrict__ sxy,
+                                                 const uint4* __restrict__ coef4,
+                                                 const uint32_t* __restrict__ cutz,
+                                                 char* __restrict__ band_bytes,
+                                                 unsigned long long* __restrict__ scratch,
+                                                 int p_first, int p_end, int lg_pass, int stride,
+                                                 int lane, int nx, int Li, int Ui, int row_base,
+                                                 uint32_t dummy_eo)
+{
+    if (Ui - 1 < Li) return;  // the band accepts no row (the unsigned range test needs Ui-1-Li >= 0)
+    const int pass = 1 << lg_pass;
+    uint32_t cu_next = 0;
+    if (p_first < p_end && lane < pass && p_first + lane < p_end) cu_next = cutz[p_first + lane];
+    for (int pass_base = p_first; pass_base < p_end; pass_base += stride) {
+        const int p = pass_base + lane;
+        const uint32_t cu = cu_next;
+        // the next pass's cut words travel while this pass is voted
+        const int pn = p + stride;
+        cu_next = 0;
+        if (pass_base + stride < p_end && lane < pass && pn < p_end) cu_next = cutz[pn];
+        const int lo = (int)(cu & 0xffffu), hi = (int)(cu >> 16);
+        const int len = max(hi - lo, 0);
+        const int incl = wave_incl_scan(len, lane);
+        const int T = __builtin_amdgcn_readlane(incl, 63);
+        if (T == 0) continue;
+        const int D = (p << 10) + lo - (incl - len);
+        const unsigned long long ne = __builtin_amdgcn_ballot_w64(len > 0);
+        const int c = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ne >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)ne, 0u));
+        const int dst = len > 0 ? c : 63 - (lane - c);  // non-empty runs to lanes 0, 1, ...; the rest behind
+        const int Dc = __builtin_amdgcn_ds_permute(dst << 2, D);
+        const int Pc32 = __builtin_amdgcn_ds_permute(dst << 2, min(p, p_end - 1) << 5);
+        int Cbase = 0;
+        for (int rbase = 0; rbase < T; rbase += 4096) {
+            scratch[lane] = 0ull;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            const int ts = incl - 1 - rbase;  // last slot of this lane's run, relative to the range
+            if (len > 0 && ts >= 0 && ts < 4096) atomicOr(&scratch[ts >> 6], 1ull << (ts & 63));
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            const unsigned long long w = scratch[lane];
+            const int pc = __builtin_popcountll(w);
+            const int inc = wave_incl_scan(pc, lane);
+            const int nb = min(64, (T - rbase + 63) >> 6);
+            vfill_range_asm(sxy, coef4, nb, rbase, T, (uint32_t)w, (uint32_t)(w >> 32), inc - pc + Cbase, Dc,
+                            Pc32, band_bytes, lane, nx, Li, Ui, row_base, dummy_eo);
+            Cbase += __builtin_amdgcn_readlane(inc, 63);
+        }
+    }
+}
+
 // ---- the same hand-scheduled loop over GROUPS of S packets sorted together (lane mapping 4).
 // A run is then S times longer (wide grids: ~19 records per packet and band at 1024 x 1024, which
 // makes the per-packet stream scalar-bound at 4.4 run pieces per batch).  A record's coefficients
@@ -1371,11 +1538,14 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const EvRec* __rest
     // batch does not reach; "its" coefficients are whatever follows the plane's table
     const uint32_t dummy_eo = (uint32_t)np * (uint32_t)kPacket;
     char* band_bytes = reinterpret_cast<char*>(band);
-    if (bp.packed == 5) {
+    if (bp.packed == 5 || bp.packed == 6) {
         // vector fill (wide grids): passes of up to 64 packets, smaller when the chunk has few
-        // packets so that every wave gets >= 2 passes; 64 words of LDS per wave behind the band
+        // packets so that every wave gets >= 2 passes; 64 words of LDS per wave behind the band.
+        // 5 = hand-scheduled batches, 6 = all compiled (A/B tests; also the IEEE-divide planes of 5)
+        // (the per-pass set-up costs a few LDS round trips: as few, as large passes as keep every
+        //  wave busy)
         int lg_pass = 6;
-        while (lg_pass > 3 && (p_end - p_begin) < ((kWaves * 2) << lg_pass)) --lg_pass;
+        while (lg_pass > 3 && (p_end - p_begin) < (kWaves << lg_pass)) --lg_pass;
         if (bp.pass_lg > 0) lg_pass = bp.pass_lg;
         const int pass = 1 << lg_pass;
         unsigned long long* scratch =
@@ -1383,9 +1553,12 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const EvRec* __rest
         if (slow_any[z] != 0)
             vfill_stream<true>(sxy, coef4, cutz, band_bytes, scratch, p_begin + wave * pass, p_end, lg_pass,
                                kWaves * pass, lane, nx, Li, Ui, r0, dummy_eo);
-        else
+        else if (bp.packed == 6)
             vfill_stream<false>(sxy, coef4, cutz, band_bytes, scratch, p_begin + wave * pass, p_end, lg_pass,
                                 kWaves * pass, lane, nx, Li, Ui, r0, dummy_eo);
+        else
+            vfill_stream_asm(sxy, coef4, cutz, band_bytes, scratch, p_begin + wave * pass, p_end, lg_pass,
+                             kWaves * pass, lane, nx, Li, Ui, r0, dummy_eo);
     } else
     // bp.packed == 3 selects the compiled stream on the fast path too (A/B testing)
     if (slow_any[z] != 0)
@@ -2301,6 +2474,51 @@ hipError_t launch_finalize(hipStream_t s, float* acc, size_t n, int mode, int n_
     case 5: break;  // min / max need no finalisation
     default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+// plane-sharded arg-max: (confidence, local index) -> one 64-bit key per pixel whose MAX over the
+// shards is the unsharded collapseMaxZSlice (cartesian3dgrid.cpp:115-137: larger value wins, the
+// smaller plane index on ties).  DSI values are >= 0 (and -0.0 never occurs: sums of >= 0 terms),
+// so their bit patterns order like the floats.
+__global__ __launch_bounds__(256) void k_pack_argmax(const float* __restrict__ conf,
+                                                     const uint8_t* __restrict__ idx, int n,
+                                                     int plane_begin,
+                                                     unsigned long long* __restrict__ keys)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long bits = __float_as_uint(conf[i]);
+    keys[i] = (bits << 8) | (unsigned long long)(255 - ((int)idx[i] + plane_begin));
+}
+
+__global__ __launch_bounds__(256) void k_unpack_argmax(const unsigned long long* __restrict__ keys,
+                                                       int n, const float* __restrict__ planes_full,
+                                                       float* __restrict__ conf,
+                                                       uint8_t* __restrict__ idx,
+                                                       float* __restrict__ depth)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long k = keys[i];
+    const int gi = 255 - (int)(k & 255ull);
+    conf[i] = __uint_as_float((uint32_t)(k >> 8));
+    idx[i] = (uint8_t)gi;
+    depth[i] = planes_full[gi];  // mapper_emvs_stereo.cpp:302-313 over the full depth vector
+}
+
+hipError_t launch_pack_argmax(hipStream_t s, const float* conf, const uint8_t* idx, int n, int plane_begin,
+                              unsigned long long* keys)
+{
+    hipLaunchKernelGGL(k_pack_argmax, dim3((n + 255) / 256), dim3(256), 0, s, conf, idx, n, plane_begin, keys);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack_argmax(hipStream_t s, const unsigned long long* keys, int n, const float* planes_full,
+                                float* conf, uint8_t* idx, float* depth)
+{
+    hipLaunchKernelGGL(k_unpack_argmax, dim3((n + 255) / 256), dim3(256), 0, s, keys, n, planes_full, conf, idx,
+                       depth);
     return hipGetLastError();
 }
 

@@ -1,5 +1,11 @@
-"""Multi-GPU sharding of the DSI path: one process per GPU, torch.distributed
-("nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+"""Multi-GPU sharding of the DSI path: one process per GPU.
+
+The collective itself is the engine's (include/dsi_engine.h "multi-GPU": RCCL called from the C
+ABI, `Comm` / `Grid3D.allReduce` here); the Engine* classes below take the collective as a callable
+`allreduce(grid, op)` so that the same orchestration runs over RCCL (production), over a
+host-staged gloo all-reduce (2-rank tests on one GPU: RCCL allows one rank per device) or over
+nothing (one rank).  The older torch.distributed classes (tensor aliases + ExternalStream) remain
+for callers that already live in torch.
 
 What shards: time slices.  Alg. 2 of the reference (process2.cpp:98-249)
 splits an event stream into `num_subintervals` sub-intervals BY EVENT COUNT, builds one
@@ -224,3 +230,113 @@ class PipelinedTemporalFusion:
             for key in ("acc_main", "acc_side"):
                 if hasattr(s[key], "close"):
                     s[key].close()
+
+
+# ------------------------------------------------------------------ engine-native orchestration
+def engine_allreduce(comm):
+    """allreduce(grid, op) over an engine communicator (RCCL from the C ABI, on the grid's stream)."""
+    def f(grid, op):
+        if comm is not None and comm.size > 1:
+            grid.allReduce(comm, op)
+    return f
+
+
+def host_staged_allreduce(group=None):
+    """allreduce(grid, op) through host memory and torch.distributed (gloo): for tests that put
+    several ranks on ONE GPU, which RCCL refuses.  Synchronises the grid's stream."""
+    def f(grid, op):
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+            return
+        t = torch.from_numpy(grid.download())
+        dist.all_reduce(t, op={0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MIN, 2: dist.ReduceOp.MAX}[int(op)],
+                        group=group)
+        grid.upload(t.numpy())
+    return f
+
+
+class EngineTemporalFusion:
+    """Time-slice sharding (configs[3]; process2.cpp:211-242 across GPUs): every rank accumulates the
+    slices it owns, ONE all-reduce of the accumulator, local finalize.  `mode` is any
+    dsi_acc_mode_t (ACC_INV_SUM = the reference's temporal HM, ACC_SUM = its temporal AM; the n-ary
+    GM / RMS / min / max modes reduce the same way).  The accumulator starts at the mode's identity,
+    so a rank that owns no slice contributes nothing."""
+
+    def __init__(self, ctx, dims, mode, num_slices, allreduce):
+        from .engine import Grid3D, acc_reduce_op
+        nx, ny, nz = dims
+        self.acc = Grid3D(ctx, nx, ny, nz)
+        self.mode, self.n, self.allreduce = int(mode), int(num_slices), allreduce
+        self.op = acc_reduce_op(self.mode)
+        self.reset()
+
+    def reset(self):
+        self.acc.accumulateBegin(self.mode)
+
+    def add(self, dsi):
+        self.acc.accumulate(dsi, self.mode)
+
+    def finish(self):
+        self.allreduce(self.acc, self.op)
+        self.acc.finalize(self.mode, self.n)
+        return self.acc
+
+    def close(self):
+        self.acc.close()
+
+
+class EnginePipelinedTemporalFusion:
+    """EngineTemporalFusion for a stream of rounds (bench steps, sliding windows): round k's
+    all-reduce + finalize + depth-map extraction run on the side context's stream while the main
+    context already votes round k+1.  Ordering is by dsi_context_wait_for only; the host never
+    blocks in submit().  The accumulator is double-buffered and aliased in both contexts."""
+
+    def __init__(self, ctx_main, ctx_side, dims, mode, num_slices, allreduce, extract=None, depth=2):
+        from .engine import Grid3D, acc_reduce_op
+        nx, ny, nz = dims
+        self.ctx_main, self.ctx_side = ctx_main, ctx_side
+        self.mode, self.n, self.allreduce, self.extract = int(mode), int(num_slices), allreduce, extract
+        self.op = acc_reduce_op(self.mode)
+        self.slots = []
+        for _ in range(depth):
+            main = Grid3D(ctx_main, nx, ny, nz)
+            side = Grid3D(ctx_side, nx, ny, nz, device_ptr=main.device_ptr)
+            self.slots.append((main, side))
+        self.k = 0
+
+    def submit(self, fused):
+        main, side = self.slots[self.k % len(self.slots)]
+        if self.k >= len(self.slots):
+            self.ctx_main.wait_for(self.ctx_side)   # the round that used this buffer has left it
+        main.accumulateBegin(self.mode)
+        main.accumulate(fused, self.mode)
+        self.ctx_side.wait_for(self.ctx_main)
+        self.allreduce(side, self.op)
+        side.finalize(self.mode, self.n)
+        if self.extract is not None:
+            self.extract(side)
+        self.k += 1
+        return side
+
+    def drain(self):
+        self.ctx_main.synchronize()
+        self.ctx_side.synchronize()
+
+    def close(self):
+        for main, side in self.slots:
+            side.close()
+            main.close()
+
+
+def plane_sharded_depth_map(mapper, fused_shard, comm=None, group=None):
+    """collapseMaxZSlice of a plane-sharded DSI (configs[4]).  With an engine communicator: ONE
+    RCCL all-reduce(MAX) of packed keys on the device (dsi_mapper_depth_map_sharded).  Without:
+    the same keys through torch.distributed `group` on the host (gloo tests).  Returns
+    (depth, conf, global idx) -- identical on every rank."""
+    if comm is not None:
+        mapper.computeDepthMapSharded(fused_shard, comm)
+        return mapper.fetchDepthMap()
+    conf, idx = fused_shard.collapseMaxZSlice()
+    conf, gidx = allreduce_argmax(conf, idx, mapper.plane_begin, group=group)
+    return mapper.full_depths_[gidx], conf, gidx

@@ -26,7 +26,8 @@ REDUCE_SUM, REDUCE_MIN, REDUCE_MAX = 0, 1, 2
 VOTE_AUTO, VOTE_GLOBAL_ATOMIC, VOTE_LDS_BANDS = 0, 1, 2
 
 (OK, ERR_INVALID, ERR_TOO_FEW_EVENTS, ERR_HIP, ERR_SHAPE, ERR_BAD_OP, ERR_NO_DEVICE,
- ERR_CONTEXT) = range(8)
+ ERR_CONTEXT, ERR_COMM) = range(9)
+COMM_ID_BYTES = 128
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -135,6 +136,16 @@ def load_library():
         "dsi_mapper_set_kernel_timing": (C.c_int, [vp, C.c_int]),
         "dsi_mapper_vote_kernel_time": (C.c_int, [vp, f32p, intp]),
         "dsi_test_div_probe": (C.c_int, [vp, f32p, f32p, C.c_size_t, f32p, f32p]),
+        "dsi_comm_unique_id": (C.c_int, [u8p]),
+        "dsi_comm_create_rank": (C.c_int, [vp, u8p, C.c_int, C.c_int, C.POINTER(vp)]),
+        "dsi_comm_create_all": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(vp)]),
+        "dsi_comm_destroy": (C.c_int, [vp]),
+        "dsi_comm_rank": (C.c_int, [vp]),
+        "dsi_comm_size": (C.c_int, [vp]),
+        "dsi_grid_allreduce": (C.c_int, [vp, vp, C.c_int]),
+        "dsi_grid_allreduce_all": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int]),
+        "dsi_mapper_depth_map_sharded": (C.c_int, [vp, vp, vp]),
+        "dsi_mapper_depth_map_sharded_all": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here = the .so does not export the ABI
@@ -248,6 +259,69 @@ class Context:
         ms = C.c_float()
         _check(load_library().dsi_context_timer_stop(self._h, C.byref(ms)))
         return ms.value
+
+
+class Comm:
+    """One rank of an RCCL communicator created by the engine itself (include/dsi_engine.h,
+    "multi-GPU"): nothing here needs torch.  One process per GPU: rank 0 makes
+    `uid = Comm.unique_id()`, ships the 128 bytes to the other ranks, every rank builds
+    `Comm(ctx, uid, nranks, rank)`.  One process, several GPUs: `Comm.create_all(contexts)`."""
+
+    def __init__(self, ctx, uid, nranks, rank, _handle=None):
+        self.ctx = ctx
+        if _handle is not None:
+            self._h = _handle
+        else:
+            buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(bytes(uid))
+            self._h = C.c_void_p()
+            _check(load_library().dsi_comm_create_rank(ctx._h, buf, int(nranks), int(rank), C.byref(self._h)))
+        _track(self)
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * COMM_ID_BYTES)()
+        _check(load_library().dsi_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def create_all(cls, contexts):
+        n = len(contexts)
+        hs = (C.c_void_p * n)(*[c._h for c in contexts])
+        out = (C.c_void_p * n)()
+        _check(load_library().dsi_comm_create_all(hs, n, out))
+        return [cls(contexts[i], None, n, i, _handle=C.c_void_p(out[i])) for i in range(n)]
+
+    @property
+    def rank(self):
+        return load_library().dsi_comm_rank(self._h)
+
+    @property
+    def size(self):
+        return load_library().dsi_comm_size(self._h)
+
+    def close(self):
+        if self._h:
+            load_library().dsi_comm_destroy(self._h)
+        self._h = C.c_void_p()
+
+    def __del__(self):
+        _safe_del(self)
+
+
+def allreduce_all(comms, grids, op):
+    """All ranks of one process at once (comms from Comm.create_all; grids[i] on comms[i]'s GPU)."""
+    n = len(comms)
+    cs = (C.c_void_p * n)(*[c._h for c in comms])
+    gs = (C.c_void_p * n)(*[g._h for g in grids])
+    _check(load_library().dsi_grid_allreduce_all(cs, gs, n, int(op)))
+
+
+def depth_map_sharded_all(mappers, grids, comms):
+    n = len(comms)
+    ms = (C.c_void_p * n)(*[m._h for m in mappers])
+    gs = (C.c_void_p * n)(*[g._h for g in grids])
+    cs = (C.c_void_p * n)(*[c._h for c in comms])
+    _check(load_library().dsi_mapper_depth_map_sharded_all(ms, gs, cs, n))
 
 
 class Grid3D:
@@ -371,6 +445,11 @@ class Grid3D:
 
     def finalize(self, mode, n):
         _check(load_library().dsi_grid_finalize(self._h, int(mode), int(n)))
+
+    def allReduce(self, comm, op):
+        """In-place RCCL all-reduce over `comm` on this grid's stream (op: REDUCE_SUM/MIN/MAX, or
+        acc_reduce_op(mode) for an accumulator)."""
+        _check(load_library().dsi_grid_allreduce(comm._h, self._h, int(op)))
 
     def setToFusionOfN(self, grids, mode):
         """self = n-ary mean of `grids`: ACC_SUM arithmetic, ACC_LOG_SUM geometric (0 where any
@@ -581,6 +660,12 @@ class MapperEMVS:
     def computeDepthMap(self, grid=None):
         """Asynchronous half of getDepthMapFromDSI; pair with fetchDepthMap()."""
         _check(load_library().dsi_mapper_depth_map_of(self._h, (grid or self.dsi_)._h))
+
+    def computeDepthMapSharded(self, grid, comm):
+        """Plane-sharded arg-max: local collapse of this rank's plane range, ONE all-reduce(MAX) of
+        packed (confidence, index) keys, index -> depth over the full depth vector; fetchDepthMap()
+        then returns the unsharded result on every rank."""
+        _check(load_library().dsi_mapper_depth_map_sharded(self._h, (grid or self.dsi_)._h, comm._h))
 
     def fetchDepthMap(self):
         depth = np.empty((self.dimY, self.dimX), np.float32)

@@ -50,7 +50,8 @@ typedef enum {
     DSI_ERR_SHAPE = 4,         /* grids of different dimensions (reference: std::out_of_range from .at()) */
     DSI_ERR_BAD_OP = 5,        /* "Improper fusion method selected" (process1.cpp:155-157) */
     DSI_ERR_NO_DEVICE = 6,     /* no usable gfx950 GPU */
-    DSI_ERR_CONTEXT = 7        /* objects belong to different devices (or a batch to another context) */
+    DSI_ERR_CONTEXT = 7,       /* objects belong to different devices (or a batch to another context) */
+    DSI_ERR_COMM = 8           /* RCCL could not be loaded or a collective call failed */
 } dsi_status_t;
 
 /* camera-fusion op codes = --stereo_fusion values (main.cpp:89, process1.cpp:136-158) */
@@ -166,6 +167,35 @@ DSI_API int dsi_grid_collapse_max_z_dev(dsi_grid_t *g, float *conf_dev, uint8_t 
 /* Grid3D::computeMeanSquare (cartesian3dgrid.cpp:164-174), accumulated in double */
 DSI_API int dsi_grid_mean_square(dsi_grid_t *g, double *out);
 
+/* ---------------------------------------------------------- multi-GPU (RCCL) */
+/* The temporal fusion of process_2 (process2.cpp:211-242: one accumulate per sub-interval, one
+ * finalize) and of the sliding window (main.cpp:177) shards by time slice: every GPU accumulates
+ * its slices locally, then ONE all-reduce of the accumulator over xGMI replaces the rest of the
+ * loop.  The engine calls RCCL itself (librccl is loaded on first use; nothing
+ * above this ABI needs torch or MPI).  Two ways to form a communicator:
+ *   - one process, n GPUs (the reference is one process): dsi_comm_create_all over n contexts on n
+ *     distinct devices; collectives through the *_all entry points (one group call);
+ *   - one process per GPU: rank 0 calls dsi_comm_unique_id and hands the 128 bytes to the other
+ *     ranks by any side channel (file, socket, MPI, a torch.distributed store), then every rank
+ *     calls dsi_comm_create_rank.
+ * A collective on a grid is issued on that grid's context stream, ordered like any other grid
+ * operation; the host does not wait. */
+typedef struct dsi_comm dsi_comm_t;
+#define DSI_COMM_ID_BYTES 128
+DSI_API int dsi_comm_unique_id(uint8_t id[DSI_COMM_ID_BYTES]);
+DSI_API int dsi_comm_create_rank(dsi_context_t *ctx, const uint8_t id[DSI_COMM_ID_BYTES], int nranks, int rank,
+                                 dsi_comm_t **out);
+/* out receives n communicators, out[i] on contexts[i]'s device (n distinct devices) */
+DSI_API int dsi_comm_create_all(dsi_context_t *const *contexts, int n, dsi_comm_t **out);
+DSI_API int dsi_comm_destroy(dsi_comm_t *comm);
+DSI_API int dsi_comm_rank(const dsi_comm_t *comm);
+DSI_API int dsi_comm_size(const dsi_comm_t *comm);
+/* in-place all-reduce of a grid over the communicator, op = dsi_reduce_op_t (use
+ * dsi_acc_reduce_op(mode) for an accumulator).  The grid must live on the communicator's device. */
+DSI_API int dsi_grid_allreduce(dsi_comm_t *comm, dsi_grid_t *g, int op);
+/* the same for the n ranks of one process (comms from dsi_comm_create_all, grids[i] on comms[i]) */
+DSI_API int dsi_grid_allreduce_all(dsi_comm_t *const *comms, dsi_grid_t *const *grids, int n, int op);
+
 /* --------------------------------------------------------------- MapperEMVS */
 typedef struct {
     int sensor_width;   /* cam.fullResolution() (mapper_emvs_stereo.cpp:34-36) */
@@ -209,7 +239,8 @@ DSI_API int dsi_mapper_set_band_params(dsi_mapper_t *m, int band_rows, int chunk
  * 3 = packed with the compiled (not hand-scheduled) wave loop, for A/B tests,
  * 4 = groups with the hand-scheduled wave loop (long runs for wide grids),
  * 5 = packed with a vector (prefix-sum + tail-bit) slot -> record mapping instead of the scalar run
- *     bookkeeping (short runs: wide grids). */
+ *     bookkeeping (short runs: wide grids), hand-scheduled batches,
+ * 6 = mapping 5 all compiled, for A/B tests. */
 DSI_API int dsi_mapper_set_packed_lanes(dsi_mapper_t *m, int mode);
 
 /* MapperEMVS::fillVoxelGrid(event_locations_z0, camera_centers)
@@ -264,6 +295,17 @@ DSI_API int dsi_mapper_depth_map(dsi_mapper_t *m, float *depth_host, float *conf
  * keeps results in the mapper's device buffers until dsi_mapper_fetch_depth_map */
 DSI_API int dsi_mapper_depth_map_of(dsi_mapper_t *m, dsi_grid_t *g);
 DSI_API int dsi_mapper_fetch_depth_map(dsi_mapper_t *m, float *depth_host, float *conf_host, uint8_t *idx_host);
+
+/* Plane sharding (one DSI too big or too slow for one GPU): every rank's mapper owns a
+ * plane range (dsi_mapper_config_t.plane_begin / plane_count) and grid g holds that range of the
+ * (fused) DSI.  collapseMaxZSlice of the whole DSI = local collapse, then ONE all-reduce(MAX) of
+ * 64-bit keys (confidence bits << 8 | 255 - global plane index: larger confidence wins, on equal
+ * confidence the smaller index -- the first-maximum rule of std::max_element,
+ * cartesian3dgrid.cpp:115-137), then index -> depth over the FULL depth vector.  Results stay in
+ * the mapper's device buffers (dsi_mapper_fetch_depth_map), identical on every rank. */
+DSI_API int dsi_mapper_depth_map_sharded(dsi_mapper_t *m, dsi_grid_t *g, dsi_comm_t *comm);
+DSI_API int dsi_mapper_depth_map_sharded_all(dsi_mapper_t *const *mappers, dsi_grid_t *const *grids,
+                                             dsi_comm_t *const *comms, int n);
 
 /* OptionsDepthMap (mapper_emvs_stereo.hpp:68-82), the fields the depth-map extraction reads */
 typedef struct {
