@@ -1,24 +1,32 @@
 #!/usr/bin/env python
 """bench.py -- DSI build + fuse + arg-max throughput on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload stereo|windows|cameras4]
 
-One "step" = one pass of the hot path over one stereo batch that is already resident
-in HBM:  for each of the 2 cameras  evaluateDSI past the pose lookup (per-packet
-homography, z0 warp, reset, voting; mapper_emvs_stereo.cpp:108-146), then camera fusion
-(harmonic mean, process1.cpp:126-141), then arg-max + depth (cartesian3dgrid.cpp:115-137,
-mapper_emvs_stereo.cpp:302-313).  At N = 1 this is BASELINE.json configs[1]:
-"Stereo (2-cam) DSEC, 10 M events/cam, 346x260x100 DSI, harmonic fusion, 1xMI355X".
+Workloads (a "step" = one pass of the hot path over one batch of synthetic input already
+resident in HBM):
 
-N > 1 (one process per GPU, launched by torch.distributed.run): every rank owns an
-independent time slice of the same size (weak scaling, configs[3] shape), builds and
-camera-fuses its DSI, then the slices are fused across time with the reference's
-harmonic accumulator (process2.cpp:217-226): local 1/(0.01+v), ONE RCCL all-reduce(sum)
-of the 36 MB volume over xGMI, local n/acc, arg-max -- issued on a second HIP stream so that it
-overlaps the next step's voting (every step's fusion is complete before the closing barrier).
-value = events voted by all ranks / max-over-ranks time.
+  stereo   (default; BASELINE.json configs[1], the configuration `metric` is quoted on)
+           2 cameras x 10 M events, 346x260x100: per camera evaluateDSI past the pose lookup
+           (per-packet homography, z0 warp, reset, voting; mapper_emvs_stereo.cpp:108-146), camera
+           fusion (harmonic mean, process1.cpp:126-141), arg-max + depth
+           (cartesian3dgrid.cpp:115-137, mapper_emvs_stereo.cpp:302-313).
+           N > 1 (one process per GPU): every rank owns an independent time slice of the same size
+           (weak scaling, configs[3]); the slices are fused across time with the reference's
+           harmonic accumulator (process2.cpp:217-226): local 1/(0.01+v), ONE RCCL all-reduce(sum)
+           of the volume over xGMI -- issued by the ENGINE (C ABI, dsi_grid_allreduce) on a second
+           HIP stream so that it overlaps the next step's voting -- local n/acc, arg-max.
+  windows  configs[2]: stream of 50 ms windows, 2 cameras x 500 k events each, sensor 640x480, DSI
+           512x512x200 (main.cpp:174-302 with process_method 1): a step = one window = reset +
+           vote x2 + HM + arg-max; the depth map of window w is fetched while w+1 is queued.
+           N > 1: independent windows round-robin over the ranks (replicas, no collective).
+  cameras4 configs[4] shape: 4 cameras, 1024x1024x256, n-ary geometric-mean camera fusion
+           (--events per camera, default 2 M).  N > 1: plane sharding -- every rank owns a plane
+           range of every camera's DSI, the only exchange is ONE all-reduce(MAX) of packed arg-max
+           keys (strong scaling: the total work is fixed).
 
-Prints ONE JSON line (rank 0).  Data: synthetic (dvs_mcemvs_amd/synthetic.py).
+value = events voted by all ranks / max-over-ranks time.  Prints ONE JSON line (rank 0).
+Data: synthetic (dvs_mcemvs_amd/synthetic.py).
 """
 import argparse
 import json
@@ -32,127 +40,437 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+CU, LANES, CLK = 256, 64, 2.4e9
+LDS_CLK_CONFLICT_FREE = 6.2     # clocks per ds_add_u64 wave instruction, conflict-free addresses
+LDS_CLK_RANDOM = 11.2           # ... random cells of a band (profiles/r01_microbench_lds_atomic_bench2.txt)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--events", type=int, default=10_000_000, help="events per camera per GPU")
-    ap.add_argument("--dims", type=int, nargs=3, default=[346, 260, 100])
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=["stereo", "windows", "cameras4"], default="stereo")
+    ap.add_argument("--events", type=int, default=None, help="events per camera per GPU (per window for `windows`)")
+    ap.add_argument("--dims", type=int, nargs=3, default=None)
     ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 global atomics, 2 LDS bands")
     ap.add_argument("--band", type=int, nargs=3, default=[0, 0, 0], help="band_rows chunks block")
     ap.add_argument("--points", type=int, default=5000, help="scene points of the synthetic rig (SURVEY 8d: 2000-20000)")
-    ap.add_argument("--packed", type=int, default=-1, help="-1 auto (= 1), 0 per-packet waves, 1 packed lanes (hand-scheduled), 2 packet groups, 3 packed (compiled loop), 4 packet groups (hand-scheduled), 5 packed with vector fill")
-    ap.add_argument("--cpu-sample", type=int, default=10_000_000,
-                    help="events of camera 0 the CPU oracle is timed on (0 = skip)")
+    ap.add_argument("--packed", type=int, default=-1,
+                    help="lane mapping: -1 auto, 0 per-packet waves, 1 packed (hand-scheduled), 2 packet groups, "
+                         "3 packed (compiled), 4 groups (hand-scheduled), 5 packed + vector fill, 6 = 5 compiled")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="2: each camera's mapper on its own HIP stream (context), meeting at the fusion")
-    return ap.parse_args()
+    ap.add_argument("--collective", choices=["engine", "torch"], default="engine",
+                    help="N > 1: who issues the all-reduce: the engine's own RCCL communicator (C ABI) or "
+                         "torch.distributed")
+    a = ap.parse_args()
+    defaults = {"stereo": ((346, 260, 100), 10_000_000, 100, 5), "windows": ((512, 512, 200), 500_000, 100, 8),
+                "cameras4": ((1024, 1024, 256), 2_000_000, 5, 1)}[a.workload]
+    a.dims = a.dims or list(defaults[0])
+    a.events = a.events or defaults[1]
+    a.steps = a.steps if a.steps is not None else defaults[2]
+    a.warmup = a.warmup if a.warmup is not None else defaults[3]
+    return a
+
+
+class Dist:
+    """Rendezvous / barrier / scalar max over the ranks.  torch.distributed is plumbing here: with
+    --collective engine it runs on gloo (CPU) and only carries the RCCL unique id, the barriers and
+    two scalars; the data-path collective is the engine's."""
+
+    def __init__(self, args):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist = self.torch = None
+        self.backend = None
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            import torch
+            import torch.distributed as dist
+            self.torch, self.dist = torch, dist
+            if args.collective == "torch":
+                torch.cuda.set_device(self.local_rank)
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                                        device_id=torch.device("cuda", self.local_rank))
+                self.backend = "nccl"
+            else:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+                self.backend = "gloo"
+
+    def barrier(self):
+        if self.dist is not None:
+            if self.backend == "nccl":
+                self.torch.cuda.synchronize()
+            self.dist.barrier()
+
+    def _dev(self):
+        return "cuda" if self.backend == "nccl" else "cpu"
+
+    def max(self, v):
+        if self.dist is None:
+            return float(v)
+        t = self.torch.tensor([float(v)], dtype=self.torch.float64, device=self._dev())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum(self, v):
+        if self.dist is None:
+            return float(v)
+        t = self.torch.tensor([float(v)], dtype=self.torch.float64, device=self._dev())
+        self.dist.all_reduce(t)
+        return float(t.item())
+
+    def broadcast_bytes(self, b):
+        if self.dist is None:
+            return b
+        obj = [b]
+        self.dist.broadcast_object_list(obj, src=0)
+        return obj[0]
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def make_comm(d, dd, ctx, D, args):
+    """(allreduce callable, comm or None, description).  The engine communicator is tried first; if
+    RCCL cannot be initialised through the C ABI on this box the torch.distributed path is used and
+    the JSON line says so (never silently)."""
+    if D.world == 1:
+        return dd.engine_allreduce(None), None, "none (1 rank)"
+    if args.collective == "engine":
+        err = None
+        try:
+            uid = d.Comm.unique_id() if D.rank == 0 else None
+        except d.DsiError as e:
+            uid, err = None, str(e)
+        uid = D.broadcast_bytes((uid, err))
+        if uid[0] is not None:
+            comm = d.Comm(ctx, uid[0], D.world, D.rank)
+            return dd.engine_allreduce(comm), comm, "RCCL from the engine's C ABI (dsi_grid_allreduce)"
+        raise RuntimeError("engine RCCL communicator failed: %s (rerun with --collective torch)" % uid[1])
+    return None, None, "torch.distributed nccl"
+
+
+def lds_block(accepted, kern_ms):
+    adds = 4.0 * accepted / (kern_ms * 1e-3)
+    lane_rate = CU * LANES * CLK
+    return adds, lane_rate / LDS_CLK_CONFLICT_FREE, lane_rate / LDS_CLK_RANDOM
+
+
+def roofline_block(info, kern_ms, kt_n, accepted, ev_per_launch, nz, traffic):
+    """The voting kernel is an LDS-privatised scatter-add: what bounds it is the rate of 64-bit LDS
+    atomic adds (4 per accepted event-plane).  peak = 256 CU x 64 lanes x 2.4 GHz / 6.2 clocks per
+    ds_add_u64 wave instruction (conflict-free addresses; guide LDS section ~6, measured 6.1-6.2).
+    The HBM view is reported beside it: measured fabric traffic / kernel time against 8 TB/s, and
+    the SURVEY 8(d) "algorithmic bytes" figure (32*Nz+8 B per event as if every vote were an HBM
+    read-modify-write), which is NOT a bound for this kernel (it exceeds the HBM peak)."""
+    kernel = {0: "k_vote_bands", 1: "k_vote_bands_packed", 2: "k_vote_groups", 3: "k_vote_bands_packed",
+              4: "k_vote_groups", 5: "k_vote_bands_packed", 6: "k_vote_bands_packed"}[info["packed"]] \
+        if info["algo"] == 2 else "k_vote_global"
+    if not kt_n:
+        return {"bound": "lds_atomic", "achieved": None, "peak": None, "unit": "G adds/s", "frac": None,
+                "traffic": traffic, "kernel": kernel}
+    adds, peak, rnd = lds_block(accepted, kern_ms)
+    alg_bytes = (32.0 * nz + 8.0) * ev_per_launch
+    out = {"bound": "lds_atomic", "achieved": adds / 1e9, "peak": peak / 1e9,
+           "unit": "G 64-bit LDS atomic adds/s", "frac": adds / peak, "traffic": traffic,
+           "kernel": kernel, "kernel_avg_ms": kern_ms, "kernel_launches": kt_n,
+           "accepted_event_planes_per_launch": accepted,
+           "rate_random_cells": rnd / 1e9, "frac_of_random_cell_rate": adds / rnd,
+           "kernel_Mevents_per_s": ev_per_launch / (kern_ms * 1e-3) / 1e6,
+           "hbm_algorithmic_equiv": {"bytes_per_launch": alg_bytes,
+                                     "GBps": alg_bytes / (kern_ms * 1e-3) / 1e9,
+                                     "note": "SURVEY 8(d) byte model; not a bound (votes never leave LDS)"}}
+    if traffic:
+        gbps = traffic / (kern_ms * 1e-3) / 1e9
+        out["hbm"] = {"achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                      "traffic_over_algorithmic": traffic / alg_bytes,
+                      "source": "profiles/traffic.json (2*FETCH_SIZE + WRITE_SIZE PMC passes of this kernel)"}
+    return out
+
+
+def stream_kernels(d, ctx):
+    """DSI-fuse and arg-max as HBM-bandwidth kernels: on a 512x512x200 pair (210 MB per volume, above
+    the 256 MiB Infinity Cache for the 3 volumes of a fuse) whatever the workload's grid is."""
+    nx, ny, nz = 512, 512, 200
+    a, b = d.Grid3D(ctx, nx, ny, nz), d.Grid3D(ctx, nx, ny, nz)
+    cam = (nx, ny, 400.0, 400.0, 256.0, 256.0)
+    m = d.MapperEMVS(ctx, cam, d.ShapeDSI(0, 0, nz, 1.0, 10.0, 0.0))
+    rng = np.random.default_rng(1)
+    vol = rng.random((nz, ny, nx), dtype=np.float32)
+    a.upload(vol)
+    b.upload(vol[::-1].copy())
+    reps = 30
+    out = {}
+    nvox = nx * ny * nz
+    for name, fn, nbytes in (("dsi_fuse", lambda: a.harmonicMeanTwoGrids(b), 12.0 * nvox),
+                             ("dsi_fuse_into", lambda: m.dsi_.setToFusionOf(a, b, d.FUSE_HM), 12.0 * nvox),
+                             ("nary_accumulate_log", lambda: a.accumulate(b, d.ACC_LOG_SUM), 12.0 * nvox),
+                             ("argmax", lambda: m.computeDepthMap(a), (4.0 * nz + 9.0) * nx * ny)):
+        fn()
+        ctx.timer_start()
+        for _ in range(reps):
+            fn()
+        ms = ctx.timer_stop() / reps
+        out[name] = {"ms": ms, "GBps": nbytes / (ms * 1e-3) / 1e9,
+                     "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    out["grid"] = "%dx%dx%d (%.0f MB per volume)" % (nx, ny, nz, 4.0 * nvox / 1e6)
+    for o in (m, a, b):
+        o.close()
+    return out
+
+
+def cpu_baseline(d, rig, dims, n_sample):
+    """The oracle (a port of the reference's CPU path, oracle/) on the GPU box's host cores, same
+    workload: stage A + reset + fillVoxelGrid of camera 0 (OpenMP over planes like the reference,
+    mapper_emvs_stereo.cpp:168), built with the reference's flags (-O3, no -march=native) and as
+    "tuned" (-O3 -march=native); best of 5 after a warm-up; one thread on a 1/16 sample; plus the CPU
+    fusion (harmonic mean) and arg-max of the same grid."""
+    from oracle import oracle as orc
+    from oracle_pipeline import OracleMapper
+    nx, ny, nz = dims
+    n_s = min(n_sample, rig["events"][0][0].shape[0])
+    x, y, ts = (a[:n_s] for a in rig["events"][0])
+    first, Rt = d.packetize(ts, rig["trajectories"][0], rig["T_rv_w"])
+    first = first.astype(np.int64)
+    out = {}
+
+    def run(tag):
+        r = OracleMapper(rig["cam"], dimX=nx, dimY=ny, dimZ=nz, min_depth=4.0, max_depth=200.0)
+        r.evaluate_packets(x, y, first[:64], Rt[:64])      # warm-up (page in, spin up OpenMP)
+        best = float("inf")
+        for _ in range(5):
+            t1 = time.perf_counter()
+            r.evaluate_packets(x, y, first, Rt)             # stage A + reset + fillVoxelGrid
+            best = min(best, time.perf_counter() - t1)
+        out[tag] = first.shape[0] * 1024 / best / 1e6
+        return r, best
+
+    r, tc = run("value")
+    n1 = max(64, first.shape[0] // 16)
+    all_threads = orc.num_threads()
+    orc.set_num_threads(1)
+    t1 = time.perf_counter()
+    r.evaluate_packets(x, y, first[:n1], Rt[:n1])
+    out["one_thread_value"] = n1 * 1024 / (time.perf_counter() - t1) / 1e6
+    orc.set_num_threads(all_threads)
+    # CPU fusion + arg-max on the same grid (the reference runs them single-threaded,
+    # cartesian3dgrid.h:63 "do not use parallelization yet")
+    g2 = r.dsi[::-1].copy()
+    best_f = best_a = float("inf")
+    for _ in range(5):
+        t1 = time.perf_counter()
+        orc.fuse2(r.dsi, g2, 2)
+        best_f = min(best_f, time.perf_counter() - t1)
+        t1 = time.perf_counter()
+        orc.collapse_max_z(r.dsi)
+        best_a = min(best_a, time.perf_counter() - t1)
+    nvox = nx * ny * nz
+    out["fuse_ms"] = best_f * 1e3
+    out["fuse_GBps"] = 12.0 * nvox / best_f / 1e9
+    out["argmax_ms"] = best_a * 1e3
+    out["argmax_GBps"] = (4.0 * nz + 9.0) * nx * ny / best_a / 1e9
+    try:
+        orc.use_native(True)                                # -O3 -march=native build, compiled on this box
+        _, tn = run("tuned_value")
+        out["tuned_flags"] = "-O3 -march=native -fopenmp -ffp-contract=off"
+    except Exception as e:                                  # no compiler on the box: report, do not fail
+        out["tuned_value"] = None
+        out["tuned_error"] = str(e)[:200]
+    finally:
+        orc.use_native(False)
+    out.update({"unit": "Mevents/s", "cores": min(all_threads, nz), "kind": "port",
+                "sample": "camera 0, first %d events (%d packets) of the same workload, %dx%dx%d DSI; oracle stage A + "
+                          "fillVoxelGrid, OpenMP over planes (reference strategy: at most dimZ threads busy of %d "
+                          "visible), -O3 no -march=native (reference flags); best of 5 after warm-up, %.2f s per run"
+                          % (n_s, first.shape[0], nx, ny, nz, all_threads, tc)})
+    return out
 
 
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    torch = None
-    use_dist = world > 1 or os.environ.get("DSI_BENCH_FORCE_DIST") == "1"  # the env knob lets a
-    # 1-GPU box exercise the torch.distributed/RCCL code path (world_size 1)
-    if use_dist:
-        # torch first: libdsi_engine.so then binds to the HIP runtime torch already loaded,
-        # so that RCCL (torch.distributed "nccl") and the engine share one runtime.
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+    D = Dist(args)
+    world, rank = D.world, D.rank
     if args.gpus != world and rank == 0:
-        print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world),
-              file=sys.stderr)
+        print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
     import __graft_entry__ as ge
     if rank == 0:
         ge.build()
-    if dist is not None:
-        dist.barrier()
+    D.barrier()
     import dvs_mcemvs_amd as d
-    from dvs_mcemvs_amd import synthetic as syn
+    from dvs_mcemvs_amd import distributed as dd, process as proc, synthetic as syn
 
     nx, ny, nz = args.dims
-    ctx = d.Context(local_rank)
+    ctx = d.Context(D.local_rank)
+    allreduce, comm, collective = make_comm(d, dd, ctx, D, args)
 
-    # ---- inputs: one stereo time slice per rank, generated and uploaded before timing ----
-    t_gen = time.time()
-    rig = syn.stereo_rig(args.events, width=nx, height=ny, t0=10.0 + 0.5 * rank, duration=0.5,
-                         seed=1234 + 100 * rank, n_points=args.points)
-    shape = d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0)  # cfg/DSEC/zurich_04_a_full/dsec.conf:11-12,17
-    mappers, batches, voted = [], [], 0
-    ctx_cam1 = d.Context(local_rank) if args.streams == 2 else ctx
-    cam_ctx = [ctx, ctx_cam1]
-    for c in range(2):
-        m = d.MapperEMVS(cam_ctx[c], rig["cam"], shape)
+    def tune(m):
         m.set_vote_algo(args.algo)
         m.set_band_params(*args.band)
         m.set_packed_lanes(args.packed)
-        first, Rt = d.packetize(rig["events"][c][2], rig["trajectories"][c], rig["T_rv_w"])
-        batches.append(d.EventBatch(cam_ctx[c], rig["events"][c][0], rig["events"][c][1], Rt, first))
-        voted += first.shape[0] * d.PACKET_SIZE
-        mappers.append(m)
-    fused = d.Grid3D(ctx, nx, ny, nz)
+        return m
+
+    t_gen = time.time()
+    extra = {}
+    closers = []
+    vote_mappers = []
+
+    if args.workload == "stereo":
+        # ---- one stereo time slice per rank, generated and uploaded before timing ----
+        rig = syn.stereo_rig(args.events, width=nx, height=ny, t0=10.0 + 0.5 * rank, duration=0.5,
+                             seed=1234 + 100 * rank, n_points=args.points)
+        shape = d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0)   # cfg/DSEC/zurich_04_a_full/dsec.conf:11-12,17
+        mappers, batches, voted = [], [], 0
+        for c in range(2):
+            m = tune(d.MapperEMVS(ctx, rig["cam"], shape))
+            first, Rt = d.packetize(rig["events"][c][2], rig["trajectories"][c], rig["T_rv_w"])
+            batches.append(d.EventBatch(ctx, rig["events"][c][0], rig["events"][c][1], Rt, first))
+            voted += first.shape[0] * d.PACKET_SIZE
+            mappers.append(m)
+        vote_mappers = mappers
+        fused = d.Grid3D(ctx, nx, ny, nz)
+        closers += mappers + batches + [fused]
+        temporal = None
+        if world > 1:
+            ctx_side = d.Context(D.local_rank)
+            mapper_fused = d.MapperEMVS(ctx_side, rig["cam"], shape)
+            if allreduce is not None:
+                temporal = dd.EnginePipelinedTemporalFusion(ctx, ctx_side, (nx, ny, nz), d.ACC_INV_SUM, world,
+                                                            allreduce, extract=mapper_fused.computeDepthMap)
+            else:
+                temporal = dd.PipelinedTemporalFusion.on_gpu(ctx, ctx_side, (nx, ny, nz), d.ACC_INV_SUM, world,
+                                                             extract=mapper_fused.computeDepthMap)
+            fused.resetGrid()
+            temporal.submit(fused)      # one un-timed round: set-up problems show up here on every rank
+            temporal.drain()
+
+        def step():
+            for c in range(2):
+                mappers[c].evaluateDSI_batch(batches[c])
+            # process1.cpp:126-141 (resetGrid; addTwoGrids(dsi0); harmonicMeanTwoGrids(dsi1)) in one pass
+            fused.setToFusionOf(mappers[0].dsi_, mappers[1].dsi_, d.FUSE_HM)
+            if temporal is None:
+                mappers[0].computeDepthMap(fused)
+            else:
+                temporal.submit(fused)   # process2.cpp:220 + ONE all-reduce(sum) + n/acc + arg-max, side stream
+
+        def sync():
+            ctx.synchronize()
+            if temporal is not None:
+                temporal.drain()
+
+        voted_per_step = voted
+        workload = ("stereo (2-cam) synthetic DSEC-like rig, %d events/cam per GPU, %dx%dx%d DSI, harmonic camera "
+                    "fusion + arg-max%s" % (args.events, nx, ny, nz, "" if world == 1 else
+                                            ", %d time slices (one per GPU) fused by ONE all-reduce of inverse sums"
+                                            % world))
+        parallelism, scaling = ("1 GPU" if world == 1 else "time-slice x%d" % world), "weak"
+        ev_per_launch = voted / 2.0
+
+    elif args.workload == "windows":
+        # ---- configs[2]: 8 distinct 50 ms windows (cycled), resident in HBM as packetised batches ----
+        n_distinct = 8
+        dur = args.events / 10.0e6                    # 10 Mev/s per camera
+        rig = syn.stereo_rig(n_distinct * args.events, width=640, height=480, t0=10.0 + 10.0 * rank,
+                             duration=n_distinct * dur, seed=77 + rank, n_points=max(args.points, 6000))
+        shape = d.ShapeDSI(nx, ny, nz, 4.0, 200.0, 0.0)
+        ws = proc.WindowStream(ctx, (rig["cam"],) * 2, shape, d.FUSE_HM)
+        for m in ws.mappers:
+            tune(m)
+        vote_mappers = ws.mappers
+        bounds = proc.window_bounds(rig["t0"], rig["t1"] + 1e-9, dur, dur)[:n_distinct]
+        wins, host_wins = [], []
+        for a, b in bounds:
+            T_rv_w = proc.reference_view_process1(rig["trajectories"][0], b)
+            per_cam, host = [], []
+            for c in range(2):
+                ev = proc.window_events(rig["events"][c], a, b)
+                first, Rt = d.packetize(ev[2], rig["trajectories"][c], T_rv_w)
+                per_cam.append(d.EventBatch(ctx, ev[0], ev[1], Rt, first))
+                host.append(ev)
+            wins.append((per_cam, b))
+            host_wins.append((host, b))
+            closers += per_cam
+        closers.append(ws)
+        state = {"w": 0, "pending": None}
+
+        def step():
+            per_cam, ts = wins[state["w"] % len(wins)]
+            slot = ws.submit(None, rig["trajectories"], ts, batches=per_cam)
+            if state["pending"] is not None:
+                ws.fetch(state["pending"])            # depth map of the previous window (device -> host)
+            state["pending"] = slot
+            state["w"] += 1
+
+        def sync():
+            if state["pending"] is not None:
+                ws.fetch(state["pending"])
+                state["pending"] = None
+            ctx.synchronize()
+
+        voted_per_step = float(np.mean([sum(b.n_packets for b in pc) for pc, _ in wins])) * d.PACKET_SIZE
+        workload = ("stream of %.0f ms windows (main.cpp:177 loop), 2 cameras x %d events per window, sensor 640x480, "
+                    "%dx%dx%d DSI, per window: reset + vote x2 + harmonic camera fusion + arg-max + depth-map fetch"
+                    % (dur * 1e3, args.events, nx, ny, nz))
+        parallelism = "1 GPU" if world == 1 else "replicas x%d (independent windows, no collective)" % world
+        scaling = "weak"
+        ev_per_launch = voted_per_step / 2.0
+        extra["host_windows"] = host_wins
+
+    else:
+        # ---- configs[4] shape: 4 cameras, n-ary GM; N > 1: plane sharding ----
+        rig = syn.stereo_rig(args.events, width=nx, height=ny, t0=10.0, duration=0.5, seed=1234, n_cams=4,
+                             n_points=args.points)
+        shape = d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0)
+        begin, count = dd.plane_ranges(nz, world)[rank]
+        mappers, batches, voted = [], [], 0
+        for c in range(4):
+            m = tune(d.MapperEMVS(ctx, rig["cam"], shape, plane_range=(begin, count)))
+            first, Rt = d.packetize(rig["events"][c][2], rig["trajectories"][c], rig["T_rv_w"])
+            batches.append(d.EventBatch(ctx, rig["events"][c][0], rig["events"][c][1], Rt, first))
+            voted += first.shape[0] * d.PACKET_SIZE
+            mappers.append(m)
+        vote_mappers = mappers
+        fused = d.Grid3D(ctx, nx, ny, count)
+        closers += mappers + batches + [fused]
+        if world > 1 and comm is None:
+            raise RuntimeError("cameras4 with N > 1 needs --collective engine")
+
+        def step():
+            for c in range(4):
+                mappers[c].evaluateDSI_batch(batches[c])
+            fused.setToFusionOfN([m.dsi_ for m in mappers], d.ACC_LOG_SUM)     # n-ary GM, voxel-wise, local
+            if comm is None:
+                mappers[0].computeDepthMap(fused)
+            else:
+                mappers[0].computeDepthMapSharded(fused, comm)                  # ONE all-reduce(MAX) of keys
+
+        def sync():
+            ctx.synchronize()
+
+        # every rank votes ALL events into its plane range: the job's events are counted once
+        voted_per_step = voted if rank == 0 else 0.0
+        workload = ("4-camera synthetic rig, %d events/cam, %dx%dx%d DSI, n-ary geometric-mean camera fusion + arg-max%s"
+                    % (args.events, nx, ny, nz, "" if world == 1 else ", planes sharded over %d GPUs" % world))
+        parallelism, scaling = ("1 GPU" if world == 1 else "plane-shard x%d" % world), "strong"
+        ev_per_launch = voted / 4.0
     t_gen = time.time() - t_gen
 
-    temporal = None
-    if use_dist:
-        # temporal fusion across ranks, pipelined: round k's all-reduce + finalize + arg-max run on
-        # a second HIP stream (its own context + the reference's "mapper_fused") while the main
-        # stream already votes round k+1
-        from dvs_mcemvs_amd import distributed as dd
-        ctx_side = d.Context(local_rank)
-        mapper_fused = d.MapperEMVS(ctx_side, rig["cam"], shape)
-        temporal = dd.PipelinedTemporalFusion.on_gpu(ctx, ctx_side, (nx, ny, nz), d.ACC_INV_SUM, world,
-                                                     extract=mapper_fused.computeDepthMap)
-        # one un-timed round now: any problem with the two-stream / RCCL set-up shows up here, on
-        # every rank, before the warm-up
-        fused.resetGrid()
-        temporal.submit(fused)
-        temporal.drain()
-
-    def step():
-        if ctx_cam1 is not ctx:
-            ctx_cam1.wait_for(ctx)        # the previous step's fusion has read camera 1's DSI
-        for c in range(2):
-            mappers[c].evaluateDSI_batch(batches[c])
-        if ctx_cam1 is not ctx:
-            ctx.wait_for(ctx_cam1)        # fusion after both cameras
-        # process1.cpp:126-141 (resetGrid; addTwoGrids(dsi0); harmonicMeanTwoGrids(dsi1)) in one pass
-        fused.setToFusionOf(mappers[0].dsi_, mappers[1].dsi_, d.FUSE_HM)
-        if temporal is None:
-            mappers[0].computeDepthMap(fused)
-        else:
-            # process2.cpp:220: acc += 1/(0.01 + fused); ONE RCCL all-reduce(sum) over xGMI; n/acc; arg-max
-            temporal.submit(fused)
-
     def barrier():
-        ctx.synchronize()
-        ctx_cam1.synchronize()
-        if temporal is not None:
-            temporal.drain()
-        if dist is not None:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+        sync()
+        D.barrier()
+        sync()
 
     for _ in range(args.warmup):
         step()
     barrier()
-    for m in mappers:
+    for m in vote_mappers:
         m.set_kernel_timing(True)
         m.vote_kernel_time()
     t0 = time.perf_counter()
@@ -163,174 +481,112 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kt_ms, kt_n = 0.0, 0
-    for m in mappers:
+    for m in vote_mappers:
         ms, n = m.vote_kernel_time()
         kt_ms += ms
         kt_n += n
         m.set_kernel_timing(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        v = torch.tensor([float(voted)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(v)
-        voted_all = float(v.item())
-    else:
-        voted_all = float(voted)
+    elapsed = D.max(elapsed)
+    voted_all = D.sum(voted_per_step)
 
-    # ---- fusion + arg-max kernels on their own (DSI-fuse GB/s, 12 B/voxel algorithmic) ----
-    reps = 50
-    ctx.timer_start()
-    for _ in range(reps):
-        fused.harmonicMeanTwoGrids(mappers[1].dsi_)
-    fuse_ms = ctx.timer_stop() / reps
-    ctx.timer_start()
-    for _ in range(reps):
-        mappers[0].computeDepthMap(fused)
-    argmax_ms = ctx.timer_stop() / reps
-    nvox = nx * ny * nz
-    fuse_gbps = 12.0 * nvox / (fuse_ms * 1e-3) / 1e9
-    argmax_gbps = (4.0 * nz + 9.0) * nx * ny / (argmax_ms * 1e-3) / 1e9
-
-    # ---- host-buffer (PCIe-inclusive) rate, reported beside `value`, never as it: upload the raw
-    # events + poses of camera 0 from pageable host memory, evaluate, wait
-    h2d_rate = h2d_stereo_rate = None
-    if rank == 0:
-        ev0 = rig["events"][0]
-        first0, Rt0 = d.packetize(ev0[2], rig["trajectories"][0], rig["T_rv_w"])
-        best = float("inf")
-        for _ in range(3):
-            t1 = time.perf_counter()
-            bt = d.EventBatch(ctx, ev0[0], ev0[1], Rt0, first0)
-            mappers[0].evaluateDSI_batch(bt)
-            ctx.synchronize()
-            best = min(best, time.perf_counter() - t1)
-            bt.close()
-        h2d_rate = first0.shape[0] * d.PACKET_SIZE / best / 1e6
-        # the whole stereo step from host memory: camera 1's upload overlaps camera 0's voting
-        # (evaluate returns as soon as its host buffers are consumed), then fusion + arg-max
-        pk = [d.packetize(rig["events"][c][2], rig["trajectories"][c], rig["T_rv_w"]) for c in range(2)]
-        best2 = float("inf")
-        for _ in range(3):
-            t1 = time.perf_counter()
-            bts = []
-            for c in range(2):
-                bts.append(d.EventBatch(cam_ctx[c], rig["events"][c][0], rig["events"][c][1], pk[c][1], pk[c][0]))
-                mappers[c].evaluateDSI_batch(bts[-1])
-            if ctx_cam1 is not ctx:
-                ctx.wait_for(ctx_cam1)
-            fused.setToFusionOf(mappers[0].dsi_, mappers[1].dsi_, d.FUSE_HM)
-            mappers[0].computeDepthMap(fused)
-            ctx.synchronize()
-            best2 = min(best2, time.perf_counter() - t1)
-            for b in bts:
-                b.close()
-        h2d_stereo_rate = sum(p_[0].shape[0] for p_ in pk) * d.PACKET_SIZE / best2 / 1e6
-
-    info = mappers[0].last_vote_info()
+    info = vote_mappers[0].last_vote_info()
     ms_per_step = 1e3 * elapsed / args.steps
-    value = voted_all * args.steps / elapsed / 1e6  # Mevents/s, whole job
-
-    # ---- roofline of the dominant kernel (the voting kernel) ----
-    # algorithmic bytes per event = Nz * 4 voxels * 8 B (fp32 read+write) + 8 B (x0,y0)
-    # (SURVEY.md 8d); one launch votes one camera's events of this rank.
-    bytes_per_event = 32.0 * nz + 8.0
-    ev_per_launch = voted / 2.0
+    value = voted_all * args.steps / elapsed / 1e6      # Mevents/s, whole job
     kern_ms = kt_ms / max(1, kt_n)
-    achieved = bytes_per_event * ev_per_launch / (kern_ms * 1e-3) / 1e9 if kt_n else None
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
-                "kernel": {0: "k_vote_bands", 1: "k_vote_bands_packed", 2: "k_vote_groups",
-                           3: "k_vote_bands_packed", 4: "k_vote_groups", 5: "k_vote_bands_packed", 6: "k_vote_bands_packed"}[info["packed"]] if info["algo"] == 2 else "k_vote_global",
-                "kernel_avg_ms": kern_ms, "kernel_launches": kt_n,
-                "algorithmic_bytes_per_launch": bytes_per_event * ev_per_launch,
-                "kernel_Mevents_per_s": ev_per_launch / (kern_ms * 1e-3) / 1e6 if kt_n else None}
+    # accepted event-planes of one launch = sum of the DSI it wrote (the 4 bilinear weights of a vote sum to 1)
+    accepted = float(np.sum(vote_mappers[0].dsi_.download(), dtype=np.float64))
 
-    # ---- what actually bounds the voting kernel: 64-bit LDS atomic adds (4 per accepted event-plane;
-    # the sum of a DSI = accepted event-planes because the 4 bilinear weights of a vote sum to 1).
-    # Rates per wave instruction measured with tools/lds_atomic_bench2.hip on this chip (16 waves/CU
-    # issuing back to back): 6.2 clk conflict-free, 11.2 clk with random cells of a band.
-    accepted = float(np.sum(mappers[0].dsi_.download(), dtype=np.float64))
-    adds = 4.0 * accepted / (kern_ms * 1e-3) if kt_n else None
-    cu_lane_rate = 256 * 64 * 2.4e9
-    lds_atomics = {"adds_per_s": adds, "unit": "64-bit LDS atomic adds/s (one camera launch)",
-                   "accepted_event_planes_per_launch": accepted,
-                   "peak_conflict_free": cu_lane_rate / 6.2, "rate_random_cells": cu_lane_rate / 11.2,
-                   "frac_of_conflict_free_peak": adds / (cu_lane_rate / 6.2) if adds else None,
-                   "frac_of_random_cell_rate": adds / (cu_lane_rate / 11.2) if adds else None}
-
-    # ---- CPU baseline: the oracle (a port of the reference's CPU path) on a bounded sample ----
-    cpu = None
-    if rank == 0 and not args.no_cpu and args.cpu_sample >= 2048:
-        from oracle import oracle as orc
-        from oracle_pipeline import OracleMapper
-        n_s = min(args.cpu_sample, rig["events"][0][0].shape[0])
-        x, y, ts = (a[:n_s] for a in rig["events"][0])
-        r = OracleMapper(rig["cam"], dimZ=nz, min_depth=4.0, max_depth=200.0)
-        first, Rt = d.packetize(ts, rig["trajectories"][0], rig["T_rv_w"])
-        first = first.astype(np.int64)
-        r.evaluate_packets(x, y, first[:64], Rt[:64])  # warm-up (page in, spin up OpenMP)
-        tc = float("inf")
-        for _ in range(3):                            # best of 3
-            t1 = time.perf_counter()
-            r.evaluate_packets(x, y, first, Rt)       # stage A + reset + fillVoxelGrid
-            tc = min(tc, time.perf_counter() - t1)
-        # one thread on a 1/16 sample (SURVEY 8d asks for both)
-        n1 = max(64, first.shape[0] // 16)
-        all_threads = orc.num_threads()
-        orc.set_num_threads(1)
-        t1 = time.perf_counter()
-        r.evaluate_packets(x, y, first[:n1], Rt[:n1])
-        t_one = time.perf_counter() - t1
-        orc.set_num_threads(all_threads)
-        cpu = {"value": first.shape[0] * 1024 / tc / 1e6, "unit": "Mevents/s",
-               "one_thread_value": n1 * 1024 / t_one / 1e6,
-               "cores": min(orc.num_threads(), nz), "kind": "port",  # OpenMP over planes: at most nz threads work
-               "sample": "camera 0, first %d events (%d packets) of the same workload, %dx%dx%d DSI; "
-                         "oracle stage A + fillVoxelGrid, OpenMP over planes (reference strategy: at most dimZ threads busy), -O3 no -march=native; best of 3, %.2f s wall"
-                         % (n_s, first.shape[0], nx, ny, nz, tc)}
-
+    out = None
     if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath) and args.workload == "stereo" and (nx, ny, nz) == (346, 260, 100):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = roofline_block(info, kern_ms, kt_n, accepted, ev_per_launch, info_nz(vote_mappers[0]), traffic)
+        streams = stream_kernels(d, ctx)
+
+        # ---- host-buffer (PCIe-inclusive) rates, reported beside `value`, never as it ----
+        h2d = {}
+        if args.workload == "stereo":
+            pk = [d.packetize(rig["events"][c][2], rig["trajectories"][c], rig["T_rv_w"]) for c in range(2)]
+            best = best2 = float("inf")
+            for _ in range(3):
+                t1 = time.perf_counter()
+                bt = d.EventBatch(ctx, rig["events"][0][0], rig["events"][0][1], pk[0][1], pk[0][0])
+                mappers[0].evaluateDSI_batch(bt)
+                ctx.synchronize()
+                best = min(best, time.perf_counter() - t1)
+                bt.close()
+            for _ in range(3):
+                t1 = time.perf_counter()
+                bts = []
+                for c in range(2):     # camera 1's upload overlaps camera 0's voting (copy stream)
+                    bts.append(d.EventBatch(ctx, rig["events"][c][0], rig["events"][c][1], pk[c][1], pk[c][0]))
+                    mappers[c].evaluateDSI_batch(bts[-1])
+                fused.setToFusionOf(mappers[0].dsi_, mappers[1].dsi_, d.FUSE_HM)
+                mappers[0].computeDepthMap(fused)
+                ctx.synchronize()
+                best2 = min(best2, time.perf_counter() - t1)
+                for b in bts:
+                    b.close()
+            h2d = {"one_camera_Mevents_per_s": pk[0][0].shape[0] * d.PACKET_SIZE / best / 1e6,
+                   "stereo_step_Mevents_per_s": sum(p_[0].shape[0] for p_ in pk) * d.PACKET_SIZE / best2 / 1e6,
+                   "source": "pageable host memory"}
+        elif args.workload == "windows":
+            hw = extra["host_windows"]
+            nrep = 40
+            pend = None
+            t1 = time.perf_counter()
+            for w in range(nrep):       # host packetisation + upload + compute + depth-map fetch per window
+                ev, ts = hw[w % len(hw)]
+                slot = ws.submit(ev, rig["trajectories"], ts)
+                if pend is not None:
+                    ws.fetch(pend)
+                pend = slot
+            ws.fetch(pend)
+            dt = (time.perf_counter() - t1) / nrep
+            h2d = {"ms_per_window": dt * 1e3, "windows_per_s": 1.0 / dt,
+                   "x_real_time": (args.events / 10.0e6) / dt, "Mevents_per_s": voted_per_step / dt / 1e6,
+                   "source": "pageable host memory; includes the host packetisation + pose interpolation"}
+
+        cpu = None
+        if not args.no_cpu:
+            cpu = cpu_baseline(d, rig, (nx, ny, nz) if args.workload != "windows" else (nx, ny, nz),
+                               10_000_000 if args.workload == "stereo" else 1_000_000)
+
         out = {
             "metric": "Mevents/s into DSI (346x260x100) + DSI-fuse GB/s",
             "value": value, "unit": "Mevents/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {
-                "workload": "stereo (2-cam) synthetic DSEC-like rig, %d events/cam per GPU, %dx%dx%d DSI, "
-                            "harmonic camera fusion + arg-max%s" % (
-                                args.events, nx, ny, nz,
-                                "" if world == 1 else
-                                ", %d time slices (one per GPU) fused by RCCL all-reduce of inverse sums" % world),
-                "events_voted_per_step": voted_all, "vote_algo": info["algo"], "bands": info["bands"],
-                "band_rows": info["band_rows"], "chunks": info["chunks"],
-                "block_threads": info["block_threads"], "lds_bytes": info["lds_bytes"], "packed_lanes": info["packed"],
-                "parallelism": "1 GPU" if world == 1 else "time-slice x%d" % world},
-            "dsi_fuse_GBps": fuse_gbps, "dsi_fuse_ms": fuse_ms, "dsi_fuse_frac_of_hbm_peak": fuse_gbps / HBM_PEAK_GBPS,
-            "argmax_GBps": argmax_gbps, "argmax_ms": argmax_ms,
+            "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "events_voted_per_step": voted_all, "vote_algo": info["algo"],
+                       "bands": info["bands"], "band_rows": info["band_rows"], "chunks": info["chunks"],
+                       "block_threads": info["block_threads"], "lds_bytes": info["lds_bytes"],
+                       "packed_lanes": info["packed"], "parallelism": parallelism, "collective": collective},
+            "dsi_fuse_GBps": streams["dsi_fuse"]["GBps"], "dsi_fuse_ms": streams["dsi_fuse"]["ms"],
+            "dsi_fuse_frac_of_hbm_peak": streams["dsi_fuse"]["frac_of_hbm_peak"],
+            "argmax_GBps": streams["argmax"]["GBps"], "argmax_ms": streams["argmax"]["ms"],
+            "stream_kernels": streams,
             "gpu_ms_per_step_hip_events": gpu_ms / args.steps,
-            "h2d_inclusive_Mevents_per_s": h2d_rate, "h2d_inclusive_stereo_step_Mevents_per_s": h2d_stereo_rate,
-            "roofline": roofline, "lds_atomics": lds_atomics, "cpu_baseline": cpu, "input_gen_s": t_gen,
+            "timed_region_s": elapsed,
+            "host_fed": h2d, "roofline": roofline, "cpu_baseline": cpu, "input_gen_s": t_gen,
         }
-    for o in mappers + batches + [fused]:
+        if args.workload == "windows":
+            out["windows_per_s"] = world * args.steps / elapsed
+            out["x_real_time"] = (args.events / 10.0e6) * world * args.steps / elapsed
+    for o in closers:
         o.close()
-    if temporal is not None:
+    if args.workload == "stereo" and world > 1:
         temporal.close()
         mapper_fused.close()
         ctx_side.close()
-    if ctx_cam1 is not ctx:
-        ctx_cam1.close()
+    if comm is not None:
+        comm.close()
     ctx.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    D.close()
     if rank == 0:
         # RCCL prints a version banner through C stdio; push it out first so that the JSON
         # line is the last line on stdout
@@ -342,6 +598,10 @@ def main():
         sys.stdout.flush()
         print(json.dumps(out))
         sys.stdout.flush()
+
+
+def info_nz(mapper):
+    return mapper.dsi_.getDimensions()[2]
 
 
 if __name__ == "__main__":

@@ -931,6 +931,14 @@ dsi_grid_t* dsi_mapper_grid(dsi_mapper_t* m) { return m ? m->grid : nullptr; }
 
 int dsi_mapper_plane_begin(const dsi_mapper_t* m) { return m ? m->plane_begin : 0; }
 
+int dsi_mapper_full_depths(const dsi_mapper_t* m, float* raw_depths, int* dim_z)
+{
+    REQUIRE(m, DSI_ERR_INVALID, "mapper is null");
+    if (raw_depths) std::memcpy(raw_depths, m->planes_full.data(), m->planes_full.size() * sizeof(float));
+    if (dim_z) *dim_z = (int)m->planes_full.size();
+    return DSI_OK;
+}
+
 int dsi_mapper_geometry(const dsi_mapper_t* m, float* Kv, float* raw_depths, int* nx, int* ny, int* nz)
 {
     REQUIRE(m, DSI_ERR_INVALID, "mapper is null");

@@ -2244,7 +2244,7 @@ hipError_t launch_packet_geometry(hipStream_t s, const float* Rt, int np, const 
     if (np <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_packet_geometry, dim3((np + 63) / 64), dim3(64), 0, s, Rt, np, g,
                        centers, H);
-    return hipGetLastError();
+    return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
 hipError_t launch_warp_z0(hipStream_t s, const uint16_t* ex, const uint16_t* ey,
@@ -2254,7 +2254,7 @@ hipError_t launch_warp_z0(hipStream_t s, const uint16_t* ex, const uint16_t* ey,
     if (np <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_warp_z0, dim3(np), dim3(256), 0, s, ex, ey, packet_first, np, H, lut,
                        sensor_w, xy);
-    return hipGetLastError();
+    return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
 hipError_t launch_vote_global(hipStream_t s, const float2* xy, const float* centers, int np,
@@ -2265,7 +2265,7 @@ hipError_t launch_vote_global(hipStream_t s, const float2* xy, const float* cent
     // gridDim.y is limited to 65535; x carries the packets
     hipLaunchKernelGGL(k_vote_global, dim3(np, zgroups), dim3(256), 0, s, xy, centers, planes, g,
                        dsi);
-    return hipGetLastError();
+    return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
 hipError_t launch_sort_packets(hipStream_t s, const float2* xy, int np, int ny, int nz, int pad,
@@ -2275,7 +2275,7 @@ hipError_t launch_sort_packets(hipStream_t s, const float2* xy, int np, int ny, 
     const size_t lds = (size_t)(ny + 2 * pad + 3) * sizeof(uint32_t);
     hipLaunchKernelGGL(k_sort_packets, dim3(np), dim3(256), lds, s, xy, np, ny, nz, pad, sxy, nvalid,
                        rowstart);
-    return hipGetLastError();
+    return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
 hipError_t launch_plane_coef(hipStream_t s, const float* centers, const float* planes,
@@ -2286,7 +2286,7 @@ hipError_t launch_plane_coef(hipStream_t s, const float* centers, const float* p
     const unsigned tiles = (unsigned)((np + 15) / 16) * (unsigned)((g.nz + 15) / 16);
     hipLaunchKernelGGL(k_plane_coef, dim3(tiles), dim3(256), 0, s, centers, planes, rowstart, nvalid,
                        np, g, bp, coef, cuts);
-    return hipGetLastError();
+    return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
 template <int BLOCK, bool PACKED>
@@ -2310,7 +2310,7 @@ static hipError_t launch_vote_bands_t(hipStream_t s, const EvRec* sxy, const Pla
     else
         hipLaunchKernelGGL(k_vote_bands<BLOCK>, dim3(blocks), dim3(BLOCK), bp.lds_bytes, s, sxy, coef,
                            cuts, np, g, bp, out, carry);
-    return hipGetLastError();
+    return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
 hipError_t launch_vote_bands(hipStream_t s, const EvRec* sxy, const PlaneCoef* coef,
@@ -2342,7 +2342,7 @@ hipError_t launch_sort_groups(hipStream_t s, const float2* xy, int np, int S, in
     const size_t lds = (size_t)(ny + 2 * pad + 3) * sizeof(uint32_t);
     hipLaunchKernelGGL(k_sort_groups, dim3(ngroups), dim3(256), lds, s, xy, np, S, ny, nz, pad, sxy, spk,
                        nvalid, rowstart);
-    return hipGetLastError();
+    return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
 hipError_t launch_group_cuts(hipStream_t s, const uint32_t* prow, const uint16_t* rowstart, int np,
@@ -2353,7 +2353,7 @@ hipError_t launch_group_cuts(hipStream_t s, const uint32_t* prow, const uint16_t
     const size_t total = (size_t)ngroups * g.nz * bp.bands;
     hipLaunchKernelGGL(k_group_cuts, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, prow,
                        rowstart, np, ngroups, S, g.nz, bp.bands, g.ny + 2 * bp.row_pad + 2, gcuts);
-    return hipGetLastError();
+    return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
 template <int BLOCK>
@@ -2374,7 +2374,7 @@ static hipError_t launch_vote_groups_t(hipStream_t s, const EvRec* sxy, const ui
     const unsigned blocks = (unsigned)(bp.chunks * bp.bands) * (unsigned)g.nz;
     hipLaunchKernelGGL(k_vote_groups<BLOCK>, dim3(blocks), dim3(BLOCK), bp.lds_bytes, s, sxy, spk,
                        coef, gcuts, slow_any, np, ngroups, S, g, bp, out, carry);
-    return hipGetLastError();
+    return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
 hipError_t launch_vote_groups(hipStream_t s, const EvRec* sxy, const uint8_t* spk,
@@ -2397,7 +2397,7 @@ hipError_t launch_add_carry(hipStream_t s, const float* carry, int chunks, const
     const size_t n = (size_t)g.nz * (bp.bands - 1) * g.nx;
     hipLaunchKernelGGL(k_add_carry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, carry, chunks, g,
                        bp.bands, bp.band_rows, dsi);
-    return hipGetLastError();
+    return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
 hipError_t launch_reduce_partials(hipStream_t s, const float* partials, int chunks, size_t n,
@@ -2405,7 +2405,7 @@ hipError_t launch_reduce_partials(hipStream_t s, const float* partials, int chun
 {
     hipLaunchKernelGGL(k_reduce_partials, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, s,
                        partials, chunks, n, dsi, accumulate);
-    return hipGetLastError();
+    return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
 hipError_t launch_fuse2(hipStream_t s, float* a, const float* g, size_t n, int op)
@@ -2420,7 +2420,7 @@ hipError_t launch_fuse2(hipStream_t s, float* a, const float* g, size_t n, int o
     case 6: hipLaunchKernelGGL(k_fuse2<6>, grid, block, 0, s, a, g, n); break;
     default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
+    return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
 hipError_t launch_fuse2_into(hipStream_t s, float* dst, const float* a, const float* g, size_t n, int op)
@@ -2435,14 +2435,14 @@ hipError_t launch_fuse2_into(hipStream_t s, float* dst, const float* a, const fl
     case 6: hipLaunchKernelGGL(k_fuse2_into<6>, grid, block, 0, s, dst, a, g, n); break;
     default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
+    return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
 hipError_t launch_fuse_hm_n(hipStream_t s, float* a, const float* g, size_t n, int n_maps)
 {
     hipLaunchKernelGGL(k_elementwise<EW_HM_N>, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, s, a,
                        g, n, (float)n_maps, (float)(n_maps - 1));
-    return hipGetLastError();
+    return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
 hipError_t launch_accumulate(hipStream_t s, float* acc, const float* g, size_t n, int mode)
@@ -2457,7 +2457,7 @@ hipError_t launch_accumulate(hipStream_t s, float* acc, const float* g, size_t n
     case 5: hipLaunchKernelGGL(k_elementwise<EW_MAX>, grid, block, 0, s, acc, g, n, 0.f, 0.f); break;
     default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
+    return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
 hipError_t launch_finalize(hipStream_t s, float* acc, size_t n, int mode, int n_maps)
@@ -2474,7 +2474,7 @@ hipError_t launch_finalize(hipStream_t s, float* acc, size_t n, int mode, int n_
     case 5: break;  // min / max need no finalisation
     default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
+    return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
 // plane-sharded arg-max: (confidence, local index) -> one 64-bit key per pixel whose MAX over the
@@ -2511,7 +2511,7 @@ hipError_t launch_pack_argmax(hipStream_t s, const float* conf, const uint8_t* i
                               unsigned long long* keys)
 {
     hipLaunchKernelGGL(k_pack_argmax, dim3((n + 255) / 256), dim3(256), 0, s, conf, idx, n, plane_begin, keys);
-    return hipGetLastError();
+    return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
 hipError_t launch_unpack_argmax(hipStream_t s, const unsigned long long* keys, int n, const float* planes_full,
@@ -2519,7 +2519,7 @@ hipError_t launch_unpack_argmax(hipStream_t s, const unsigned long long* keys, i
 {
     hipLaunchKernelGGL(k_unpack_argmax, dim3((n + 255) / 256), dim3(256), 0, s, keys, n, planes_full, conf, idx,
                        depth);
-    return hipGetLastError();
+    return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
 // identity element of an accumulate mode: 0 for the sums, +inf for min, -inf for max
@@ -2532,7 +2532,7 @@ __global__ __launch_bounds__(256) void k_fill(float* __restrict__ a, size_t n, f
 hipError_t launch_fill(hipStream_t s, float* a, size_t n, float v)
 {
     hipLaunchKernelGGL(k_fill, dim3(grid_for(n, 256)), dim3(256), 0, s, a, n, v);
-    return hipGetLastError();
+    return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
 hipError_t launch_collapse_max_z(hipStream_t s, const float* dsi, int nx, int ny, int nz,
@@ -2541,14 +2541,14 @@ hipError_t launch_collapse_max_z(hipStream_t s, const float* dsi, int nx, int ny
     const int npix = nx * ny;
     hipLaunchKernelGGL(k_collapse_max_z, dim3((npix + 255) / 256), dim3(256), 0, s, dsi, npix, nz,
                        conf, idx, planes, depth);
-    return hipGetLastError();
+    return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
 hipError_t launch_mean_square(hipStream_t s, const float* dsi, size_t n, double* accum)
 {
     hipLaunchKernelGGL(k_mean_square, dim3(grid_for(n, 256, 1024)), dim3(256), 0, s, dsi, n,
                        accum);
-    return hipGetLastError();
+    return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
 hipError_t launch_depth_map_filters(hipStream_t s, float* conf, const uint8_t* idx, int nx, int ny,
@@ -2592,7 +2592,7 @@ hipError_t launch_depth_map_filters(hipStream_t s, float* conf, const uint8_t* i
     const int border = ksize / 2 > 1 ? ksize / 2 : 1;
     hipLaunchKernelGGL(k_finish_depth, dim3((n + 255) / 256), dim3(256), 0, s, mask, idx_filtered, nx,
                        ny, border, planes, depth);
-    return hipGetLastError();
+    return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
 hipError_t launch_div_probe(hipStream_t s, const float* n, const float* d, size_t count, float* q,
@@ -2600,7 +2600,7 @@ hipError_t launch_div_probe(hipStream_t s, const float* n, const float* d, size_
 {
     hipLaunchKernelGGL(k_div_probe, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, n, d,
                        count, q, ref);
-    return hipGetLastError();
+    return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
 }  // namespace dsi

@@ -82,6 +82,7 @@ def load_library():
         "dsi_last_error": (C.c_char_p, []),
         "dsi_abi_version": (C.c_int, []),
         "dsi_mapper_plane_begin": (C.c_int, [vp]),
+        "dsi_mapper_full_depths": (C.c_int, [vp, f32p, intp]),
         "dsi_device_count": (C.c_int, []),
         "dsi_context_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
         "dsi_context_destroy": (C.c_int, [vp]),
@@ -563,6 +564,10 @@ class MapperEMVS:
         _check(L.dsi_mapper_geometry(self._h, None, _ptr(planes, C.c_float), None, None, None))
         self.raw_depths_vec_ = planes
         self.plane_begin = int(L.dsi_mapper_plane_begin(self._h))
+        nfull = C.c_int()
+        _check(L.dsi_mapper_full_depths(self._h, None, C.byref(nfull)))
+        self.full_depths_ = np.empty(nfull.value, np.float32)   # whole depth vector (plane shards index into it)
+        _check(L.dsi_mapper_full_depths(self._h, _ptr(self.full_depths_, C.c_float), None))
         self.virtual_cam_ = tuple(float(v) for v in kv)  # fx, fy, cx, cy
         # public member dsi_ (mapper_emvs_stereo.hpp:116)
         self.dsi_ = Grid3D(ctx, 0, 0, 0, _handle=C.c_void_p(L.dsi_mapper_grid(self._h)), _owner=self)

@@ -7,6 +7,8 @@ engine kernel.
     process_2   mapper_emvs_stereo/src/process2.cpp:28-302
     process_5   mapper_emvs_stereo/src/process5.cpp:28-260  (process_2 with the right camera's
                 sub-intervals circularly shifted by num_subintervals/2)
+    full_sequence / WindowStream   mapper_emvs_stereo/src/main.cpp:174-302  (--full_seq: a window of
+                `duration` seconds every `out_skip` seconds, process_1 per window)
 """
 import numpy as np
 
@@ -146,3 +148,113 @@ def process_5(*args, **kw):
     """process5.cpp:28-260: process_2 with the right camera's sub-intervals circularly shifted."""
     kw["shuffle_right"] = True
     return process_2(*args, **kw)
+
+
+def process_1_nary(mappers, events, trajectories, mapper_fused, ts, mode, rv_pos=0.0):
+    """Alg. 1 for n >= 2 cameras with an n-ary mean across ALL cameras (BASELINE configs[4]: 4-camera
+    rig, geometric mean).  The reference's process_1 fuses two cameras and, for GM / AM / RMS,
+    silently drops a third one (process1.cpp:169-191); this is the n-ary form of the same ops
+    (engine.ACC_SUM arithmetic, ACC_LOG_SUM geometric, ACC_SQ_SUM rms, ACC_MIN, ACC_MAX;
+    include/dsi_engine.h dsi_acc_mode_t).  Returns T_rv_w; the fused DSI is mapper_fused.dsi_."""
+    T_rv_w = reference_view_process1(trajectories[0], ts, rv_pos)
+    for m, ev, tr in zip(mappers, events, trajectories):
+        m.evaluateDSI(ev, tr, T_rv_w)
+    mapper_fused.dsi_.setToFusionOfN([m.dsi_ for m in mappers], mode)
+    return T_rv_w
+
+
+def window_bounds(start_time_s, stop_time_s, duration, out_skip):
+    """The intervals of main.cpp:177: for (t = start; t + duration <= stop; t += out_skip)."""
+    out = []
+    t = float(start_time_s)
+    while t + duration <= stop_time_s:
+        out.append((t, t + duration))
+        t += out_skip
+    return out
+
+
+def window_events(events, t_start, t_stop):
+    """Events of one camera with t_start <= ts <= t_stop (parse_rosbag, data_loading.cpp:272-285,
+    on an already time-sorted array)."""
+    x, y, ts = events
+    a = int(np.searchsorted(ts, t_start, side="left"))
+    b = int(np.searchsorted(ts, t_stop, side="right"))
+    return x[a:b], y[a:b], ts[a:b]
+
+
+class WindowStream:
+    """The --full_seq loop of main.cpp:174-302 with process_method 1 as a STREAM: per window
+    packetise on the host, upload both cameras' events (pooled device blocks on the copy stream, so
+    window w+1's upload overlaps window w's voting), evaluateDSI x2 (reset + vote), camera fusion,
+    arg-max + depth; the depth map of window w is fetched while window w+1 is already queued
+    (`depth` fused grids / extraction mappers alternate).  The reference constructs fresh mappers per
+    window (main.cpp:262-275); here they are reused -- evaluateDSI resets the DSI anyway (:145)."""
+
+    def __init__(self, ctx, cams, dsi_shape, fusion_method=E.FUSE_HM, luts=(None, None),
+                 inverse_depth=False, depth=2):
+        self.ctx = ctx
+        self.fusion_method = int(fusion_method)
+        self.mappers = [E.MapperEMVS(ctx, cams[c], dsi_shape, lut=luts[c], inverse_depth=inverse_depth)
+                        for c in range(2)]
+        dims = self.mappers[0].dsi_.getDimensions()
+        self.fused = [E.Grid3D(ctx, *dims) for _ in range(depth)]
+        self.extract = [E.MapperEMVS(ctx, cams[0], dsi_shape, inverse_depth=inverse_depth) for _ in range(depth)]
+        self.k = 0
+        self.voted = 0
+
+    def submit(self, events, trajectories, ts, rv_pos=0.0, batches=None):
+        """Queue one window (process1.cpp:54-166 + :222).  events: per camera (x, y, ts) of the
+        window; batches: optional pre-uploaded EventBatch per camera (device-resident inputs).
+        Returns the slot to pass to fetch().  The host does not wait."""
+        slot = self.k % len(self.fused)
+        T_rv_w = reference_view_process1(trajectories[0], ts, rv_pos)
+        own = []
+        for c in range(2):
+            if batches is not None:
+                b = batches[c]
+            else:
+                pk = E.packetize(events[c][2], trajectories[c], T_rv_w)
+                if pk is None:                      # evaluateDSI returns false: < 1024 events (:71-75)
+                    self.mappers[c].dsi_.resetGrid()
+                    continue
+                b = E.EventBatch(self.ctx, events[c][0], events[c][1], pk[1], pk[0])
+                own.append(b)
+            self.mappers[c].evaluateDSI_batch(b)
+            self.voted += b.n_packets * E.PACKET_SIZE
+        self.fused[slot].setToFusionOf(self.mappers[0].dsi_, self.mappers[1].dsi_, self.fusion_method)
+        self.extract[slot].computeDepthMap(self.fused[slot])
+        for b in own:
+            b.close()                               # the block returns to the pool once its readers are done
+        self.k += 1
+        return slot
+
+    def fetch(self, slot):
+        """(depth, confidence, indices) of the window submitted into `slot` (synchronises)."""
+        return self.extract[slot].fetchDepthMap()
+
+    def fused_grid(self, slot):
+        return self.fused[slot]
+
+    def close(self):
+        for o in self.mappers + self.fused + self.extract:
+            o.close()
+
+
+def full_sequence(ctx, cams, dsi_shape, events, trajectories, start_time_s, stop_time_s, duration,
+                  out_skip, fusion_method=E.FUSE_HM, forward_looking=True, rv_pos=0.0, **kw):
+    """Generator over the windows of main.cpp:177-302: yields (ts, depth, confidence, indices) per
+    window, pipelined one window deep."""
+    ws = WindowStream(ctx, cams, dsi_shape, fusion_method, **kw)
+    pending = None
+    try:
+        for t0, t1 in window_bounds(start_time_s, stop_time_s, duration, out_skip):
+            ts = t1 if forward_looking else 0.5 * (t0 + t1)          # main.cpp:185-189
+            ev = [window_events(events[c], t0, t1) for c in range(2)]
+            slot = ws.submit(ev, trajectories, ts, rv_pos)
+            if pending is not None:
+                yield (pending[0],) + ws.fetch(pending[1])
+            pending = (ts, slot)
+        if pending is not None:
+            yield (pending[0],) + ws.fetch(pending[1])
+    finally:
+        ws.close()

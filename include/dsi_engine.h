@@ -229,6 +229,9 @@ DSI_API dsi_grid_t *dsi_mapper_grid(dsi_mapper_t *m);
 DSI_API int dsi_mapper_geometry(const dsi_mapper_t *m, float *Kv, float *raw_depths, int *nx, int *ny, int *nz);
 /* first plane this mapper owns (0 unless plane-sharded); raw_depths / nz above describe the owned planes */
 DSI_API int dsi_mapper_plane_begin(const dsi_mapper_t *m);
+/* the WHOLE depth vector of the ShapeDSI (dim_z floats; global arg-max index -> depth of a plane-sharded
+ * DSI); either pointer may be NULL */
+DSI_API int dsi_mapper_full_depths(const dsi_mapper_t *m, float *raw_depths, int *dim_z);
 DSI_API int dsi_mapper_set_vote_algo(dsi_mapper_t *m, int algo);
 /* tuning knobs of DSI_VOTE_LDS_BANDS; 0 = automatic */
 DSI_API int dsi_mapper_set_band_params(dsi_mapper_t *m, int band_rows, int chunks, int block_threads);

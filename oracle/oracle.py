@@ -16,51 +16,72 @@ _LIB = None
 PACKET = 1024
 
 
+_LIB_NATIVE = None
+_USE_NATIVE = False
+
+
 def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 
 
+def use_native(flag):
+    """bench.py's "tuned CPU" row: route the calls below through a second build of the same file
+    with -O3 -march=native, compiled ON THIS MACHINE (the CPU it runs on decides the ISA).
+    Timing only -- every parity test uses the reference-flag build."""
+    global _USE_NATIVE, _LIB_NATIVE
+    if flag and _LIB_NATIVE is None:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "native"])
+        _LIB_NATIVE = _load(os.path.join(_HERE, "libdsi_oracle_native.so"))
+    _USE_NATIVE = bool(flag)
+
+
 def lib():
     global _LIB
+    if _USE_NATIVE and _LIB_NATIVE is not None:
+        return _LIB_NATIVE
     if _LIB is None:
         path = os.path.join(_HERE, "libdsi_oracle.so")
         if not os.path.exists(path):
             build()
-        L = C.CDLL(path)
-        f32p, u8p, u16p, f64p = (C.POINTER(C.c_float), C.POINTER(C.c_uint8),
-                                 C.POINTER(C.c_uint16), C.POINTER(C.c_double))
-        szp = C.POINTER(C.c_size_t)
-        L.orc_depth_planes.argtypes = [C.c_float, C.c_float, C.c_int, C.c_int, f32p]
-        L.orc_virtual_focal.argtypes = [C.c_float, C.c_float, C.c_int]
-        L.orc_virtual_focal.restype = C.c_float
-        L.orc_inverse3x3.argtypes = [f32p, f32p]
-        L.orc_packet_geometry.argtypes = [f32p, f32p, f32p, C.c_float, f32p, f32p]
-        L.orc_warp_z0.argtypes = [u16p, u16p, C.c_size_t, f32p, f32p, C.c_int, f32p]
-        L.orc_fill_voxel_grid.argtypes = [f32p, f32p, C.c_size_t, f32p, C.c_int, f32p,
-                                          C.c_int, C.c_int, f32p]
-        L.orc_vote.argtypes = [C.c_float, C.c_float, f32p, C.c_int, C.c_int]
-        L.orc_packetize.argtypes = [C.c_size_t, u8p, szp, szp]
-        L.orc_packetize.restype = C.c_long
-        L.orc_fuse2.argtypes = [f32p, f32p, C.c_size_t, C.c_int]
-        L.orc_fuse2.restype = C.c_int
-        L.orc_fuse_hm_n.argtypes = [f32p, f32p, C.c_size_t, C.c_int]
-        L.orc_accumulate.argtypes = [f32p, f32p, C.c_size_t, C.c_int]
-        L.orc_finalize.argtypes = [f32p, C.c_size_t, C.c_int, C.c_int]
-        L.orc_accumulate_begin.argtypes = [f32p, C.c_size_t, C.c_int]
-        L.orc_collapse_max_z.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p, u8p]
-        L.orc_indices_to_depth.argtypes = [u8p, C.c_size_t, f32p, f32p]
-        L.orc_mean_square.argtypes = [f32p, C.c_size_t]
-        L.orc_mean_square.restype = C.c_double
-        L.orc_pose_at.argtypes = [f64p, f64p, C.c_size_t, C.c_double, f64p]
-        L.orc_pose_at.restype = C.c_int
-        L.orc_event_pose_Rt.argtypes = [f64p, f64p, f32p]
-        L.orc_depth_map_filters.argtypes = [f32p, u8p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
-                                            C.c_double, f32p, u8p, u8p, u8p, f32p]
-        L.orc_num_threads.restype = C.c_int
-        L.orc_set_num_threads.argtypes = [C.c_int]
-        L.orc_set_num_threads.restype = None
-        _LIB = L
+        _LIB = _load(path)
     return _LIB
+
+
+def _load(path):
+    L = C.CDLL(path)
+    f32p, u8p, u16p, f64p = (C.POINTER(C.c_float), C.POINTER(C.c_uint8),
+                             C.POINTER(C.c_uint16), C.POINTER(C.c_double))
+    szp = C.POINTER(C.c_size_t)
+    L.orc_depth_planes.argtypes = [C.c_float, C.c_float, C.c_int, C.c_int, f32p]
+    L.orc_virtual_focal.argtypes = [C.c_float, C.c_float, C.c_int]
+    L.orc_virtual_focal.restype = C.c_float
+    L.orc_inverse3x3.argtypes = [f32p, f32p]
+    L.orc_packet_geometry.argtypes = [f32p, f32p, f32p, C.c_float, f32p, f32p]
+    L.orc_warp_z0.argtypes = [u16p, u16p, C.c_size_t, f32p, f32p, C.c_int, f32p]
+    L.orc_fill_voxel_grid.argtypes = [f32p, f32p, C.c_size_t, f32p, C.c_int, f32p,
+                                      C.c_int, C.c_int, f32p]
+    L.orc_vote.argtypes = [C.c_float, C.c_float, f32p, C.c_int, C.c_int]
+    L.orc_packetize.argtypes = [C.c_size_t, u8p, szp, szp]
+    L.orc_packetize.restype = C.c_long
+    L.orc_fuse2.argtypes = [f32p, f32p, C.c_size_t, C.c_int]
+    L.orc_fuse2.restype = C.c_int
+    L.orc_fuse_hm_n.argtypes = [f32p, f32p, C.c_size_t, C.c_int]
+    L.orc_accumulate.argtypes = [f32p, f32p, C.c_size_t, C.c_int]
+    L.orc_finalize.argtypes = [f32p, C.c_size_t, C.c_int, C.c_int]
+    L.orc_accumulate_begin.argtypes = [f32p, C.c_size_t, C.c_int]
+    L.orc_collapse_max_z.argtypes = [f32p, C.c_int, C.c_int, C.c_int, f32p, u8p]
+    L.orc_indices_to_depth.argtypes = [u8p, C.c_size_t, f32p, f32p]
+    L.orc_mean_square.argtypes = [f32p, C.c_size_t]
+    L.orc_mean_square.restype = C.c_double
+    L.orc_pose_at.argtypes = [f64p, f64p, C.c_size_t, C.c_double, f64p]
+    L.orc_pose_at.restype = C.c_int
+    L.orc_event_pose_Rt.argtypes = [f64p, f64p, f32p]
+    L.orc_depth_map_filters.argtypes = [f32p, u8p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
+                                        C.c_double, f32p, u8p, u8p, u8p, f32p]
+    L.orc_num_threads.restype = C.c_int
+    L.orc_set_num_threads.argtypes = [C.c_int]
+    L.orc_set_num_threads.restype = None
+    return L
 
 
 def _p(a, ct):
