@@ -34,6 +34,7 @@ from .engine import (  # noqa: F401
     Grid3D,
     MapperEMVS,
     OptionsDepthMap,
+    PinnedArray,
     ShapeDSI,
     acc_reduce_op,
     allreduce_all,
@@ -46,7 +47,7 @@ from .engine import (  # noqa: F401
 )
 
 __all__ = [
-    "Comm", "allreduce_all", "depth_map_sharded_all", "Context", "Grid3D", "MapperEMVS", "ShapeDSI", "OptionsDepthMap", "EventBatch", "DsiError", "device_count",
+    "Comm", "allreduce_all", "depth_map_sharded_all", "Context", "Grid3D", "MapperEMVS", "ShapeDSI", "OptionsDepthMap", "EventBatch", "PinnedArray", "DsiError", "device_count",
     "library_path", "load_library", "packetize", "pose_at", "PACKET_SIZE",
     "FUSE_MIN", "FUSE_HM", "FUSE_GM", "FUSE_AM", "FUSE_RMS", "FUSE_MAX", "ACC_SUM", "ACC_INV_SUM", "ACC_LOG_SUM", "ACC_SQ_SUM", "ACC_MIN", "ACC_MAX",
     "REDUCE_SUM", "REDUCE_MIN", "REDUCE_MAX", "acc_reduce_op",

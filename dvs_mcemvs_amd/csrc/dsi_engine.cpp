@@ -197,6 +197,12 @@ struct dsi_mapper {
     DevBuf<uint8_t> idx, conf8, mask, idx_filtered;
     DevBuf<uint32_t> minmax;
     bool depth_valid = false;
+    // The depth map leaves the device on the context's COPY stream, so that fetching window w's map
+    // does not queue behind window w+1's kernels on the compute stream: "ready" (compute stream, after
+    // the arg-max) gates the copies, "read" (copy stream, after them) gates the next arg-max into the
+    // same buffers.
+    hipEvent_t ev_depth_ready = nullptr, ev_depth_read = nullptr;
+    bool depth_read_pending = false;
     // HIP-event stopwatch around the dominant (voting) kernel, for bench.py's roofline
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> timing_pairs;  // recorded, not yet read
@@ -311,7 +317,7 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
         chunks = (int)std::min<size_t>((size_t)chunks, std::max<size_t>(1, n_packets));
         const size_t vol_bytes = (size_t)g.nx * g.ny * g.nz * sizeof(float);
         const size_t budget = (size_t)16 << 30;  // partial DSIs may use up to 16 GiB of HBM
-        while (chunks > 1 && (size_t)chunks * vol_bytes > budget) --chunks;
+        while (chunks > 1 && (size_t)chunks * (vol_bytes + 16) > budget) --chunks;
     }
     bp->chunks = std::max(1, chunks);
     return true;
@@ -388,6 +394,44 @@ int vote_done(dsi_mapper* m)
     return DSI_OK;
 }
 
+// before a kernel overwrites the mapper's depth-map buffers: the previous fetch must have read them
+int depth_buffers_acquire(dsi_mapper* m)
+{
+    if (m->depth_read_pending) {
+        HIP_TRY(hipStreamWaitEvent(m->ctx->stream, m->ev_depth_read, 0));
+        m->depth_read_pending = false;
+    }
+    return DSI_OK;
+}
+
+// after the kernels that produce the depth map have been queued on the mapper's stream
+int depth_buffers_ready(dsi_mapper* m)
+{
+    if (!m->ev_depth_ready) {
+        HIP_TRY(hipEventCreateWithFlags(&m->ev_depth_ready, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&m->ev_depth_read, hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventRecord(m->ev_depth_ready, m->ctx->stream));
+    m->depth_valid = true;
+    return DSI_OK;
+}
+
+// device -> host copies of the depth map on the copy stream (see dsi_mapper::ev_depth_ready)
+int depth_buffers_fetch(dsi_mapper* m, float* depth_host, float* conf_host, uint8_t* idx_host, bool wait)
+{
+    dsi_context* ctx = m->ctx;
+    hipStream_t cs = ctx->copy_stream;
+    const size_t npix = (size_t)m->geom.nx * m->geom.ny;
+    HIP_TRY(hipStreamWaitEvent(cs, m->ev_depth_ready, 0));
+    if (depth_host) HIP_TRY(hipMemcpyAsync(depth_host, m->depth.p, npix * sizeof(float), hipMemcpyDeviceToHost, cs));
+    if (conf_host) HIP_TRY(hipMemcpyAsync(conf_host, m->conf.p, npix * sizeof(float), hipMemcpyDeviceToHost, cs));
+    if (idx_host) HIP_TRY(hipMemcpyAsync(idx_host, m->idx.p, npix, hipMemcpyDeviceToHost, cs));
+    HIP_TRY(hipEventRecord(m->ev_depth_read, cs));
+    m->depth_read_pending = true;
+    if (wait) HIP_TRY(hipEventSynchronize(m->ev_depth_read));
+    return DSI_OK;
+}
+
 // fillVoxelGrid on device data.  xy: np*1024 z0 locations (reference order);
 // centers: np*3.  accumulate != 0: add to the grid's current contents.  ps: the stream the sort and
 // coefficient kernels go to (see prep_begin); the caller has already put xy / centers on it.
@@ -445,7 +489,7 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
     HIP_TRY(m->cuts.reserve(np * geom.nz * bp.bands));
     HIP_TRY(m->carry.reserve((size_t)bp.chunks * geom.nz * bp.bands * geom.nx));
     const bool direct = (bp.chunks == 1 && !accumulate);
-    if (!direct) HIP_TRY(m->partials.reserve((size_t)bp.chunks * g->n));
+    if (!direct) HIP_TRY(m->partials.reserve((size_t)bp.chunks * dsi::partial_stride(g->n)));
 
     if (bp.packed == 2 || bp.packed == 4) {
         const int S = bp.group_packets;
@@ -631,6 +675,9 @@ int dsi_grid_create(dsi_context_t* ctx, int nx, int ny, int nz, dsi_grid_t** out
 int dsi_grid_wrap(dsi_context_t* ctx, int nx, int ny, int nz, void* data_dev, dsi_grid_t** out)
 {
     REQUIRE(data_dev, DSI_ERR_INVALID, "data_dev is null");
+    // the voxel-wise kernels sweep volumes as float4
+    REQUIRE((reinterpret_cast<uintptr_t>(data_dev) & 15u) == 0, DSI_ERR_INVALID,
+            "wrapped device memory must be 16-byte aligned");
     return grid_make(ctx, nx, ny, nz, data_dev, out);
 }
 
@@ -893,6 +940,11 @@ int dsi_mapper_destroy(dsi_mapper_t* m)
         (void)hipEventDestroy(m->ev_prep);
         (void)hipEventDestroy(m->ev_vote_done);
     }
+    if (m->ev_depth_ready) {
+        (void)hipStreamSynchronize(m->ctx->copy_stream);
+        (void)hipEventDestroy(m->ev_depth_ready);
+        (void)hipEventDestroy(m->ev_depth_read);
+    }
     if (m->grid) dsi_grid_destroy(m->grid);
     if (m->planes_dev) (void)hipFree(m->planes_dev);
     if (m->planes_full_dev) (void)hipFree(m->planes_full_dev);
@@ -1003,8 +1055,9 @@ int dsi_mapper_fill_voxel_grid(dsi_mapper_t* m, const float* xy_z0, const float*
     return rc;
 }
 
-int dsi_batch_create(dsi_context_t* ctx, const uint16_t* x, const uint16_t* y, size_t n_events,
-                     const uint32_t* packet_first, const float* Rt, size_t n_packets, dsi_batch_t** out)
+static int batch_create(dsi_context_t* ctx, const uint16_t* x, const uint16_t* y, size_t n_events,
+                        const uint32_t* packet_first, const float* Rt, size_t n_packets, dsi_batch_t** out,
+                        bool wait)
 {
     REQUIRE(ctx && out, DSI_ERR_INVALID, "null argument");
     *out = nullptr;
@@ -1050,8 +1103,9 @@ int dsi_batch_create(dsi_context_t* ctx, const uint16_t* x, const uint16_t* y, s
         e = hipMemcpyAsync(b->first, packet_first, n_packets * sizeof(uint32_t), hipMemcpyHostToDevice, cs);
     if (e == hipSuccess) e = hipEventRecord(b->ready, cs);
     // the host arrays are the caller's: they must be consumed before this call returns (this waits
-    // for the copies only, not for whatever the compute stream is doing)
-    if (e == hipSuccess) e = hipStreamSynchronize(cs);
+    // for the copies only, not for whatever the compute stream is doing) -- unless the caller
+    // vouches for them (dsi_batch_create_async: page-locked memory, left alone until uploaded)
+    if (e == hipSuccess && wait) e = hipStreamSynchronize(cs);
     if (e != hipSuccess) {
         dsi_batch_destroy(b);
         return fail(DSI_ERR_HIP, "batch upload failed: %s", hipGetErrorString(e));
@@ -1060,10 +1114,46 @@ int dsi_batch_create(dsi_context_t* ctx, const uint16_t* x, const uint16_t* y, s
     return DSI_OK;
 }
 
+int dsi_batch_create(dsi_context_t* ctx, const uint16_t* x, const uint16_t* y, size_t n_events,
+                     const uint32_t* packet_first, const float* Rt, size_t n_packets, dsi_batch_t** out)
+{
+    return batch_create(ctx, x, y, n_events, packet_first, Rt, n_packets, out, /*wait=*/true);
+}
+
+int dsi_batch_create_async(dsi_context_t* ctx, const uint16_t* x, const uint16_t* y, size_t n_events,
+                           const uint32_t* packet_first, const float* Rt, size_t n_packets, dsi_batch_t** out)
+{
+    return batch_create(ctx, x, y, n_events, packet_first, Rt, n_packets, out, /*wait=*/false);
+}
+
+int dsi_batch_uploaded(const dsi_batch_t* b)
+{
+    if (!b || !b->ready) return 1;
+    return hipEventQuery(b->ready) == hipSuccess ? 1 : 0;
+}
+
+int dsi_host_alloc(size_t bytes, void** out)
+{
+    REQUIRE(out, DSI_ERR_INVALID, "out is null");
+    *out = nullptr;
+    REQUIRE(bytes > 0, DSI_ERR_INVALID, "bytes must be > 0");
+    HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocPortable));
+    return DSI_OK;
+}
+
+int dsi_host_free(void* p)
+{
+    if (!p) return DSI_OK;
+    HIP_TRY(hipHostFree(p));
+    return DSI_OK;
+}
+
 int dsi_batch_destroy(dsi_batch_t* b)
 {
     if (!b) return DSI_OK;
     (void)hipSetDevice(b->ctx->device);
+    // an upload that nobody waited for yet (async batch destroyed unused): order the block's reuse after it
+    if (b->ready) (void)hipStreamWaitEvent(b->ctx->stream, b->ready, 0);
     pool_give(b->ctx, b->block);  // no wait: the block's "freed" event orders its reuse
     if (b->ready) (void)hipEventDestroy(b->ready);
     delete b;
@@ -1163,25 +1253,34 @@ int dsi_mapper_depth_map_of(dsi_mapper_t* m, dsi_grid_t* g)
     // of the same device is first waited for: everything queued on its stream so far.
     REQUIRE(g->nz <= 256, DSI_ERR_INVALID, "arg-max indices are u8: dimZ must be <= 256 (got %d)", g->nz);
     if (int rc = dsi_context_wait_for(m->ctx, g->ctx)) return rc;
+    if (int rc = depth_buffers_acquire(m)) return rc;
     HIP_TRY(dsi::launch_collapse_max_z(m->ctx->stream, g->data, g->nx, g->ny, g->nz, m->conf.p, m->idx.p,
                                        m->planes_dev, m->depth.p));
-    m->depth_valid = true;
-    return DSI_OK;
+    return depth_buffers_ready(m);
 }
 
 int dsi_mapper_fetch_depth_map(dsi_mapper_t* m, float* depth_host, float* conf_host, uint8_t* idx_host)
 {
     REQUIRE(m, DSI_ERR_INVALID, "mapper is null");
     REQUIRE(m->depth_valid, DSI_ERR_INVALID, "no depth map has been computed since the last vote");
-    dsi_context* ctx = m->ctx;
-    if (int rc = set_device(ctx)) return rc;
-    const size_t npix = (size_t)m->geom.nx * m->geom.ny;
-    if (depth_host)
-        HIP_TRY(hipMemcpyAsync(depth_host, m->depth.p, npix * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    if (conf_host)
-        HIP_TRY(hipMemcpyAsync(conf_host, m->conf.p, npix * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    if (idx_host) HIP_TRY(hipMemcpyAsync(idx_host, m->idx.p, npix, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (int rc = set_device(m->ctx)) return rc;
+    return depth_buffers_fetch(m, depth_host, conf_host, idx_host, /*wait=*/true);
+}
+
+int dsi_mapper_fetch_depth_map_async(dsi_mapper_t* m, float* depth_host, float* conf_host, uint8_t* idx_host)
+{
+    REQUIRE(m, DSI_ERR_INVALID, "mapper is null");
+    REQUIRE(m->depth_valid, DSI_ERR_INVALID, "no depth map has been computed since the last vote");
+    if (int rc = set_device(m->ctx)) return rc;
+    return depth_buffers_fetch(m, depth_host, conf_host, idx_host, /*wait=*/false);
+}
+
+int dsi_mapper_fetch_wait(dsi_mapper_t* m)
+{
+    REQUIRE(m, DSI_ERR_INVALID, "mapper is null");
+    if (!m->depth_read_pending) return DSI_OK;
+    if (int rc = set_device(m->ctx)) return rc;
+    HIP_TRY(hipEventSynchronize(m->ev_depth_read));
     return DSI_OK;
 }
 
@@ -1232,7 +1331,7 @@ int dsi_mapper_get_depth_map_from_dsi(dsi_mapper_t* m, dsi_grid_t* g, const dsi_
     REQUIRE(opts->median_filter_size >= 1 && (opts->median_filter_size & 1) && opts->median_filter_size <= 31,
             DSI_ERR_INVALID, "median_filter_size must be odd and in 1..31 (median_filtering.cpp:44)");
     if (!g) g = m->grid;
-    if (int rc = dsi_mapper_depth_map_of(m, g)) return rc;  // collapseMaxZSlice, :368
+    if (int rc = dsi_mapper_depth_map_of(m, g)) return rc;  // collapseMaxZSlice, :368 (acquires the buffers)
     dsi_context* ctx = m->ctx;
     const int nx = m->geom.nx, ny = m->geom.ny;
     const size_t npix = (size_t)nx * ny;
@@ -1316,8 +1415,7 @@ DSI_API int dsi_test_div_probe(dsi_context_t* ctx, const float* n, const float* 
 /* ---------------------------------------------------------- multi-GPU (RCCL) */
 namespace {
 
-// librccl entry points, resolved once.  When the process already holds an RCCL (e.g. the one torch
-// ships) dlopen by soname returns that copy; otherwise /opt/rocm's.
+// librccl entry points, resolved once (see load_rccl for which copy).
 struct Rccl {
     void* lib = nullptr;
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
@@ -1337,9 +1435,27 @@ Rccl* load_rccl()
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
-        for (const char* n : names) {
-            r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        // The RCCL that belongs to the HIP runtime this process runs on: the librccl next to the loaded
+        // libamdhip64 (/opt/rocm/lib, or torch's lib directory when torch brought its own runtime in
+        // first).  Opening by soname instead could hand back an RCCL built for another runtime that
+        // some other package loaded (seen: torch's librccl on /opt/rocm's libamdhip64 fails in
+        // ncclCommInitAll).
+        std::vector<std::string> names;
+        Dl_info di;
+        if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &di) && di.dli_fname) {
+            std::string dir(di.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash);
+                names.push_back(dir + "/librccl.so.1");
+                names.push_back(dir + "/librccl.so");
+            }
+        }
+        names.push_back("/opt/rocm/lib/librccl.so.1");
+        names.push_back("librccl.so.1");
+        names.push_back("librccl.so");
+        for (const std::string& n : names) {
+            r.lib = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
             if (r.lib) break;
         }
         if (!r.lib) {
@@ -1550,6 +1666,7 @@ static int sharded_prepare(dsi_mapper_t* m, dsi_grid_t* g)
         HIP_TRY(hipStreamSynchronize(m->ctx->stream));  // the source is host memory of this object: simplest
     }
     if (int rc = dsi_context_wait_for(m->ctx, g->ctx)) return rc;
+    if (int rc = depth_buffers_acquire(m)) return rc;
     HIP_TRY(dsi::launch_collapse_max_z(m->ctx->stream, g->data, g->nx, g->ny, g->nz, m->conf.p, m->idx.p, nullptr,
                                        nullptr));
     HIP_TRY(dsi::launch_pack_argmax(m->ctx->stream, m->conf.p, m->idx.p, (int)npix, m->plane_begin,
@@ -1563,8 +1680,7 @@ static int sharded_finish(dsi_mapper_t* m)
     HIP_TRY(hipSetDevice(m->ctx->device));
     HIP_TRY(dsi::launch_unpack_argmax(m->ctx->stream, m->argmax_keys.p, (int)npix, m->planes_full_dev, m->conf.p,
                                       m->idx.p, m->depth.p));
-    m->depth_valid = true;
-    return DSI_OK;
+    return depth_buffers_ready(m);
 }
 
 int dsi_mapper_depth_map_sharded(dsi_mapper_t* m, dsi_grid_t* g, dsi_comm_t* c)

@@ -53,6 +53,10 @@ struct BandPlan {
     int scratch_offset; // mapping 5: byte offset of that area behind the band
 };
 
+// distance in floats between the partial volumes of consecutive packet chunks: the volume size
+// rounded up to 4 floats, so that every partial volume starts 16-byte aligned (float4 sweeps)
+__host__ __device__ inline size_t partial_stride(size_t n_voxels) { return (n_voxels + 3) & ~(size_t)3; }
+
 // ---- stage A ---------------------------------------------------------------
 hipError_t launch_packet_geometry(hipStream_t s, const float* Rt, int np, const Geom& g,
                                   float* centers, float* H);

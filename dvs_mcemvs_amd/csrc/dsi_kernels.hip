@@ -16,6 +16,8 @@
 #include "dsi_kernels.h"
 
 #include <cmath>
+#include <mutex>
+#include <vector>
 
 #pragma clang fp contract(off)
 
@@ -595,7 +597,7 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands(const EvRec* __restrict__ 
     __syncthreads();
 
     // owned rows are contiguous in the [z][y][x] volume: a linear coalesced copy
-    const size_t vol = (size_t)g.nx * g.ny * g.nz;
+    const size_t vol = partial_stride((size_t)g.nx * g.ny * g.nz);
     float* __restrict__ dst = out + (size_t)c * vol + ((size_t)z * g.ny + r0) * nx;
     flush_band<BLOCK>(band, nx, (r1 - r0) * nx, dst, carry_row(carry, c, z, j, g, bp));
 }
@@ -1572,7 +1574,7 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const EvRec* __rest
                           kWaves * group, lane, nx, Li, Ui, r0, dummy_eo);
     __syncthreads();
 
-    const size_t vol = (size_t)g.nx * g.ny * g.nz;
+    const size_t vol = partial_stride((size_t)g.nx * g.ny * g.nz);
     float* __restrict__ dst = out + (size_t)c * vol + ((size_t)z * g.ny + r0) * nx;
     flush_band<BLOCK>(band, nx, (r1 - r0) * nx, dst, carry_row(carry, c, z, j, g, bp));
 }
@@ -1801,7 +1803,7 @@ __global__ __launch_bounds__(BLOCK) void k_vote_groups(const EvRec* __restrict__
         }
     }
     __syncthreads();
-    const size_t vol = (size_t)g.nx * g.ny * g.nz;
+    const size_t vol = partial_stride((size_t)g.nx * g.ny * g.nz);
     float* __restrict__ dst = out + (size_t)c * vol + ((size_t)z * g.ny + r0) * nx;
     flush_band<BLOCK>(band, nx, (r1 - r0) * nx, dst, carry_row(carry, c, z, j, g, bp));
 }
@@ -1833,7 +1835,7 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict
         float4 acc = accumulate ? reinterpret_cast<const float4*>(dsi)[i]
                                 : make_float4(0.f, 0.f, 0.f, 0.f);
         for (int c = 0; c < chunks; ++c) {
-            const float4 v = reinterpret_cast<const float4*>(partials + (size_t)c * n)[i];
+            const float4 v = reinterpret_cast<const float4*>(partials + (size_t)c * partial_stride(n))[i];
             acc.x += v.x;
             acc.y += v.y;
             acc.z += v.z;
@@ -1844,7 +1846,7 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const size_t i = n4 * 4 + threadIdx.x;
         float acc = accumulate ? dsi[i] : 0.f;
-        for (int c = 0; c < chunks; ++c) acc += partials[(size_t)c * n + i];
+        for (int c = 0; c < chunks; ++c) acc += partials[(size_t)c * partial_stride(n) + i];
         dsi[i] = acc;
     }
 }
@@ -2238,6 +2240,34 @@ int grid_for(size_t work_items, int block, int max_blocks = 256 * 8)
 
 size_t max_dynamic_lds() { return 160 * 1024; }
 
+// The dynamic-LDS limit of a kernel is a per-device function attribute: set it for the CURRENT
+// device whenever this (kernel, device) pair has not been given at least `bytes` yet.  The table is
+// per process; several host threads (one context each) may launch concurrently.
+static hipError_t allow_dynamic_lds(const void* kern, size_t bytes)
+{
+    struct Entry {
+        const void* kern;
+        int device;
+        size_t bytes;
+    };
+    static std::mutex mu;
+    static std::vector<Entry> table;
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev)) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    for (Entry& t : table)
+        if (t.kern == kern && t.device == dev) {
+            if (t.bytes >= bytes) return hipSuccess;
+            if (hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes))
+                return e;
+            t.bytes = bytes;
+            return hipSuccess;
+        }
+    if (hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)) return e;
+    table.push_back({kern, dev, bytes});
+    return hipSuccess;
+}
+
 hipError_t launch_packet_geometry(hipStream_t s, const float* Rt, int np, const Geom& g,
                                   float* centers, float* H)
 {
@@ -2294,15 +2324,9 @@ static hipError_t launch_vote_bands_t(hipStream_t s, const EvRec* sxy, const Pla
                                       const uint32_t* cuts, const uint32_t* slow_any, int np,
                                       const Geom& g, const BandPlan& bp, float* out, float* carry)
 {
-    static size_t configured = 0;
     const void* kern = PACKED ? reinterpret_cast<const void*>(&k_vote_bands_packed<BLOCK>)
                               : reinterpret_cast<const void*>(&k_vote_bands<BLOCK>);
-    if (bp.lds_bytes > configured) {
-        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)bp.lds_bytes);
-        if (e != hipSuccess) return e;
-        configured = bp.lds_bytes;
-    }
+    if (hipError_t e = allow_dynamic_lds(kern, bp.lds_bytes)) return e;
     const unsigned blocks = (unsigned)(bp.chunks * bp.bands) * (unsigned)g.nz;
     if (PACKED)
         hipLaunchKernelGGL(k_vote_bands_packed<BLOCK>, dim3(blocks), dim3(BLOCK), bp.lds_bytes, s,
@@ -2362,14 +2386,8 @@ static hipError_t launch_vote_groups_t(hipStream_t s, const EvRec* sxy, const ui
                                        const uint32_t* slow_any, int np, int S, const Geom& g,
                                        const BandPlan& bp, float* out, float* carry)
 {
-    static size_t configured = 0;
-    if (bp.lds_bytes > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_vote_groups<BLOCK>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)bp.lds_bytes);
-        if (e != hipSuccess) return e;
-        configured = bp.lds_bytes;
-    }
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_vote_groups<BLOCK>), bp.lds_bytes))
+        return e;
     const int ngroups = (np + S - 1) / S;
     const unsigned blocks = (unsigned)(bp.chunks * bp.bands) * (unsigned)g.nz;
     hipLaunchKernelGGL(k_vote_groups<BLOCK>, dim3(blocks), dim3(BLOCK), bp.lds_bytes, s, sxy, spk,

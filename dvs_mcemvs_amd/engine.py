@@ -121,6 +121,13 @@ def load_library():
         "dsi_batch_create": (C.c_int, [vp, u16p, u16p, C.c_size_t, u32p, f32p, C.c_size_t,
                                        C.POINTER(vp)]),
         "dsi_batch_destroy": (C.c_int, [vp]),
+        "dsi_batch_create_async": (C.c_int, [vp, u16p, u16p, C.c_size_t, u32p, f32p, C.c_size_t,
+                                             C.POINTER(vp)]),
+        "dsi_batch_uploaded": (C.c_int, [vp]),
+        "dsi_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(vp)]),
+        "dsi_host_free": (C.c_int, [vp]),
+        "dsi_mapper_fetch_depth_map_async": (C.c_int, [vp, f32p, f32p, u8p]),
+        "dsi_mapper_fetch_wait": (C.c_int, [vp]),
         "dsi_batch_num_packets": (C.c_size_t, [vp]),
         "dsi_mapper_evaluate_batch": (C.c_int, [vp, vp]),
         "dsi_mapper_evaluate": (C.c_int, [vp, u16p, u16p, f64p, C.c_size_t, f64p, f64p,
@@ -231,6 +238,14 @@ class Context:
 
     def close(self):
         if self._h:
+            # objects created from this context hold a pointer to it on the C side: release whatever is
+            # still open (e.g. left behind by an exception) BEFORE the context goes
+            for o in list(_LIVE):
+                if o is not self and getattr(o, "ctx", None) is self:
+                    try:
+                        o.close()
+                    except Exception:
+                        pass
             load_library().dsi_context_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -495,11 +510,36 @@ class OptionsDepthMap:
         self.max_confidence = float(max_confidence)
 
 
+class PinnedArray:
+    """numpy array in page-locked host memory (dsi_host_alloc): the source / destination of
+    asynchronous uploads and depth-map fetches.  `a` is the array; close() frees the memory."""
+
+    def __init__(self, shape, dtype):
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape))
+        self._p = C.c_void_p()
+        _check(load_library().dsi_host_alloc(max(1, n * dtype.itemsize), C.byref(self._p)))
+        buf = (C.c_uint8 * (n * dtype.itemsize)).from_address(self._p.value)
+        self.a = np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+        _track(self)
+
+    def close(self):
+        if self._p:
+            self.a = None
+            load_library().dsi_host_free(self._p)
+        self._p = C.c_void_p()
+
+    def __del__(self):
+        _safe_del(self)
+
+
 class EventBatch:
     """Device-resident events of one evaluateDSI call + their packetisation
-    (mapper_emvs_stereo.cpp:88-105)."""
+    (mapper_emvs_stereo.cpp:88-105).  asynchronous=True: x, y, Rt, packet_first are views of
+    PinnedArray memory that the caller leaves alone until uploaded() (or a later synchronisation of
+    the context that evaluated the batch); the constructor then returns without waiting."""
 
-    def __init__(self, ctx, x, y, Rt, packet_first=None):
+    def __init__(self, ctx, x, y, Rt, packet_first=None, asynchronous=False):
         x = _arr(x, np.uint16)
         y = _arr(y, np.uint16)
         Rt = _arr(Rt, np.float32).reshape(-1, 12)
@@ -511,10 +551,16 @@ class EventBatch:
         self.n_packets = Rt.shape[0]
         self.n_events = x.shape[0]
         self._h = C.c_void_p()
-        _check(load_library().dsi_batch_create(ctx._h, _ptr(x, C.c_uint16), _ptr(y, C.c_uint16),
-                                               x.shape[0], pf, _ptr(Rt, C.c_float), Rt.shape[0],
-                                               C.byref(self._h)))
+        L = load_library()
+        fn = L.dsi_batch_create_async if asynchronous else L.dsi_batch_create
+        if asynchronous:
+            self._keep = (x, y, Rt, packet_first)   # the views (not the pinned memory itself)
+        _check(fn(ctx._h, _ptr(x, C.c_uint16), _ptr(y, C.c_uint16), x.shape[0], pf, _ptr(Rt, C.c_float),
+                  Rt.shape[0], C.byref(self._h)))
         _track(self)
+
+    def uploaded(self):
+        return bool(load_library().dsi_batch_uploaded(self._h))
 
     def close(self):
         if self._h:
@@ -671,6 +717,16 @@ class MapperEMVS:
         packed (confidence, index) keys, index -> depth over the full depth vector; fetchDepthMap()
         then returns the unsharded result on every rank."""
         _check(load_library().dsi_mapper_depth_map_sharded(self._h, (grid or self.dsi_)._h, comm._h))
+
+    def fetchDepthMapAsync(self, depth, conf, idx):
+        """Queue the device -> host copies into PinnedArray-backed arrays (any may be None) on the copy
+        stream; they are valid after fetchWait()."""
+        _check(load_library().dsi_mapper_fetch_depth_map_async(
+            self._h, None if depth is None else _ptr(depth, C.c_float),
+            None if conf is None else _ptr(conf, C.c_float), None if idx is None else _ptr(idx, C.c_uint8)))
+
+    def fetchWait(self):
+        _check(load_library().dsi_mapper_fetch_wait(self._h))
 
     def fetchDepthMap(self):
         depth = np.empty((self.dimY, self.dimX), np.float32)

@@ -201,11 +201,25 @@ class WindowStream:
         self.extract = [E.MapperEMVS(ctx, cams[0], dsi_shape, inverse_depth=inverse_depth) for _ in range(depth)]
         self.k = 0
         self.voted = 0
+        self._pins = {}     # (slot, camera) -> page-locked (Rt, packet_first) staging of asynchronous uploads
 
-    def submit(self, events, trajectories, ts, rv_pos=0.0, batches=None):
+    def _staging(self, slot, c, n_packets):
+        cur = self._pins.get((slot, c))
+        if cur is None or cur[0].a.shape[0] < n_packets:
+            if cur is not None:
+                for a in cur:
+                    a.close()
+            cap = max(1024, 2 * n_packets)
+            cur = (E.PinnedArray((cap, 12), np.float32), E.PinnedArray((cap,), np.uint32))
+            self._pins[(slot, c)] = cur
+        return cur
+
+    def submit(self, events, trajectories, ts, rv_pos=0.0, batches=None, asynchronous=False):
         """Queue one window (process1.cpp:54-166 + :222).  events: per camera (x, y, ts) of the
         window; batches: optional pre-uploaded EventBatch per camera (device-resident inputs).
-        Returns the slot to pass to fetch().  The host does not wait."""
+        asynchronous: the x / y arrays live in page-locked memory (engine.PinnedArray) and stay
+        unchanged until this window's result has been fetched; the uploads then run as plain DMAs
+        and the host does not wait for them.  Returns the slot to pass to fetch()."""
         slot = self.k % len(self.fused)
         T_rv_w = reference_view_process1(trajectories[0], ts, rv_pos)
         own = []
@@ -217,7 +231,13 @@ class WindowStream:
                 if pk is None:                      # evaluateDSI returns false: < 1024 events (:71-75)
                     self.mappers[c].dsi_.resetGrid()
                     continue
-                b = E.EventBatch(self.ctx, events[c][0], events[c][1], pk[1], pk[0])
+                first, Rt = pk
+                if asynchronous:
+                    pr, pf = self._staging(slot, c, first.shape[0])
+                    pr.a[:Rt.shape[0]] = Rt
+                    pf.a[:first.shape[0]] = first
+                    Rt, first = pr.a[:Rt.shape[0]], pf.a[:first.shape[0]]
+                b = E.EventBatch(self.ctx, events[c][0], events[c][1], Rt, first, asynchronous=asynchronous)
                 own.append(b)
             self.mappers[c].evaluateDSI_batch(b)
             self.voted += b.n_packets * E.PACKET_SIZE
@@ -238,6 +258,10 @@ class WindowStream:
     def close(self):
         for o in self.mappers + self.fused + self.extract:
             o.close()
+        for pair in self._pins.values():
+            for a in pair:
+                a.close()
+        self._pins = {}
 
 
 def full_sequence(ctx, cams, dsi_shape, events, trajectories, start_time_s, stop_time_s, duration,

@@ -127,7 +127,7 @@ DSI_API int dsi_context_timer_stop(dsi_context_t *ctx, float *elapsed_ms);
 /* ------------------------------------------------------------------- Grid3D */
 /* Grid3D::Grid3D(dimX,dimY,dimZ) + allocate + resetGrid (cartesian3dgrid.cpp:30-46) */
 DSI_API int dsi_grid_create(dsi_context_t *ctx, int nx, int ny, int nz, dsi_grid_t **out);
-/* same, over caller-owned device memory of nx*ny*nz floats (not zeroed, not freed) */
+/* same, over caller-owned device memory of nx*ny*nz floats, 16-byte aligned (not zeroed, not freed) */
 DSI_API int dsi_grid_wrap(dsi_context_t *ctx, int nx, int ny, int nz, void *data_dev, dsi_grid_t **out);
 DSI_API int dsi_grid_destroy(dsi_grid_t *g);
 /* Grid3D::getDimensions (cartesian3dgrid.h:230-235) */
@@ -260,6 +260,18 @@ DSI_API int dsi_mapper_fill_voxel_grid(dsi_mapper_t *m, const float *xy_z0, cons
  * pose Rt[12k..12k+11] = R (row-major 3x3) then t of T_ev_rv, already cast to float. */
 DSI_API int dsi_batch_create(dsi_context_t *ctx, const uint16_t *x, const uint16_t *y, size_t n_events,
                      const uint32_t *packet_first, const float *Rt, size_t n_packets, dsi_batch_t **out);
+/* Host-fed streams (a 50 ms window every 50 ms, main.cpp:177): page-locked host memory lets the
+ * upload run as one DMA without the runtime's staging copies, and lets the host go on while it
+ * runs.  dsi_host_alloc returns such memory (hipHostMalloc; any context of the process may use it).
+ * dsi_batch_create_async is dsi_batch_create for arrays that live in it: it returns as soon as the
+ * copies are queued on the copy stream.  The arrays must stay unchanged until the upload is done --
+ * dsi_batch_uploaded(b) (non-blocking: 1 done, 0 in flight), or any later synchronisation of a
+ * context that evaluated the batch. */
+DSI_API int dsi_host_alloc(size_t bytes, void **out);
+DSI_API int dsi_host_free(void *p);
+DSI_API int dsi_batch_create_async(dsi_context_t *ctx, const uint16_t *x, const uint16_t *y, size_t n_events,
+                           const uint32_t *packet_first, const float *Rt, size_t n_packets, dsi_batch_t **out);
+DSI_API int dsi_batch_uploaded(const dsi_batch_t *b);
 DSI_API int dsi_batch_destroy(dsi_batch_t *b);
 DSI_API size_t dsi_batch_num_packets(const dsi_batch_t *b);
 
@@ -298,6 +310,12 @@ DSI_API int dsi_mapper_depth_map(dsi_mapper_t *m, float *depth_host, float *conf
  * keeps results in the mapper's device buffers until dsi_mapper_fetch_depth_map */
 DSI_API int dsi_mapper_depth_map_of(dsi_mapper_t *m, dsi_grid_t *g);
 DSI_API int dsi_mapper_fetch_depth_map(dsi_mapper_t *m, float *depth_host, float *conf_host, uint8_t *idx_host);
+/* the same without waiting: the copies are queued (on the context's copy stream, behind the arg-max
+ * only -- not behind later work of the compute stream); the outputs (page-locked memory from
+ * dsi_host_alloc) are valid after dsi_mapper_fetch_wait */
+DSI_API int dsi_mapper_fetch_depth_map_async(dsi_mapper_t *m, float *depth_host, float *conf_host,
+                                             uint8_t *idx_host);
+DSI_API int dsi_mapper_fetch_wait(dsi_mapper_t *m);
 
 /* Plane sharding (one DSI too big or too slow for one GPU): every rank's mapper owns a
  * plane range (dsi_mapper_config_t.plane_begin / plane_count) and grid g holds that range of the

@@ -19,10 +19,12 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -94,6 +96,94 @@ private:
     dsi_context_t* h_ = nullptr;
 };
 
+// The reference's classes are constructed without a device argument (MapperEMVS(cam, shape),
+// Grid3D(dimX, dimY, dimZ): mapper_emvs_stereo.hpp:101, cartesian3dgrid.h:26).  Those arities use this
+// process-wide context: GPU `DSI_DEVICE` (environment, default 0), created on first use.
+inline Context& default_context()
+{
+    static Context ctx([] {
+        const char* e = std::getenv("DSI_DEVICE");
+        return e ? std::atoi(e) : 0;
+    }());
+    return ctx;
+}
+
+// How the reference's third-party value types are read.  Specialise (or overload) for other types;
+// the defaults cover: timestamps that are a double or have .toSec() (ros::Time), poses that are a
+// dsi::Transformation or have getPosition() / getRotation().w() ... (kindr::minimal::QuatTransformation,
+// the reference's geometry_utils::Transformation), cameras that are a dsi::PinholeCameraModel or
+// have fullResolution() / fx() / fy() / cx() / cy() (image_geometry::PinholeCameraModel).
+inline double to_seconds(double t) { return t; }
+template <typename TimeT>
+inline auto to_seconds(const TimeT& t) -> decltype(t.toSec())
+{
+    return t.toSec();
+}
+
+inline void to_pose7(const Transformation& T, double* p) { T.to7(p); }
+template <typename PoseT>
+inline auto to_pose7(const PoseT& T, double* p) -> decltype(T.getRotation().w(), void())
+{
+    const auto pos = T.getPosition();
+    const auto rot = T.getRotation();
+    p[0] = pos[0]; p[1] = pos[1]; p[2] = pos[2];
+    p[3] = rot.w(); p[4] = rot.x(); p[5] = rot.y(); p[6] = rot.z();
+}
+
+inline void camera_of(const PinholeCameraModel& c, PinholeCameraModel* out) { *out = c; }
+template <typename CamT>
+inline auto camera_of(const CamT& c, PinholeCameraModel* out) -> decltype(c.fullResolution(), void())
+{
+    // mapper_emvs_stereo.cpp:34-48: size from fullResolution(), K from the projection matrix
+    out->width = c.fullResolution().width;
+    out->height = c.fullResolution().height;
+    out->fx = (float)c.fx();
+    out->fy = (float)c.fy();
+    out->cx = (float)c.cx();
+    out->cy = (float)c.cy();
+    // precomputeRectifiedPoints (mapper_emvs_stereo.cpp:256-299): raw pixel -> rectified pixel, by
+    // the camera model's own rectifyPoint (OpenCV arithmetic stays on the host side of the boundary)
+    out->rectified_points.resize((size_t)2 * out->width * out->height);
+    for (int y = 0; y < out->height; ++y)
+        for (int x = 0; x < out->width; ++x) {
+            const auto r = c.rectifyPoint(decltype(c.rectifyPoint({}))((double)x, (double)y));
+            out->rectified_points[2 * ((size_t)y * out->width + x)] = (float)r.x;
+            out->rectified_points[2 * ((size_t)y * out->width + x) + 1] = (float)r.y;
+        }
+}
+
+// One rank of an RCCL communicator owned by the engine (dsi_engine.h "multi-GPU").
+class Comm {
+public:
+    Comm() = default;
+    Comm(Context& ctx, const uint8_t id[DSI_COMM_ID_BYTES], int nranks, int rank)
+    {
+        check(dsi_comm_create_rank(ctx.handle(), id, nranks, rank, &h_));
+    }
+    ~Comm() { dsi_comm_destroy(h_); }
+    Comm(const Comm&) = delete;
+    Comm& operator=(const Comm&) = delete;
+    Comm(Comm&& o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+    // one process, several GPUs: one communicator rank per context (distinct devices)
+    static std::vector<Comm> createAll(const std::vector<Context*>& ctxs)
+    {
+        std::vector<dsi_context_t*> hs;
+        for (Context* c : ctxs) hs.push_back(c->handle());
+        std::vector<dsi_comm_t*> out(ctxs.size(), nullptr);
+        check(dsi_comm_create_all(hs.data(), (int)hs.size(), out.data()));
+        std::vector<Comm> v(ctxs.size());
+        for (size_t i = 0; i < out.size(); ++i) v[i].h_ = out[i];
+        return v;
+    }
+    static void uniqueId(uint8_t id[DSI_COMM_ID_BYTES]) { check(dsi_comm_unique_id(id)); }
+    int rank() const { return dsi_comm_rank(h_); }
+    int size() const { return dsi_comm_size(h_); }
+    dsi_comm_t* handle() const { return h_; }
+
+private:
+    dsi_comm_t* h_ = nullptr;
+};
+
 }  // namespace dsi
 
 // trajectory.hpp:81-128
@@ -101,13 +191,16 @@ class LinearTrajectory {
 public:
     typedef std::map<double, dsi::Transformation> PoseMap;
     LinearTrajectory() = default;
-    explicit LinearTrajectory(const PoseMap& poses)
+    // any std::map<TimeT, PoseT> the traits above can read (the reference's
+    // std::map<ros::Time, geometry_utils::Transformation>, trajectory.hpp:84)
+    template <typename TimeT, typename PoseT, typename... Rest>
+    explicit LinearTrajectory(const std::map<TimeT, PoseT, Rest...>& poses)
     {
         if (poses.size() < 2) throw dsi::Error(DSI_ERR_INVALID, "At least two poses need to be provided");
         for (const auto& kv : poses) {
-            times_.push_back(kv.first);
+            times_.push_back(dsi::to_seconds(kv.first));
             double p[7];
-            kv.second.to7(p);
+            dsi::to_pose7(kv.second, p);
             poses_.insert(poses_.end(), p, p + 7);
         }
     }
@@ -117,6 +210,18 @@ public:
         double out[7];
         if (dsi_pose_at(times_.data(), poses_.data(), times_.size(), t, out) != DSI_OK) return false;
         T = dsi::Transformation::from7(out);
+        return true;
+    }
+    // the reference's signature getPoseAt(const ros::Time&, Transformation&) for any time type with
+    // toSec() and any pose type constructible from (rotation(w,x,y,z), position(x,y,z)) like minkindr's
+    template <typename TimeT, typename PoseT>
+    auto getPoseAt(const TimeT& t, PoseT& T) const -> decltype(t.toSec(), T.getRotation(), bool())
+    {
+        dsi::Transformation D;
+        if (!getPoseAt(t.toSec(), D)) return false;
+        typedef typename std::decay<decltype(T.getRotation())>::type Rot;
+        typedef typename std::decay<decltype(T.getPosition())>::type Pos;
+        T = PoseT(Rot(D.q[0], D.q[1], D.q[2], D.q[3]), Pos(D.t[0], D.t[1], D.t[2]));
         return true;
     }
     size_t getNumControlPoses() const { return times_.size(); }
@@ -132,6 +237,8 @@ class Grid3D {
 public:
     Grid3D() = default;
     Grid3D(dsi::Context& ctx, unsigned dimX, unsigned dimY, unsigned dimZ) { allocate(ctx, dimX, dimY, dimZ); }
+    // the reference's arity (cartesian3dgrid.h:26), on the process-wide default context
+    Grid3D(unsigned dimX, unsigned dimY, unsigned dimZ) { allocate(dsi::default_context(), dimX, dimY, dimZ); }
     ~Grid3D() { deallocate(); }
     Grid3D(const Grid3D&) = delete;
     Grid3D& operator=(const Grid3D&) = delete;
@@ -183,6 +290,13 @@ public:
     void geometricMeanTwoGrids(const Grid3D& grid2) { dsi::check(dsi_grid_fuse2(h_, grid2.h_, DSI_FUSE_GM)); }
     void arithmeticMeanTwoGrids(const Grid3D& grid2) { dsi::check(dsi_grid_fuse2(h_, grid2.h_, DSI_FUSE_AM)); }
     void maxTwoGrids(const Grid3D& grid2) { dsi::check(dsi_grid_fuse2(h_, grid2.h_, DSI_FUSE_MAX)); }
+    // n-ary accumulate / finalize (dsi_acc_mode_t: the temporal accumulators above are modes 0 / 1;
+    // LOG_SUM / SQ_SUM / MIN / MAX are the n-ary forms of the 2-ary camera-fusion ops, which the
+    // reference lacks) and the all-reduce that joins accumulators across GPUs
+    void accumulateBegin(int mode) { dsi::check(dsi_grid_accumulate_begin(h_, mode)); }
+    void accumulate(const Grid3D& grid2, int mode) { dsi::check(dsi_grid_accumulate(h_, grid2.h_, mode)); }
+    void finalize(int mode, int n) { dsi::check(dsi_grid_finalize(h_, mode, n)); }
+    void allReduce(dsi::Comm& comm, int op) { dsi::check(dsi_grid_allreduce(comm.handle(), h_, op)); }
 
     // cartesian3dgrid.cpp:115-137
     void collapseMaxZSlice(dsi::Image<float>* max_val, dsi::Image<uint8_t>* max_pos) const
@@ -266,6 +380,12 @@ class MapperEMVS {  // mapper_emvs_stereo.hpp:94-155
 public:
     // plane_begin / plane_count: own only that range of the dimZ planes (plane sharding over GPUs;
     // 0, 0 = all planes, the reference behaviour)
+    // the reference's arity MapperEMVS(cam, dsi_shape) (mapper_emvs_stereo.hpp:101) for any camera
+    // type dsi::camera_of can read, on the process-wide default context
+    template <typename CamT>
+    MapperEMVS(const CamT& cam, const ShapeDSI& dsi_shape) : MapperEMVS(dsi::default_context(), convert(cam), dsi_shape)
+    {
+    }
     MapperEMVS(dsi::Context& ctx, const dsi::PinholeCameraModel& cam, const ShapeDSI& dsi_shape,
                bool inverse_depth = false, int plane_begin = 0, int plane_count = 0)
     {
@@ -294,21 +414,24 @@ public:
     MapperEMVS(const MapperEMVS&) = delete;
     MapperEMVS& operator=(const MapperEMVS&) = delete;
 
-    // mapper_emvs_stereo.cpp:67-148.  Returns false when events.size() < 1024.
-    bool evaluateDSI(const std::vector<dsi::Event>& events, const TrajectoryType& trajectory,
-                     const dsi::Transformation& T_rv_w)
+    // mapper_emvs_stereo.cpp:67-148.  Returns false when events.size() < 1024.  Any event type with
+    // .x .y .ts (ts a double in seconds or with .toSec(): dvs_msgs::Event) and any pose type
+    // dsi::to_pose7 can read (geometry_utils::Transformation) -- the reference's call
+    // evaluateDSI(events, trajectory, T_rv_w) (process1.cpp:76) compiles as it stands.
+    template <typename EventT, typename PoseT>
+    bool evaluateDSI(const std::vector<EventT>& events, const TrajectoryType& trajectory, const PoseT& T_rv_w)
     {
         const size_t n = events.size();
         xs_.resize(n);
         ys_.resize(n);
         ts_.resize(n);
         for (size_t i = 0; i < n; ++i) {
-            xs_[i] = events[i].x;
-            ys_[i] = events[i].y;
-            ts_[i] = events[i].ts;
+            xs_[i] = (uint16_t)events[i].x;
+            ys_[i] = (uint16_t)events[i].y;
+            ts_[i] = dsi::to_seconds(events[i].ts);
         }
         double T7[7];
-        T_rv_w.to7(T7);
+        dsi::to_pose7(T_rv_w, T7);
         size_t voted = 0;
         const int rc = dsi_mapper_evaluate(h_, xs_.data(), ys_.data(), ts_.data(), n, trajectory.times().data(),
                                            trajectory.poses7().data(), trajectory.times().size(), T7, &voted);
@@ -371,6 +494,13 @@ public:
     std::string name;  // mapper_emvs_stereo.hpp:117
 
 private:
+    template <typename CamT>
+    static dsi::PinholeCameraModel convert(const CamT& cam)
+    {
+        dsi::PinholeCameraModel c;
+        dsi::camera_of(cam, &c);
+        return c;
+    }
     dsi_mapper_t* h_ = nullptr;
     std::vector<uint16_t> xs_, ys_;
     std::vector<double> ts_;

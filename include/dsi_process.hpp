@@ -7,6 +7,9 @@
 //                                                            temporal fusion, and the converse order
 //   process_5   mapper_emvs_stereo/src/process5.cpp:28-260   process_2 with the right camera's
 //                                                            sub-intervals circularly shifted
+//   process_2_multi_gpu                                      process_2's temporal fusion over the GPUs of
+//                                                            one node: sub-interval -> device, ONE RCCL
+//                                                            all-reduce per accumulator
 //
 // Pure call sequencing: which mapper gets which events, where the reference view sits, the fusion
 // order and op codes (1 min, 2 HM, 3 GM, 4 AM, 5 RMS, 6 max), the temporal accumulators
@@ -15,6 +18,7 @@
 #ifndef DSI_PROCESS_HPP
 #define DSI_PROCESS_HPP
 
+#include <memory>
 #include <vector>
 
 #include "dsi_engine.hpp"
@@ -180,6 +184,98 @@ inline Process2Result process_2(dsi::Context& ctx, const dsi::PinholeCameraModel
     if (stereo_fusion < 1 || stereo_fusion > 6) throw dsi::Error(DSI_ERR_BAD_OP, "Improper stereo fusion method selected");
     dsi::fuseTwoGrids(mapper_fused_camera_time.dsi_, out.right, converse[stereo_fusion],
                       "Improper stereo fusion method selected");
+    return out;
+}
+
+// Alg. 2 on the GPUs of one node (BASELINE configs[3]): sub-interval k goes to device
+// k mod n, every device fuses the cameras of its sub-intervals and accumulates them locally
+// (process2.cpp:98-242), then ONE RCCL all-reduce over xGMI of each accumulator (sum; harmonic:
+// of the inverse sums, cartesian3dgrid.h:72-86) replaces the rest of the temporal loop, and every
+// device finalizes its copy.  One host thread drives all devices, like the reference's single
+// process; work on different devices overlaps because every call is asynchronous on its
+// context's stream.  Events never cross devices.
+//   ctxs / comms: one context per device and the communicator ranks from dsi::Comm::createAll(ctxs)
+//   (comms may be empty when there is one device).
+// The result is on EVERY device (fused[i], left[i], right[i]); the converse order
+// (process2.cpp:266-289) is computed on device 0 into camera_time.
+struct Process2MultiResult {
+    dsi::Transformation T_rv_w;
+    std::vector<Grid3D> fused, left, right;  // per device: time-fused camera fusion, left / right temporal DSIs
+    Grid3D camera_time;                      // device 0
+};
+
+inline Process2MultiResult process_2_multi_gpu(const std::vector<dsi::Context*>& ctxs, std::vector<dsi::Comm>& comms,
+                                               const dsi::PinholeCameraModel& cam0,
+                                               const dsi::PinholeCameraModel& cam1,
+                                               const LinearTrajectory& trajectory0,
+                                               const LinearTrajectory& trajectory1,
+                                               const std::vector<dsi::Event>& events0,
+                                               const std::vector<dsi::Event>& events1,
+                                               const EMVS::ShapeDSI& dsi_shape, const int num_subintervals, double ts,
+                                               int stereo_fusion, int temporal_fusion)
+{
+    const int ndev = (int)ctxs.size();
+    if (ndev < 1) throw dsi::Error(DSI_ERR_INVALID, "no device");
+    if (ndev > 1 && (int)comms.size() != ndev) throw dsi::Error(DSI_ERR_INVALID, "one communicator rank per device");
+    if (temporal_fusion != 2 && temporal_fusion != 4)
+        throw dsi::Error(DSI_ERR_BAD_OP, "temporal fusion 2 (harmonic) or 4 (arithmetic) -- the others do nothing (process2.cpp:213-243)");
+    const int mode = temporal_fusion == 2 ? DSI_ACC_INV_SUM : DSI_ACC_SUM;
+    Process2MultiResult out;
+    dsi::Transformation T_w_l;
+    if (!trajectory0.getPoseAt(ts, T_w_l)) throw dsi::Error(DSI_ERR_INVALID, "no pose at the reference timestamp");
+    out.T_rv_w = dsi::inverse(T_w_l);  // process2.cpp:79-81
+    std::vector<std::unique_ptr<EMVS::MapperEMVS>> m0, m1;
+    std::vector<Grid3D> sub(ndev);
+    out.fused.resize(ndev);
+    out.left.resize(ndev);
+    out.right.resize(ndev);
+    int nx = 0, ny = 0, nz = 0;
+    for (int i = 0; i < ndev; ++i) {
+        m0.emplace_back(new EMVS::MapperEMVS(*ctxs[i], cam0, dsi_shape));
+        m1.emplace_back(new EMVS::MapperEMVS(*ctxs[i], cam1, dsi_shape));
+        m0[i]->dsi_.getDimensions(&nx, &ny, &nz);
+        sub[i].allocate(*ctxs[i], nx, ny, nz);
+        for (Grid3D* g : {&out.fused[i], &out.left[i], &out.right[i]}) {
+            g->allocate(*ctxs[i], nx, ny, nz);
+            g->accumulateBegin(mode);  // resetGrid (process2.cpp:90)
+        }
+    }
+    const size_t per0 = events0.size() / (size_t)num_subintervals;  // :46-47
+    const size_t per1 = events1.size() / (size_t)num_subintervals;
+    for (int k = 0; k < num_subintervals; ++k) {
+        const int i = k % ndev;
+        const std::vector<dsi::Event> ev0(events0.begin() + (long)(k * per0), events0.begin() + (long)((k + 1) * per0));
+        const std::vector<dsi::Event> ev1(events1.begin() + (long)(k * per1), events1.begin() + (long)((k + 1) * per1));
+        m0[i]->dsi_.resetGrid();                           // :100-101 (a sub-interval with < 1024 events votes nothing)
+        m1[i]->dsi_.resetGrid();
+        m0[i]->evaluateDSI(ev0, trajectory0, out.T_rv_w);  // :119
+        m1[i]->evaluateDSI(ev1, trajectory1, out.T_rv_w);  // :146
+        sub[i].resetGrid();                                // :159-160
+        sub[i].addTwoGrids(m0[i]->dsi_);
+        dsi::fuseTwoGrids(sub[i], m1[i]->dsi_, stereo_fusion, "Improper stereo fusion method selected");  // :168-189
+        out.left[i].accumulate(m0[i]->dsi_, mode);   // :218-220 / :231-233
+        out.right[i].accumulate(m1[i]->dsi_, mode);
+        out.fused[i].accumulate(sub[i], mode);
+    }
+    if (ndev > 1) {  // the three accumulators, one group call each
+        std::vector<dsi_comm_t*> cs;
+        for (dsi::Comm& c : comms) cs.push_back(c.handle());
+        for (std::vector<Grid3D>* acc : {&out.fused, &out.left, &out.right}) {
+            std::vector<dsi_grid_t*> gs;
+            for (Grid3D& g : *acc) gs.push_back(g.handle());
+            dsi::check(dsi_grid_allreduce_all(cs.data(), gs.data(), ndev, dsi_acc_reduce_op(mode)));
+        }
+    }
+    for (int i = 0; i < ndev; ++i)
+        for (Grid3D* g : {&out.fused[i], &out.left[i], &out.right[i]}) g->finalize(mode, num_subintervals);  // :221-225
+    // converse order on device 0 (:266-289; cases 3 and 4 swapped there, kept)
+    out.camera_time.allocate(*ctxs[0], nx, ny, nz);
+    out.camera_time.resetGrid();
+    out.camera_time.addTwoGrids(out.left[0]);
+    static const int converse[7] = {0, 1, 2, 4, 3, 5, 6};
+    if (stereo_fusion < 1 || stereo_fusion > 6) throw dsi::Error(DSI_ERR_BAD_OP, "Improper stereo fusion method selected");
+    dsi::fuseTwoGrids(out.camera_time, out.right[0], converse[stereo_fusion], "Improper stereo fusion method selected");
+    for (int i = 0; i < ndev; ++i) ctxs[i]->synchronize();  // the mappers go out of scope
     return out;
 }
 

@@ -6,7 +6,9 @@
 //   exit 0: parity ok      exit 3: no GPU (adapter threw DSI_ERR_NO_DEVICE)      else: failure
 #include <cmath>
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
+#include <memory>
 #include <vector>
 
 #include "dsi_engine.hpp"
@@ -284,6 +286,53 @@ int main()
             std::printf("%s: left %.3g right %.3g fused %.3g camera-time %.3g\n", shuffle ? "process_5" : "process_2",
                         el, er, ef, ec);
             if (el > 3e-4 || er > 3e-4 || ef > 1e-3 || ec > 1e-3) return 70 + variant;
+        }
+        // ---- process_2 over every GPU of the node (one here on the test box, eight under the driver's
+        //      multi-GPU run): sub-interval -> device, ONE RCCL all-reduce per accumulator issued by the
+        //      engine; must equal the single-device process_2 (to summation order when n > 1)
+        {
+            int ndev = dsi_device_count();
+            if (const char* e = std::getenv("DSI_TEST_DEVICES")) ndev = std::min(ndev, std::atoi(e));
+            std::vector<std::unique_ptr<dsi::Context>> owned;
+            std::vector<dsi::Context*> ctxs;
+            for (int i = 0; i < ndev; ++i) {
+                owned.emplace_back(new dsi::Context(i));
+                ctxs.push_back(owned.back().get());
+            }
+            std::vector<dsi::Comm> comms = dsi::Comm::createAll(ctxs);   // also with one device: RCCL is exercised
+            if ((int)comms.size() != ndev || comms[0].size() != ndev) return 90;
+            const int n_sub = 8;
+            EMVS::MapperEMVS fused_ct(ctx, cam, dsi_shape);
+            fused_ct.dsi_.resetGrid();
+            Process2Result single = process_2(ctx, cam, cam, trajectory0, trajectory1, events0, events1, dsi_shape, n_sub,
+                                              mapper_fused, fused_ct, 0.5, 2, 2);
+            Process2MultiResult multi = process_2_multi_gpu(ctxs, comms, cam, cam, trajectory0, trajectory1, events0,
+                                                            events1, dsi_shape, n_sub, 0.5, 2, 2);
+            const std::vector<float> want = mapper_fused.dsi_.download();
+            for (int i = 0; i < ndev; ++i) {
+                const double e1 = max_rel_err(multi.fused[i].download(), want);
+                const double e2 = max_rel_err(multi.left[i].download(), single.left.download());
+                std::printf("process_2_multi_gpu device %d of %d: fused %.3g left %.3g\n", i, ndev, e1, e2);
+                if (e1 > (ndev > 1 ? 1e-5 : 0.0) || e2 > (ndev > 1 ? 1e-5 : 0.0)) return 91;
+            }
+            if (max_rel_err(multi.camera_time.download(), fused_ct.dsi_.download()) > (ndev > 1 ? 1e-5 : 0.0)) return 92;
+            // a plain grid all-reduce: sum over n copies of the same volume = n * volume
+            std::vector<Grid3D> gs(ndev);
+            std::vector<dsi_grid_t*> gh;
+            std::vector<dsi_comm_t*> ch;
+            int gx, gy, gz;
+            mapper_fused.dsi_.getDimensions(&gx, &gy, &gz);
+            for (int i = 0; i < ndev; ++i) {
+                gs[i].allocate(*ctxs[i], gx, gy, gz);
+                gs[i].upload(want);
+                gh.push_back(gs[i].handle());
+                ch.push_back(comms[i].handle());
+            }
+            dsi::check(dsi_grid_allreduce_all(ch.data(), gh.data(), ndev, DSI_REDUCE_SUM));
+            std::vector<float> scaled = want;
+            for (float& v : scaled) v *= (float)ndev;
+            for (int i = 0; i < ndev; ++i)
+                if (max_rel_err(gs[i].download(), scaled) > 1e-6) return 93;
         }
         if (const char* out = std::getenv("DSI_TEST_NPY")) {  // for tests/test_cpp_adapter.py
             if (mapper_fused.dsi_.writeGridNpy(out) != 0) return 80;
