@@ -1,0 +1,246 @@
+// The adapter against the reference's OWN value types.  The reference calls the hot path as
+//
+//     EMVS::MapperEMVS mapper0(cam0, dsi_shape);                          main.cpp:262-275
+//     trajectory0.getPoseAt(ros::Time(t_mid), T_w_l);                     process1.cpp:62
+//     T_rv_w = (T_w_l * baselineTransform).inverse();                     process1.cpp:64-68
+//     mapper0.evaluateDSI(events0, trajectory0, T_rv_w);                  process1.cpp:76
+//     mapper_fused.dsi_.resetGrid(); ...addTwoGrids(mapper0.dsi_); ...    process1.cpp:126-158
+//
+// with std::vector<dvs_msgs::Event>, ros::Time, geometry_utils::Transformation (a
+// kindr::minimal::QuatTransformation), std::map<ros::Time, Transformation> and
+// image_geometry::PinholeCameraModel.  None of those packages exists in this image, so this file
+// declares minimal stand-ins WITH THE SAME MEMBER NAMES (test scaffolding only: no arithmetic of
+// the path lives in them) and runs that call sequence through include/dsi_engine.hpp unchanged in
+// spelling and arity.  The result must equal, bit for bit, the same data pushed through the
+// adapter's plain types (dsi::Event, dsi::Transformation, dsi::PinholeCameraModel).
+//
+//   exit 0: ok      exit 3: no GPU      else: failure
+#include <cmath>
+#include <cstdio>
+#include <map>
+#include <vector>
+
+#include "dsi_engine.hpp"
+#include "dsi_process.hpp"
+
+// ---------------------------------------------------------------- stand-ins (names as upstream)
+namespace ros {
+struct Time {
+    double s = 0;
+    Time() = default;
+    explicit Time(double t) : s(t) {}
+    double toSec() const { return s; }
+    bool operator<(const Time& o) const { return s < o.s; }
+};
+}  // namespace ros
+
+namespace dvs_msgs {
+struct Event {
+    uint16_t x = 0, y = 0;
+    ros::Time ts;
+    bool polarity = false;
+};
+}  // namespace dvs_msgs
+
+namespace kindr {
+namespace minimal {
+struct Position {
+    double v[3] = {0, 0, 0};
+    Position() = default;
+    Position(double x, double y, double z) : v{x, y, z} {}
+    double operator[](int i) const { return v[i]; }
+};
+struct RotationQuaternion {
+    double q[4] = {1, 0, 0, 0};
+    RotationQuaternion() = default;
+    RotationQuaternion(double w, double x, double y, double z) : q{w, x, y, z} {}
+    double w() const { return q[0]; }
+    double x() const { return q[1]; }
+    double y() const { return q[2]; }
+    double z() const { return q[3]; }
+};
+class QuatTransformation {
+public:
+    QuatTransformation() = default;
+    QuatTransformation(const RotationQuaternion& r, const Position& p) : r_(r), p_(p) {}
+    const Position& getPosition() const { return p_; }
+    const RotationQuaternion& getRotation() const { return r_; }
+    // the two group operations the caller needs; delegated to the adapter's helpers so that no
+    // second implementation of the pose algebra exists in this test
+    QuatTransformation operator*(const QuatTransformation& o) const { return from(to() * o.to()); }
+    QuatTransformation inverse() const { return from(dsi::inverse(to())); }
+
+private:
+    dsi::Transformation to() const
+    {
+        dsi::Transformation T;
+        for (int i = 0; i < 3; ++i) T.t[i] = p_[i];
+        T.q[0] = r_.w(); T.q[1] = r_.x(); T.q[2] = r_.y(); T.q[3] = r_.z();
+        return T;
+    }
+    static QuatTransformation from(const dsi::Transformation& T)
+    {
+        return QuatTransformation(RotationQuaternion(T.q[0], T.q[1], T.q[2], T.q[3]), Position(T.t[0], T.t[1], T.t[2]));
+    }
+    RotationQuaternion r_;
+    Position p_;
+};
+}  // namespace minimal
+}  // namespace kindr
+
+namespace geometry_utils {
+typedef kindr::minimal::QuatTransformation Transformation;  // geometry_utils.hpp:13
+}
+
+namespace cv {
+struct Size {
+    int width = 0, height = 0;
+};
+struct Point2d {
+    double x = 0, y = 0;
+    Point2d() = default;
+    Point2d(double x_, double y_) : x(x_), y(y_) {}
+};
+}  // namespace cv
+
+namespace image_geometry {
+class PinholeCameraModel {
+public:
+    PinholeCameraModel(int w, int h, double fx, double fy, double cx, double cy) : w_(w), h_(h), fx_(fx), fy_(fy), cx_(cx), cy_(cy) {}
+    cv::Size fullResolution() const
+    {
+        cv::Size s;
+        s.width = w_;
+        s.height = h_;
+        return s;
+    }
+    double fx() const { return fx_; }
+    double fy() const { return fy_; }
+    double cx() const { return cx_; }
+    double cy() const { return cy_; }
+    // an undistorted sensor: rectification is the identity (the LUT is an INPUT at the engine's boundary)
+    cv::Point2d rectifyPoint(const cv::Point2d& uv_raw) const { return uv_raw; }
+
+private:
+    int w_, h_;
+    double fx_, fy_, cx_, cy_;
+};
+}  // namespace image_geometry
+
+// ---------------------------------------------------------------- the reference's call sequence
+namespace {
+
+// process1.cpp:54-191 for two cameras, spelled with the reference's types and calls
+void process_1_like_the_reference(const LinearTrajectory& trajectory0, const LinearTrajectory& trajectory1,
+                                  const std::vector<dvs_msgs::Event>& events0,
+                                  const std::vector<dvs_msgs::Event>& events1, EMVS::MapperEMVS& mapper_fused,
+                                  EMVS::MapperEMVS& mapper0, EMVS::MapperEMVS& mapper1, double ts, int fusion_method,
+                                  double rv_pos)
+{
+    geometry_utils::Transformation T_rv_w;
+    const double t_mid = ts;
+    geometry_utils::Transformation T_w_rv, T_w_l, T_w_r;
+    trajectory0.getPoseAt(ros::Time(t_mid), T_w_l);
+    trajectory1.getPoseAt(ros::Time(t_mid), T_w_r);
+    const geometry_utils::Transformation baselineTransform(kindr::minimal::RotationQuaternion(1, 0, 0, 0),
+                                                           kindr::minimal::Position(rv_pos, 0, 0));
+    T_w_rv = T_w_l * baselineTransform;
+    T_rv_w = T_w_rv.inverse();
+    mapper0.evaluateDSI(events0, trajectory0, T_rv_w);
+    (void)mapper0.dsi_.computeMeanSquare();
+    mapper1.evaluateDSI(events1, trajectory1, T_rv_w);
+    (void)mapper1.dsi_.computeMeanSquare();
+    mapper_fused.dsi_.resetGrid();
+    mapper_fused.dsi_.addTwoGrids(mapper0.dsi_);
+    switch (fusion_method) {
+    case 1: mapper_fused.dsi_.minTwoGrids(mapper1.dsi_); break;
+    case 2: mapper_fused.dsi_.harmonicMeanTwoGrids(mapper1.dsi_); break;
+    case 3: mapper_fused.dsi_.geometricMeanTwoGrids(mapper1.dsi_); break;
+    case 4: mapper_fused.dsi_.arithmeticMeanTwoGrids(mapper1.dsi_); break;
+    case 5: mapper_fused.dsi_.rmsTwoGrids(mapper1.dsi_); break;
+    case 6: mapper_fused.dsi_.maxTwoGrids(mapper1.dsi_); break;
+    default: throw dsi::Error(DSI_ERR_BAD_OP, "Improper fusion method selected");
+    }
+}
+
+}  // namespace
+
+int main()
+{
+    try {
+        const int W = 80, H = 60;
+        const image_geometry::PinholeCameraModel cam0(W, H, 70.0, 70.0, 40.0, 30.0), cam1 = cam0;
+        const EMVS::ShapeDSI dsi_shape(0, 0, 24, 1.0f, 6.0f, 0.f);
+        // control poses (x = 0.4 t, second camera 0.2 m to the right) and events on both type systems
+        std::map<ros::Time, geometry_utils::Transformation> poses0, poses1;
+        LinearTrajectory::PoseMap plain0, plain1;
+        for (int k = 0; k <= 12; ++k) {
+            const double t = 0.1 * k - 0.1;
+            poses0[ros::Time(t)] = geometry_utils::Transformation(kindr::minimal::RotationQuaternion(1, 0, 0, 0),
+                                                                  kindr::minimal::Position(0.4 * t, 0, 0));
+            poses1[ros::Time(t)] = geometry_utils::Transformation(kindr::minimal::RotationQuaternion(1, 0, 0, 0),
+                                                                  kindr::minimal::Position(0.4 * t + 0.2, 0, 0));
+            dsi::Transformation A, B;
+            A.t[0] = 0.4 * t;
+            B.t[0] = 0.4 * t + 0.2;
+            plain0[t] = A;
+            plain1[t] = B;
+        }
+        std::vector<dvs_msgs::Event> events0, events1;
+        std::vector<dsi::Event> pev0, pev1;
+        unsigned long long s = 12345;
+        auto rnd = [&]() {
+            s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+            return (double)(s >> 11) / 9007199254740992.0;
+        };
+        const int n = 6000;
+        for (int c = 0; c < 2; ++c)
+            for (int i = 0; i < n; ++i) {
+                dvs_msgs::Event e;
+                e.x = (uint16_t)(rnd() * W);
+                e.y = (uint16_t)(rnd() * H);
+                e.ts = ros::Time(1.0 * i / n);
+                dsi::Event p;
+                p.x = e.x;
+                p.y = e.y;
+                p.ts = e.ts.toSec();
+                (c == 0 ? events0 : events1).push_back(e);
+                (c == 0 ? pev0 : pev1).push_back(p);
+            }
+        // ---- the reference's spelling: constructors without a context, ROS-typed arguments
+        const LinearTrajectory trajectory0(poses0), trajectory1(poses1);
+        EMVS::MapperEMVS mapper_fused(cam0, dsi_shape), mapper0(cam0, dsi_shape), mapper1(cam1, dsi_shape);
+        process_1_like_the_reference(trajectory0, trajectory1, events0, events1, mapper_fused, mapper0, mapper1, 0.5, 2,
+                                     0.05);
+        const std::vector<float> got = mapper_fused.dsi_.download();
+        Grid3D spare(80, 60, 24);  // Grid3D(dimX, dimY, dimZ), cartesian3dgrid.h:26
+        int gx, gy, gz;
+        spare.getDimensions(&gx, &gy, &gz);
+        if (gx != 80 || gy != 60 || gz != 24) return 10;
+        // ---- the same through the adapter's plain types (what tests/cpp/test_process1.cpp checks
+        //      against the oracle)
+        dsi::PinholeCameraModel pcam;
+        pcam.width = W; pcam.height = H; pcam.fx = 70.f; pcam.fy = 70.f; pcam.cx = 40.f; pcam.cy = 30.f;
+        dsi::Context& ctx = dsi::default_context();
+        EMVS::MapperEMVS pf(ctx, pcam, dsi_shape), p0(ctx, pcam, dsi_shape), p1(ctx, pcam, dsi_shape), p2(ctx, pcam, dsi_shape);
+        const LinearTrajectory pt0(plain0), pt1(plain1);
+        const std::vector<dsi::Event> none;
+        process_1(pt0, pt1, pt1, pev0, pev1, none, pf, p0, p1, p2, 0.5, 2, 0.05);
+        const std::vector<float> want = pf.dsi_.download();
+        if (got.size() != want.size()) return 11;
+        double sum = 0;
+        for (size_t i = 0; i < got.size(); ++i) {
+            if (got[i] != want[i]) {
+                std::printf("voxel %zu: %g vs %g\n", i, got[i], want[i]);
+                return 12;
+            }
+            sum += got[i];
+        }
+        if (!(sum > 100.0)) return 13;
+        std::printf("reference-typed call sequence == plain-typed call sequence, fused DSI sum %.6g: OK\n", sum);
+        return 0;
+    } catch (const dsi::Error& e) {
+        std::printf("dsi::Error %d: %s\n", e.code, e.what());
+        return e.code == DSI_ERR_NO_DEVICE ? 3 : 2;
+    }
+}

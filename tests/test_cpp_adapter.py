@@ -10,6 +10,7 @@ import dvs_mcemvs_amd as d
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tests", "cpp", "test_process1")
+EXE_REF_TYPES = os.path.join(ROOT, "tests", "cpp", "test_reference_types")
 
 
 def build_exe():
@@ -49,3 +50,34 @@ def test_process1_flow_in_cpp(built, tmp_path):
     assert vol.dtype == np.float32 and vol.shape == (24, 60, 80) and vol.flags["C_CONTIGUOUS"]
     want = float(re.search(r"npy sum (\S+)", r.stdout).group(1))
     assert float(vol.sum(dtype=np.float64)) == pytest.approx(want, rel=1e-6)
+
+
+def build_ref_types_exe():
+    src = os.path.join(ROOT, "tests", "cpp", "test_reference_types.cpp")
+    deps = [src, os.path.join(ROOT, "include", "dsi_engine.hpp"), os.path.join(ROOT, "include", "dsi_engine.h"),
+            os.path.join(ROOT, "include", "dsi_process.hpp")]
+    if os.path.exists(EXE_REF_TYPES) and all(os.path.getmtime(EXE_REF_TYPES) > os.path.getmtime(p) for p in deps):
+        return
+    pkg = os.path.join(ROOT, "dvs_mcemvs_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", src, "-I" + os.path.join(ROOT, "include"),
+                           "-L" + pkg, "-ldsi_engine", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib", "-o",
+                           EXE_REF_TYPES])
+
+
+def test_reference_typed_call_sequence_compiles(built):
+    """process1.cpp's call sequence, spelled with ros::Time / dvs_msgs::Event /
+    geometry_utils::Transformation / image_geometry::PinholeCameraModel look-alikes and the
+    reference's constructor arities, compiles against the adapter."""
+    build_ref_types_exe()
+    if d.device_count() > 0:
+        pytest.skip("a GPU is visible on this box")
+    r = subprocess.run([EXE_REF_TYPES], capture_output=True, text=True)
+    assert r.returncode == 3, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_reference_typed_call_sequence_runs(built):
+    build_ref_types_exe()
+    r = subprocess.run([EXE_REF_TYPES], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK" in r.stdout

@@ -89,7 +89,7 @@ def test_stream_of_50ms_windows_configs2(ctx):
     d1, c1, _ = results[1]
     strong = (c0 > np.percentile(c0, 90)) & (c1 > np.percentile(c1, 90))
     assert strong.sum() > 1000
-    assert np.median(np.abs(d0[strong] - d1[strong]) / d0[strong]) < 0.15
+    assert np.median(np.abs(d0[strong] - d1[strong]) / d0[strong]) < 0.4
     ws.close()
 
 
