@@ -61,6 +61,9 @@ def parse():
                     help="lane mapping: -1 auto, 0 per-packet waves, 1 packed (hand-scheduled), 2 packet groups, "
                          "3 packed (compiled), 4 groups (hand-scheduled), 5 packed + vector fill, 6 = 5 compiled")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--materialize-fused", action="store_true",
+                    help="windows: also write the fused DSI (mapper_fused.dsi_) per window instead of fusing the "
+                         "cameras inside the arg-max kernel")
     ap.add_argument("--collective", choices=["engine", "torch"], default="engine",
                     help="N > 1: who issues the all-reduce: the engine's own RCCL communicator (C ABI) or "
                          "torch.distributed")
@@ -380,7 +383,7 @@ def main():
         rig = syn.stereo_rig(n_distinct * args.events, width=640, height=480, t0=10.0 + 10.0 * rank,
                              duration=n_distinct * dur, seed=77 + rank, n_points=max(args.points, 6000))
         shape = d.ShapeDSI(nx, ny, nz, 4.0, 200.0, 0.0)
-        ws = proc.WindowStream(ctx, (rig["cam"],) * 2, shape, d.FUSE_HM)
+        ws = proc.WindowStream(ctx, (rig["cam"],) * 2, shape, d.FUSE_HM, materialize_fused=args.materialize_fused)
         for m in ws.mappers:
             tune(m)
         vote_mappers = ws.mappers
@@ -416,8 +419,10 @@ def main():
 
         voted_per_step = float(np.mean([sum(b.n_packets for b in pc) for pc, _ in wins])) * d.PACKET_SIZE
         workload = ("stream of %.0f ms windows (main.cpp:177 loop), 2 cameras x %d events per window, sensor 640x480, "
-                    "%dx%dx%d DSI, per window: reset + vote x2 + harmonic camera fusion + arg-max + depth-map fetch"
-                    % (dur * 1e3, args.events, nx, ny, nz))
+                    "%dx%dx%d DSI, per window: reset + vote x2 + harmonic camera fusion + arg-max + depth-map fetch (%s)"
+                    % (dur * 1e3, args.events, nx, ny, nz,
+                       "fused DSI written" if args.materialize_fused else
+                       "camera fusion computed inside the arg-max kernel, fused DSI not written"))
         parallelism = "1 GPU" if world == 1 else "replicas x%d (independent windows, no collective)" % world
         scaling = "weak"
         ev_per_launch = voted_per_step / 2.0

@@ -296,6 +296,8 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
         if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) S = v;
     }
     bp->group_packets = S;
+    bp->persistent = 1;
+    if (const char* e = std::getenv("DSI_PERSISTENT")) bp->persistent = std::atoi(e) != 0;  // A/B experiments
     bp->pass_lg = 0;
     if (const char* e = std::getenv("DSI_PASS_LG")) {  // tuning experiments only
         const int v = std::atoi(e);
@@ -483,7 +485,7 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
         return vote_done(m);
     }
     HIP_TRY(m->sxy.reserve(np * dsi::kPacket + 1));  // + the multiplicity-0 dummy record
-    HIP_TRY(m->nvalid.reserve(np + (size_t)geom.nz));  // + one "needs IEEE divide" word per plane
+    HIP_TRY(m->nvalid.reserve(np + (size_t)geom.nz + 8));  // + one "needs IEEE divide" word per plane + 8 work counters
     HIP_TRY(m->rowstart.reserve(np * (size_t)(geom.ny + 2 * bp.row_pad + 3)));
     HIP_TRY(m->coef.reserve(np * geom.nz + 1));       // + the dummy record's "coefficients"
     HIP_TRY(m->cuts.reserve(np * geom.nz * bp.bands));
@@ -1256,6 +1258,27 @@ int dsi_mapper_depth_map_of(dsi_mapper_t* m, dsi_grid_t* g)
     if (int rc = depth_buffers_acquire(m)) return rc;
     HIP_TRY(dsi::launch_collapse_max_z(m->ctx->stream, g->data, g->nx, g->ny, g->nz, m->conf.p, m->idx.p,
                                        m->planes_dev, m->depth.p));
+    return depth_buffers_ready(m);
+}
+
+int dsi_mapper_depth_map_of_fusion(dsi_mapper_t* m, const dsi_grid_t* a, const dsi_grid_t* b, int op)
+{
+    REQUIRE(m && a && b, DSI_ERR_INVALID, "null argument");
+    REQUIRE(m->ctx->device == a->ctx->device && m->ctx->device == b->ctx->device, DSI_ERR_CONTEXT,
+            "mapper and grids live on different devices");
+    REQUIRE(same_shape(m->grid, a) && same_shape(m->grid, b), DSI_ERR_SHAPE, "grid shape differs from the mapper's DSI");
+    REQUIRE(op >= 1 && op <= 6, DSI_ERR_BAD_OP, "improper fusion method %d (expected 1..6)", op);
+    REQUIRE(a->nz <= 256, DSI_ERR_INVALID, "arg-max indices are u8: dimZ must be <= 256 (got %d)", a->nz);
+    if (int rc = set_device(m->ctx)) return rc;
+    const size_t npix = (size_t)a->nx * a->ny;
+    HIP_TRY(m->conf.reserve(npix));
+    HIP_TRY(m->depth.reserve(npix));
+    HIP_TRY(m->idx.reserve(npix));
+    if (int rc = dsi_context_wait_for(m->ctx, a->ctx)) return rc;
+    if (int rc = dsi_context_wait_for(m->ctx, b->ctx)) return rc;
+    if (int rc = depth_buffers_acquire(m)) return rc;
+    HIP_TRY(dsi::launch_collapse_max_z_fused(m->ctx->stream, a->data, b->data, a->nx, a->ny, a->nz, op, m->conf.p,
+                                             m->idx.p, m->planes_dev, m->depth.p));
     return depth_buffers_ready(m);
 }
 

@@ -51,6 +51,7 @@ struct BandPlan {
     size_t lds_bytes;   // (band_rows + 1) * nx * 8 (u64 fixed-point accumulators; +1 = the carry row)
                         // + mapping 5: 512 B per wave for the tail-bit words
     int scratch_offset; // mapping 5: byte offset of that area behind the band
+    int persistent;     // packed mappings: workgroups pull work items from per-XCD counters
 };
 
 // distance in floats between the partial volumes of consecutive packet chunks: the volume size
@@ -105,6 +106,8 @@ hipError_t launch_depth_map_filters(hipStream_t s, float* conf, const uint8_t* i
                                     int ksize, double C, int median_size, double max_confidence,
                                     const float* planes, uint32_t* minmax_scratch, uint8_t* conf8,
                                     uint8_t* mask, uint8_t* idx_filtered, float* depth);
+hipError_t launch_collapse_max_z_fused(hipStream_t s, const float* a, const float* b, int nx, int ny, int nz, int op,
+                                       float* conf, uint8_t* idx, const float* planes, float* depth);
 hipError_t launch_mean_square(hipStream_t s, const float* dsi, size_t n, double* accum);
 
 // test hook: q[i] = residual-corrected division, ref[i] = n[i] / d[i]

@@ -15,6 +15,7 @@
 // it); explicit fmaf() calls are the only fused operations.
 #include "dsi_kernels.h"
 
+#include <algorithm>
 #include <cmath>
 #include <mutex>
 #include <vector>
@@ -245,7 +246,8 @@ __global__ __launch_bounds__(256) void k_sort_packets(const float2* __restrict__
     // nvalid[np + z]: "plane z has a coefficient set that needs the IEEE divide", set by
     // k_plane_coef (next kernel on the stream), read by the packed voting kernel
     if (k == 0) {
-        for (int i = threadIdx.x; i < nz; i += 256) nvalid[np + i] = 0;
+        // (+ 8 work counters of the persistent voting kernel behind the per-plane flags)
+        for (int i = threadIdx.x; i < nz + 8; i += 256) nvalid[np + i] = 0;
         if (threadIdx.x == 0) {  // the multiplicity-0 record behind the last packet
             const EvRec none = {0.f, 0.f, 0u};
             sxy[(size_t)np * kPacket] = none;
@@ -471,6 +473,22 @@ __device__ __forceinline__ void flush_band(const acc_t* __restrict__ band, int n
     if (carry_dst) {
         const acc_t* src = band + n_out;
         for (int i = threadIdx.x; i < nx; i += BLOCK) carry_dst[i] = (float)((double)src[i] * kFixInv);
+    }
+}
+
+// the same, leaving the band zeroed for the workgroup's next work item (persistent kernel)
+template <int BLOCK>
+__device__ __forceinline__ void flush_band_and_clear(acc_t* __restrict__ band, int nx, int n_out,
+                                                     float* __restrict__ dst, float* __restrict__ carry_dst)
+{
+    for (int i = threadIdx.x; i < n_out; i += BLOCK) {
+        dst[i] = (float)((double)band[i] * kFixInv);
+        band[i] = 0;
+    }
+    acc_t* src = band + n_out;
+    for (int i = threadIdx.x; i < nx; i += BLOCK) {
+        if (carry_dst) carry_dst[i] = (float)((double)src[i] * kFixInv);
+        src[i] = 0;
     }
 }
 
@@ -1497,12 +1515,34 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const EvRec* __rest
                                                              const uint32_t* __restrict__ slow_any,
                                                              int np, Geom g, BandPlan bp,
                                                              float* __restrict__ out,
-                                                             float* __restrict__ carry)
+                                                             float* __restrict__ carry,
+                                                             uint32_t* __restrict__ work_counters)
 {
     extern __shared__ acc_t band[];
-    const int b = blockIdx.x;
+    __shared__ int s_item;
     const int pairs = bp.chunks * bp.bands;
     const int full = (pairs / 8) * 8 * g.nz;
+    const int total = pairs * g.nz;
+    const int nx = g.nx;
+    // PERSISTENT workgroups (work_counters != nullptr): the grid is only as large as the chip holds
+    // at once and every workgroup pulls work items until none is left -- a 1024-thread workgroup
+    // with up to 160 KB of LDS costs ~5 us to launch and a CU cannot overlap that with the previous
+    // workgroup (measured at 512x512x200: 7.7 us of fixed cost per work item, 38 % of a 500 k-event
+    // launch).  Items are dealt per XCD class (block % 8, the dispatch rule the block -> (pair, plane)
+    // mapping relies on): class x takes items x, x + 8, x + 16, ... in order, through one atomic
+    // counter per class, so the load stays balanced like the hardware's own dispatch.
+    const int cls = blockIdx.x & 7;
+    if (work_counters) {
+        const int all_cells = (bp.band_rows + 1) * nx;
+        for (int i = threadIdx.x; i < all_cells; i += BLOCK) band[i] = 0;
+    }
+    for (;;) {
+    if (work_counters) {
+        if (threadIdx.x == 0) s_item = (int)atomicAdd(&work_counters[cls], 1u) * 8 + cls;
+        __syncthreads();  // also: the previous item's flush has cleared the band
+    }
+    const int b = work_counters ? s_item : (int)blockIdx.x;
+    if (b >= total) break;
     int q, z;
     if (b < full) {
         const int xcd = b & 7, s = b >> 3;
@@ -1516,10 +1556,11 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const EvRec* __rest
     const int c = q / bp.bands, j = q % bp.bands;
     const int r0 = j * bp.band_rows;
     const int r1 = min(g.ny, r0 + bp.band_rows);
-    const int nx = g.nx;
     const int cells = (r1 - r0 + 1) * nx;  // owned rows + the carry row
-    for (int i = threadIdx.x; i < cells; i += BLOCK) band[i] = 0;
-    __syncthreads();
+    if (!work_counters) {
+        for (int i = threadIdx.x; i < cells; i += BLOCK) band[i] = 0;
+        __syncthreads();
+    }
 
     const int p_begin = (int)(((long long)np * c) / bp.chunks);
     const int p_end = (int)(((long long)np * (c + 1)) / bp.chunks);
@@ -1576,7 +1617,13 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const EvRec* __rest
 
     const size_t vol = partial_stride((size_t)g.nx * g.ny * g.nz);
     float* __restrict__ dst = out + (size_t)c * vol + ((size_t)z * g.ny + r0) * nx;
-    flush_band<BLOCK>(band, nx, (r1 - r0) * nx, dst, carry_row(carry, c, z, j, g, bp));
+    if (!work_counters) {
+        flush_band<BLOCK>(band, nx, (r1 - r0) * nx, dst, carry_row(carry, c, z, j, g, bp));
+        break;
+    }
+    flush_band_and_clear<BLOCK>(band, nx, (r1 - r0) * nx, dst, carry_row(carry, c, z, j, g, bp));
+    __syncthreads();  // every thread has read s_item and cleared its cells before thread 0 draws again
+    }
 }
 
 // (3c) GROUPED mapping: S consecutive packets (a "group"; their poses are microseconds apart)
@@ -1600,7 +1647,7 @@ __global__ __launch_bounds__(256) void k_sort_groups(const float2* __restrict__ 
     const int n_ev = min(S, np - p0) * kPacket;
     const float2* __restrict__ src = xy + (size_t)p0 * kPacket;
     if (gidx == 0) {
-        for (int i = threadIdx.x; i < nz; i += 256) nvalid[np + i] = 0;  // see k_sort_packets
+        for (int i = threadIdx.x; i < nz + 8; i += 256) nvalid[np + i] = 0;  // see k_sort_packets
         if (threadIdx.x == 0) {
             const EvRec none = {0.f, 0.f, 0u};
             sxy[(size_t)np * kPacket] = none;  // the multiplicity-0 record
@@ -2065,6 +2112,54 @@ __global__ __launch_bounds__(256) void k_collapse_max_z(const float* __restrict_
     if (depth) depth[p] = planes[best_k];  // mapper_emvs_stereo.cpp:302-313
 }
 
+// collapseMaxZSlice of op(a, b) without materialising the fused volume: what
+// "fused.resetGrid(); fused.addTwoGrids(a); fused.<op>TwoGrids(b); fused.collapseMaxZSlice()"
+// (process1.cpp:126-158 + mapper_emvs_stereo.cpp:368) yields, bit for bit (the fused value is
+// computed by the same fuse_op as k_fuse2_into), with 8 instead of 12 + 4 bytes per voxel of
+// traffic.  For streams of windows that only need the depth map (main.cpp:177).
+template <int OP>
+__global__ __launch_bounds__(256) void k_collapse_max_z_fused(const float* __restrict__ a,
+                                                              const float* __restrict__ b, int npix,
+                                                              int nz, float* __restrict__ conf,
+                                                              uint8_t* __restrict__ idx,
+                                                              const float* __restrict__ planes,
+                                                              float* __restrict__ depth)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    const float* ca = a + p;
+    const float* cb = b + p;
+    float best = fuse_op<OP>(0.f + ca[0], cb[0]);
+    int best_k = 0;
+    int k = 1;
+    for (; k + 4 <= nz; k += 4) {
+        float va[4], vb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            va[u] = ca[(size_t)(k + u) * npix];
+            vb[u] = cb[(size_t)(k + u) * npix];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float v = fuse_op<OP>(0.f + va[u], vb[u]);
+            if (best < v) {
+                best = v;
+                best_k = k + u;
+            }
+        }
+    }
+    for (; k < nz; ++k) {
+        const float v = fuse_op<OP>(0.f + ca[(size_t)k * npix], cb[(size_t)k * npix]);
+        if (best < v) {
+            best = v;
+            best_k = k;
+        }
+    }
+    conf[p] = best;
+    idx[p] = (uint8_t)best_k;
+    if (depth) depth[p] = planes[best_k];
+}
+
 // cartesian3dgrid.cpp:164-174: sum of squares in double (order differs from the
 // sequential loop; relative difference ~1e-16 * log n)
 __global__ __launch_bounds__(256) void k_mean_square(const float* __restrict__ dsi, size_t n,
@@ -2327,10 +2422,23 @@ static hipError_t launch_vote_bands_t(hipStream_t s, const EvRec* sxy, const Pla
     const void* kern = PACKED ? reinterpret_cast<const void*>(&k_vote_bands_packed<BLOCK>)
                               : reinterpret_cast<const void*>(&k_vote_bands<BLOCK>);
     if (hipError_t e = allow_dynamic_lds(kern, bp.lds_bytes)) return e;
-    const unsigned blocks = (unsigned)(bp.chunks * bp.bands) * (unsigned)g.nz;
+    unsigned blocks = (unsigned)(bp.chunks * bp.bands) * (unsigned)g.nz;
+    uint32_t* counters = nullptr;
+    if (PACKED && bp.persistent) {
+        // as many workgroups as are resident at once: per CU, what the LDS and the 2048-thread limit allow
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const unsigned per_cu = std::max<unsigned>(1, std::min<unsigned>(2048u / BLOCK, (unsigned)(max_dynamic_lds() / std::max<size_t>(1, bp.lds_bytes))));
+        unsigned resident = (unsigned)cus * per_cu;
+        resident -= resident % 8;
+        if (resident >= 8 && blocks > resident) {
+            blocks = resident;
+            counters = const_cast<uint32_t*>(slow_any) + g.nz;  // 8 counters behind the per-plane flags (zeroed by the sort kernel)
+        }
+    }
     if (PACKED)
         hipLaunchKernelGGL(k_vote_bands_packed<BLOCK>, dim3(blocks), dim3(BLOCK), bp.lds_bytes, s,
-                           sxy, coef, cuts, slow_any, np, g, bp, out, carry);
+                           sxy, coef, cuts, slow_any, np, g, bp, out, carry, counters);
     else
         hipLaunchKernelGGL(k_vote_bands<BLOCK>, dim3(blocks), dim3(BLOCK), bp.lds_bytes, s, sxy, coef,
                            cuts, np, g, bp, out, carry);
@@ -2560,6 +2668,23 @@ hipError_t launch_collapse_max_z(hipStream_t s, const float* dsi, int nx, int ny
     hipLaunchKernelGGL(k_collapse_max_z, dim3((npix + 255) / 256), dim3(256), 0, s, dsi, npix, nz,
                        conf, idx, planes, depth);
     return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
+}
+
+hipError_t launch_collapse_max_z_fused(hipStream_t s, const float* a, const float* b, int nx, int ny, int nz, int op,
+                                       float* conf, uint8_t* idx, const float* planes, float* depth)
+{
+    const int npix = nx * ny;
+    const dim3 grid((npix + 255) / 256), block(256);
+    switch (op) {
+    case 1: hipLaunchKernelGGL(k_collapse_max_z_fused<1>, grid, block, 0, s, a, b, npix, nz, conf, idx, planes, depth); break;
+    case 2: hipLaunchKernelGGL(k_collapse_max_z_fused<2>, grid, block, 0, s, a, b, npix, nz, conf, idx, planes, depth); break;
+    case 3: hipLaunchKernelGGL(k_collapse_max_z_fused<3>, grid, block, 0, s, a, b, npix, nz, conf, idx, planes, depth); break;
+    case 4: hipLaunchKernelGGL(k_collapse_max_z_fused<4>, grid, block, 0, s, a, b, npix, nz, conf, idx, planes, depth); break;
+    case 5: hipLaunchKernelGGL(k_collapse_max_z_fused<5>, grid, block, 0, s, a, b, npix, nz, conf, idx, planes, depth); break;
+    case 6: hipLaunchKernelGGL(k_collapse_max_z_fused<6>, grid, block, 0, s, a, b, npix, nz, conf, idx, planes, depth); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipExtGetLastError();
 }
 
 hipError_t launch_mean_square(hipStream_t s, const float* dsi, size_t n, double* accum)

@@ -138,6 +138,7 @@ def load_library():
         "dsi_mapper_depth_map": (C.c_int, [vp, f32p, f32p, u8p]),
         "dsi_mapper_depth_map_of": (C.c_int, [vp, vp]),
         "dsi_mapper_fetch_depth_map": (C.c_int, [vp, f32p, f32p, u8p]),
+        "dsi_mapper_depth_map_of_fusion": (C.c_int, [vp, vp, vp, C.c_int]),
         "dsi_mapper_get_depth_map_from_dsi": (C.c_int, [vp, vp, C.POINTER(_DepthMapOptions), f32p, f32p,
                                                        u8p, u8p]),
         "dsi_mapper_last_vote_info": (C.c_int, [vp, C.POINTER(_VoteInfo)]),
@@ -711,6 +712,11 @@ class MapperEMVS:
     def computeDepthMap(self, grid=None):
         """Asynchronous half of getDepthMapFromDSI; pair with fetchDepthMap()."""
         _check(load_library().dsi_mapper_depth_map_of(self._h, (grid or self.dsi_)._h))
+
+    def computeDepthMapOfFusion(self, grid_a, grid_b, fusion_method):
+        """computeDepthMap of op(grid_a, grid_b) without materialising the fused DSI (bit-identical to
+        setToFusionOf + computeDepthMap; one pass over the two volumes)."""
+        _check(load_library().dsi_mapper_depth_map_of_fusion(self._h, grid_a._h, grid_b._h, int(fusion_method)))
 
     def computeDepthMapSharded(self, grid, comm):
         """Plane-sharded arg-max: local collapse of this rank's plane range, ONE all-reduce(MAX) of

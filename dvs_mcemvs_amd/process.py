@@ -191,13 +191,17 @@ class WindowStream:
     window (main.cpp:262-275); here they are reused -- evaluateDSI resets the DSI anyway (:145)."""
 
     def __init__(self, ctx, cams, dsi_shape, fusion_method=E.FUSE_HM, luts=(None, None),
-                 inverse_depth=False, depth=2):
+                 inverse_depth=False, depth=2, materialize_fused=True):
+        """materialize_fused=False: the fused DSI (the reference's mapper_fused.dsi_) is not written;
+        the camera fusion happens inside the arg-max kernel (same bits, one pass less over the
+        volume) -- for streams that only keep the depth maps."""
         self.ctx = ctx
+        self.materialize_fused = bool(materialize_fused)
         self.fusion_method = int(fusion_method)
         self.mappers = [E.MapperEMVS(ctx, cams[c], dsi_shape, lut=luts[c], inverse_depth=inverse_depth)
                         for c in range(2)]
         dims = self.mappers[0].dsi_.getDimensions()
-        self.fused = [E.Grid3D(ctx, *dims) for _ in range(depth)]
+        self.fused = [E.Grid3D(ctx, *dims) if self.materialize_fused else None for _ in range(depth)]
         self.extract = [E.MapperEMVS(ctx, cams[0], dsi_shape, inverse_depth=inverse_depth) for _ in range(depth)]
         self.k = 0
         self.voted = 0
@@ -241,8 +245,12 @@ class WindowStream:
                 own.append(b)
             self.mappers[c].evaluateDSI_batch(b)
             self.voted += b.n_packets * E.PACKET_SIZE
-        self.fused[slot].setToFusionOf(self.mappers[0].dsi_, self.mappers[1].dsi_, self.fusion_method)
-        self.extract[slot].computeDepthMap(self.fused[slot])
+        if self.materialize_fused:
+            self.fused[slot].setToFusionOf(self.mappers[0].dsi_, self.mappers[1].dsi_, self.fusion_method)
+            self.extract[slot].computeDepthMap(self.fused[slot])
+        else:
+            self.extract[slot].computeDepthMapOfFusion(self.mappers[0].dsi_, self.mappers[1].dsi_,
+                                                       self.fusion_method)
         for b in own:
             b.close()                               # the block returns to the pool once its readers are done
         self.k += 1
@@ -256,7 +264,7 @@ class WindowStream:
         return self.fused[slot]
 
     def close(self):
-        for o in self.mappers + self.fused + self.extract:
+        for o in self.mappers + [f for f in self.fused if f is not None] + self.extract:
             o.close()
         for pair in self._pins.values():
             for a in pair:

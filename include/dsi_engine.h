@@ -309,6 +309,11 @@ DSI_API int dsi_mapper_depth_map(dsi_mapper_t *m, float *depth_host, float *conf
 /* the same for any grid of the mapper's shape (e.g. a fused DSI); asynchronous variant
  * keeps results in the mapper's device buffers until dsi_mapper_fetch_depth_map */
 DSI_API int dsi_mapper_depth_map_of(dsi_mapper_t *m, dsi_grid_t *g);
+/* depth map of op(a, b) (op = dsi_fuse_op_t) WITHOUT materialising the fused DSI: exactly what
+ * "fused.resetGrid(); fused.addTwoGrids(a); fused.<op>TwoGrids(b)" (process1.cpp:126-158) followed by
+ * dsi_mapper_depth_map_of(m, fused) gives, bit for bit, in one pass over a and b.  For streams of
+ * windows that only keep the depth map (main.cpp:177-302). */
+DSI_API int dsi_mapper_depth_map_of_fusion(dsi_mapper_t *m, const dsi_grid_t *a, const dsi_grid_t *b, int op);
 DSI_API int dsi_mapper_fetch_depth_map(dsi_mapper_t *m, float *depth_host, float *conf_host, uint8_t *idx_host);
 /* the same without waiting: the copies are queued (on the context's copy stream, behind the arg-max
  * only -- not behind later work of the compute stream); the outputs (page-locked memory from

@@ -350,6 +350,41 @@ def test_depth_map_of_fused_grid(ctx):
     assert np.abs(depth - orc.indices_to_depth(ridx, ms[0].raw_depths_vec_)).max() <= 1e-4
 
 
+@pytest.mark.parametrize("shape", [(64, 48, 16), (50, 40, 7), (33, 17, 1), (96, 72, 130)])
+def test_depth_map_of_fusion_equals_fuse_then_collapse(ctx, shape):
+    """dsi_mapper_depth_map_of_fusion (camera fusion inside the arg-max kernel) = the reference's
+    sequence resetGrid / addTwoGrids / <op>TwoGrids (process1.cpp:126-158) then collapseMaxZSlice +
+    convertDepthIndicesToValues, for every op code, bit for bit -- ties and all-zero columns included."""
+    nx, ny, nz = shape
+    rng = np.random.default_rng(nx + nz)
+    a = np.floor(rng.gamma(1.5, 2.0, (nz, ny, nx))).astype(np.float32)      # integers: many ties
+    g = np.floor(rng.gamma(1.5, 2.0, (nz, ny, nx))).astype(np.float32)
+    a[:, :2] = 0.0
+    g[:, 1:3] = 0.0
+    a[:, 5, 5] = 3.25
+    g[:, 5, 5] = 3.25                                                         # a whole column tied: index 0
+    cam = (nx, ny, 0.8 * nx, 0.8 * nx, 0.5 * nx, 0.5 * ny)
+    m = d.MapperEMVS(ctx, cam, d.ShapeDSI(0, 0, nz, 1.0, 9.0, 0.0))
+    A, G, F = d.Grid3D(ctx, nx, ny, nz), d.Grid3D(ctx, nx, ny, nz), d.Grid3D(ctx, nx, ny, nz)
+    A.upload(a)
+    G.upload(g)
+    for op in range(1, 7):
+        F.setToFusionOf(A, G, op)
+        m.computeDepthMap(F)
+        want = m.fetchDepthMap()
+        m.computeDepthMapOfFusion(A, G, op)
+        got = m.fetchDepthMap()
+        for x, y in zip(got, want):
+            assert np.array_equal(x, y), "op %d" % op
+        rconf, ridx = orc.collapse_max_z(orc.fuse2(a, g, op))
+        assert np.array_equal(got[2], ridx) and np.array_equal(got[1], rconf)
+    with pytest.raises(d.DsiError) as e:
+        m.computeDepthMapOfFusion(A, G, 7)
+    assert e.value.code == 5
+    for o in (m, A, G, F):
+        o.close()
+
+
 def test_residual_corrected_division_is_ieee(ctx):
     """The banded kernel's 5-op division must equal the IEEE divide bit for bit wherever it
     is used (2^-40 <= |d| <= 2^40), otherwise its coordinates would not be the oracle's."""

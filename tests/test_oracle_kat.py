@@ -323,3 +323,67 @@ def test_nary_fusion_modes_against_float64_and_the_two_ary_ops():
     # identities: a rank that owns no map contributes the identity to the all-reduce
     for mode, ident in ((0, 0.0), (2, 0.0), (3, 0.0), (4, np.inf), (5, -np.inf)):
         assert np.all(orc.accumulate_begin((3, 2), mode) == ident)
+
+
+def test_c_oracle_equals_the_independent_numpy_restatement_bit_for_bit():
+    """oracle/dsi_oracle.c against tests/independent_numpy.py -- a second restatement of the same
+    reference lines, vectorised and differently structured: depth planes, per-packet geometry, z0
+    warp (identity and LUT), fillVoxelGrid (sequential vote order), every fusion op, the temporal
+    accumulators and the arg-max.  Bit equality of two independently written programs is what
+    stands in for the golden vectors the reference does not have."""
+    import independent_numpy as ind
+    from dvs_mcemvs_amd import synthetic as syn
+    rng = np.random.default_rng(11)
+    for inverse in (False, True):
+        for nz in (1, 7, 100, 256):
+            assert np.array_equal(orc.depth_planes(0.7, 31.0, nz, inverse), ind.depth_planes(0.7, 31.0, nz, inverse))
+    nx, ny, nz, npk = 96, 72, 12, 5
+    cam = syn.camera(nx, ny)
+    K = np.array(cam[2:], np.float32)
+    Kv = np.array([K[0], K[0], K[2], K[3]], np.float32)
+    planes = orc.depth_planes(1.0, 7.0, nz)
+    # per-packet poses: small rotations + translations
+    Rt = np.empty((npk, 12), np.float32)
+    for k in range(npk):
+        ang = rng.normal(0, 0.02, 3)
+        Rx = np.array([[1, 0, 0], [0, np.cos(ang[0]), -np.sin(ang[0])], [0, np.sin(ang[0]), np.cos(ang[0])]])
+        Ry = np.array([[np.cos(ang[1]), 0, np.sin(ang[1])], [0, 1, 0], [-np.sin(ang[1]), 0, np.cos(ang[1])]])
+        Rt[k, :9] = (Rx @ Ry).astype(np.float32).reshape(-1)
+        Rt[k, 9:] = rng.normal(0, 0.15, 3)
+    centers_c, H_c = orc.packet_geometry(Rt, K, Kv, planes[0])
+    ex = rng.integers(0, nx, npk * 1024).astype(np.uint16)
+    ey = rng.integers(0, ny, npk * 1024).astype(np.uint16)
+    lut = syn.radial_lut(cam)
+    for use_lut in (None, lut):
+        xy_c = orc.warp_z0(ex, ey, H_c, use_lut, nx)
+        for k in range(npk):
+            C, H = ind.packet_geometry(Rt[k], K, Kv, planes[0])
+            assert np.array_equal(C, centers_c[k]) and np.array_equal(H.reshape(-1), H_c[k])
+            sl = slice(k * 1024, (k + 1) * 1024)
+            assert np.array_equal(ind.warp_z0(ex[sl], ey[sl], H, use_lut, nx), xy_c[sl])
+    xy = orc.warp_z0(ex, ey, H_c, None, nx)
+    xy[7] = (np.nan, 3.0)                       # rejected by the >= tests
+    xy[9] = (np.inf, 3.0)
+    xy[11] = (3.0e38, 3.0)
+    xy[13] = (-0.0, 2.5)                        # accepted (>= 0)
+    xy[15] = (nx - 1.0, 2.5)                    # x + 1 == nx: rejected
+    centers = centers_c.copy()
+    centers[3] = (0.1, 0.1, planes[0])          # d == 0 on every plane: inf / nan coordinates
+    dsi_c = orc.fill_voxel_grid(xy, centers, planes, Kv, nx, ny)
+    dsi_n = ind.fill_voxel_grid(xy, centers, planes, Kv, nx, ny)
+    assert dsi_c.sum() > 1000
+    assert np.array_equal(dsi_c, dsi_n)
+    g = np.roll(dsi_c, 5, axis=2) * np.float32(1.7)
+    for op in range(1, 7):
+        assert np.array_equal(orc.fuse2(dsi_c, g, op), ind.fuse2(dsi_c, g, op)), op
+    for n in (3, 4):
+        assert np.array_equal(orc.fuse_hm_n(dsi_c, g, n), ind.fuse_hm_n(dsi_c, g, n))
+    for mode in (0, 1):
+        acc_c, acc_n = np.zeros_like(g), np.zeros_like(g)
+        for v in (dsi_c, g, dsi_c):
+            acc_c, acc_n = orc.accumulate(acc_c, v, mode), ind.accumulate(acc_n, v, mode)
+        assert np.array_equal(acc_c, acc_n)
+        assert np.array_equal(orc.finalize(acc_c, mode, 3), ind.finalize(acc_n, mode, 3))
+    conf_c, idx_c = orc.collapse_max_z(dsi_c)
+    conf_n, idx_n = ind.collapse_max_z(dsi_c)
+    assert np.array_equal(conf_c, conf_n) and np.array_equal(idx_c, idx_n)
