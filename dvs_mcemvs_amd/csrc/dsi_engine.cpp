@@ -184,6 +184,7 @@ struct dsi_mapper {
     int algo = DSI_VOTE_AUTO;
     int want_band_rows = 0, want_chunks = 0, want_block = 0;
     int want_packed = -1;  // -1 automatic, 0 per-packet waves, 1 packed lanes, 2 packet groups
+    bool keep_z0 = false;  // tests: materialise event_locations_z0 (stage A as separate kernels)
     dsi_vote_info_t info{};
     // scratch
     DevBuf<float> centers, H, partials, Rt_tmp, conf, depth;
@@ -296,8 +297,8 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
         if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) S = v;
     }
     bp->group_packets = S;
-    bp->persistent = 1;
-    if (const char* e = std::getenv("DSI_PERSISTENT")) bp->persistent = std::atoi(e) != 0;  // A/B experiments
+    bp->persistent = (bp->packed == 1 || bp->packed == 3 || bp->packed == 5 || bp->packed == 6) ? 1 : 0;
+    if (const char* e = std::getenv("DSI_PERSISTENT")) bp->persistent = bp->persistent && std::atoi(e) != 0;  // A/B experiments
     bp->pass_lg = 0;
     if (const char* e = std::getenv("DSI_PASS_LG")) {  // tuning experiments only
         const int v = std::atoi(e);
@@ -305,7 +306,14 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
     }
     int chunks = m->want_chunks;
     if (chunks <= 0) {
-        const long items_target = 8L * 256;  // ~8 work items per CU
+        // Work items = chunks x bands x planes.  With persistent workgroups pulling items from per-XCD
+        // counters ~3.5 items per resident workgroup keep the tail short (measured at 346x260x100,
+        // 10 M events: 2 chunks 1.33 ms, 4 chunks 1.35 ms, 1 chunk 1.36 ms; every chunk beyond the
+        // first costs a partial volume to write and to reduce); without them ~8 per CU.
+        // (one workgroup per CU -- the band takes more than half the LDS: items are twice as heavy and
+        //  the tail of the last round weighs more; 640x480x100: 2 chunks 1.57 ms, 1 chunk 1.69 ms)
+        const bool two_per_cu = bp->lds_bytes * 2 <= dsi::max_dynamic_lds() && bp->block_threads <= 1024;
+        const long items_target = (bp->persistent && two_per_cu) ? 7L * 256 : 8L * 256;
         chunks = (int)std::max<long>(1, (items_target + (long)bands * g.nz - 1) / ((long)bands * g.nz));
         // below ~8 M events one chunk is faster when the planes alone fill the chip 1.5 times: no
         // partial volumes to write and reduce, fewer workgroup set-ups (measured at 346x260x100:
@@ -315,7 +323,7 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
         int step = 8;
         for (int f = 2; f <= 8; f *= 2)
             if (bands % f == 0) step = 8 / f;
-        if (chunks > 1) chunks = ((chunks + step - 1) / step) * step;  // whole groups of 8 pairs
+        if (chunks > 1 && !bp->persistent) chunks = ((chunks + step - 1) / step) * step;  // whole groups of 8 pairs
         chunks = (int)std::min<size_t>((size_t)chunks, std::max<size_t>(1, n_packets));
         const size_t vol_bytes = (size_t)g.nx * g.ny * g.nz * sizeof(float);
         const size_t budget = (size_t)16 << 30;  // partial DSIs may use up to 16 GiB of HBM
@@ -438,8 +446,21 @@ int depth_buffers_fetch(dsi_mapper* m, float* depth_host, float* conf_host, uint
 // centers: np*3.  accumulate != 0: add to the grid's current contents.  ps: the stream the sort and
 // coefficient kernels go to (see prep_begin); the caller has already put xy / centers on it.
 int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np, bool accumulate,
-                hipStream_t ps)
+                hipStream_t ps, const dsi_batch* raw = nullptr)
 {
+    // raw != nullptr: the events of `raw` have not been through stage A yet (xy / centers are the
+    // mapper's buffers to fill).  The LDS-band path with per-packet sorting does stage A inside the
+    // sort kernel; the other paths run the two stage-A kernels first.
+    auto stage_a = [&]() -> int {
+        if (!raw || np == 0) return DSI_OK;
+        HIP_TRY(m->H.reserve(np * 9));
+        HIP_TRY(m->xy.reserve(np * dsi::kPacket));
+        HIP_TRY(dsi::launch_packet_geometry(ps, raw->Rt, (int)np, m->geom, m->centers.p, m->H.p));
+        HIP_TRY(dsi::launch_warp_z0(ps, raw->x, raw->y, raw->first, (int)np, m->H.p, m->lut_dev, m->sensor_w,
+                                    m->xy.p));
+        xy = m->xy.p;
+        return DSI_OK;
+    };
     dsi_context* ctx = m->ctx;
     dsi_grid* g = m->grid;
     const dsi::Geom& geom = m->geom;
@@ -456,6 +477,7 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
     m->depth_valid = false;
 
     if (algo == DSI_VOTE_GLOBAL_ATOMIC) {
+        if (int rc = stage_a()) return rc;
         if (int rc = prep_end(m, ps)) return rc;
         if (!accumulate) HIP_TRY(hipMemsetAsync(g->data, 0, g->n * sizeof(float), ctx->stream));
         VoteTimer vt(m);
@@ -494,6 +516,7 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
     if (!direct) HIP_TRY(m->partials.reserve((size_t)bp.chunks * dsi::partial_stride(g->n)));
 
     if (bp.packed == 2 || bp.packed == 4) {
+        if (int rc = stage_a()) return rc;
         const int S = bp.group_packets;
         const size_t ngroups = (np + S - 1) / S;
         HIP_TRY(m->spk.reserve(np * dsi::kPacket));
@@ -511,7 +534,15 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
                                         bp, direct ? g->data : m->partials.p, m->carry.p));
         vt.stop();
     } else {
-    HIP_TRY(dsi::launch_sort_packets(ps, xy, (int)np, geom.ny, geom.nz, bp.row_pad, m->sxy.p, m->nvalid.p, m->rowstart.p));
+    if (raw && !m->keep_z0) {
+        HIP_TRY(dsi::launch_sort_packets_raw(ps, raw->Rt, raw->x, raw->y, raw->first, m->lut_dev, m->sensor_w, geom,
+                                             m->centers.p, (int)np, bp.row_pad, m->sxy.p, m->nvalid.p,
+                                             m->rowstart.p));
+    } else {
+        if (int rc = stage_a()) return rc;
+        HIP_TRY(dsi::launch_sort_packets(ps, xy, (int)np, geom.ny, geom.nz, bp.row_pad, m->sxy.p, m->nvalid.p,
+                                         m->rowstart.p));
+    }
     HIP_TRY(dsi::launch_plane_coef(ps, centers, m->planes_dev, m->rowstart.p, m->nvalid.p, (int)np,
                                    geom, bp, m->coef.p, m->cuts.p));
     if (int rc = prep_end(m, ps)) return rc;
@@ -796,6 +827,21 @@ int dsi_grid_accumulate(dsi_grid_t* dst, const dsi_grid_t* src, int mode)
     if (int rc = check_pair(dst, src)) return rc;
     REQUIRE(valid_acc_mode(mode), DSI_ERR_BAD_OP, "bad accumulate mode %d", mode);
     HIP_TRY(dsi::launch_accumulate(dst->ctx->stream, dst->data, src->data, dst->n, mode));
+    return DSI_OK;
+}
+
+int dsi_grid_fuse_n(dsi_grid_t* dst, const dsi_grid_t* const* srcs, int n, int mode)
+{
+    REQUIRE(dst && srcs, DSI_ERR_INVALID, "null argument");
+    REQUIRE(valid_acc_mode(mode), DSI_ERR_BAD_OP, "bad accumulate mode %d", mode);
+    REQUIRE(n >= 1 && n <= 8, DSI_ERR_INVALID, "1 <= n <= 8 sources (got %d)", n);
+    const float* ptrs[8];
+    for (int i = 0; i < n; ++i) {
+        if (int rc = check_pair(dst, srcs[i])) return rc;
+        REQUIRE(srcs[i] != dst, DSI_ERR_INVALID, "dst must not be one of the sources");
+        ptrs[i] = srcs[i]->data;
+    }
+    HIP_TRY(dsi::launch_fuse_n(dst->ctx->stream, dst->data, ptrs, n, dst->n, mode));
     return DSI_OK;
 }
 
@@ -1174,16 +1220,12 @@ int dsi_mapper_evaluate_batch(dsi_mapper_t* m, const dsi_batch_t* batch)
     hipStream_t ps = ctx->stream;
     if (np) {
         HIP_TRY(m->centers.reserve(np * 3));
-        HIP_TRY(m->H.reserve(np * 9));
-        HIP_TRY(m->xy.reserve(np * dsi::kPacket));
         if (int rc = prep_begin(m, &ps)) return rc;
         if (batch->ready) HIP_TRY(hipStreamWaitEvent(ps, batch->ready, 0));  // uploaded on the copy stream
-        HIP_TRY(dsi::launch_packet_geometry(ps, batch->Rt, (int)np, m->geom, m->centers.p, m->H.p));
-        HIP_TRY(dsi::launch_warp_z0(ps, batch->x, batch->y, batch->first, (int)np, m->H.p,
-                                    m->lut_dev, m->sensor_w, m->xy.p));
     }
+    // stage A (:108-142) happens inside vote_device (fused into the packet sort on the default path);
     // resetGrid (:145) is folded into the vote: accumulate = false
-    return vote_device(m, m->xy.p, m->centers.p, np, /*accumulate=*/false, ps);
+    return vote_device(m, m->xy.p, m->centers.p, np, /*accumulate=*/false, ps, batch);
 }
 
 int dsi_pose_at(const double* traj_times, const double* traj_poses, size_t n_poses, double t, double* out)

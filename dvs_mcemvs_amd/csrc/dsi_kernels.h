@@ -68,6 +68,11 @@ hipError_t launch_warp_z0(hipStream_t s, const uint16_t* ex, const uint16_t* ey,
 hipError_t launch_vote_global(hipStream_t s, const float2* xy, const float* centers, int np,
                               const float* planes, const Geom& g, float* dsi);
 // ---- stage B, LDS row-band form -------------------------------------------
+// the same with stage A (per-packet geometry + z0 warp) fused in: raw events in, centers out
+hipError_t launch_sort_packets_raw(hipStream_t s, const float* Rt, const uint16_t* ex, const uint16_t* ey,
+                                   const uint32_t* packet_first, const float2* lut, int sensor_w, const Geom& g,
+                                   float* centers, int np, int pad, EvRec* sxy, uint32_t* nvalid,
+                                   uint16_t* rowstart);
 hipError_t launch_sort_packets(hipStream_t s, const float2* xy, int np, int ny, int nz, int pad,
                                EvRec* sxy, uint32_t* nvalid, uint16_t* rowstart);
 hipError_t launch_plane_coef(hipStream_t s, const float* centers, const float* planes,
@@ -96,6 +101,7 @@ hipError_t launch_fuse_hm_n(hipStream_t s, float* a, const float* g, size_t n, i
 hipError_t launch_accumulate(hipStream_t s, float* acc, const float* g, size_t n, int mode);
 hipError_t launch_finalize(hipStream_t s, float* acc, size_t n, int mode, int n_maps);
 hipError_t launch_fill(hipStream_t s, float* a, size_t n, float v);
+hipError_t launch_fuse_n(hipStream_t s, float* dst, const float* const* srcs, int n_src, size_t n, int mode);
 hipError_t launch_pack_argmax(hipStream_t s, const float* conf, const uint8_t* idx, int n, int plane_begin,
                               unsigned long long* keys);
 hipError_t launch_unpack_argmax(hipStream_t s, const unsigned long long* keys, int n, const float* planes_full,

@@ -95,21 +95,20 @@ __device__ __forceinline__ void plane_coefficients(float cx_, float cy_, float c
 
 // ---------------------------------------------------------------- stage A --
 // mapper_emvs_stereo.cpp:101-126: one thread per packet.
-__global__ void k_packet_geometry(const float* __restrict__ Rt, int np, Geom g,
-                                  float* __restrict__ centers, float* __restrict__ H)
+// camera centre (3 floats) and H_z0 (9 floats, row-major) of one packet from its pose Rt (12 floats)
+__device__ __forceinline__ void packet_geometry_of(const float* __restrict__ Rtk, const Geom& g,
+                                                   float* __restrict__ center, float* __restrict__ Hout)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= np) return;
     float R[9], t[3];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) R[i] = Rt[12 * k + i];
+    for (int i = 0; i < 9; ++i) R[i] = Rtk[i];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) t[i] = Rt[12 * k + 9 + i];
+    for (int i = 0; i < 3; ++i) t[i] = Rtk[9 + i];
 
     // :108  C = -R^T t
 #pragma unroll
     for (int i = 0; i < 3; ++i)
-        centers[3 * k + i] = dot3(-R[i], t[0], -R[3 + i], t[1], -R[6 + i], t[2]);
+        center[i] = dot3(-R[i], t[0], -R[3 + i], t[1], -R[6 + i], t[2]);
 
     // :114-116
     float Hinv[9];
@@ -127,7 +126,35 @@ __global__ void k_packet_geometry(const float* __restrict__ Rt, int np, Geom g,
     mul3x3(M1, Kvinv, M);
     inverse3x3(M, Hk);       // :120
 #pragma unroll
-    for (int i = 0; i < 9; ++i) H[9 * k + i] = Hk[i];
+    for (int i = 0; i < 9; ++i) Hout[i] = Hk[i];
+}
+
+__global__ void k_packet_geometry(const float* __restrict__ Rt, int np, Geom g,
+                                  float* __restrict__ centers, float* __restrict__ H)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= np) return;
+    packet_geometry_of(Rt + 12 * (size_t)k, g, centers + 3 * (size_t)k, H + 9 * (size_t)k);
+}
+
+// mapper_emvs_stereo.cpp:129-142 for one event: LUT, 4x4 packet product ((c0*u + c1*v) + c2*1) + c3*0,
+// p /= p[2]
+__device__ __forceinline__ float2 warp_event_z0(unsigned x, unsigned y, const float* __restrict__ h,
+                                                const float2* __restrict__ lut, int sensor_w)
+{
+    float u, v;
+    if (lut) {
+        const float2 p = lut[(size_t)y * sensor_w + x];  // :134
+        u = p.x;
+        v = p.y;
+    } else {
+        u = (float)x;
+        v = (float)y;
+    }
+    const float px = ((h[0] * u + h[1] * v) + h[2] * 1.f) + 0.f;
+    const float py = ((h[3] * u + h[4] * v) + h[5] * 1.f) + 0.f;
+    const float pz = ((h[6] * u + h[7] * v) + h[8] * 1.f) + 0.f;
+    return make_float2(px / pz, py / pz);
 }
 
 // mapper_emvs_stereo.cpp:129-142: one thread per event slot of a packet.
@@ -141,23 +168,9 @@ __global__ void k_warp_z0(const uint16_t* __restrict__ ex, const uint16_t* __res
     const float* h = H + 9 * (size_t)k;
     const float h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3], h4 = h[4], h5 = h[5], h6 = h[6],
                 h7 = h[7], h8 = h[8];
-    for (int j = threadIdx.x; j < kPacket; j += blockDim.x) {
-        const unsigned x = ex[first + j], y = ey[first + j];
-        float u, v;
-        if (lut) {
-            const float2 p = lut[(size_t)y * sensor_w + x];  // :134
-            u = p.x;
-            v = p.y;
-        } else {
-            u = (float)x;
-            v = (float)y;
-        }
-        // :138 4x4 packet product ((c0*u + c1*v) + c2*1) + c3*0 ; :139 p /= p[2]
-        const float px = ((h0 * u + h1 * v) + h2 * 1.f) + 0.f;
-        const float py = ((h3 * u + h4 * v) + h5 * 1.f) + 0.f;
-        const float pz = ((h6 * u + h7 * v) + h8 * 1.f) + 0.f;
-        xy[(size_t)k * kPacket + j] = make_float2(px / pz, py / pz);
-    }
+    const float hh[9] = {h0, h1, h2, h3, h4, h5, h6, h7, h8};
+    for (int j = threadIdx.x; j < kPacket; j += blockDim.x)
+        xy[(size_t)k * kPacket + j] = warp_event_z0(ex[first + j], ey[first + j], hh, lut, sensor_w);
 }
 
 // ------------------------------------------------- stage B: global atomics --
@@ -231,12 +244,28 @@ __device__ __forceinline__ int row_bin(float y0, int ny, int pad)
 constexpr int kHashSlots = 2048;  // >= 2 * kPacket
 constexpr unsigned long long kHashEmpty = ~0ull;  // a NaN pair: never a finite location
 
-__global__ __launch_bounds__(256) void k_sort_packets(const float2* __restrict__ xy, int np, int ny,
+// Stage A of a packet, fused in when the events come raw (xy == nullptr): the block computes its
+// packet's camera centre and H_z0 (one thread; written to `centers` for k_plane_coef) and warps its
+// 1024 events to z0 in registers -- the z0 locations never go through HBM (saves 8 B written +
+// 8 B read per event and two launches per evaluateDSI).
+struct RawEvents {
+    const float* Rt;             // [np][12]
+    const uint16_t *ex, *ey;
+    const uint32_t* packet_first;  // or nullptr: packet k starts at k * 1024
+    const float2* lut;             // or nullptr: identity
+    int sensor_w;
+    Geom g;
+    float* centers;              // out [np][3]
+};
+
+__global__ __launch_bounds__(256) void k_sort_packets(const float2* __restrict__ xy, RawEvents raw,
+                                                      int np, int ny,
                                                       int nz, int pad, EvRec* __restrict__ sxy,
                                                       uint32_t* __restrict__ nvalid,
                                                       uint16_t* __restrict__ rowstart)
 {
     extern __shared__ uint32_t hist[];  // nb + 1 counters, then scanned in place
+    __shared__ float s_H[9];
     __shared__ unsigned long long hkey[kHashSlots];
     __shared__ uint32_t hcnt[kHashSlots];
     __shared__ uint32_t wave_tot[4];
@@ -259,13 +288,27 @@ __global__ __launch_bounds__(256) void k_sort_packets(const float2* __restrict__
         hkey[i] = kHashEmpty;
         hcnt[i] = 0;
     }
+    if (!xy && threadIdx.x == 0) {
+        float c3[3], h9[9];
+        packet_geometry_of(raw.Rt + 12 * (size_t)k, raw.g, c3, h9);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) raw.centers[3 * (size_t)k + i] = c3[i];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) s_H[i] = h9[i];
+    }
     __syncthreads();
     float2 ev[4];
     int bin[4], slot[4];
     uint32_t rank[4];
+    const size_t first_ev = (!xy && raw.packet_first) ? (size_t)raw.packet_first[k] : (size_t)k * kPacket;
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
-        ev[h] = xy[(size_t)k * kPacket + threadIdx.x + 256 * h];
+        if (xy) {
+            ev[h] = xy[(size_t)k * kPacket + threadIdx.x + 256 * h];
+        } else {
+            const size_t e = first_ev + threadIdx.x + 256 * h;
+            ev[h] = warp_event_z0(raw.ex[e], raw.ey[e], s_H, raw.lut, raw.sensor_w);
+        }
         bin[h] = -1;
         slot[h] = 0;
         rank[h] = 0;
@@ -1508,8 +1551,12 @@ __device__ __forceinline__ void group_stream_asm(const EvRec* sxy, const uint4* 
           "v59", "v60", "v61", "v62", "v63");
 }
 
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const EvRec* __restrict__ sxy,
+// MAPPING = the lane mapping (1 packed / hand-scheduled, 3 packed / compiled, 5 vector fill /
+// hand-scheduled, 6 vector fill / compiled): one kernel per mapping, so that each carries only its own
+// streams (all of them in one kernel needed 70 VGPRs -- 7 waves per SIMD, i.e. ONE 1024-thread
+// workgroup per CU instead of two -- and spilled scalars).  8 waves per SIMD = at most 64 VGPRs.
+template <int BLOCK, int MAPPING>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_vote_bands_packed(const EvRec* __restrict__ sxy,
                                                              const PlaneCoef* __restrict__ coef,
                                                              const uint32_t* __restrict__ cuts,
                                                              const uint32_t* __restrict__ slow_any,
@@ -1581,7 +1628,7 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const EvRec* __rest
     // batch does not reach; "its" coefficients are whatever follows the plane's table
     const uint32_t dummy_eo = (uint32_t)np * (uint32_t)kPacket;
     char* band_bytes = reinterpret_cast<char*>(band);
-    if (bp.packed == 5 || bp.packed == 6) {
+    if constexpr (MAPPING == 5 || MAPPING == 6) {
         // vector fill (wide grids): passes of up to 64 packets, smaller when the chunk has few
         // packets so that every wave gets >= 2 passes; 64 words of LDS per wave behind the band.
         // 5 = hand-scheduled batches, 6 = all compiled (A/B tests; also the IEEE-divide planes of 5)
@@ -1596,23 +1643,24 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands_packed(const EvRec* __rest
         if (slow_any[z] != 0)
             vfill_stream<true>(sxy, coef4, cutz, band_bytes, scratch, p_begin + wave * pass, p_end, lg_pass,
                                kWaves * pass, lane, nx, Li, Ui, r0, dummy_eo);
-        else if (bp.packed == 6)
+        else if constexpr (MAPPING == 6)
             vfill_stream<false>(sxy, coef4, cutz, band_bytes, scratch, p_begin + wave * pass, p_end, lg_pass,
                                 kWaves * pass, lane, nx, Li, Ui, r0, dummy_eo);
         else
             vfill_stream_asm(sxy, coef4, cutz, band_bytes, scratch, p_begin + wave * pass, p_end, lg_pass,
                              kWaves * pass, lane, nx, Li, Ui, r0, dummy_eo);
-    } else
-    // bp.packed == 3 selects the compiled stream on the fast path too (A/B testing)
-    if (slow_any[z] != 0)
-        packed_stream<true>(sxy, coef4, cutz, band_bytes, p_begin + wave * group, p_end, lg_group,
-                            kWaves * group, lane, nx, Li, Ui, r0, dummy_eo);
-    else if (bp.packed == 3)
-        packed_stream<false>(sxy, coef4, cutz, band_bytes, p_begin + wave * group, p_end, lg_group,
-                             kWaves * group, lane, nx, Li, Ui, r0, dummy_eo);
-    else
-        packed_stream_asm(sxy, coef4, cutz, band_bytes, p_begin + wave * group, p_end, lg_group,
-                          kWaves * group, lane, nx, Li, Ui, r0, dummy_eo);
+    } else {
+        // MAPPING 3 is the compiled stream on the fast path too (A/B testing)
+        if (slow_any[z] != 0)
+            packed_stream<true>(sxy, coef4, cutz, band_bytes, p_begin + wave * group, p_end, lg_group,
+                                kWaves * group, lane, nx, Li, Ui, r0, dummy_eo);
+        else if constexpr (MAPPING == 3)
+            packed_stream<false>(sxy, coef4, cutz, band_bytes, p_begin + wave * group, p_end, lg_group,
+                                 kWaves * group, lane, nx, Li, Ui, r0, dummy_eo);
+        else
+            packed_stream_asm(sxy, coef4, cutz, band_bytes, p_begin + wave * group, p_end, lg_group,
+                              kWaves * group, lane, nx, Li, Ui, r0, dummy_eo);
+    }
     __syncthreads();
 
     const size_t vol = partial_stride((size_t)g.nx * g.ny * g.nz);
@@ -2074,6 +2122,47 @@ __global__ __launch_bounds__(256) void k_elementwise(float* __restrict__ a,
     }
 }
 
+// n-ary fusion in ONE pass: dst = finalize(accumulate(... accumulate(identity, src[0]) ..., src[n-1]))
+// with exactly the operations, in exactly the order, of dsi_grid_accumulate_begin / n x
+// dsi_grid_accumulate / dsi_grid_finalize (so the bits are the same), reading every source once:
+// (n + 1) * 4 B per voxel instead of (3 n + 2) * 4 B.
+constexpr int kMaxFuseSources = 8;
+struct FuseSources {
+    const float* p[kMaxFuseSources];
+};
+
+template <int ACC, int FIN>
+__global__ __launch_bounds__(256) void k_fuse_n(float* __restrict__ dst, FuseSources src, int n_src,
+                                                size_t n, float identity, float fn)
+{
+    const size_t n4 = n / 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 acc = make_float4(identity, identity, identity, identity);
+        for (int c = 0; c < n_src; ++c) {
+            const float4 v = reinterpret_cast<const float4*>(src.p[c])[i];
+            acc.x = ew_op<ACC>(acc.x, v.x, 0.f, 0.f);
+            acc.y = ew_op<ACC>(acc.y, v.y, 0.f, 0.f);
+            acc.z = ew_op<ACC>(acc.z, v.z, 0.f, 0.f);
+            acc.w = ew_op<ACC>(acc.w, v.w, 0.f, 0.f);
+        }
+        if (FIN >= 0) {
+            acc.x = ew_op<(FIN >= 0 ? FIN : 0)>(acc.x, 0.f, fn, 0.f);
+            acc.y = ew_op<(FIN >= 0 ? FIN : 0)>(acc.y, 0.f, fn, 0.f);
+            acc.z = ew_op<(FIN >= 0 ? FIN : 0)>(acc.z, 0.f, fn, 0.f);
+            acc.w = ew_op<(FIN >= 0 ? FIN : 0)>(acc.w, 0.f, fn, 0.f);
+        }
+        reinterpret_cast<float4*>(dst)[i] = acc;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = n4 * 4 + threadIdx.x;
+        float acc = identity;
+        for (int c = 0; c < n_src; ++c) acc = ew_op<ACC>(acc, src.p[c][i], 0.f, 0.f);
+        if (FIN >= 0) acc = ew_op<(FIN >= 0 ? FIN : 0)>(acc, 0.f, fn, 0.f);
+        dst[i] = acc;
+    }
+}
+
 // cartesian3dgrid.cpp:115-137: thread = pixel, planes walked in order, strict '<'
 // keeps the first maximum (std::max_element).  Lanes of a wave read consecutive x
 // of one plane row: coalesced 256-B segments.
@@ -2333,7 +2422,8 @@ int grid_for(size_t work_items, int block, int max_blocks = 256 * 8)
 
 }  // namespace
 
-size_t max_dynamic_lds() { return 160 * 1024; }
+// 160 KB per CU, minus a little room for the kernels' static __shared__ variables
+size_t max_dynamic_lds() { return 160 * 1024 - 128; }
 
 // The dynamic-LDS limit of a kernel is a per-device function attribute: set it for the CURRENT
 // device whenever this (kernel, device) pair has not been given at least `bytes` yet.  The table is
@@ -2398,8 +2488,21 @@ hipError_t launch_sort_packets(hipStream_t s, const float2* xy, int np, int ny, 
 {
     if (np <= 0) return hipSuccess;
     const size_t lds = (size_t)(ny + 2 * pad + 3) * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_sort_packets, dim3(np), dim3(256), lds, s, xy, np, ny, nz, pad, sxy, nvalid,
+    hipLaunchKernelGGL(k_sort_packets, dim3(np), dim3(256), lds, s, xy, RawEvents{}, np, ny, nz, pad, sxy, nvalid,
                        rowstart);
+    return hipExtGetLastError();
+}
+
+hipError_t launch_sort_packets_raw(hipStream_t s, const float* Rt, const uint16_t* ex, const uint16_t* ey,
+                                   const uint32_t* packet_first, const float2* lut, int sensor_w, const Geom& g,
+                                   float* centers, int np, int pad, EvRec* sxy, uint32_t* nvalid,
+                                   uint16_t* rowstart)
+{
+    if (np <= 0) return hipSuccess;
+    const size_t lds = (size_t)(g.ny + 2 * pad + 3) * sizeof(uint32_t);
+    RawEvents raw{Rt, ex, ey, packet_first, lut, sensor_w, g, centers};
+    hipLaunchKernelGGL(k_sort_packets, dim3(np), dim3(256), lds, s, (const float2*)nullptr, raw, np, g.ny, g.nz, pad,
+                       sxy, nvalid, rowstart);
     return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
@@ -2414,12 +2517,13 @@ hipError_t launch_plane_coef(hipStream_t s, const float* centers, const float* p
     return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
-template <int BLOCK, bool PACKED>
+template <int BLOCK, int MAPPING>
 static hipError_t launch_vote_bands_t(hipStream_t s, const EvRec* sxy, const PlaneCoef* coef,
                                       const uint32_t* cuts, const uint32_t* slow_any, int np,
                                       const Geom& g, const BandPlan& bp, float* out, float* carry)
 {
-    const void* kern = PACKED ? reinterpret_cast<const void*>(&k_vote_bands_packed<BLOCK>)
+    constexpr bool PACKED = MAPPING != 0;
+    const void* kern = PACKED ? reinterpret_cast<const void*>(&k_vote_bands_packed<BLOCK, (PACKED ? MAPPING : 1)>)
                               : reinterpret_cast<const void*>(&k_vote_bands<BLOCK>);
     if (hipError_t e = allow_dynamic_lds(kern, bp.lds_bytes)) return e;
     unsigned blocks = (unsigned)(bp.chunks * bp.bands) * (unsigned)g.nz;
@@ -2436,8 +2540,8 @@ static hipError_t launch_vote_bands_t(hipStream_t s, const EvRec* sxy, const Pla
             counters = const_cast<uint32_t*>(slow_any) + g.nz;  // 8 counters behind the per-plane flags (zeroed by the sort kernel)
         }
     }
-    if (PACKED)
-        hipLaunchKernelGGL(k_vote_bands_packed<BLOCK>, dim3(blocks), dim3(BLOCK), bp.lds_bytes, s,
+    if constexpr (PACKED)
+        hipLaunchKernelGGL((k_vote_bands_packed<BLOCK, (PACKED ? MAPPING : 1)>), dim3(blocks), dim3(BLOCK), bp.lds_bytes, s,
                            sxy, coef, cuts, slow_any, np, g, bp, out, carry, counters);
     else
         hipLaunchKernelGGL(k_vote_bands<BLOCK>, dim3(blocks), dim3(BLOCK), bp.lds_bytes, s, sxy, coef,
@@ -2445,23 +2549,30 @@ static hipError_t launch_vote_bands_t(hipStream_t s, const EvRec* sxy, const Pla
     return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
+template <int BLOCK>
+static hipError_t launch_vote_bands_b(hipStream_t s, const EvRec* sxy, const PlaneCoef* coef,
+                                      const uint32_t* cuts, const uint32_t* slow_any, int np, const Geom& g,
+                                      const BandPlan& bp, float* out, float* carry)
+{
+    switch (bp.packed) {
+    case 0: return launch_vote_bands_t<BLOCK, 0>(s, sxy, coef, cuts, slow_any, np, g, bp, out, carry);
+    case 1: return launch_vote_bands_t<BLOCK, 1>(s, sxy, coef, cuts, slow_any, np, g, bp, out, carry);
+    case 3: return launch_vote_bands_t<BLOCK, 3>(s, sxy, coef, cuts, slow_any, np, g, bp, out, carry);
+    case 5: return launch_vote_bands_t<BLOCK, 5>(s, sxy, coef, cuts, slow_any, np, g, bp, out, carry);
+    case 6: return launch_vote_bands_t<BLOCK, 6>(s, sxy, coef, cuts, slow_any, np, g, bp, out, carry);
+    default: return hipErrorInvalidValue;
+    }
+}
+
 hipError_t launch_vote_bands(hipStream_t s, const EvRec* sxy, const PlaneCoef* coef,
                              const uint32_t* cuts, const uint32_t* slow_any, int np, const Geom& g,
                              const BandPlan& bp, float* out, float* carry)
 {
     if (np <= 0) return hipSuccess;
-    if (bp.packed) {
-        switch (bp.block_threads) {
-        case 256: return launch_vote_bands_t<256, true>(s, sxy, coef, cuts, slow_any, np, g, bp, out, carry);
-        case 512: return launch_vote_bands_t<512, true>(s, sxy, coef, cuts, slow_any, np, g, bp, out, carry);
-        case 1024: return launch_vote_bands_t<1024, true>(s, sxy, coef, cuts, slow_any, np, g, bp, out, carry);
-        default: return hipErrorInvalidValue;
-        }
-    }
     switch (bp.block_threads) {
-    case 256: return launch_vote_bands_t<256, false>(s, sxy, coef, cuts, slow_any, np, g, bp, out, carry);
-    case 512: return launch_vote_bands_t<512, false>(s, sxy, coef, cuts, slow_any, np, g, bp, out, carry);
-    case 1024: return launch_vote_bands_t<1024, false>(s, sxy, coef, cuts, slow_any, np, g, bp, out, carry);
+    case 256: return launch_vote_bands_b<256>(s, sxy, coef, cuts, slow_any, np, g, bp, out, carry);
+    case 512: return launch_vote_bands_b<512>(s, sxy, coef, cuts, slow_any, np, g, bp, out, carry);
+    case 1024: return launch_vote_bands_b<1024>(s, sxy, coef, cuts, slow_any, np, g, bp, out, carry);
     default: return hipErrorInvalidValue;
     }
 }
@@ -2646,6 +2757,26 @@ hipError_t launch_unpack_argmax(hipStream_t s, const unsigned long long* keys, i
     hipLaunchKernelGGL(k_unpack_argmax, dim3((n + 255) / 256), dim3(256), 0, s, keys, n, planes_full, conf, idx,
                        depth);
     return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
+}
+
+hipError_t launch_fuse_n(hipStream_t s, float* dst, const float* const* srcs, int n_src, size_t n, int mode)
+{
+    if (n_src < 1 || n_src > kMaxFuseSources) return hipErrorInvalidValue;
+    FuseSources fs{};
+    for (int c = 0; c < n_src; ++c) fs.p[c] = srcs[c];
+    const dim3 grid(grid_for(n / 4 + 1, 256)), block(256);
+    const float fn = (float)n_src;
+    const float inf = __builtin_inff();
+    switch (mode) {
+    case 0: hipLaunchKernelGGL((k_fuse_n<EW_ADD, EW_FIN_AM>), grid, block, 0, s, dst, fs, n_src, n, 0.f, fn); break;
+    case 1: hipLaunchKernelGGL((k_fuse_n<EW_ADD_INV, EW_FIN_HM>), grid, block, 0, s, dst, fs, n_src, n, 0.f, fn); break;
+    case 2: hipLaunchKernelGGL((k_fuse_n<EW_ADD_LOG, EW_FIN_GM>), grid, block, 0, s, dst, fs, n_src, n, 0.f, fn); break;
+    case 3: hipLaunchKernelGGL((k_fuse_n<EW_ADD_SQ, EW_FIN_RMS>), grid, block, 0, s, dst, fs, n_src, n, 0.f, fn); break;
+    case 4: hipLaunchKernelGGL((k_fuse_n<EW_MIN, -1>), grid, block, 0, s, dst, fs, n_src, n, inf, fn); break;
+    case 5: hipLaunchKernelGGL((k_fuse_n<EW_MAX, -1>), grid, block, 0, s, dst, fs, n_src, n, -inf, fn); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipExtGetLastError();
 }
 
 // identity element of an accumulate mode: 0 for the sums, +inf for min, -inf for max

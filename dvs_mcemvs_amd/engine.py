@@ -106,6 +106,7 @@ def load_library():
         "dsi_grid_accumulate": (C.c_int, [vp, vp, C.c_int]),
         "dsi_grid_finalize": (C.c_int, [vp, C.c_int, C.c_int]),
         "dsi_grid_accumulate_begin": (C.c_int, [vp, C.c_int]),
+        "dsi_grid_fuse_n": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_int]),
         "dsi_acc_reduce_op": (C.c_int, [C.c_int]),
         "dsi_grid_collapse_max_z": (C.c_int, [vp, f32p, u8p]),
         "dsi_grid_collapse_max_z_dev": (C.c_int, [vp, vp, vp, vp, vp]),
@@ -471,6 +472,10 @@ class Grid3D:
     def setToFusionOfN(self, grids, mode):
         """self = n-ary mean of `grids`: ACC_SUM arithmetic, ACC_LOG_SUM geometric (0 where any
         grid is 0), ACC_SQ_SUM root mean square, ACC_MIN / ACC_MAX."""
+        if len(grids) <= 8 and all(g is not self for g in grids):
+            hs = (C.c_void_p * len(grids))(*[g._h for g in grids])   # one pass over the volumes, same bits
+            _check(load_library().dsi_grid_fuse_n(self._h, hs, len(grids), int(mode)))
+            return
         self.accumulateBegin(mode)
         for g in grids:
             self.accumulate(g, mode)

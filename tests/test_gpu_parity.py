@@ -271,6 +271,17 @@ def test_nary_fusion_modes_bit_exact(ctx, n_maps):
         same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
         assert same.all(), "mode %d: %d voxels differ, first at %s: gpu %r cpu %r" % (
             mode, (~same).sum(), np.argwhere(~same)[0], got[~same][0], ref[~same][0])
+    # the one-pass kernel (setToFusionOfN -> dsi_grid_fuse_n) and the begin / accumulate / finalize
+    # sequence it stands for give the same bits
+    for mode in (d.ACC_SUM, d.ACC_INV_SUM, d.ACC_LOG_SUM, d.ACC_SQ_SUM, d.ACC_MIN, d.ACC_MAX):
+        A.setToFusionOfN(G, mode)
+        one = A.download()
+        A.accumulateBegin(mode)
+        for g in G:
+            A.accumulate(g, mode)
+        A.finalize(mode, n_maps)
+        seq = A.download()
+        assert ((one.view(np.uint32) == seq.view(np.uint32)) | (np.isnan(one) & np.isnan(seq))).all(), mode
     # "0 if any factor is 0" and the all-reduce forms
     gm = orc.fuse_nary(maps, d.ACC_LOG_SUM)
     anyzero = np.zeros(gm.shape, bool)
