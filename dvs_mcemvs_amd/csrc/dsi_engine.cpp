@@ -297,8 +297,17 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
         if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) S = v;
     }
     bp->group_packets = S;
-    bp->persistent = (bp->packed == 1 || bp->packed == 3 || bp->packed == 5 || bp->packed == 6) ? 1 : 0;
-    if (const char* e = std::getenv("DSI_PERSISTENT")) bp->persistent = bp->persistent && std::atoi(e) != 0;  // A/B experiments
+    // Persistent workgroups (the grid is what the chip holds at once; workgroups pull work items from
+    // per-XCD counters) pay off when only ONE workgroup fits a CU -- nothing else hides the ~5 us it
+    // takes to retire a 16-wave, 160 KB workgroup and launch the next (512x512x200, 500 k events:
+    // 0.232 -> 0.222 ms).  With two per CU the hardware dispatcher already overlaps them and the item
+    // loop only adds a barrier and an atomic (346x260x100: 1.175 ms plain, 1.204 ms persistent).
+    const bool two_per_cu = bp->lds_bytes * 2 <= dsi::max_dynamic_lds() && bp->block_threads <= 1024;
+    bp->persistent = ((bp->packed == 1 || bp->packed == 3 || bp->packed == 5 || bp->packed == 6) && !two_per_cu) ? 1 : 0;
+    if (const char* e = std::getenv("DSI_PERSISTENT")) {  // A/B experiments: 0 off, 1 on wherever the kernel supports it
+        const int v = std::atoi(e);
+        bp->persistent = (v != 0 && (bp->packed == 1 || bp->packed == 3 || bp->packed == 5 || bp->packed == 6)) ? 1 : 0;
+    }
     bp->pass_lg = 0;
     if (const char* e = std::getenv("DSI_PASS_LG")) {  // tuning experiments only
         const int v = std::atoi(e);
@@ -306,14 +315,9 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
     }
     int chunks = m->want_chunks;
     if (chunks <= 0) {
-        // Work items = chunks x bands x planes.  With persistent workgroups pulling items from per-XCD
-        // counters ~3.5 items per resident workgroup keep the tail short (measured at 346x260x100,
-        // 10 M events: 2 chunks 1.33 ms, 4 chunks 1.35 ms, 1 chunk 1.36 ms; every chunk beyond the
-        // first costs a partial volume to write and to reduce); without them ~8 per CU.
-        // (one workgroup per CU -- the band takes more than half the LDS: items are twice as heavy and
-        //  the tail of the last round weighs more; 640x480x100: 2 chunks 1.57 ms, 1 chunk 1.69 ms)
-        const bool two_per_cu = bp->lds_bytes * 2 <= dsi::max_dynamic_lds() && bp->block_threads <= 1024;
-        const long items_target = (bp->persistent && two_per_cu) ? 7L * 256 : 8L * 256;
+        // Work items = chunks x bands x planes: ~8 per CU keep the tail of the last round short; every
+        // chunk beyond the first costs a partial volume to write and to reduce.
+        const long items_target = 8L * 256;
         chunks = (int)std::max<long>(1, (items_target + (long)bands * g.nz - 1) / ((long)bands * g.nz));
         // below ~8 M events one chunk is faster when the planes alone fill the chip 1.5 times: no
         // partial volumes to write and reduce, fewer workgroup set-ups (measured at 346x260x100:
@@ -323,7 +327,7 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
         int step = 8;
         for (int f = 2; f <= 8; f *= 2)
             if (bands % f == 0) step = 8 / f;
-        if (chunks > 1 && !bp->persistent) chunks = ((chunks + step - 1) / step) * step;  // whole groups of 8 pairs
+        if (chunks > 1) chunks = ((chunks + step - 1) / step) * step;  // whole groups of 8 pairs
         chunks = (int)std::min<size_t>((size_t)chunks, std::max<size_t>(1, n_packets));
         const size_t vol_bytes = (size_t)g.nx * g.ny * g.nz * sizeof(float);
         const size_t budget = (size_t)16 << 30;  // partial DSIs may use up to 16 GiB of HBM

@@ -1247,7 +1247,7 @@ __device__ __forceinline__ void packed_stream_asm(const EvRec* sxy, const uint4*
 // waited for with lgkmcnt(4) (the four ds_add_u64 of batch k are younger), and the gathers of
 // batch k+2 go into the register set batch k has just released.
 //   s42 batch counter k   s45 k+2   s46,s49,s50 tail-bit words / tails before the batch   s51 first slot of batch k+2
-//   v32 slot per lane   v33 coefficient byte offset   v34 D (record - slot)   v35 table index   v40 record index
+//   v32 slot per lane   v33 coefficient byte offset   v34 12 * (record - slot)   v35 table index
 //   sets A / B and the temporaries as in packed_stream_asm
 #define DSI_ASM_VPREP1                                                                             \
     "v_readlane_b32 s46, %5, s45\n\t"     /* tail bits of the batch, low / high half */             \
@@ -1263,10 +1263,10 @@ __device__ __forceinline__ void packed_stream_asm(const EvRec* sxy, const uint4*
 
 #define DSI_ASM_VPREP2(EV, CA, CR)                                                                 \
     "v_add_u32 v32, s51, %15\n\t"         /* slot */                                                \
-    "v_add_u32 v40, v34, v32\n\t"         /* record */                                              \
+    "s_mul_i32 s46, s51, 12\n\t"                                                                    \
     "v_cmp_gt_i32 vcc, %4, v32\n\t"       /* slot < T */                                            \
-    "v_cndmask_b32 v40, %14, v40, vcc\n\t" /* beyond the pass: the multiplicity-0 record */         \
-    "v_mul_lo_u32 v58, v40, 12\n\t"                                                                 \
+    "v_add3_u32 v58, v34, s46, %17\n\t"   /* byte offset of the record: 12 * (D + slot) */          \
+    "v_cndmask_b32 v58, %14, v58, vcc\n\t" /* beyond the pass: the multiplicity-0 record */         \
     "global_load_dwordx3 " EV ", v58, %0\n\t"                                                       \
     "global_load_dwordx4 " CA ", v33, %1\n\t"                                                       \
     "global_load_dword " CR ", v33, %1 offset:16\n\t"
@@ -1340,8 +1340,8 @@ __device__ __forceinline__ void vfill_range_asm(const EvRec* sxy, const uint4* c
         "s_waitcnt vmcnt(0) lgkmcnt(0)"
         :
         : "s"(sxy), "s"(coef4), "s"(s_nb), "s"(s_slot0), "s"(s_T), "v"(wlo), "v"(whi), "v"(cb), "v"(Dc),
-          "s"(s_nx8), "s"(s_cbase), "s"(s_nxm2), "s"(s_Li), "s"(s_Uim1), "v"(dummy_eo), "v"(lane),
-          "v"(Pc32)
+          "s"(s_nx8), "s"(s_cbase), "s"(s_nxm2), "s"(s_Li), "s"(s_Uim1), "v"(dummy_eo * 12u), "v"(lane),
+          "v"(Pc32), "v"(lane * 12)
         : "memory", "scc", "vcc", "s42", "s45", "s46", "s49", "s50", "s51", "v32", "v33", "v34", "v35",
           "v36", "v37", "v38", "v39", "v40", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50",
           "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
@@ -1378,7 +1378,7 @@ __device__ __forceinline__ void vfill_stream_asm(const EvRec* __restrict__ sxy,
         const int c = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ne >> 32),
                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)ne, 0u));
         const int dst = len > 0 ? c : 63 - (lane - c);  // non-empty runs to lanes 0, 1, ...; the rest behind
-        const int Dc = __builtin_amdgcn_ds_permute(dst << 2, D);
+        const int Dc = __builtin_amdgcn_ds_permute(dst << 2, D * 12);  // byte offsets of 12-byte records (mod 2^32)
         const int Pc32 = __builtin_amdgcn_ds_permute(dst << 2, min(p, p_end - 1) << 5);
         int Cbase = 0;
         for (int rbase = 0; rbase < T; rbase += 4096) {

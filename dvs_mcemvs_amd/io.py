@@ -128,6 +128,40 @@ def read_pose_bag(path, topic=None):
     return times, poses
 
 
+def parse_rosbag_gt(path, topic=None, tmin=0.0, tmax=float("inf")):
+    """data_loading::parse_rosbag_gt (data_loading.cpp:303-420) for PoseStamped bags: the stamps of the
+    returned control poses are RELATIVE to the first pose message of the topic (`initial_timestamp`,
+    :339-343 -- the same convention parse_rosbag applies to the events, :262-268, so that events and
+    poses share a time axis starting at ~0); poses with relative stamp < tmin are skipped, the first
+    one beyond tmax is still taken and ends the scan (:346-353, the flag is tested at the next
+    message).  read_pose_bag() above keeps the absolute stamps instead.
+    Returns (times float64[n], poses float64[n][7] = tx,ty,tz,qw,qx,qy,qz), in bag order."""
+    out = []
+    state = {"t0": None, "go": True}
+
+    def on_message(tpc, typ, data):
+        if not state["go"]:
+            return False
+        if (topic is None or tpc == topic) and typ == "geometry_msgs/PoseStamped":
+            t, p = _parse_pose_stamped(data)
+            if state["t0"] is None:
+                state["t0"] = t
+            rel = t - state["t0"]
+            if rel < tmin:
+                return True
+            if rel > tmax:
+                state["go"] = False
+            out.append((rel, p))
+        return True
+
+    _scan_bag(path, on_message)
+    # the reference keeps them in a std::map keyed by stamp: ascending
+    out.sort(key=lambda tp: tp[0])
+    times = np.array([t for t, _ in out], np.float64)
+    poses = np.array([p for _, p in out], np.float64).reshape(-1, 7)
+    return times, poses
+
+
 def _field(name, val):
     body = name.encode() + b"=" + val
     return struct.pack("<I", len(body)) + body

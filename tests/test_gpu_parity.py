@@ -719,7 +719,12 @@ def test_configs1_against_the_oracle_at_full_size(ctx):
     rconf, ridx = orc.collapse_max_z(ref)
     srt = np.sort(ref, axis=0)
     safe = (srt[-1] - srt[-2]) > 6 * DSI_TOL * np.maximum(1.0, srt[-1])
-    assert safe.mean() > 0.5
+    # what the statement "depth map equal to the CPU reference" covers: the pixels whose CPU top-2 gap
+    # exceeds the DSI tolerance (elsewhere either plane is a correct arg-max of an equally valid DSI)
+    agree = float((idx == ridx).mean())
+    print("configs[1] arg-max: %.4f of the pixels have a top-2 gap above 6x tolerance; indices agree on %.5f of "
+          "ALL pixels" % (safe.mean(), agree))
+    assert safe.mean() > 0.95 and agree > 0.99      # measured: 0.961 safe
     assert np.array_equal(idx[safe], ridx[safe])
     assert (np.abs(depth - orc.indices_to_depth(ridx, cpu[0].planes))[safe] <= 1e-4).all()
     for o in gpu + [fused]:

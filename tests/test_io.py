@@ -44,6 +44,22 @@ def test_pose_bag_round_trip(tmp_path):
         io.read_pose_bag(tmp_path / "junk.bag")
 
 
+def test_parse_rosbag_gt_relative_stamps_and_window(tmp_path):
+    """data_loading::parse_rosbag_gt (data_loading.cpp:303-420): stamps relative to the first pose
+    message, poses before tmin skipped, the first one beyond tmax still taken, then the scan stops."""
+    times = 1000.0 + 0.1 * np.arange(60)
+    poses = np.zeros((60, 7))
+    poses[:, 0] = np.arange(60)
+    poses[:, 3] = 1.0
+    io.write_pose_bag(tmp_path / "pose.bag", times, poses, topic="/pose")
+    t, p = io.parse_rosbag_gt(tmp_path / "pose.bag", topic="/pose")
+    assert t.shape[0] == 60 and t[0] == 0.0 and np.allclose(t, 0.1 * np.arange(60), atol=1e-9)
+    t, p = io.parse_rosbag_gt(tmp_path / "pose.bag", topic="/pose", tmin=1.0, tmax=2.0)
+    # rel 1.0 .. 2.0 inclusive, plus the first stamp beyond tmax (2.1)
+    assert np.allclose(t, 0.1 * np.arange(10, 22), atol=1e-9)
+    assert np.array_equal(p[:, 0], np.arange(10, 22))
+
+
 @pytest.mark.skipif(not os.path.exists(REF_BAG), reason="reference checkout not present on this box")
 def test_reads_the_reference_dsec_odometry_bag():
     """The only real data in the reference repo: LiDAR-IMU odometry of
