@@ -61,6 +61,9 @@ def parse():
                     help="lane mapping: -1 auto, 0 per-packet waves, 1 packed (hand-scheduled), 2 packet groups, "
                          "3 packed (compiled), 4 groups (hand-scheduled), 5 packed + vector fill, 6 = 5 compiled")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-host-fed", action="store_true",
+                    help="skip the host-fed (PCIe-inclusive) measurements and the 512x512x200 stream-kernel timings "
+                         "(profiling runs: only the timed steps launch kernels)")
     ap.add_argument("--materialize-fused", action="store_true",
                     help="windows: also write the fused DSI (mapper_fused.dsi_) per window instead of fusing the "
                          "cameras inside the arg-max kernel")
@@ -511,11 +514,13 @@ def main():
             except Exception:
                 traffic = None
         roofline = roofline_block(info, kern_ms, kt_n, accepted, ev_per_launch, info_nz(vote_mappers[0]), traffic)
-        streams = stream_kernels(d, ctx)
+        streams = stream_kernels(d, ctx) if not args.no_host_fed else None
 
         # ---- host-buffer (PCIe-inclusive) rates, reported beside `value`, never as it ----
         h2d = {}
-        if args.workload == "stereo":
+        if args.no_host_fed:
+            pass
+        elif args.workload == "stereo":
             pk = [d.packetize(rig["events"][c][2], rig["trajectories"][c], rig["T_rv_w"]) for c in range(2)]
             best = best2 = float("inf")
             for _ in range(3):
@@ -603,9 +608,11 @@ def main():
                        "bands": info["bands"], "band_rows": info["band_rows"], "chunks": info["chunks"],
                        "block_threads": info["block_threads"], "lds_bytes": info["lds_bytes"],
                        "packed_lanes": info["packed"], "parallelism": parallelism, "collective": collective},
-            "dsi_fuse_GBps": streams["dsi_fuse"]["GBps"], "dsi_fuse_ms": streams["dsi_fuse"]["ms"],
-            "dsi_fuse_frac_of_hbm_peak": streams["dsi_fuse"]["frac_of_hbm_peak"],
-            "argmax_GBps": streams["argmax"]["GBps"], "argmax_ms": streams["argmax"]["ms"],
+            "dsi_fuse_GBps": streams["dsi_fuse"]["GBps"] if streams else None,
+            "dsi_fuse_ms": streams["dsi_fuse"]["ms"] if streams else None,
+            "dsi_fuse_frac_of_hbm_peak": streams["dsi_fuse"]["frac_of_hbm_peak"] if streams else None,
+            "argmax_GBps": streams["argmax"]["GBps"] if streams else None,
+            "argmax_ms": streams["argmax"]["ms"] if streams else None,
             "stream_kernels": streams,
             "gpu_ms_per_step_hip_events": gpu_ms / args.steps,
             "timed_region_s": elapsed,

@@ -3,6 +3,7 @@
 WRITE_SIZE passes of tools/profile_round.sh).  Fabric-side traffic of the voting kernel per launch
 = fetch_correction * FETCH_SIZE + WRITE_SIZE (KiB -> bytes), with the FETCH_SIZE correction
 calibrated on k_fuse2<2>, whose traffic is known exactly (reads two volumes, writes one).
+NX NY NZ = the grid k_fuse2<2> ran on (bench.py's stream_kernels: 512 512 200).
 Usage: make_traffic_json.py profiles/rNN_pmc_counters.txt NX NY NZ > profiles/traffic.json"""
 import json
 import sys
@@ -23,7 +24,7 @@ def main():
     v = vals[vote]
     out = {
         "kernel": vote,
-        "config": "%dx%dx%d, one camera of configs[1] per launch" % (nx, ny, nz),
+        "config": "346x260x100, one camera of configs[1] per launch (default bench.py workload)",
         "FETCH_SIZE_KiB": v["FETCH_SIZE"], "WRITE_SIZE_KiB": v["WRITE_SIZE"],
         "calibration": {"kernel": "k_fuse2<2> (reads 2 volumes, writes 1; %d bytes each)" % vol,
                         "FETCH_SIZE_KiB": cal["FETCH_SIZE"], "expected_read_bytes": 2 * vol,
