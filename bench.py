@@ -94,6 +94,10 @@ class Dist:
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
+            if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+                # one node: RCCL's bootstrap sockets on the loopback interface (the container's
+                # hostname may not resolve)
+                os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
             import torch
             import torch.distributed as dist
             self.torch, self.dist = torch, dist
@@ -122,6 +126,13 @@ class Dist:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def min(self, v):
+        if self.dist is None:
+            return float(v)
+        t = self.torch.tensor([float(v)], dtype=self.torch.float64, device=self._dev())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return float(t.item())
+
     def sum(self, v):
         if self.dist is None:
             return float(v)
@@ -143,23 +154,38 @@ class Dist:
 
 
 def make_comm(d, dd, ctx, D, args):
-    """(allreduce callable, comm or None, description).  The engine communicator is tried first; if
-    RCCL cannot be initialised through the C ABI on this box the torch.distributed path is used and
-    the JSON line says so (never silently)."""
+    """(allreduce callable or None, engine comm or None, description, torch group or None).
+    The engine's own RCCL communicator is the default; if it cannot be initialised on every rank
+    the torch.distributed (nccl) path takes over -- loudly: the JSON line's config.collective says so."""
     if D.world == 1:
-        return dd.engine_allreduce(None), None, "none (1 rank)"
+        return dd.engine_allreduce(None), None, "none (1 rank)", None
+    why = "requested with --collective torch"
     if args.collective == "engine":
-        err = None
-        try:
-            uid = d.Comm.unique_id() if D.rank == 0 else None
-        except d.DsiError as e:
-            uid, err = None, str(e)
-        uid = D.broadcast_bytes((uid, err))
-        if uid[0] is not None:
-            comm = d.Comm(ctx, uid[0], D.world, D.rank)
-            return dd.engine_allreduce(comm), comm, "RCCL from the engine's C ABI (dsi_grid_allreduce)"
-        raise RuntimeError("engine RCCL communicator failed: %s (rerun with --collective torch)" % uid[1])
-    return None, None, "torch.distributed nccl"
+        uid, err, comm = None, "", None
+        if D.rank == 0:
+            try:
+                uid = d.Comm.unique_id()
+            except d.DsiError as e:
+                err = str(e)
+        uid, err = D.broadcast_bytes((uid, err))
+        ok = 0
+        if uid is not None:
+            try:
+                comm = d.Comm(ctx, uid, D.world, D.rank)
+                ok = 1
+            except d.DsiError as e:
+                err = str(e)
+        if D.min(ok) >= 1.0:
+            return dd.engine_allreduce(comm), comm, "RCCL from the engine's C ABI (dsi_grid_allreduce)", None
+        if comm is not None:
+            comm.close()
+        why = "FALLBACK, the engine's RCCL communicator failed on some rank: %s" % (err or "see other ranks")
+        print("bench.py rank %d: %s" % (D.rank, why), file=sys.stderr)
+    if D.backend == "nccl":
+        return None, None, "torch.distributed nccl (%s)" % why, None
+    D.torch.cuda.set_device(D.local_rank)
+    group = D.dist.new_group(backend="nccl")
+    return None, None, "torch.distributed nccl (%s)" % why, group
 
 
 def lds_block(accepted, kern_ms):
@@ -314,7 +340,7 @@ def main():
 
     nx, ny, nz = args.dims
     ctx = d.Context(D.local_rank)
-    allreduce, comm, collective = make_comm(d, dd, ctx, D, args)
+    allreduce, comm, collective, torch_group = make_comm(d, dd, ctx, D, args)
 
     def tune(m):
         m.set_vote_algo(args.algo)
@@ -351,7 +377,7 @@ def main():
                                                             allreduce, extract=mapper_fused.computeDepthMap)
             else:
                 temporal = dd.PipelinedTemporalFusion.on_gpu(ctx, ctx_side, (nx, ny, nz), d.ACC_INV_SUM, world,
-                                                             extract=mapper_fused.computeDepthMap)
+                                                             extract=mapper_fused.computeDepthMap, group=torch_group)
             fused.resetGrid()
             temporal.submit(fused)      # one un-timed round: set-up problems show up here on every rank
             temporal.drain()

@@ -308,6 +308,8 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
         const int v = std::atoi(e);
         bp->persistent = (v != 0 && (bp->packed == 1 || bp->packed == 3 || bp->packed == 5 || bp->packed == 6)) ? 1 : 0;
     }
+    bp->experiment = 0;
+    if (const char* e = std::getenv("DSI_EXPERIMENT")) bp->experiment = std::atoi(e);  // timing experiments: WRONG results
     bp->pass_lg = 0;
     if (const char* e = std::getenv("DSI_PASS_LG")) {  // tuning experiments only
         const int v = std::atoi(e);

@@ -52,6 +52,7 @@ struct BandPlan {
                         // + mapping 5: 512 B per wave for the tail-bit words
     int scratch_offset; // mapping 5: byte offset of that area behind the band
     int persistent;     // packed mappings: workgroups pull work items from per-XCD counters
+    int experiment;     // DSI_EXPERIMENT (timing experiments only, results are wrong): 1 no votes, 2 no flush
 };
 
 // distance in floats between the partial volumes of consecutive packet chunks: the volume size

@@ -1628,7 +1628,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     // batch does not reach; "its" coefficients are whatever follows the plane's table
     const uint32_t dummy_eo = (uint32_t)np * (uint32_t)kPacket;
     char* band_bytes = reinterpret_cast<char*>(band);
-    if constexpr (MAPPING == 5 || MAPPING == 6) {
+    if (bp.experiment == 1) {
+        // timing experiment: the item's fixed cost only (zero, barriers, flush)
+    } else if constexpr (MAPPING == 5 || MAPPING == 6) {
         // vector fill (wide grids): passes of up to 64 packets, smaller when the chunk has few
         // packets so that every wave gets >= 2 passes; 64 words of LDS per wave behind the band.
         // 5 = hand-scheduled batches, 6 = all compiled (A/B tests; also the IEEE-divide planes of 5)
@@ -1669,7 +1671,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         flush_band<BLOCK>(band, nx, (r1 - r0) * nx, dst, carry_row(carry, c, z, j, g, bp));
         break;
     }
-    flush_band_and_clear<BLOCK>(band, nx, (r1 - r0) * nx, dst, carry_row(carry, c, z, j, g, bp));
+    if (bp.experiment != 2)  // (2: timing experiment without the flush)
+        flush_band_and_clear<BLOCK>(band, nx, (r1 - r0) * nx, dst, carry_row(carry, c, z, j, g, bp));
     __syncthreads();  // every thread has read s_item and cleared its cells before thread 0 draws again
     }
 }
