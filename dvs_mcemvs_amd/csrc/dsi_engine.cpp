@@ -102,6 +102,10 @@ struct dsi_context {
         hipEvent_t freed;  // recorded on `stream` when the batch was released: its last reader is done
     };
     std::vector<PoolBlock> batch_pool;
+    // grow-only scratch of Grid3D::collapseMaxZSlice's host-output form (no hipMalloc / hipFree --
+    // i.e. no device synchronisation -- per call)
+    void* collapse_scratch = nullptr;
+    size_t collapse_scratch_bytes = 0;
 };
 
 bool pool_take(dsi_context* ctx, size_t bytes, dsi_context::PoolBlock* out)
@@ -627,6 +631,7 @@ int dsi_context_destroy(dsi_context_t* ctx)
     }
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->ms_accum) (void)hipFree(ctx->ms_accum);
+    if (ctx->collapse_scratch) (void)hipFree(ctx->collapse_scratch);
     if (ctx->t0) (void)hipEventDestroy(ctx->t0);
     if (ctx->t1) (void)hipEventDestroy(ctx->t1);
     if (ctx->sync_ev) (void)hipEventDestroy(ctx->sync_ev);
@@ -876,29 +881,27 @@ int dsi_grid_collapse_max_z_dev(dsi_grid_t* g, float* conf_dev, uint8_t* idx_dev
 int dsi_grid_collapse_max_z(dsi_grid_t* g, float* conf_host, uint8_t* idx_host)
 {
     REQUIRE(g && conf_host && idx_host, DSI_ERR_INVALID, "null argument");
-    if (int rc = set_device(g->ctx)) return rc;
+    dsi_context* ctx = g->ctx;
+    if (int rc = set_device(ctx)) return rc;
     const size_t npix = (size_t)g->nx * g->ny;
-    float* conf = nullptr;
-    uint8_t* idx = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&conf), npix * sizeof(float)));
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&idx), npix);
-    int rc = DSI_OK;
-    if (e != hipSuccess) {
-        rc = fail(DSI_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
-    } else {
-        rc = dsi_grid_collapse_max_z_dev(g, conf, idx, nullptr, nullptr);
-        if (rc == DSI_OK) {
-            e = hipMemcpyAsync(conf_host, conf, npix * sizeof(float), hipMemcpyDeviceToHost, g->ctx->stream);
-            if (e == hipSuccess)
-                e = hipMemcpyAsync(idx_host, idx, npix, hipMemcpyDeviceToHost, g->ctx->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(g->ctx->stream);
-            if (e != hipSuccess) rc = fail(DSI_ERR_HIP, "copy back failed: %s", hipGetErrorString(e));
+    const size_t need = npix * sizeof(float) + npix;
+    if (ctx->collapse_scratch_bytes < need) {
+        if (ctx->collapse_scratch) {
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            HIP_TRY(hipFree(ctx->collapse_scratch));
+            ctx->collapse_scratch = nullptr;
+            ctx->collapse_scratch_bytes = 0;
         }
+        HIP_TRY(hipMalloc(&ctx->collapse_scratch, need));
+        ctx->collapse_scratch_bytes = need;
     }
-    (void)hipStreamSynchronize(g->ctx->stream);
-    if (conf) (void)hipFree(conf);
-    if (idx) (void)hipFree(idx);
-    return rc;
+    float* conf = static_cast<float*>(ctx->collapse_scratch);
+    uint8_t* idx = reinterpret_cast<uint8_t*>(conf + npix);
+    if (int rc = dsi_grid_collapse_max_z_dev(g, conf, idx, nullptr, nullptr)) return rc;
+    HIP_TRY(hipMemcpyAsync(conf_host, conf, npix * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(idx_host, idx, npix, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return DSI_OK;
 }
 
 int dsi_grid_mean_square(dsi_grid_t* g, double* out)

@@ -1347,6 +1347,107 @@ __device__ __forceinline__ void vfill_range_asm(const EvRec* sxy, const uint4* c
           "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
 }
 
+// The same range with THREE register sets (k_vote_bands_vfill: one workgroup per CU, 128 VGPRs): the
+// gathers of batch k+3 are issued while batch k is voted, i.e. two whole iterations of other work
+// cover a gather's round trip instead of one -- with 16 waves per CU a wave's iteration is ~1300
+// clocks and the loaded L2 / fabric takes about that long.  Set C = v[24:26] record, v27 r,
+// v[28:31] a,bx,by,d.  The closing votes wait for everything in flight at once (vmcnt(0)) and then
+// run in any order, so one drain serves all three phases: s52 = bit mask of the sets still to vote.
+__device__ __forceinline__ void vfill_range_asm3(const EvRec* sxy, const uint4* coef4, int nb, int slot0,
+                                                 int T, uint32_t wlo, uint32_t whi, int cb, int Dc,
+                                                 int Pc32, char* band_bytes, int lane, int nx, int Li,
+                                                 int Ui, int row_base, uint32_t dummy_eo)
+{
+    const int s_nb = __builtin_amdgcn_readfirstlane(nb);
+    const int s_slot0 = __builtin_amdgcn_readfirstlane(slot0);
+    const int s_T = __builtin_amdgcn_readfirstlane(T);
+    const int s_nx8 = __builtin_amdgcn_readfirstlane(nx * 8);
+    const int lds_base = (int)(uintptr_t)band_bytes;
+    const int s_cbase = __builtin_amdgcn_readfirstlane(lds_base - row_base * nx * 8);
+    const int s_nxm2 = __builtin_amdgcn_readfirstlane(nx - 2);
+    const int s_Li = __builtin_amdgcn_readfirstlane(Li);
+    const int s_Uim1 = __builtin_amdgcn_readfirstlane(Ui - 1 - Li);
+    asm volatile(
+        // prologue: up to three batches in flight
+        "s_mov_b32 s42, 0\n\t"
+        "s_mov_b32 s45, 0\n\t"
+        DSI_ASM_VPREP1
+        "s_waitcnt lgkmcnt(0)\n\t"
+        DSI_ASM_VPREP2("v[42:44]", "v[46:49]", "v45")
+        "s_mov_b32 s52, 1\n\t"
+        "s_cmp_lt_i32 1, %2\n\t"
+        "s_cbranch_scc0 Ldrain%=\n\t"
+        "s_mov_b32 s45, 1\n\t"
+        DSI_ASM_VPREP1
+        "s_waitcnt lgkmcnt(0)\n\t"
+        DSI_ASM_VPREP2("v[50:52]", "v[54:57]", "v53")
+        "s_mov_b32 s52, 3\n\t"
+        "s_cmp_lt_i32 2, %2\n\t"
+        "s_cbranch_scc0 Ldrain%=\n\t"
+        "s_mov_b32 s45, 2\n\t"
+        DSI_ASM_VPREP1
+        "s_waitcnt lgkmcnt(0)\n\t"
+        DSI_ASM_VPREP2("v[24:26]", "v[28:31]", "v27")
+        "Lloop%=:\n\t"
+        // ---- batch k in set A; B and C in flight behind it
+        "s_add_i32 s45, s42, 3\n\t"
+        "s_cmp_lt_i32 s45, %2\n\t"
+        "s_mov_b32 s52, 7\n\t"
+        "s_cbranch_scc0 Ldrain%=\n\t"
+        DSI_ASM_VPREP1
+        "s_waitcnt vmcnt(6)\n\t"
+        DSI_ASM_VOTE("v42", "v43", "v44", "v46", "v47", "v48", "v49", "v45")
+        "s_waitcnt lgkmcnt(4)\n\t"
+        DSI_ASM_VPREP2("v[42:44]", "v[46:49]", "v45")
+        "s_add_i32 s42, s42, 1\n\t"
+        // ---- batch k in set B; C and A behind it
+        "s_add_i32 s45, s42, 3\n\t"
+        "s_cmp_lt_i32 s45, %2\n\t"
+        "s_cbranch_scc0 Ldrain%=\n\t"
+        DSI_ASM_VPREP1
+        "s_waitcnt vmcnt(6)\n\t"
+        DSI_ASM_VOTE("v50", "v51", "v52", "v54", "v55", "v56", "v57", "v53")
+        "s_waitcnt lgkmcnt(4)\n\t"
+        DSI_ASM_VPREP2("v[50:52]", "v[54:57]", "v53")
+        "s_add_i32 s42, s42, 1\n\t"
+        // ---- batch k in set C; A and B behind it
+        "s_add_i32 s45, s42, 3\n\t"
+        "s_cmp_lt_i32 s45, %2\n\t"
+        "s_cbranch_scc0 Ldrain%=\n\t"
+        DSI_ASM_VPREP1
+        "s_waitcnt vmcnt(6)\n\t"
+        DSI_ASM_VOTE("v24", "v25", "v26", "v28", "v29", "v30", "v31", "v27")
+        "s_waitcnt lgkmcnt(4)\n\t"
+        DSI_ASM_VPREP2("v[24:26]", "v[28:31]", "v27")
+        "s_add_i32 s42, s42, 1\n\t"
+        "s_branch Lloop%=\n"
+        // ---- everything that is still in flight (1..3 batches: exactly nb - k of them, and when the
+        //      loop has run all three sets hold one) is voted after one wait, in any order
+        "Ldrain%=:\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "s_bitcmp1_b32 s52, 0\n\t"
+        "s_cbranch_scc0 LnoA%=\n\t"
+        DSI_ASM_VOTE("v42", "v43", "v44", "v46", "v47", "v48", "v49", "v45")
+        "LnoA%=:\n\t"
+        "s_bitcmp1_b32 s52, 1\n\t"
+        "s_cbranch_scc0 LnoB%=\n\t"
+        DSI_ASM_VOTE("v50", "v51", "v52", "v54", "v55", "v56", "v57", "v53")
+        "LnoB%=:\n\t"
+        "s_bitcmp1_b32 s52, 2\n\t"
+        "s_cbranch_scc0 LnoC%=\n\t"
+        DSI_ASM_VOTE("v24", "v25", "v26", "v28", "v29", "v30", "v31", "v27")
+        "LnoC%=:\n\t"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)"
+        :
+        : "s"(sxy), "s"(coef4), "s"(s_nb), "s"(s_slot0), "s"(s_T), "v"(wlo), "v"(whi), "v"(cb), "v"(Dc),
+          "s"(s_nx8), "s"(s_cbase), "s"(s_nxm2), "s"(s_Li), "s"(s_Uim1), "v"(dummy_eo * 12u), "v"(lane),
+          "v"(Pc32), "v"(lane * 12)
+        : "memory", "scc", "vcc", "s42", "s45", "s46", "s49", "s50", "s51", "s52", "v24", "v25", "v26", "v27",
+          "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v42", "v43",
+          "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58",
+          "v59", "v60", "v61", "v62", "v63");
+}
+
 // the passes of a wave: per-pass tables by compiled code, the batches by vfill_range_asm
 __device__ __forceinline__ void vfill_stream_asm(const EvRec* __restrict__ sxy,
                                                  const uint4* __restrict__ coef4,
@@ -1355,7 +1456,7 @@ __device__ __forceinline__ void vfill_stream_asm(const EvRec* __restrict__ sxy,
                                                  unsigned long long* __restrict__ scratch,
                                                  int p_first, int p_end, int lg_pass, int stride,
                                                  int lane, int nx, int Li, int Ui, int row_base,
-                                                 uint32_t dummy_eo)
+                                                 uint32_t dummy_eo, bool two_sets)
 {
     if (Ui - 1 < Li) return;  // the band accepts no row (the unsigned range test needs Ui-1-Li >= 0)
     const int pass = 1 << lg_pass;
@@ -1391,8 +1492,12 @@ __device__ __forceinline__ void vfill_stream_asm(const EvRec* __restrict__ sxy,
             const int pc = __builtin_popcountll(w);
             const int inc = wave_incl_scan(pc, lane);
             const int nb = min(64, (T - rbase + 63) >> 6);
-            vfill_range_asm(sxy, coef4, nb, rbase, T, (uint32_t)w, (uint32_t)(w >> 32), inc - pc + Cbase, Dc,
-                            Pc32, band_bytes, lane, nx, Li, Ui, row_base, dummy_eo);
+            if (two_sets)
+                vfill_range_asm(sxy, coef4, nb, rbase, T, (uint32_t)w, (uint32_t)(w >> 32), inc - pc + Cbase, Dc,
+                                Pc32, band_bytes, lane, nx, Li, Ui, row_base, dummy_eo);
+            else
+                vfill_range_asm3(sxy, coef4, nb, rbase, T, (uint32_t)w, (uint32_t)(w >> 32), inc - pc + Cbase, Dc,
+                                 Pc32, band_bytes, lane, nx, Li, Ui, row_base, dummy_eo);
             Cbase += __builtin_amdgcn_readlane(inc, 63);
         }
     }
@@ -1556,14 +1661,14 @@ __device__ __forceinline__ void group_stream_asm(const EvRec* sxy, const uint4* 
 // streams (all of them in one kernel needed 70 VGPRs -- 7 waves per SIMD, i.e. ONE 1024-thread
 // workgroup per CU instead of two -- and spilled scalars).  8 waves per SIMD = at most 64 VGPRs.
 template <int BLOCK, int MAPPING>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_vote_bands_packed(const EvRec* __restrict__ sxy,
-                                                             const PlaneCoef* __restrict__ coef,
-                                                             const uint32_t* __restrict__ cuts,
-                                                             const uint32_t* __restrict__ slow_any,
-                                                             int np, Geom g, BandPlan bp,
-                                                             float* __restrict__ out,
-                                                             float* __restrict__ carry,
-                                                             uint32_t* __restrict__ work_counters)
+__device__ __forceinline__ void vote_bands_packed_body(const EvRec* __restrict__ sxy,
+                                                       const PlaneCoef* __restrict__ coef,
+                                                       const uint32_t* __restrict__ cuts,
+                                                       const uint32_t* __restrict__ slow_any,
+                                                       int np, const Geom& g, const BandPlan& bp,
+                                                       float* __restrict__ out,
+                                                       float* __restrict__ carry,
+                                                       uint32_t* __restrict__ work_counters)
 {
     extern __shared__ acc_t band[];
     __shared__ int s_item;
@@ -1650,7 +1755,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                                 kWaves * pass, lane, nx, Li, Ui, r0, dummy_eo);
         else
             vfill_stream_asm(sxy, coef4, cutz, band_bytes, scratch, p_begin + wave * pass, p_end, lg_pass,
-                             kWaves * pass, lane, nx, Li, Ui, r0, dummy_eo);
+                             kWaves * pass, lane, nx, Li, Ui, r0, dummy_eo, bp.experiment == 3);
     } else {
         // MAPPING 3 is the compiled stream on the fast path too (A/B testing)
         if (slow_any[z] != 0)
@@ -1675,6 +1780,27 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         flush_band_and_clear<BLOCK>(band, nx, (r1 - r0) * nx, dst, carry_row(carry, c, z, j, g, bp));
     __syncthreads();  // every thread has read s_item and cleared its cells before thread 0 draws again
     }
+}
+
+template <int BLOCK, int MAPPING>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_vote_bands_packed(
+    const EvRec* __restrict__ sxy, const PlaneCoef* __restrict__ coef, const uint32_t* __restrict__ cuts,
+    const uint32_t* __restrict__ slow_any, int np, Geom g, BandPlan bp, float* __restrict__ out,
+    float* __restrict__ carry, uint32_t* __restrict__ work_counters)
+{
+    vote_bands_packed_body<BLOCK, MAPPING>(sxy, coef, cuts, slow_any, np, g, bp, out, carry, work_counters);
+}
+
+// The vector-fill mappings run where ONE workgroup fills a CU (wide grids): 4 waves per SIMD may use up
+// to 128 VGPRs, which pays for a third register set -- three batches of gathers in flight.  (Run with a
+// band small enough for two workgroups per CU, this kernel still places only one.)
+template <int BLOCK, int MAPPING>
+__global__ __launch_bounds__(BLOCK) void k_vote_bands_vfill(
+    const EvRec* __restrict__ sxy, const PlaneCoef* __restrict__ coef, const uint32_t* __restrict__ cuts,
+    const uint32_t* __restrict__ slow_any, int np, Geom g, BandPlan bp, float* __restrict__ out,
+    float* __restrict__ carry, uint32_t* __restrict__ work_counters)
+{
+    vote_bands_packed_body<BLOCK, MAPPING>(sxy, coef, cuts, slow_any, np, g, bp, out, carry, work_counters);
 }
 
 // (3c) GROUPED mapping: S consecutive packets (a "group"; their poses are microseconds apart)
@@ -2526,7 +2652,9 @@ static hipError_t launch_vote_bands_t(hipStream_t s, const EvRec* sxy, const Pla
                                       const Geom& g, const BandPlan& bp, float* out, float* carry)
 {
     constexpr bool PACKED = MAPPING != 0;
-    const void* kern = PACKED ? reinterpret_cast<const void*>(&k_vote_bands_packed<BLOCK, (PACKED ? MAPPING : 1)>)
+    constexpr bool VFILL = MAPPING == 5 || MAPPING == 6;
+    const void* kern = VFILL ? reinterpret_cast<const void*>(&k_vote_bands_vfill<BLOCK, (VFILL ? MAPPING : 5)>)
+                     : PACKED ? reinterpret_cast<const void*>(&k_vote_bands_packed<BLOCK, (PACKED && !VFILL ? MAPPING : 1)>)
                               : reinterpret_cast<const void*>(&k_vote_bands<BLOCK>);
     if (hipError_t e = allow_dynamic_lds(kern, bp.lds_bytes)) return e;
     unsigned blocks = (unsigned)(bp.chunks * bp.bands) * (unsigned)g.nz;
@@ -2543,8 +2671,11 @@ static hipError_t launch_vote_bands_t(hipStream_t s, const EvRec* sxy, const Pla
             counters = const_cast<uint32_t*>(slow_any) + g.nz;  // 8 counters behind the per-plane flags (zeroed by the sort kernel)
         }
     }
-    if constexpr (PACKED)
-        hipLaunchKernelGGL((k_vote_bands_packed<BLOCK, (PACKED ? MAPPING : 1)>), dim3(blocks), dim3(BLOCK), bp.lds_bytes, s,
+    if constexpr (VFILL)
+        hipLaunchKernelGGL((k_vote_bands_vfill<BLOCK, (VFILL ? MAPPING : 5)>), dim3(blocks), dim3(BLOCK), bp.lds_bytes, s,
+                           sxy, coef, cuts, slow_any, np, g, bp, out, carry, counters);
+    else if constexpr (PACKED)
+        hipLaunchKernelGGL((k_vote_bands_packed<BLOCK, (PACKED && !VFILL ? MAPPING : 1)>), dim3(blocks), dim3(BLOCK), bp.lds_bytes, s,
                            sxy, coef, cuts, slow_any, np, g, bp, out, carry, counters);
     else
         hipLaunchKernelGGL(k_vote_bands<BLOCK>, dim3(blocks), dim3(BLOCK), bp.lds_bytes, s, sxy, coef,

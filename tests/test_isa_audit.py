@@ -1,7 +1,7 @@
 """Static audit of the compiled gfx950 code of the voting kernels (no GPU needed): the hand-written
-wave loops name physical registers, so the kernels must not spill vector registers nor use scratch
-(the vector-fill mappings excepted, see below), and must stay within 64 VGPRs (8 waves per SIMD =
-two 1024-thread workgroups per CU)."""
+wave loops name physical registers, so the kernels must not spill vector registers nor use scratch,
+and must stay within 64 VGPRs (8 waves per SIMD = two 1024-thread workgroups per CU; 128 for the
+vector-fill kernels, which run one workgroup per CU)."""
 import os
 import re
 import shutil
@@ -34,16 +34,16 @@ def test_vote_kernels_do_not_spill(tmp_path):
             continue
         seen += 1
         val = lambda key: int(re.search(r"\.%s:\s+(\d+)" % key, block).group(1))
-        # 8 waves per SIMD (two 1024-thread workgroups per CU) need <= 64 VGPRs -- the persistent loop
-        # once pushed the all-in-one packed kernel to 70 and cost 15 % at 346x260x100
-        assert val("vgpr_count") <= 64, name
-        vector_fill = "k_vote_bands_packedILi" in name and re.search(r"ELi[56]EE", name) is not None
+        vector_fill = "k_vote_bands_vfill" in name
         if vector_fill:
-            # lane mappings 5 / 6: the per-pass set-up (compiled, once per 64 packets) may park a few
-            # values in scratch; the hot loop of 5 is the assembly block, which owns its registers
-            assert val("vgpr_spill_count") <= 4 and val("private_segment_fixed_size") <= 32, name
+            # lane mappings 5 / 6 run where ONE workgroup fills a CU (wide grids): 4 waves per SIMD, up to
+            # 128 VGPRs -- the third register set of gathers in flight lives there
+            assert val("vgpr_count") <= 128, name
         else:
-            assert val("vgpr_spill_count") == 0 and val("private_segment_fixed_size") == 0, name
+            # 8 waves per SIMD (two 1024-thread workgroups per CU) need <= 64 VGPRs -- the persistent loop
+            # once pushed the all-in-one packed kernel to 70 and cost 15 % at 346x260x100
+            assert val("vgpr_count") <= 64, name
+        assert val("vgpr_spill_count") == 0 and val("private_segment_fixed_size") == 0, name
         # (scalar spills go to VGPR lanes with v_writelane / v_readlane outside the wave loops: harmless,
         #  the packed kernels hand ~15 scalars to each assembly block and keep ~30 for the item loop)
     assert seen >= 16
