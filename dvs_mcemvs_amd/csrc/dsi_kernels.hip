@@ -1456,19 +1456,27 @@ __device__ __forceinline__ void vfill_stream_asm(const EvRec* __restrict__ sxy,
                                                  unsigned long long* __restrict__ scratch,
                                                  int p_first, int p_end, int lg_pass, int stride,
                                                  int lane, int nx, int Li, int Ui, int row_base,
-                                                 uint32_t dummy_eo, bool two_sets)
+                                                 uint32_t dummy_eo, int variant, int p_begin_of_wg)
 {
     if (Ui - 1 < Li) return;  // the band accepts no row (the unsigned range test needs Ui-1-Li >= 0)
     const int pass = 1 << lg_pass;
+    const int p_begin = p_begin_of_wg;
+    const int npass = (p_end - p_begin + pass - 1) / pass;
+    const int j0 = (p_first - p_begin) / pass;       // this wave's first pass
+    const int jstep = stride / pass;                 // waves of the workgroup
+    // lane l = packet l of pass j.  (Tried: interleaved passes -- lane l = packet p_begin + l * npass + j,
+    // so that the 3-4 packets a batch mixes are far apart in time and a scene point's votes do not meet in
+    // one wave instruction: -1 % ... +3 %, not adopted.  Tried: the ds_bpermute look-ups issued a further
+    // iteration ahead, waited for with lgkmcnt(6): no change, 5.01 vs 5.00 ms.)
+    auto packet_of = [&](int j) { return p_begin + j * pass + lane; };
     uint32_t cu_next = 0;
-    if (p_first < p_end && lane < pass && p_first + lane < p_end) cu_next = cutz[p_first + lane];
-    for (int pass_base = p_first; pass_base < p_end; pass_base += stride) {
-        const int p = pass_base + lane;
+    if (j0 < npass && lane < pass && packet_of(j0) < p_end) cu_next = cutz[packet_of(j0)];
+    for (int j = j0; j < npass; j += jstep) {
+        const int p = packet_of(j);
         const uint32_t cu = cu_next;
         // the next pass's cut words travel while this pass is voted
-        const int pn = p + stride;
         cu_next = 0;
-        if (pass_base + stride < p_end && lane < pass && pn < p_end) cu_next = cutz[pn];
+        if (j + jstep < npass && lane < pass && packet_of(j + jstep) < p_end) cu_next = cutz[packet_of(j + jstep)];
         const int lo = (int)(cu & 0xffffu), hi = (int)(cu >> 16);
         const int len = max(hi - lo, 0);
         const int incl = wave_incl_scan(len, lane);
@@ -1492,7 +1500,7 @@ __device__ __forceinline__ void vfill_stream_asm(const EvRec* __restrict__ sxy,
             const int pc = __builtin_popcountll(w);
             const int inc = wave_incl_scan(pc, lane);
             const int nb = min(64, (T - rbase + 63) >> 6);
-            if (two_sets)
+            if (variant == 3)
                 vfill_range_asm(sxy, coef4, nb, rbase, T, (uint32_t)w, (uint32_t)(w >> 32), inc - pc + Cbase, Dc,
                                 Pc32, band_bytes, lane, nx, Li, Ui, row_base, dummy_eo);
             else
@@ -1755,7 +1763,7 @@ __device__ __forceinline__ void vote_bands_packed_body(const EvRec* __restrict__
                                 kWaves * pass, lane, nx, Li, Ui, r0, dummy_eo);
         else
             vfill_stream_asm(sxy, coef4, cutz, band_bytes, scratch, p_begin + wave * pass, p_end, lg_pass,
-                             kWaves * pass, lane, nx, Li, Ui, r0, dummy_eo, bp.experiment == 3);
+                             kWaves * pass, lane, nx, Li, Ui, r0, dummy_eo, bp.experiment, p_begin);
     } else {
         // MAPPING 3 is the compiled stream on the fast path too (A/B testing)
         if (slow_any[z] != 0)
