@@ -89,6 +89,9 @@ class Dist:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        # (plumbing tests on a one-GPU box: DSI_BENCH_DEVICE=0 puts every rank on GPU 0 -- RCCL then refuses
+        #  the communicator, which is the point of such a test)
+        self.local_rank = int(os.environ.get("DSI_BENCH_DEVICE", self.local_rank))
         self.dist = self.torch = None
         self.backend = None
         if self.world > 1:

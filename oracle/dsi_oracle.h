@@ -12,7 +12,9 @@
  * without writing stand-ins for OpenCV / Eigen / minkindr / ROS headers (not
  * allowed), so this oracle has never been checked against an execution of the
  * reference.  It is pinned only by analytic known-answer tests that we
- * authored (tests/test_oracle_kat.py).
+ * authored (tests/test_oracle_kat.py) and by bit-equality with a second,
+ * independently written numpy restatement of the same reference lines
+ * (tests/independent_numpy.py) -- neither is an execution of the reference.
  *
  * Third-party arithmetic that is NOT under the reference tree and is restated
  * here from its published algorithm (dependencies.yaml pins all of them only
