@@ -2154,64 +2154,106 @@ enum { EW_HM_N = 0, EW_ADD = 1, EW_ADD_INV = 2, EW_FIN_AM = 3, EW_FIN_HM = 4,
 
 // ---- n-ary geometric mean: exp(mean(log v)), 0 as soon as one factor is 0 (SURVEY 8d cfg 5).
 // The reference only has the 2-ary sqrt(a*g) (cartesian3dgrid.h:150-156).  log and exp are
-// spelled out in IEEE double operations (+, *, /, floor, bit moves; no libm, no FMA) so that the
-// CPU oracle, which repeats exactly this sequence, gets the same bits.
-__device__ __forceinline__ float det_logf(float v)
+// spelled out in IEEE double operations (+, *, /, floor, bit moves, explicit fused multiply-adds;
+// no libm, nothing fused implicitly: -ffp-contract=off) so that the CPU oracle, which repeats
+// exactly this sequence, gets the same bits.
+//
+// log v = e ln2 + log c_i + log1p(r):  v = 2^e m, m in [1, 2); the top 7 mantissa bits pick
+// c_i = 1 + (2 i + 1) / 256 (the centre of m's 1/128 interval), r = (m - c_i) / c_i with |r| <= 2^-8,
+// log1p(r) by its degree-5 Taylor polynomial (next term r^6 / 6 < 6e-16).  {1 / c_i, log c_i} come
+// from a 128-entry table in LDS that every block fills for itself with the division-based series
+// below (full double accuracy; 128 threads x ~60 operations per block), so the per-voxel path has
+// no division: ~25 instructions per log instead of ~60 (4-camera fusion at 1024 x 1024 x 256:
+// 2.09 -> 1.37 ms, still bound by fp64 issue rather than by the 5.4 GB it streams).
+// The absolute error of the log is ~1e-15; its fp32 rounding and the fp32 sum of logs
+// dominate (the accumulator is a float grid).
+__device__ __forceinline__ double det_log_series(double m)  // m in [1, 2); table set-up only
 {
-    if (!(v > 0.f)) return v == 0.f ? -__builtin_inff() : __builtin_nanf("");
-    if (!finitef(v)) return v;
-    const double x = (double)v;  // every positive float is a normal double
-    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
-    int e = (int)((b >> 52) & 0x7ffull) - 1023;
-    double m = __longlong_as_double((long long)((b & 0x000fffffffffffffull) | 0x3ff0000000000000ull));
+    double e = 0.0;
     if (m > 1.4142135623730951) {
         m = m * 0.5;
-        e += 1;
+        e = 1.0;
     }
     const double f = m - 1.0;
     const double s = f / (2.0 + f);
-    const double z = s * s;
-    double p = 0.07692307692307693;          // 1/13
+    const double z = s * s;  // <= 0.0295
+    double p = 0.047619047619047616;         // 1/21
+    p = p * z + 0.05263157894736842;         // 1/19
+    p = p * z + 0.058823529411764705;        // 1/17
+    p = p * z + 0.06666666666666667;         // 1/15
+    p = p * z + 0.07692307692307693;         // 1/13
     p = p * z + 0.09090909090909091;         // 1/11
     p = p * z + 0.1111111111111111;          // 1/9
     p = p * z + 0.14285714285714285;         // 1/7
     p = p * z + 0.2;                         // 1/5
     p = p * z + 0.3333333333333333;          // 1/3
     p = p * z + 1.0;
-    const double t1 = (double)e * 0.6931471805599453;
+    const double t1 = e * 0.6931471805599453;
     const double t2 = 2.0 * s;
-    const double t3 = t2 * p;
-    return (float)(t1 + t3);
+    return t1 + t2 * p;
 }
 
+constexpr int kLogTabSize = 128;
+
+__device__ __forceinline__ void det_log_table_fill(double2* tab)  // whole block; ends with a barrier
+{
+    for (int i = threadIdx.x; i < kLogTabSize; i += blockDim.x) {
+        const double c = 1.0 + (double)(2 * i + 1) * 0.00390625;  // exact
+        tab[i] = make_double2(1.0 / c, det_log_series(c));
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ float det_logf(float v, const double2* __restrict__ tab)
+{
+    // (selects instead of early returns: the special cases are rare and a wave would take both
+    //  sides anyway)
+    const bool positive = v > 0.f, regular = positive && finitef(v);
+    const double x = (double)(regular ? v : 1.f);  // every positive float is a normal double
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    const int e = (int)((b >> 52) & 0x7ffull) - 1023;
+    const unsigned i = (unsigned)(b >> 45) & 127u;
+    const double m = __longlong_as_double((long long)((b & 0x000fffffffffffffull) | 0x3ff0000000000000ull));
+    const double c = __longlong_as_double((long long)(0x3ff0000000000000ull | ((unsigned long long)(2u * i + 1u) << 44)));
+    const double2 t = tab[i];
+    const double r = (m - c) * t.x;          // m - c is exact
+    double p = __builtin_fma(r, 0.2, -0.25);  // fused multiply-adds, spelled out (IEEE 754 fma)
+    p = __builtin_fma(p, r, 0.3333333333333333);
+    p = __builtin_fma(p, r, -0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = p * r;
+    const float res = (float)__builtin_fma((double)e, 0.6931471805599453, t.y + p);
+    const float special = positive ? v /* +inf */ : (v == 0.f ? -__builtin_inff() : __builtin_nanf(""));
+    return regular ? res : special;
+}
+
+// exp(y) rounded to float: y = k ln2 + r, |r| <= 0.347, degree-9 Taylor polynomial (next term
+// r^10 / 10! < 7e-12 relative, far below the float rounding)
 __device__ __forceinline__ float det_expf(double y)
 {
-    if (y != y) return __builtin_nanf("");
-    if (y > 89.0) return __builtin_inff();
-    if (y < -104.0) return 0.f;  // includes -inf: one factor was 0
+    const bool regular = y >= -104.0 && y <= 89.0;  // false for NaN
+    const float special = (y != y) ? __builtin_nanf("") : (y > 89.0 ? __builtin_inff() : 0.f);  // (-inf: a factor was 0)
+    y = regular ? y : 0.0;
     const double kd = __builtin_floor(y * 1.4426950408889634 + 0.5);
-    double r = y - kd * 0.6931471803691238;      // ln2 split as in fdlibm (hi part has 32 bits)
-    r = r - kd * 1.9082149292705877e-10;
-    double p = 2.08767569878681e-09;             // 1/12!
-    p = p * r + 2.505210838544172e-08;
-    p = p * r + 2.755731922398589e-07;
-    p = p * r + 2.7557319223985893e-06;
-    p = p * r + 2.48015873015873e-05;
-    p = p * r + 0.0001984126984126984;
-    p = p * r + 0.001388888888888889;
-    p = p * r + 0.008333333333333333;
-    p = p * r + 0.041666666666666664;
-    p = p * r + 0.16666666666666666;
-    p = p * r + 0.5;
-    p = p * r + 1.0;
-    p = p * r + 1.0;
+    double r = __builtin_fma(kd, -0.6931471803691238, y);      // ln2 split as in fdlibm (hi part has 32 bits)
+    r = __builtin_fma(kd, -1.9082149292705877e-10, r);
+    double p = 2.7557319223985893e-06;           // 1/9!
+    p = __builtin_fma(p, r, 2.48015873015873e-05);
+    p = __builtin_fma(p, r, 0.0001984126984126984);
+    p = __builtin_fma(p, r, 0.001388888888888889);
+    p = __builtin_fma(p, r, 0.008333333333333333);
+    p = __builtin_fma(p, r, 0.041666666666666664);
+    p = __builtin_fma(p, r, 0.16666666666666666);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
     const long long k = (long long)kd;           // |k| <= 151: 2^k is a normal double
     const double sc = __longlong_as_double((k + 1023) << 52);
-    return (float)(p * sc);
+    return regular ? (float)(p * sc) : special;
 }
 
 template <int KIND>
-__device__ __forceinline__ float ew_op(float a, float g, float fn, float fn1)
+__device__ __forceinline__ float ew_op(float a, float g, float fn, float fn1, const double2* __restrict__ log_tab = nullptr)
 {
     if (KIND == EW_HM_N) {  // cartesian3dgrid.h:130-139
         const float av = a / fn1;
@@ -2224,11 +2266,11 @@ __device__ __forceinline__ float ew_op(float a, float g, float fn, float fn1)
     if (KIND == EW_FIN_HM) return fn / a;                   // :84
     // n-ary extensions of the 2-ary camera-fusion ops (cartesian3dgrid.h:111-190) in
     // accumulate / finalize form; sum-, min- and max-reducible across GPUs
-    if (KIND == EW_ADD_LOG) return a + det_logf(g);         // GM: sum of log v (-inf once a v is 0)
+    if (KIND == EW_ADD_LOG) return a + det_logf(g, log_tab);  // GM: sum of log v (-inf once a v is 0)
     if (KIND == EW_ADD_SQ) return a + g * g;                // RMS: sum of v^2
     if (KIND == EW_MIN) return (g < a) ? g : a;             // std::min, :115
     if (KIND == EW_MAX) return (a < g) ? g : a;             // std::max, :188
-    if (KIND == EW_FIN_GM) return det_expf((double)a / (double)fn);
+    if (KIND == EW_FIN_GM) return det_expf((double)a * (1.0 / (double)fn));  // (the reciprocal is loop-invariant)
     // EW_FIN_RMS: mean square in double rounded to float, then sqrt like rmsTwoGrids (:145-146)
     const float ms = (float)((double)a / (double)fn);
     return __builtin_sqrtf(ms);
@@ -2241,21 +2283,23 @@ __global__ __launch_bounds__(256) void k_elementwise(float* __restrict__ a,
 {
     constexpr bool has_g = (KIND == EW_HM_N || KIND == EW_ADD || KIND == EW_ADD_INV ||
                             KIND == EW_ADD_LOG || KIND == EW_ADD_SQ || KIND == EW_MIN || KIND == EW_MAX);
+    __shared__ double2 log_tab[KIND == EW_ADD_LOG ? kLogTabSize : 1];
+    if (KIND == EW_ADD_LOG) det_log_table_fill(log_tab);
     const size_t n4 = n / 4;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         float4 va = reinterpret_cast<float4*>(a)[i];
         float4 vg = make_float4(0.f, 0.f, 0.f, 0.f);
         if (has_g) vg = reinterpret_cast<const float4*>(g)[i];
-        va.x = ew_op<KIND>(va.x, vg.x, fn, fn1);
-        va.y = ew_op<KIND>(va.y, vg.y, fn, fn1);
-        va.z = ew_op<KIND>(va.z, vg.z, fn, fn1);
-        va.w = ew_op<KIND>(va.w, vg.w, fn, fn1);
+        va.x = ew_op<KIND>(va.x, vg.x, fn, fn1, log_tab);
+        va.y = ew_op<KIND>(va.y, vg.y, fn, fn1, log_tab);
+        va.z = ew_op<KIND>(va.z, vg.z, fn, fn1, log_tab);
+        va.w = ew_op<KIND>(va.w, vg.w, fn, fn1, log_tab);
         reinterpret_cast<float4*>(a)[i] = va;
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const size_t i = n4 * 4 + threadIdx.x;
-        a[i] = ew_op<KIND>(a[i], has_g ? g[i] : 0.f, fn, fn1);
+        a[i] = ew_op<KIND>(a[i], has_g ? g[i] : 0.f, fn, fn1, log_tab);
     }
 }
 
@@ -2272,17 +2316,24 @@ template <int ACC, int FIN>
 __global__ __launch_bounds__(256) void k_fuse_n(float* __restrict__ dst, FuseSources src, int n_src,
                                                 size_t n, float identity, float fn)
 {
+    __shared__ double2 log_tab[ACC == EW_ADD_LOG ? kLogTabSize : 1];
+    if (ACC == EW_ADD_LOG) det_log_table_fill(log_tab);
     const size_t n4 = n / 4;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         float4 acc = make_float4(identity, identity, identity, identity);
-        for (int c = 0; c < n_src; ++c) {
-            const float4 v = reinterpret_cast<const float4*>(src.p[c])[i];
-            acc.x = ew_op<ACC>(acc.x, v.x, 0.f, 0.f);
-            acc.y = ew_op<ACC>(acc.y, v.y, 0.f, 0.f);
-            acc.z = ew_op<ACC>(acc.z, v.z, 0.f, 0.f);
-            acc.w = ew_op<ACC>(acc.w, v.w, 0.f, 0.f);
-        }
+        float4 v[kMaxFuseSources];  // all loads of a voxel group in flight before the arithmetic
+#pragma unroll
+        for (int c = 0; c < kMaxFuseSources; ++c)
+            if (c < n_src) v[c] = reinterpret_cast<const float4*>(src.p[c])[i];
+#pragma unroll
+        for (int c = 0; c < kMaxFuseSources; ++c)
+            if (c < n_src) {
+                acc.x = ew_op<ACC>(acc.x, v[c].x, 0.f, 0.f, log_tab);
+                acc.y = ew_op<ACC>(acc.y, v[c].y, 0.f, 0.f, log_tab);
+                acc.z = ew_op<ACC>(acc.z, v[c].z, 0.f, 0.f, log_tab);
+                acc.w = ew_op<ACC>(acc.w, v[c].w, 0.f, 0.f, log_tab);
+            }
         if (FIN >= 0) {
             acc.x = ew_op<(FIN >= 0 ? FIN : 0)>(acc.x, 0.f, fn, 0.f);
             acc.y = ew_op<(FIN >= 0 ? FIN : 0)>(acc.y, 0.f, fn, 0.f);
@@ -2294,7 +2345,7 @@ __global__ __launch_bounds__(256) void k_fuse_n(float* __restrict__ dst, FuseSou
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const size_t i = n4 * 4 + threadIdx.x;
         float acc = identity;
-        for (int c = 0; c < n_src; ++c) acc = ew_op<ACC>(acc, src.p[c][i], 0.f, 0.f);
+        for (int c = 0; c < n_src; ++c) acc = ew_op<ACC>(acc, src.p[c][i], 0.f, 0.f, log_tab);
         if (FIN >= 0) acc = ew_op<(FIN >= 0 ? FIN : 0)>(acc, 0.f, fn, 0.f);
         dst[i] = acc;
     }

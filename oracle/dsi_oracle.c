@@ -294,7 +294,8 @@ void orc_fuse_hm_n(float *a, const float *g, size_t n, int n_maps)
 }
 
 /* ---- n-ary geometric mean helpers: log and exp spelled out in IEEE double operations
- * (+, *, /, floor, bit moves; no libm, no FMA -- this file is built with -ffp-contract=off).
+ * (+, *, /, floor, bit moves and explicit fma() calls -- IEEE 754 fusedMultiplyAdd, exact in
+ * glibc with or without the instruction; nothing is fused implicitly: -ffp-contract=off).
  * The n-ary forms are NOT in the reference (it has 2-ary ops only and drops a third camera for
  * GM / AM / RMS, process1.cpp:169-191); they restate SURVEY.md 8(d) cfg 5:
  * GM = exp(mean(log v)), 0 if any v is 0. */
@@ -303,6 +304,53 @@ static double bits_to_double(uint64_t b)
     double d;
     memcpy(&d, &b, sizeof d);
     return d;
+}
+
+/* log v = e ln2 + log c_i + log1p(r): v = 2^e m, m in [1, 2); the top 7 mantissa bits pick
+ * c_i = 1 + (2 i + 1) / 256, r = (m - c_i) / c_i, |r| <= 2^-8, log1p by its degree-5 Taylor
+ * polynomial; {1 / c_i, log c_i} from a 128-entry table built once with the division-based
+ * atanh series (full double accuracy).  Same operations in the same order as the engine's
+ * det_logf / det_log_series (dvs_mcemvs_amd/csrc/dsi_kernels.hip), which were defined together
+ * with this restatement: the n-ary GM has no reference implementation to follow. */
+static double log_series(double m) /* m in [1, 2) */
+{
+    double e = 0.0;
+    if (m > 1.4142135623730951) {
+        m = m * 0.5;
+        e = 1.0;
+    }
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    double p = 0.047619047619047616;
+    p = p * z + 0.05263157894736842;
+    p = p * z + 0.058823529411764705;
+    p = p * z + 0.06666666666666667;
+    p = p * z + 0.07692307692307693;
+    p = p * z + 0.09090909090909091;
+    p = p * z + 0.1111111111111111;
+    p = p * z + 0.14285714285714285;
+    p = p * z + 0.2;
+    p = p * z + 0.3333333333333333;
+    p = p * z + 1.0;
+    const double t1 = e * 0.6931471805599453;
+    const double t2 = 2.0 * s;
+    return t1 + t2 * p;
+}
+
+static double log_tab_inv[128], log_tab_log[128];
+static int log_tab_ready = 0;
+
+static void log_table_init(void) /* call before any parallel region that uses det_logf */
+{
+    if (log_tab_ready)
+        return;
+    for (int i = 0; i < 128; ++i) {
+        const double c = 1.0 + (double)(2 * i + 1) * 0.00390625;
+        log_tab_inv[i] = 1.0 / c;
+        log_tab_log[i] = log_series(c);
+    }
+    log_tab_ready = 1;
 }
 
 static float det_logf(float v)
@@ -314,26 +362,17 @@ static float det_logf(float v)
     const double x = (double)v;
     uint64_t b;
     memcpy(&b, &x, sizeof b);
-    int e = (int)((b >> 52) & 0x7ffull) - 1023;
-    double m = bits_to_double((b & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
-    if (m > 1.4142135623730951) {
-        m = m * 0.5;
-        e += 1;
-    }
-    const double f = m - 1.0;
-    const double s = f / (2.0 + f);
-    const double z = s * s;
-    double p = 0.07692307692307693;
-    p = p * z + 0.09090909090909091;
-    p = p * z + 0.1111111111111111;
-    p = p * z + 0.14285714285714285;
-    p = p * z + 0.2;
-    p = p * z + 0.3333333333333333;
-    p = p * z + 1.0;
-    const double t1 = (double)e * 0.6931471805599453;
-    const double t2 = 2.0 * s;
-    const double t3 = t2 * p;
-    return (float)(t1 + t3);
+    const int e = (int)((b >> 52) & 0x7ffull) - 1023;
+    const unsigned i = (unsigned)(b >> 45) & 127u;
+    const double m = bits_to_double((b & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
+    const double c = bits_to_double(0x3ff0000000000000ull | ((uint64_t)(2u * i + 1u) << 44));
+    const double r = (m - c) * log_tab_inv[i];
+    double p = fma(r, 0.2, -0.25);             /* fused multiply-adds, spelled out (IEEE 754 fma) */
+    p = fma(p, r, 0.3333333333333333);
+    p = fma(p, r, -0.5);
+    p = fma(p, r, 1.0);
+    p = p * r;
+    return (float)fma((double)e, 0.6931471805599453, log_tab_log[i] + p);
 }
 
 static float det_expf(double y)
@@ -345,21 +384,18 @@ static float det_expf(double y)
     if (y < -104.0)
         return 0.f;
     const double kd = floor(y * 1.4426950408889634 + 0.5);
-    double r = y - kd * 0.6931471803691238;
-    r = r - kd * 1.9082149292705877e-10;
-    double p = 2.08767569878681e-09;
-    p = p * r + 2.505210838544172e-08;
-    p = p * r + 2.755731922398589e-07;
-    p = p * r + 2.7557319223985893e-06;
-    p = p * r + 2.48015873015873e-05;
-    p = p * r + 0.0001984126984126984;
-    p = p * r + 0.001388888888888889;
-    p = p * r + 0.008333333333333333;
-    p = p * r + 0.041666666666666664;
-    p = p * r + 0.16666666666666666;
-    p = p * r + 0.5;
-    p = p * r + 1.0;
-    p = p * r + 1.0;
+    double r = fma(kd, -0.6931471803691238, y);      /* ln2 split as in fdlibm (hi part has 32 bits) */
+    r = fma(kd, -1.9082149292705877e-10, r);
+    double p = 2.7557319223985893e-06;           /* 1/9! */
+    p = fma(p, r, 2.48015873015873e-05);
+    p = fma(p, r, 0.0001984126984126984);
+    p = fma(p, r, 0.001388888888888889);
+    p = fma(p, r, 0.008333333333333333);
+    p = fma(p, r, 0.041666666666666664);
+    p = fma(p, r, 0.16666666666666666);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
     const int64_t k = (int64_t)kd;
     const double sc = bits_to_double((uint64_t)(k + 1023) << 52);
     return (float)(p * sc);
@@ -386,6 +422,7 @@ void orc_accumulate(float *acc, const float *g, size_t n, int mode)
         break;
     }
     case 2: /* n-ary GM: sum of log v */
+        log_table_init();
         for (size_t p = 0; p < n; ++p)
             acc[p] = acc[p] + det_logf(g[p]);
         break;
@@ -415,10 +452,12 @@ void orc_finalize(float *acc, size_t n, int mode, int n_maps)
         for (size_t p = 0; p < n; ++p)
             acc[p] = (float)n_maps / acc[p];
         break;
-    case 2: /* GM = exp(mean(log v)) */
+    case 2: { /* GM = exp(mean(log v)) */
+        const double inv_n = 1.0 / (double)(float)n_maps;
         for (size_t p = 0; p < n; ++p)
-            acc[p] = det_expf((double)acc[p] / (double)(float)n_maps);
+            acc[p] = det_expf((double)acc[p] * inv_n);
         break;
+    }
     case 3: /* RMS: mean square in double -> float, sqrt of the float like rmsTwoGrids :145-146 */
         for (size_t p = 0; p < n; ++p) {
             const float ms = (float)((double)acc[p] / (double)(float)n_maps);
