@@ -518,7 +518,7 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
     }
     HIP_TRY(m->sxy.reserve(np * dsi::kPacket + 1));  // + the multiplicity-0 dummy record
     HIP_TRY(m->nvalid.reserve(np + (size_t)geom.nz + 8));  // + one "needs IEEE divide" word per plane + 8 work counters
-    HIP_TRY(m->rowstart.reserve(np * (size_t)(geom.ny + 2 * bp.row_pad + 3)));
+    HIP_TRY(m->rowstart.reserve(np * (size_t)(geom.ny + 2 * bp.row_pad + 3) + 2));  // (+ slack: k_plane_coef copies 32-bit words)
     HIP_TRY(m->coef.reserve(np * geom.nz + 1));       // + the dummy record's "coefficients"
     HIP_TRY(m->cuts.reserve(np * geom.nz * bp.bands));
     HIP_TRY(m->carry.reserve((size_t)bp.chunks * geom.nz * bp.bands * geom.nx));

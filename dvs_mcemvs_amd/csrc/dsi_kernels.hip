@@ -376,7 +376,15 @@ __device__ __host__ __forceinline__ bool grouped(int packed) { return packed == 
 //     packet whose Y can fall into the band.  The band's Y interval is mapped back to z0 rows
 //     (in double, widened by one row on each side), and the run is read off the packet's
 //     rowstart table.  The run is a superset; the voting kernel re-tests every event exactly.
-__global__ __launch_bounds__(256) void k_plane_coef(const float* __restrict__ centers,
+//     A block covers 16 packets x (blockDim / 16) planes and, when they fit (STAGED), first copies
+//     the 16 packets' rowstart tables into LDS with coalesced loads: every thread looks up two
+//     entries per band at data-dependent positions, and out of global memory those look-ups, not
+//     the table writes, bounded the kernel (1024 x 1024 x 256, 10 M events: 440 us, 16 x 16 tiles
+//     best; wider tiles for longer write segments were slower).
+constexpr int kCoefTilePackets = 16;
+
+template <bool STAGED>
+__global__ __launch_bounds__(1024) void k_plane_coef(const float* __restrict__ centers,
                                                     const float* __restrict__ planes,
                                                     const uint16_t* __restrict__ rowstart,
                                                     uint32_t* __restrict__ nvalid, int np,
@@ -384,12 +392,31 @@ __global__ __launch_bounds__(256) void k_plane_coef(const float* __restrict__ ce
                                                     PlaneCoef* __restrict__ coef,
                                                     uint32_t* __restrict__ cuts)
 {
-    // a block covers a tile of 16 packets x 16 planes: 16 consecutive packets per plane make
-    // the plane-major tables (coef[z][p], cuts[band][z][p]) 64-byte coalesced writes, and the 16
-    // planes of a packet re-read the same rowstart table out of cache
-    const int tiles_p = (np + 15) / 16;
-    const int k = (int)(blockIdx.x % tiles_p) * 16 + (threadIdx.x & 15);
-    const int z = (int)(blockIdx.x / tiles_p) * 16 + (threadIdx.x >> 4);
+    // 16 consecutive packets per plane make the plane-major tables (coef[z][p], cuts[band][z][p])
+    // 64-byte coalesced writes
+    extern __shared__ uint16_t s_rowstart[];  // STAGED: [16][nb + 1]
+    // Block b runs on XCD b % 8 (the dispatch rule the voting kernel relies on too).  Four tiles that
+    // are neighbours along the packet axis -- the four 64-byte pieces of a 256-byte stretch of every
+    // table row -- go to four consecutive blocks of ONE XCD, so that they meet in that XCD's L2 and
+    // leave it as whole lines (dealt round-robin over the XCDs, every line was written in pieces).
+    const int tiles_p = (np + kCoefTilePackets - 1) / kCoefTilePackets;
+    const unsigned tile = (blockIdx.x >> 5) * 32u + (blockIdx.x & 7u) * 4u + ((blockIdx.x >> 3) & 3u);
+    const int planes_per_block = (int)(blockDim.x >> 4);
+    if (tile >= (unsigned)tiles_p * (unsigned)((g.nz + planes_per_block - 1) / planes_per_block)) return;
+    const int k0 = (int)(tile % (unsigned)tiles_p) * kCoefTilePackets;
+    const int k = k0 + (int)(threadIdx.x & 15);
+    const int z = (int)(tile / (unsigned)tiles_p) * planes_per_block + (int)(threadIdx.x >> 4);
+    const int pad = bp.row_pad;
+    const int nb = g.ny + 2 * pad + 2;
+    if (STAGED) {
+        // the tile's tables are one contiguous piece of rowstart, 4-byte aligned (k0 is even); the
+        // last 32-bit word may reach one element past the piece (the buffer has that slack)
+        const int count = min(kCoefTilePackets, np - k0) * (nb + 1);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(rowstart + (size_t)k0 * (nb + 1));
+        uint32_t* dst = reinterpret_cast<uint32_t*>(s_rowstart);
+        for (int i = threadIdx.x; i < (count + 1) / 2; i += blockDim.x) dst[i] = src[i];
+        __syncthreads();
+    }
     if (k >= np || z >= g.nz) return;
     const size_t tid = (size_t)z * np + k;
     PlaneCoef c;
@@ -415,14 +442,17 @@ __global__ __launch_bounds__(256) void k_plane_coef(const float* __restrict__ ce
     coef[tid] = c;
     if (slow) atomicOr(&nvalid[np + z], 1u);
 
-    const int pad = bp.row_pad;
-    const int nb = g.ny + 2 * pad + 2;
-    const uint16_t* rs = rowstart + (grouped(bp.packed) ? 0 : (size_t)k * (nb + 1));
+    const uint16_t* rs = STAGED ? s_rowstart + (size_t)(threadIdx.x & 15) * (nb + 1)
+                                : rowstart + (grouped(bp.packed) ? 0 : (size_t)k * (nb + 1));
     // y0 = (Y*d - by)/a inverts the transfer; unusable when the map is (nearly) constant or
     // the inversion is ill-conditioned -- then the whole packet is the (superset) run
     const double a = (double)c.a, d = (double)c.d, by = (double)c.by;
     const bool invertible = !dead && !slow && fabs(a) > 1e-3 * fabs(d);
-    const double inv_a = 1.0 / a, by_a = by * inv_a, d_a = d * inv_a;  // y0 = Y * d_a - by_a
+    const double inv_a = 1.0 / a;
+    // y0 = Y * d_a - by_a, per band in fp32: its rounding (<= 4e-7 of |y0| + |by/a|) disappears in the
+    // widening below, and 2 x bands x planes x packets double-precision chains were what the kernel
+    // spent its time on
+    const float by_a = (float)(by * inv_a), d_a = (float)(d * inv_a);
     for (int j = 0; j < bp.bands; ++j) {
         uint32_t lo = 0, hi = 0;
         if (!dead) {
@@ -431,17 +461,17 @@ __global__ __launch_bounds__(256) void k_plane_coef(const float* __restrict__ ce
                 const int r0 = j * bp.band_rows;
                 const int r1 = min(g.ny, r0 + bp.band_rows);
                 // accepted iff 0 <= Y < ny-1; the band needs floor(Y) in [r0, r1-1]
-                const double L = (double)r0 - 0.01, U = (double)min(r1, g.ny - 1) + 0.01;
-                const double ya = L * d_a - by_a, yb = U * d_a - by_a;
-                double ymin = fmin(ya, yb), ymax = fmax(ya, yb);
-                if (ymin == ymin && ymax == ymax) {  // not NaN
+                const float L = (float)r0 - 0.01f, U = (float)min(r1, g.ny - 1) + 0.01f;
+                const float ya = L * d_a - by_a, yb = U * d_a - by_a;
+                float ymin = fminf(ya, yb), ymax = fmaxf(ya, yb);
+                if (ya == ya && yb == yb) {  // not NaN
                     // the fp32 forward map (mul, add, divide) is within a few ulps of the real
-                    // one: in y0 units that is ~2^-22 * (|y0| + |by/a|); widen by 40x that
-                    const double m = 1e-5 * (fmax(fabs(ymin), fabs(ymax)) + fabs(by_a));
+                    // one: in y0 units that is ~2^-22 * (|y0| + |by/a|); widen by 80x that
+                    const float m = 2e-5f * (fmaxf(fabsf(ymin), fabsf(ymax)) + fabsf(by_a));
                     ymin -= m;
                     ymax += m;
-                    const double fa = fmin(fmax(floor(ymin), (double)(-pad - 1)), (double)(g.ny + pad));
-                    const double fb = fmin(fmax(floor(ymax), (double)(-pad - 1)), (double)(g.ny + pad));
+                    const float fa = fminf(fmaxf(__builtin_floorf(ymin), (float)(-pad - 1)), (float)(g.ny + pad));
+                    const float fb = fminf(fmaxf(__builtin_floorf(ymax), (float)(-pad - 1)), (float)(g.ny + pad));
                     if (grouped(bp.packed)) {  // grouped mapping: row bins, resolved per group later
                         lo = (uint32_t)((int)fa + pad + 1);
                         hi = (uint32_t)((int)fb + pad + 2);
@@ -2699,9 +2729,17 @@ hipError_t launch_plane_coef(hipStream_t s, const float* centers, const float* p
                              const Geom& g, const BandPlan& bp, PlaneCoef* coef, uint32_t* cuts)
 {
     if (np <= 0) return hipSuccess;
-    const unsigned tiles = (unsigned)((np + 15) / 16) * (unsigned)((g.nz + 15) / 16);
-    hipLaunchKernelGGL(k_plane_coef, dim3(tiles), dim3(256), 0, s, centers, planes, rowstart, nvalid,
-                       np, g, bp, coef, cuts);
+    const unsigned tiles_p = (unsigned)((np + kCoefTilePackets - 1) / kCoefTilePackets);
+    const size_t table_bytes = ((size_t)kCoefTilePackets * (size_t)(g.ny + 2 * bp.row_pad + 3) * sizeof(uint16_t) + 7) & ~(size_t)7;
+    if (!grouped(bp.packed) && table_bytes <= max_dynamic_lds()) {
+        // 16 packets x 64 planes per block: the tables are loaded nz / 64 times
+        if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_plane_coef<true>), table_bytes)) return e;
+        hipLaunchKernelGGL(k_plane_coef<true>, dim3((tiles_p * (unsigned)((g.nz + 63) / 64) + 31u) & ~31u), dim3(1024), table_bytes, s,
+                           centers, planes, rowstart, nvalid, np, g, bp, coef, cuts);
+    } else {
+        hipLaunchKernelGGL(k_plane_coef<false>, dim3((tiles_p * (unsigned)((g.nz + 15) / 16) + 31u) & ~31u), dim3(256), 0, s, centers,
+                           planes, rowstart, nvalid, np, g, bp, coef, cuts);
+    }
     return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
