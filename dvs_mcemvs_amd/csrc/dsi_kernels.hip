@@ -2073,19 +2073,42 @@ __global__ __launch_bounds__(BLOCK) void k_vote_groups(const EvRec* __restrict__
 
 // (4) DSI = sum of the chunk partials (fixed order => deterministic given partials)
 // dsi[z][first row of band j+1][x] += sum over chunks of carry[c][z][j][x]
+// block x = one (plane, seam) row, block y = a 1024-voxel stretch of it; four voxels per thread
+// (one 16-byte access per stream when the rows are 16-byte aligned, i.e. nx % 4 == 0)
 __global__ __launch_bounds__(256) void k_add_carry(const float* __restrict__ carry, int chunks,
                                                    Geom g, int bands, int band_rows,
                                                    float* __restrict__ dsi)
 {
-    const size_t n = (size_t)g.nz * (bands - 1) * g.nx;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int x = (int)(i % g.nx);
-    const int j = (int)((i / g.nx) % (bands - 1));
-    const int z = (int)(i / ((size_t)g.nx * (bands - 1)));
-    float acc = 0.f;
-    for (int c = 0; c < chunks; ++c) acc += carry[(((size_t)c * g.nz + z) * bands + j) * g.nx + x];
-    dsi[((size_t)z * g.ny + (size_t)(j + 1) * band_rows) * g.nx + x] += acc;
+    const int j = (int)(blockIdx.x % (unsigned)(bands - 1));
+    const int z = (int)(blockIdx.x / (unsigned)(bands - 1));
+    const bool vec = (g.nx & 3) == 0;
+    const int x = vec ? ((int)blockIdx.y * 256 + (int)threadIdx.x) * 4 : (int)blockIdx.y * 1024 + (int)threadIdx.x;
+    if (x >= g.nx) return;
+    const size_t chunk_stride = (size_t)g.nz * bands * g.nx;
+    const float* src = carry + ((size_t)z * bands + j) * g.nx + x;
+    float* dst = dsi + ((size_t)z * g.ny + (size_t)(j + 1) * band_rows) * g.nx + x;
+    if (vec) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = 0; c < chunks; ++c) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)c * chunk_stride);
+            acc.x += v.x;
+            acc.y += v.y;
+            acc.z += v.z;
+            acc.w += v.w;
+        }
+        float4 d = *reinterpret_cast<float4*>(dst);
+        d.x += acc.x;
+        d.y += acc.y;
+        d.z += acc.z;
+        d.w += acc.w;
+        *reinterpret_cast<float4*>(dst) = d;
+    } else {
+        for (int u = 0; u < 1024 && x + u < g.nx; u += 256) {
+            float acc = 0.f;
+            for (int c = 0; c < chunks; ++c) acc += src[(size_t)c * chunk_stride + u];
+            dst[u] += acc;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ partials,
@@ -2863,9 +2886,8 @@ hipError_t launch_add_carry(hipStream_t s, const float* carry, int chunks, const
                             const BandPlan& bp, float* dsi)
 {
     if (bp.bands < 2) return hipSuccess;
-    const size_t n = (size_t)g.nz * (bp.bands - 1) * g.nx;
-    hipLaunchKernelGGL(k_add_carry, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, carry, chunks, g,
-                       bp.bands, bp.band_rows, dsi);
+    hipLaunchKernelGGL(k_add_carry, dim3((unsigned)g.nz * (unsigned)(bp.bands - 1), (unsigned)((g.nx + 1023) / 1024)),
+                       dim3(256), 0, s, carry, chunks, g, bp.bands, bp.band_rows, dsi);
     return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 

@@ -3,7 +3,7 @@ timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_windows.py
 export TMPDIR=/tmp
 prof() { # tag, args
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/tr29 -o t -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --no-host-fed $2 > $GRAFT_REPO_ROOT/gpurun_out/tr29.log 2>&1)
-echo "$1:"; python tools/rocpd_summary.py gpurun_out/tr29/*.db | grep "plane_coef\|vote\|fuse_n\|sort"; rm -rf gpurun_out/tr29
+echo "$1:"; python tools/rocpd_summary.py gpurun_out/tr29/*.db | grep "plane_coef\|vote\|fuse_n\|sort\|carry"; rm -rf gpurun_out/tr29
 }
 prof 1024 "--dims 1024 1024 256 --steps 4 --warmup 1"
 prof stereo "--steps 10 --warmup 1"
