@@ -258,7 +258,13 @@ struct RawEvents {
     float* centers;              // out [np][3]
 };
 
-__global__ __launch_bounds__(256) void k_sort_packets(const float2* __restrict__ xy, RawEvents raw,
+// RAW (the events come as sensor pixels, stage A fused in): two events of a packet have the same z0
+// location iff they have the same pixel, so the hash set is keyed by the 32-bit pixel and one 64-bit
+// word per slot holds key and count -- 16 KB instead of 24 KB of LDS, which is what decides how many
+// packets a CU sorts at once (time at 10 M events: 35 us + 260 us / blocks per CU, measured by
+// padding the LDS: 5 blocks 86 us, 4: 99, 3: 122, 2: 172; now 8).
+template <bool RAW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_sort_packets(const float2* __restrict__ xy, RawEvents raw,
                                                       int np, int ny,
                                                       int nz, int pad, EvRec* __restrict__ sxy,
                                                       uint32_t* __restrict__ nvalid,
@@ -266,8 +272,8 @@ __global__ __launch_bounds__(256) void k_sort_packets(const float2* __restrict__
 {
     extern __shared__ uint32_t hist[];  // nb + 1 counters, then scanned in place
     __shared__ float s_H[9];
-    __shared__ __attribute__((aligned(16))) unsigned long long hkey[kHashSlots];
-    __shared__ uint32_t hcnt[kHashSlots];
+    __shared__ __attribute__((aligned(16))) unsigned long long hkey[kHashSlots];  // RAW: pixel | count << 32
+    __shared__ uint32_t hcnt[RAW ? 1 : kHashSlots];
     __shared__ uint32_t wave_tot[4];
     __shared__ uint32_t big;  // some |x0| or |y0| above 2^40 (never a real pixel)
     const int nb = ny + 2 * pad + 2;
@@ -286,9 +292,9 @@ __global__ __launch_bounds__(256) void k_sort_packets(const float2* __restrict__
     for (int i = threadIdx.x; i <= nb; i += 256) hist[i] = 0;
     for (int i = threadIdx.x; i < kHashSlots; i += 256) {
         hkey[i] = kHashEmpty;
-        hcnt[i] = 0;
+        if (!RAW) hcnt[i] = 0;
     }
-    if (!xy && threadIdx.x == 0) {
+    if (RAW && threadIdx.x == 0) {
         float c3[3], h9[9];
         packet_geometry_of(raw.Rt + 12 * (size_t)k, raw.g, c3, h9);
 #pragma unroll
@@ -299,37 +305,58 @@ __global__ __launch_bounds__(256) void k_sort_packets(const float2* __restrict__
     __syncthreads();
     float2 ev[4];
     int bin[4], slot[4];
-    uint32_t rank[4];
-    const size_t first_ev = (!xy && raw.packet_first) ? (size_t)raw.packet_first[k] : (size_t)k * kPacket;
+    uint32_t rank[4], mult[4];
+    const size_t first_ev = (RAW && raw.packet_first) ? (size_t)raw.packet_first[k] : (size_t)k * kPacket;
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
-        if (xy) {
+        uint32_t pixel = 0;
+        if (!RAW) {
             ev[h] = xy[(size_t)k * kPacket + threadIdx.x + 256 * h];
         } else {
             const size_t e = first_ev + threadIdx.x + 256 * h;
-            ev[h] = warp_event_z0(raw.ex[e], raw.ey[e], s_H, raw.lut, raw.sensor_w);
+            const unsigned px = raw.ex[e], py = raw.ey[e];
+            pixel = px | (py << 16);
+            ev[h] = warp_event_z0(px, py, s_H, raw.lut, raw.sensor_w);
         }
         bin[h] = -1;
         slot[h] = 0;
         rank[h] = 0;
+        mult[h] = 0;
         if (finitef(ev[h].x) && finitef(ev[h].y)) {
-            const unsigned long long key =
-                ((unsigned long long)__float_as_uint(ev[h].y) << 32) | __float_as_uint(ev[h].x);
-            uint32_t hs = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 53);  // 11 bits
-            for (;;) {
-                const unsigned long long old = atomicCAS(&hkey[hs], kHashEmpty, key);
-                if (old == kHashEmpty || old == key) break;
-                hs = (hs + 1) & (kHashSlots - 1);
+            bool first;
+            if (RAW) {
+                // (an all-ones pixel would look like the empty word: x = y = 65535 is no sensor's)
+                uint32_t hs = (pixel * 0x9E3779B1u) >> 21;  // 11 bits
+                for (;;) {
+                    const unsigned long long old = atomicCAS(&hkey[hs], kHashEmpty, (unsigned long long)pixel);
+                    if (old == kHashEmpty || (uint32_t)old == pixel) break;
+                    hs = (hs + 1) & (kHashSlots - 1);
+                }
+                slot[h] = (int)hs;
+                first = (atomicAdd(&hkey[hs], 1ull << 32) >> 32) == 0ull;
+            } else {
+                const unsigned long long key =
+                    ((unsigned long long)__float_as_uint(ev[h].y) << 32) | __float_as_uint(ev[h].x);
+                uint32_t hs = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 53);  // 11 bits
+                for (;;) {
+                    const unsigned long long old = atomicCAS(&hkey[hs], kHashEmpty, key);
+                    if (old == kHashEmpty || old == key) break;
+                    hs = (hs + 1) & (kHashSlots - 1);
+                }
+                slot[h] = (int)hs;
+                first = atomicAdd(&hcnt[hs], 1u) == 0u;
             }
-            slot[h] = (int)hs;
-            if (atomicAdd(&hcnt[hs], 1u) == 0u) bin[h] = row_bin(ev[h].y, ny, pad);  // representative
+            if (first) bin[h] = row_bin(ev[h].y, ny, pad);  // representative
             if (!(fabsf(ev[h].x) <= 0x1p40f && fabsf(ev[h].y) <= 0x1p40f)) big = 1u;
         }
     }
     __syncthreads();
 #pragma unroll
     for (int h = 0; h < 4; ++h)
-        if (bin[h] >= 0) rank[h] = atomicAdd(&hist[bin[h]], 1u);
+        if (bin[h] >= 0) {
+            rank[h] = atomicAdd(&hist[bin[h]], 1u);
+            mult[h] = RAW ? (uint32_t)(hkey[slot[h]] >> 32) : hcnt[slot[h]];  // (the records are staged over hkey later)
+        }
     __syncthreads();
     // exclusive scan of hist[0..nb): each thread owns a contiguous slice
     const int per = (nb + 255) / 256;
@@ -367,7 +394,7 @@ __global__ __launch_bounds__(256) void k_sort_packets(const float2* __restrict__
             EvRec r;
             r.x = ev[h].x;
             r.y = ev[h].y;
-            r.m = hcnt[slot[h]];
+            r.m = mult[h];
             stage[hist[bin[h]] + rank[h]] = r;
         }
     __syncthreads();
@@ -2741,7 +2768,7 @@ hipError_t launch_sort_packets(hipStream_t s, const float2* xy, int np, int ny, 
 {
     if (np <= 0) return hipSuccess;
     const size_t lds = (size_t)(ny + 2 * pad + 3) * sizeof(uint32_t);
-    hipLaunchKernelGGL(k_sort_packets, dim3(np), dim3(256), lds, s, xy, RawEvents{}, np, ny, nz, pad, sxy, nvalid,
+    hipLaunchKernelGGL(k_sort_packets<false>, dim3(np), dim3(256), lds, s, xy, RawEvents{}, np, ny, nz, pad, sxy, nvalid,
                        rowstart);
     return hipExtGetLastError();
 }
@@ -2754,7 +2781,7 @@ hipError_t launch_sort_packets_raw(hipStream_t s, const float* Rt, const uint16_
     if (np <= 0) return hipSuccess;
     const size_t lds = (size_t)(g.ny + 2 * pad + 3) * sizeof(uint32_t);
     RawEvents raw{Rt, ex, ey, packet_first, lut, sensor_w, g, centers};
-    hipLaunchKernelGGL(k_sort_packets, dim3(np), dim3(256), lds, s, (const float2*)nullptr, raw, np, g.ny, g.nz, pad,
+    hipLaunchKernelGGL(k_sort_packets<true>, dim3(np), dim3(256), lds, s, (const float2*)nullptr, raw, np, g.ny, g.nz, pad,
                        sxy, nvalid, rowstart);
     return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
