@@ -264,7 +264,7 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
         packed = 1024L * (rows_full + 1) / g.ny < 32 ? 5 : 1;
     }
     // lane mapping 5 keeps 64 tail-bit words per wave behind the band
-    const size_t scratch_bytes = (packed == 5 || packed == 6) ? (size_t)(block_threads / 64) * 512 : 0;
+    const size_t scratch_bytes = (packed == 5 || packed == 6) ? (size_t)(block_threads / 64) * dsi::kVfillScratchWords * 8 : 0;
     const long max_rows_total = (long)((dsi::max_dynamic_lds() - scratch_bytes) / row_bytes);
     if (max_rows_total < 2 || g.nx < 2 || g.ny < 2 || g.ny > 16000) return false;
     long max_owned = max_rows_total - 1;  // + the carry row

@@ -37,6 +37,10 @@ struct Geom {
     float z0;                  // raw_depths_vec_[0]
 };
 
+// lane mappings 5 / 6: 64-bit words of LDS scratch per wave (64 tail-bit words, reused as the run table
+// of the hand-scheduled loop, whose entry 64 serves the slots beyond a pass)
+constexpr int kVfillScratchWords = 65;
+
 struct BandPlan {
     int bands;          // row bands per plane
     int band_rows;      // owned rows per band (last band may own fewer)
@@ -49,7 +53,7 @@ struct BandPlan {
     int row_pad;        // z0 rows binned over [-row_pad, ny + row_pad) by k_sort_packets
     int pass_lg;        // packed mappings: log2(packets a wave takes per pass); 0 = automatic
     size_t lds_bytes;   // (band_rows + 1) * nx * 8 (u64 fixed-point accumulators; +1 = the carry row)
-                        // + mapping 5: 512 B per wave for the tail-bit words
+                        // + mappings 5 / 6: kVfillScratchWords * 8 B per wave (tail-bit words / run table)
     int scratch_offset; // mapping 5: byte offset of that area behind the band
     int persistent;     // packed mappings: workgroups pull work items from per-XCD counters
     int experiment;     // DSI_EXPERIMENT (timing experiments only, results are wrong): 1 no votes, 2 no flush

@@ -1309,14 +1309,16 @@ __device__ __forceinline__ void packed_stream_asm(const EvRec* sxy, const uint4*
 
 // ---- lane mapping 5, hand-scheduled: the batches of one range (<= 64 batches = 4096 slots) of a
 // vector-fill pass (see vfill_stream for the slot -> record mapping; the per-pass tables are built
-// by compiled code and handed over in vector registers).  Per batch: 3 v_readlane + 2 v_mbcnt +
-// 2 ds_bpermute find every lane's record and packet, then the same GATHER / VOTE as the packed
-// stream.  Two batches of gathers are in flight while one is voted: the ds_bpermutes of batch k+2
-// are issued BEFORE the votes of batch k (their latency hides behind ~45 vector instructions),
+// by compiled code and handed over through the wave's LDS scratch).  Per batch: 3 v_readlane +
+// 2 v_mbcnt + 1 ds_read_b64 of the run table find every lane's record and packet (two ds_bpermute of
+// register tables at first: one LDS instruction fewer per batch was worth 7 % at 1024 x 1024 x 256,
+// 4.96 -> 4.60 ms), then the same GATHER / VOTE as the packed
+// stream.  Two batches of gathers are in flight while one is voted: the table look-up of batch k+2
+// is issued BEFORE the votes of batch k (its latency hides behind ~45 vector instructions),
 // waited for with lgkmcnt(4) (the four ds_add_u64 of batch k are younger), and the gathers of
 // batch k+2 go into the register set batch k has just released.
 //   s42 batch counter k   s45 k+2   s46,s49,s50 tail-bit words / tails before the batch   s51 first slot of batch k+2
-//   v32 slot per lane   v33 coefficient byte offset   v34 12 * (record - slot)   v35 table index
+//   v32 slot per lane   v34 12 * (record - slot)   v35 table address, then the coefficient byte offset
 //   sets A / B and the temporaries as in packed_stream_asm
 #define DSI_ASM_VPREP1                                                                             \
     "v_readlane_b32 s46, %5, s45\n\t"     /* tail bits of the batch, low / high half */             \
@@ -1324,9 +1326,9 @@ __device__ __forceinline__ void packed_stream_asm(const EvRec* sxy, const uint4*
     "v_readlane_b32 s50, %7, s45\n\t"     /* runs that end before the batch */                      \
     "v_mbcnt_lo_u32_b32 v35, s46, 0\n\t"                                                            \
     "v_mbcnt_hi_u32_b32 v35, s49, v35\n\t" /* + runs that end before this lane's slot */            \
-    "v_add_lshl_u32 v35, v35, s50, 2\n\t"                                                           \
-    "ds_bpermute_b32 v34, v35, %8\n\t"    /* D of the lane's run */                                 \
-    "ds_bpermute_b32 v33, v35, %16\n\t"   /* byte offset of its packet's coefficients */            \
+    "v_add_u32 v35, v35, s50\n\t"                                                                   \
+    "v_lshl_add_u32 v35, v35, 3, %8\n\t"                                                            \
+    "ds_read_b64 v[34:35], v35\n\t"       /* the run's {D, coefficient byte offset} */              \
     "s_lshl_b32 s51, s45, 6\n\t"                                                                    \
     "s_add_i32 s51, s51, %3\n\t"          /* first slot of the batch */
 
@@ -1337,14 +1339,15 @@ __device__ __forceinline__ void packed_stream_asm(const EvRec* sxy, const uint4*
     "v_add3_u32 v58, v34, s46, %17\n\t"   /* byte offset of the record: 12 * (D + slot) */          \
     "v_cndmask_b32 v58, %14, v58, vcc\n\t" /* beyond the pass: the multiplicity-0 record */         \
     "global_load_dwordx3 " EV ", v58, %0\n\t"                                                       \
-    "global_load_dwordx4 " CA ", v33, %1\n\t"                                                       \
-    "global_load_dword " CR ", v33, %1 offset:16\n\t"
+    "global_load_dwordx4 " CA ", v35, %1\n\t"                                                       \
+    "global_load_dword " CR ", v35, %1 offset:16\n\t"
 
 __device__ __forceinline__ void vfill_range_asm(const EvRec* sxy, const uint4* coef4, int nb, int slot0,
-                                                int T, uint32_t wlo, uint32_t whi, int cb, int Dc,
-                                                int Pc32, char* band_bytes, int lane, int nx, int Li,
+                                                int T, uint32_t wlo, uint32_t whi, int cb, const void* tab,
+                                                char* band_bytes, int lane, int nx, int Li,
                                                 int Ui, int row_base, uint32_t dummy_eo)
 {
+    const int s_tab = __builtin_amdgcn_readfirstlane((int)(uintptr_t)tab);  // LDS address of the run table
     const int s_nb = __builtin_amdgcn_readfirstlane(nb);
     const int s_slot0 = __builtin_amdgcn_readfirstlane(slot0);
     const int s_T = __builtin_amdgcn_readfirstlane(T);
@@ -1408,9 +1411,9 @@ __device__ __forceinline__ void vfill_range_asm(const EvRec* sxy, const uint4* c
         "Lend%=:\n\t"
         "s_waitcnt vmcnt(0) lgkmcnt(0)"
         :
-        : "s"(sxy), "s"(coef4), "s"(s_nb), "s"(s_slot0), "s"(s_T), "v"(wlo), "v"(whi), "v"(cb), "v"(Dc),
+        : "s"(sxy), "s"(coef4), "s"(s_nb), "s"(s_slot0), "s"(s_T), "v"(wlo), "v"(whi), "v"(cb), "s"(s_tab),
           "s"(s_nx8), "s"(s_cbase), "s"(s_nxm2), "s"(s_Li), "s"(s_Uim1), "v"(dummy_eo * 12u), "v"(lane),
-          "v"(Pc32), "v"(lane * 12)
+          "v"(0), "v"(lane * 12)
         : "memory", "scc", "vcc", "s42", "s45", "s46", "s49", "s50", "s51", "v32", "v33", "v34", "v35",
           "v36", "v37", "v38", "v39", "v40", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50",
           "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
@@ -1423,10 +1426,11 @@ __device__ __forceinline__ void vfill_range_asm(const EvRec* sxy, const uint4* c
 // v[28:31] a,bx,by,d.  The closing votes wait for everything in flight at once (vmcnt(0)) and then
 // run in any order, so one drain serves all three phases: s52 = bit mask of the sets still to vote.
 __device__ __forceinline__ void vfill_range_asm3(const EvRec* sxy, const uint4* coef4, int nb, int slot0,
-                                                 int T, uint32_t wlo, uint32_t whi, int cb, int Dc,
-                                                 int Pc32, char* band_bytes, int lane, int nx, int Li,
+                                                 int T, uint32_t wlo, uint32_t whi, int cb, const void* tab,
+                                                 char* band_bytes, int lane, int nx, int Li,
                                                  int Ui, int row_base, uint32_t dummy_eo)
 {
+    const int s_tab = __builtin_amdgcn_readfirstlane((int)(uintptr_t)tab);  // LDS address of the run table
     const int s_nb = __builtin_amdgcn_readfirstlane(nb);
     const int s_slot0 = __builtin_amdgcn_readfirstlane(slot0);
     const int s_T = __builtin_amdgcn_readfirstlane(T);
@@ -1508,9 +1512,9 @@ __device__ __forceinline__ void vfill_range_asm3(const EvRec* sxy, const uint4* 
         "LnoC%=:\n\t"
         "s_waitcnt vmcnt(0) lgkmcnt(0)"
         :
-        : "s"(sxy), "s"(coef4), "s"(s_nb), "s"(s_slot0), "s"(s_T), "v"(wlo), "v"(whi), "v"(cb), "v"(Dc),
+        : "s"(sxy), "s"(coef4), "s"(s_nb), "s"(s_slot0), "s"(s_T), "v"(wlo), "v"(whi), "v"(cb), "s"(s_tab),
           "s"(s_nx8), "s"(s_cbase), "s"(s_nxm2), "s"(s_Li), "s"(s_Uim1), "v"(dummy_eo * 12u), "v"(lane),
-          "v"(Pc32), "v"(lane * 12)
+          "v"(0), "v"(lane * 12)
         : "memory", "scc", "vcc", "s42", "s45", "s46", "s49", "s50", "s51", "s52", "v24", "v25", "v26", "v27",
           "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v42", "v43",
           "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58",
@@ -1566,15 +1570,24 @@ __device__ __forceinline__ void vfill_stream_asm(const EvRec* __restrict__ sxy,
             if (len > 0 && ts >= 0 && ts < 4096) atomicOr(&scratch[ts >> 6], 1ull << (ts & 63));
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             const unsigned long long w = scratch[lane];
+            // the tail words now live in registers: the same words carry the run table
+            // {D, coefficient byte offset} of the compacted runs, one ds_read_b64 per batch instead
+            // of two ds_bpermute
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            scratch[lane] = (unsigned long long)(uint32_t)Dc | ((unsigned long long)(uint32_t)Pc32 << 32);
+            // slots beyond the pass count all R <= 64 runs as ended: entry 64 must hold a valid
+            // coefficient offset too (their record is the multiplicity-0 dummy)
+            if (lane == 0) scratch[64] = (unsigned long long)(uint32_t)Pc32 << 32;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             const int pc = __builtin_popcountll(w);
             const int inc = wave_incl_scan(pc, lane);
             const int nb = min(64, (T - rbase + 63) >> 6);
             if (variant == 3)
-                vfill_range_asm(sxy, coef4, nb, rbase, T, (uint32_t)w, (uint32_t)(w >> 32), inc - pc + Cbase, Dc,
-                                Pc32, band_bytes, lane, nx, Li, Ui, row_base, dummy_eo);
+                vfill_range_asm(sxy, coef4, nb, rbase, T, (uint32_t)w, (uint32_t)(w >> 32), inc - pc + Cbase, scratch,
+                                band_bytes, lane, nx, Li, Ui, row_base, dummy_eo);
             else
-                vfill_range_asm3(sxy, coef4, nb, rbase, T, (uint32_t)w, (uint32_t)(w >> 32), inc - pc + Cbase, Dc,
-                                 Pc32, band_bytes, lane, nx, Li, Ui, row_base, dummy_eo);
+                vfill_range_asm3(sxy, coef4, nb, rbase, T, (uint32_t)w, (uint32_t)(w >> 32), inc - pc + Cbase, scratch,
+                                 band_bytes, lane, nx, Li, Ui, row_base, dummy_eo);
             Cbase += __builtin_amdgcn_readlane(inc, 63);
         }
     }
@@ -1823,7 +1836,7 @@ __device__ __forceinline__ void vote_bands_packed_body(const EvRec* __restrict__
         if (bp.pass_lg > 0) lg_pass = bp.pass_lg;
         const int pass = 1 << lg_pass;
         unsigned long long* scratch =
-            reinterpret_cast<unsigned long long*>(band_bytes + bp.scratch_offset) + wave * 64;
+            reinterpret_cast<unsigned long long*>(band_bytes + bp.scratch_offset) + wave * kVfillScratchWords;
         if (slow_any[z] != 0)
             vfill_stream<true>(sxy, coef4, cutz, band_bytes, scratch, p_begin + wave * pass, p_end, lg_pass,
                                kWaves * pass, lane, nx, Li, Ui, r0, dummy_eo);
