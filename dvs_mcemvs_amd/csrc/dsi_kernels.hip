@@ -1560,8 +1560,10 @@ __device__ __forceinline__ void vfill_stream_asm(const EvRec* __restrict__ sxy,
         const int c = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(ne >> 32),
                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)ne, 0u));
         const int dst = len > 0 ? c : 63 - (lane - c);  // non-empty runs to lanes 0, 1, ...; the rest behind
-        const int Dc = __builtin_amdgcn_ds_permute(dst << 2, D * 12);  // byte offsets of 12-byte records (mod 2^32)
-        const int Pc32 = __builtin_amdgcn_ds_permute(dst << 2, min(p, p_end - 1) << 5);
+        // table entry of compacted run `dst`: {12 * D (byte offsets of 12-byte records, mod 2^32), byte
+        // offset of the packet's coefficients}
+        const unsigned long long entry =
+            (unsigned long long)(uint32_t)(D * 12) | ((unsigned long long)(uint32_t)(min(p, p_end - 1) << 5) << 32);
         int Cbase = 0;
         for (int rbase = 0; rbase < T; rbase += 4096) {
             scratch[lane] = 0ull;
@@ -1574,10 +1576,10 @@ __device__ __forceinline__ void vfill_stream_asm(const EvRec* __restrict__ sxy,
             // {D, coefficient byte offset} of the compacted runs, one ds_read_b64 per batch instead
             // of two ds_bpermute
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            scratch[lane] = (unsigned long long)(uint32_t)Dc | ((unsigned long long)(uint32_t)Pc32 << 32);
+            scratch[dst] = entry;  // (a permutation of the lanes: every entry 0..63 is written)
             // slots beyond the pass count all R <= 64 runs as ended: entry 64 must hold a valid
             // coefficient offset too (their record is the multiplicity-0 dummy)
-            if (lane == 0) scratch[64] = (unsigned long long)(uint32_t)Pc32 << 32;
+            if (lane == 0) scratch[64] = entry;
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             const int pc = __builtin_popcountll(w);
             const int inc = wave_incl_scan(pc, lane);
