@@ -205,7 +205,7 @@ def roofline_block(info, kern_ms, kt_n, accepted, ev_per_launch, nz, traffic):
     the SURVEY 8(d) "algorithmic bytes" figure (32*Nz+8 B per event as if every vote were an HBM
     read-modify-write), which is NOT a bound for this kernel (it exceeds the HBM peak)."""
     kernel = {0: "k_vote_bands", 1: "k_vote_bands_packed", 2: "k_vote_groups", 3: "k_vote_bands_packed",
-              4: "k_vote_groups", 5: "k_vote_bands_packed", 6: "k_vote_bands_packed"}[info["packed"]] \
+              4: "k_vote_groups", 5: "k_vote_bands_vfill", 6: "k_vote_bands_vfill"}[info["packed"]] \
         if info["algo"] == 2 else "k_vote_global"
     if not kt_n:
         return {"bound": "lds_atomic", "achieved": None, "peak": None, "unit": "G adds/s", "frac": None,
