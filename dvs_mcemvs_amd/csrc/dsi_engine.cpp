@@ -466,7 +466,7 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
         HIP_TRY(m->H.reserve(np * 9));
         HIP_TRY(m->xy.reserve(np * dsi::kPacket));
         HIP_TRY(dsi::launch_packet_geometry(ps, raw->Rt, (int)np, m->geom, m->centers.p, m->H.p));
-        HIP_TRY(dsi::launch_warp_z0(ps, raw->x, raw->y, raw->first, (int)np, m->H.p, m->lut_dev, m->sensor_w,
+        HIP_TRY(dsi::launch_warp_z0(ps, raw->x, raw->y, raw->first, (int)np, m->H.p, m->lut_dev, m->sensor_w, m->sensor_h,
                                     m->xy.p));
         xy = m->xy.p;
         return DSI_OK;
@@ -545,7 +545,7 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
         vt.stop();
     } else {
     if (raw && !m->keep_z0) {
-        HIP_TRY(dsi::launch_sort_packets_raw(ps, raw->Rt, raw->x, raw->y, raw->first, m->lut_dev, m->sensor_w, geom,
+        HIP_TRY(dsi::launch_sort_packets_raw(ps, raw->Rt, raw->x, raw->y, raw->first, m->lut_dev, m->sensor_w, m->sensor_h, geom,
                                              m->centers.p, (int)np, bp.row_pad, m->sxy.p, m->nvalid.p,
                                              m->rowstart.p));
     } else {

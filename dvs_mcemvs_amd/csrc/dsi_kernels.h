@@ -68,14 +68,14 @@ hipError_t launch_packet_geometry(hipStream_t s, const float* Rt, int np, const 
                                   float* centers, float* H);
 hipError_t launch_warp_z0(hipStream_t s, const uint16_t* ex, const uint16_t* ey,
                           const uint32_t* packet_first, int np, const float* H,
-                          const float2* lut, int sensor_w, float2* xy);
+                          const float2* lut, int sensor_w, int sensor_h, float2* xy);
 // ---- stage B, global-atomic form ------------------------------------------
 hipError_t launch_vote_global(hipStream_t s, const float2* xy, const float* centers, int np,
                               const float* planes, const Geom& g, float* dsi);
 // ---- stage B, LDS row-band form -------------------------------------------
 // the same with stage A (per-packet geometry + z0 warp) fused in: raw events in, centers out
 hipError_t launch_sort_packets_raw(hipStream_t s, const float* Rt, const uint16_t* ex, const uint16_t* ey,
-                                   const uint32_t* packet_first, const float2* lut, int sensor_w, const Geom& g,
+                                   const uint32_t* packet_first, const float2* lut, int sensor_w, int sensor_h, const Geom& g,
                                    float* centers, int np, int pad, EvRec* sxy, uint32_t* nvalid,
                                    uint16_t* rowstart);
 hipError_t launch_sort_packets(hipStream_t s, const float2* xy, int np, int ny, int nz, int pad,

@@ -140,10 +140,13 @@ __global__ void k_packet_geometry(const float* __restrict__ Rt, int np, Geom g,
 // mapper_emvs_stereo.cpp:129-142 for one event: LUT, 4x4 packet product ((c0*u + c1*v) + c2*1) + c3*0,
 // p /= p[2]
 __device__ __forceinline__ float2 warp_event_z0(unsigned x, unsigned y, const float* __restrict__ h,
-                                                const float2* __restrict__ lut, int sensor_w)
+                                                const float2* __restrict__ lut, int sensor_w, int sensor_h)
 {
     float u, v;
     if (lut) {
+        // a pixel outside the sensor has no LUT entry (the reference would read past its matrix): the
+        // event gets a non-finite location, which no plane accepts
+        if (x >= (unsigned)sensor_w || y >= (unsigned)sensor_h) return make_float2(__builtin_nanf(""), __builtin_nanf(""));
         const float2 p = lut[(size_t)y * sensor_w + x];  // :134
         u = p.x;
         v = p.y;
@@ -161,7 +164,7 @@ __device__ __forceinline__ float2 warp_event_z0(unsigned x, unsigned y, const fl
 __global__ void k_warp_z0(const uint16_t* __restrict__ ex, const uint16_t* __restrict__ ey,
                           const uint32_t* __restrict__ packet_first, int np,
                           const float* __restrict__ H, const float2* __restrict__ lut,
-                          int sensor_w, float2* __restrict__ xy)
+                          int sensor_w, int sensor_h, float2* __restrict__ xy)
 {
     const int k = blockIdx.x;  // packet
     const size_t first = packet_first ? (size_t)packet_first[k] : (size_t)k * kPacket;
@@ -170,7 +173,7 @@ __global__ void k_warp_z0(const uint16_t* __restrict__ ex, const uint16_t* __res
                 h7 = h[7], h8 = h[8];
     const float hh[9] = {h0, h1, h2, h3, h4, h5, h6, h7, h8};
     for (int j = threadIdx.x; j < kPacket; j += blockDim.x)
-        xy[(size_t)k * kPacket + j] = warp_event_z0(ex[first + j], ey[first + j], hh, lut, sensor_w);
+        xy[(size_t)k * kPacket + j] = warp_event_z0(ex[first + j], ey[first + j], hh, lut, sensor_w, sensor_h);
 }
 
 // ------------------------------------------------- stage B: global atomics --
@@ -253,7 +256,7 @@ struct RawEvents {
     const uint16_t *ex, *ey;
     const uint32_t* packet_first;  // or nullptr: packet k starts at k * 1024
     const float2* lut;             // or nullptr: identity
-    int sensor_w;
+    int sensor_w, sensor_h;
     Geom g;
     float* centers;              // out [np][3]
 };
@@ -316,7 +319,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             const size_t e = first_ev + threadIdx.x + 256 * h;
             const unsigned px = raw.ex[e], py = raw.ey[e];
             pixel = px | (py << 16);
-            ev[h] = warp_event_z0(px, py, s_H, raw.lut, raw.sensor_w);
+            ev[h] = warp_event_z0(px, py, s_H, raw.lut, raw.sensor_w, raw.sensor_h);
         }
         bin[h] = -1;
         slot[h] = 0;
@@ -325,7 +328,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         if (finitef(ev[h].x) && finitef(ev[h].y)) {
             bool first;
             if (RAW) {
-                // (an all-ones pixel would look like the empty word: x = y = 65535 is no sensor's)
+                // (a claimed word has a count < 2^11 in its high half, the empty word all ones: no pixel
+                //  value can be mistaken for an empty slot)
                 uint32_t hs = (pixel * 0x9E3779B1u) >> 21;  // 11 bits
                 for (;;) {
                     const unsigned long long old = atomicCAS(&hkey[hs], kHashEmpty, (unsigned long long)pixel);
@@ -2759,11 +2763,11 @@ hipError_t launch_packet_geometry(hipStream_t s, const float* Rt, int np, const 
 
 hipError_t launch_warp_z0(hipStream_t s, const uint16_t* ex, const uint16_t* ey,
                           const uint32_t* packet_first, int np, const float* H,
-                          const float2* lut, int sensor_w, float2* xy)
+                          const float2* lut, int sensor_w, int sensor_h, float2* xy)
 {
     if (np <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_warp_z0, dim3(np), dim3(256), 0, s, ex, ey, packet_first, np, H, lut,
-                       sensor_w, xy);
+                       sensor_w, sensor_h, xy);
     return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
@@ -2789,13 +2793,13 @@ hipError_t launch_sort_packets(hipStream_t s, const float2* xy, int np, int ny, 
 }
 
 hipError_t launch_sort_packets_raw(hipStream_t s, const float* Rt, const uint16_t* ex, const uint16_t* ey,
-                                   const uint32_t* packet_first, const float2* lut, int sensor_w, const Geom& g,
+                                   const uint32_t* packet_first, const float2* lut, int sensor_w, int sensor_h, const Geom& g,
                                    float* centers, int np, int pad, EvRec* sxy, uint32_t* nvalid,
                                    uint16_t* rowstart)
 {
     if (np <= 0) return hipSuccess;
     const size_t lds = (size_t)(g.ny + 2 * pad + 3) * sizeof(uint32_t);
-    RawEvents raw{Rt, ex, ey, packet_first, lut, sensor_w, g, centers};
+    RawEvents raw{Rt, ex, ey, packet_first, lut, sensor_w, sensor_h, g, centers};
     hipLaunchKernelGGL(k_sort_packets<true>, dim3(np), dim3(256), lds, s, (const float2*)nullptr, raw, np, g.ny, g.nz, pad,
                        sxy, nvalid, rowstart);
     return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)

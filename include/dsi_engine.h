@@ -262,7 +262,10 @@ DSI_API int dsi_mapper_fill_voxel_grid(dsi_mapper_t *m, const float *xy_z0, cons
  * timestamps are not needed past packetisation) plus the packetisation done by
  * mapper_emvs_stereo.cpp:88-105: packet k covers events
  * [packet_first[k], packet_first[k]+1024) (packet_first == NULL: k*1024) and has
- * pose Rt[12k..12k+11] = R (row-major 3x3) then t of T_ev_rv, already cast to float. */
+ * pose Rt[12k..12k+11] = R (row-major 3x3) then t of T_ev_rv, already cast to float.
+ * An event whose pixel lies outside the sensor of the mapper that evaluates the batch has no
+ * rectification-LUT entry (the reference would index past its matrix, :134); with a LUT it is
+ * dropped -- it votes on no plane -- instead of being looked up out of bounds. */
 DSI_API int dsi_batch_create(dsi_context_t *ctx, const uint16_t *x, const uint16_t *y, size_t n_events,
                      const uint32_t *packet_first, const float *Rt, size_t n_packets, dsi_batch_t **out);
 /* Host-fed streams (a 50 ms window every 50 ms, main.cpp:177): page-locked host memory lets the

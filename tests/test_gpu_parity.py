@@ -167,6 +167,34 @@ def test_evaluate_dsi_matches_oracle(ctx, algo, variant):
         m.close()
 
 
+def test_events_outside_the_sensor_are_dropped(ctx):
+    """An event whose pixel lies outside the sensor has no LUT entry (the reference would read past its
+    matrix, mapper_emvs_stereo.cpp:134): the engine gives it a non-finite z0 location, which no plane
+    accepts -- same DSI as if its LUT entry were NaN, and no out-of-bounds access on the device."""
+    rig = syn.stereo_rig(20000, width=96, height=72, duration=0.3, seed=23)
+    cam = rig["cam"]
+    lut = syn.radial_lut(cam).copy()
+    lut.reshape(72, 96, 2)[0, 0] = np.nan
+    x, y, ts = rig["events"][0]
+    bad = np.zeros(x.shape, bool)
+    bad[5::37] = True
+    x_out, y_out = x.copy(), y.copy()
+    x_out[bad & (np.arange(x.size) % 2 == 0)] = 96          # one past the last column
+    y_out[bad & (np.arange(x.size) % 2 == 1)] = 65535       # far outside
+    x_nan, y_nan = x.copy(), y.copy()
+    x_nan[bad], y_nan[bad] = 0, 0                            # the pixel whose LUT entry is NaN
+    got = []
+    for xs, ys in ((x_out, y_out), (x_nan, y_nan)):
+        m = make_mapper(ctx, cam, 16, 4.0, 200.0, d.VOTE_LDS_BANDS, lut=lut)
+        assert m.evaluateDSI((xs, ys, ts), rig["trajectories"][0], rig["T_rv_w"])
+        got.append(m.dsi_.download())
+        m.close()
+    assert np.array_equal(got[0], got[1]) and got[0].any()
+    r = OracleMapper(cam, dimZ=16, min_depth=4.0, max_depth=200.0, lut=lut)
+    assert r.evaluateDSI((x_nan, y_nan, ts), rig["trajectories"][0], rig["T_rv_w"])
+    assert_dsi_close(got[0], r.dsi)
+
+
 def test_evaluate_dsi_packet_counts(ctx):
     """mapper_emvs_stereo.cpp:71-75, :88: 1023 -> false, 1024 -> true with 0 packets,
     1025 -> 1 packet, 2048 -> 1, 2049 -> 2."""
