@@ -514,6 +514,51 @@ def test_baseline_large_grids(ctx, dims):
     m.close()
 
 
+def test_configs4_camera_at_full_size(ctx):
+    """One camera of BASELINE.json configs[4] at FULL size: 100 M events (97,650 packets) into a
+    1024x1024x256 DSI (1 GiB) in one evaluateDSI call.  The oracle cannot follow there (it runs at
+    ~2.5 Mevents/s on this shape), so the check is linearity, a size-independent property of the vote:
+    the DSI of the whole batch equals the sum of the DSIs of its ten packet-aligned tenths (each
+    voxel is an exact fixed-point sum rounded once, so the two differ by at most ten roundings), and
+    no plane holds more votes than there are events."""
+    nx = ny = 1024
+    nz, parts = 256, 10
+    rig = syn.stereo_rig(10_000_000, width=nx, height=ny, t0=10.0, duration=0.5, seed=1234)
+    x, y, ts = rig["events"][0]
+    first, Rt = d.packetize(ts, rig["trajectories"][0], rig["T_rv_w"])
+    n_packets = first.shape[0]
+    assert np.array_equal(first, np.arange(n_packets, dtype=np.uint32) * 1024)
+    n = n_packets * 1024
+    x, y = x[:n], y[:n]
+    parts_Rt = []
+    for i in range(parts):       # the same pixels seen from a rig that has moved on: ten different tenths
+        r = Rt.copy()
+        r[:, 9] += 0.02 * i
+        r[:, 11] += 0.01 * i
+        parts_Rt.append(r)
+    m = d.MapperEMVS(ctx, rig["cam"], d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0))
+    acc = d.Grid3D(ctx, nx, ny, nz)
+    acc.resetGrid()
+    for i in range(parts):
+        b = d.EventBatch(ctx, x, y, parts_Rt[i])
+        m.evaluateDSI_batch(b)
+        acc.addTwoGrids(m.dsi_)
+        ctx.synchronize()
+        b.close()
+    full = d.EventBatch(ctx, np.tile(x, parts), np.tile(y, parts), np.concatenate(parts_Rt))
+    m.evaluateDSI_batch(full)
+    info = m.last_vote_info()
+    assert info["n_packets"] * 1024 == n * parts == 99_993_600 and info["algo"] == d.VOTE_LDS_BANDS
+    whole = m.dsi_.download()
+    summed = acc.download()
+    sums = whole.reshape(nz, -1).sum(axis=1, dtype=np.float64)
+    assert (sums <= n * parts + 64).all() and sums.max() > 0.9 * n * parts
+    err = np.abs(whole.astype(np.float64) - summed) / np.maximum(1.0, np.abs(summed))
+    assert err.max() < 2e-6, err.max()
+    for o in (full, acc, m):
+        o.close()
+
+
 def test_fuse_into_equals_reference_sequence(ctx):
     """dsi_grid_fuse2_into == resetGrid + addTwoGrids + <op>TwoGrids (process1.cpp:126-158)."""
     rng = np.random.default_rng(12)
