@@ -1232,16 +1232,16 @@ __device__ __forceinline__ void vfill_stream(const EvRec* __restrict__ sxy,
     "v_mul_f32 v38, v62, v61\n\t"                                                                   \
     "v_mul_f32 v39, v60, v61\n\t"                                                                   \
     "v_cvt_u32_f32 v36, v36\n\t"                                                                    \
-    "v_cvt_u32_f32 v37, v37\n\t"                                                                    \
-    "v_cvt_u32_f32 v38, v38\n\t"                                                                    \
-    "v_cvt_u32_f32 v39, v39\n\t"                                                                    \
-    "v_add_u32 v58, %9, v59\n\t"          /* next row */                                            \
     "v_mad_u64_u32 v[62:63], vcc, v36, " EM ", 0\n\t"                                               \
     "ds_add_u64 v59, v[62:63]\n\t"                                                                  \
+    "v_cvt_u32_f32 v37, v37\n\t"                                                                    \
     "v_mad_u64_u32 v[60:61], vcc, v37, " EM ", 0\n\t"                                               \
     "ds_add_u64 v59, v[60:61] offset:8\n\t"                                                         \
+    "v_add_u32 v58, %9, v59\n\t"          /* next row */                                            \
+    "v_cvt_u32_f32 v38, v38\n\t"                                                                    \
     "v_mad_u64_u32 v[62:63], vcc, v38, " EM ", 0\n\t"                                               \
     "ds_add_u64 v58, v[62:63]\n\t"                                                                  \
+    "v_cvt_u32_f32 v39, v39\n\t"                                                                    \
     "v_mad_u64_u32 v[60:61], vcc, v39, " EM ", 0\n\t"                                               \
     "ds_add_u64 v58, v[60:61] offset:8\n\t"                                                         \
     "s_mov_b64 exec, -1\n\t"
