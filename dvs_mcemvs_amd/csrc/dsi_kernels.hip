@@ -1533,14 +1533,25 @@ __device__ __forceinline__ void vfill_stream_asm(const EvRec* __restrict__ sxy,
                                                  unsigned long long* __restrict__ scratch,
                                                  int p_first, int p_end, int lg_pass, int stride,
                                                  int lane, int nx, int Li, int Ui, int row_base,
-                                                 uint32_t dummy_eo, int variant, int p_begin_of_wg)
+                                                 uint32_t dummy_eo, int variant, int p_begin_of_wg,
+                                                 int* __restrict__ pass_counter)
 {
     if (Ui - 1 < Li) return;  // the band accepts no row (the unsigned range test needs Ui-1-Li >= 0)
     const int pass = 1 << lg_pass;
     const int p_begin = p_begin_of_wg;
     const int npass = (p_end - p_begin + pass - 1) / pass;
     const int j0 = (p_first - p_begin) / pass;       // this wave's first pass
-    const int jstep = stride / pass;                 // waves of the workgroup
+    (void)stride;
+    // Passes are DEALT, not pre-assigned: wave w starts with pass w and draws every further one from a
+    // counter in LDS (set to the number of waves by the item's set-up).  A pass holds 64 packets'
+    // records of this band and plane -- anything from a few hundred to a few thousand slots -- and an
+    // item has only ~2-10 passes per wave, so with fixed assignments the workgroup waited for its
+    // unluckiest wave.  (The sums are integer: which wave votes a pass does not change a bit.)
+    auto draw = [&]() {
+        int v = 0;
+        if (lane == 0) v = atomicAdd(pass_counter, 1);
+        return __builtin_amdgcn_readfirstlane(v);
+    };
     // lane l = packet l of pass j.  (Tried: interleaved passes -- lane l = packet p_begin + l * npass + j,
     // so that the 3-4 packets a batch mixes are far apart in time and a scene point's votes do not meet in
     // one wave instruction: -1 % ... +3 %, not adopted.  Tried: the ds_bpermute look-ups issued a further
@@ -1548,12 +1559,13 @@ __device__ __forceinline__ void vfill_stream_asm(const EvRec* __restrict__ sxy,
     auto packet_of = [&](int j) { return p_begin + j * pass + lane; };
     uint32_t cu_next = 0;
     if (j0 < npass && lane < pass && packet_of(j0) < p_end) cu_next = cutz[packet_of(j0)];
-    for (int j = j0; j < npass; j += jstep) {
+    for (int j = j0, jn; j < npass; j = jn) {
         const int p = packet_of(j);
         const uint32_t cu = cu_next;
-        // the next pass's cut words travel while this pass is voted
+        // the next pass is drawn now and its cut words travel while this pass is voted
+        jn = draw();
         cu_next = 0;
-        if (j + jstep < npass && lane < pass && packet_of(j + jstep) < p_end) cu_next = cutz[packet_of(j + jstep)];
+        if (jn < npass && lane < pass && packet_of(jn) < p_end) cu_next = cutz[packet_of(jn)];
         const int lo = (int)(cu & 0xffffu), hi = (int)(cu >> 16);
         const int len = max(hi - lo, 0);
         const int incl = wave_incl_scan(len, lane);
@@ -1768,6 +1780,7 @@ __device__ __forceinline__ void vote_bands_packed_body(const EvRec* __restrict__
 {
     extern __shared__ acc_t band[];
     __shared__ int s_item;
+    __shared__ int s_pass;  // mapping 5: the next pass of the item to hand out (vfill_stream_asm)
     const int pairs = bp.chunks * bp.bands;
     const int full = (pairs / 8) * 8 * g.nz;
     const int total = pairs * g.nz;
@@ -1786,7 +1799,10 @@ __device__ __forceinline__ void vote_bands_packed_body(const EvRec* __restrict__
     }
     for (;;) {
     if (work_counters) {
-        if (threadIdx.x == 0) s_item = (int)atomicAdd(&work_counters[cls], 1u) * 8 + cls;
+        if (threadIdx.x == 0) {
+            s_item = (int)atomicAdd(&work_counters[cls], 1u) * 8 + cls;
+            s_pass = BLOCK / kWave;
+        }
         __syncthreads();  // also: the previous item's flush has cleared the band
     }
     const int b = work_counters ? s_item : (int)blockIdx.x;
@@ -1807,6 +1823,7 @@ __device__ __forceinline__ void vote_bands_packed_body(const EvRec* __restrict__
     const int cells = (r1 - r0 + 1) * nx;  // owned rows + the carry row
     if (!work_counters) {
         for (int i = threadIdx.x; i < cells; i += BLOCK) band[i] = 0;
+        if (threadIdx.x == 0) s_pass = BLOCK / kWave;
         __syncthreads();
     }
 
@@ -1851,7 +1868,7 @@ __device__ __forceinline__ void vote_bands_packed_body(const EvRec* __restrict__
                                 kWaves * pass, lane, nx, Li, Ui, r0, dummy_eo);
         else
             vfill_stream_asm(sxy, coef4, cutz, band_bytes, scratch, p_begin + wave * pass, p_end, lg_pass,
-                             kWaves * pass, lane, nx, Li, Ui, r0, dummy_eo, bp.experiment, p_begin);
+                             kWaves * pass, lane, nx, Li, Ui, r0, dummy_eo, bp.experiment, p_begin, &s_pass);
     } else {
         // MAPPING 3 is the compiled stream on the fast path too (A/B testing)
         if (slow_any[z] != 0)
