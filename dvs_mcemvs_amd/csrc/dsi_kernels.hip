@@ -1171,16 +1171,25 @@ __device__ __forceinline__ void vfill_stream(const EvRec* __restrict__ sxy,
     "s_add_i32 s40, s43, s45\n\t"                                                                   \
     "s_add_i32 s41, s43, s46\n\t"                                                                   \
     "s_branch Ltop" L "%=\n"                                                                        \
-    "Lreload" L "%=:\n\t"                 /* first packet of a pass: load the pass's cut words */   \
-    "s_lshr_b32 s45, s42, %7\n\t"                                                                   \
-    "s_mul_i32 s45, s45, %6\n\t"                                                                    \
-    "s_add_i32 s45, s45, %5\n\t"          /* first packet of the pass */                            \
+    "Lreload" L "%=:\n\t"                 /* first packet of a pass: its cut words were prefetched */ \
+    "s_lshr_b32 s45, s42, %7\n\t"         /* into v35 one pass ago (loads return in order: once a    */ \
+    "s_mul_i32 s45, s45, %6\n\t"          /* GATHER has been issued since, all but the 3 newest      */ \
+    "s_add_i32 s45, s45, %5\n\t"          /* loads include them; first packet of the pass:)          */ \
     "s_lshl_b32 s43, s45, 10\n\t"                                                                   \
+    "s_cmp_eq_u32 s50, 0\n\t"                                                                       \
+    "s_cbranch_scc1 Lwall" L "%=\n\t"                                                               \
+    "s_waitcnt vmcnt(3)\n\t"                                                                        \
+    "s_branch Lgot" L "%=\n"                                                                        \
+    "Lwall" L "%=:\n\t"                                                                             \
+    "s_waitcnt vmcnt(0)\n"                                                                          \
+    "Lgot" L "%=:\n\t"                                                                              \
+    "v_mov_b32 v41, v35\n\t"                                                                        \
+    "s_add_i32 s45, s45, %6\n\t"          /* the next pass's cut words travel during this pass */   \
     "v_add_u32 v58, s45, %15\n\t"                                                                   \
     "v_min_i32 v58, %8, v58\n\t"                                                                    \
     "v_lshlrev_b32 v58, 2, v58\n\t"                                                                 \
-    "global_load_dword v41, v58, %2\n\t"                                                            \
-    "s_waitcnt vmcnt(0)\n\t"                                                                        \
+    "global_load_dword v35, v58, %2\n\t"                                                            \
+    "s_mov_b32 s50, 0\n\t"                                                                          \
     "v_readfirstlane_b32 s46, v41\n\t"                                                              \
     "s_branch Lhave" L "%=\n"                                                                       \
     "Leos" L "%=:\n\t"                    /* stream over: unreached lanes -> multiplicity-0 record */ \
@@ -1198,7 +1207,8 @@ __device__ __forceinline__ void vfill_stream(const EvRec* __restrict__ sxy,
     "v_and_b32 v59, 0x7ffffe0, v59\n\t"   /* byte offset of the packet's coefficients */            \
     "global_load_dwordx3 " EV ", v58, %0\n\t"                                                       \
     "global_load_dwordx4 " CA ", v59, %1\n\t"                                                       \
-    "global_load_dword " CR ", v59, %1 offset:16\n\t"
+    "global_load_dword " CR ", v59, %1 offset:16\n\t"                                               \
+    "s_mov_b32 s50, 1\n\t"              /* (three loads behind the cut-word prefetch) */
 
 #define DSI_ASM_VOTE(EX, EY, EM, KA, KBX, KBY, KD, KR)                                             \
     "v_mul_f32 v58, " EX ", " KA "\n\t"                                                             \
@@ -1282,6 +1292,12 @@ __device__ __forceinline__ void packed_stream_asm(const EvRec* sxy, const uint4*
         "s_mov_b32 s43, 0\n\t"
         "v_mov_b32 v40, 0\n\t"
         "v_mov_b32 v41, 0\n\t"
+        "s_mov_b32 s50, 0\n\t"
+        "v_add_u32 v58, %5, %15\n\t"        // the first pass's cut words
+        "v_min_i32 v58, %8, v58\n\t"
+        "v_max_i32 v58, 0, v58\n\t"          // (a chunk without packets has p_end - 1 = -1)
+        "v_lshlrev_b32 v58, 2, v58\n\t"
+        "global_load_dword v35, v58, %2\n\t"
         DSI_ASM_FILL("s47", "a")
         DSI_ASM_GATHER("v[42:44]", "v[46:49]", "v45")
         "s_cmp_eq_u32 s47, 0\n\t"
@@ -1305,8 +1321,8 @@ __device__ __forceinline__ void packed_stream_asm(const EvRec* sxy, const uint4*
         : "s"(sxy), "s"(coef4), "s"(cutz), "s"(s_n_my), "s"(s_gmask), "s"(s_p_first), "s"(s_stride),
           "s"(s_lg), "s"(s_p_last), "s"(s_nx8), "s"(s_cbase), "s"(s_nxm2), "s"(s_Li), "s"(s_Uim1),
           "s"(s_dummy), "v"(lane)
-        : "memory", "scc", "vcc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48",
-          "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48",
+        : "memory", "scc", "vcc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s50",
+          "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48",
           "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61",
           "v62", "v63");
 }
