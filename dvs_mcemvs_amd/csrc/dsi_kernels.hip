@@ -1850,10 +1850,12 @@ __device__ __forceinline__ void vote_bands_packed_body(const EvRec* __restrict__
     const int Li = r0, Ui = min(r1, g.ny - 1);
     // packets a wave takes per pass:
     constexpr int kWaves = BLOCK / kWave;
-    // as many as possible (fewer reloads of cut words), but every wave should get >= 4 passes so
-    // that the waves of the workgroup finish together (measured: 2 % at 346x260, 6 % at 512x512)
+    // as many as possible (fewer pass boundaries), but every wave should get >= 3 passes so that the
+    // waves of the workgroup finish together (measured: 2 % at 346x260, 6 % at 512x512 against one
+    // pass per wave; 512x512x200, 489 packets: passes of 16 / 8 / 4 / 2 packets 0.224 / 0.216 / 0.219 /
+    // 0.232 ms)
     int lg_group = 6;
-    while (lg_group > 2 && (p_end - p_begin) < ((kWaves * 4) << lg_group)) --lg_group;
+    while (lg_group > 2 && (p_end - p_begin) < ((kWaves * 3) << lg_group)) --lg_group;
     if (bp.pass_lg > 0) lg_group = bp.pass_lg;
     const int group = 1 << lg_group;
     const uint4* __restrict__ coef4 = reinterpret_cast<const uint4*>(coef) + 2 * (size_t)z * np;
