@@ -253,15 +253,29 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
     const dsi::Geom& g = m->geom;
     const size_t row_bytes = (size_t)g.nx * sizeof(unsigned long long);  // Q33.31 LDS accumulators
     const int block_threads = m->want_block > 0 ? m->want_block : 1024;
-    // Lane mapping: the packed mapping with the hand-scheduled scalar run bookkeeping (1) is the
-    // default (measured 1.1x (240x180) to 3x faster than the per-packet mapping 0); when a band sees
-    // fewer than ~32 records of a packet (wide grids: 19 at 1024x1024) the scalar bookkeeping per run
-    // dominates and the vector fill (5) takes over (measured at 1024x1024x256, 10 M events:
-    // 7.6 -> 4.9 ms; at 512x512x200 and 640x480x100 mapping 1 still wins).
+    // Lane mapping and workgroups per CU, by the records of a packet a band sees (its run):
+    // rows + 1 of Ny rows see 1024 * (rows + 1) / Ny events of a packet.
+    //  * TWO 1024-thread workgroups per CU (32 waves; half the LDS each) with the packed mapping and its
+    //    hand-scheduled scalar run bookkeeping (1) when half the LDS still gives runs of >= ~56
+    //    records (346x260x100: 106; measured against one workgroup per CU with either mapping, 10 M
+    //    events: 480x360x100 (57) 1.33 vs 1.44 / 1.48 ms, 400x300x64 (85) 0.89 vs 0.91 / 0.96);
+    //  * else ONE workgroup per CU; the scalar bookkeeping per run piece then dominates when the run
+    //    is short and the vector fill (5) takes over below ~72 records (mapping 1 / mapping 5:
+    //    1024x1024x256 (20) 7.6 / 4.25 ms, 800x600x128 (42) 2.43 / 1.84, 720x540x100 (53) 1.68 / 1.48,
+    //    640x480x100 (68) 1.55 / 1.43, 512x512x200 (78) 2.81 / 2.63 at 10 M events but 0.216 / 0.222
+    //    at a 0.5 M-event window and 0.379 / 0.380 at 1 M).
+    // (The packed mapping is 1.1x (240x180) to 3x faster than the per-packet mapping 0.)
     int packed = m->want_packed;
+    bool auto_two_per_cu = false;
     if (packed < 0) {
         const long rows_full = std::max<long>(1, (long)(dsi::max_dynamic_lds() / row_bytes) - 1);
-        packed = 1024L * (rows_full + 1) / g.ny < 32 ? 5 : 1;
+        const long rows_half = (long)((dsi::max_dynamic_lds() / 2) / row_bytes) - 1;
+        if (rows_half >= 4 && 1024L * (rows_half + 1) / g.ny >= 56) {
+            packed = 1;
+            auto_two_per_cu = true;
+        } else {
+            packed = 1024L * (rows_full + 1) / g.ny < 72 ? 5 : 1;
+        }
     }
     // lane mapping 5 keeps 64 tail-bit words per wave behind the band
     const size_t scratch_bytes = (packed == 5 || packed == 6) ? (size_t)(block_threads / 64) * dsi::kVfillScratchWords * 8 : 0;
@@ -271,11 +285,9 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
     if (m->want_band_rows > 0) {
         max_owned = std::min<long>(max_owned, m->want_band_rows);
     } else {
-        // Two 1024-thread workgroups per CU (32 waves) hide latency better than one, if half the
-        // LDS still gives runs of >= ~96 events per (packet, band): rows+1 of Ny rows see
-        // 1024*(rows+1)/Ny events of a packet.
+        // two workgroups per CU (above; a mapping forced by the caller keeps the older, stricter rule)
         const long half_rows = (long)((dsi::max_dynamic_lds() / 2 - scratch_bytes) / row_bytes) - 1;
-        if (half_rows >= 4 && 1024L * (half_rows + 1) / g.ny >= 96) max_owned = half_rows;
+        if (half_rows >= 4 && (auto_two_per_cu || 1024L * (half_rows + 1) / g.ny >= 96)) max_owned = half_rows;
     }
     int bands = (int)((g.ny + max_owned - 1) / max_owned);
     int band_rows = (g.ny + bands - 1) / bands;  // balanced
@@ -333,7 +345,13 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
         int step = 8;
         for (int f = 2; f <= 8; f *= 2)
             if (bands % f == 0) step = 8 / f;
-        if (chunks > 1) chunks = ((chunks + step - 1) / step) * step;  // whole groups of 8 pairs
+        if (chunks > 1) {  // whole groups of 8 pairs -- unless that multiplies the partial volumes (an odd
+                           // number of bands would turn 2 chunks into 8: 640x480x100 with 17 bands paid
+                           // 0.3 ms per step for it); the pairs beyond the last whole group are dealt plane
+                           // by plane over all XCDs anyway
+            const int rounded = ((chunks + step - 1) / step) * step;
+            if (rounded <= chunks + chunks / 2 + 1) chunks = rounded;
+        }
         chunks = (int)std::min<size_t>((size_t)chunks, std::max<size_t>(1, n_packets));
         const size_t vol_bytes = (size_t)g.nx * g.ny * g.nz * sizeof(float);
         const size_t budget = (size_t)16 << 30;  // partial DSIs may use up to 16 GiB of HBM
