@@ -65,7 +65,7 @@ def parse():
                     help="skip the host-fed (PCIe-inclusive) measurements and the 512x512x200 stream-kernel timings "
                          "(profiling runs: only the timed steps launch kernels)")
     ap.add_argument("--materialize-fused", action="store_true",
-                    help="windows: also write the fused DSI (mapper_fused.dsi_) per window instead of fusing the "
+                    help="windows / cameras4: also write the fused DSI (mapper_fused.dsi_) instead of fusing the "
                          "cameras inside the arg-max kernel")
     ap.add_argument("--collective", choices=["engine", "torch"], default="engine",
                     help="N > 1: who issues the all-reduce: the engine's own RCCL communicator (C ABI) or "
@@ -482,6 +482,10 @@ def main():
         def step():
             for c in range(4):
                 mappers[c].evaluateDSI_batch(batches[c])
+            if comm is None and not args.materialize_fused:
+                # n-ary GM inside the arg-max kernel: same bits, the fused volume is never written
+                mappers[0].computeDepthMapOfFusionN([m.dsi_ for m in mappers], d.ACC_LOG_SUM)
+                return
             fused.setToFusionOfN([m.dsi_ for m in mappers], d.ACC_LOG_SUM)     # n-ary GM, voxel-wise, local
             if comm is None:
                 mappers[0].computeDepthMap(fused)
@@ -494,7 +498,9 @@ def main():
         # every rank votes ALL events into its plane range: the job's events are counted once
         voted_per_step = voted if rank == 0 else 0.0
         workload = ("4-camera synthetic rig, %d events/cam, %dx%dx%d DSI, n-ary geometric-mean camera fusion + arg-max%s"
-                    % (args.events, nx, ny, nz, "" if world == 1 else ", planes sharded over %d GPUs" % world))
+                    % (args.events, nx, ny, nz,
+                       (" (fused DSI written)" if args.materialize_fused else " in one kernel (fused DSI not written)")
+                       if world == 1 else ", planes sharded over %d GPUs" % world))
         parallelism, scaling = ("1 GPU" if world == 1 else "plane-shard x%d" % world), "strong"
         ev_per_launch = voted / 4.0
     t_gen = time.time() - t_gen

@@ -1351,6 +1351,32 @@ int dsi_mapper_depth_map_of_fusion(dsi_mapper_t* m, const dsi_grid_t* a, const d
     return depth_buffers_ready(m);
 }
 
+int dsi_mapper_depth_map_of_fusion_n(dsi_mapper_t* m, const dsi_grid_t* const* srcs, int n, int mode)
+{
+    REQUIRE(m && srcs, DSI_ERR_INVALID, "null argument");
+    REQUIRE(valid_acc_mode(mode), DSI_ERR_BAD_OP, "bad accumulate mode %d", mode);
+    REQUIRE(n >= 1 && n <= 8, DSI_ERR_INVALID, "1 <= n <= 8 sources (got %d)", n);
+    const float* ptrs[8];
+    for (int i = 0; i < n; ++i) {
+        REQUIRE(srcs[i], DSI_ERR_INVALID, "source %d is null", i);
+        REQUIRE(m->ctx->device == srcs[i]->ctx->device, DSI_ERR_CONTEXT, "mapper and grids live on different devices");
+        REQUIRE(same_shape(m->grid, srcs[i]), DSI_ERR_SHAPE, "grid shape differs from the mapper's DSI");
+        ptrs[i] = srcs[i]->data;
+    }
+    REQUIRE(m->grid->nz <= 256, DSI_ERR_INVALID, "arg-max indices are u8: dimZ must be <= 256 (got %d)", m->grid->nz);
+    if (int rc = set_device(m->ctx)) return rc;
+    const size_t npix = (size_t)m->grid->nx * m->grid->ny;
+    HIP_TRY(m->conf.reserve(npix));
+    HIP_TRY(m->depth.reserve(npix));
+    HIP_TRY(m->idx.reserve(npix));
+    for (int i = 0; i < n; ++i)
+        if (int rc = dsi_context_wait_for(m->ctx, srcs[i]->ctx)) return rc;
+    if (int rc = depth_buffers_acquire(m)) return rc;
+    HIP_TRY(dsi::launch_collapse_max_z_fused_n(m->ctx->stream, ptrs, n, mode, m->grid->nx, m->grid->ny, m->grid->nz,
+                                               m->conf.p, m->idx.p, m->planes_dev, m->depth.p));
+    return depth_buffers_ready(m);
+}
+
 int dsi_mapper_fetch_depth_map(dsi_mapper_t* m, float* depth_host, float* conf_host, uint8_t* idx_host)
 {
     REQUIRE(m, DSI_ERR_INVALID, "mapper is null");

@@ -119,6 +119,8 @@ hipError_t launch_depth_map_filters(hipStream_t s, float* conf, const uint8_t* i
                                     uint8_t* mask, uint8_t* idx_filtered, float* depth);
 hipError_t launch_collapse_max_z_fused(hipStream_t s, const float* a, const float* b, int nx, int ny, int nz, int op,
                                        float* conf, uint8_t* idx, const float* planes, float* depth);
+hipError_t launch_collapse_max_z_fused_n(hipStream_t s, const float* const* srcs, int n_src, int mode, int nx, int ny,
+                                         int nz, float* conf, uint8_t* idx, const float* planes, float* depth);
 hipError_t launch_mean_square(hipStream_t s, const float* dsi, size_t n, double* accum);
 
 // test hook: q[i] = residual-corrected division, ref[i] = n[i] / d[i]

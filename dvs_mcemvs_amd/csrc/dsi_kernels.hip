@@ -2583,6 +2583,52 @@ __global__ __launch_bounds__(256) void k_collapse_max_z_fused(const float* __res
     if (depth) depth[p] = planes[best_k];
 }
 
+// collapseMaxZSlice of the n-ary fusion of up to 8 volumes (dsi_grid_fuse_n's begin / accumulate x n /
+// finalize per voxel, the same operations in the same order, hence the same bits) without
+// materialising the fused volume: n * 4 B per voxel read, nothing written but the maps.
+template <int ACC, int FIN>
+__global__ __launch_bounds__(256) void k_collapse_max_z_fused_n(FuseSources src, int n_src, int npix, int nz,
+                                                                float identity, float fn,
+                                                                float* __restrict__ conf,
+                                                                uint8_t* __restrict__ idx,
+                                                                const float* __restrict__ planes,
+                                                                float* __restrict__ depth)
+{
+    __shared__ double2 log_tab[ACC == EW_ADD_LOG ? kLogTabSize : 1];
+    if (ACC == EW_ADD_LOG) det_log_table_fill(log_tab);
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    float best = 0.f;
+    int best_k = 0;
+    for (int k = 0; k < nz; k += 2) {
+        // two planes' loads in flight before the arithmetic
+        float v[2][kMaxFuseSources];
+        const int k1 = min(k + 1, nz - 1);
+#pragma unroll
+        for (int c = 0; c < kMaxFuseSources; ++c)
+            if (c < n_src) {
+                v[0][c] = src.p[c][(size_t)k * npix + p];
+                v[1][c] = src.p[c][(size_t)k1 * npix + p];
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (k + u >= nz) break;
+            float acc = identity;
+#pragma unroll
+            for (int c = 0; c < kMaxFuseSources; ++c)
+                if (c < n_src) acc = ew_op<ACC>(acc, v[u][c], 0.f, 0.f, log_tab);
+            if (FIN >= 0) acc = ew_op<(FIN >= 0 ? FIN : 0)>(acc, 0.f, fn, 0.f);
+            if (k + u == 0 || best < acc) {  // std::max_element: the first maximum wins
+                best = acc;
+                best_k = k + u;
+            }
+        }
+    }
+    conf[p] = best;
+    idx[p] = (uint8_t)best_k;
+    if (depth) depth[p] = planes[best_k];
+}
+
 // cartesian3dgrid.cpp:164-174: sum of squares in double (order differs from the
 // sequential loop; relative difference ~1e-16 * log n)
 __global__ __launch_bounds__(256) void k_mean_square(const float* __restrict__ dsi, size_t n,
@@ -3159,6 +3205,28 @@ hipError_t launch_collapse_max_z_fused(hipStream_t s, const float* a, const floa
     case 4: hipLaunchKernelGGL(k_collapse_max_z_fused<4>, grid, block, 0, s, a, b, npix, nz, conf, idx, planes, depth); break;
     case 5: hipLaunchKernelGGL(k_collapse_max_z_fused<5>, grid, block, 0, s, a, b, npix, nz, conf, idx, planes, depth); break;
     case 6: hipLaunchKernelGGL(k_collapse_max_z_fused<6>, grid, block, 0, s, a, b, npix, nz, conf, idx, planes, depth); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipExtGetLastError();
+}
+
+hipError_t launch_collapse_max_z_fused_n(hipStream_t s, const float* const* srcs, int n_src, int mode, int nx, int ny,
+                                         int nz, float* conf, uint8_t* idx, const float* planes, float* depth)
+{
+    if (n_src < 1 || n_src > kMaxFuseSources) return hipErrorInvalidValue;
+    FuseSources fs{};
+    for (int c = 0; c < n_src; ++c) fs.p[c] = srcs[c];
+    const int npix = nx * ny;
+    const dim3 grid((npix + 255) / 256), block(256);
+    const float fn = (float)n_src;
+    const float inf = __builtin_inff();
+    switch (mode) {
+    case 0: hipLaunchKernelGGL((k_collapse_max_z_fused_n<EW_ADD, EW_FIN_AM>), grid, block, 0, s, fs, n_src, npix, nz, 0.f, fn, conf, idx, planes, depth); break;
+    case 1: hipLaunchKernelGGL((k_collapse_max_z_fused_n<EW_ADD_INV, EW_FIN_HM>), grid, block, 0, s, fs, n_src, npix, nz, 0.f, fn, conf, idx, planes, depth); break;
+    case 2: hipLaunchKernelGGL((k_collapse_max_z_fused_n<EW_ADD_LOG, EW_FIN_GM>), grid, block, 0, s, fs, n_src, npix, nz, 0.f, fn, conf, idx, planes, depth); break;
+    case 3: hipLaunchKernelGGL((k_collapse_max_z_fused_n<EW_ADD_SQ, EW_FIN_RMS>), grid, block, 0, s, fs, n_src, npix, nz, 0.f, fn, conf, idx, planes, depth); break;
+    case 4: hipLaunchKernelGGL((k_collapse_max_z_fused_n<EW_MIN, -1>), grid, block, 0, s, fs, n_src, npix, nz, inf, fn, conf, idx, planes, depth); break;
+    case 5: hipLaunchKernelGGL((k_collapse_max_z_fused_n<EW_MAX, -1>), grid, block, 0, s, fs, n_src, npix, nz, -inf, fn, conf, idx, planes, depth); break;
     default: return hipErrorInvalidValue;
     }
     return hipExtGetLastError();

@@ -140,6 +140,7 @@ def load_library():
         "dsi_mapper_depth_map_of": (C.c_int, [vp, vp]),
         "dsi_mapper_fetch_depth_map": (C.c_int, [vp, f32p, f32p, u8p]),
         "dsi_mapper_depth_map_of_fusion": (C.c_int, [vp, vp, vp, C.c_int]),
+        "dsi_mapper_depth_map_of_fusion_n": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_int]),
         "dsi_mapper_get_depth_map_from_dsi": (C.c_int, [vp, vp, C.POINTER(_DepthMapOptions), f32p, f32p,
                                                        u8p, u8p]),
         "dsi_mapper_last_vote_info": (C.c_int, [vp, C.POINTER(_VoteInfo)]),
@@ -722,6 +723,12 @@ class MapperEMVS:
         """computeDepthMap of op(grid_a, grid_b) without materialising the fused DSI (bit-identical to
         setToFusionOf + computeDepthMap; one pass over the two volumes)."""
         _check(load_library().dsi_mapper_depth_map_of_fusion(self._h, grid_a._h, grid_b._h, int(fusion_method)))
+
+    def computeDepthMapOfFusionN(self, grids, mode):
+        """computeDepthMap of the n-ary fusion of up to 8 grids (mode = ACC_*) without materialising
+        the fused DSI: bit-identical to Grid3D.setToFusionOfN + computeDepthMap."""
+        hs = (C.c_void_p * len(grids))(*[g._h for g in grids])
+        _check(load_library().dsi_mapper_depth_map_of_fusion_n(self._h, hs, len(grids), int(mode)))
 
     def computeDepthMapSharded(self, grid, comm):
         """Plane-sharded arg-max: local collapse of this rank's plane range, ONE all-reduce(MAX) of

@@ -39,7 +39,7 @@ extern "C" {
 #define DSI_API
 #endif
 
-#define DSI_ENGINE_ABI_VERSION 3
+#define DSI_ENGINE_ABI_VERSION 4
 #define DSI_PACKET_SIZE 1024 /* mapper_emvs_stereo.hpp:152 packet_size_ */
 
 typedef enum {
@@ -322,6 +322,10 @@ DSI_API int dsi_mapper_depth_map_of(dsi_mapper_t *m, dsi_grid_t *g);
  * dsi_mapper_depth_map_of(m, fused) gives, bit for bit, in one pass over a and b.  For streams of
  * windows that only keep the depth map (main.cpp:177-302). */
 DSI_API int dsi_mapper_depth_map_of_fusion(dsi_mapper_t *m, const dsi_grid_t *a, const dsi_grid_t *b, int op);
+/* the n-ary form: depth map of dsi_grid_fuse_n(srcs, n, mode) (mode = dsi_acc_mode_t; the n-camera
+ * generalisation of process1.cpp:126-191, SURVEY 8d cfg 5) without materialising the fused DSI --
+ * the same per-voxel operations in the same order, so the same bits as fuse-then-collapse. */
+DSI_API int dsi_mapper_depth_map_of_fusion_n(dsi_mapper_t *m, const dsi_grid_t *const *srcs, int n, int mode);
 DSI_API int dsi_mapper_fetch_depth_map(dsi_mapper_t *m, float *depth_host, float *conf_host, uint8_t *idx_host);
 /* the same without waiting: the copies are queued (on the context's copy stream, behind the arg-max
  * only -- not behind later work of the compute stream); the outputs (page-locked memory from

@@ -341,6 +341,41 @@ def test_nary_fusion_modes_bit_exact(ctx, n_maps):
         o.close()
 
 
+@pytest.mark.parametrize("n_maps", [1, 3, 4, 8])
+def test_depth_map_of_nary_fusion_equals_fuse_then_collapse(ctx, n_maps):
+    """dsi_mapper_depth_map_of_fusion_n (the n-camera fusion inside the arg-max kernel) = setToFusionOfN
+    followed by computeDepthMap, bit for bit, for every accumulate mode -- zeros, ties and an odd
+    number of planes included -- and equal to the oracle's fuse_nary + collapse."""
+    rng = np.random.default_rng(60 + n_maps)
+    nx, ny, nz = 37, 21, 9
+    cam = (nx, ny, 30.0, 30.0, 18.0, 10.0)
+    m = make_mapper(ctx, cam, nz, 1.0, 6.0, d.VOTE_AUTO)
+    maps = []
+    for k in range(n_maps):
+        v = np.rint(rng.gamma(2.0, 2.0, (nz, ny, nx))).astype(np.float32)   # small integers: many ties
+        v.flat[k::7] = 0.0
+        maps.append(v)
+    G = [d.Grid3D(ctx, nx, ny, nz) for _ in range(n_maps)]
+    for g, v in zip(G, maps):
+        g.upload(v)
+    F = d.Grid3D(ctx, nx, ny, nz)
+    for mode in (d.ACC_SUM, d.ACC_INV_SUM, d.ACC_LOG_SUM, d.ACC_SQ_SUM, d.ACC_MIN, d.ACC_MAX):
+        m.computeDepthMapOfFusionN(G, mode)
+        depth, conf, idx = m.fetchDepthMap()
+        F.setToFusionOfN(G, mode)
+        m.computeDepthMap(F)
+        depth2, conf2, idx2 = m.fetchDepthMap()
+        assert np.array_equal(idx, idx2) and np.array_equal(depth, depth2), mode
+        assert np.array_equal(conf.view(np.uint32), conf2.view(np.uint32)), mode
+        if mode != d.ACC_INV_SUM:
+            rconf, ridx = orc.collapse_max_z(orc.fuse_nary(maps, mode))
+            assert np.array_equal(idx, ridx) and np.array_equal(conf, rconf), mode
+    with pytest.raises(d.DsiError):
+        m.computeDepthMapOfFusionN(G, 9)
+    for o in G + [F, m]:
+        o.close()
+
+
 def test_fusion_errors(ctx):
     A, B = d.Grid3D(ctx, 8, 8, 4), d.Grid3D(ctx, 8, 8, 5)
     with pytest.raises(d.DsiError) as e:
