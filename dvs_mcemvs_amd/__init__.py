@@ -27,6 +27,7 @@ from .engine import (  # noqa: F401
     VOTE_AUTO,
     VOTE_GLOBAL_ATOMIC,
     VOTE_LDS_BANDS,
+    VOTE_FUSED_ARGMAX,
     Comm,
     Context,
     DsiError,
@@ -51,5 +52,5 @@ __all__ = [
     "library_path", "load_library", "packetize", "pose_at", "PACKET_SIZE",
     "FUSE_MIN", "FUSE_HM", "FUSE_GM", "FUSE_AM", "FUSE_RMS", "FUSE_MAX", "ACC_SUM", "ACC_INV_SUM", "ACC_LOG_SUM", "ACC_SQ_SUM", "ACC_MIN", "ACC_MAX",
     "REDUCE_SUM", "REDUCE_MIN", "REDUCE_MAX", "acc_reduce_op",
-    "VOTE_AUTO", "VOTE_GLOBAL_ATOMIC", "VOTE_LDS_BANDS",
+    "VOTE_AUTO", "VOTE_GLOBAL_ATOMIC", "VOTE_LDS_BANDS", "VOTE_FUSED_ARGMAX",
 ]

@@ -194,7 +194,7 @@ struct dsi_mapper {
     DevBuf<float> centers, H, partials, Rt_tmp, conf, depth;
     DevBuf<float2> xy;
     DevBuf<dsi::EvRec> sxy;
-    DevBuf<float> carry;  // [chunks][nz][bands][nx]: votes into the row below each band
+    DevBuf<unsigned long long> seam;  // [chunks][nz][bands][2][nx]: 64-bit sums of each band's first row and of the row below it
     DevBuf<uint32_t> nvalid, cuts, gcuts;
     DevBuf<uint8_t> spk;
     DevBuf<uint16_t> rowstart;
@@ -358,6 +358,49 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
         while (chunks > 1 && (size_t)chunks * (vol_bytes + 16) > budget) --chunks;
     }
     bp->chunks = std::max(1, chunks);
+    return true;
+}
+
+// Band decomposition of the fused vote -> camera fusion -> arg-max kernel (k_vote_fuse_argmax): one
+// 1024-thread workgroup per CU, the band as tall as the LDS (and the per-thread register arrays) allow,
+// a halo row on either side of the owned rows instead of a carry row, one chunk.
+bool plan_fused(const dsi_mapper* m, size_t n_packets_max, dsi::BandPlan* bp)
+{
+    const dsi::Geom& g = m->geom;
+    const size_t row_bytes = (size_t)g.nx * sizeof(unsigned long long);
+    if (g.nx < 2 || g.ny < 2 || g.ny > 16000 || g.nz > 256) return false;
+    int packed = m->want_packed;
+    if (!(packed == 1 || packed == 3 || packed == 5 || packed == 6)) {
+        // the rule of plan_bands for one workgroup per CU: vector fill below ~72 records per (packet, band)
+        const long rows_full = (long)std::min(dsi::max_dynamic_lds() / row_bytes, dsi::fused_max_cells(1) / (size_t)g.nx);
+        packed = 1024L * rows_full / g.ny < 72 ? 5 : 1;
+    }
+    // the hand-scheduled loops address records with 32-bit byte offsets (see vote_device)
+    if ((n_packets_max + 1) * dsi::kPacket * sizeof(dsi::EvRec) > 0xffffffffull) packed = packed == 1 ? 3 : (packed == 5 ? 6 : packed);
+    const size_t scratch_bytes = (packed == 5 || packed == 6) ? (size_t)(1024 / 64) * dsi::kVfillScratchWords * 8 : 0;
+    const long max_rows_total =
+        (long)std::min((dsi::max_dynamic_lds() - scratch_bytes) / row_bytes, dsi::fused_max_cells(packed) / (size_t)g.nx);
+    if (max_rows_total < 3) return false;
+    long max_owned = max_rows_total - 2;  // + the two halo rows
+    if (m->want_band_rows > 0) max_owned = std::min<long>(max_owned, m->want_band_rows);
+    int bands = (int)((g.ny + max_owned - 1) / max_owned);
+    int band_rows = (g.ny + bands - 1) / bands;  // balanced
+    if (m->want_band_rows > 0) band_rows = (int)max_owned;
+    bands = (g.ny + band_rows - 1) / band_rows;
+    *bp = dsi::BandPlan{};
+    bp->bands = bands;
+    bp->band_rows = band_rows;
+    bp->chunks = 1;
+    bp->block_threads = 1024;
+    bp->packed = packed;
+    bp->group_packets = 1;
+    bp->row_pad = std::min(g.ny, 4096);
+    bp->pass_lg = 0;
+    bp->scratch_offset = (int)((size_t)(band_rows + 2) * row_bytes);
+    bp->lds_bytes = (size_t)(band_rows + 2) * row_bytes + scratch_bytes;
+    bp->persistent = 0;
+    bp->halo = 1;
+    bp->experiment = 0;
     return true;
 }
 
@@ -539,7 +582,7 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
     HIP_TRY(m->rowstart.reserve(np * (size_t)(geom.ny + 2 * bp.row_pad + 3) + 2));  // (+ slack: k_plane_coef copies 32-bit words)
     HIP_TRY(m->coef.reserve(np * geom.nz + 1));       // + the dummy record's "coefficients"
     HIP_TRY(m->cuts.reserve(np * geom.nz * bp.bands));
-    HIP_TRY(m->carry.reserve((size_t)bp.chunks * geom.nz * bp.bands * geom.nx));
+    HIP_TRY(m->seam.reserve((size_t)bp.chunks * geom.nz * bp.bands * 2 * geom.nx));
     const bool direct = (bp.chunks == 1 && !accumulate);
     if (!direct) HIP_TRY(m->partials.reserve((size_t)bp.chunks * dsi::partial_stride(g->n)));
 
@@ -559,7 +602,7 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
         if (int rc = prep_end(m, ps)) return rc;
         VoteTimer vt(m);
         HIP_TRY(dsi::launch_vote_groups(ctx->stream, m->sxy.p, m->spk.p, m->coef.p, m->gcuts.p, m->nvalid.p + np, (int)np, S, geom,
-                                        bp, direct ? g->data : m->partials.p, m->carry.p));
+                                        bp, direct ? g->data : m->partials.p, m->seam.p));
         vt.stop();
     } else {
     if (raw && !m->keep_z0) {
@@ -576,13 +619,14 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
     if (int rc = prep_end(m, ps)) return rc;
     VoteTimer vt(m);
     HIP_TRY(dsi::launch_vote_bands(ctx->stream, m->sxy.p, m->coef.p, m->cuts.p, m->nvalid.p + np, (int)np, geom, bp,
-                                   direct ? g->data : m->partials.p, m->carry.p));
+                                   direct ? g->data : m->partials.p, m->seam.p));
     vt.stop();
     }
+    // seam rows of every chunk volume from the exact 64-bit sums, then the sum over the chunks
+    HIP_TRY(dsi::launch_seam_rows(ctx->stream, m->seam.p, bp.chunks, geom, bp, direct ? g->data : m->partials.p));
     if (!direct)
         HIP_TRY(dsi::launch_reduce_partials(ctx->stream, m->partials.p, bp.chunks, g->n, g->data,
                                             accumulate ? 1 : 0));
-    HIP_TRY(dsi::launch_add_carry(ctx->stream, m->carry.p, bp.chunks, geom, bp, g->data));
     return vote_done(m);
 }
 
@@ -1033,7 +1077,7 @@ int dsi_mapper_destroy(dsi_mapper_t* m)
     m->depth.release();
     m->xy.release();
     m->sxy.release();
-    m->carry.release();
+    m->seam.release();
     m->nvalid.release();
     m->gcuts.release();
     m->spk.release();
@@ -1375,6 +1419,81 @@ int dsi_mapper_depth_map_of_fusion_n(dsi_mapper_t* m, const dsi_grid_t* const* s
     HIP_TRY(dsi::launch_collapse_max_z_fused_n(m->ctx->stream, ptrs, n, mode, m->grid->nx, m->grid->ny, m->grid->nz,
                                                m->conf.p, m->idx.p, m->planes_dev, m->depth.p));
     return depth_buffers_ready(m);
+}
+
+int dsi_mapper_depth_map_of_events(dsi_mapper_t* out, dsi_mapper_t* const* mappers, const dsi_batch_t* const* batches, int n,
+                                   int op)
+{
+    REQUIRE(out && mappers && batches, DSI_ERR_INVALID, "null argument");
+    REQUIRE(n == 1 || n == 2, DSI_ERR_INVALID, "1 or 2 cameras (got %d)", n);
+    REQUIRE(n == 1 || (op >= 1 && op <= 6), DSI_ERR_BAD_OP, "improper fusion method %d (expected 1..6)", op);
+    dsi_context* ctx = out->ctx;
+    size_t np_max = 0;
+    for (int i = 0; i < n; ++i) {
+        REQUIRE(mappers[i] && batches[i], DSI_ERR_INVALID, "camera %d: null mapper or batch", i);
+        REQUIRE(mappers[i]->ctx == ctx && batches[i]->ctx == ctx, DSI_ERR_CONTEXT,
+                "mappers, batches and the output mapper must share one context");
+        REQUIRE(same_shape(out->grid, mappers[i]->grid), DSI_ERR_SHAPE, "camera %d: DSI shape differs from the output mapper's", i);
+        REQUIRE(i == 0 || mappers[i] != mappers[0], DSI_ERR_INVALID, "the cameras need distinct mappers (their tables are per mapper)");
+        np_max = std::max(np_max, batches[i]->n_packets);
+    }
+    REQUIRE(out->geom.nz <= 256, DSI_ERR_INVALID, "arg-max indices are u8: dimZ must be <= 256 (got %d)", out->geom.nz);
+    if (int rc = set_device(ctx)) return rc;
+    dsi::BandPlan bp{};
+    REQUIRE(plan_fused(mappers[0], np_max, &bp), DSI_ERR_INVALID, "grid rows of %d floats do not fit the fused kernel", out->geom.nx);
+    const dsi::Geom& geom = mappers[0]->geom;
+    hipStream_t st = ctx->stream;
+    dsi::FusedCameras cams{};
+    cams.n = n;
+    for (int i = 0; i < n; ++i) {
+        dsi_mapper* m = mappers[i];
+        const dsi_batch* b = batches[i];
+        const size_t np = b->n_packets;
+        // the per-camera tables of the banded vote, built for bands with halo rows
+        HIP_TRY(m->centers.reserve(std::max<size_t>(np, 1) * 3));
+        HIP_TRY(m->sxy.reserve(np * dsi::kPacket + 1));
+        HIP_TRY(m->nvalid.reserve(np + (size_t)geom.nz + 8));
+        HIP_TRY(m->rowstart.reserve(np * (size_t)(geom.ny + 2 * bp.row_pad + 3) + 2));
+        HIP_TRY(m->coef.reserve(np * geom.nz + 1));
+        HIP_TRY(m->cuts.reserve(std::max<size_t>(np * geom.nz * bp.bands, 64)));
+        if (b->ready) HIP_TRY(hipStreamWaitEvent(st, b->ready, 0));  // uploaded on the copy stream
+        if (np == 0) {
+            // evaluateDSI returns false (mapper_emvs_stereo.cpp:71-75): this camera's DSI is all zero
+            HIP_TRY(hipMemsetAsync(m->nvalid.p, 0, ((size_t)geom.nz + 8) * sizeof(uint32_t), st));
+        } else {
+            HIP_TRY(dsi::launch_sort_packets_raw(st, b->Rt, b->x, b->y, b->first, m->lut_dev, m->sensor_w, m->sensor_h, m->geom,
+                                                 m->centers.p, (int)np, bp.row_pad, m->sxy.p, m->nvalid.p, m->rowstart.p));
+            HIP_TRY(dsi::launch_plane_coef(st, m->centers.p, m->planes_dev, m->rowstart.p, m->nvalid.p, (int)np, m->geom, bp,
+                                           m->coef.p, m->cuts.p));
+        }
+        cams.cam[i] = dsi::FusedCamera{m->sxy.p, m->coef.p, m->cuts.p, m->nvalid.p + np, (int)np};
+        m->info = dsi_vote_info_t{};
+        m->info.algo = DSI_VOTE_FUSED_ARGMAX;
+        m->info.n_packets = np;
+        m->info.bands = bp.bands;
+        m->info.band_rows = bp.band_rows;
+        m->info.chunks = 1;
+        m->info.block_threads = bp.block_threads;
+        m->info.lds_bytes = bp.lds_bytes;
+        m->info.packed = bp.packed;
+        m->info.group_packets = 1;
+    }
+    const size_t npix = (size_t)geom.nx * geom.ny;
+    HIP_TRY(out->conf.reserve(npix));
+    HIP_TRY(out->depth.reserve(npix));
+    HIP_TRY(out->idx.reserve(npix));
+    HIP_TRY(out->argmax_keys.reserve(npix));
+    if (int rc = depth_buffers_acquire(out)) return rc;
+    HIP_TRY(hipMemsetAsync(out->argmax_keys.p, 0, npix * sizeof(unsigned long long), st));
+    {
+        VoteTimer vt(mappers[0]);
+        HIP_TRY(dsi::launch_vote_fuse_argmax(st, cams, geom, bp, op, nullptr, out->argmax_keys.p));
+        vt.stop();
+    }
+    // keys -> confidence, index, depth over the planes the cameras voted (mapper_emvs_stereo.cpp:302-313)
+    HIP_TRY(dsi::launch_unpack_argmax(st, out->argmax_keys.p, (int)npix, mappers[0]->planes_dev, out->conf.p, out->idx.p,
+                                      out->depth.p));
+    return depth_buffers_ready(out);
 }
 
 int dsi_mapper_fetch_depth_map(dsi_mapper_t* m, float* depth_host, float* conf_host, uint8_t* idx_host)

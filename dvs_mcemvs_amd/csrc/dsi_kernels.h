@@ -56,6 +56,8 @@ struct BandPlan {
                         // + mappings 5 / 6: kVfillScratchWords * 8 B per wave (tail-bit words / run table)
     int scratch_offset; // mapping 5: byte offset of that area behind the band
     int persistent;     // packed mappings: workgroups pull work items from per-XCD counters
+    int halo;           // 1: a band also takes the events of the row above its first owned row and keeps a halo row
+                        // on either side in LDS ((band_rows + 2) rows; k_vote_fuse_argmax), 0: carry row ((band_rows + 1))
     int experiment;     // DSI_EXPERIMENT (timing experiments only, results are wrong): 1 no votes, 2 no flush
 };
 
@@ -85,19 +87,40 @@ hipError_t launch_plane_coef(hipStream_t s, const float* centers, const float* p
                              const Geom& g, const BandPlan& bp, PlaneCoef* coef, uint32_t* cuts);
 hipError_t launch_vote_bands(hipStream_t s, const EvRec* sxy, const PlaneCoef* coef,
                              const uint32_t* cuts, const uint32_t* slow_any, int np, const Geom& g,
-                             const BandPlan& bp, float* out, float* carry);
-// adds the bands' carry rows (votes of a band's last row into the next band's first row) to the volume
-hipError_t launch_add_carry(hipStream_t s, const float* carry, int chunks, const Geom& g,
-                            const BandPlan& bp, float* dsi);
+                             const BandPlan& bp, float* out, unsigned long long* seam);
+// seam rows (first row of every band but the first, of every plane of every chunk volume in `out`) =
+// fl((head + carry) * 2^-31) from the voting kernel's 64-bit sums seam[chunks][nz][bands][2][nx]
+hipError_t launch_seam_rows(hipStream_t s, const unsigned long long* seam, int chunks, const Geom& g,
+                            const BandPlan& bp, float* out);
 hipError_t launch_sort_groups(hipStream_t s, const float2* xy, int np, int S, int ny, int nz, int pad,
                               EvRec* sxy, uint8_t* spk, uint32_t* nvalid, uint16_t* rowstart);
 hipError_t launch_group_cuts(hipStream_t s, const uint32_t* prow, const uint16_t* rowstart, int np,
                              int S, const Geom& g, const BandPlan& bp, uint32_t* gcuts);
 hipError_t launch_vote_groups(hipStream_t s, const EvRec* sxy, const uint8_t* spk,
                               const PlaneCoef* coef, const uint32_t* gcuts, const uint32_t* slow_any,
-                              int np, int S, const Geom& g, const BandPlan& bp, float* out, float* carry);
+                              int np, int S, const Geom& g, const BandPlan& bp, float* out, unsigned long long* seam);
 hipError_t launch_reduce_partials(hipStream_t s, const float* partials, int chunks, size_t n,
                                   float* dsi, int accumulate);
+// ---- stage B fused with the camera fusion and the arg-max (no DSI leaves the CU) ----
+// the per-camera tables of the banded vote (k_sort_packets / k_plane_coef outputs, built with bp.halo = 1)
+struct FusedCamera {
+    const EvRec* sxy;
+    const PlaneCoef* coef;
+    const uint32_t* cuts;
+    const uint32_t* slow_any;
+    int np;
+};
+struct FusedCameras {
+    FusedCamera cam[2];
+    int n;  // 1 (vote -> arg-max) or 2 (vote x 2 -> op -> arg-max)
+};
+// keys[ny * nx] (zeroed by the caller) receive max over planes of conf_bits << 8 | 255 - plane: feed
+// launch_unpack_argmax.  splits: optional balanced partition of the (band-major) pair list, one entry
+// per workgroup + 1 (fused_grid_blocks() workgroups)
+int fused_grid_blocks();
+size_t fused_max_cells(int mapping);  // (band_rows + 2) * nx may not exceed this
+hipError_t launch_vote_fuse_argmax(hipStream_t s, const FusedCameras& cams, const Geom& g, const BandPlan& bp, int op,
+                                   const uint32_t* splits, unsigned long long* keys);
 // ---- Grid3D ops ------------------------------------------------------------
 hipError_t launch_fuse2(hipStream_t s, float* a, const float* g, size_t n, int op);
 hipError_t launch_fuse2_into(hipStream_t s, float* dst, const float* a, const float* g, size_t n,

@@ -504,7 +504,8 @@ __global__ __launch_bounds__(1024) void k_plane_coef(const float* __restrict__ c
                 const int r0 = j * bp.band_rows;
                 const int r1 = min(g.ny, r0 + bp.band_rows);
                 // accepted iff 0 <= Y < ny-1; the band needs floor(Y) in [r0, r1-1]
-                const float L = (float)r0 - 0.01f, U = (float)min(r1, g.ny - 1) + 0.01f;
+                // (bp.halo: the fused kernel's bands also take the events of the row above their first)
+                const float L = (float)(r0 - bp.halo) - 0.01f, U = (float)min(r1, g.ny - 1) + 0.01f;
                 const float ya = L * d_a - by_a, yb = U * d_a - by_a;
                 float ymin = fminf(ya, yb), ymax = fmaxf(ya, yb);
                 if (ya == ya && yb == yb) {  // not NaN
@@ -558,6 +559,9 @@ __global__ __launch_bounds__(1024) void k_plane_coef(const float* __restrict__ c
 // independent of vote order, and is rounded to fp32 once at write-back.  (The CPU reference
 // rounds after every += instead.)
 using acc_t = unsigned long long;
+// k_vote_fuse_argmax keeps two fp32 values and a plane index per band cell in registers: 1024-cell stretches per
+// thread.  20 cover the whole LDS (160 KB of 8-byte cells); the vector-fill mappings leave fewer registers: 16.
+__host__ __device__ constexpr int fused_cells_per_thread(int mapping) { return (mapping == 5 || mapping == 6) ? 16 : 20; }
 constexpr float kFixScale = 2147483648.f;      // 2^31
 constexpr double kFixInv = 1.0 / 2147483648.0;  // 2^-31
 
@@ -576,44 +580,52 @@ __device__ __forceinline__ void vote4(acc_t* __restrict__ band, int idx, int nx,
     __hip_atomic_fetch_add(cell + nx + 1, (acc_t)(unsigned int)(fxs * fy) * m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// owned rows of the band -> fp32 volume (a linear, coalesced copy); the row below the band (votes
-// of this band's last row into the next band's first row) -> the carry buffer, added to the
-// volume afterwards by k_add_carry.  A band therefore processes exactly the events with
-// floor(Y) in its OWNED rows: no event is processed by two bands.
-template <int BLOCK>
-__device__ __forceinline__ void flush_band(const acc_t* __restrict__ band, int nx, int n_out,
-                                           float* __restrict__ dst, float* __restrict__ carry_dst)
+// owned rows of the band -> fp32 volume (a linear, coalesced copy).  A vote of an event in the band's
+// last owned row also lands in the row below, which is the next band's first row: that "carry" row,
+// and the next band's own sums for its first row (its "head"), leave the CU as the raw 64-bit
+// fixed-point sums -- seam[c][z][j][0][x] = head of band j (j >= 1), seam[c][z][j][1][x] = carry of
+// band j (j < bands - 1) -- and k_seam_rows writes fl((head + carry) * 2^-31) into the volume: ONE
+// rounding of the exact sum, like every other voxel.  The DSI therefore does not depend on the band
+// decomposition (round 2 added fl(carry) to fl(head) in fp32: two roundings on seam rows).  A band
+// processes exactly the events with floor(Y) in its OWNED rows: no event is processed by two bands.
+__device__ __forceinline__ acc_t* seam_rows(acc_t* seam, int c, int z, int j, const Geom& g, const BandPlan& bp)
 {
-    for (int i = threadIdx.x; i < n_out; i += BLOCK)
-        dst[i] = (float)((double)band[i] * kFixInv);  // < 2^53: exact in f64, one rounding to f32
-    if (carry_dst) {
-        const acc_t* src = band + n_out;
-        for (int i = threadIdx.x; i < nx; i += BLOCK) carry_dst[i] = (float)((double)src[i] * kFixInv);
+    return seam + ((((size_t)c * g.nz + z) * bp.bands + j) * 2) * g.nx;
+}
+
+template <int BLOCK, bool CLEAR>
+__device__ __forceinline__ void flush_band_t(acc_t* __restrict__ band, int nx, int n_out, float* __restrict__ dst,
+                                             acc_t* __restrict__ seam_j, int j, int bands)
+{
+    const int head = j >= 1 ? nx : 0;  // cells that go to the seam buffer instead of the volume
+    for (int i = threadIdx.x; i < n_out; i += BLOCK) {
+        const acc_t v = band[i];
+        if (i < head)
+            seam_j[i] = v;
+        else
+            dst[i] = (float)((double)v * kFixInv);  // < 2^53: exact in f64, one rounding to f32
+        if (CLEAR) band[i] = 0;
     }
+    acc_t* src = band + n_out;
+    for (int i = threadIdx.x; i < nx; i += BLOCK) {
+        if (j < bands - 1) seam_j[nx + i] = src[i];
+        if (CLEAR) src[i] = 0;
+    }
+}
+
+template <int BLOCK>
+__device__ __forceinline__ void flush_band(acc_t* __restrict__ band, int nx, int n_out, float* __restrict__ dst,
+                                           acc_t* __restrict__ seam_j, int j, int bands)
+{
+    flush_band_t<BLOCK, false>(band, nx, n_out, dst, seam_j, j, bands);
 }
 
 // the same, leaving the band zeroed for the workgroup's next work item (persistent kernel)
 template <int BLOCK>
-__device__ __forceinline__ void flush_band_and_clear(acc_t* __restrict__ band, int nx, int n_out,
-                                                     float* __restrict__ dst, float* __restrict__ carry_dst)
+__device__ __forceinline__ void flush_band_and_clear(acc_t* __restrict__ band, int nx, int n_out, float* __restrict__ dst,
+                                                     acc_t* __restrict__ seam_j, int j, int bands)
 {
-    for (int i = threadIdx.x; i < n_out; i += BLOCK) {
-        dst[i] = (float)((double)band[i] * kFixInv);
-        band[i] = 0;
-    }
-    acc_t* src = band + n_out;
-    for (int i = threadIdx.x; i < nx; i += BLOCK) {
-        if (carry_dst) carry_dst[i] = (float)((double)src[i] * kFixInv);
-        src[i] = 0;
-    }
-}
-
-// carry[c][z][j][x] of band j (written for j < bands - 1)
-__device__ __forceinline__ float* carry_row(float* carry, int c, int z, int j, const Geom& g,
-                                            const BandPlan& bp)
-{
-    if (j >= bp.bands - 1) return nullptr;
-    return carry + (((size_t)c * g.nz + z) * bp.bands + j) * g.nx;
+    flush_band_t<BLOCK, true>(band, nx, n_out, dst, seam_j, j, bands);
 }
 
 template <int BLOCK>
@@ -622,7 +634,7 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands(const EvRec* __restrict__ 
                                                       const uint32_t* __restrict__ cuts, int np,
                                                       Geom g, BandPlan bp,
                                                       float* __restrict__ out,
-                                                      float* __restrict__ carry)
+                                                      acc_t* __restrict__ seam)
 {
     extern __shared__ acc_t band[];
     // block -> (pair q = (chunk, band), plane z).  Groups of 8 pairs: XCD x (= block % 8) walks
@@ -733,7 +745,7 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands(const EvRec* __restrict__ 
     // owned rows are contiguous in the [z][y][x] volume: a linear coalesced copy
     const size_t vol = partial_stride((size_t)g.nx * g.ny * g.nz);
     float* __restrict__ dst = out + (size_t)c * vol + ((size_t)z * g.ny + r0) * nx;
-    flush_band<BLOCK>(band, nx, (r1 - r0) * nx, dst, carry_row(carry, c, z, j, g, bp));
+    flush_band<BLOCK>(band, nx, (r1 - r0) * nx, dst, seam_rows(seam, c, z, j, g, bp), j, bp.bands);
 }
 
 // (3b) the same work item decomposition for SHORT runs (tall or wide grids: a band of a
@@ -1780,8 +1792,73 @@ __device__ __forceinline__ void group_stream_asm(const EvRec* sxy, const uint4* 
           "v59", "v60", "v61", "v62", "v63");
 }
 
+// The votes of ONE work item (band j, plane z, packets [p_begin, p_end) of one camera) into the band in
+// LDS: every wave of the workgroup streams its share of the packets.  LDS row 0 of the band is grid
+// row `row_base`; the item accepts events with floor(Y) in [Li, Ui - 1].
 // MAPPING = the lane mapping (1 packed / hand-scheduled, 3 packed / compiled, 5 vector fill /
-// hand-scheduled, 6 vector fill / compiled): one kernel per mapping, so that each carries only its own
+// hand-scheduled, 6 vector fill / compiled).  TWO_SETS: the vector fill keeps two instead of three batches of
+// gathers in flight (32 instead of 40 named registers; the fused kernel needs the difference).
+template <int BLOCK, int MAPPING, bool TWO_SETS = false>
+__device__ __forceinline__ void stream_item(const EvRec* __restrict__ sxy, const PlaneCoef* __restrict__ coef,
+                                            const uint32_t* __restrict__ cuts, const uint32_t* __restrict__ slow_any,
+                                            int np, const Geom& g, const BandPlan& bp, int j, int z, int p_begin,
+                                            int p_end, char* __restrict__ band_bytes, int Li, int Ui, int row_base,
+                                            int* __restrict__ s_pass)
+{
+    const int nx = g.nx;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int lane = threadIdx.x & (kWave - 1);
+    // packets a wave takes per pass:
+    constexpr int kWaves = BLOCK / kWave;
+    // as many as possible (fewer pass boundaries), but every wave should get >= 3 passes so that the
+    // waves of the workgroup finish together (measured: 2 % at 346x260, 6 % at 512x512 against one
+    // pass per wave; 512x512x200, 489 packets: passes of 16 / 8 / 4 / 2 packets 0.224 / 0.216 / 0.219 /
+    // 0.232 ms)
+    int lg_group = 6;
+    while (lg_group > 2 && (p_end - p_begin) < ((kWaves * 3) << lg_group)) --lg_group;
+    if (bp.pass_lg > 0) lg_group = bp.pass_lg;
+    const int group = 1 << lg_group;
+    const uint4* __restrict__ coef4 = reinterpret_cast<const uint4*>(coef) + 2 * (size_t)z * np;
+    const uint32_t* __restrict__ cutz = cuts + ((size_t)j * g.nz + z) * np;
+    // record np * 1024 is a dummy with multiplicity 0 (k_sort_packets) for the lanes a short last
+    // batch does not reach; "its" coefficients are whatever follows the plane's table
+    const uint32_t dummy_eo = (uint32_t)np * (uint32_t)kPacket;
+    if constexpr (MAPPING == 5 || MAPPING == 6) {
+        // vector fill (wide grids): passes of up to 64 packets, smaller when the chunk has few
+        // packets so that every wave gets >= 2 passes; 64 words of LDS per wave behind the band.
+        // 5 = hand-scheduled batches, 6 = all compiled (A/B tests; also the IEEE-divide planes of 5)
+        // (the per-pass set-up costs a few LDS round trips: as few, as large passes as keep every
+        //  wave busy)
+        int lg_pass = 6;
+        while (lg_pass > 3 && (p_end - p_begin) < (kWaves << lg_pass)) --lg_pass;
+        if (bp.pass_lg > 0) lg_pass = bp.pass_lg;
+        const int pass = 1 << lg_pass;
+        unsigned long long* scratch =
+            reinterpret_cast<unsigned long long*>(band_bytes + bp.scratch_offset) + wave * kVfillScratchWords;
+        if (slow_any[z] != 0)
+            vfill_stream<true>(sxy, coef4, cutz, band_bytes, scratch, p_begin + wave * pass, p_end, lg_pass,
+                               kWaves * pass, lane, nx, Li, Ui, row_base, dummy_eo);
+        else if constexpr (MAPPING == 6)
+            vfill_stream<false>(sxy, coef4, cutz, band_bytes, scratch, p_begin + wave * pass, p_end, lg_pass,
+                                kWaves * pass, lane, nx, Li, Ui, row_base, dummy_eo);
+        else
+            vfill_stream_asm(sxy, coef4, cutz, band_bytes, scratch, p_begin + wave * pass, p_end, lg_pass,
+                             kWaves * pass, lane, nx, Li, Ui, row_base, dummy_eo, TWO_SETS ? 3 : bp.experiment, p_begin, s_pass);
+    } else {
+        // MAPPING 3 is the compiled stream on the fast path too (A/B testing)
+        if (slow_any[z] != 0)
+            packed_stream<true>(sxy, coef4, cutz, band_bytes, p_begin + wave * group, p_end, lg_group,
+                                kWaves * group, lane, nx, Li, Ui, row_base, dummy_eo);
+        else if constexpr (MAPPING == 3)
+            packed_stream<false>(sxy, coef4, cutz, band_bytes, p_begin + wave * group, p_end, lg_group,
+                                 kWaves * group, lane, nx, Li, Ui, row_base, dummy_eo);
+        else
+            packed_stream_asm(sxy, coef4, cutz, band_bytes, p_begin + wave * group, p_end, lg_group,
+                              kWaves * group, lane, nx, Li, Ui, row_base, dummy_eo);
+    }
+}
+
+// One kernel per mapping, so that each carries only its own
 // streams (all of them in one kernel needed 70 VGPRs -- 7 waves per SIMD, i.e. ONE 1024-thread
 // workgroup per CU instead of two -- and spilled scalars).  8 waves per SIMD = at most 64 VGPRs.
 template <int BLOCK, int MAPPING>
@@ -1791,7 +1868,7 @@ __device__ __forceinline__ void vote_bands_packed_body(const EvRec* __restrict__
                                                        const uint32_t* __restrict__ slow_any,
                                                        int np, const Geom& g, const BandPlan& bp,
                                                        float* __restrict__ out,
-                                                       float* __restrict__ carry,
+                                                       acc_t* __restrict__ seam,
                                                        uint32_t* __restrict__ work_counters)
 {
     extern __shared__ acc_t band[];
@@ -1845,70 +1922,19 @@ __device__ __forceinline__ void vote_bands_packed_body(const EvRec* __restrict__
 
     const int p_begin = (int)(((long long)np * c) / bp.chunks);
     const int p_end = (int)(((long long)np * (c + 1)) / bp.chunks);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const int lane = threadIdx.x & (kWave - 1);
-    const int Li = r0, Ui = min(r1, g.ny - 1);
-    // packets a wave takes per pass:
-    constexpr int kWaves = BLOCK / kWave;
-    // as many as possible (fewer pass boundaries), but every wave should get >= 3 passes so that the
-    // waves of the workgroup finish together (measured: 2 % at 346x260, 6 % at 512x512 against one
-    // pass per wave; 512x512x200, 489 packets: passes of 16 / 8 / 4 / 2 packets 0.224 / 0.216 / 0.219 /
-    // 0.232 ms)
-    int lg_group = 6;
-    while (lg_group > 2 && (p_end - p_begin) < ((kWaves * 3) << lg_group)) --lg_group;
-    if (bp.pass_lg > 0) lg_group = bp.pass_lg;
-    const int group = 1 << lg_group;
-    const uint4* __restrict__ coef4 = reinterpret_cast<const uint4*>(coef) + 2 * (size_t)z * np;
-    const uint32_t* __restrict__ cutz = cuts + ((size_t)j * g.nz + z) * np;
-    // record np * 1024 is a dummy with multiplicity 0 (k_sort_packets) for the lanes a short last
-    // batch does not reach; "its" coefficients are whatever follows the plane's table
-    const uint32_t dummy_eo = (uint32_t)np * (uint32_t)kPacket;
-    char* band_bytes = reinterpret_cast<char*>(band);
-    if (bp.experiment == 1) {
-        // timing experiment: the item's fixed cost only (zero, barriers, flush)
-    } else if constexpr (MAPPING == 5 || MAPPING == 6) {
-        // vector fill (wide grids): passes of up to 64 packets, smaller when the chunk has few
-        // packets so that every wave gets >= 2 passes; 64 words of LDS per wave behind the band.
-        // 5 = hand-scheduled batches, 6 = all compiled (A/B tests; also the IEEE-divide planes of 5)
-        // (the per-pass set-up costs a few LDS round trips: as few, as large passes as keep every
-        //  wave busy)
-        int lg_pass = 6;
-        while (lg_pass > 3 && (p_end - p_begin) < (kWaves << lg_pass)) --lg_pass;
-        if (bp.pass_lg > 0) lg_pass = bp.pass_lg;
-        const int pass = 1 << lg_pass;
-        unsigned long long* scratch =
-            reinterpret_cast<unsigned long long*>(band_bytes + bp.scratch_offset) + wave * kVfillScratchWords;
-        if (slow_any[z] != 0)
-            vfill_stream<true>(sxy, coef4, cutz, band_bytes, scratch, p_begin + wave * pass, p_end, lg_pass,
-                               kWaves * pass, lane, nx, Li, Ui, r0, dummy_eo);
-        else if constexpr (MAPPING == 6)
-            vfill_stream<false>(sxy, coef4, cutz, band_bytes, scratch, p_begin + wave * pass, p_end, lg_pass,
-                                kWaves * pass, lane, nx, Li, Ui, r0, dummy_eo);
-        else
-            vfill_stream_asm(sxy, coef4, cutz, band_bytes, scratch, p_begin + wave * pass, p_end, lg_pass,
-                             kWaves * pass, lane, nx, Li, Ui, r0, dummy_eo, bp.experiment, p_begin, &s_pass);
-    } else {
-        // MAPPING 3 is the compiled stream on the fast path too (A/B testing)
-        if (slow_any[z] != 0)
-            packed_stream<true>(sxy, coef4, cutz, band_bytes, p_begin + wave * group, p_end, lg_group,
-                                kWaves * group, lane, nx, Li, Ui, r0, dummy_eo);
-        else if constexpr (MAPPING == 3)
-            packed_stream<false>(sxy, coef4, cutz, band_bytes, p_begin + wave * group, p_end, lg_group,
-                                 kWaves * group, lane, nx, Li, Ui, r0, dummy_eo);
-        else
-            packed_stream_asm(sxy, coef4, cutz, band_bytes, p_begin + wave * group, p_end, lg_group,
-                              kWaves * group, lane, nx, Li, Ui, r0, dummy_eo);
-    }
+    if (bp.experiment != 1)  // (1: timing experiment, the item's fixed cost only: zero, barriers, flush)
+        stream_item<BLOCK, MAPPING>(sxy, coef, cuts, slow_any, np, g, bp, j, z, p_begin, p_end,
+                                    reinterpret_cast<char*>(band), r0, min(r1, g.ny - 1), r0, &s_pass);
     __syncthreads();
 
     const size_t vol = partial_stride((size_t)g.nx * g.ny * g.nz);
     float* __restrict__ dst = out + (size_t)c * vol + ((size_t)z * g.ny + r0) * nx;
     if (!work_counters) {
-        flush_band<BLOCK>(band, nx, (r1 - r0) * nx, dst, carry_row(carry, c, z, j, g, bp));
+        flush_band<BLOCK>(band, nx, (r1 - r0) * nx, dst, seam_rows(seam, c, z, j, g, bp), j, bp.bands);
         break;
     }
     if (bp.experiment != 2)  // (2: timing experiment without the flush)
-        flush_band_and_clear<BLOCK>(band, nx, (r1 - r0) * nx, dst, carry_row(carry, c, z, j, g, bp));
+        flush_band_and_clear<BLOCK>(band, nx, (r1 - r0) * nx, dst, seam_rows(seam, c, z, j, g, bp), j, bp.bands);
     __syncthreads();  // every thread has read s_item and cleared its cells before thread 0 draws again
     }
 }
@@ -1917,9 +1943,9 @@ template <int BLOCK, int MAPPING>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_vote_bands_packed(
     const EvRec* __restrict__ sxy, const PlaneCoef* __restrict__ coef, const uint32_t* __restrict__ cuts,
     const uint32_t* __restrict__ slow_any, int np, Geom g, BandPlan bp, float* __restrict__ out,
-    float* __restrict__ carry, uint32_t* __restrict__ work_counters)
+    acc_t* __restrict__ seam, uint32_t* __restrict__ work_counters)
 {
-    vote_bands_packed_body<BLOCK, MAPPING>(sxy, coef, cuts, slow_any, np, g, bp, out, carry, work_counters);
+    vote_bands_packed_body<BLOCK, MAPPING>(sxy, coef, cuts, slow_any, np, g, bp, out, seam, work_counters);
 }
 
 // The vector-fill mappings run where ONE workgroup fills a CU (wide grids): 4 waves per SIMD may use up
@@ -1929,9 +1955,185 @@ template <int BLOCK, int MAPPING>
 __global__ __launch_bounds__(BLOCK) void k_vote_bands_vfill(
     const EvRec* __restrict__ sxy, const PlaneCoef* __restrict__ coef, const uint32_t* __restrict__ cuts,
     const uint32_t* __restrict__ slow_any, int np, Geom g, BandPlan bp, float* __restrict__ out,
-    float* __restrict__ carry, uint32_t* __restrict__ work_counters)
+    acc_t* __restrict__ seam, uint32_t* __restrict__ work_counters)
 {
-    vote_bands_packed_body<BLOCK, MAPPING>(sxy, coef, cuts, slow_any, np, g, bp, out, carry, work_counters);
+    vote_bands_packed_body<BLOCK, MAPPING>(sxy, coef, cuts, slow_any, np, g, bp, out, seam, work_counters);
+}
+
+// the 2-ary camera-fusion ops of Grid3D (cartesian3dgrid.h:111-192), used by the fused kernel below and by
+// the Grid3D kernels further down
+template <int OP>
+__device__ __forceinline__ float fuse_op(float a, float g)
+{
+    if (OP == 1) return (g < a) ? g : a;  // std::min, cartesian3dgrid.h:115
+    if (OP == 2) {                        // :119-127, eps = 1e-1f in the denominator
+        const float prod = a * g, sum = a + g;
+        return 2.f * prod / (sum + 0.1f);
+    }
+    if (OP == 3) return __builtin_sqrtf(a * g);  // :154
+    if (OP == 4) return 0.5f * (a + g);  // :162, double 0.5 * float sum: exact halving
+    if (OP == 5) {                       // :145-146, pow() and 0.5 in double
+        const double ad = (double)a, gd = (double)g;
+        const float ms = (float)(0.5 * (ad * ad + gd * gd));
+        return __builtin_sqrtf(ms);  // == (float)sqrt((double)ms): 53 >= 2*24+2
+    }
+    return (a < g) ? g : a;  // std::max, :188
+}
+
+// (3d) FUSED: vote -> camera fusion -> arg-max over Z without the DSIs ever leaving the CU.
+//
+// What "evaluateDSI x n; fused = op(dsi_0, dsi_1); collapseMaxZSlice(fused)" (process1.cpp:76-166 + :222
+// -> mapper_emvs_stereo.cpp:368) computes, for callers that keep only the depth map (the 50 ms window
+// loop of main.cpp:177-302): at 512 x 512 x 200 a window writes 2 x 210 MB of camera DSIs only for the
+// arg-max to read them straight back.  Here a persistent workgroup owns a contiguous range of
+// (band, plane) pairs; for each pair it votes camera 0's events into the band in LDS, reads the
+// owned rows back as fp32 into REGISTERS (one value per thread and 1024-voxel stretch; <= 20 of them),
+// clears the band, votes camera 1, applies the 2-ary op per voxel (fuse_op, the function k_fuse2_into
+// and k_collapse_max_z_fused use: same bits) and keeps a running (maximum, first index) per pixel in
+// registers.  When its range leaves a band (and at the end) the running maxima go to one 64-bit key
+// per pixel -- confidence bits << 8 | 255 - plane, the key of the plane-sharded arg-max -- with a
+// global atomic MAX, which is collapseMaxZSlice's first-maximum-wins over the plane ranges of all
+// workgroups; k_unpack_argmax turns the keys into confidence / index / depth.
+//
+// A band cannot wait for the band above to hand over its carry row here, so the band keeps a HALO row
+// on either side of its owned rows [r0, r1) (LDS row 0 = grid row r0 - 1) and processes the events
+// with floor(Y) in [r0 - 1, r1 - 1]: the events of the two seam rows are voted by both neighbours
+// (1 / band_rows more votes), the halo rows collect the halves that belong to the neighbours and are
+// dropped.  The owned rows then hold the exact 64-bit sums, which is what k_seam_rows reconstructs
+// for the unfused path: both paths round the same integers once, so their depth maps are bit-equal.
+template <int CELLS>
+struct FusedBest {
+    float best[CELLS];
+    uint32_t idx4[(CELLS + 3) / 4];  // plane indices, four per register
+};
+
+template <int CELLS, int OP, bool LAST, bool TWO>
+__device__ __forceinline__ void fused_consume(acc_t* __restrict__ band, int nx, int n_own, int rows_lds,
+                                              float* __restrict__ va, FusedBest<CELLS>& fb, int z)
+{
+    acc_t* own = band + nx;
+    // (the thread index is re-read behind an opaque barrier so that the compiler recomputes the 20 cell
+    //  addresses per call instead of keeping them -- 60 registers of loop invariants -- alive across
+    //  the voting loops, which name 40 physical registers themselves)
+    int t = (int)threadIdx.x;
+    asm volatile("" : "+v"(t));
+#pragma unroll
+    for (int k = 0; k < CELLS; ++k) {
+        const int i = t + k * 1024;
+        if (i < n_own) {
+            const float v = (float)((double)own[i] * kFixInv);  // flush_band's rounding
+            own[i] = 0;
+            if (!LAST) {
+                va[k] = v;
+            } else {
+                // process1.cpp:126-158: fused = 0; fused += dsi0; fused.<op>TwoGrids(dsi1)
+                const float f = TWO ? fuse_op<OP>(0.f + va[k], v) : v;
+                if (fb.best[k] < f) {  // strict: the first maximum wins (cartesian3dgrid.cpp:132-134)
+                    fb.best[k] = f;
+                    const int sh = (k & 3) * 8;
+                    fb.idx4[k >> 2] = (fb.idx4[k >> 2] & ~(0xffu << sh)) | ((uint32_t)z << sh);
+                }
+            }
+        }
+    }
+    acc_t* last = band + (size_t)(rows_lds - 1) * nx;
+    for (int i = threadIdx.x; i < nx; i += 1024) {
+        band[i] = 0;
+        last[i] = 0;
+    }
+}
+
+template <int MAPPING, int CELLS>
+__global__ __launch_bounds__(1024) void k_vote_fuse_argmax(FusedCameras cams, Geom g, BandPlan bp, int op,
+                                                           const uint32_t* __restrict__ splits,
+                                                           unsigned long long* __restrict__ keys)
+{
+    constexpr int BLOCK = 1024;
+    extern __shared__ acc_t band[];
+    __shared__ int s_pass;
+    const int nx = g.nx;
+    // Workgroup b runs on XCD b % 8: each XCD gets one contiguous eighth of the (band-major) pair list,
+    // so that a band's records stream through at most two XCDs' L2s, and splits it evenly over its
+    // workgroups -- or by `splits` (gridDim.x + 1 pair indices, block order) when the host supplies a
+    // balanced partition.
+    const int P = bp.bands * g.nz;
+    int q_begin, q_end;
+    if (splits) {
+        q_begin = (int)splits[blockIdx.x];
+        q_end = (int)splits[blockIdx.x + 1];
+    } else {
+        const int x = blockIdx.x & 7, l = blockIdx.x >> 3, per = gridDim.x >> 3;
+        const int lo = (int)(((long long)P * x) / 8), hi = (int)(((long long)P * (x + 1)) / 8);
+        q_begin = lo + (int)(((long long)(hi - lo) * l) / per);
+        q_end = lo + (int)(((long long)(hi - lo) * (l + 1)) / per);
+    }
+    if (q_begin >= q_end) return;
+    {
+        const int all_cells = (bp.band_rows + 2) * nx;
+        for (int i = threadIdx.x; i < all_cells; i += BLOCK) band[i] = 0;
+        if (threadIdx.x == 0) s_pass = BLOCK / kWave;
+    }
+    __syncthreads();
+
+    float va[CELLS];
+    FusedBest<CELLS> fb;
+    int cur_j = -1, r0 = 0, r1 = 0, n_own = 0;
+    auto emit = [&]() {
+        // one key per owned pixel (the owned rows are contiguous in the image)
+        unsigned long long* kp = keys + (size_t)r0 * nx;
+        int t = (int)threadIdx.x;
+        asm volatile("" : "+v"(t));  // see fused_consume
+#pragma unroll
+        for (int k = 0; k < CELLS; ++k) {
+            const int i = t + k * 1024;
+            if (i < n_own) {
+                const uint32_t zi = (fb.idx4[k >> 2] >> ((k & 3) * 8)) & 0xffu;
+                const unsigned long long key = ((unsigned long long)__float_as_uint(fb.best[k]) << 8) | (255u - zi);
+                atomicMax(kp + i, key);
+            }
+        }
+    };
+    for (int q = q_begin; q < q_end; ++q) {
+        const int j = q / g.nz, z = q - j * g.nz;
+        if (j != cur_j) {
+            if (cur_j >= 0) emit();
+            cur_j = j;
+            r0 = j * bp.band_rows;
+            r1 = min(g.ny, r0 + bp.band_rows);
+            n_own = (r1 - r0) * nx;
+#pragma unroll
+            for (int k = 0; k < CELLS; ++k) fb.best[k] = -1.f;  // below every DSI value (>= 0)
+#pragma unroll
+            for (int k = 0; k < (CELLS + 3) / 4; ++k) fb.idx4[k] = 0u;
+        }
+        const int rows_lds = r1 - r0 + 2;
+        // events with floor(Y) in [r0 - 1, r1 - 1] (and in [0, ny - 2], cartesian3dgrid.h:255-259)
+        const int Li = max(r0 - 1, 0), Ui = min(r1, g.ny - 1);
+        for (int c = 0; c < cams.n; ++c) {
+            const FusedCamera& cam = cams.cam[c];
+            stream_item<BLOCK, MAPPING, true>(cam.sxy, cam.coef, cam.cuts, cam.slow_any, cam.np, g, bp, j, z, 0, cam.np,
+                                        reinterpret_cast<char*>(band), Li, Ui, r0 - 1, &s_pass);
+            __syncthreads();
+            if (threadIdx.x == 0) s_pass = BLOCK / kWave;
+            const bool last = c == cams.n - 1;
+            if (!last) {
+                fused_consume<CELLS, 1, false, true>(band, nx, n_own, rows_lds, va, fb, z);
+            } else if (cams.n == 1) {
+                fused_consume<CELLS, 1, true, false>(band, nx, n_own, rows_lds, va, fb, z);
+            } else {
+                switch (op) {
+                case 1: fused_consume<CELLS, 1, true, true>(band, nx, n_own, rows_lds, va, fb, z); break;
+                case 2: fused_consume<CELLS, 2, true, true>(band, nx, n_own, rows_lds, va, fb, z); break;
+                case 3: fused_consume<CELLS, 3, true, true>(band, nx, n_own, rows_lds, va, fb, z); break;
+                case 4: fused_consume<CELLS, 4, true, true>(band, nx, n_own, rows_lds, va, fb, z); break;
+                case 5: fused_consume<CELLS, 5, true, true>(band, nx, n_own, rows_lds, va, fb, z); break;
+                default: fused_consume<CELLS, 6, true, true>(band, nx, n_own, rows_lds, va, fb, z); break;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    emit();
 }
 
 // (3c) GROUPED mapping: S consecutive packets (a "group"; their poses are microseconds apart)
@@ -2049,7 +2251,7 @@ __global__ __launch_bounds__(BLOCK) void k_vote_groups(const EvRec* __restrict__
                                                        const uint32_t* __restrict__ slow_any, int np,
                                                        int ngroups, int S, Geom g, BandPlan bp,
                                                        float* __restrict__ out,
-                                                       float* __restrict__ carry)
+                                                       acc_t* __restrict__ seam)
 {
     extern __shared__ acc_t band[];
     const int b = blockIdx.x;
@@ -2160,46 +2362,37 @@ __global__ __launch_bounds__(BLOCK) void k_vote_groups(const EvRec* __restrict__
     __syncthreads();
     const size_t vol = partial_stride((size_t)g.nx * g.ny * g.nz);
     float* __restrict__ dst = out + (size_t)c * vol + ((size_t)z * g.ny + r0) * nx;
-    flush_band<BLOCK>(band, nx, (r1 - r0) * nx, dst, carry_row(carry, c, z, j, g, bp));
+    flush_band<BLOCK>(band, nx, (r1 - r0) * nx, dst, seam_rows(seam, c, z, j, g, bp), j, bp.bands);
 }
 
-// (4) DSI = sum of the chunk partials (fixed order => deterministic given partials)
-// dsi[z][first row of band j+1][x] += sum over chunks of carry[c][z][j][x]
-// block x = one (plane, seam) row, block y = a 1024-voxel stretch of it; four voxels per thread
-// (one 16-byte access per stream when the rows are 16-byte aligned, i.e. nx % 4 == 0)
-__global__ __launch_bounds__(256) void k_add_carry(const float* __restrict__ carry, int chunks,
-                                                   Geom g, int bands, int band_rows,
-                                                   float* __restrict__ dsi)
+// (4) seam rows: the first row of band j >= 1 of every plane of every chunk's volume is the exact
+// fixed-point sum of the band's own votes (head) and of the band above's votes into the row below
+// it (carry), rounded to fp32 ONCE: out[c][z][j * band_rows][x] = fl((head + carry) * 2^-31).
+// Runs after the voting kernel and before the chunk volumes are summed.
+// block x = one (plane, seam) row, block y = a 512-voxel stretch of it, block z = chunk; two voxels
+// per thread (16-byte loads, 8-byte stores) when nx is even
+__global__ __launch_bounds__(256) void k_seam_rows(const acc_t* __restrict__ seam, Geom g, int bands, int band_rows,
+                                                   float* __restrict__ out, size_t vol_stride)
 {
-    const int j = (int)(blockIdx.x % (unsigned)(bands - 1));
+    const int j = (int)(blockIdx.x % (unsigned)(bands - 1)) + 1;
     const int z = (int)(blockIdx.x / (unsigned)(bands - 1));
-    const bool vec = (g.nx & 3) == 0;
-    const int x = vec ? ((int)blockIdx.y * 256 + (int)threadIdx.x) * 4 : (int)blockIdx.y * 1024 + (int)threadIdx.x;
-    if (x >= g.nx) return;
-    const size_t chunk_stride = (size_t)g.nz * bands * g.nx;
-    const float* src = carry + ((size_t)z * bands + j) * g.nx + x;
-    float* dst = dsi + ((size_t)z * g.ny + (size_t)(j + 1) * band_rows) * g.nx + x;
-    if (vec) {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int c = 0; c < chunks; ++c) {
-            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)c * chunk_stride);
-            acc.x += v.x;
-            acc.y += v.y;
-            acc.z += v.z;
-            acc.w += v.w;
-        }
-        float4 d = *reinterpret_cast<float4*>(dst);
-        d.x += acc.x;
-        d.y += acc.y;
-        d.z += acc.z;
-        d.w += acc.w;
-        *reinterpret_cast<float4*>(dst) = d;
+    const int c = (int)blockIdx.z;
+    const size_t row = ((size_t)c * g.nz + z) * bands;
+    const acc_t* head = seam + ((row + j) * 2) * g.nx;
+    const acc_t* carry = seam + ((row + j - 1) * 2 + 1) * g.nx;
+    float* dst = out + (size_t)c * vol_stride + ((size_t)z * g.ny + (size_t)j * band_rows) * g.nx;
+    if ((g.nx & 1) == 0) {
+        const int x = ((int)blockIdx.y * 256 + (int)threadIdx.x) * 2;
+        if (x >= g.nx) return;
+        const ulonglong2 h = *reinterpret_cast<const ulonglong2*>(head + x);
+        const ulonglong2 k = *reinterpret_cast<const ulonglong2*>(carry + x);
+        float2 r;
+        r.x = (float)((double)(h.x + k.x) * kFixInv);  // < 2^53: exact in f64, one rounding to f32
+        r.y = (float)((double)(h.y + k.y) * kFixInv);
+        *reinterpret_cast<float2*>(dst + x) = r;
     } else {
-        for (int u = 0; u < 1024 && x + u < g.nx; u += 256) {
-            float acc = 0.f;
-            for (int c = 0; c < chunks; ++c) acc += src[(size_t)c * chunk_stride + u];
-            dst[u] += acc;
-        }
+        for (int x = (int)blockIdx.y * 512 + (int)threadIdx.x; x < min(g.nx, ((int)blockIdx.y + 1) * 512); x += 256)
+            dst[x] = (float)((double)(head[x] + carry[x]) * kFixInv);
     }
 }
 
@@ -2230,24 +2423,6 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict
 }
 
 // ------------------------------------------------------------ Grid3D ops ---
-template <int OP>
-__device__ __forceinline__ float fuse_op(float a, float g)
-{
-    if (OP == 1) return (g < a) ? g : a;  // std::min, cartesian3dgrid.h:115
-    if (OP == 2) {                        // :119-127, eps = 1e-1f in the denominator
-        const float prod = a * g, sum = a + g;
-        return 2.f * prod / (sum + 0.1f);
-    }
-    if (OP == 3) return __builtin_sqrtf(a * g);  // :154
-    if (OP == 4) return 0.5f * (a + g);  // :162, double 0.5 * float sum: exact halving
-    if (OP == 5) {                       // :145-146, pow() and 0.5 in double
-        const double ad = (double)a, gd = (double)g;
-        const float ms = (float)(0.5 * (ad * ad + gd * gd));
-        return __builtin_sqrtf(ms);  // == (float)sqrt((double)ms): 53 >= 2*24+2
-    }
-    return (a < g) ? g : a;  // std::max, :188
-}
-
 template <int OP>
 __global__ __launch_bounds__(256) void k_fuse2(float* __restrict__ a, const float* __restrict__ g,
                                                size_t n)
@@ -2908,7 +3083,7 @@ hipError_t launch_plane_coef(hipStream_t s, const float* centers, const float* p
 template <int BLOCK, int MAPPING>
 static hipError_t launch_vote_bands_t(hipStream_t s, const EvRec* sxy, const PlaneCoef* coef,
                                       const uint32_t* cuts, const uint32_t* slow_any, int np,
-                                      const Geom& g, const BandPlan& bp, float* out, float* carry)
+                                      const Geom& g, const BandPlan& bp, float* out, unsigned long long* seam)
 {
     constexpr bool PACKED = MAPPING != 0;
     constexpr bool VFILL = MAPPING == 5 || MAPPING == 6;
@@ -2932,40 +3107,75 @@ static hipError_t launch_vote_bands_t(hipStream_t s, const EvRec* sxy, const Pla
     }
     if constexpr (VFILL)
         hipLaunchKernelGGL((k_vote_bands_vfill<BLOCK, (VFILL ? MAPPING : 5)>), dim3(blocks), dim3(BLOCK), bp.lds_bytes, s,
-                           sxy, coef, cuts, slow_any, np, g, bp, out, carry, counters);
+                           sxy, coef, cuts, slow_any, np, g, bp, out, seam, counters);
     else if constexpr (PACKED)
         hipLaunchKernelGGL((k_vote_bands_packed<BLOCK, (PACKED && !VFILL ? MAPPING : 1)>), dim3(blocks), dim3(BLOCK), bp.lds_bytes, s,
-                           sxy, coef, cuts, slow_any, np, g, bp, out, carry, counters);
+                           sxy, coef, cuts, slow_any, np, g, bp, out, seam, counters);
     else
         hipLaunchKernelGGL(k_vote_bands<BLOCK>, dim3(blocks), dim3(BLOCK), bp.lds_bytes, s, sxy, coef,
-                           cuts, np, g, bp, out, carry);
+                           cuts, np, g, bp, out, seam);
     return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
 template <int BLOCK>
 static hipError_t launch_vote_bands_b(hipStream_t s, const EvRec* sxy, const PlaneCoef* coef,
                                       const uint32_t* cuts, const uint32_t* slow_any, int np, const Geom& g,
-                                      const BandPlan& bp, float* out, float* carry)
+                                      const BandPlan& bp, float* out, unsigned long long* seam)
 {
     switch (bp.packed) {
-    case 0: return launch_vote_bands_t<BLOCK, 0>(s, sxy, coef, cuts, slow_any, np, g, bp, out, carry);
-    case 1: return launch_vote_bands_t<BLOCK, 1>(s, sxy, coef, cuts, slow_any, np, g, bp, out, carry);
-    case 3: return launch_vote_bands_t<BLOCK, 3>(s, sxy, coef, cuts, slow_any, np, g, bp, out, carry);
-    case 5: return launch_vote_bands_t<BLOCK, 5>(s, sxy, coef, cuts, slow_any, np, g, bp, out, carry);
-    case 6: return launch_vote_bands_t<BLOCK, 6>(s, sxy, coef, cuts, slow_any, np, g, bp, out, carry);
+    case 0: return launch_vote_bands_t<BLOCK, 0>(s, sxy, coef, cuts, slow_any, np, g, bp, out, seam);
+    case 1: return launch_vote_bands_t<BLOCK, 1>(s, sxy, coef, cuts, slow_any, np, g, bp, out, seam);
+    case 3: return launch_vote_bands_t<BLOCK, 3>(s, sxy, coef, cuts, slow_any, np, g, bp, out, seam);
+    case 5: return launch_vote_bands_t<BLOCK, 5>(s, sxy, coef, cuts, slow_any, np, g, bp, out, seam);
+    case 6: return launch_vote_bands_t<BLOCK, 6>(s, sxy, coef, cuts, slow_any, np, g, bp, out, seam);
     default: return hipErrorInvalidValue;
     }
 }
 
 hipError_t launch_vote_bands(hipStream_t s, const EvRec* sxy, const PlaneCoef* coef,
                              const uint32_t* cuts, const uint32_t* slow_any, int np, const Geom& g,
-                             const BandPlan& bp, float* out, float* carry)
+                             const BandPlan& bp, float* out, unsigned long long* seam)
 {
     if (np <= 0) return hipSuccess;
     switch (bp.block_threads) {
-    case 256: return launch_vote_bands_b<256>(s, sxy, coef, cuts, slow_any, np, g, bp, out, carry);
-    case 512: return launch_vote_bands_b<512>(s, sxy, coef, cuts, slow_any, np, g, bp, out, carry);
-    case 1024: return launch_vote_bands_b<1024>(s, sxy, coef, cuts, slow_any, np, g, bp, out, carry);
+    case 256: return launch_vote_bands_b<256>(s, sxy, coef, cuts, slow_any, np, g, bp, out, seam);
+    case 512: return launch_vote_bands_b<512>(s, sxy, coef, cuts, slow_any, np, g, bp, out, seam);
+    case 1024: return launch_vote_bands_b<1024>(s, sxy, coef, cuts, slow_any, np, g, bp, out, seam);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <int MAPPING>
+static hipError_t launch_vote_fuse_argmax_t(hipStream_t s, const FusedCameras& cams, const Geom& g, const BandPlan& bp,
+                                            int op, const uint32_t* splits, unsigned blocks, unsigned long long* keys)
+{
+    constexpr int CELLS = fused_cells_per_thread(MAPPING);
+    if ((size_t)(bp.band_rows + 2) * g.nx > (size_t)CELLS * 1024) return hipErrorInvalidValue;
+    const void* kern = reinterpret_cast<const void*>(&k_vote_fuse_argmax<MAPPING, CELLS>);
+    if (hipError_t e = allow_dynamic_lds(kern, bp.lds_bytes)) return e;
+    hipLaunchKernelGGL((k_vote_fuse_argmax<MAPPING, CELLS>), dim3(blocks), dim3(1024), bp.lds_bytes, s, cams, g, bp, op, splits, keys);
+    return hipExtGetLastError();
+}
+
+size_t fused_max_cells(int mapping) { return (size_t)fused_cells_per_thread(mapping) * 1024; }
+
+int fused_grid_blocks()
+{
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return std::max(8, cus - cus % 8);  // one 1024-thread workgroup per CU, whole groups of 8 (XCDs)
+}
+
+hipError_t launch_vote_fuse_argmax(hipStream_t s, const FusedCameras& cams, const Geom& g, const BandPlan& bp, int op,
+                                   const uint32_t* splits, unsigned long long* keys)
+{
+    if (cams.n < 1 || cams.n > 2 || bp.block_threads != 1024 || bp.chunks != 1 || !bp.halo) return hipErrorInvalidValue;
+    const unsigned blocks = (unsigned)fused_grid_blocks();
+    switch (bp.packed) {
+    case 1: return launch_vote_fuse_argmax_t<1>(s, cams, g, bp, op, splits, blocks, keys);
+    case 3: return launch_vote_fuse_argmax_t<3>(s, cams, g, bp, op, splits, blocks, keys);
+    case 5: return launch_vote_fuse_argmax_t<5>(s, cams, g, bp, op, splits, blocks, keys);
+    case 6: return launch_vote_fuse_argmax_t<6>(s, cams, g, bp, op, splits, blocks, keys);
     default: return hipErrorInvalidValue;
     }
 }
@@ -2996,36 +3206,37 @@ template <int BLOCK>
 static hipError_t launch_vote_groups_t(hipStream_t s, const EvRec* sxy, const uint8_t* spk,
                                        const PlaneCoef* coef, const uint32_t* gcuts,
                                        const uint32_t* slow_any, int np, int S, const Geom& g,
-                                       const BandPlan& bp, float* out, float* carry)
+                                       const BandPlan& bp, float* out, unsigned long long* seam)
 {
     if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_vote_groups<BLOCK>), bp.lds_bytes))
         return e;
     const int ngroups = (np + S - 1) / S;
     const unsigned blocks = (unsigned)(bp.chunks * bp.bands) * (unsigned)g.nz;
     hipLaunchKernelGGL(k_vote_groups<BLOCK>, dim3(blocks), dim3(BLOCK), bp.lds_bytes, s, sxy, spk,
-                       coef, gcuts, slow_any, np, ngroups, S, g, bp, out, carry);
+                       coef, gcuts, slow_any, np, ngroups, S, g, bp, out, seam);
     return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
 hipError_t launch_vote_groups(hipStream_t s, const EvRec* sxy, const uint8_t* spk,
                               const PlaneCoef* coef, const uint32_t* gcuts, const uint32_t* slow_any,
-                              int np, int S, const Geom& g, const BandPlan& bp, float* out, float* carry)
+                              int np, int S, const Geom& g, const BandPlan& bp, float* out, unsigned long long* seam)
 {
     if (np <= 0) return hipSuccess;
     switch (bp.block_threads) {
-    case 256: return launch_vote_groups_t<256>(s, sxy, spk, coef, gcuts, slow_any, np, S, g, bp, out, carry);
-    case 512: return launch_vote_groups_t<512>(s, sxy, spk, coef, gcuts, slow_any, np, S, g, bp, out, carry);
-    case 1024: return launch_vote_groups_t<1024>(s, sxy, spk, coef, gcuts, slow_any, np, S, g, bp, out, carry);
+    case 256: return launch_vote_groups_t<256>(s, sxy, spk, coef, gcuts, slow_any, np, S, g, bp, out, seam);
+    case 512: return launch_vote_groups_t<512>(s, sxy, spk, coef, gcuts, slow_any, np, S, g, bp, out, seam);
+    case 1024: return launch_vote_groups_t<1024>(s, sxy, spk, coef, gcuts, slow_any, np, S, g, bp, out, seam);
     default: return hipErrorInvalidValue;
     }
 }
 
-hipError_t launch_add_carry(hipStream_t s, const float* carry, int chunks, const Geom& g,
-                            const BandPlan& bp, float* dsi)
+hipError_t launch_seam_rows(hipStream_t s, const unsigned long long* seam, int chunks, const Geom& g,
+                            const BandPlan& bp, float* out)
 {
     if (bp.bands < 2) return hipSuccess;
-    hipLaunchKernelGGL(k_add_carry, dim3((unsigned)g.nz * (unsigned)(bp.bands - 1), (unsigned)((g.nx + 1023) / 1024)),
-                       dim3(256), 0, s, carry, chunks, g, bp.bands, bp.band_rows, dsi);
+    const size_t vol = partial_stride((size_t)g.nx * g.ny * g.nz);
+    hipLaunchKernelGGL(k_seam_rows, dim3((unsigned)g.nz * (unsigned)(bp.bands - 1), (unsigned)((g.nx + 511) / 512), (unsigned)chunks),
+                       dim3(256), 0, s, seam, g, bp.bands, bp.band_rows, out, vol);
     return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 

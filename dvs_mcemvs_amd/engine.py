@@ -23,7 +23,7 @@ PACKET_SIZE = 1024
 FUSE_MIN, FUSE_HM, FUSE_GM, FUSE_AM, FUSE_RMS, FUSE_MAX = 1, 2, 3, 4, 5, 6
 ACC_SUM, ACC_INV_SUM, ACC_LOG_SUM, ACC_SQ_SUM, ACC_MIN, ACC_MAX = 0, 1, 2, 3, 4, 5
 REDUCE_SUM, REDUCE_MIN, REDUCE_MAX = 0, 1, 2
-VOTE_AUTO, VOTE_GLOBAL_ATOMIC, VOTE_LDS_BANDS = 0, 1, 2
+VOTE_AUTO, VOTE_GLOBAL_ATOMIC, VOTE_LDS_BANDS, VOTE_FUSED_ARGMAX = 0, 1, 2, 3
 
 (OK, ERR_INVALID, ERR_TOO_FEW_EVENTS, ERR_HIP, ERR_SHAPE, ERR_BAD_OP, ERR_NO_DEVICE,
  ERR_CONTEXT, ERR_COMM) = range(9)
@@ -141,6 +141,7 @@ def load_library():
         "dsi_mapper_fetch_depth_map": (C.c_int, [vp, f32p, f32p, u8p]),
         "dsi_mapper_depth_map_of_fusion": (C.c_int, [vp, vp, vp, C.c_int]),
         "dsi_mapper_depth_map_of_fusion_n": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_int]),
+        "dsi_mapper_depth_map_of_events": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int]),
         "dsi_mapper_get_depth_map_from_dsi": (C.c_int, [vp, vp, C.POINTER(_DepthMapOptions), f32p, f32p,
                                                        u8p, u8p]),
         "dsi_mapper_last_vote_info": (C.c_int, [vp, C.POINTER(_VoteInfo)]),
@@ -729,6 +730,16 @@ class MapperEMVS:
         the fused DSI: bit-identical to Grid3D.setToFusionOfN + computeDepthMap."""
         hs = (C.c_void_p * len(grids))(*[g._h for g in grids])
         _check(load_library().dsi_mapper_depth_map_of_fusion_n(self._h, hs, len(grids), int(mode)))
+
+    def computeDepthMapOfEvents(self, mappers, batches, fusion_method=FUSE_HM):
+        """Depth map of 1 or 2 cameras' events without building their DSIs: one kernel votes each
+        (band, plane) of every camera into LDS, fuses the cameras per voxel and keeps the running
+        arg-max in registers (dsi_mapper_depth_map_of_events).  Bit-identical to evaluateDSI_batch on
+        every mapper + computeDepthMapOfFusion (or computeDepthMap for one camera); the mappers' DSIs
+        are not touched.  Results land in THIS mapper's depth-map buffers (fetchDepthMap)."""
+        hm = (C.c_void_p * len(mappers))(*[m._h for m in mappers])
+        hb = (C.c_void_p * len(batches))(*[b._h for b in batches])
+        _check(load_library().dsi_mapper_depth_map_of_events(self._h, hm, hb, len(mappers), int(fusion_method)))
 
     def computeDepthMapSharded(self, grid, comm):
         """Plane-sharded arg-max: local collapse of this rank's plane range, ONE all-reduce(MAX) of

@@ -191,12 +191,16 @@ class WindowStream:
     window (main.cpp:262-275); here they are reused -- evaluateDSI resets the DSI anyway (:145)."""
 
     def __init__(self, ctx, cams, dsi_shape, fusion_method=E.FUSE_HM, luts=(None, None),
-                 inverse_depth=False, depth=2, materialize_fused=True):
+                 inverse_depth=False, depth=2, materialize_fused=True, fused_vote=False):
         """materialize_fused=False: the fused DSI (the reference's mapper_fused.dsi_) is not written;
         the camera fusion happens inside the arg-max kernel (same bits, one pass less over the
-        volume) -- for streams that only keep the depth maps."""
+        volume) -- for streams that only keep the depth maps.
+        fused_vote=True (implies materialize_fused=False): not even the camera DSIs are written -- one
+        kernel votes, fuses and keeps the running arg-max on the CU (MapperEMVS.computeDepthMapOfEvents;
+        the same depth maps bit for bit)."""
         self.ctx = ctx
-        self.materialize_fused = bool(materialize_fused)
+        self.fused_vote = bool(fused_vote)
+        self.materialize_fused = bool(materialize_fused) and not self.fused_vote
         self.fusion_method = int(fusion_method)
         self.mappers = [E.MapperEMVS(ctx, cams[c], dsi_shape, lut=luts[c], inverse_depth=inverse_depth)
                         for c in range(2)]
@@ -226,15 +230,17 @@ class WindowStream:
         and the host does not wait for them.  Returns the slot to pass to fetch()."""
         slot = self.k % len(self.fused)
         T_rv_w = reference_view_process1(trajectories[0], ts, rv_pos)
-        own = []
+        own, fused_batches = [], []
         for c in range(2):
             if batches is not None:
                 b = batches[c]
             else:
                 pk = E.packetize(events[c][2], trajectories[c], T_rv_w)
                 if pk is None:                      # evaluateDSI returns false: < 1024 events (:71-75)
-                    self.mappers[c].dsi_.resetGrid()
-                    continue
+                    if not self.fused_vote:
+                        self.mappers[c].dsi_.resetGrid()
+                        continue
+                    pk = (np.zeros(0, np.uint32), np.zeros((0, 12), np.float32))   # a batch without packets
                 first, Rt = pk
                 if asynchronous:
                     pr, pf = self._staging(slot, c, first.shape[0])
@@ -243,9 +249,14 @@ class WindowStream:
                     Rt, first = pr.a[:Rt.shape[0]], pf.a[:first.shape[0]]
                 b = E.EventBatch(self.ctx, events[c][0], events[c][1], Rt, first, asynchronous=asynchronous)
                 own.append(b)
-            self.mappers[c].evaluateDSI_batch(b)
+            if self.fused_vote:
+                fused_batches.append(b)
+            else:
+                self.mappers[c].evaluateDSI_batch(b)
             self.voted += b.n_packets * E.PACKET_SIZE
-        if self.materialize_fused:
+        if self.fused_vote:
+            self.extract[slot].computeDepthMapOfEvents(self.mappers, fused_batches, self.fusion_method)
+        elif self.materialize_fused:
             self.fused[slot].setToFusionOf(self.mappers[0].dsi_, self.mappers[1].dsi_, self.fusion_method)
             self.extract[slot].computeDepthMap(self.fused[slot])
         else:

@@ -39,7 +39,7 @@ extern "C" {
 #define DSI_API
 #endif
 
-#define DSI_ENGINE_ABI_VERSION 4
+#define DSI_ENGINE_ABI_VERSION 5
 #define DSI_PACKET_SIZE 1024 /* mapper_emvs_stereo.hpp:152 packet_size_ */
 
 typedef enum {
@@ -94,7 +94,9 @@ typedef enum { DSI_REDUCE_SUM = 0, DSI_REDUCE_MIN = 1, DSI_REDUCE_MAX = 2 } dsi_
 typedef enum {
     DSI_VOTE_AUTO = 0,
     DSI_VOTE_GLOBAL_ATOMIC = 1, /* thread = event, global_atomic_add_f32 into the DSI */
-    DSI_VOTE_LDS_BANDS = 2      /* plane x row-band privatised in LDS as Q33.31 fixed point (ds_add_u64), coalesced flush */
+    DSI_VOTE_LDS_BANDS = 2,     /* plane x row-band privatised in LDS as Q33.31 fixed point (ds_add_u64), coalesced flush */
+    DSI_VOTE_FUSED_ARGMAX = 3   /* reported only: the same bands, fused with the camera fusion and the arg-max
+                                   (dsi_mapper_depth_map_of_events); not selectable with dsi_mapper_set_vote_algo */
 } dsi_vote_algo_t;
 
 typedef struct dsi_context dsi_context_t; /* one GPU + one HIP stream + scratch */
@@ -326,6 +328,20 @@ DSI_API int dsi_mapper_depth_map_of_fusion(dsi_mapper_t *m, const dsi_grid_t *a,
  * generalisation of process1.cpp:126-191, SURVEY 8d cfg 5) without materialising the fused DSI --
  * the same per-voxel operations in the same order, so the same bits as fuse-then-collapse. */
 DSI_API int dsi_mapper_depth_map_of_fusion_n(dsi_mapper_t *m, const dsi_grid_t *const *srcs, int n, int mode);
+/* The depth map of n = 1 or 2 cameras' events WITHOUT building their DSIs: bit for bit what
+ *     for c in 0..n-1: dsi_mapper_evaluate_batch(mappers[c], batches[c]);                 (process1.cpp:76-117)
+ *     n == 2: dsi_mapper_depth_map_of_fusion(out, grid(mappers[0]), grid(mappers[1]), op);  (:126-166, :222 -> mapper_emvs_stereo.cpp:368)
+ *     n == 1: dsi_mapper_depth_map_of(out, grid(mappers[0]))
+ * leaves in out's depth-map buffers (dsi_mapper_fetch_depth_map*), computed by one kernel that votes a
+ * (band, plane) of each camera into LDS, applies the 2-ary op per voxel and keeps the running arg-max
+ * in registers -- no DSI is written or read (at 512x512x200 a window saves 840 MB of HBM traffic).  For
+ * streams that keep only the depth maps (the --full_seq loop, main.cpp:177-302).  The mappers' grids
+ * are NOT touched (they keep whatever an earlier evaluate left there); `out` may be one of the
+ * mappers; all must share one context and one DSI shape; the cameras need distinct mappers.  op =
+ * dsi_fuse_op_t (ignored for n == 1).  A batch without packets stands for an all-zero DSI (evaluateDSI
+ * returned false, mapper_emvs_stereo.cpp:71-75).  Asynchronous on the context's stream. */
+DSI_API int dsi_mapper_depth_map_of_events(dsi_mapper_t *out, dsi_mapper_t *const *mappers,
+                                           const dsi_batch_t *const *batches, int n, int op);
 DSI_API int dsi_mapper_fetch_depth_map(dsi_mapper_t *m, float *depth_host, float *conf_host, uint8_t *idx_host);
 /* the same without waiting: the copies are queued (on the context's copy stream, behind the arg-max
  * only -- not behind later work of the compute stream); the outputs (page-locked memory from

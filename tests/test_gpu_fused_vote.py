@@ -1,0 +1,197 @@
+"""The fused vote -> camera fusion -> arg-max kernel (dsi_mapper_depth_map_of_events) against the
+unfused sequence it replaces, and the property that makes the comparison exact: the DSI's bits do not
+depend on the band decomposition (seam rows are rounded once from the exact 64-bit sums).
+
+Reference sequence: process1.cpp:76-166 (evaluateDSI x 2, camera fusion) + :222 ->
+mapper_emvs_stereo.cpp:368 (collapseMaxZSlice) + :302-313 (index -> depth).
+
+Every comparison here is `array_equal`: same confidence bits, same indices, same depths.
+"""
+import numpy as np
+import pytest
+
+import dvs_mcemvs_amd as d
+from dvs_mcemvs_amd import engine, process as proc, synthetic as syn
+from oracle import oracle as orc
+from oracle_pipeline import OracleMapper
+
+pytestmark = pytest.mark.gpu
+
+
+def rig_batches(ctx, rig, n_cams=2):
+    out = []
+    for c in range(n_cams):
+        first, Rt = d.packetize(rig["events"][c][2], rig["trajectories"][c], rig["T_rv_w"])
+        out.append(d.EventBatch(ctx, rig["events"][c][0], rig["events"][c][1], Rt, first))
+    return out
+
+
+def unfused(ctx, mappers, batches, op):
+    for m, b in zip(mappers, batches):
+        m.evaluateDSI_batch(b)
+    if len(mappers) == 2:
+        mappers[0].computeDepthMapOfFusion(mappers[0].dsi_, mappers[1].dsi_, op)
+    else:
+        mappers[0].computeDepthMap()
+    return mappers[0].fetchDepthMap()
+
+
+@pytest.mark.parametrize("packed", [1, 3, 5, 6])
+@pytest.mark.parametrize("shape,band_rows", [((96, 72, 32), 0), ((96, 72, 32), 7), ((130, 97, 9), 5),
+                                             ((346, 260, 20), 0), ((64, 48, 256), 11)])
+def test_fused_equals_vote_fuse_collapse(ctx, packed, shape, band_rows):
+    nx, ny, nz = shape
+    rig = syn.stereo_rig(30_000, width=nx, height=ny, duration=0.25, seed=31 + nx, n_points=900)
+    dsi_shape = d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0)
+    batches = rig_batches(ctx, rig)
+    ref_m = [d.MapperEMVS(ctx, rig["cam"], dsi_shape) for _ in range(2)]
+    fus_m = [d.MapperEMVS(ctx, rig["cam"], dsi_shape) for _ in range(2)]
+    for m in fus_m:
+        m.set_packed_lanes(packed)
+        if band_rows:
+            m.set_band_params(band_rows, 0, 0)
+    out = d.MapperEMVS(ctx, rig["cam"], dsi_shape)
+    for op in (d.FUSE_MIN, d.FUSE_HM, d.FUSE_GM, d.FUSE_AM, d.FUSE_RMS, d.FUSE_MAX):
+        want = unfused(ctx, ref_m, batches, op)
+        out.computeDepthMapOfEvents(fus_m, batches, op)
+        got = out.fetchDepthMap()
+        info = fus_m[0].last_vote_info()
+        assert info["algo"] == d.VOTE_FUSED_ARGMAX and info["packed"] == packed
+        if band_rows:
+            assert info["band_rows"] == band_rows and info["bands"] == -(-ny // band_rows)
+        for g, w, name in zip(got, want, ("depth", "confidence", "index")):
+            assert np.array_equal(g, w), "op %d %s differs at %d pixels" % (op, name, (g != w).sum())
+        assert want[1].max() > 1.0
+    # one camera: vote -> arg-max (`out` may be the voting mapper itself)
+    want = unfused(ctx, ref_m[:1], batches[:1], 0)
+    fus_m[0].computeDepthMapOfEvents(fus_m[:1], batches[:1], 0)
+    got = fus_m[0].fetchDepthMap()
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    for o in ref_m + fus_m + [out] + batches:
+        o.close()
+
+
+def test_fused_against_the_oracle(ctx):
+    """Not only self-consistent: indices equal the CPU oracle's wherever its top-2 gap exceeds the DSI
+    tolerance, and everywhere else the GPU's plane is a provable near-tie of the oracle's fused DSI."""
+    nx, ny, nz = 120, 90, 40
+    rig = syn.stereo_rig(60_000, width=nx, height=ny, duration=0.3, seed=8, n_points=1500)
+    shape = d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0)
+    batches = rig_batches(ctx, rig)
+    ms = [d.MapperEMVS(ctx, rig["cam"], shape) for _ in range(2)]
+    ms[0].computeDepthMapOfEvents(ms, batches, d.FUSE_HM)
+    depth, conf, idx = ms[0].fetchDepthMap()
+    refs = []
+    for c in range(2):
+        r = OracleMapper(rig["cam"], dimZ=nz, min_depth=4.0, max_depth=200.0)
+        assert r.evaluateDSI(rig["events"][c], rig["trajectories"][c], rig["T_rv_w"])
+        refs.append(r.dsi)
+    rf = orc.fuse2(refs[0], refs[1], 2)
+    rconf, ridx = orc.collapse_max_z(rf)
+    tol = 2e-4 * np.maximum(1.0, rconf)
+    picked = np.take_along_axis(rf, idx[None].astype(np.int64), axis=0)[0]
+    assert np.all((idx == ridx) | (picked >= rconf - tol)), "a GPU arg-max that is not a near-tie of the oracle's"
+    assert np.allclose(conf, rconf, rtol=1e-4, atol=1e-4)
+    assert np.array_equal(depth, ms[0].raw_depths_vec_[idx])
+    assert (idx == ridx).mean() > 0.97
+    for o in ms + batches:
+        o.close()
+
+
+def test_fused_camera_without_packets(ctx):
+    """evaluateDSI returns false for < 1024 events (mapper_emvs_stereo.cpp:71-75): that camera's DSI is
+    all zero; HM with a zero volume is zero everywhere -> confidence 0, index 0."""
+    nx, ny, nz = 96, 72, 16
+    rig = syn.stereo_rig(20_000, width=nx, height=ny, duration=0.2, seed=3)
+    shape = d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0)
+    b0 = rig_batches(ctx, rig, 1)[0]
+    empty = d.EventBatch(ctx, np.zeros(0, np.uint16), np.zeros(0, np.uint16), np.zeros((0, 12), np.float32),
+                         np.zeros(0, np.uint32))
+    ms = [d.MapperEMVS(ctx, rig["cam"], shape) for _ in range(2)]
+    ms[0].computeDepthMapOfEvents(ms, [b0, empty], d.FUSE_HM)
+    depth, conf, idx = ms[0].fetchDepthMap()
+    assert not conf.any() and not idx.any() and np.all(depth == ms[0].raw_depths_vec_[0])
+    # max(dsi0, 0) = dsi0: the single-camera arg-max
+    ms[0].computeDepthMapOfEvents(ms, [b0, empty], d.FUSE_MAX)
+    got = ms[0].fetchDepthMap()
+    ms[1].evaluateDSI_batch(b0)
+    ms[1].computeDepthMap()
+    want = ms[1].fetchDepthMap()
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    for o in ms + [b0, empty]:
+        o.close()
+
+
+def test_fused_rejects_bad_arguments(ctx):
+    rig = syn.stereo_rig(5_000, width=64, height=48, duration=0.1, seed=1)
+    a = d.MapperEMVS(ctx, rig["cam"], d.ShapeDSI(0, 0, 8, 4.0, 100.0, 0.0))
+    b = d.MapperEMVS(ctx, rig["cam"], d.ShapeDSI(0, 0, 9, 4.0, 100.0, 0.0))
+    batches = rig_batches(ctx, rig)
+    with pytest.raises(d.DsiError) as e:
+        a.computeDepthMapOfEvents([a, b], batches, d.FUSE_HM)
+    assert e.value.code == engine.ERR_SHAPE
+    with pytest.raises(d.DsiError) as e:
+        a.computeDepthMapOfEvents([a, a], batches, d.FUSE_HM)
+    assert e.value.code == engine.ERR_INVALID
+    c = d.MapperEMVS(ctx, rig["cam"], d.ShapeDSI(0, 0, 8, 4.0, 100.0, 0.0))
+    with pytest.raises(d.DsiError) as e:
+        a.computeDepthMapOfEvents([a, c], batches, 9)
+    assert e.value.code == engine.ERR_BAD_OP
+    for o in [a, b, c] + batches:
+        o.close()
+
+
+@pytest.mark.parametrize("packed", [0, 1, 5])
+def test_dsi_bits_do_not_depend_on_the_band_decomposition(ctx, packed):
+    """One chunk: every voxel is fl(exact 64-bit sum), also on the seam rows between bands
+    (k_seam_rows), so any band height gives the same bits.  With several chunks the per-chunk volumes
+    have that property and are added in chunk order, so the bits depend on the chunk count only."""
+    nx, ny, nz = 130, 97, 12
+    rig = syn.stereo_rig(40_000, width=nx, height=ny, duration=0.25, seed=17, n_points=400)
+    shape = d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0)
+    batch = rig_batches(ctx, rig, 1)[0]
+    got = {}
+    for chunks in (1, 3):
+        for band_rows in (3, 10, 31, 97):
+            m = d.MapperEMVS(ctx, rig["cam"], shape)
+            m.set_vote_algo(d.VOTE_LDS_BANDS)
+            m.set_packed_lanes(packed)
+            m.set_band_params(band_rows, chunks, 0)
+            m.evaluateDSI_batch(batch)
+            info = m.last_vote_info()
+            assert info["band_rows"] == band_rows and info["chunks"] == chunks
+            got[(chunks, band_rows)] = m.dsi_.download()
+            m.close()
+        base = got[(chunks, 97)]                      # one band: no seam at all
+        assert base.max() > 4.0
+        for band_rows in (3, 10, 31):
+            assert np.array_equal(got[(chunks, band_rows)], base), (chunks, band_rows)
+    # and the chunked sum stays within the DSI tolerance of the one-chunk volume
+    err = np.abs(got[(3, 97)].astype(np.float64) - got[(1, 97)]) / np.maximum(1.0, got[(1, 97)])
+    assert err.max() <= 1e-5
+    batch.close()
+
+
+def test_window_stream_fused_vote_is_bit_identical(ctx):
+    """BASELINE configs[2] shape (512x512x200, 2 x 500 k events per 50 ms window): the stream with
+    fused_vote=True returns the depth maps of the materialising stream bit for bit."""
+    NX, NY, NZ, EV, DUR, NWIN = 512, 512, 200, 500_000, 0.05, 4
+    t0 = 10.0
+    rig = syn.stereo_rig(NWIN * EV, width=640, height=480, t0=t0, duration=NWIN * DUR, seed=77, n_points=6000)
+    shape = d.ShapeDSI(NX, NY, NZ, 4.0, 200.0, 0.0)
+    bounds = proc.window_bounds(t0, t0 + NWIN * DUR + 1e-9, DUR, DUR)
+    a = proc.WindowStream(ctx, (rig["cam"],) * 2, shape, d.FUSE_HM)
+    b = proc.WindowStream(ctx, (rig["cam"],) * 2, shape, d.FUSE_HM, fused_vote=True)
+    for (lo, hi) in bounds:
+        ev = [proc.window_events(rig["events"][c], lo, hi) for c in range(2)]
+        want = a.fetch(a.submit(ev, rig["trajectories"], hi))
+        got = b.fetch(b.submit(ev, rig["trajectories"], hi))
+        for g, w, name in zip(got, want, ("depth", "confidence", "index")):
+            assert np.array_equal(g, w), "%s differs at %d pixels" % (name, (g != w).sum())
+        assert want[1].max() > 1.0
+    info = b.mappers[0].last_vote_info()
+    assert info["algo"] == d.VOTE_FUSED_ARGMAX and info["bands"] == 14 and info["band_rows"] == 37
+    a.close()
+    b.close()

@@ -34,10 +34,12 @@ def test_vote_kernels_do_not_spill(tmp_path):
             continue
         seen += 1
         val = lambda key: int(re.search(r"\.%s:\s+(\d+)" % key, block).group(1))
-        vector_fill = "k_vote_bands_vfill" in name
+        vector_fill = "k_vote_bands_vfill" in name or "k_vote_fuse_argmax" in name
         if vector_fill:
             # lane mappings 5 / 6 run where ONE workgroup fills a CU (wide grids): 4 waves per SIMD, up to
-            # 128 VGPRs -- the third register set of gathers in flight lives there
+            # 128 VGPRs -- the third register set of gathers in flight lives there; the fused vote -> fusion
+            # -> arg-max kernel keeps camera 0's values and the running maxima of <= 20 cells per thread in
+            # registers across the wave loops (which name 32-40 registers themselves): no spill there either
             assert val("vgpr_count") <= 128, name
         else:
             # 8 waves per SIMD (two 1024-thread workgroups per CU) need <= 64 VGPRs -- the persistent loop
