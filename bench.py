@@ -67,6 +67,13 @@ def parse():
     ap.add_argument("--materialize-fused", action="store_true",
                     help="windows / cameras4: also write the fused DSI (mapper_fused.dsi_) instead of fusing the "
                          "cameras inside the arg-max kernel")
+    ap.add_argument("--fused-vote", dest="fused_vote", action="store_true", default=None,
+                    help="windows: vote, fuse the cameras and keep the arg-max in ONE kernel, no DSI written "
+                         "(dsi_mapper_depth_map_of_events); default for the windows workload")
+    ap.add_argument("--no-fused-vote", dest="fused_vote", action="store_false")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="default (stereo, 1 GPU) run only: do not append the one-GPU lines of the windows and "
+                         "cameras4 workloads (each is a sub-run of this script) to the JSON line")
     ap.add_argument("--collective", choices=["engine", "torch"], default="engine",
                     help="N > 1: who issues the all-reduce: the engine's own RCCL communicator (C ABI) or "
                          "torch.distributed")
@@ -191,13 +198,19 @@ def make_comm(d, dd, ctx, D, args):
     return None, None, "torch.distributed nccl (%s)" % why, group
 
 
+def kernel_source_sha16():
+    import hashlib
+    path = os.path.join(ROOT, "dvs_mcemvs_amd", "csrc", "dsi_kernels.hip")
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+
+
 def lds_block(accepted, kern_ms):
     adds = 4.0 * accepted / (kern_ms * 1e-3)
     lane_rate = CU * LANES * CLK
     return adds, lane_rate / LDS_CLK_CONFLICT_FREE, lane_rate / LDS_CLK_RANDOM
 
 
-def roofline_block(info, kern_ms, kt_n, accepted, ev_per_launch, nz, traffic):
+def roofline_block(info, kern_ms, kt_n, accepted, ev_per_launch, nz, traffic, records=None):
     """The voting kernel is an LDS-privatised scatter-add: what bounds it is the rate of 64-bit LDS
     atomic adds (4 per accepted event-plane).  peak = 256 CU x 64 lanes x 2.4 GHz / 6.2 clocks per
     ds_add_u64 wave instruction (conflict-free addresses; guide LDS section ~6, measured 6.1-6.2).
@@ -206,7 +219,7 @@ def roofline_block(info, kern_ms, kt_n, accepted, ev_per_launch, nz, traffic):
     read-modify-write), which is NOT a bound for this kernel (it exceeds the HBM peak)."""
     kernel = {0: "k_vote_bands", 1: "k_vote_bands_packed", 2: "k_vote_groups", 3: "k_vote_bands_packed",
               4: "k_vote_groups", 5: "k_vote_bands_vfill", 6: "k_vote_bands_vfill"}[info["packed"]] \
-        if info["algo"] == 2 else "k_vote_global"
+        if info["algo"] == 2 else ("k_vote_fuse_argmax" if info["algo"] == 3 else "k_vote_global")
     if not kt_n:
         return {"bound": "lds_atomic", "achieved": None, "peak": None, "unit": "G adds/s", "frac": None,
                 "traffic": traffic, "kernel": kernel}
@@ -221,6 +234,14 @@ def roofline_block(info, kern_ms, kt_n, accepted, ev_per_launch, nz, traffic):
            "hbm_algorithmic_equiv": {"bytes_per_launch": alg_bytes,
                                      "GBps": alg_bytes / (kern_ms * 1e-3) / 1e9,
                                      "note": "SURVEY 8(d) byte model; not a bound (votes never leave LDS)"}}
+    if records:
+        # `achieved` counts ALGORITHMIC adds (4 per accepted event-plane, i.e. with the multiplicity of merged
+        # duplicates); the hardware issues 4 per accepted RECORD.  Both fractions of the same roof:
+        issued, _, _ = lds_block(records, kern_ms)
+        out["accepted_records_per_launch"] = records
+        out["records_per_accepted_event_plane"] = records / accepted if accepted else None   # duplicate-merge ratio
+        out["achieved_issued"] = issued / 1e9
+        out["frac_issued"] = issued / peak
     if traffic:
         gbps = traffic / (kern_ms * 1e-3) / 1e9
         out["hbm"] = {"achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
@@ -327,6 +348,60 @@ def cpu_baseline(d, rig, dims, n_sample):
     return out
 
 
+def parity_block(d, rig, dims, mappers, batches, fused):
+    """Closes the depth-map statement on the bench's own inputs (rank 0, N = 1, stereo): the CPU oracle
+    (oracle/, the checker -- never the thing measured) builds both camera DSIs from the same events, fuses
+    them and takes the arg-max; reported: the worst voxel error of the GPU DSIs and of the fused DSI, the
+    fraction of pixels whose plane index equals the oracle's, the fraction where it differs but is a provable
+    near-tie of the oracle's column, and the number of pixels that are neither (0 = "depth map equal to the CPU
+    reference wherever that is defined")."""
+    from oracle import oracle as orc
+    from oracle_pipeline import OracleMapper, argmax_report
+    nx, ny, nz = dims
+    t1 = time.perf_counter()
+    refs, errs = [], []
+    for c in range(2):
+        mappers[c].evaluateDSI_batch(batches[c])
+        r = OracleMapper(rig["cam"], dimX=nx, dimY=ny, dimZ=nz, min_depth=4.0, max_depth=200.0)
+        r.evaluateDSI(rig["events"][c], rig["trajectories"][c], rig["T_rv_w"])
+        got = mappers[c].dsi_.download()
+        errs.append(float((np.abs(got.astype(np.float64) - r.dsi) / np.maximum(1.0, np.abs(r.dsi))).max()))
+        refs.append(r.dsi)
+    fused.setToFusionOf(mappers[0].dsi_, mappers[1].dsi_, d.FUSE_HM)
+    mappers[0].computeDepthMap(fused)
+    depth, conf, idx = mappers[0].fetchDepthMap()
+    ref = orc.fuse2(refs[0].copy(), refs[1], 2)
+    gf = fused.download()
+    ferr = float((np.abs(gf.astype(np.float64) - ref) / np.maximum(1.0, np.abs(ref))).max())
+    tol = 3e-4                                               # HM of two volumes each within 1e-4
+    rep = argmax_report(idx, ref, tol)
+    planes = mappers[0].raw_depths_vec_
+    rep.update({"dsi_max_rel_err": errs, "fused_max_rel_err": ferr, "dsi_tolerance": 1e-4, "fused_tolerance": tol,
+                "depth_is_plane_of_index": bool(np.array_equal(depth, planes[idx])),
+                "checker": "oracle/ (CPU restatement, parity unpinned), both cameras, all events; %.1f s" %
+                           (time.perf_counter() - t1)})
+    return rep
+
+
+def other_workloads():
+    """The one-GPU lines of BASELINE configs[2] (stream of 50 ms windows) and of the configs[4] shape (4 cameras,
+    1024x1024x256, n-ary GM), each a sub-run of this script with its own roofline block, so that the driver's
+    default run carries them too.  Run after this process has released the GPU."""
+    import subprocess
+    res = {}
+    for name in ("windows", "cameras4"):
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--no-cpu", "--no-host-fed", "--no-extra"]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            line = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1]
+            j = json.loads(line)
+            res[name] = {k: j.get(k) for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline",
+                                                 "step_ms", "windows_per_s", "x_real_time", "timed_region_s")}
+        except Exception as e:                                  # report, do not fail the headline
+            res[name] = {"error": str(e)[:300]}
+    return res
+
+
 def main():
     args = parse()
     D = Dist(args)
@@ -369,6 +444,7 @@ def main():
             voted += first.shape[0] * d.PACKET_SIZE
             mappers.append(m)
         vote_mappers = mappers
+        extra["batch0"] = batches[0]
         fused = d.Grid3D(ctx, nx, ny, nz)
         closers += mappers + batches + [fused]
         temporal = None
@@ -415,7 +491,9 @@ def main():
         rig = syn.stereo_rig(n_distinct * args.events, width=640, height=480, t0=10.0 + 10.0 * rank,
                              duration=n_distinct * dur, seed=77 + rank, n_points=max(args.points, 6000))
         shape = d.ShapeDSI(nx, ny, nz, 4.0, 200.0, 0.0)
-        ws = proc.WindowStream(ctx, (rig["cam"],) * 2, shape, d.FUSE_HM, materialize_fused=args.materialize_fused)
+        fused_vote = (args.fused_vote is not False) and not args.materialize_fused and args.algo in (0, 2)
+        ws = proc.WindowStream(ctx, (rig["cam"],) * 2, shape, d.FUSE_HM, materialize_fused=args.materialize_fused,
+                               fused_vote=fused_vote)
         for m in ws.mappers:
             tune(m)
         vote_mappers = ws.mappers
@@ -454,11 +532,15 @@ def main():
                     "%dx%dx%d DSI, per window: reset + vote x2 + harmonic camera fusion + arg-max + depth-map fetch (%s)"
                     % (dur * 1e3, args.events, nx, ny, nz,
                        "fused DSI written" if args.materialize_fused else
+                       "ONE kernel votes both cameras band by band in LDS, fuses them and keeps the running arg-max: "
+                       "no DSI is written" if fused_vote else
                        "camera fusion computed inside the arg-max kernel, fused DSI not written"))
         parallelism = "1 GPU" if world == 1 else "replicas x%d (independent windows, no collective)" % world
         scaling = "weak"
-        ev_per_launch = voted_per_step / 2.0
+        ev_per_launch = voted_per_step if fused_vote else voted_per_step / 2.0
         extra["host_windows"] = host_wins
+        extra["fused_vote"] = fused_vote
+        extra["last_window"] = wins[-1][0]
 
     else:
         # ---- configs[4] shape: 4 cameras, n-ary GM; N > 1: plane sharding ----
@@ -474,6 +556,7 @@ def main():
             voted += first.shape[0] * d.PACKET_SIZE
             mappers.append(m)
         vote_mappers = mappers
+        extra["batch0"] = batches[0]
         fused = d.Grid3D(ctx, nx, ny, count)
         closers += mappers + batches + [fused]
         if world > 1 and comm is None:
@@ -518,11 +601,14 @@ def main():
         m.vote_kernel_time()
     t0 = time.perf_counter()
     ctx.timer_start()
+    ctx.timeline_mark()
     for _ in range(args.steps):
         step()
+        ctx.timeline_mark()             # a HIP event per step on the compute stream (asynchronous)
     gpu_ms = ctx.timer_stop()
     barrier()
     elapsed = time.perf_counter() - t0
+    step_ms = ctx.timeline_read()
     kt_ms, kt_n = 0.0, 0
     for m in vote_mappers:
         ms, n = m.vote_kernel_time()
@@ -537,18 +623,51 @@ def main():
     value = voted_all * args.steps / elapsed / 1e6      # Mevents/s, whole job
     kern_ms = kt_ms / max(1, kt_n)
     # accepted event-planes of one launch = sum of the DSI it wrote (the 4 bilinear weights of a vote sum to 1)
-    accepted = float(np.sum(vote_mappers[0].dsi_.download(), dtype=np.float64))
+    # records the voting kernel ACCEPTED in one launch (one record = up to `multiplicity` merged events of a packet
+    # with the same pixel = 4 LDS atomics actually issued): the same launch with every multiplicity forced to 1
+    def issued_records(pairs):
+        total = 0.0
+        for m, b in pairs:
+            m._unit_multiplicity(True)
+            m.evaluateDSI_batch(b)
+            total += float(np.sum(m.dsi_.download(), dtype=np.float64))
+            m._unit_multiplicity(False)
+        return total
+
+    if extra.get("fused_vote"):
+        # the fused kernel writes no DSI: build the two camera DSIs of one window once, outside the timed
+        # region, to count the accepted event-planes of a launch (both cameras are voted by one launch)
+        accepted = 0.0
+        for m, b in zip(vote_mappers, extra["last_window"]):
+            m.evaluateDSI_batch(b)
+            accepted += float(np.sum(m.dsi_.download(), dtype=np.float64))
+        records = issued_records(zip(vote_mappers, extra["last_window"]))
+        vote_mappers[0].computeDepthMapOfEvents(vote_mappers, extra["last_window"], d.FUSE_HM)   # restores last_vote_info
+        ctx.synchronize()
+        info = vote_mappers[0].last_vote_info()
+    else:
+        accepted = float(np.sum(vote_mappers[0].dsi_.download(), dtype=np.float64))
+        records = issued_records([(vote_mappers[0], extra["batch0"])]) if "batch0" in extra else None
+        if records is not None:
+            vote_mappers[0].evaluateDSI_batch(extra["batch0"])          # back to the real DSI
 
     out = None
     if rank == 0:
+        # PMC traffic of the dominant kernel is a separate rocprofv3 run (tools/profile_round.sh ->
+        # profiles/traffic.json); it is quoted here only if that run profiled THIS kernel source on THIS
+        # workload shape -- otherwise null (a stale constant would look like a measurement)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and args.workload == "stereo" and (nx, ny, nz) == (346, 260, 100):
+        if os.path.exists(tpath) and args.workload == "stereo":
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                if (tj.get("kernel_source_sha16") == kernel_source_sha16() and tj.get("dims") == [nx, ny, nz]
+                        and tj.get("events_per_launch") == int(ev_per_launch)):
+                    traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = roofline_block(info, kern_ms, kt_n, accepted, ev_per_launch, info_nz(vote_mappers[0]), traffic)
+        roofline = roofline_block(info, kern_ms, kt_n, accepted, ev_per_launch, info_nz(vote_mappers[0]), traffic,
+                                  records)
         streams = stream_kernels(d, ctx) if not args.no_host_fed else None
 
         # ---- host-buffer (PCIe-inclusive) rates, reported beside `value`, never as it ----
@@ -634,6 +753,11 @@ def main():
             cpu = cpu_baseline(d, rig, (nx, ny, nz) if args.workload != "windows" else (nx, ny, nz),
                                10_000_000 if args.workload == "stereo" else 1_000_000)
 
+        parity = None
+        if not args.no_cpu and args.workload == "stereo" and world == 1:
+            parity = parity_block(d, rig, (nx, ny, nz), mappers, batches, fused)
+
+        others = args.workload == "stereo" and world == 1 and not args.no_extra and not args.no_host_fed
         out = {
             "metric": "Mevents/s into DSI (346x260x100) + DSI-fuse GB/s",
             "value": value, "unit": "Mevents/s", "n_gpus": world, "steps": args.steps,
@@ -652,7 +776,18 @@ def main():
             "gpu_ms_per_step_hip_events": gpu_ms / args.steps,
             "timed_region_s": elapsed,
             "host_fed": h2d, "roofline": roofline, "cpu_baseline": cpu, "input_gen_s": t_gen,
+            "step_ms": {"min": float(step_ms.min()), "median": float(np.median(step_ms)), "max": float(step_ms.max()),
+                        "n": int(step_ms.shape[0]), "source": "HIP events between consecutive steps on the compute stream"}
+            if step_ms.shape[0] else None,
+            "parity": parity,
         }
+        if others:
+            out["other_workloads_pending"] = True
+        out["config"]["n_points"] = int(max(args.points, 6000) if args.workload == "windows" else args.points)
+        out["config"]["noise_frac"] = 0.10
+        if parity:
+            out["argmax_agree_frac"] = parity["argmax_agree_frac"]
+            out["near_tie_frac"] = parity["near_tie_frac"]
         if args.workload == "windows":
             out["windows_per_s"] = world * args.steps / elapsed
             out["x_real_time"] = (args.events / 10.0e6) * world * args.steps / elapsed
@@ -666,6 +801,9 @@ def main():
         comm.close()
     ctx.close()
     D.close()
+    if rank == 0 and out is not None and out.get("other_workloads_pending"):
+        out.pop("other_workloads_pending")
+        out["other_workloads"] = other_workloads()
     if rank == 0:
         # RCCL prints a version banner through C stdio; push it out first so that the JSON
         # line is the last line on stdout

@@ -89,6 +89,8 @@ struct dsi_context {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr;
+    std::vector<hipEvent_t> marks;  // dsi_context_timeline_mark
+    size_t n_marks = 0;
     hipEvent_t sync_ev = nullptr;  // dsi_context_wait_for: "everything queued on this stream so far"
     double* ms_accum = nullptr;    // device scalar for mean-square
     // Event batches are uploaded on their own stream so that the upload of the next batch (camera,
@@ -172,6 +174,9 @@ struct dsi_mapper {
     std::vector<float> planes_full;  // the whole depth vector (plane-sharded arg-max: index -> depth)
     float* planes_full_dev = nullptr;
     DevBuf<unsigned long long> argmax_keys;
+    DevBuf<unsigned long long> fused_trace;  // test hook: time stamps of the fused kernel's phases
+    bool fused_trace_on = false;
+    int unit_multiplicity = 0;  // test hook (dsi_test_unit_multiplicity)
     int plane_begin = 0;        // first owned plane of the full depth vector (plane sharding)
     float* planes_dev = nullptr;
     float2* lut_dev = nullptr;
@@ -191,7 +196,8 @@ struct dsi_mapper {
     bool keep_z0 = false;  // tests: materialise event_locations_z0 (stage A as separate kernels)
     dsi_vote_info_t info{};
     // scratch
-    DevBuf<float> centers, H, partials, Rt_tmp, conf, depth;
+    DevBuf<float> centers, H, Rt_tmp, conf, depth;
+    DevBuf<unsigned long long> partials;  // [chunks][partial_stride]: raw 64-bit sums per chunk (several chunks, or accumulation)
     DevBuf<float2> xy;
     DevBuf<dsi::EvRec> sxy;
     DevBuf<unsigned long long> seam;  // [chunks][nz][bands][2][nx]: 64-bit sums of each band's first row and of the row below it
@@ -354,8 +360,8 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
         }
         chunks = (int)std::min<size_t>((size_t)chunks, std::max<size_t>(1, n_packets));
         const size_t vol_bytes = (size_t)g.nx * g.ny * g.nz * sizeof(float);
-        const size_t budget = (size_t)16 << 30;  // partial DSIs may use up to 16 GiB of HBM
-        while (chunks > 1 && (size_t)chunks * (vol_bytes + 16) > budget) --chunks;
+        const size_t budget = (size_t)16 << 30;  // partial DSIs (8 bytes per voxel) may use up to 16 GiB of HBM
+        while (chunks > 1 && (size_t)chunks * (2 * vol_bytes + 32) > budget) --chunks;
     }
     bp->chunks = std::max(1, chunks);
     return true;
@@ -584,6 +590,7 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
     HIP_TRY(m->cuts.reserve(np * geom.nz * bp.bands));
     HIP_TRY(m->seam.reserve((size_t)bp.chunks * geom.nz * bp.bands * 2 * geom.nx));
     const bool direct = (bp.chunks == 1 && !accumulate);
+    bp.raw_out = direct ? 0 : 1;
     if (!direct) HIP_TRY(m->partials.reserve((size_t)bp.chunks * dsi::partial_stride(g->n)));
 
     if (bp.packed == 2 || bp.packed == 4) {
@@ -602,13 +609,13 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
         if (int rc = prep_end(m, ps)) return rc;
         VoteTimer vt(m);
         HIP_TRY(dsi::launch_vote_groups(ctx->stream, m->sxy.p, m->spk.p, m->coef.p, m->gcuts.p, m->nvalid.p + np, (int)np, S, geom,
-                                        bp, direct ? g->data : m->partials.p, m->seam.p));
+                                        bp, direct ? (void*)g->data : (void*)m->partials.p, m->seam.p));
         vt.stop();
     } else {
     if (raw && !m->keep_z0) {
         HIP_TRY(dsi::launch_sort_packets_raw(ps, raw->Rt, raw->x, raw->y, raw->first, m->lut_dev, m->sensor_w, m->sensor_h, geom,
                                              m->centers.p, (int)np, bp.row_pad, m->sxy.p, m->nvalid.p,
-                                             m->rowstart.p));
+                                             m->rowstart.p, m->unit_multiplicity));
     } else {
         if (int rc = stage_a()) return rc;
         HIP_TRY(dsi::launch_sort_packets(ps, xy, (int)np, geom.ny, geom.nz, bp.row_pad, m->sxy.p, m->nvalid.p,
@@ -619,11 +626,11 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
     if (int rc = prep_end(m, ps)) return rc;
     VoteTimer vt(m);
     HIP_TRY(dsi::launch_vote_bands(ctx->stream, m->sxy.p, m->coef.p, m->cuts.p, m->nvalid.p + np, (int)np, geom, bp,
-                                   direct ? g->data : m->partials.p, m->seam.p));
+                                   direct ? (void*)g->data : (void*)m->partials.p, m->seam.p));
     vt.stop();
     }
     // seam rows of every chunk volume from the exact 64-bit sums, then the sum over the chunks
-    HIP_TRY(dsi::launch_seam_rows(ctx->stream, m->seam.p, bp.chunks, geom, bp, direct ? g->data : m->partials.p));
+    HIP_TRY(dsi::launch_seam_rows(ctx->stream, m->seam.p, bp.chunks, geom, bp, direct ? (void*)g->data : (void*)m->partials.p));
     if (!direct)
         HIP_TRY(dsi::launch_reduce_partials(ctx->stream, m->partials.p, bp.chunks, g->n, g->data,
                                             accumulate ? 1 : 0));
@@ -694,6 +701,8 @@ int dsi_context_destroy(dsi_context_t* ctx)
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->ms_accum) (void)hipFree(ctx->ms_accum);
     if (ctx->collapse_scratch) (void)hipFree(ctx->collapse_scratch);
+    for (hipEvent_t ev : ctx->marks) (void)hipEventDestroy(ev);
+    ctx->marks.clear();
     if (ctx->t0) (void)hipEventDestroy(ctx->t0);
     if (ctx->t1) (void)hipEventDestroy(ctx->t1);
     if (ctx->sync_ev) (void)hipEventDestroy(ctx->sync_ev);
@@ -737,6 +746,33 @@ int dsi_context_timer_stop(dsi_context_t* ctx, float* elapsed_ms)
     HIP_TRY(hipEventRecord(ctx->t1, ctx->stream));
     HIP_TRY(hipEventSynchronize(ctx->t1));
     HIP_TRY(hipEventElapsedTime(elapsed_ms, ctx->t0, ctx->t1));
+    return DSI_OK;
+}
+
+int dsi_context_timeline_mark(dsi_context_t* ctx)
+{
+    REQUIRE(ctx, DSI_ERR_INVALID, "context is null");
+    if (int rc = set_device(ctx)) return rc;
+    if (ctx->n_marks == ctx->marks.size()) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreate(&e));
+        ctx->marks.push_back(e);
+    }
+    HIP_TRY(hipEventRecord(ctx->marks[ctx->n_marks], ctx->stream));
+    ++ctx->n_marks;
+    return DSI_OK;
+}
+
+int dsi_context_timeline_read(dsi_context_t* ctx, float* intervals_ms, size_t capacity, size_t* n_intervals)
+{
+    REQUIRE(ctx && n_intervals, DSI_ERR_INVALID, "null argument");
+    if (int rc = set_device(ctx)) return rc;
+    const size_t n = ctx->n_marks > 0 ? ctx->n_marks - 1 : 0;
+    *n_intervals = n;
+    if (ctx->n_marks) HIP_TRY(hipEventSynchronize(ctx->marks[ctx->n_marks - 1]));
+    for (size_t i = 0; i < n && i < capacity && intervals_ms; ++i)
+        HIP_TRY(hipEventElapsedTime(&intervals_ms[i], ctx->marks[i], ctx->marks[i + 1]));
+    ctx->n_marks = 0;
     return DSI_OK;
 }
 
@@ -1072,6 +1108,7 @@ int dsi_mapper_destroy(dsi_mapper_t* m)
     m->centers.release();
     m->H.release();
     m->partials.release();
+    m->fused_trace.release();
     m->Rt_tmp.release();
     m->conf.release();
     m->depth.release();
@@ -1462,7 +1499,8 @@ int dsi_mapper_depth_map_of_events(dsi_mapper_t* out, dsi_mapper_t* const* mappe
             HIP_TRY(hipMemsetAsync(m->nvalid.p, 0, ((size_t)geom.nz + 8) * sizeof(uint32_t), st));
         } else {
             HIP_TRY(dsi::launch_sort_packets_raw(st, b->Rt, b->x, b->y, b->first, m->lut_dev, m->sensor_w, m->sensor_h, m->geom,
-                                                 m->centers.p, (int)np, bp.row_pad, m->sxy.p, m->nvalid.p, m->rowstart.p));
+                                                 m->centers.p, (int)np, bp.row_pad, m->sxy.p, m->nvalid.p, m->rowstart.p,
+                                                 m->unit_multiplicity));
             HIP_TRY(dsi::launch_plane_coef(st, m->centers.p, m->planes_dev, m->rowstart.p, m->nvalid.p, (int)np, m->geom, bp,
                                            m->coef.p, m->cuts.p));
         }
@@ -1487,7 +1525,8 @@ int dsi_mapper_depth_map_of_events(dsi_mapper_t* out, dsi_mapper_t* const* mappe
     HIP_TRY(hipMemsetAsync(out->argmax_keys.p, 0, npix * sizeof(unsigned long long), st));
     {
         VoteTimer vt(mappers[0]);
-        HIP_TRY(dsi::launch_vote_fuse_argmax(st, cams, geom, bp, op, nullptr, out->argmax_keys.p));
+        HIP_TRY(dsi::launch_vote_fuse_argmax(st, cams, geom, bp, op, nullptr, out->argmax_keys.p,
+                                             mappers[0]->fused_trace_on ? mappers[0]->fused_trace.p : nullptr));
         vt.stop();
     }
     // keys -> confidence, index, depth over the planes the cameras voted (mapper_emvs_stereo.cpp:302-313)
@@ -1596,6 +1635,41 @@ int dsi_mapper_last_vote_info(const dsi_mapper_t* m, dsi_vote_info_t* info)
 {
     REQUIRE(m && info, DSI_ERR_INVALID, "null argument");
     *info = m->info;
+    return DSI_OK;
+}
+
+/* test hook (not in the public header): with flag != 0 the packet sort gives every merged record the
+ * multiplicity 1 instead of the number of events it stands for, so that the sum of the DSI counts the
+ * RECORDS the voting kernel accepted = a quarter of the LDS atomics it issued (bench.py: roofline.frac_issued) */
+DSI_API int dsi_test_unit_multiplicity(dsi_mapper_t* m, int flag)
+{
+    REQUIRE(m, DSI_ERR_INVALID, "mapper is null");
+    m->unit_multiplicity = flag != 0;
+    return DSI_OK;
+}
+
+/* test hooks (not in the public header): time stamps of the phases of the next fused vote kernels that
+ * mapper m leads (dsi_mapper_depth_map_of_events with mappers[0] == m): [workgroup][64 phases][16 waves][4]
+ * ticks of the 100 MHz clock; *_read synchronises, copies and switches tracing off */
+DSI_API int dsi_test_fused_trace_enable(dsi_mapper_t* m, size_t* n_words)
+{
+    REQUIRE(m && n_words, DSI_ERR_INVALID, "null argument");
+    if (int rc = set_device(m->ctx)) return rc;
+    *n_words = dsi::fused_trace_words();
+    HIP_TRY(m->fused_trace.reserve(*n_words));
+    HIP_TRY(hipMemsetAsync(m->fused_trace.p, 0, *n_words * sizeof(unsigned long long), m->ctx->stream));
+    m->fused_trace_on = true;
+    return DSI_OK;
+}
+
+DSI_API int dsi_test_fused_trace_read(dsi_mapper_t* m, unsigned long long* host, size_t n_words)
+{
+    REQUIRE(m && host, DSI_ERR_INVALID, "null argument");
+    REQUIRE(m->fused_trace_on && n_words <= m->fused_trace.cap, DSI_ERR_INVALID, "tracing is not enabled");
+    if (int rc = set_device(m->ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+    HIP_TRY(hipMemcpy(host, m->fused_trace.p, n_words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    m->fused_trace_on = false;
     return DSI_OK;
 }
 

@@ -56,13 +56,15 @@ struct BandPlan {
                         // + mappings 5 / 6: kVfillScratchWords * 8 B per wave (tail-bit words / run table)
     int scratch_offset; // mapping 5: byte offset of that area behind the band
     int persistent;     // packed mappings: workgroups pull work items from per-XCD counters
+    int raw_out;        // the voting kernel's `out` is 1: the chunks' partial volumes of raw 64-bit sums (unsigned long long
+                        // [chunks][partial_stride]), summed exactly by k_reduce_partials; 0: the fp32 DSI itself (one chunk)
     int halo;           // 1: a band also takes the events of the row above its first owned row and keeps a halo row
                         // on either side in LDS ((band_rows + 2) rows; k_vote_fuse_argmax), 0: carry row ((band_rows + 1))
     int experiment;     // DSI_EXPERIMENT (timing experiments only, results are wrong): 1 no votes, 2 no flush
 };
 
-// distance in floats between the partial volumes of consecutive packet chunks: the volume size
-// rounded up to 4 floats, so that every partial volume starts 16-byte aligned (float4 sweeps)
+// distance in voxels between the partial volumes of consecutive packet chunks: the volume size
+// rounded up to 4 voxels, so that every partial volume starts 16-byte aligned
 __host__ __device__ inline size_t partial_stride(size_t n_voxels) { return (n_voxels + 3) & ~(size_t)3; }
 
 // ---- stage A ---------------------------------------------------------------
@@ -79,7 +81,7 @@ hipError_t launch_vote_global(hipStream_t s, const float2* xy, const float* cent
 hipError_t launch_sort_packets_raw(hipStream_t s, const float* Rt, const uint16_t* ex, const uint16_t* ey,
                                    const uint32_t* packet_first, const float2* lut, int sensor_w, int sensor_h, const Geom& g,
                                    float* centers, int np, int pad, EvRec* sxy, uint32_t* nvalid,
-                                   uint16_t* rowstart);
+                                   uint16_t* rowstart, int unit_multiplicity = 0);
 hipError_t launch_sort_packets(hipStream_t s, const float2* xy, int np, int ny, int nz, int pad,
                                EvRec* sxy, uint32_t* nvalid, uint16_t* rowstart);
 hipError_t launch_plane_coef(hipStream_t s, const float* centers, const float* planes,
@@ -87,19 +89,19 @@ hipError_t launch_plane_coef(hipStream_t s, const float* centers, const float* p
                              const Geom& g, const BandPlan& bp, PlaneCoef* coef, uint32_t* cuts);
 hipError_t launch_vote_bands(hipStream_t s, const EvRec* sxy, const PlaneCoef* coef,
                              const uint32_t* cuts, const uint32_t* slow_any, int np, const Geom& g,
-                             const BandPlan& bp, float* out, unsigned long long* seam);
+                             const BandPlan& bp, void* out, unsigned long long* seam);
 // seam rows (first row of every band but the first, of every plane of every chunk volume in `out`) =
 // fl((head + carry) * 2^-31) from the voting kernel's 64-bit sums seam[chunks][nz][bands][2][nx]
 hipError_t launch_seam_rows(hipStream_t s, const unsigned long long* seam, int chunks, const Geom& g,
-                            const BandPlan& bp, float* out);
+                            const BandPlan& bp, void* out);
 hipError_t launch_sort_groups(hipStream_t s, const float2* xy, int np, int S, int ny, int nz, int pad,
                               EvRec* sxy, uint8_t* spk, uint32_t* nvalid, uint16_t* rowstart);
 hipError_t launch_group_cuts(hipStream_t s, const uint32_t* prow, const uint16_t* rowstart, int np,
                              int S, const Geom& g, const BandPlan& bp, uint32_t* gcuts);
 hipError_t launch_vote_groups(hipStream_t s, const EvRec* sxy, const uint8_t* spk,
                               const PlaneCoef* coef, const uint32_t* gcuts, const uint32_t* slow_any,
-                              int np, int S, const Geom& g, const BandPlan& bp, float* out, unsigned long long* seam);
-hipError_t launch_reduce_partials(hipStream_t s, const float* partials, int chunks, size_t n,
+                              int np, int S, const Geom& g, const BandPlan& bp, void* out, unsigned long long* seam);
+hipError_t launch_reduce_partials(hipStream_t s, const unsigned long long* partials, int chunks, size_t n,
                                   float* dsi, int accumulate);
 // ---- stage B fused with the camera fusion and the arg-max (no DSI leaves the CU) ----
 // the per-camera tables of the banded vote (k_sort_packets / k_plane_coef outputs, built with bp.halo = 1)
@@ -120,7 +122,8 @@ struct FusedCameras {
 int fused_grid_blocks();
 size_t fused_max_cells(int mapping);  // (band_rows + 2) * nx may not exceed this
 hipError_t launch_vote_fuse_argmax(hipStream_t s, const FusedCameras& cams, const Geom& g, const BandPlan& bp, int op,
-                                   const uint32_t* splits, unsigned long long* keys);
+                                   const uint32_t* splits, unsigned long long* keys, unsigned long long* trace = nullptr);
+size_t fused_trace_words();  // trace: [workgroup][64 phases][16 waves][4 stamps] of 100 MHz ticks, or nullptr
 // ---- Grid3D ops ------------------------------------------------------------
 hipError_t launch_fuse2(hipStream_t s, float* a, const float* g, size_t n, int op);
 hipError_t launch_fuse2_into(hipStream_t s, float* dst, const float* a, const float* g, size_t n,

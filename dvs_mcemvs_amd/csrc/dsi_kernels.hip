@@ -259,6 +259,7 @@ struct RawEvents {
     int sensor_w, sensor_h;
     Geom g;
     float* centers;              // out [np][3]
+    int unit_multiplicity;       // test hook: every record gets multiplicity 1 (the DSI then counts accepted RECORDS)
 };
 
 // RAW (the events come as sensor pixels, stage A fused in): two events of a packet have the same z0
@@ -360,6 +361,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         if (bin[h] >= 0) {
             rank[h] = atomicAdd(&hist[bin[h]], 1u);
             mult[h] = RAW ? (uint32_t)(hkey[slot[h]] >> 32) : hcnt[slot[h]];  // (the records are staged over hkey later)
+            if (RAW && raw.unit_multiplicity) mult[h] = 1u;
         }
     __syncthreads();
     // exclusive scan of hist[0..nb): each thread owns a contiguous slice
@@ -561,9 +563,21 @@ __global__ __launch_bounds__(1024) void k_plane_coef(const float* __restrict__ c
 using acc_t = unsigned long long;
 // k_vote_fuse_argmax keeps two fp32 values and a plane index per band cell in registers: 1024-cell stretches per
 // thread.  20 cover the whole LDS (160 KB of 8-byte cells); the vector-fill mappings leave fewer registers: 16.
+constexpr int kFusedTracePhases = 64;
 __host__ __device__ constexpr int fused_cells_per_thread(int mapping) { return (mapping == 5 || mapping == 6) ? 16 : 20; }
 constexpr float kFixScale = 2147483648.f;      // 2^31
 constexpr double kFixInv = 1.0 / 2147483648.0;  // 2^-31
+
+// Q33.31 sum -> fp32, ONE rounding.  For v < 2^52 the double whose bits are (1044 << 52) | v is exactly
+// 2^21 + v * 2^-31; subtracting 2^21 is exact, so two double-rate instructions replace the 64-bit
+// integer -> double conversion (two conversions, a scale and an add).  Larger sums (> 2 M votes in one
+// voxel) take the general conversion, exact up to 2^53.
+__device__ __forceinline__ float fix_to_float(acc_t v)
+{
+    if (__builtin_expect((v >> 52) == 0ull, 1))
+        return (float)(__longlong_as_double((long long)(v | 0x4140000000000000ull)) - 2097152.0);
+    return (float)((double)v * kFixInv);
+}
 
 // the four bilinear votes of m identical events (cartesian3dgrid.h:261-270) into the band
 __device__ __forceinline__ void vote4(acc_t* __restrict__ band, int idx, int nx, float fx, float fy,
@@ -593,17 +607,25 @@ __device__ __forceinline__ acc_t* seam_rows(acc_t* seam, int c, int z, int j, co
     return seam + ((((size_t)c * g.nz + z) * bp.bands + j) * 2) * g.nx;
 }
 
+// `out` + `off`: the band's first owned voxel in the chunk's volume -- fp32 (the DSI itself: one chunk, no
+// accumulation) or, raw != 0, the chunk's PARTIAL volume of raw 64-bit sums, which k_reduce_partials adds up
+// exactly over the chunks before the one rounding to fp32: the DSI is fl(exact sum of all votes) for any
+// number of chunks as well.
 template <int BLOCK, bool CLEAR>
-__device__ __forceinline__ void flush_band_t(acc_t* __restrict__ band, int nx, int n_out, float* __restrict__ dst,
-                                             acc_t* __restrict__ seam_j, int j, int bands)
+__device__ __forceinline__ void flush_band_t(acc_t* __restrict__ band, int nx, int n_out, void* __restrict__ out, size_t off,
+                                             int raw, acc_t* __restrict__ seam_j, int j, int bands)
 {
     const int head = j >= 1 ? nx : 0;  // cells that go to the seam buffer instead of the volume
+    float* __restrict__ dstf = reinterpret_cast<float*>(out) + off;
+    acc_t* __restrict__ dstr = reinterpret_cast<acc_t*>(out) + off;
     for (int i = threadIdx.x; i < n_out; i += BLOCK) {
         const acc_t v = band[i];
         if (i < head)
             seam_j[i] = v;
+        else if (raw)
+            dstr[i] = v;
         else
-            dst[i] = (float)((double)v * kFixInv);  // < 2^53: exact in f64, one rounding to f32
+            dstf[i] = fix_to_float(v);  // exact in f64, one rounding to f32
         if (CLEAR) band[i] = 0;
     }
     acc_t* src = band + n_out;
@@ -614,18 +636,18 @@ __device__ __forceinline__ void flush_band_t(acc_t* __restrict__ band, int nx, i
 }
 
 template <int BLOCK>
-__device__ __forceinline__ void flush_band(acc_t* __restrict__ band, int nx, int n_out, float* __restrict__ dst,
-                                           acc_t* __restrict__ seam_j, int j, int bands)
+__device__ __forceinline__ void flush_band(acc_t* __restrict__ band, int nx, int n_out, void* __restrict__ out, size_t off,
+                                           int raw, acc_t* __restrict__ seam_j, int j, int bands)
 {
-    flush_band_t<BLOCK, false>(band, nx, n_out, dst, seam_j, j, bands);
+    flush_band_t<BLOCK, false>(band, nx, n_out, out, off, raw, seam_j, j, bands);
 }
 
 // the same, leaving the band zeroed for the workgroup's next work item (persistent kernel)
 template <int BLOCK>
-__device__ __forceinline__ void flush_band_and_clear(acc_t* __restrict__ band, int nx, int n_out, float* __restrict__ dst,
-                                                     acc_t* __restrict__ seam_j, int j, int bands)
+__device__ __forceinline__ void flush_band_and_clear(acc_t* __restrict__ band, int nx, int n_out, void* __restrict__ out,
+                                                     size_t off, int raw, acc_t* __restrict__ seam_j, int j, int bands)
 {
-    flush_band_t<BLOCK, true>(band, nx, n_out, dst, seam_j, j, bands);
+    flush_band_t<BLOCK, true>(band, nx, n_out, out, off, raw, seam_j, j, bands);
 }
 
 template <int BLOCK>
@@ -633,7 +655,7 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands(const EvRec* __restrict__ 
                                                       const PlaneCoef* __restrict__ coef,
                                                       const uint32_t* __restrict__ cuts, int np,
                                                       Geom g, BandPlan bp,
-                                                      float* __restrict__ out,
+                                                      void* __restrict__ out,
                                                       acc_t* __restrict__ seam)
 {
     extern __shared__ acc_t band[];
@@ -744,8 +766,8 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands(const EvRec* __restrict__ 
 
     // owned rows are contiguous in the [z][y][x] volume: a linear coalesced copy
     const size_t vol = partial_stride((size_t)g.nx * g.ny * g.nz);
-    float* __restrict__ dst = out + (size_t)c * vol + ((size_t)z * g.ny + r0) * nx;
-    flush_band<BLOCK>(band, nx, (r1 - r0) * nx, dst, seam_rows(seam, c, z, j, g, bp), j, bp.bands);
+    const size_t off = (size_t)c * vol + ((size_t)z * g.ny + r0) * nx;
+    flush_band<BLOCK>(band, nx, (r1 - r0) * nx, out, off, bp.raw_out, seam_rows(seam, c, z, j, g, bp), j, bp.bands);
 }
 
 // (3b) the same work item decomposition for SHORT runs (tall or wide grids: a band of a
@@ -1339,6 +1361,165 @@ __device__ __forceinline__ void packed_stream_asm(const EvRec* sxy, const uint4*
           "v62", "v63");
 }
 
+// ---- the packed stream with DEALT passes (the fused kernel: one workgroup per CU, nothing else hides a
+// workgroup's tail).  With fixed assignments (wave w takes passes w, w + 16, ...) the waves of a workgroup
+// finish a work item at very different times -- 512 x 512 x 200, 489 packets in passes of 8: 61 passes over
+// 16 waves is 3 or 4 each, and waves with EQUAL work still spread by 20 % (time stamps of
+// tools/fused_trace.py: first wave done after 11.3 us, median 13.7, last 16.8) -- and everybody waits at the
+// item's barrier.  Here wave w starts with passes w and w + 16 and draws every further pass from a counter in
+// LDS (set to 32 by the item's set-up): ds_add_rtn_u32 by one lane, two passes ahead, so that neither the
+// atomic's round trip through the vote-filled LDS queue nor the next pass's cut words are ever waited for:
+//   at the start of pass k:  its cut words (requested at pass k-1) arrive; the index of pass k+1 (drawn at
+//   pass k-1) is read; pass k+1's cut words are requested; pass k+2 is drawn.
+// The sums are integer, so which wave votes a pass changes no bit.
+//   s53 current pass, s55 next pass, s54 packets of the current pass, s42 packet within the pass,
+//   v34 the drawn pass index (lane 0); everything else as in packed_stream_asm.
+#define DSI_ASM_FILL_DEAL(NOUT, L)                                                                 \
+    "s_mov_b32 s44, 0\n"                                                                            \
+    "Ltop" L "%=:\n\t"                                                                              \
+    "s_cmp_ge_i32 s40, s41\n\t"                                                                     \
+    "s_cbranch_scc1 Lnext" L "%=\n\t"                                                               \
+    "s_sub_i32 s45, 64, s44\n\t"          /* room in the batch */                                   \
+    "s_sub_i32 s46, s41, s40\n\t"         /* records left in the run */                             \
+    "s_min_i32 s45, s45, s46\n\t"         /* take */                                                \
+    "s_sub_i32 s46, s40, s44\n\t"         /* record of lane 0 if the run started there */           \
+    "s_lshl_b64 exec, -1, s44\n\t"        /* lanes >= fill */                                       \
+    "v_add_u32 v40, s46, %15\n\t"                                                                   \
+    "s_mov_b64 exec, -1\n\t"                                                                        \
+    "s_add_i32 s44, s44, s45\n\t"                                                                   \
+    "s_add_i32 s40, s40, s45\n\t"                                                                   \
+    "s_cmp_lt_u32 s44, 64\n\t"                                                                      \
+    "s_cbranch_scc0 Ldone" L "%=\n"       /* not full => the run is exhausted */                    \
+    "Lnext" L "%=:\n\t"                                                                             \
+    "s_add_i32 s42, s42, 1\n\t"                                                                     \
+    "s_cmp_ge_i32 s42, s54\n\t"                                                                     \
+    "s_cbranch_scc1 Lreload" L "%=\n\t"   /* the pass is exhausted */                               \
+    "v_readlane_b32 s46, v41, s42\n\t"    /* the packet's cut word */                               \
+    "s_addk_i32 s43, 0x400\n"                                                                       \
+    "Lhave" L "%=:\n\t"                                                                             \
+    "s_and_b32 s45, s46, 0xffff\n\t"                                                                \
+    "s_lshr_b32 s46, s46, 16\n\t"                                                                   \
+    "s_add_i32 s40, s43, s45\n\t"                                                                   \
+    "s_add_i32 s41, s43, s46\n\t"                                                                   \
+    "s_branch Ltop" L "%=\n"                                                                        \
+    "Lreload" L "%=:\n\t"                                                                           \
+    "s_mov_b32 s53, s55\n\t"              /* the pass whose cut words are in flight */              \
+    "s_cmp_ge_i32 s53, %3\n\t"                                                                      \
+    "s_cbranch_scc1 Leos" L "%=\n\t"                                                                \
+    "s_lshl_b32 s45, s53, %7\n\t"                                                                   \
+    "s_add_i32 s45, s45, %5\n\t"          /* its first packet */                                    \
+    "s_sub_i32 s54, %6, s45\n\t"                                                                    \
+    "s_min_i32 s54, s54, %4\n\t"          /* its packets (the last pass may be short) */            \
+    "s_lshl_b32 s43, s45, 10\n\t"                                                                   \
+    "s_cmp_eq_u32 s50, 0\n\t"                                                                       \
+    "s_cbranch_scc1 Lwall" L "%=\n\t"                                                               \
+    "s_waitcnt vmcnt(3)\n\t"              /* (a GATHER has been issued since: all but the 3 newest) */ \
+    "s_branch Lgot" L "%=\n"                                                                        \
+    "Lwall" L "%=:\n\t"                                                                             \
+    "s_waitcnt vmcnt(0)\n"                                                                          \
+    "Lgot" L "%=:\n\t"                                                                              \
+    "v_mov_b32 v41, v35\n\t"                                                                        \
+    "s_waitcnt lgkmcnt(0)\n\t"            /* the draw of one pass ago */                            \
+    "v_readfirstlane_b32 s55, v34\n\t"                                                              \
+    "s_lshl_b32 s45, s55, %7\n\t"                                                                   \
+    "s_add_i32 s45, s45, %5\n\t"                                                                    \
+    "v_add_u32 v58, s45, %15\n\t"         /* the next pass's cut words travel during this pass */   \
+    "v_min_i32 v58, %8, v58\n\t"                                                                    \
+    "v_lshlrev_b32 v58, 2, v58\n\t"                                                                 \
+    "global_load_dword v35, v58, %2\n\t"                                                            \
+    "s_mov_b32 s50, 0\n\t"                                                                          \
+    "s_mov_b64 exec, 1\n\t"                                                                         \
+    "ds_add_rtn_u32 v34, %16, %17\n\t"    /* draw the pass after the next */                        \
+    "s_mov_b64 exec, -1\n\t"                                                                        \
+    "s_mov_b32 s42, 0\n\t"                                                                          \
+    "v_readfirstlane_b32 s46, v41\n\t"                                                              \
+    "s_branch Lhave" L "%=\n"                                                                       \
+    "Leos" L "%=:\n\t"                    /* stream over: unreached lanes -> multiplicity-0 record */ \
+    "s_mov_b32 s40, 0\n\t"                                                                          \
+    "s_mov_b32 s41, 0\n\t"                                                                          \
+    "s_mov_b32 s42, 0\n\t"                                                                          \
+    "s_mov_b32 s54, 0\n\t"                /* (a later fill comes straight back here) */             \
+    "s_cmp_eq_u32 s44, 0\n\t"                                                                       \
+    "s_cbranch_scc1 Ldone" L "%=\n\t"                                                               \
+    "s_lshl_b64 exec, -1, s44\n\t"                                                                  \
+    "v_mov_b32 v40, %14\n\t"                                                                        \
+    "s_mov_b64 exec, -1\n"                                                                          \
+    "Ldone" L "%=:\n\t"                                                                             \
+    "s_mov_b32 " NOUT ", s44\n\t"
+
+// passes of `1 << lg_group` packets of [p_begin, p_end); wave `wave` of `n_waves`; pass_counter: LDS word set
+// to 2 * n_waves before the workgroup's waves enter
+__device__ __forceinline__ void packed_stream_asm_dealt(const EvRec* sxy, const uint4* coef4,
+                                                        const uint32_t* cutz, char* band_bytes,
+                                                        int p_begin, int p_end, int lg_group, int wave, int n_waves,
+                                                        int lane, int nx, int Li, int Ui, int row_base,
+                                                        uint32_t dummy_eo, int* pass_counter)
+{
+    const int group = 1 << lg_group;
+    int npass = (p_end - p_begin + group - 1) >> lg_group;
+    if (Ui - 1 < Li) npass = 0;  // no acceptable row (the unsigned range test needs Ui-1-Li >= 0)
+    const int s_npass = __builtin_amdgcn_readfirstlane(npass);
+    const int s_group = __builtin_amdgcn_readfirstlane(group);
+    const int s_p_begin = __builtin_amdgcn_readfirstlane(p_begin);
+    const int s_p_end = __builtin_amdgcn_readfirstlane(p_end);
+    const int s_lg = __builtin_amdgcn_readfirstlane(lg_group);
+    const int s_p_last = __builtin_amdgcn_readfirstlane(p_end - 1);
+    const int s_nx8 = __builtin_amdgcn_readfirstlane(nx * 8);
+    const int lds_base = (int)(uintptr_t)band_bytes;  // LDS byte offset of the band
+    const int s_cbase = __builtin_amdgcn_readfirstlane(lds_base - row_base * nx * 8);
+    const int s_nxm2 = __builtin_amdgcn_readfirstlane(nx - 2);
+    const int s_Li = __builtin_amdgcn_readfirstlane(Li);
+    const int s_Uim1 = __builtin_amdgcn_readfirstlane(Ui - 1 - Li);
+    const uint32_t s_dummy = __builtin_amdgcn_readfirstlane(dummy_eo);
+    const int ctr_addr = (int)(uintptr_t)pass_counter;
+    const int s_first = __builtin_amdgcn_readfirstlane(wave);
+    asm volatile(
+        "s_mov_b32 s42, 0\n\t"
+        "s_mov_b32 s54, 0\n\t"
+        "s_mov_b32 s40, 0\n\t"
+        "s_mov_b32 s41, 0\n\t"
+        "s_mov_b32 s43, 0\n\t"
+        "s_mov_b32 s55, %18\n\t"             // the first pass: the wave's index ...
+        "v_mov_b32 v34, %19\n\t"             // ... the second: n_waves further
+        "v_mov_b32 v40, 0\n\t"
+        "v_mov_b32 v41, 0\n\t"
+        "s_mov_b32 s50, 0\n\t"
+        "s_lshl_b32 s45, s55, %7\n\t"
+        "s_add_i32 s45, s45, %5\n\t"
+        "v_add_u32 v58, s45, %15\n\t"        // the first pass's cut words
+        "v_min_i32 v58, %8, v58\n\t"
+        "v_max_i32 v58, 0, v58\n\t"          // (a camera without packets has p_end - 1 = -1)
+        "v_lshlrev_b32 v58, 2, v58\n\t"
+        "global_load_dword v35, v58, %2\n\t"
+        DSI_ASM_FILL_DEAL("s47", "a")
+        DSI_ASM_GATHER("v[42:44]", "v[46:49]", "v45")
+        "s_cmp_eq_u32 s47, 0\n\t"
+        "s_cbranch_scc1 Lend%=\n"
+        "Lloop%=:\n\t"
+        DSI_ASM_FILL_DEAL("s48", "b")
+        DSI_ASM_GATHER("v[50:52]", "v[54:57]", "v53")
+        "s_waitcnt vmcnt(3)\n\t"
+        DSI_ASM_VOTE("v42", "v43", "v44", "v46", "v47", "v48", "v49", "v45")
+        "s_cmp_eq_u32 s48, 0\n\t"
+        "s_cbranch_scc1 Lend%=\n\t"
+        DSI_ASM_FILL_DEAL("s47", "c")
+        DSI_ASM_GATHER("v[42:44]", "v[46:49]", "v45")
+        "s_waitcnt vmcnt(3)\n\t"
+        DSI_ASM_VOTE("v50", "v51", "v52", "v54", "v55", "v56", "v57", "v53")
+        "s_cmp_lg_u32 s47, 0\n\t"
+        "s_cbranch_scc1 Lloop%=\n"
+        "Lend%=:\n\t"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)"
+        :
+        : "s"(sxy), "s"(coef4), "s"(cutz), "s"(s_npass), "s"(s_group), "s"(s_p_begin), "s"(s_p_end),
+          "s"(s_lg), "s"(s_p_last), "s"(s_nx8), "s"(s_cbase), "s"(s_nxm2), "s"(s_Li), "s"(s_Uim1),
+          "s"(s_dummy), "v"(lane), "v"(ctr_addr), "v"(1), "s"(s_first), "v"(wave + n_waves)
+        : "memory", "scc", "vcc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s50", "s53", "s54", "s55",
+          "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48",
+          "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61",
+          "v62", "v63");
+}
+
 // ---- lane mapping 5, hand-scheduled: the batches of one range (<= 64 batches = 4096 slots) of a
 // vector-fill pass (see vfill_stream for the slot -> record mapping; the per-pass tables are built
 // by compiled code and handed over through the wave's LDS scratch).  Per batch: 3 v_readlane +
@@ -1797,8 +1978,9 @@ __device__ __forceinline__ void group_stream_asm(const EvRec* sxy, const uint4* 
 // row `row_base`; the item accepts events with floor(Y) in [Li, Ui - 1].
 // MAPPING = the lane mapping (1 packed / hand-scheduled, 3 packed / compiled, 5 vector fill /
 // hand-scheduled, 6 vector fill / compiled).  TWO_SETS: the vector fill keeps two instead of three batches of
-// gathers in flight (32 instead of 40 named registers; the fused kernel needs the difference).
-template <int BLOCK, int MAPPING, bool TWO_SETS = false>
+// gathers in flight (32 instead of 40 named registers; the fused kernel needs the difference).  DEAL: the hand-scheduled
+// packed stream draws its passes from *s_pass instead of taking every kWaves-th one.
+template <int BLOCK, int MAPPING, bool TWO_SETS = false, bool DEAL = false>
 __device__ __forceinline__ void stream_item(const EvRec* __restrict__ sxy, const PlaneCoef* __restrict__ coef,
                                             const uint32_t* __restrict__ cuts, const uint32_t* __restrict__ slow_any,
                                             int np, const Geom& g, const BandPlan& bp, int j, int z, int p_begin,
@@ -1852,6 +2034,10 @@ __device__ __forceinline__ void stream_item(const EvRec* __restrict__ sxy, const
         else if constexpr (MAPPING == 3)
             packed_stream<false>(sxy, coef4, cutz, band_bytes, p_begin + wave * group, p_end, lg_group,
                                  kWaves * group, lane, nx, Li, Ui, row_base, dummy_eo);
+        else if constexpr (DEAL)
+            // (*s_pass = 2 * kWaves, set by the item's set-up; passes of 4 packets unless bp.pass_lg says otherwise)
+            packed_stream_asm_dealt(sxy, coef4, cutz, band_bytes, p_begin, p_end, bp.pass_lg > 0 ? bp.pass_lg : 2, wave, kWaves,
+                                    lane, nx, Li, Ui, row_base, dummy_eo, s_pass);
         else
             packed_stream_asm(sxy, coef4, cutz, band_bytes, p_begin + wave * group, p_end, lg_group,
                               kWaves * group, lane, nx, Li, Ui, row_base, dummy_eo);
@@ -1867,7 +2053,7 @@ __device__ __forceinline__ void vote_bands_packed_body(const EvRec* __restrict__
                                                        const uint32_t* __restrict__ cuts,
                                                        const uint32_t* __restrict__ slow_any,
                                                        int np, const Geom& g, const BandPlan& bp,
-                                                       float* __restrict__ out,
+                                                       void* __restrict__ out,
                                                        acc_t* __restrict__ seam,
                                                        uint32_t* __restrict__ work_counters)
 {
@@ -1928,13 +2114,13 @@ __device__ __forceinline__ void vote_bands_packed_body(const EvRec* __restrict__
     __syncthreads();
 
     const size_t vol = partial_stride((size_t)g.nx * g.ny * g.nz);
-    float* __restrict__ dst = out + (size_t)c * vol + ((size_t)z * g.ny + r0) * nx;
+    const size_t off = (size_t)c * vol + ((size_t)z * g.ny + r0) * nx;
     if (!work_counters) {
-        flush_band<BLOCK>(band, nx, (r1 - r0) * nx, dst, seam_rows(seam, c, z, j, g, bp), j, bp.bands);
+        flush_band<BLOCK>(band, nx, (r1 - r0) * nx, out, off, bp.raw_out, seam_rows(seam, c, z, j, g, bp), j, bp.bands);
         break;
     }
     if (bp.experiment != 2)  // (2: timing experiment without the flush)
-        flush_band_and_clear<BLOCK>(band, nx, (r1 - r0) * nx, dst, seam_rows(seam, c, z, j, g, bp), j, bp.bands);
+        flush_band_and_clear<BLOCK>(band, nx, (r1 - r0) * nx, out, off, bp.raw_out, seam_rows(seam, c, z, j, g, bp), j, bp.bands);
     __syncthreads();  // every thread has read s_item and cleared its cells before thread 0 draws again
     }
 }
@@ -1942,7 +2128,7 @@ __device__ __forceinline__ void vote_bands_packed_body(const EvRec* __restrict__
 template <int BLOCK, int MAPPING>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_vote_bands_packed(
     const EvRec* __restrict__ sxy, const PlaneCoef* __restrict__ coef, const uint32_t* __restrict__ cuts,
-    const uint32_t* __restrict__ slow_any, int np, Geom g, BandPlan bp, float* __restrict__ out,
+    const uint32_t* __restrict__ slow_any, int np, Geom g, BandPlan bp, void* __restrict__ out,
     acc_t* __restrict__ seam, uint32_t* __restrict__ work_counters)
 {
     vote_bands_packed_body<BLOCK, MAPPING>(sxy, coef, cuts, slow_any, np, g, bp, out, seam, work_counters);
@@ -1954,7 +2140,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 template <int BLOCK, int MAPPING>
 __global__ __launch_bounds__(BLOCK) void k_vote_bands_vfill(
     const EvRec* __restrict__ sxy, const PlaneCoef* __restrict__ coef, const uint32_t* __restrict__ cuts,
-    const uint32_t* __restrict__ slow_any, int np, Geom g, BandPlan bp, float* __restrict__ out,
+    const uint32_t* __restrict__ slow_any, int np, Geom g, BandPlan bp, void* __restrict__ out,
     acc_t* __restrict__ seam, uint32_t* __restrict__ work_counters)
 {
     vote_bands_packed_body<BLOCK, MAPPING>(sxy, coef, cuts, slow_any, np, g, bp, out, seam, work_counters);
@@ -2021,7 +2207,7 @@ __device__ __forceinline__ void fused_consume(acc_t* __restrict__ band, int nx, 
     for (int k = 0; k < CELLS; ++k) {
         const int i = t + k * 1024;
         if (i < n_own) {
-            const float v = (float)((double)own[i] * kFixInv);  // flush_band's rounding
+            const float v = fix_to_float(own[i]);  // flush_band's rounding
             own[i] = 0;
             if (!LAST) {
                 va[k] = v;
@@ -2046,11 +2232,14 @@ __device__ __forceinline__ void fused_consume(acc_t* __restrict__ band, int nx, 
 template <int MAPPING, int CELLS>
 __global__ __launch_bounds__(1024) void k_vote_fuse_argmax(FusedCameras cams, Geom g, BandPlan bp, int op,
                                                            const uint32_t* __restrict__ splits,
-                                                           unsigned long long* __restrict__ keys)
+                                                           unsigned long long* __restrict__ keys,
+                                                           unsigned long long* __restrict__ trace)
 {
     constexpr int BLOCK = 1024;
     extern __shared__ acc_t band[];
-    __shared__ int s_pass;
+    __shared__ int s_pass;  // the next pass of the item to hand out
+    // (the vector fill pre-assigns one pass per wave, the dealt packed stream two)
+    constexpr int kPass0 = (MAPPING == 5 || MAPPING == 6) ? BLOCK / kWave : 2 * (BLOCK / kWave);
     const int nx = g.nx;
     // Workgroup b runs on XCD b % 8: each XCD gets one contiguous eighth of the (band-major) pair list,
     // so that a band's records stream through at most two XCDs' L2s, and splits it evenly over its
@@ -2071,7 +2260,7 @@ __global__ __launch_bounds__(1024) void k_vote_fuse_argmax(FusedCameras cams, Ge
     {
         const int all_cells = (bp.band_rows + 2) * nx;
         for (int i = threadIdx.x; i < all_cells; i += BLOCK) band[i] = 0;
-        if (threadIdx.x == 0) s_pass = BLOCK / kWave;
+        if (threadIdx.x == 0) s_pass = kPass0;
     }
     __syncthreads();
 
@@ -2111,10 +2300,20 @@ __global__ __launch_bounds__(1024) void k_vote_fuse_argmax(FusedCameras cams, Ge
         const int Li = max(r0 - 1, 0), Ui = min(r1, g.ny - 1);
         for (int c = 0; c < cams.n; ++c) {
             const FusedCamera& cam = cams.cam[c];
-            stream_item<BLOCK, MAPPING, true>(cam.sxy, cam.coef, cam.cuts, cam.slow_any, cam.np, g, bp, j, z, 0, cam.np,
+            // development aid (test hook dsi_test_fused_trace_*): 100 MHz time stamps per (workgroup, phase, wave):
+            // stream begins, stream ends, after the barrier + the read-back / clear, after the closing barrier
+            int tr = -1;  // (wave-uniform: lives in a scalar register)
+            if (trace) {
+                const int phase = (q - q_begin) * cams.n + c;
+                if (phase < kFusedTracePhases)
+                    tr = __builtin_amdgcn_readfirstlane((((int)blockIdx.x * kFusedTracePhases + phase) * (BLOCK / kWave) + (int)(threadIdx.x / kWave)) * 4);
+                if (tr >= 0 && (threadIdx.x & 63) == 0) trace[tr] = wall_clock64();
+            }
+            stream_item<BLOCK, MAPPING, true, true>(cam.sxy, cam.coef, cam.cuts, cam.slow_any, cam.np, g, bp, j, z, 0, cam.np,
                                         reinterpret_cast<char*>(band), Li, Ui, r0 - 1, &s_pass);
+            if (tr >= 0 && (threadIdx.x & 63) == 0) trace[tr + 1] = wall_clock64();
             __syncthreads();
-            if (threadIdx.x == 0) s_pass = BLOCK / kWave;
+            if (threadIdx.x == 0) s_pass = kPass0;
             const bool last = c == cams.n - 1;
             if (!last) {
                 fused_consume<CELLS, 1, false, true>(band, nx, n_own, rows_lds, va, fb, z);
@@ -2130,7 +2329,9 @@ __global__ __launch_bounds__(1024) void k_vote_fuse_argmax(FusedCameras cams, Ge
                 default: fused_consume<CELLS, 6, true, true>(band, nx, n_own, rows_lds, va, fb, z); break;
                 }
             }
+            if (tr >= 0 && (threadIdx.x & 63) == 0) trace[tr + 2] = wall_clock64();
             __syncthreads();
+            if (tr >= 0 && (threadIdx.x & 63) == 0) trace[tr + 3] = wall_clock64();
         }
     }
     emit();
@@ -2250,7 +2451,7 @@ __global__ __launch_bounds__(BLOCK) void k_vote_groups(const EvRec* __restrict__
                                                        const uint32_t* __restrict__ gcuts,
                                                        const uint32_t* __restrict__ slow_any, int np,
                                                        int ngroups, int S, Geom g, BandPlan bp,
-                                                       float* __restrict__ out,
+                                                       void* __restrict__ out,
                                                        acc_t* __restrict__ seam)
 {
     extern __shared__ acc_t band[];
@@ -2361,8 +2562,8 @@ __global__ __launch_bounds__(BLOCK) void k_vote_groups(const EvRec* __restrict__
     }
     __syncthreads();
     const size_t vol = partial_stride((size_t)g.nx * g.ny * g.nz);
-    float* __restrict__ dst = out + (size_t)c * vol + ((size_t)z * g.ny + r0) * nx;
-    flush_band<BLOCK>(band, nx, (r1 - r0) * nx, dst, seam_rows(seam, c, z, j, g, bp), j, bp.bands);
+    const size_t off = (size_t)c * vol + ((size_t)z * g.ny + r0) * nx;
+    flush_band<BLOCK>(band, nx, (r1 - r0) * nx, out, off, bp.raw_out, seam_rows(seam, c, z, j, g, bp), j, bp.bands);
 }
 
 // (4) seam rows: the first row of band j >= 1 of every plane of every chunk's volume is the exact
@@ -2371,8 +2572,9 @@ __global__ __launch_bounds__(BLOCK) void k_vote_groups(const EvRec* __restrict__
 // Runs after the voting kernel and before the chunk volumes are summed.
 // block x = one (plane, seam) row, block y = a 512-voxel stretch of it, block z = chunk; two voxels
 // per thread (16-byte loads, 8-byte stores) when nx is even
+template <bool RAW>
 __global__ __launch_bounds__(256) void k_seam_rows(const acc_t* __restrict__ seam, Geom g, int bands, int band_rows,
-                                                   float* __restrict__ out, size_t vol_stride)
+                                                   void* __restrict__ out, size_t vol_stride)
 {
     const int j = (int)(blockIdx.x % (unsigned)(bands - 1)) + 1;
     const int z = (int)(blockIdx.x / (unsigned)(bands - 1));
@@ -2380,45 +2582,64 @@ __global__ __launch_bounds__(256) void k_seam_rows(const acc_t* __restrict__ sea
     const size_t row = ((size_t)c * g.nz + z) * bands;
     const acc_t* head = seam + ((row + j) * 2) * g.nx;
     const acc_t* carry = seam + ((row + j - 1) * 2 + 1) * g.nx;
-    float* dst = out + (size_t)c * vol_stride + ((size_t)z * g.ny + (size_t)j * band_rows) * g.nx;
+    const size_t off = (size_t)c * vol_stride + ((size_t)z * g.ny + (size_t)j * band_rows) * g.nx;
+    float* dstf = reinterpret_cast<float*>(out) + off;
+    acc_t* dstr = reinterpret_cast<acc_t*>(out) + off;
     if ((g.nx & 1) == 0) {
         const int x = ((int)blockIdx.y * 256 + (int)threadIdx.x) * 2;
         if (x >= g.nx) return;
         const ulonglong2 h = *reinterpret_cast<const ulonglong2*>(head + x);
         const ulonglong2 k = *reinterpret_cast<const ulonglong2*>(carry + x);
-        float2 r;
-        r.x = (float)((double)(h.x + k.x) * kFixInv);  // < 2^53: exact in f64, one rounding to f32
-        r.y = (float)((double)(h.y + k.y) * kFixInv);
-        *reinterpret_cast<float2*>(dst + x) = r;
+        if (RAW) {
+            *reinterpret_cast<ulonglong2*>(dstr + x) = make_ulonglong2(h.x + k.x, h.y + k.y);
+        } else {
+            float2 r;
+            r.x = fix_to_float(h.x + k.x);  // one rounding to f32
+            r.y = fix_to_float(h.y + k.y);
+            *reinterpret_cast<float2*>(dstf + x) = r;
+        }
     } else {
-        for (int x = (int)blockIdx.y * 512 + (int)threadIdx.x; x < min(g.nx, ((int)blockIdx.y + 1) * 512); x += 256)
-            dst[x] = (float)((double)(head[x] + carry[x]) * kFixInv);
+        for (int x = (int)blockIdx.y * 512 + (int)threadIdx.x; x < min(g.nx, ((int)blockIdx.y + 1) * 512); x += 256) {
+            if (RAW)
+                dstr[x] = head[x] + carry[x];
+            else
+                dstf[x] = fix_to_float(head[x] + carry[x]);
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void k_reduce_partials(const float* __restrict__ partials,
+// (5) DSI = fl(sum over the chunks of their raw 64-bit partial volumes * 2^-31) [+ the grid's previous
+// contents: fillVoxelGrid accumulates, mapper_emvs_stereo.cpp:151-205 has no reset]: the integer sum is
+// exact and order-free, so the DSI does not depend on the number of chunks.  Two voxels per thread.
+__global__ __launch_bounds__(256) void k_reduce_partials(const acc_t* __restrict__ partials,
                                                          int chunks, size_t n,
                                                          float* __restrict__ dsi, int accumulate)
 {
-    const size_t n4 = n / 4;
+    const size_t n2 = n / 2;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        float4 acc = accumulate ? reinterpret_cast<const float4*>(dsi)[i]
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t vs = partial_stride(n);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        ulonglong2 acc = make_ulonglong2(0ull, 0ull);
         for (int c = 0; c < chunks; ++c) {
-            const float4 v = reinterpret_cast<const float4*>(partials + (size_t)c * partial_stride(n))[i];
+            const ulonglong2 v = reinterpret_cast<const ulonglong2*>(partials + (size_t)c * vs)[i];
             acc.x += v.x;
             acc.y += v.y;
-            acc.z += v.z;
-            acc.w += v.w;
         }
-        reinterpret_cast<float4*>(dsi)[i] = acc;
+        float2 r = make_float2(fix_to_float(acc.x), fix_to_float(acc.y));
+        float2* d2 = reinterpret_cast<float2*>(dsi) + i;  // (grids are 16-byte aligned, also wrapped ones)
+        if (accumulate) {
+            const float2 old = *d2;
+            r.x = old.x + r.x;
+            r.y = old.y + r.y;
+        }
+        *d2 = r;
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
-        const size_t i = n4 * 4 + threadIdx.x;
-        float acc = accumulate ? dsi[i] : 0.f;
-        for (int c = 0; c < chunks; ++c) acc += partials[(size_t)c * partial_stride(n) + i];
-        dsi[i] = acc;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (n & 1)) {
+        const size_t i = n - 1;
+        acc_t acc = 0;
+        for (int c = 0; c < chunks; ++c) acc += partials[(size_t)c * vs + i];
+        const float r = fix_to_float(acc);
+        dsi[i] = accumulate ? dsi[i] + r : r;
     }
 }
 
@@ -3051,11 +3272,11 @@ hipError_t launch_sort_packets(hipStream_t s, const float2* xy, int np, int ny, 
 hipError_t launch_sort_packets_raw(hipStream_t s, const float* Rt, const uint16_t* ex, const uint16_t* ey,
                                    const uint32_t* packet_first, const float2* lut, int sensor_w, int sensor_h, const Geom& g,
                                    float* centers, int np, int pad, EvRec* sxy, uint32_t* nvalid,
-                                   uint16_t* rowstart)
+                                   uint16_t* rowstart, int unit_multiplicity)
 {
     if (np <= 0) return hipSuccess;
     const size_t lds = (size_t)(g.ny + 2 * pad + 3) * sizeof(uint32_t);
-    RawEvents raw{Rt, ex, ey, packet_first, lut, sensor_w, sensor_h, g, centers};
+    RawEvents raw{Rt, ex, ey, packet_first, lut, sensor_w, sensor_h, g, centers, unit_multiplicity};
     hipLaunchKernelGGL(k_sort_packets<true>, dim3(np), dim3(256), lds, s, (const float2*)nullptr, raw, np, g.ny, g.nz, pad,
                        sxy, nvalid, rowstart);
     return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
@@ -3083,7 +3304,7 @@ hipError_t launch_plane_coef(hipStream_t s, const float* centers, const float* p
 template <int BLOCK, int MAPPING>
 static hipError_t launch_vote_bands_t(hipStream_t s, const EvRec* sxy, const PlaneCoef* coef,
                                       const uint32_t* cuts, const uint32_t* slow_any, int np,
-                                      const Geom& g, const BandPlan& bp, float* out, unsigned long long* seam)
+                                      const Geom& g, const BandPlan& bp, void* out, unsigned long long* seam)
 {
     constexpr bool PACKED = MAPPING != 0;
     constexpr bool VFILL = MAPPING == 5 || MAPPING == 6;
@@ -3120,7 +3341,7 @@ static hipError_t launch_vote_bands_t(hipStream_t s, const EvRec* sxy, const Pla
 template <int BLOCK>
 static hipError_t launch_vote_bands_b(hipStream_t s, const EvRec* sxy, const PlaneCoef* coef,
                                       const uint32_t* cuts, const uint32_t* slow_any, int np, const Geom& g,
-                                      const BandPlan& bp, float* out, unsigned long long* seam)
+                                      const BandPlan& bp, void* out, unsigned long long* seam)
 {
     switch (bp.packed) {
     case 0: return launch_vote_bands_t<BLOCK, 0>(s, sxy, coef, cuts, slow_any, np, g, bp, out, seam);
@@ -3134,7 +3355,7 @@ static hipError_t launch_vote_bands_b(hipStream_t s, const EvRec* sxy, const Pla
 
 hipError_t launch_vote_bands(hipStream_t s, const EvRec* sxy, const PlaneCoef* coef,
                              const uint32_t* cuts, const uint32_t* slow_any, int np, const Geom& g,
-                             const BandPlan& bp, float* out, unsigned long long* seam)
+                             const BandPlan& bp, void* out, unsigned long long* seam)
 {
     if (np <= 0) return hipSuccess;
     switch (bp.block_threads) {
@@ -3147,17 +3368,20 @@ hipError_t launch_vote_bands(hipStream_t s, const EvRec* sxy, const PlaneCoef* c
 
 template <int MAPPING>
 static hipError_t launch_vote_fuse_argmax_t(hipStream_t s, const FusedCameras& cams, const Geom& g, const BandPlan& bp,
-                                            int op, const uint32_t* splits, unsigned blocks, unsigned long long* keys)
+                                            int op, const uint32_t* splits, unsigned blocks, unsigned long long* keys,
+                                            unsigned long long* trace)
 {
     constexpr int CELLS = fused_cells_per_thread(MAPPING);
     if ((size_t)(bp.band_rows + 2) * g.nx > (size_t)CELLS * 1024) return hipErrorInvalidValue;
     const void* kern = reinterpret_cast<const void*>(&k_vote_fuse_argmax<MAPPING, CELLS>);
     if (hipError_t e = allow_dynamic_lds(kern, bp.lds_bytes)) return e;
-    hipLaunchKernelGGL((k_vote_fuse_argmax<MAPPING, CELLS>), dim3(blocks), dim3(1024), bp.lds_bytes, s, cams, g, bp, op, splits, keys);
+    hipLaunchKernelGGL((k_vote_fuse_argmax<MAPPING, CELLS>), dim3(blocks), dim3(1024), bp.lds_bytes, s, cams, g, bp, op, splits, keys, trace);
     return hipExtGetLastError();
 }
 
 size_t fused_max_cells(int mapping) { return (size_t)fused_cells_per_thread(mapping) * 1024; }
+
+size_t fused_trace_words() { return (size_t)fused_grid_blocks() * kFusedTracePhases * 16 * 4; }
 
 int fused_grid_blocks()
 {
@@ -3167,15 +3391,15 @@ int fused_grid_blocks()
 }
 
 hipError_t launch_vote_fuse_argmax(hipStream_t s, const FusedCameras& cams, const Geom& g, const BandPlan& bp, int op,
-                                   const uint32_t* splits, unsigned long long* keys)
+                                   const uint32_t* splits, unsigned long long* keys, unsigned long long* trace)
 {
     if (cams.n < 1 || cams.n > 2 || bp.block_threads != 1024 || bp.chunks != 1 || !bp.halo) return hipErrorInvalidValue;
     const unsigned blocks = (unsigned)fused_grid_blocks();
     switch (bp.packed) {
-    case 1: return launch_vote_fuse_argmax_t<1>(s, cams, g, bp, op, splits, blocks, keys);
-    case 3: return launch_vote_fuse_argmax_t<3>(s, cams, g, bp, op, splits, blocks, keys);
-    case 5: return launch_vote_fuse_argmax_t<5>(s, cams, g, bp, op, splits, blocks, keys);
-    case 6: return launch_vote_fuse_argmax_t<6>(s, cams, g, bp, op, splits, blocks, keys);
+    case 1: return launch_vote_fuse_argmax_t<1>(s, cams, g, bp, op, splits, blocks, keys, trace);
+    case 3: return launch_vote_fuse_argmax_t<3>(s, cams, g, bp, op, splits, blocks, keys, trace);
+    case 5: return launch_vote_fuse_argmax_t<5>(s, cams, g, bp, op, splits, blocks, keys, trace);
+    case 6: return launch_vote_fuse_argmax_t<6>(s, cams, g, bp, op, splits, blocks, keys, trace);
     default: return hipErrorInvalidValue;
     }
 }
@@ -3206,7 +3430,7 @@ template <int BLOCK>
 static hipError_t launch_vote_groups_t(hipStream_t s, const EvRec* sxy, const uint8_t* spk,
                                        const PlaneCoef* coef, const uint32_t* gcuts,
                                        const uint32_t* slow_any, int np, int S, const Geom& g,
-                                       const BandPlan& bp, float* out, unsigned long long* seam)
+                                       const BandPlan& bp, void* out, unsigned long long* seam)
 {
     if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_vote_groups<BLOCK>), bp.lds_bytes))
         return e;
@@ -3219,7 +3443,7 @@ static hipError_t launch_vote_groups_t(hipStream_t s, const EvRec* sxy, const ui
 
 hipError_t launch_vote_groups(hipStream_t s, const EvRec* sxy, const uint8_t* spk,
                               const PlaneCoef* coef, const uint32_t* gcuts, const uint32_t* slow_any,
-                              int np, int S, const Geom& g, const BandPlan& bp, float* out, unsigned long long* seam)
+                              int np, int S, const Geom& g, const BandPlan& bp, void* out, unsigned long long* seam)
 {
     if (np <= 0) return hipSuccess;
     switch (bp.block_threads) {
@@ -3231,19 +3455,22 @@ hipError_t launch_vote_groups(hipStream_t s, const EvRec* sxy, const uint8_t* sp
 }
 
 hipError_t launch_seam_rows(hipStream_t s, const unsigned long long* seam, int chunks, const Geom& g,
-                            const BandPlan& bp, float* out)
+                            const BandPlan& bp, void* out)
 {
     if (bp.bands < 2) return hipSuccess;
     const size_t vol = partial_stride((size_t)g.nx * g.ny * g.nz);
-    hipLaunchKernelGGL(k_seam_rows, dim3((unsigned)g.nz * (unsigned)(bp.bands - 1), (unsigned)((g.nx + 511) / 512), (unsigned)chunks),
-                       dim3(256), 0, s, seam, g, bp.bands, bp.band_rows, out, vol);
+    const dim3 grid((unsigned)g.nz * (unsigned)(bp.bands - 1), (unsigned)((g.nx + 511) / 512), (unsigned)chunks);
+    if (bp.raw_out)
+        hipLaunchKernelGGL(k_seam_rows<true>, grid, dim3(256), 0, s, seam, g, bp.bands, bp.band_rows, out, vol);
+    else
+        hipLaunchKernelGGL(k_seam_rows<false>, grid, dim3(256), 0, s, seam, g, bp.bands, bp.band_rows, out, vol);
     return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
-hipError_t launch_reduce_partials(hipStream_t s, const float* partials, int chunks, size_t n,
+hipError_t launch_reduce_partials(hipStream_t s, const unsigned long long* partials, int chunks, size_t n,
                                   float* dsi, int accumulate)
 {
-    hipLaunchKernelGGL(k_reduce_partials, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(k_reduce_partials, dim3(grid_for(n / 2 + 1, 256)), dim3(256), 0, s,
                        partials, chunks, n, dsi, accumulate);
     return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }

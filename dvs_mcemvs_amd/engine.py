@@ -92,6 +92,9 @@ def load_library():
         "dsi_context_device": (C.c_int, [vp]),
         "dsi_context_timer_start": (C.c_int, [vp]),
         "dsi_context_timer_stop": (C.c_int, [vp, f32p]),
+        "dsi_context_timeline_mark": (C.c_int, [vp]),
+        "dsi_context_timeline_read": (C.c_int, [vp, f32p, C.c_size_t, szp]),
+        "dsi_test_unit_multiplicity": (C.c_int, [vp, C.c_int]),
         "dsi_grid_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
         "dsi_grid_wrap": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp)]),
         "dsi_grid_destroy": (C.c_int, [vp]),
@@ -279,6 +282,17 @@ class Context:
         ms = C.c_float()
         _check(load_library().dsi_context_timer_stop(self._h, C.byref(ms)))
         return ms.value
+
+    def timeline_mark(self):
+        """Record a HIP event on the stream (asynchronous); see timeline_read()."""
+        _check(load_library().dsi_context_timeline_mark(self._h))
+
+    def timeline_read(self, capacity=1 << 16):
+        """Milliseconds between consecutive marks (waits for the last one; clears the timeline)."""
+        out = np.zeros(capacity, np.float32)
+        n = C.c_size_t()
+        _check(load_library().dsi_context_timeline_read(self._h, _ptr(out, C.c_float), capacity, C.byref(n)))
+        return out[:min(n.value, capacity)].copy()
 
 
 class Comm:
@@ -650,6 +664,11 @@ class MapperEMVS:
         info = _VoteInfo()
         _check(load_library().dsi_mapper_last_vote_info(self._h, C.byref(info)))
         return {k: getattr(info, k) for k, _ in _VoteInfo._fields_}
+
+    def _unit_multiplicity(self, flag):
+        """Test hook: merged records vote once instead of `multiplicity` times (the DSI then counts the
+        records the voting kernel accepted)."""
+        _check(load_library().dsi_test_unit_multiplicity(self._h, int(bool(flag))))
 
     def set_kernel_timing(self, enable=True):
         _check(load_library().dsi_mapper_set_kernel_timing(self._h, 1 if enable else 0))

@@ -125,6 +125,11 @@ DSI_API int dsi_context_wait_for(dsi_context_t *ctx, dsi_context_t *other);
  * std::chrono timers at process1.cpp:72-85,132-166). stop synchronises. */
 DSI_API int dsi_context_timer_start(dsi_context_t *ctx);
 DSI_API int dsi_context_timer_stop(dsi_context_t *ctx, float *elapsed_ms);
+/* a timeline of HIP events on the context's stream: _mark records one (asynchronous); _read waits for the last
+ * one, returns the n-1 intervals between consecutive marks in milliseconds (the first `capacity` of them) and
+ * clears the timeline.  bench.py marks every step to report the spread of the per-step times. */
+DSI_API int dsi_context_timeline_mark(dsi_context_t *ctx);
+DSI_API int dsi_context_timeline_read(dsi_context_t *ctx, float *intervals_ms, size_t capacity, size_t *n_intervals);
 
 /* ------------------------------------------------------------------- Grid3D */
 /* Grid3D::Grid3D(dimX,dimY,dimZ) + allocate + resetGrid (cartesian3dgrid.cpp:30-46) */

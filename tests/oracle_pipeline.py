@@ -138,3 +138,26 @@ def oracle_process_2(make_mapper, events, trajectories, n_sub, ts, stereo_fusion
     converse = {1: 1, 2: 2, 3: 4, 4: 3, 5: 5, 6: 6}[stereo_fusion]  # process2.cpp:274-279 swap
     cam_time = orc.fuse2(orc.accumulate(zero, left, 0), right, converse)
     return {"left": left, "right": right, "fused": fused, "camera_time": cam_time}
+
+
+# ---- the depth-map statement ---------------------------------------------------------------
+def argmax_report(idx_gpu, ref_volume, vol_tol):
+    """Closes "depth map equal to the CPU reference" for EVERY pixel (cartesian3dgrid.cpp:132-134).
+
+    ref_volume: the CPU oracle's volume [nz][ny][nx] the arg-max runs over; idx_gpu: the GPU's plane
+    index per pixel, taken from ITS volume g, which agrees with ref_volume to
+    |g - ref| <= vol_tol * max(1, |ref|) for every voxel (asserted separately by the caller).
+    Then for every pixel either the indices are equal, or the GPU's plane is a provable near-tie of
+    the oracle's column:  ref[idx_gpu] >= ref_max - 2 * vol_tol * max(1, ref_max), because
+    ref[idx_gpu] >= g[idx_gpu] - t >= g[idx_cpu] - t >= ref_max - 2 t.  Anything else is a wrong
+    depth.  Returns the fractions and the violation count (0 = the statement holds)."""
+    ref_max = ref_volume.max(axis=0)
+    idx_cpu = ref_volume.argmax(axis=0)                     # first maximum, like std::max_element
+    picked = np.take_along_axis(ref_volume, idx_gpu[None].astype(np.int64), axis=0)[0]
+    same = idx_gpu == idx_cpu
+    slack = 2.0 * vol_tol * np.maximum(1.0, np.abs(ref_max.astype(np.float64)))
+    near = (~same) & (picked.astype(np.float64) >= ref_max.astype(np.float64) - slack)
+    bad = ~(same | near)
+    return {"argmax_agree_frac": float(same.mean()), "near_tie_frac": float(near.mean()),
+            "violations": int(bad.sum()), "pixels": int(same.size),
+            "worst_deficit_over_slack": float(np.max((ref_max.astype(np.float64) - picked) / slack))}

@@ -144,17 +144,17 @@ def test_fused_rejects_bad_arguments(ctx):
 
 
 @pytest.mark.parametrize("packed", [0, 1, 5])
-def test_dsi_bits_do_not_depend_on_the_band_decomposition(ctx, packed):
-    """One chunk: every voxel is fl(exact 64-bit sum), also on the seam rows between bands
-    (k_seam_rows), so any band height gives the same bits.  With several chunks the per-chunk volumes
-    have that property and are added in chunk order, so the bits depend on the chunk count only."""
+def test_dsi_bits_do_not_depend_on_bands_or_chunks(ctx, packed):
+    """Every voxel is fl(exact 64-bit sum of its votes): on the seam rows between bands the sums of the
+    two neighbours are added as integers (k_seam_rows), and several packet chunks leave raw 64-bit partial
+    volumes that are added as integers (k_reduce_partials) -- one rounding, whatever the decomposition."""
     nx, ny, nz = 130, 97, 12
     rig = syn.stereo_rig(40_000, width=nx, height=ny, duration=0.25, seed=17, n_points=400)
     shape = d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0)
     batch = rig_batches(ctx, rig, 1)[0]
-    got = {}
-    for chunks in (1, 3):
-        for band_rows in (3, 10, 31, 97):
+    base = None
+    for chunks in (1, 3, 8):
+        for band_rows in (97, 3, 10, 31):
             m = d.MapperEMVS(ctx, rig["cam"], shape)
             m.set_vote_algo(d.VOTE_LDS_BANDS)
             m.set_packed_lanes(packed)
@@ -162,15 +162,12 @@ def test_dsi_bits_do_not_depend_on_the_band_decomposition(ctx, packed):
             m.evaluateDSI_batch(batch)
             info = m.last_vote_info()
             assert info["band_rows"] == band_rows and info["chunks"] == chunks
-            got[(chunks, band_rows)] = m.dsi_.download()
+            got = m.dsi_.download()
             m.close()
-        base = got[(chunks, 97)]                      # one band: no seam at all
-        assert base.max() > 4.0
-        for band_rows in (3, 10, 31):
-            assert np.array_equal(got[(chunks, band_rows)], base), (chunks, band_rows)
-    # and the chunked sum stays within the DSI tolerance of the one-chunk volume
-    err = np.abs(got[(3, 97)].astype(np.float64) - got[(1, 97)]) / np.maximum(1.0, got[(1, 97)])
-    assert err.max() <= 1e-5
+            if base is None:
+                base = got                              # one band, one chunk: no seam, no partial volume
+                assert base.max() > 4.0
+            assert np.array_equal(got, base), (chunks, band_rows, int((got != base).sum()))
     batch.close()
 
 

@@ -15,7 +15,7 @@ import pytest
 import dvs_mcemvs_amd as d
 from dvs_mcemvs_amd import synthetic as syn
 from oracle import oracle as orc
-from oracle_pipeline import OracleMapper
+from oracle_pipeline import OracleMapper, argmax_report
 
 pytestmark = pytest.mark.gpu
 
@@ -527,6 +527,9 @@ def test_full_size_properties(ctx):
     safe = gap > 2 * DSI_TOL * np.maximum(1.0, srt[-1])
     assert np.array_equal(idx[safe], i1[safe])
     assert (np.abs(orc.indices_to_depth(idx, r.planes) - d1)[safe] <= 1e-4).all()
+    # ... and on EVERY other pixel the GPU's plane is a provable near-tie of the oracle's column
+    rep = argmax_report(idx, r.dsi, DSI_TOL)
+    assert rep["violations"] == 0, rep
 
 
 @pytest.mark.parametrize("dims", [(512, 512, 200), (1024, 1024, 256)])
@@ -835,5 +838,11 @@ def test_configs1_against_the_oracle_at_full_size(ctx):
     assert safe.mean() > 0.95 and agree > 0.99      # measured: 0.961 safe
     assert np.array_equal(idx[safe], ridx[safe])
     assert (np.abs(depth - orc.indices_to_depth(ridx, cpu[0].planes))[safe] <= 1e-4).all()
+    # EVERY pixel: equal index, or the GPU's plane is a provable near-tie of the oracle's fused column
+    # (fused volume within 3 x DSI_TOL, asserted above => ref[idx_gpu] >= ref_max - 6 x DSI_TOL x max(1, ref_max))
+    rep = argmax_report(idx, ref, 3 * DSI_TOL)
+    print("configs[1] depth map, all %d pixels: %r" % (rep["pixels"], rep))
+    assert rep["violations"] == 0, rep
+    assert np.array_equal(depth, orc.indices_to_depth(idx, cpu[0].planes))   # depth = plane of the index, exactly
     for o in gpu + [fused]:
         o.close()

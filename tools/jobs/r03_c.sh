@@ -1,0 +1,8 @@
+#!/bin/bash
+cd "$(dirname "$0")/../.."
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests/test_gpu_fused_vote.py tests/test_gpu_first_principles.py -x -q 2>&1 | tail -25
+for lg in 2 3; do echo "== dealt passes of 2^$lg packets"; DSI_PASS_LG=$lg timeout 300 python tools/fused_trace.py 2>&1 | tail -12; done
+timeout 600 python bench.py --workload windows --no-cpu --no-host-fed > gpurun_out/r03c_windows.json 2> gpurun_out/r03c_windows.err
+tail -c 3000 gpurun_out/r03c_windows.json | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['roofline']['kernel'], d['roofline']['kernel_avg_ms'], d['roofline']['frac'])"
+timeout 1800 python -m pytest tests/test_gpu_parity.py tests/test_golden.py tests/test_gpu_windows.py -x -q 2>&1 | tail -8
