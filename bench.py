@@ -71,6 +71,10 @@ def parse():
                     help="windows: vote, fuse the cameras and keep the arg-max in ONE kernel, no DSI written "
                          "(dsi_mapper_depth_map_of_events); default for the windows workload")
     ap.add_argument("--no-fused-vote", dest="fused_vote", action="store_false")
+    ap.add_argument("--serial-windows", action="store_true",
+                    help="windows: all windows on ONE stream (no overlap of consecutive windows); for rocprofv3 runs, "
+                         "whose per-kernel durations otherwise include the time a kernel waits for the previous "
+                         "window's workgroups to leave the CUs")
     ap.add_argument("--no-extra", action="store_true",
                     help="default (stereo, 1 GPU) run only: do not append the one-GPU lines of the windows and "
                          "cameras4 workloads (each is a sub-run of this script) to the JSON line")
@@ -492,20 +496,23 @@ def main():
                              duration=n_distinct * dur, seed=77 + rank, n_points=max(args.points, 6000))
         shape = d.ShapeDSI(nx, ny, nz, 4.0, 200.0, 0.0)
         fused_vote = (args.fused_vote is not False) and not args.materialize_fused and args.algo in (0, 2)
+        concurrent = fused_vote and not args.serial_windows
         ws = proc.WindowStream(ctx, (rig["cam"],) * 2, shape, d.FUSE_HM, materialize_fused=args.materialize_fused,
-                               fused_vote=fused_vote)
-        for m in ws.mappers:
-            tune(m)
-        vote_mappers = ws.mappers
+                               fused_vote=fused_vote, concurrent=concurrent)
+        for ms_ in ws.mapper_sets:
+            for m in ms_:
+                tune(m)
+        vote_mappers = [m for ms_ in ws.mapper_sets for m in ms_]
         bounds = proc.window_bounds(rig["t0"], rig["t1"] + 1e-9, dur, dur)[:n_distinct]
         wins, host_wins = [], []
-        for a, b in bounds:
+        for wi, (a, b) in enumerate(bounds):
             T_rv_w = proc.reference_view_process1(rig["trajectories"][0], b)
             per_cam, host = [], []
             for c in range(2):
                 ev = proc.window_events(rig["events"][c], a, b)
                 first, Rt = d.packetize(ev[2], rig["trajectories"][c], T_rv_w)
-                per_cam.append(d.EventBatch(ctx, ev[0], ev[1], Rt, first))
+                # (window wi always lands in slot wi % 2: n_distinct is even; its batches live in that slot's context)
+                per_cam.append(d.EventBatch(ws.context_of_slot(wi % 2), ev[0], ev[1], Rt, first))
                 host.append(ev)
             wins.append((per_cam, b))
             host_wins.append((host, b))
@@ -525,15 +532,18 @@ def main():
             if state["pending"] is not None:
                 ws.fetch(state["pending"])
                 state["pending"] = None
-            ctx.synchronize()
+            for c_ in ws.contexts:
+                c_.synchronize()
 
+        extra["concurrent"] = concurrent
+        extra["serial_step"] = (step, sync)
         voted_per_step = float(np.mean([sum(b.n_packets for b in pc) for pc, _ in wins])) * d.PACKET_SIZE
         workload = ("stream of %.0f ms windows (main.cpp:177 loop), 2 cameras x %d events per window, sensor 640x480, "
                     "%dx%dx%d DSI, per window: reset + vote x2 + harmonic camera fusion + arg-max + depth-map fetch (%s)"
                     % (dur * 1e3, args.events, nx, ny, nz,
                        "fused DSI written" if args.materialize_fused else
                        "ONE kernel votes both cameras band by band in LDS, fuses them and keeps the running arg-max: "
-                       "no DSI is written" if fused_vote else
+                       "no DSI is written" + ("; consecutive windows on two streams" if concurrent else "") if fused_vote else
                        "camera fusion computed inside the arg-max kernel, fused DSI not written"))
         parallelism = "1 GPU" if world == 1 else "replicas x%d (independent windows, no collective)" % world
         scaling = "weak"
@@ -541,6 +551,7 @@ def main():
         extra["host_windows"] = host_wins
         extra["fused_vote"] = fused_vote
         extra["last_window"] = wins[-1][0]
+        extra["last_mappers"] = ws.mapper_sets[(len(wins) - 1) % len(ws.mapper_sets)]
 
     else:
         # ---- configs[4] shape: 4 cameras, n-ary GM; N > 1: plane sharding ----
@@ -596,8 +607,9 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    overlapped = bool(extra.get("concurrent"))
     for m in vote_mappers:
-        m.set_kernel_timing(True)
+        m.set_kernel_timing(not overlapped)
         m.vote_kernel_time()
     t0 = time.perf_counter()
     ctx.timer_start()
@@ -609,6 +621,16 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     step_ms = ctx.timeline_read()
+    if overlapped:
+        # consecutive windows overlap on the device (two streams), so an event pair around a kernel also times
+        # its wait for the previous window's workgroups: the dominant kernel's duration is measured on extra,
+        # un-overlapped launches AFTER the timed region (one window at a time)
+        for m in vote_mappers:
+            m.set_kernel_timing(True)
+        s_step, s_sync = extra["serial_step"]
+        for _ in range(max(8, min(args.steps, 32))):
+            s_step()
+            s_sync()
     kt_ms, kt_n = 0.0, 0
     for m in vote_mappers:
         ms, n = m.vote_kernel_time()
@@ -638,13 +660,14 @@ def main():
         # the fused kernel writes no DSI: build the two camera DSIs of one window once, outside the timed
         # region, to count the accepted event-planes of a launch (both cameras are voted by one launch)
         accepted = 0.0
-        for m, b in zip(vote_mappers, extra["last_window"]):
+        lm = extra["last_mappers"]
+        for m, b in zip(lm, extra["last_window"]):
             m.evaluateDSI_batch(b)
             accepted += float(np.sum(m.dsi_.download(), dtype=np.float64))
-        records = issued_records(zip(vote_mappers, extra["last_window"]))
-        vote_mappers[0].computeDepthMapOfEvents(vote_mappers, extra["last_window"], d.FUSE_HM)   # restores last_vote_info
-        ctx.synchronize()
-        info = vote_mappers[0].last_vote_info()
+        records = issued_records(zip(lm, extra["last_window"]))
+        lm[0].computeDepthMapOfEvents(lm, extra["last_window"], d.FUSE_HM)   # restores last_vote_info
+        sync()
+        info = lm[0].last_vote_info()
     else:
         accepted = float(np.sum(vote_mappers[0].dsi_.download(), dtype=np.float64))
         records = issued_records([(vote_mappers[0], extra["batch0"])]) if "batch0" in extra else None
@@ -668,6 +691,9 @@ def main():
                 traffic = None
         roofline = roofline_block(info, kern_ms, kt_n, accepted, ev_per_launch, info_nz(vote_mappers[0]), traffic,
                                   records)
+        if overlapped:
+            roofline["kernel_timing"] = ("HIP events around %d un-overlapped launches after the timed region (in the "
+                                         "timed region consecutive windows overlap on two streams)" % kt_n)
         streams = stream_kernels(d, ctx) if not args.no_host_fed else None
 
         # ---- host-buffer (PCIe-inclusive) rates, reported beside `value`, never as it ----
@@ -777,7 +803,8 @@ def main():
             "timed_region_s": elapsed,
             "host_fed": h2d, "roofline": roofline, "cpu_baseline": cpu, "input_gen_s": t_gen,
             "step_ms": {"min": float(step_ms.min()), "median": float(np.median(step_ms)), "max": float(step_ms.max()),
-                        "n": int(step_ms.shape[0]), "source": "HIP events between consecutive steps on the compute stream"}
+                        "n": int(step_ms.shape[0]), "source": "HIP events between consecutive steps on the compute stream" +
+                        (" of slot 0 (with two streams a step's events bracket parts of two windows)" if overlapped else "")}
             if step_ms.shape[0] else None,
             "parity": parity,
         }

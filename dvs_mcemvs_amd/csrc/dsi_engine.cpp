@@ -174,9 +174,18 @@ struct dsi_mapper {
     std::vector<float> planes_full;  // the whole depth vector (plane-sharded arg-max: index -> depth)
     float* planes_full_dev = nullptr;
     DevBuf<unsigned long long> argmax_keys;
+    DevBuf<unsigned long long> fused_keys;   // dsi_mapper_depth_map_of_events: one arg-max key per pixel, kept zero between calls
     DevBuf<unsigned long long> fused_trace;  // test hook: time stamps of the fused kernel's phases
     bool fused_trace_on = false;
     int unit_multiplicity = 0;  // test hook (dsi_test_unit_multiplicity)
+    // fused kernel: records per (band, plane) pair of this camera's tables; the balanced partition; the cost of
+    // a phase's set-up, pass switches, barriers and read-back in record units (measured with tools/fused_trace.py at
+    // 512 x 512 x 200: a phase without records takes 8.6 us, a full one 18.7 us for ~38 k records)
+    DevBuf<uint32_t> pair_work, fused_splits;
+    DevBuf<unsigned long long> fused_prefix;
+    int fused_fixed_cost = -1;  // < 0: equal pair counts per workgroup (default: balancing by records did not pay at
+                                // 512 x 512 x 200 -- 446 vs 447 us, the slow workgroups are slow per record, not by count)
+    int want_pass_lg = 0;  // test hook: log2(packets per pass) of the packed / vector-fill streams (0 = automatic)
     int plane_begin = 0;        // first owned plane of the full depth vector (plane sharding)
     float* planes_dev = nullptr;
     float2* lut_dev = nullptr;
@@ -401,7 +410,7 @@ bool plan_fused(const dsi_mapper* m, size_t n_packets_max, dsi::BandPlan* bp)
     bp->packed = packed;
     bp->group_packets = 1;
     bp->row_pad = std::min(g.ny, 4096);
-    bp->pass_lg = 0;
+    bp->pass_lg = (m->want_pass_lg >= 1 && m->want_pass_lg <= 6) ? m->want_pass_lg : 0;
     bp->scratch_offset = (int)((size_t)(band_rows + 2) * row_bytes);
     bp->lds_bytes = (size_t)(band_rows + 2) * row_bytes + scratch_bytes;
     bp->persistent = 0;
@@ -1109,6 +1118,10 @@ int dsi_mapper_destroy(dsi_mapper_t* m)
     m->H.release();
     m->partials.release();
     m->fused_trace.release();
+    m->fused_keys.release();
+    m->pair_work.release();
+    m->fused_splits.release();
+    m->fused_prefix.release();
     m->Rt_tmp.release();
     m->conf.release();
     m->depth.release();
@@ -1482,6 +1495,9 @@ int dsi_mapper_depth_map_of_events(dsi_mapper_t* out, dsi_mapper_t* const* mappe
     hipStream_t st = ctx->stream;
     dsi::FusedCameras cams{};
     cams.n = n;
+    dsi::PrepCameraArgs prep[2] = {};
+    const int n_pairs = bp.bands * geom.nz;
+    const bool balance = n_pairs <= dsi::fused_max_pairs() && out->fused_fixed_cost >= 0;
     for (int i = 0; i < n; ++i) {
         dsi_mapper* m = mappers[i];
         const dsi_batch* b = batches[i];
@@ -1493,17 +1509,16 @@ int dsi_mapper_depth_map_of_events(dsi_mapper_t* out, dsi_mapper_t* const* mappe
         HIP_TRY(m->rowstart.reserve(np * (size_t)(geom.ny + 2 * bp.row_pad + 3) + 2));
         HIP_TRY(m->coef.reserve(np * geom.nz + 1));
         HIP_TRY(m->cuts.reserve(std::max<size_t>(np * geom.nz * bp.bands, 64)));
+        HIP_TRY(m->pair_work.reserve((size_t)n_pairs));
         if (b->ready) HIP_TRY(hipStreamWaitEvent(st, b->ready, 0));  // uploaded on the copy stream
         if (np == 0) {
             // evaluateDSI returns false (mapper_emvs_stereo.cpp:71-75): this camera's DSI is all zero
             HIP_TRY(hipMemsetAsync(m->nvalid.p, 0, ((size_t)geom.nz + 8) * sizeof(uint32_t), st));
-        } else {
-            HIP_TRY(dsi::launch_sort_packets_raw(st, b->Rt, b->x, b->y, b->first, m->lut_dev, m->sensor_w, m->sensor_h, m->geom,
-                                                 m->centers.p, (int)np, bp.row_pad, m->sxy.p, m->nvalid.p, m->rowstart.p,
-                                                 m->unit_multiplicity));
-            HIP_TRY(dsi::launch_plane_coef(st, m->centers.p, m->planes_dev, m->rowstart.p, m->nvalid.p, (int)np, m->geom, bp,
-                                           m->coef.p, m->cuts.p));
+            HIP_TRY(hipMemsetAsync(m->pair_work.p, 0, (size_t)n_pairs * sizeof(uint32_t), st));
         }
+        prep[i] = dsi::PrepCameraArgs{b->Rt, b->x, b->y, b->first, m->lut_dev, m->sensor_w, m->sensor_h, m->centers.p, (int)np,
+                                      m->sxy.p, m->nvalid.p, m->rowstart.p, m->planes_dev, m->coef.p, m->cuts.p,
+                                      balance ? m->pair_work.p : nullptr};
         cams.cam[i] = dsi::FusedCamera{m->sxy.p, m->coef.p, m->cuts.p, m->nvalid.p + np, (int)np};
         m->info = dsi_vote_info_t{};
         m->info.algo = DSI_VOTE_FUSED_ARGMAX;
@@ -1516,22 +1531,37 @@ int dsi_mapper_depth_map_of_events(dsi_mapper_t* out, dsi_mapper_t* const* mappe
         m->info.packed = bp.packed;
         m->info.group_packets = 1;
     }
+    // stage A + packet sort of all cameras in one launch, their coefficient / cut tables in another
+    // (a window's ~490 packets per camera do not fill the chip: two launches each would only add latency)
+    HIP_TRY(dsi::launch_prepare_cameras(st, prep, n, geom, bp));
+    // workgroup -> stretch of (band, plane) pairs, balanced by the records the tables hold per pair
+    const uint32_t* splits = nullptr;
+    if (balance) {
+        HIP_TRY(out->fused_splits.reserve((size_t)dsi::fused_grid_blocks() + 1));
+        HIP_TRY(out->fused_prefix.reserve((size_t)n_pairs));
+        HIP_TRY(dsi::launch_fused_splits(st, mappers[0]->pair_work.p, n > 1 ? mappers[1]->pair_work.p : nullptr, n_pairs,
+                                         (uint32_t)(out->fused_fixed_cost * n), out->fused_prefix.p, out->fused_splits.p));
+        splits = out->fused_splits.p;
+    }
     const size_t npix = (size_t)geom.nx * geom.ny;
     HIP_TRY(out->conf.reserve(npix));
     HIP_TRY(out->depth.reserve(npix));
     HIP_TRY(out->idx.reserve(npix));
-    HIP_TRY(out->argmax_keys.reserve(npix));
     if (int rc = depth_buffers_acquire(out)) return rc;
-    HIP_TRY(hipMemsetAsync(out->argmax_keys.p, 0, npix * sizeof(unsigned long long), st));
+    // one key per pixel, zero before the kernel: zeroed once when (re)allocated, then by every unpack
+    if (out->fused_keys.cap < npix) {
+        HIP_TRY(out->fused_keys.reserve(npix));
+        HIP_TRY(hipMemsetAsync(out->fused_keys.p, 0, out->fused_keys.cap * sizeof(unsigned long long), st));
+    }
     {
         VoteTimer vt(mappers[0]);
-        HIP_TRY(dsi::launch_vote_fuse_argmax(st, cams, geom, bp, op, nullptr, out->argmax_keys.p,
+        HIP_TRY(dsi::launch_vote_fuse_argmax(st, cams, geom, bp, op, splits, out->fused_keys.p,
                                              mappers[0]->fused_trace_on ? mappers[0]->fused_trace.p : nullptr));
         vt.stop();
     }
     // keys -> confidence, index, depth over the planes the cameras voted (mapper_emvs_stereo.cpp:302-313)
-    HIP_TRY(dsi::launch_unpack_argmax(st, out->argmax_keys.p, (int)npix, mappers[0]->planes_dev, out->conf.p, out->idx.p,
-                                      out->depth.p));
+    HIP_TRY(dsi::launch_unpack_argmax(st, out->fused_keys.p, (int)npix, mappers[0]->planes_dev, out->conf.p, out->idx.p,
+                                      out->depth.p, /*clear=*/1));
     return depth_buffers_ready(out);
 }
 
@@ -1635,6 +1665,23 @@ int dsi_mapper_last_vote_info(const dsi_mapper_t* m, dsi_vote_info_t* info)
 {
     REQUIRE(m && info, DSI_ERR_INVALID, "null argument");
     *info = m->info;
+    return DSI_OK;
+}
+
+/* test hook (not in the public header): packets per pass of the voting streams, as a power of two (0 = automatic) */
+DSI_API int dsi_test_pass_lg(dsi_mapper_t* m, int lg)
+{
+    REQUIRE(m, DSI_ERR_INVALID, "mapper is null");
+    m->want_pass_lg = lg;
+    return DSI_OK;
+}
+
+/* test hook (not in the public header): the fixed cost of one phase of the fused kernel in record units (the
+ * balanced partition's only tunable); < 0 switches the balancing off (equal pair counts per workgroup) */
+DSI_API int dsi_test_fused_fixed_cost(dsi_mapper_t* m, int records)
+{
+    REQUIRE(m, DSI_ERR_INVALID, "mapper is null");
+    m->fused_fixed_cost = records;
     return DSI_OK;
 }
 

@@ -116,6 +116,30 @@ struct FusedCameras {
     FusedCamera cam[2];
     int n;  // 1 (vote -> arg-max) or 2 (vote x 2 -> op -> arg-max)
 };
+// The preparation of up to two cameras in two launches instead of four (stage A + packet sort; coefficient /
+// cut tables), optionally counting the records per (band, plane) pair for launch_fused_splits.
+struct PrepCameraArgs {
+    const float* Rt;
+    const uint16_t *ex, *ey;
+    const uint32_t* packet_first;
+    const float2* lut;
+    int sensor_w, sensor_h;
+    float* centers;
+    int np;
+    EvRec* sxy;
+    uint32_t* nvalid;
+    uint16_t* rowstart;
+    const float* planes;
+    PlaneCoef* coef;
+    uint32_t* cuts;
+    uint32_t* pair_work;  // [bands * nz] or nullptr
+};
+hipError_t launch_prepare_cameras(hipStream_t s, const PrepCameraArgs* cams, int n, const Geom& g, const BandPlan& bp);
+// splits[fused_grid_blocks() + 1] <- cuts of the pair list into stretches of equal cost (records + fixed_per_pair
+// each); prefix: n_pairs words of scratch.  n_pairs <= fused_max_pairs()
+hipError_t launch_fused_splits(hipStream_t s, const uint32_t* work0, const uint32_t* work1, int n_pairs, uint32_t fixed_per_pair,
+                               unsigned long long* prefix, uint32_t* splits);
+int fused_max_pairs();
 // keys[ny * nx] (zeroed by the caller) receive max over planes of conf_bits << 8 | 255 - plane: feed
 // launch_unpack_argmax.  splits: optional balanced partition of the (band-major) pair list, one entry
 // per workgroup + 1 (fused_grid_blocks() workgroups)
@@ -135,8 +159,9 @@ hipError_t launch_fill(hipStream_t s, float* a, size_t n, float v);
 hipError_t launch_fuse_n(hipStream_t s, float* dst, const float* const* srcs, int n_src, size_t n, int mode);
 hipError_t launch_pack_argmax(hipStream_t s, const float* conf, const uint8_t* idx, int n, int plane_begin,
                               unsigned long long* keys);
-hipError_t launch_unpack_argmax(hipStream_t s, const unsigned long long* keys, int n, const float* planes_full,
-                                float* conf, uint8_t* idx, float* depth);
+// clear != 0: the keys are zeroed as they are read (the fused vote kernel needs them zero before it runs)
+hipError_t launch_unpack_argmax(hipStream_t s, unsigned long long* keys, int n, const float* planes_full,
+                                float* conf, uint8_t* idx, float* depth, int clear = 0);
 hipError_t launch_collapse_max_z(hipStream_t s, const float* dsi, int nx, int ny, int nz,
                                  float* conf, uint8_t* idx, const float* planes, float* depth);
 hipError_t launch_depth_map_filters(hipStream_t s, float* conf, const uint8_t* idx, int nx, int ny,

@@ -262,17 +262,35 @@ struct RawEvents {
     int unit_multiplicity;       // test hook: every record gets multiplicity 1 (the DSI then counts accepted RECORDS)
 };
 
+// one camera's share of a multi-camera preparation launch (k_sort_packets_multi, k_plane_coef_multi)
+struct PrepCamera {
+    RawEvents raw;
+    int np;
+    EvRec* sxy;
+    uint32_t* nvalid;
+    uint16_t* rowstart;
+    const float* planes;
+    PlaneCoef* coef;
+    uint32_t* cuts;
+    uint32_t* pair_work;  // [bands][nz]: records the voting kernel will look at per (band, plane), or nullptr
+};
+struct PrepCameras {
+    PrepCamera cam[2];
+    int n;
+};
+
 // RAW (the events come as sensor pixels, stage A fused in): two events of a packet have the same z0
 // location iff they have the same pixel, so the hash set is keyed by the 32-bit pixel and one 64-bit
 // word per slot holds key and count -- 16 KB instead of 24 KB of LDS, which is what decides how many
 // packets a CU sorts at once (time at 10 M events: 35 us + 260 us / blocks per CU, measured by
 // padding the LDS: 5 blocks 86 us, 4: 99, 3: 122, 2: 172; now 8).
 template <bool RAW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_sort_packets(const float2* __restrict__ xy, RawEvents raw,
-                                                      int np, int ny,
-                                                      int nz, int pad, EvRec* __restrict__ sxy,
-                                                      uint32_t* __restrict__ nvalid,
-                                                      uint16_t* __restrict__ rowstart)
+__device__ __forceinline__ void sort_packets_body(const int k, const float2* __restrict__ xy, const RawEvents& raw,
+                                                  int np, int ny,
+                                                  int nz, int pad, EvRec* __restrict__ sxy,
+                                                  uint32_t* __restrict__ nvalid,
+                                                  uint16_t* __restrict__ rowstart, uint32_t* __restrict__ pair_work,
+                                                  int n_pairs)
 {
     extern __shared__ uint32_t hist[];  // nb + 1 counters, then scanned in place
     __shared__ float s_H[9];
@@ -281,12 +299,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     __shared__ uint32_t wave_tot[4];
     __shared__ uint32_t big;  // some |x0| or |y0| above 2^40 (never a real pixel)
     const int nb = ny + 2 * pad + 2;
-    const int k = blockIdx.x;
     // nvalid[np + z]: "plane z has a coefficient set that needs the IEEE divide", set by
     // k_plane_coef (next kernel on the stream), read by the packed voting kernel
     if (k == 0) {
         // (+ 8 work counters of the persistent voting kernel behind the per-plane flags)
         for (int i = threadIdx.x; i < nz + 8; i += 256) nvalid[np + i] = 0;
+        // (+ the records per (band, plane) pair that k_plane_coef counts for the fused kernel's partition)
+        if (pair_work)
+            for (int i = threadIdx.x; i < n_pairs; i += 256) pair_work[i] = 0;
         if (threadIdx.x == 0) {  // the multiplicity-0 record behind the last packet
             const EvRec none = {0.f, 0.f, 0u};
             sxy[(size_t)np * kPacket] = none;
@@ -413,6 +433,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     if (threadIdx.x == 0) nvalid[k] = total | (big << 31);  // total <= 1024
 }
 
+template <bool RAW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_sort_packets(const float2* __restrict__ xy, RawEvents raw,
+                                                      int np, int ny,
+                                                      int nz, int pad, EvRec* __restrict__ sxy,
+                                                      uint32_t* __restrict__ nvalid,
+                                                      uint16_t* __restrict__ rowstart)
+{
+    sort_packets_body<RAW>((int)blockIdx.x, xy, raw, np, ny, nz, pad, sxy, nvalid, rowstart, nullptr, 0);
+}
+
+// the packets of up to two cameras in ONE launch (the fused kernel's preparation: a 50 ms window has ~490
+// packets per camera, and two launches of ~490 blocks each cost two launch latencies for nothing)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_sort_packets_multi(PrepCameras cams, int ny, int nz, int pad,
+                                                                                                       int n_pairs)
+{
+    int k = (int)blockIdx.x;
+    const int c = (cams.n > 1 && k >= cams.cam[0].np) ? 1 : 0;
+    if (c) k -= cams.cam[0].np;
+    const PrepCamera& pc = cams.cam[c];
+    sort_packets_body<true>(k, nullptr, pc.raw, pc.np, ny, nz, pad, pc.sxy, pc.nvalid, pc.rowstart, pc.pair_work, n_pairs);
+}
+
 // lane mappings 2 and 4 sort groups of packets together (k_sort_groups)
 __device__ __host__ __forceinline__ bool grouped(int packed) { return packed == 2 || packed == 4; }
 
@@ -428,13 +470,13 @@ __device__ __host__ __forceinline__ bool grouped(int packed) { return packed == 
 constexpr int kCoefTilePackets = 16;
 
 template <bool STAGED>
-__global__ __launch_bounds__(1024) void k_plane_coef(const float* __restrict__ centers,
-                                                    const float* __restrict__ planes,
-                                                    const uint16_t* __restrict__ rowstart,
-                                                    uint32_t* __restrict__ nvalid, int np,
-                                                    Geom g, BandPlan bp,
-                                                    PlaneCoef* __restrict__ coef,
-                                                    uint32_t* __restrict__ cuts)
+__device__ __forceinline__ void plane_coef_body(const unsigned bid, const float* __restrict__ centers,
+                                                const float* __restrict__ planes,
+                                                const uint16_t* __restrict__ rowstart,
+                                                uint32_t* __restrict__ nvalid, int np,
+                                                const Geom& g, const BandPlan& bp,
+                                                PlaneCoef* __restrict__ coef,
+                                                uint32_t* __restrict__ cuts, uint32_t* __restrict__ pair_work)
 {
     // 16 consecutive packets per plane make the plane-major tables (coef[z][p], cuts[band][z][p])
     // 64-byte coalesced writes
@@ -445,7 +487,7 @@ __global__ __launch_bounds__(1024) void k_plane_coef(const float* __restrict__ c
     // leave it as whole lines (dealt round-robin over the XCDs, every line was written in pieces:
     // 1024 x 1024 x 256, 10 M events: 422 us; groups of four 365 us; groups of eight 337 us).
     const int tiles_p = (np + kCoefTilePackets - 1) / kCoefTilePackets;
-    const unsigned tile = (blockIdx.x >> 6) * 64u + (blockIdx.x & 7u) * 8u + ((blockIdx.x >> 3) & 7u);
+    const unsigned tile = (bid >> 6) * 64u + (bid & 7u) * 8u + ((bid >> 3) & 7u);
     const int planes_per_block = (int)(blockDim.x >> 4);
     if (tile >= (unsigned)tiles_p * (unsigned)((g.nz + planes_per_block - 1) / planes_per_block)) return;
     const int k0 = (int)(tile % (unsigned)tiles_p) * kCoefTilePackets;
@@ -462,14 +504,18 @@ __global__ __launch_bounds__(1024) void k_plane_coef(const float* __restrict__ c
         for (int i = threadIdx.x; i < (count + 1) / 2; i += blockDim.x) dst[i] = src[i];
         __syncthreads();
     }
-    if (k >= np || z >= g.nz) return;
-    const size_t tid = (size_t)z * np + k;
+    // (with pair_work the threads beyond the tables stay: the row reductions below need whole rows of lanes;
+    //  they act as dead packets and store nothing)
+    const bool valid = k < np && z < g.nz;
+    if (!valid && !pair_work) return;
+    const int kq = valid ? k : 0, zq = valid ? z : 0;
+    const size_t tid = (size_t)zq * np + kq;
     PlaneCoef c;
-    plane_coefficients(centers[3 * k], centers[3 * k + 1], centers[3 * k + 2], planes[z], g, c.a,
+    plane_coefficients(centers[3 * kq], centers[3 * kq + 1], centers[3 * kq + 2], planes[zq], g, c.a,
                        c.bx, c.by, c.d);
     c.r = 1.f / c.d;
     c.pad0 = c.pad1 = 0;
-    const uint32_t nvraw = grouped(bp.packed) ? 1u : nvalid[k];
+    const uint32_t nvraw = !valid ? 0u : (grouped(bp.packed) ? 1u : nvalid[kq]);
     const int nv = (int)(nvraw & 0x7fffffffu);
     const bool big_events = (nvraw >> 31) != 0;
     // Which (packet, plane) pairs can vote at all?  NaN anywhere, d == 0, or an
@@ -484,11 +530,11 @@ __global__ __launch_bounds__(1024) void k_plane_coef(const float* __restrict__ c
                                 big_events || fabsf(c.a) > 0x1p40f || fabsf(c.bx) > 0x1p40f ||
                                 fabsf(c.by) > 0x1p40f);
     c.flags = dead ? kCoefSkip : (slow ? kCoefSlow : 0u);
-    coef[tid] = c;
-    if (slow) atomicOr(&nvalid[np + z], 1u);
+    if (valid) coef[tid] = c;
+    if (slow) atomicOr(&nvalid[np + zq], 1u);  // (slow implies valid: nv > 0)
 
     const uint16_t* rs = STAGED ? s_rowstart + (size_t)(threadIdx.x & 15) * (nb + 1)
-                                : rowstart + (grouped(bp.packed) ? 0 : (size_t)k * (nb + 1));
+                                : rowstart + (grouped(bp.packed) ? 0 : (size_t)kq * (nb + 1));
     // y0 = (Y*d - by)/a inverts the transfer; unusable when the map is (nearly) constant or
     // the inversion is ill-conditioned -- then the whole packet is the (superset) run
     const double a = (double)c.a, d = (double)c.d, by = (double)c.by;
@@ -538,8 +584,41 @@ __global__ __launch_bounds__(1024) void k_plane_coef(const float* __restrict__ c
             lo = 0xffffu;  // dead packet: contributes no rows
             hi = 0;
         }
-        cuts[((size_t)j * g.nz + z) * np + k] = lo | (hi << 16);  // 16 bits each
+        if (valid) cuts[((size_t)j * g.nz + zq) * np + kq] = lo | (hi << 16);  // 16 bits each
+        if (pair_work) {
+            // records of this (band, plane) over the 16 packets of the tile (lanes 16 i .. 16 i + 15 of a wave
+            // share the plane): a row reduction, then one atomic per (band, plane, tile)
+            int len = (int)hi - (int)lo;
+            len += __builtin_amdgcn_update_dpp(0, len, 0x111, 0xf, 0xf, true);  // row_shr:1
+            len += __builtin_amdgcn_update_dpp(0, len, 0x112, 0xf, 0xf, true);  // row_shr:2
+            len += __builtin_amdgcn_update_dpp(0, len, 0x114, 0xf, 0xf, true);  // row_shr:4
+            len += __builtin_amdgcn_update_dpp(0, len, 0x118, 0xf, 0xf, true);  // row_shr:8
+            if ((threadIdx.x & 15) == 15 && len > 0 && z < g.nz) atomicAdd(&pair_work[j * g.nz + z], (uint32_t)len);
+        }
     }
+}
+
+template <bool STAGED>
+__global__ __launch_bounds__(1024) void k_plane_coef(const float* __restrict__ centers,
+                                                    const float* __restrict__ planes,
+                                                    const uint16_t* __restrict__ rowstart,
+                                                    uint32_t* __restrict__ nvalid, int np,
+                                                    Geom g, BandPlan bp,
+                                                    PlaneCoef* __restrict__ coef,
+                                                    uint32_t* __restrict__ cuts)
+{
+    plane_coef_body<STAGED>(blockIdx.x, centers, planes, rowstart, nvalid, np, g, bp, coef, cuts, nullptr);
+}
+
+// the coefficient / cut tables of up to two cameras in one launch; camera 1's blocks start at blocks0
+template <bool STAGED>
+__global__ __launch_bounds__(1024) void k_plane_coef_multi(PrepCameras cams, Geom g, BandPlan bp, unsigned blocks0)
+{
+    unsigned bid = blockIdx.x;
+    const int c = (cams.n > 1 && bid >= blocks0) ? 1 : 0;
+    if (c) bid -= blocks0;
+    const PrepCamera& pc = cams.cam[c];
+    plane_coef_body<STAGED>(bid, pc.raw.centers, pc.planes, pc.rowstart, pc.nvalid, pc.np, g, bp, pc.coef, pc.cuts, pc.pair_work);
 }
 
 // (3) the voting kernel.  Work item = (packet chunk c, band j, plane z): the band's
@@ -1453,8 +1532,11 @@ __device__ __forceinline__ void packed_stream_asm_dealt(const EvRec* sxy, const 
                                                         const uint32_t* cutz, char* band_bytes,
                                                         int p_begin, int p_end, int lg_group, int wave, int n_waves,
                                                         int lane, int nx, int Li, int Ui, int row_base,
-                                                        uint32_t dummy_eo, int* pass_counter)
+                                                        uint32_t dummy_eo, int* pass_counter, uint32_t first_cuts)
 {
+    // first_cuts: the cut words of the wave's first pass, lane l = packet p_begin + wave * group + l (clamped to
+    // p_end - 1), loaded by the caller -- in the fused kernel BEFORE the previous phase's barrier and read-back,
+    // which hide the round trip that would otherwise open every phase
     const int group = 1 << lg_group;
     int npass = (p_end - p_begin + group - 1) >> lg_group;
     if (Ui - 1 < Li) npass = 0;  // no acceptable row (the unsigned range test needs Ui-1-Li >= 0)
@@ -1484,13 +1566,7 @@ __device__ __forceinline__ void packed_stream_asm_dealt(const EvRec* sxy, const 
         "v_mov_b32 v40, 0\n\t"
         "v_mov_b32 v41, 0\n\t"
         "s_mov_b32 s50, 0\n\t"
-        "s_lshl_b32 s45, s55, %7\n\t"
-        "s_add_i32 s45, s45, %5\n\t"
-        "v_add_u32 v58, s45, %15\n\t"        // the first pass's cut words
-        "v_min_i32 v58, %8, v58\n\t"
-        "v_max_i32 v58, 0, v58\n\t"          // (a camera without packets has p_end - 1 = -1)
-        "v_lshlrev_b32 v58, 2, v58\n\t"
-        "global_load_dword v35, v58, %2\n\t"
+        "v_mov_b32 v35, %20\n\t"             // the first pass's cut words (already here)
         DSI_ASM_FILL_DEAL("s47", "a")
         DSI_ASM_GATHER("v[42:44]", "v[46:49]", "v45")
         "s_cmp_eq_u32 s47, 0\n\t"
@@ -1513,7 +1589,7 @@ __device__ __forceinline__ void packed_stream_asm_dealt(const EvRec* sxy, const 
         :
         : "s"(sxy), "s"(coef4), "s"(cutz), "s"(s_npass), "s"(s_group), "s"(s_p_begin), "s"(s_p_end),
           "s"(s_lg), "s"(s_p_last), "s"(s_nx8), "s"(s_cbase), "s"(s_nxm2), "s"(s_Li), "s"(s_Uim1),
-          "s"(s_dummy), "v"(lane), "v"(ctr_addr), "v"(1), "s"(s_first), "v"(wave + n_waves)
+          "s"(s_dummy), "v"(lane), "v"(ctr_addr), "v"(1), "s"(s_first), "v"(wave + n_waves), "v"(first_cuts)
         : "memory", "scc", "vcc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s50", "s53", "s54", "s55",
           "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48",
           "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61",
@@ -1985,7 +2061,7 @@ __device__ __forceinline__ void stream_item(const EvRec* __restrict__ sxy, const
                                             const uint32_t* __restrict__ cuts, const uint32_t* __restrict__ slow_any,
                                             int np, const Geom& g, const BandPlan& bp, int j, int z, int p_begin,
                                             int p_end, char* __restrict__ band_bytes, int Li, int Ui, int row_base,
-                                            int* __restrict__ s_pass)
+                                            int* __restrict__ s_pass, uint32_t first_cuts = 0)
 {
     const int nx = g.nx;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -2037,7 +2113,7 @@ __device__ __forceinline__ void stream_item(const EvRec* __restrict__ sxy, const
         else if constexpr (DEAL)
             // (*s_pass = 2 * kWaves, set by the item's set-up; passes of 4 packets unless bp.pass_lg says otherwise)
             packed_stream_asm_dealt(sxy, coef4, cutz, band_bytes, p_begin, p_end, bp.pass_lg > 0 ? bp.pass_lg : 2, wave, kWaves,
-                                    lane, nx, Li, Ui, row_base, dummy_eo, s_pass);
+                                    lane, nx, Li, Ui, row_base, dummy_eo, s_pass, first_cuts);
         else
             packed_stream_asm(sxy, coef4, cutz, band_bytes, p_begin + wave * group, p_end, lg_group,
                               kWaves * group, lane, nx, Li, Ui, row_base, dummy_eo);
@@ -2193,6 +2269,11 @@ struct FusedBest {
     uint32_t idx4[(CELLS + 3) / 4];  // plane indices, four per register
 };
 
+// Read the band's owned rows back (one value per thread and 1024-cell stretch), zero the band, and either keep
+// the fp32 values (camera 0 of 2) or fuse them with camera 0's and update the running arg-max.  Written without
+// control flow per cell -- out-of-range lanes read the last owned cell and "zero" a halo cell that is zeroed
+// anyway -- so that the CELLS / 2 LDS reads of a half are in flight together: with a branch per cell every
+// read was waited for on its own, and the read-back took 3 us per phase (tools/fused_trace.py).
 template <int CELLS, int OP, bool LAST, bool TWO>
 __device__ __forceinline__ void fused_consume(acc_t* __restrict__ band, int nx, int n_own, int rows_lds,
                                               float* __restrict__ va, FusedBest<CELLS>& fb, int z)
@@ -2203,22 +2284,39 @@ __device__ __forceinline__ void fused_consume(acc_t* __restrict__ band, int nx, 
     //  the voting loops, which name 40 physical registers themselves)
     int t = (int)threadIdx.x;
     asm volatile("" : "+v"(t));
+    constexpr int HALF = CELLS / 2;
+    static_assert(CELLS % 2 == 0, "two halves");
 #pragma unroll
-    for (int k = 0; k < CELLS; ++k) {
-        const int i = t + k * 1024;
-        if (i < n_own) {
-            const float v = fix_to_float(own[i]);  // flush_band's rounding
-            own[i] = 0;
+    for (int h = 0; h < CELLS; h += HALF) {
+        acc_t raw[HALF];
+#pragma unroll
+        for (int k = 0; k < HALF; ++k) raw[k] = own[min(t + (h + k) * 1024, n_own - 1)];
+        uint32_t hi_or = 0;
+#pragma unroll
+        for (int k = 0; k < HALF; ++k) hi_or |= (uint32_t)(raw[k] >> 32);
+#pragma unroll
+        for (int k = 0; k < HALF; ++k) {
+            const int i = t + (h + k) * 1024;
+            acc_t* cell = i < n_own ? own + i : band;  // band[0]: first halo row, cleared below
+            *cell = 0;
+        }
+        // sums of 2^52 and more (2 M votes in one voxel) take the general conversion: decided per wave
+        const bool big = __builtin_amdgcn_ballot_w64((hi_or >> 20) != 0u) != 0ull;
+#pragma unroll
+        for (int k = 0; k < HALF; ++k) {
+            const float v = big ? (float)((double)raw[k] * kFixInv)
+                                : (float)(__longlong_as_double((long long)(raw[k] | 0x4140000000000000ull)) - 2097152.0);
+            const int kk = h + k;
             if (!LAST) {
-                va[k] = v;
+                va[kk] = v;
             } else {
                 // process1.cpp:126-158: fused = 0; fused += dsi0; fused.<op>TwoGrids(dsi1)
-                const float f = TWO ? fuse_op<OP>(0.f + va[k], v) : v;
-                if (fb.best[k] < f) {  // strict: the first maximum wins (cartesian3dgrid.cpp:132-134)
-                    fb.best[k] = f;
-                    const int sh = (k & 3) * 8;
-                    fb.idx4[k >> 2] = (fb.idx4[k >> 2] & ~(0xffu << sh)) | ((uint32_t)z << sh);
-                }
+                const float f = TWO ? fuse_op<OP>(0.f + va[kk], v) : v;
+                const bool better = fb.best[kk] < f;  // strict: the first maximum wins (cartesian3dgrid.cpp:132-134)
+                fb.best[kk] = better ? f : fb.best[kk];
+                const int sh = (kk & 3) * 8;
+                const uint32_t with_z = (fb.idx4[kk >> 2] & ~(0xffu << sh)) | ((uint32_t)z << sh);
+                fb.idx4[kk >> 2] = better ? with_z : fb.idx4[kk >> 2];
             }
         }
     }
@@ -2243,13 +2341,15 @@ __global__ __launch_bounds__(1024) void k_vote_fuse_argmax(FusedCameras cams, Ge
     const int nx = g.nx;
     // Workgroup b runs on XCD b % 8: each XCD gets one contiguous eighth of the (band-major) pair list,
     // so that a band's records stream through at most two XCDs' L2s, and splits it evenly over its
-    // workgroups -- or by `splits` (gridDim.x + 1 pair indices, block order) when the host supplies a
-    // balanced partition.
+    // workgroups -- or by `splits` (gridDim.x + 1 pair indices in XCD-major workgroup order) when
+    // k_fused_splits has balanced the partition by the records each pair holds.
     const int P = bp.bands * g.nz;
     int q_begin, q_end;
     if (splits) {
-        q_begin = (int)splits[blockIdx.x];
-        q_end = (int)splits[blockIdx.x + 1];
+        // rank = position of this workgroup in XCD-major order: XCD x still covers one contiguous stretch
+        const int rank = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+        q_begin = (int)splits[rank];
+        q_end = (int)splits[rank + 1];
     } else {
         const int x = blockIdx.x & 7, l = blockIdx.x >> 3, per = gridDim.x >> 3;
         const int lo = (int)(((long long)P * x) / 8), hi = (int)(((long long)P * (x + 1)) / 8);
@@ -2267,6 +2367,18 @@ __global__ __launch_bounds__(1024) void k_vote_fuse_argmax(FusedCameras cams, Ge
     float va[CELLS];
     FusedBest<CELLS> fb;
     int cur_j = -1, r0 = 0, r1 = 0, n_own = 0;
+    // the cut words of this wave's first pass of phase (pair q, camera c) -- see packed_stream_asm_dealt
+    constexpr bool kPrefetchCuts = MAPPING == 1;
+    auto first_cuts_of = [&](int q, int c) -> uint32_t {
+        if (!kPrefetchCuts) return 0u;
+        const FusedCamera& cam = cams.cam[c];
+        if (cam.np <= 0) return 0u;
+        const int j = q / g.nz, z = q - j * g.nz;
+        const int lg = bp.pass_lg > 0 ? bp.pass_lg : 2;
+        const int p = min((int)((threadIdx.x / kWave) << lg) + (int)(threadIdx.x & 63), cam.np - 1);
+        return cam.cuts[((size_t)j * g.nz + z) * cam.np + p];
+    };
+    uint32_t cuts_next = first_cuts_of(q_begin, 0);
     auto emit = [&]() {
         // one key per owned pixel (the owned rows are contiguous in the image)
         unsigned long long* kp = keys + (size_t)r0 * nx;
@@ -2309,8 +2421,14 @@ __global__ __launch_bounds__(1024) void k_vote_fuse_argmax(FusedCameras cams, Ge
                     tr = __builtin_amdgcn_readfirstlane((((int)blockIdx.x * kFusedTracePhases + phase) * (BLOCK / kWave) + (int)(threadIdx.x / kWave)) * 4);
                 if (tr >= 0 && (threadIdx.x & 63) == 0) trace[tr] = wall_clock64();
             }
+            const uint32_t cuts_now = cuts_next;
             stream_item<BLOCK, MAPPING, true, true>(cam.sxy, cam.coef, cam.cuts, cam.slow_any, cam.np, g, bp, j, z, 0, cam.np,
-                                        reinterpret_cast<char*>(band), Li, Ui, r0 - 1, &s_pass);
+                                        reinterpret_cast<char*>(band), Li, Ui, r0 - 1, &s_pass, cuts_now);
+            // the next phase's first cut words travel during this phase's barrier and read-back
+            if (c + 1 < cams.n)
+                cuts_next = first_cuts_of(q, c + 1);
+            else if (q + 1 < q_end)
+                cuts_next = first_cuts_of(q + 1, 0);
             if (tr >= 0 && (threadIdx.x & 63) == 0) trace[tr + 1] = wall_clock64();
             __syncthreads();
             if (threadIdx.x == 0) s_pass = kPass0;
@@ -2335,6 +2453,54 @@ __global__ __launch_bounds__(1024) void k_vote_fuse_argmax(FusedCameras cams, Ge
         }
     }
     emit();
+}
+
+// Balanced partition of the (band-major) pair list for the fused kernel: pair q costs work0[q] + work1[q]
+// records (counted by k_plane_coef from the runs the voting loop will walk) plus a fixed cost per pair (the
+// set-up, barriers and read-back of its phases, in record units); the n_wg + 1 split points cut the list
+// into stretches of equal cost.  One block; P <= 1024 * kSplitSlice pairs.
+constexpr int kSplitSlice = 64;
+
+__global__ __launch_bounds__(1024) void k_fused_splits(const uint32_t* __restrict__ work0, const uint32_t* __restrict__ work1,
+                                                       int P, uint32_t fixed_per_pair, int n_wg,
+                                                       unsigned long long* __restrict__ prefix /* [P] scratch */,
+                                                       uint32_t* __restrict__ splits)
+{
+    __shared__ unsigned long long wave_tot[16];
+    const int per = (P + 1023) / 1024;
+    const int b0 = min(P, (int)threadIdx.x * per), b1 = min(P, b0 + per);
+    unsigned long long local = 0;
+    for (int i = b0; i < b1; ++i) local += (unsigned long long)work0[i] + (work1 ? work1[i] : 0u) + fixed_per_pair;
+    unsigned long long incl = local;
+    const int lane = threadIdx.x & 63;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wave_tot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    unsigned long long base = incl - local, total = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < (int)(threadIdx.x >> 6)) base += wave_tot[w];
+        total += wave_tot[w];
+    }
+    for (int i = b0; i < b1; ++i) {
+        base += (unsigned long long)work0[i] + (work1 ? work1[i] : 0u) + fixed_per_pair;
+        prefix[i] = base;  // cost of pairs 0 .. i
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r <= n_wg; r += 1024) {
+        // first pair index whose inclusive prefix reaches r / n_wg of the total: that many pairs lie before the cut
+        const unsigned long long target = (total * (unsigned long long)r + (unsigned long long)n_wg - 1) / (unsigned long long)n_wg;
+        int lo = 0, hi = P;  // smallest i in [0, P] with (i == P or prefix[i] >= target) -> pairs [0, i] ... cut after i
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (prefix[mid] >= target) hi = mid; else lo = mid + 1;
+        }
+        // pairs before the r-th cut: those whose inclusive prefix is <= target (so that the last cut takes all)
+        int cut = (r == 0) ? 0 : (r == n_wg ? P : min(P, lo + 1));
+        splits[r] = (uint32_t)cut;
+    }
 }
 
 // (3c) GROUPED mapping: S consecutive packets (a "group"; their poses are microseconds apart)
@@ -3366,6 +3532,60 @@ hipError_t launch_vote_bands(hipStream_t s, const EvRec* sxy, const PlaneCoef* c
     }
 }
 
+int fused_max_pairs() { return 1024 * kSplitSlice; }
+
+hipError_t launch_prepare_cameras(hipStream_t s, const PrepCameraArgs* args, int n, const Geom& g, const BandPlan& bp)
+{
+    if (n < 1 || n > 2) return hipErrorInvalidValue;
+    const int n_pairs = bp.bands * g.nz;
+    PrepCameras cams{};
+    cams.n = n;
+    for (int c = 0; c < n; ++c) {
+        const PrepCameraArgs& a = args[c];
+        cams.cam[c].raw = RawEvents{a.Rt, a.ex, a.ey, a.packet_first, a.lut, a.sensor_w, a.sensor_h, g, a.centers, 0};
+        cams.cam[c].np = a.np;
+        cams.cam[c].sxy = a.sxy;
+        cams.cam[c].nvalid = a.nvalid;
+        cams.cam[c].rowstart = a.rowstart;
+        cams.cam[c].planes = a.planes;
+        cams.cam[c].coef = a.coef;
+        cams.cam[c].cuts = a.cuts;
+        cams.cam[c].pair_work = a.pair_work;
+    }
+    unsigned total_np = 0;
+    for (int c = 0; c < cams.n; ++c) total_np += (unsigned)cams.cam[c].np;
+    if (total_np == 0) return hipSuccess;
+    {
+        const size_t lds = (size_t)(g.ny + 2 * bp.row_pad + 3) * sizeof(uint32_t);
+        hipLaunchKernelGGL(k_sort_packets_multi, dim3(total_np), dim3(256), lds, s, cams, g.ny, g.nz, bp.row_pad, n_pairs);
+        if (hipError_t e = hipExtGetLastError()) return e;
+    }
+    const size_t table_bytes = ((size_t)kCoefTilePackets * (size_t)(g.ny + 2 * bp.row_pad + 3) * sizeof(uint16_t) + 7) & ~(size_t)7;
+    const bool staged = table_bytes <= max_dynamic_lds();
+    const unsigned zdiv = staged ? 64u : 16u;
+    unsigned blocks[2] = {0, 0};
+    for (int c = 0; c < cams.n; ++c) {
+        const unsigned tiles_p = (unsigned)((cams.cam[c].np + kCoefTilePackets - 1) / kCoefTilePackets);
+        blocks[c] = (tiles_p * (((unsigned)g.nz + zdiv - 1) / zdiv) + 63u) & ~63u;
+    }
+    if (staged) {
+        if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_plane_coef_multi<true>), table_bytes)) return e;
+        hipLaunchKernelGGL(k_plane_coef_multi<true>, dim3(blocks[0] + blocks[1]), dim3(1024), table_bytes, s, cams, g, bp, blocks[0]);
+    } else {
+        hipLaunchKernelGGL(k_plane_coef_multi<false>, dim3(blocks[0] + blocks[1]), dim3(256), 0, s, cams, g, bp, blocks[0]);
+    }
+    return hipExtGetLastError();
+}
+
+hipError_t launch_fused_splits(hipStream_t s, const uint32_t* work0, const uint32_t* work1, int n_pairs, uint32_t fixed_per_pair,
+                               unsigned long long* prefix, uint32_t* splits)
+{
+    if (n_pairs > 1024 * kSplitSlice) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_fused_splits, dim3(1), dim3(1024), 0, s, work0, work1, n_pairs, fixed_per_pair, fused_grid_blocks(), prefix,
+                       splits);
+    return hipExtGetLastError();
+}
+
 template <int MAPPING>
 static hipError_t launch_vote_fuse_argmax_t(hipStream_t s, const FusedCameras& cams, const Geom& g, const BandPlan& bp,
                                             int op, const uint32_t* splits, unsigned blocks, unsigned long long* keys,
@@ -3559,15 +3779,16 @@ __global__ __launch_bounds__(256) void k_pack_argmax(const float* __restrict__ c
     keys[i] = (bits << 8) | (unsigned long long)(255 - ((int)idx[i] + plane_begin));
 }
 
-__global__ __launch_bounds__(256) void k_unpack_argmax(const unsigned long long* __restrict__ keys,
+__global__ __launch_bounds__(256) void k_unpack_argmax(unsigned long long* __restrict__ keys,
                                                        int n, const float* __restrict__ planes_full,
                                                        float* __restrict__ conf,
                                                        uint8_t* __restrict__ idx,
-                                                       float* __restrict__ depth)
+                                                       float* __restrict__ depth, int clear)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const unsigned long long k = keys[i];
+    if (clear) keys[i] = 0ull;  // ready for the next fused vote (saves a memset launch per window)
     const int gi = 255 - (int)(k & 255ull);
     conf[i] = __uint_as_float((uint32_t)(k >> 8));
     idx[i] = (uint8_t)gi;
@@ -3581,11 +3802,11 @@ hipError_t launch_pack_argmax(hipStream_t s, const float* conf, const uint8_t* i
     return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
-hipError_t launch_unpack_argmax(hipStream_t s, const unsigned long long* keys, int n, const float* planes_full,
-                                float* conf, uint8_t* idx, float* depth)
+hipError_t launch_unpack_argmax(hipStream_t s, unsigned long long* keys, int n, const float* planes_full,
+                                float* conf, uint8_t* idx, float* depth, int clear)
 {
     hipLaunchKernelGGL(k_unpack_argmax, dim3((n + 255) / 256), dim3(256), 0, s, keys, n, planes_full, conf, idx,
-                       depth);
+                       depth, clear);
     return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 

@@ -191,7 +191,7 @@ class WindowStream:
     window (main.cpp:262-275); here they are reused -- evaluateDSI resets the DSI anyway (:145)."""
 
     def __init__(self, ctx, cams, dsi_shape, fusion_method=E.FUSE_HM, luts=(None, None),
-                 inverse_depth=False, depth=2, materialize_fused=True, fused_vote=False):
+                 inverse_depth=False, depth=2, materialize_fused=True, fused_vote=False, concurrent=False):
         """materialize_fused=False: the fused DSI (the reference's mapper_fused.dsi_) is not written;
         the camera fusion happens inside the arg-max kernel (same bits, one pass less over the
         volume) -- for streams that only keep the depth maps.
@@ -202,11 +202,22 @@ class WindowStream:
         self.fused_vote = bool(fused_vote)
         self.materialize_fused = bool(materialize_fused) and not self.fused_vote
         self.fusion_method = int(fusion_method)
-        self.mappers = [E.MapperEMVS(ctx, cams[c], dsi_shape, lut=luts[c], inverse_depth=inverse_depth)
-                        for c in range(2)]
+        # concurrent=True: every slot owns a context (HIP stream) and its own pair of camera mappers, so that
+        # consecutive windows are INDEPENDENT streams of work: the next window's preparation kernels and the
+        # first workgroups of its voting kernel run on the CUs the current window's tail has already left
+        # (the fused kernel is one persistent workgroup per CU; they finish between 0.5x and 1x its duration).
+        # Windows are independent in the reference too (main.cpp:177: fresh mappers per window).
+        self.concurrent = bool(concurrent) and depth > 1
+        self.contexts = [ctx] + ([E.Context(ctx.device) for _ in range(depth - 1)] if self.concurrent else [])
+        self._own_contexts = self.contexts[1:]
+        sets = len(self.contexts)
+        self.mapper_sets = [[E.MapperEMVS(self.contexts[k], cams[c], dsi_shape, lut=luts[c], inverse_depth=inverse_depth)
+                             for c in range(2)] for k in range(sets)]
+        self.mappers = self.mapper_sets[0]
         dims = self.mappers[0].dsi_.getDimensions()
-        self.fused = [E.Grid3D(ctx, *dims) if self.materialize_fused else None for _ in range(depth)]
-        self.extract = [E.MapperEMVS(ctx, cams[0], dsi_shape, inverse_depth=inverse_depth) for _ in range(depth)]
+        self.fused = [E.Grid3D(self.contexts[k % sets], *dims) if self.materialize_fused else None for k in range(depth)]
+        self.extract = [E.MapperEMVS(self.contexts[k % sets], cams[0], dsi_shape, inverse_depth=inverse_depth)
+                        for k in range(depth)]
         self.k = 0
         self.voted = 0
         self._pins = {}     # (slot, camera) -> page-locked (Rt, packet_first) staging of asynchronous uploads
@@ -229,6 +240,8 @@ class WindowStream:
         unchanged until this window's result has been fetched; the uploads then run as plain DMAs
         and the host does not wait for them.  Returns the slot to pass to fetch()."""
         slot = self.k % len(self.fused)
+        ctx = self.contexts[slot % len(self.contexts)]
+        mappers = self.mapper_sets[slot % len(self.mapper_sets)]
         T_rv_w = reference_view_process1(trajectories[0], ts, rv_pos)
         own, fused_batches = [], []
         for c in range(2):
@@ -238,7 +251,7 @@ class WindowStream:
                 pk = E.packetize(events[c][2], trajectories[c], T_rv_w)
                 if pk is None:                      # evaluateDSI returns false: < 1024 events (:71-75)
                     if not self.fused_vote:
-                        self.mappers[c].dsi_.resetGrid()
+                        mappers[c].dsi_.resetGrid()
                         continue
                     pk = (np.zeros(0, np.uint32), np.zeros((0, 12), np.float32))   # a batch without packets
                 first, Rt = pk
@@ -247,20 +260,20 @@ class WindowStream:
                     pr.a[:Rt.shape[0]] = Rt
                     pf.a[:first.shape[0]] = first
                     Rt, first = pr.a[:Rt.shape[0]], pf.a[:first.shape[0]]
-                b = E.EventBatch(self.ctx, events[c][0], events[c][1], Rt, first, asynchronous=asynchronous)
+                b = E.EventBatch(ctx, events[c][0], events[c][1], Rt, first, asynchronous=asynchronous)
                 own.append(b)
             if self.fused_vote:
                 fused_batches.append(b)
             else:
-                self.mappers[c].evaluateDSI_batch(b)
+                mappers[c].evaluateDSI_batch(b)
             self.voted += b.n_packets * E.PACKET_SIZE
         if self.fused_vote:
-            self.extract[slot].computeDepthMapOfEvents(self.mappers, fused_batches, self.fusion_method)
+            self.extract[slot].computeDepthMapOfEvents(mappers, fused_batches, self.fusion_method)
         elif self.materialize_fused:
-            self.fused[slot].setToFusionOf(self.mappers[0].dsi_, self.mappers[1].dsi_, self.fusion_method)
+            self.fused[slot].setToFusionOf(mappers[0].dsi_, mappers[1].dsi_, self.fusion_method)
             self.extract[slot].computeDepthMap(self.fused[slot])
         else:
-            self.extract[slot].computeDepthMapOfFusion(self.mappers[0].dsi_, self.mappers[1].dsi_,
+            self.extract[slot].computeDepthMapOfFusion(mappers[0].dsi_, mappers[1].dsi_,
                                                        self.fusion_method)
         for b in own:
             b.close()                               # the block returns to the pool once its readers are done
@@ -274,9 +287,16 @@ class WindowStream:
     def fused_grid(self, slot):
         return self.fused[slot]
 
+    def context_of_slot(self, slot):
+        """The context window `slot` runs in (pre-uploaded batches must live there)."""
+        return self.contexts[slot % len(self.contexts)]
+
     def close(self):
-        for o in self.mappers + [f for f in self.fused if f is not None] + self.extract:
+        for o in [m for ms in self.mapper_sets for m in ms] + [f for f in self.fused if f is not None] + self.extract:
             o.close()
+        for c in self._own_contexts:
+            c.close()
+        self._own_contexts = []
         for pair in self._pins.values():
             for a in pair:
                 a.close()

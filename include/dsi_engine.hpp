@@ -131,6 +131,38 @@ inline auto to_pose7(const PoseT& T, double* p) -> decltype(T.getRotation().w(),
 }
 
 inline void camera_of(const PinholeCameraModel& c, PinholeCameraModel* out) { *out = c; }
+
+// The distortion model the reference reads from cam.cameraInfo().distortion_model
+// (mapper_emvs_stereo.cpp:62): "plumb_bob" -> the camera's own rectifyPoint, "fisheye" ->
+// fisheye_rectifyPoint = cv::fisheye::undistortPoints(K, D, R, P) (:243-254, :256-299).  A camera type
+// without cameraInfo() is taken as plumb_bob (image_geometry's default model).
+template <typename CamT>
+inline auto distortion_model_of(const CamT& c, int) -> decltype(std::string(c.cameraInfo().distortion_model))
+{
+    return std::string(c.cameraInfo().distortion_model);
+}
+template <typename CamT>
+inline std::string distortion_model_of(const CamT&, long)
+{
+    return "plumb_bob";
+}
+
+// Customisation point for fisheye cameras: OpenCV's arithmetic stays on the host side of the boundary, so
+// the caller overloads this for its camera type -- in that type's namespace (camera_of finds it by
+// argument-dependent lookup) or in namespace dsi before this header -- with the reference's own four lines --
+//   cv::Point2f raw32(x, y), rect32;  cv::fisheye::undistortPoints(src(raw32), dst(rect32), c.intrinsicMatrix(),
+//   c.distortionCoeffs(), c.rotationMatrix(), c.fullProjectionMatrix());  *u = rect32.x; *v = rect32.y;
+// (mapper_emvs_stereo.cpp:243-254).  The default refuses: a plumb_bob LUT for a fisheye lens would shift
+// every vote without any error being reported.
+template <typename CamT>
+inline void fisheye_rectify_point(const CamT&, double, double, double*, double*)
+{
+    throw Error(DSI_ERR_INVALID,
+                "fisheye distortion model: overload dsi::fisheye_rectify_point for this camera type "
+                "(cv::fisheye::undistortPoints with K, D, R, P, mapper_emvs_stereo.cpp:243-254), or build the "
+                "rectification LUT yourself and pass a dsi::PinholeCameraModel");
+}
+
 template <typename CamT>
 inline auto camera_of(const CamT& c, PinholeCameraModel* out) -> decltype(c.fullResolution(), void())
 {
@@ -141,14 +173,26 @@ inline auto camera_of(const CamT& c, PinholeCameraModel* out) -> decltype(c.full
     out->fy = (float)c.fy();
     out->cx = (float)c.cx();
     out->cy = (float)c.cy();
-    // precomputeRectifiedPoints (mapper_emvs_stereo.cpp:256-299): raw pixel -> rectified pixel, by
-    // the camera model's own rectifyPoint (OpenCV arithmetic stays on the host side of the boundary)
+    // precomputeRectifiedPoints (mapper_emvs_stereo.cpp:256-299): raw pixel -> rectified pixel by the model
+    // the camera declares (OpenCV arithmetic stays on the host side of the boundary)
+    const std::string model = distortion_model_of(c, 0);
+    const bool plumb_bob = model == "plumb_bob", fisheye = model == "fisheye";
+    if (!plumb_bob && !fisheye)  // the reference logs "Distortion model not set properly!" and goes on with an
+                                 // uninitialised table (:289-293); here the caller gets to know
+        throw Error(DSI_ERR_INVALID, "Distortion model not set properly: '" + model + "' (expected plumb_bob or fisheye)");
     out->rectified_points.resize((size_t)2 * out->width * out->height);
     for (int y = 0; y < out->height; ++y)
         for (int x = 0; x < out->width; ++x) {
-            const auto r = c.rectifyPoint(decltype(c.rectifyPoint({}))((double)x, (double)y));
-            out->rectified_points[2 * ((size_t)y * out->width + x)] = (float)r.x;
-            out->rectified_points[2 * ((size_t)y * out->width + x) + 1] = (float)r.y;
+            double u, v;
+            if (plumb_bob) {
+                const auto r = c.rectifyPoint(decltype(c.rectifyPoint({}))((double)x, (double)y));
+                u = r.x;
+                v = r.y;
+            } else {
+                fisheye_rectify_point(c, (double)x, (double)y, &u, &v);
+            }
+            out->rectified_points[2 * ((size_t)y * out->width + x)] = (float)u;
+            out->rectified_points[2 * ((size_t)y * out->width + x) + 1] = (float)v;
         }
 }
 

@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdio>
 #include <map>
+#include <string>
 #include <vector>
 
 #include "dsi_engine.hpp"
@@ -106,7 +107,16 @@ struct Point2d {
 namespace image_geometry {
 class PinholeCameraModel {
 public:
-    PinholeCameraModel(int w, int h, double fx, double fy, double cx, double cy) : w_(w), h_(h), fx_(fx), fy_(fy), cx_(cx), cy_(cy) {}
+    // sensor_msgs::CameraInfo, the one field MapperEMVS reads (mapper_emvs_stereo.cpp:62)
+    struct CameraInfo {
+        std::string distortion_model;
+    };
+    PinholeCameraModel(int w, int h, double fx, double fy, double cx, double cy, const char* model = "plumb_bob")
+        : w_(w), h_(h), fx_(fx), fy_(fy), cx_(cx), cy_(cy)
+    {
+        info_.distortion_model = model;
+    }
+    const CameraInfo& cameraInfo() const { return info_; }
     cv::Size fullResolution() const
     {
         cv::Size s;
@@ -124,7 +134,21 @@ public:
 private:
     int w_, h_;
     double fx_, fy_, cx_, cy_;
+    CameraInfo info_;
 };
+// a second camera type whose owner supplies the fisheye rectification (see dsi::fisheye_rectify_point below)
+class FisheyeCameraModel : public PinholeCameraModel {
+public:
+    using PinholeCameraModel::PinholeCameraModel;
+};
+// what a maintainer adds for a fisheye camera, in the camera type's namespace (found by argument-dependent
+// lookup from dsi::camera_of): the reference's fisheye_rectifyPoint (mapper_emvs_stereo.cpp:243-254); here a
+// closed form stands in for cv::fisheye::undistortPoints
+inline void fisheye_rectify_point(const FisheyeCameraModel&, double x, double y, double* u, double* v)
+{
+    *u = 0.5 * x + 1.0;
+    *v = 0.25 * y - 2.0;
+}
 }  // namespace image_geometry
 
 // ---------------------------------------------------------------- the reference's call sequence
@@ -165,8 +189,35 @@ void process_1_like_the_reference(const LinearTrajectory& trajectory0, const Lin
 
 }  // namespace
 
-int main()
+// dsi::camera_of and the distortion model (mapper_emvs_stereo.cpp:62, :256-299): host-only, no GPU needed
+static int check_camera_of()
 {
+    const int W = 12, H = 7;
+    dsi::PinholeCameraModel out;
+    dsi::camera_of(image_geometry::PinholeCameraModel(W, H, 70.0, 71.0, 6.0, 3.0), &out);   // plumb_bob: rectifyPoint
+    if (out.width != W || out.height != H || out.fy != 71.f || out.rectified_points.size() != (size_t)2 * W * H) return 20;
+    if (out.rectified_points[2 * (3 * W + 5)] != 5.f || out.rectified_points[2 * (3 * W + 5) + 1] != 3.f) return 21;
+    try {   // a fisheye camera nobody supplied the rectification for: refused, not silently plumb_bob
+        dsi::camera_of(image_geometry::PinholeCameraModel(W, H, 70.0, 70.0, 6.0, 3.0, "fisheye"), &out);
+        return 22;
+    } catch (const dsi::Error& e) {
+        if (e.code != DSI_ERR_INVALID || std::string(e.what()).find("fisheye") == std::string::npos) return 23;
+    }
+    try {   // "Distortion model not set properly!" (:289-293)
+        dsi::camera_of(image_geometry::PinholeCameraModel(W, H, 70.0, 70.0, 6.0, 3.0, "equidistant"), &out);
+        return 24;
+    } catch (const dsi::Error& e) {
+        if (e.code != DSI_ERR_INVALID) return 25;
+    }
+    dsi::camera_of(image_geometry::FisheyeCameraModel(W, H, 70.0, 70.0, 6.0, 3.0, "fisheye"), &out);   // the owner's overload
+    if (out.rectified_points[2 * (4 * W + 6)] != 4.f || out.rectified_points[2 * (4 * W + 6) + 1] != -1.f) return 26;
+    std::printf("camera_of: plumb_bob / fisheye / unknown distortion models handled: OK\n");
+    return 0;
+}
+
+int main(int argc, char** argv)
+{
+    if (argc > 1 && std::string(argv[1]) == "--camera-of") return check_camera_of();
     try {
         const int W = 80, H = 60;
         const image_geometry::PinholeCameraModel cam0(W, H, 70.0, 70.0, 40.0, 30.0), cam1 = cam0;

@@ -81,3 +81,13 @@ def test_reference_typed_call_sequence_runs(built):
     r = subprocess.run([EXE_REF_TYPES], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK" in r.stdout
+
+
+def test_camera_of_honours_the_distortion_model(built):
+    """ADVICE r02 (medium): dsi::camera_of reads cam.cameraInfo().distortion_model like the reference
+    (mapper_emvs_stereo.cpp:62, :256-299): plumb_bob -> rectifyPoint, fisheye -> the owner's
+    fisheye_rectify_point overload or a loud refusal, anything else -> an error.  Host-only."""
+    build_ref_types_exe()
+    r = subprocess.run([EXE_REF_TYPES, "--camera-of"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK" in r.stdout

@@ -3,7 +3,7 @@
 Runs one 512x512x200 window (2 x 500 k events) through dsi_mapper_depth_map_of_events with the test hook
 that stamps every (workgroup, phase, wave) with the 100 MHz clock at: stream begins / stream ends / after
 barrier + read-back + clear / after the closing barrier, and prints the averages.
-Usage (GPU box): python tools/fused_trace.py [events_per_window] [packed]
+Usage (GPU box): python tools/fused_trace.py [events_per_window] [packed] [fixed cost of a phase in records] [pass_lg]
 """
 import ctypes as C
 import os
@@ -37,6 +37,13 @@ for _ in range(3):
     ms[0].computeDepthMapOfEvents(ms, batches, d.FUSE_HM)
 ctx.synchronize()
 n = C.c_size_t()
+if len(sys.argv) > 3:
+    L.dsi_test_fused_fixed_cost.argtypes = [C.c_void_p, C.c_int]
+    assert L.dsi_test_fused_fixed_cost(ms[0]._h, int(sys.argv[3])) == 0
+if len(sys.argv) > 4:
+    L.dsi_test_pass_lg.argtypes = [C.c_void_p, C.c_int]
+    for m in ms:
+        assert L.dsi_test_pass_lg(m._h, int(sys.argv[4])) == 0
 L.dsi_test_fused_trace_enable.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
 L.dsi_test_fused_trace_read.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
 assert L.dsi_test_fused_trace_enable(ms[0]._h, C.byref(n)) == 0
@@ -71,6 +78,15 @@ names = ["start skew", "first wave done", "median wave done", "last wave done", 
 for k, nm in enumerate(names):
     print("%-18s mean %7.2f us   p10 %7.2f   p90 %7.2f" % (nm, ph[:, k].mean(), np.percentile(ph[:, k], 10), np.percentile(ph[:, k], 90)))
 print("phases: %d; sum of phase totals / workgroups = %.1f us" % (len(ph), ph[:, 6].sum() / wg_valid.sum()))
+# the slowest and the fastest workgroups: phases, mean stream time, first / last stamp
+order = np.argsort(-np.where(wg_valid, t[..., 3].max(axis=(1, 2)), 0))
+for w in list(order[:6]) + list(order[wg_valid.sum() - 3:wg_valid.sum()]):
+    nph = int(valid[w, :, 0].sum())
+    s_ = t[w, :nph]
+    dur = s_[:, :, 3].max(axis=1) - s_[:, :, 0].min(axis=1)
+    stream = s_[:, :, 1].max(axis=1) - s_[:, :, 0].min(axis=1)
+    print("wg %3d (xcd %d, slot %2d): %2d phases, %.1f -> %.1f us, phase mean %.1f (stream %.1f) max %.1f us"
+          % (w, w & 7, w >> 3, nph, s_[..., 0].min() - t0, s_[..., 3].max() - t0, dur.mean(), stream.mean(), dur.max()))
 for o in ms + batches:
     o.close()
 ctx.close()
