@@ -75,6 +75,14 @@ def parse():
                     help="windows: all windows on ONE stream (no overlap of consecutive windows); for rocprofv3 runs, "
                          "whose per-kernel durations otherwise include the time a kernel waits for the previous "
                          "window's workgroups to leave the CUs")
+    ap.add_argument("--temporal-collective", choices=["allreduce", "reduce_scatter"], default="allreduce",
+                    help="stereo, N > 1, --collective engine: the time slices' temporal fusion as ONE all-reduce of the "
+                         "accumulator + finalize + arg-max on every rank (default), or as a reduce-scatter by planes + "
+                         "finalize / arg-max of the owned planes + all-reduce(MAX) of 8-byte keys (half the xGMI bytes; "
+                         "the fused DSI is not completed on any rank)")
+    ap.add_argument("--gm", choices=["tree", "log"], default="tree",
+                    help="cameras4: n-ary geometric mean as the balanced tree of the reference's 2-ary sqrt(a*b) "
+                         "(DSI_ACC_GM_TREE, default) or as exp(mean(log)) (DSI_ACC_LOG_SUM)")
     ap.add_argument("--no-extra", action="store_true",
                     help="default (stereo, 1 GPU) run only: do not append the one-GPU lines of the windows and "
                          "cameras4 workloads (each is a sub-run of this script) to the JSON line")
@@ -279,8 +287,24 @@ def stream_kernels(d, ctx):
         ms = ctx.timer_stop() / reps
         out[name] = {"ms": ms, "GBps": nbytes / (ms * 1e-3) / 1e9,
                      "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    # the 4-camera geometric mean as the tree of the reference's 2-ary op: 4 reads + 1 write per voxel, and
+    # inside the arg-max kernel (4 reads)
+    c4 = [a, b, d.Grid3D(ctx, nx, ny, nz), d.Grid3D(ctx, nx, ny, nz)]
+    c4[2].upload(vol[:, ::-1].copy())
+    c4[3].upload(vol[:, :, ::-1].copy())
+    for name, fn, nbytes in (("gm_tree_4", lambda: m.dsi_.setToFusionOfN(c4, d.ACC_GM_TREE), 20.0 * nvox),
+                             ("gm_log_4", lambda: m.dsi_.setToFusionOfN(c4, d.ACC_LOG_SUM), 20.0 * nvox),
+                             ("argmax_of_gm_tree_4", lambda: m.computeDepthMapOfFusionN(c4, d.ACC_GM_TREE),
+                              16.0 * nvox + 9.0 * nx * ny)):
+        fn()
+        ctx.timer_start()
+        for _ in range(reps):
+            fn()
+        ms = ctx.timer_stop() / reps
+        out[name] = {"ms": ms, "GBps": nbytes / (ms * 1e-3) / 1e9,
+                     "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
     out["grid"] = "%dx%dx%d (%.0f MB per volume)" % (nx, ny, nz, 4.0 * nvox / 1e6)
-    for o in (m, a, b):
+    for o in [m] + c4:
         o.close()
     return out
 
@@ -456,8 +480,10 @@ def main():
             ctx_side = d.Context(D.local_rank)
             mapper_fused = d.MapperEMVS(ctx_side, rig["cam"], shape)
             if allreduce is not None:
-                temporal = dd.EnginePipelinedTemporalFusion(ctx, ctx_side, (nx, ny, nz), d.ACC_INV_SUM, world,
-                                                            allreduce, extract=mapper_fused.computeDepthMap)
+                temporal = dd.EnginePipelinedTemporalFusion(
+                    ctx, ctx_side, (nx, ny, nz), d.ACC_INV_SUM, world, allreduce, extract=mapper_fused.computeDepthMap,
+                    scattered=(mapper_fused, comm) if (args.temporal_collective == "reduce_scatter" and comm is not None)
+                    else None)
             else:
                 temporal = dd.PipelinedTemporalFusion.on_gpu(ctx, ctx_side, (nx, ny, nz), d.ACC_INV_SUM, world,
                                                              extract=mapper_fused.computeDepthMap, group=torch_group)
@@ -573,14 +599,16 @@ def main():
         if world > 1 and comm is None:
             raise RuntimeError("cameras4 with N > 1 needs --collective engine")
 
+        gm_mode = d.ACC_GM_TREE if args.gm == "tree" else d.ACC_LOG_SUM
+
         def step():
             for c in range(4):
                 mappers[c].evaluateDSI_batch(batches[c])
             if comm is None and not args.materialize_fused:
                 # n-ary GM inside the arg-max kernel: same bits, the fused volume is never written
-                mappers[0].computeDepthMapOfFusionN([m.dsi_ for m in mappers], d.ACC_LOG_SUM)
+                mappers[0].computeDepthMapOfFusionN([m.dsi_ for m in mappers], gm_mode)
                 return
-            fused.setToFusionOfN([m.dsi_ for m in mappers], d.ACC_LOG_SUM)     # n-ary GM, voxel-wise, local
+            fused.setToFusionOfN([m.dsi_ for m in mappers], gm_mode)           # n-ary GM, voxel-wise, local
             if comm is None:
                 mappers[0].computeDepthMap(fused)
             else:
@@ -591,8 +619,9 @@ def main():
 
         # every rank votes ALL events into its plane range: the job's events are counted once
         voted_per_step = voted if rank == 0 else 0.0
-        workload = ("4-camera synthetic rig, %d events/cam, %dx%dx%d DSI, n-ary geometric-mean camera fusion + arg-max%s"
+        workload = ("4-camera synthetic rig, %d events/cam, %dx%dx%d DSI, n-ary geometric-mean camera fusion (%s) + arg-max%s"
                     % (args.events, nx, ny, nz,
+                       "tree of the reference's 2-ary sqrt(a*b)" if args.gm == "tree" else "exp(mean(log))",
                        (" (fused DSI written)" if args.materialize_fused else " in one kernel (fused DSI not written)")
                        if world == 1 else ", planes sharded over %d GPUs" % world))
         parallelism, scaling = ("1 GPU" if world == 1 else "plane-shard x%d" % world), "strong"

@@ -8,6 +8,7 @@ package: if the shared library is missing or no gfx950 GPU is visible, the
 constructors raise.
 """
 from .engine import (  # noqa: F401
+    ACC_GM_TREE,
     ACC_INV_SUM,
     ACC_LOG_SUM,
     ACC_MAX,
@@ -39,6 +40,7 @@ from .engine import (  # noqa: F401
     ShapeDSI,
     acc_reduce_op,
     allreduce_all,
+    depth_map_reduce_scattered_all,
     depth_map_sharded_all,
     device_count,
     library_path,
@@ -48,9 +50,9 @@ from .engine import (  # noqa: F401
 )
 
 __all__ = [
-    "Comm", "allreduce_all", "depth_map_sharded_all", "Context", "Grid3D", "MapperEMVS", "ShapeDSI", "OptionsDepthMap", "EventBatch", "PinnedArray", "DsiError", "device_count",
+    "Comm", "allreduce_all", "depth_map_sharded_all", "depth_map_reduce_scattered_all", "Context", "Grid3D", "MapperEMVS", "ShapeDSI", "OptionsDepthMap", "EventBatch", "PinnedArray", "DsiError", "device_count",
     "library_path", "load_library", "packetize", "pose_at", "PACKET_SIZE",
-    "FUSE_MIN", "FUSE_HM", "FUSE_GM", "FUSE_AM", "FUSE_RMS", "FUSE_MAX", "ACC_SUM", "ACC_INV_SUM", "ACC_LOG_SUM", "ACC_SQ_SUM", "ACC_MIN", "ACC_MAX",
+    "FUSE_MIN", "FUSE_HM", "FUSE_GM", "FUSE_AM", "FUSE_RMS", "FUSE_MAX", "ACC_SUM", "ACC_INV_SUM", "ACC_LOG_SUM", "ACC_SQ_SUM", "ACC_MIN", "ACC_MAX", "ACC_GM_TREE",
     "REDUCE_SUM", "REDUCE_MIN", "REDUCE_MAX", "acc_reduce_op",
     "VOTE_AUTO", "VOTE_GLOBAL_ATOMIC", "VOTE_LDS_BANDS", "VOTE_FUSED_ARGMAX",
 ]

@@ -32,10 +32,14 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
+def build(force=False, verbose=False, experiments=False):
+    """experiments=True (`--experiments`): also compile the environment knobs of the timing experiments quoted in
+    DESIGN.md (DSI_EXPERIMENT, DSI_PERSISTENT, DSI_PASS_LG, DSI_GROUP_PACKETS, DSI_PREP_OVERLAP).  The production
+    library does not read the environment."""
+    if not force and not experiments and not needs_build():
         return OUT
-    cmd = [hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT + ".tmp"]
+    cmd = ([hipcc()] + FLAGS + (["-DDSI_TIMING_EXPERIMENTS"] if experiments else []) +
+           [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT + ".tmp"])
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
@@ -44,4 +48,4 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, experiments="--experiments" in sys.argv))

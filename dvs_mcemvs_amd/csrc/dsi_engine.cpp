@@ -323,10 +323,12 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
     const long want_run = bp->packed == 4 ? 160 : 512;
     int S = 1;
     while (S < 32 && (long)S * std::max<long>(run, 1) < want_run) S <<= 1;
-    if (const char* e = std::getenv("DSI_GROUP_PACKETS")) {  // tuning experiments only
+#ifdef DSI_TIMING_EXPERIMENTS  // (tuning knobs exist only in builds made with build.py --experiments)
+    if (const char* e = std::getenv("DSI_GROUP_PACKETS")) {
         const int v = std::atoi(e);
         if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) S = v;
     }
+#endif
     bp->group_packets = S;
     // Persistent workgroups (the grid is what the chip holds at once; workgroups pull work items from
     // per-XCD counters) pay off when only ONE workgroup fits a CU -- nothing else hides the ~5 us it
@@ -335,17 +337,29 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
     // loop only adds a barrier and an atomic (346x260x100: 1.175 ms plain, 1.204 ms persistent).
     const bool two_per_cu = bp->lds_bytes * 2 <= dsi::max_dynamic_lds() && bp->block_threads <= 1024;
     bp->persistent = ((bp->packed == 1 || bp->packed == 3 || bp->packed == 5 || bp->packed == 6) && !two_per_cu) ? 1 : 0;
-    if (const char* e = std::getenv("DSI_PERSISTENT")) {  // A/B experiments: 0 off, 1 on wherever the kernel supports it
+    bp->experiment = 0;
+    bp->pass_lg = (m->want_pass_lg >= 1 && m->want_pass_lg <= 6) ? m->want_pass_lg : 0;  // test hook dsi_test_pass_lg
+#ifdef DSI_TIMING_EXPERIMENTS
+    // Environment knobs of the timing experiments quoted in DESIGN.md.  They are compiled in ONLY by
+    // `python -m dvs_mcemvs_amd.build --experiments` (a stray variable in a job's environment must
+    // not be able to change -- DSI_EXPERIMENT: corrupt -- the results of the production library).
+    if (const char* e = std::getenv("DSI_PERSISTENT")) {  // A/B: 0 off, 1 on wherever the kernel supports it
         const int v = std::atoi(e);
         bp->persistent = (v != 0 && (bp->packed == 1 || bp->packed == 3 || bp->packed == 5 || bp->packed == 6)) ? 1 : 0;
     }
-    bp->experiment = 0;
-    if (const char* e = std::getenv("DSI_EXPERIMENT")) bp->experiment = std::atoi(e);  // timing experiments: WRONG results
-    bp->pass_lg = 0;
-    if (const char* e = std::getenv("DSI_PASS_LG")) {  // tuning experiments only
+    if (const char* e = std::getenv("DSI_EXPERIMENT")) {  // 1 no votes, 2 no flush: WRONG results, timing only
+        bp->experiment = std::atoi(e);
+        static bool warned = false;
+        if (!warned && bp->experiment) {
+            std::fprintf(stderr, "dsi_engine: DSI_EXPERIMENT=%d -- timing experiment, the DSIs are WRONG\n", bp->experiment);
+            warned = true;
+        }
+    }
+    if (const char* e = std::getenv("DSI_PASS_LG")) {
         const int v = std::atoi(e);
         if (v >= 1 && v <= 6) bp->pass_lg = v;
     }
+#endif
     int chunks = m->want_chunks;
     if (chunks <= 0) {
         // Work items = chunks x bands x planes: ~8 per CU keep the tail of the last round short; every
@@ -917,6 +931,11 @@ int dsi_grid_fuse_hm_n(dsi_grid_t* dst, const dsi_grid_t* src, int n)
 }
 
 static bool valid_acc_mode(int mode) { return mode >= DSI_ACC_SUM && mode <= DSI_ACC_MAX; }
+// the one-pass n-ary fusions also take DSI_ACC_GM_TREE (n = 2, 4, 8): not an accumulation, so not in the streaming API
+static bool valid_fuse_n_mode(int mode, int n)
+{
+    return valid_acc_mode(mode) || (mode == DSI_ACC_GM_TREE && (n == 2 || n == 4 || n == 8));
+}
 
 int dsi_acc_reduce_op(int mode)
 {
@@ -951,7 +970,7 @@ int dsi_grid_accumulate(dsi_grid_t* dst, const dsi_grid_t* src, int mode)
 int dsi_grid_fuse_n(dsi_grid_t* dst, const dsi_grid_t* const* srcs, int n, int mode)
 {
     REQUIRE(dst && srcs, DSI_ERR_INVALID, "null argument");
-    REQUIRE(valid_acc_mode(mode), DSI_ERR_BAD_OP, "bad accumulate mode %d", mode);
+    REQUIRE(valid_fuse_n_mode(mode, n), DSI_ERR_BAD_OP, "bad fusion mode %d for %d grids (DSI_ACC_GM_TREE needs 2, 4 or 8)", mode, n);
     REQUIRE(n >= 1 && n <= 8, DSI_ERR_INVALID, "1 <= n <= 8 sources (got %d)", n);
     const float* ptrs[8];
     for (int i = 0; i < n; ++i) {
@@ -1068,7 +1087,9 @@ int dsi_mapper_create(dsi_context_t* ctx, const dsi_mapper_config_t* cfg, dsi_ma
     g.z0 = m->planes[0];  // :111, :163 -- of the full depth vector, also for a plane shard
     m->planes_full = m->planes;
     m->plane_begin = cfg->plane_begin;
+#ifdef DSI_TIMING_EXPERIMENTS
     if (const char* e = std::getenv("DSI_PREP_OVERLAP")) m->prep_overlap = std::atoi(e) != 0;
+#endif
     g.nz = cfg->plane_count > 0 ? cfg->plane_count : cfg->dim_z - cfg->plane_begin;
     m->planes = std::vector<float>(m->planes.begin() + m->plane_begin, m->planes.begin() + m->plane_begin + g.nz);
 
@@ -1403,6 +1424,16 @@ int dsi_mapper_evaluate(dsi_mapper_t* m, const uint16_t* x, const uint16_t* y, c
     return rc;
 }
 
+// A kernel on `reader`'s stream has just been queued that READS a grid of context `owner`: whatever `owner`
+// queues from now on (the next vote or fusion overwriting that grid) must start after it (the
+// one-way wait_for before the arg-max left a write-after-read hazard for grids of another context).  Device-
+// side ordering only; nothing to do within one context (one in-order stream).
+static int release_to(dsi_context* owner, dsi_context* reader)
+{
+    if (owner == reader) return DSI_OK;
+    return dsi_context_wait_for(owner, reader);
+}
+
 int dsi_mapper_depth_map_of(dsi_mapper_t* m, dsi_grid_t* g)
 {
     REQUIRE(m && g, DSI_ERR_INVALID, "null argument");
@@ -1421,6 +1452,7 @@ int dsi_mapper_depth_map_of(dsi_mapper_t* m, dsi_grid_t* g)
     if (int rc = depth_buffers_acquire(m)) return rc;
     HIP_TRY(dsi::launch_collapse_max_z(m->ctx->stream, g->data, g->nx, g->ny, g->nz, m->conf.p, m->idx.p,
                                        m->planes_dev, m->depth.p));
+    if (int rc = release_to(g->ctx, m->ctx)) return rc;
     return depth_buffers_ready(m);
 }
 
@@ -1442,13 +1474,15 @@ int dsi_mapper_depth_map_of_fusion(dsi_mapper_t* m, const dsi_grid_t* a, const d
     if (int rc = depth_buffers_acquire(m)) return rc;
     HIP_TRY(dsi::launch_collapse_max_z_fused(m->ctx->stream, a->data, b->data, a->nx, a->ny, a->nz, op, m->conf.p,
                                              m->idx.p, m->planes_dev, m->depth.p));
+    if (int rc = release_to(a->ctx, m->ctx)) return rc;
+    if (int rc = release_to(b->ctx, m->ctx)) return rc;
     return depth_buffers_ready(m);
 }
 
 int dsi_mapper_depth_map_of_fusion_n(dsi_mapper_t* m, const dsi_grid_t* const* srcs, int n, int mode)
 {
     REQUIRE(m && srcs, DSI_ERR_INVALID, "null argument");
-    REQUIRE(valid_acc_mode(mode), DSI_ERR_BAD_OP, "bad accumulate mode %d", mode);
+    REQUIRE(valid_fuse_n_mode(mode, n), DSI_ERR_BAD_OP, "bad fusion mode %d for %d grids (DSI_ACC_GM_TREE needs 2, 4 or 8)", mode, n);
     REQUIRE(n >= 1 && n <= 8, DSI_ERR_INVALID, "1 <= n <= 8 sources (got %d)", n);
     const float* ptrs[8];
     for (int i = 0; i < n; ++i) {
@@ -1468,6 +1502,8 @@ int dsi_mapper_depth_map_of_fusion_n(dsi_mapper_t* m, const dsi_grid_t* const* s
     if (int rc = depth_buffers_acquire(m)) return rc;
     HIP_TRY(dsi::launch_collapse_max_z_fused_n(m->ctx->stream, ptrs, n, mode, m->grid->nx, m->grid->ny, m->grid->nz,
                                                m->conf.p, m->idx.p, m->planes_dev, m->depth.p));
+    for (int i = 0; i < n; ++i)
+        if (int rc = release_to(srcs[i]->ctx, m->ctx)) return rc;
     return depth_buffers_ready(m);
 }
 
@@ -1782,6 +1818,8 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
                               hipStream_t) = nullptr;
+    ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
+                                  hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -1830,6 +1868,7 @@ Rccl* load_rccl()
         r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
         r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+        r.ReduceScatter = reinterpret_cast<decltype(r.ReduceScatter)>(sym("ncclReduceScatter"));
         r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
         r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
@@ -2004,6 +2043,16 @@ int dsi_grid_allreduce_all(dsi_comm_t* const* comms, dsi_grid_t* const* grids, i
     return DSI_OK;
 }
 
+static int ensure_planes_full_dev(dsi_mapper_t* m)
+{
+    if (m->planes_full_dev) return DSI_OK;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->planes_full_dev), m->planes_full.size() * sizeof(float)));
+    HIP_TRY(hipMemcpyAsync(m->planes_full_dev, m->planes_full.data(), m->planes_full.size() * sizeof(float),
+                           hipMemcpyHostToDevice, m->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(m->ctx->stream));  // the source is host memory of this object: simplest
+    return DSI_OK;
+}
+
 // local collapse + key packing of one shard (everything on the mapper's stream)
 static int sharded_prepare(dsi_mapper_t* m, dsi_grid_t* g)
 {
@@ -2017,18 +2066,13 @@ static int sharded_prepare(dsi_mapper_t* m, dsi_grid_t* g)
     HIP_TRY(m->depth.reserve(npix));
     HIP_TRY(m->idx.reserve(npix));
     HIP_TRY(m->argmax_keys.reserve(npix));
-    if (!m->planes_full_dev) {
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->planes_full_dev), m->planes_full.size() * sizeof(float)));
-        HIP_TRY(hipMemcpyAsync(m->planes_full_dev, m->planes_full.data(), m->planes_full.size() * sizeof(float),
-                               hipMemcpyHostToDevice, m->ctx->stream));
-        HIP_TRY(hipStreamSynchronize(m->ctx->stream));  // the source is host memory of this object: simplest
-    }
+    if (int rc = ensure_planes_full_dev(m)) return rc;
     if (int rc = dsi_context_wait_for(m->ctx, g->ctx)) return rc;
     if (int rc = depth_buffers_acquire(m)) return rc;
     HIP_TRY(dsi::launch_collapse_max_z(m->ctx->stream, g->data, g->nx, g->ny, g->nz, m->conf.p, m->idx.p, nullptr,
                                        nullptr));
     HIP_TRY(dsi::launch_pack_argmax(m->ctx->stream, m->conf.p, m->idx.p, (int)npix, m->plane_begin,
-                                    m->argmax_keys.p));
+                                    m->argmax_keys.p, 0));
     return DSI_OK;
 }
 
@@ -2076,6 +2120,126 @@ int dsi_mapper_depth_map_sharded_all(dsi_mapper_t* const* ms, dsi_grid_t* const*
         if (e != ncclSuccess && bad == ncclSuccess) bad = e;
     }
     const ncclResult_t e2 = r->GroupEnd();
+    if (bad != ncclSuccess) return fail(DSI_ERR_COMM, "ncclAllReduce failed: %s", r->GetErrorString(bad));
+    if (e2 != ncclSuccess) return fail(DSI_ERR_COMM, "ncclGroupEnd failed: %s", r->GetErrorString(e2));
+    for (int i = 0; i < n; ++i)
+        if (int rc = sharded_finish(ms[i])) return rc;
+    return DSI_OK;
+}
+
+// ---- temporal fusion's last step with a reduce-scatter: rank r of n reduces only planes
+// [r q, (r+1) q), q = nz / n, of the accumulator (the nz mod n planes left over are all-reduced: every rank then
+// has them), finalises and arg-maxes what it owns, and ONE all-reduce(MAX) of the packed keys gives every rank
+// the depth map.  Per rank (n-1)/n x S bytes cross xGMI instead of the all-reduce's 2 (n-1)/n x S.
+static int scattered_check(dsi_mapper_t* m, dsi_grid_t* acc, dsi_comm_t* c, int mode)
+{
+    REQUIRE(m && acc && c, DSI_ERR_INVALID, "null argument");
+    REQUIRE(valid_acc_mode(mode), DSI_ERR_BAD_OP, "bad accumulate mode %d", mode);
+    REQUIRE(m->ctx->device == acc->ctx->device && c->device == acc->ctx->device, DSI_ERR_CONTEXT,
+            "mapper, accumulator and communicator rank must live on one device");
+    REQUIRE(same_shape(m->grid, acc), DSI_ERR_SHAPE, "accumulator shape differs from the mapper's DSI");
+    REQUIRE(m->plane_begin == 0 && (int)m->planes_full.size() == acc->nz, DSI_ERR_INVALID,
+            "the mapper must own the whole depth vector (time slices shard by time, not by plane)");
+    REQUIRE(acc->nz <= 256, DSI_ERR_INVALID, "arg-max indices are u8: dimZ must be <= 256 (got %d)", acc->nz);
+    return DSI_OK;
+}
+
+// the two collectives on the accumulator (callers bracket several ranks with ncclGroupStart / End)
+static ncclResult_t scattered_reduce(Rccl* r, dsi_grid_t* acc, dsi_comm_t* c, ncclRedOp_t nop)
+{
+    const size_t plane = (size_t)acc->nx * acc->ny;
+    const int q = acc->nz / c->size, rem = acc->nz - q * c->size;
+    ncclResult_t e = ncclSuccess;
+    if (q > 0)  // in place: the receive buffer is this rank's stretch of the send buffer
+        e = r->ReduceScatter(acc->data, acc->data + (size_t)c->rank * q * plane, (size_t)q * plane, ncclFloat32, nop, c->comm,
+                             acc->ctx->stream);
+    if (e == ncclSuccess && rem > 0) {
+        float* tail = acc->data + (size_t)q * c->size * plane;
+        e = r->AllReduce(tail, tail, (size_t)rem * plane, ncclFloat32, nop, c->comm, acc->ctx->stream);
+    }
+    return e;
+}
+
+// finalize + arg-max of the planes this rank owns -> packed keys (on the mapper's stream)
+static int scattered_local(dsi_mapper_t* m, dsi_grid_t* acc, dsi_comm_t* c, int mode, int n_maps)
+{
+    if (int rc = set_device(m->ctx)) return rc;
+    const size_t plane = (size_t)acc->nx * acc->ny;
+    const int q = acc->nz / c->size, rem = acc->nz - q * c->size;
+    HIP_TRY(m->conf.reserve(plane));
+    HIP_TRY(m->depth.reserve(plane));
+    HIP_TRY(m->idx.reserve(plane));
+    HIP_TRY(m->argmax_keys.reserve(plane));
+    if (int rc = ensure_planes_full_dev(m)) return rc;
+    if (int rc = dsi_context_wait_for(m->ctx, acc->ctx)) return rc;
+    if (int rc = depth_buffers_acquire(m)) return rc;
+    hipStream_t st = m->ctx->stream;
+    const int begin[2] = {c->rank * q, q * c->size}, count[2] = {q, rem};
+    bool first = true;
+    for (int k = 0; k < 2; ++k) {
+        if (count[k] <= 0) continue;
+        float* p = acc->data + (size_t)begin[k] * plane;
+        HIP_TRY(dsi::launch_finalize(st, p, (size_t)count[k] * plane, mode, n_maps));
+        HIP_TRY(dsi::launch_collapse_max_z(st, p, acc->nx, acc->ny, count[k], m->conf.p, m->idx.p, nullptr, nullptr));
+        HIP_TRY(dsi::launch_pack_argmax(st, m->conf.p, m->idx.p, (int)plane, begin[k], m->argmax_keys.p, first ? 0 : 1));
+        first = false;
+    }
+    if (first) HIP_TRY(hipMemsetAsync(m->argmax_keys.p, 0, plane * sizeof(unsigned long long), st));  // owns no plane
+    return DSI_OK;
+}
+
+int dsi_mapper_depth_map_reduce_scattered(dsi_mapper_t* m, dsi_grid_t* acc, dsi_comm_t* c, int mode, int n_maps)
+{
+    if (int rc = scattered_check(m, acc, c, mode)) return rc;
+    Rccl* r = nullptr;
+    if (int rc = rccl_ready(&r)) return rc;
+    ncclRedOp_t nop;
+    REQUIRE(to_nccl_op(dsi_acc_reduce_op(mode), &nop), DSI_ERR_BAD_OP, "mode %d has no reduce op", mode);
+    if (int rc = set_device(acc->ctx)) return rc;
+    RCCL_TRY(r, r->GroupStart());
+    const ncclResult_t e = scattered_reduce(r, acc, c, nop);
+    const ncclResult_t e2 = r->GroupEnd();
+    if (e != ncclSuccess) return fail(DSI_ERR_COMM, "reduce-scatter failed: %s", r->GetErrorString(e));
+    if (e2 != ncclSuccess) return fail(DSI_ERR_COMM, "ncclGroupEnd failed: %s", r->GetErrorString(e2));
+    if (int rc = scattered_local(m, acc, c, mode, n_maps)) return rc;
+    const size_t npix = (size_t)acc->nx * acc->ny;
+    RCCL_TRY(r, r->AllReduce(m->argmax_keys.p, m->argmax_keys.p, npix, ncclUint64, ncclMax, c->comm, m->ctx->stream));
+    return sharded_finish(m);
+}
+
+int dsi_mapper_depth_map_reduce_scattered_all(dsi_mapper_t* const* ms, dsi_grid_t* const* accs, dsi_comm_t* const* cs, int n,
+                                              int mode, int n_maps)
+{
+    REQUIRE(ms && accs && cs && n >= 1, DSI_ERR_INVALID, "bad argument");
+    for (int i = 0; i < n; ++i) {
+        if (int rc = scattered_check(ms[i], accs[i], cs[i], mode)) return rc;
+        REQUIRE(same_shape(accs[0], accs[i]), DSI_ERR_SHAPE, "accumulator %d has another shape", i);
+    }
+    Rccl* r = nullptr;
+    if (int rc = rccl_ready(&r)) return rc;
+    ncclRedOp_t nop;
+    REQUIRE(to_nccl_op(dsi_acc_reduce_op(mode), &nop), DSI_ERR_BAD_OP, "mode %d has no reduce op", mode);
+    RCCL_TRY(r, r->GroupStart());
+    ncclResult_t bad = ncclSuccess;
+    for (int i = 0; i < n; ++i) {
+        (void)hipSetDevice(accs[i]->ctx->device);
+        const ncclResult_t e = scattered_reduce(r, accs[i], cs[i], nop);
+        if (e != ncclSuccess && bad == ncclSuccess) bad = e;
+    }
+    ncclResult_t e2 = r->GroupEnd();
+    if (bad != ncclSuccess) return fail(DSI_ERR_COMM, "reduce-scatter failed: %s", r->GetErrorString(bad));
+    if (e2 != ncclSuccess) return fail(DSI_ERR_COMM, "ncclGroupEnd failed: %s", r->GetErrorString(e2));
+    for (int i = 0; i < n; ++i)
+        if (int rc = scattered_local(ms[i], accs[i], cs[i], mode, n_maps)) return rc;
+    const size_t npix = (size_t)accs[0]->nx * accs[0]->ny;
+    RCCL_TRY(r, r->GroupStart());
+    for (int i = 0; i < n; ++i) {
+        (void)hipSetDevice(ms[i]->ctx->device);
+        const ncclResult_t e = r->AllReduce(ms[i]->argmax_keys.p, ms[i]->argmax_keys.p, npix, ncclUint64, ncclMax, cs[i]->comm,
+                                            ms[i]->ctx->stream);
+        if (e != ncclSuccess && bad == ncclSuccess) bad = e;
+    }
+    e2 = r->GroupEnd();
     if (bad != ncclSuccess) return fail(DSI_ERR_COMM, "ncclAllReduce failed: %s", r->GetErrorString(bad));
     if (e2 != ncclSuccess) return fail(DSI_ERR_COMM, "ncclGroupEnd failed: %s", r->GetErrorString(e2));
     for (int i = 0; i < n; ++i)

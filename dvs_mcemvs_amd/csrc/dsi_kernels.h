@@ -158,7 +158,7 @@ hipError_t launch_finalize(hipStream_t s, float* acc, size_t n, int mode, int n_
 hipError_t launch_fill(hipStream_t s, float* a, size_t n, float v);
 hipError_t launch_fuse_n(hipStream_t s, float* dst, const float* const* srcs, int n_src, size_t n, int mode);
 hipError_t launch_pack_argmax(hipStream_t s, const float* conf, const uint8_t* idx, int n, int plane_begin,
-                              unsigned long long* keys);
+                              unsigned long long* keys, int combine = 0);
 // clear != 0: the keys are zeroed as they are read (the fused vote kernel needs them zero before it runs)
 hipError_t launch_unpack_argmax(hipStream_t s, unsigned long long* keys, int n, const float* planes_full,
                                 float* conf, uint8_t* idx, float* depth, int clear = 0);

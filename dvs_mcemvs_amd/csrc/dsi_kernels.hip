@@ -3059,6 +3059,86 @@ __global__ __launch_bounds__(256) void k_fuse_n(float* __restrict__ dst, FuseSou
     }
 }
 
+// ---- n-ary geometric mean as the balanced TREE of the reference's own 2-ary op (DSI_ACC_GM_TREE):
+//   n = 2: sqrt(a b)                     = Grid3D::geometricMeanTwoGrids, cartesian3dgrid.h:150-156, bit for bit
+//   n = 4: sqrt(sqrt(a b) sqrt(c d))     n = 8: one level more
+// i.e. what a user of the reference gets by calling geometricMeanTwoGrids on pairs of grids and then on the
+// results.  ~2 fp32 operations per source and voxel: a pure HBM stream, where exp(mean(log v)) of
+// DSI_ACC_LOG_SUM (any n, sum-reducible across GPUs) costs ~100 fp64 operations per voxel.
+template <int N>
+__device__ __forceinline__ float gm_tree(const float* v)
+{
+    float t[N];
+#pragma unroll
+    for (int c = 0; c < N; ++c) t[c] = v[c];
+#pragma unroll
+    for (int w = N; w > 1; w >>= 1)
+#pragma unroll
+        for (int c = 0; c < w / 2; ++c) t[c] = fuse_op<3>(t[2 * c], t[2 * c + 1]);
+    return t[0];
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void k_fuse_gm_tree(float* __restrict__ dst, FuseSources src, size_t n)
+{
+    const size_t n4 = n / 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 v[N];
+#pragma unroll
+        for (int c = 0; c < N; ++c) v[c] = reinterpret_cast<const float4*>(src.p[c])[i];
+        float x[N], y[N], z[N], w[N];
+#pragma unroll
+        for (int c = 0; c < N; ++c) {
+            x[c] = v[c].x;
+            y[c] = v[c].y;
+            z[c] = v[c].z;
+            w[c] = v[c].w;
+        }
+        reinterpret_cast<float4*>(dst)[i] = make_float4(gm_tree<N>(x), gm_tree<N>(y), gm_tree<N>(z), gm_tree<N>(w));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = n4 * 4 + threadIdx.x;
+        float x[N];
+#pragma unroll
+        for (int c = 0; c < N; ++c) x[c] = src.p[c][i];
+        dst[i] = gm_tree<N>(x);
+    }
+}
+
+// collapseMaxZSlice of the tree geometric mean without materialising it (same bits as k_fuse_gm_tree + k_collapse_max_z)
+template <int N>
+__global__ __launch_bounds__(256) void k_collapse_max_z_gm_tree(FuseSources src, int npix, int nz,
+                                                                float* __restrict__ conf, uint8_t* __restrict__ idx,
+                                                                const float* __restrict__ planes, float* __restrict__ depth)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    float best = 0.f;
+    int best_k = 0;
+    for (int k = 0; k < nz; k += 2) {
+        float v[2][N];  // two planes' loads in flight before the arithmetic
+        const int k1 = min(k + 1, nz - 1);
+#pragma unroll
+        for (int c = 0; c < N; ++c) {
+            v[0][c] = src.p[c][(size_t)k * npix + p];
+            v[1][c] = src.p[c][(size_t)k1 * npix + p];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (k + u >= nz) break;
+            const float f = gm_tree<N>(v[u]);
+            if (k + u == 0 || best < f) {  // std::max_element: the first maximum wins
+                best = f;
+                best_k = k + u;
+            }
+        }
+    }
+    conf[p] = best;
+    idx[p] = (uint8_t)best_k;
+    if (depth) depth[p] = planes[best_k];
+}
+
 // cartesian3dgrid.cpp:115-137: thread = pixel, planes walked in order, strict '<'
 // keeps the first maximum (std::max_element).  Lanes of a wave read consecutive x
 // of one plane row: coalesced 256-B segments.
@@ -3771,12 +3851,14 @@ hipError_t launch_finalize(hipStream_t s, float* acc, size_t n, int mode, int n_
 __global__ __launch_bounds__(256) void k_pack_argmax(const float* __restrict__ conf,
                                                      const uint8_t* __restrict__ idx, int n,
                                                      int plane_begin,
-                                                     unsigned long long* __restrict__ keys)
+                                                     unsigned long long* __restrict__ keys, int combine)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const unsigned long long bits = __float_as_uint(conf[i]);
-    keys[i] = (bits << 8) | (unsigned long long)(255 - ((int)idx[i] + plane_begin));
+    const unsigned long long key = (bits << 8) | (unsigned long long)(255 - ((int)idx[i] + plane_begin));
+    // combine: a second plane range of the same rank joins the keys of the first
+    keys[i] = (combine && keys[i] > key) ? keys[i] : key;
 }
 
 __global__ __launch_bounds__(256) void k_unpack_argmax(unsigned long long* __restrict__ keys,
@@ -3796,9 +3878,9 @@ __global__ __launch_bounds__(256) void k_unpack_argmax(unsigned long long* __res
 }
 
 hipError_t launch_pack_argmax(hipStream_t s, const float* conf, const uint8_t* idx, int n, int plane_begin,
-                              unsigned long long* keys)
+                              unsigned long long* keys, int combine)
 {
-    hipLaunchKernelGGL(k_pack_argmax, dim3((n + 255) / 256), dim3(256), 0, s, conf, idx, n, plane_begin, keys);
+    hipLaunchKernelGGL(k_pack_argmax, dim3((n + 255) / 256), dim3(256), 0, s, conf, idx, n, plane_begin, keys, combine);
     return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
@@ -3825,6 +3907,12 @@ hipError_t launch_fuse_n(hipStream_t s, float* dst, const float* const* srcs, in
     case 3: hipLaunchKernelGGL((k_fuse_n<EW_ADD_SQ, EW_FIN_RMS>), grid, block, 0, s, dst, fs, n_src, n, 0.f, fn); break;
     case 4: hipLaunchKernelGGL((k_fuse_n<EW_MIN, -1>), grid, block, 0, s, dst, fs, n_src, n, inf, fn); break;
     case 5: hipLaunchKernelGGL((k_fuse_n<EW_MAX, -1>), grid, block, 0, s, dst, fs, n_src, n, -inf, fn); break;
+    case 6:  // the tree of 2-ary geometric means: n = 2, 4, 8
+        if (n_src == 2) hipLaunchKernelGGL(k_fuse_gm_tree<2>, grid, block, 0, s, dst, fs, n);
+        else if (n_src == 4) hipLaunchKernelGGL(k_fuse_gm_tree<4>, grid, block, 0, s, dst, fs, n);
+        else if (n_src == 8) hipLaunchKernelGGL(k_fuse_gm_tree<8>, grid, block, 0, s, dst, fs, n);
+        else return hipErrorInvalidValue;
+        break;
     default: return hipErrorInvalidValue;
     }
     return hipExtGetLastError();
@@ -3886,6 +3974,12 @@ hipError_t launch_collapse_max_z_fused_n(hipStream_t s, const float* const* srcs
     case 3: hipLaunchKernelGGL((k_collapse_max_z_fused_n<EW_ADD_SQ, EW_FIN_RMS>), grid, block, 0, s, fs, n_src, npix, nz, 0.f, fn, conf, idx, planes, depth); break;
     case 4: hipLaunchKernelGGL((k_collapse_max_z_fused_n<EW_MIN, -1>), grid, block, 0, s, fs, n_src, npix, nz, inf, fn, conf, idx, planes, depth); break;
     case 5: hipLaunchKernelGGL((k_collapse_max_z_fused_n<EW_MAX, -1>), grid, block, 0, s, fs, n_src, npix, nz, -inf, fn, conf, idx, planes, depth); break;
+    case 6:
+        if (n_src == 2) hipLaunchKernelGGL(k_collapse_max_z_gm_tree<2>, grid, block, 0, s, fs, npix, nz, conf, idx, planes, depth);
+        else if (n_src == 4) hipLaunchKernelGGL(k_collapse_max_z_gm_tree<4>, grid, block, 0, s, fs, npix, nz, conf, idx, planes, depth);
+        else if (n_src == 8) hipLaunchKernelGGL(k_collapse_max_z_gm_tree<8>, grid, block, 0, s, fs, npix, nz, conf, idx, planes, depth);
+        else return hipErrorInvalidValue;
+        break;
     default: return hipErrorInvalidValue;
     }
     return hipExtGetLastError();

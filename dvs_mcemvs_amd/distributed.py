@@ -282,6 +282,13 @@ class EngineTemporalFusion:
         self.acc.finalize(self.mode, self.n)
         return self.acc
 
+    def finish_depth_map(self, mapper, comm):
+        """The depth map of the fused DSI on every rank WITHOUT completing the fused DSI anywhere: reduce-scatter
+        by planes, local finalize + arg-max of the owned planes, one all-reduce(MAX) of packed keys
+        (dsi_mapper_depth_map_reduce_scattered: half the xGMI bytes of finish() + computeDepthMap).  The
+        accumulator is consumed; results via mapper.fetchDepthMap()."""
+        mapper.computeDepthMapReduceScattered(self.acc, comm, self.mode, self.n)
+
     def close(self):
         self.acc.close()
 
@@ -292,11 +299,16 @@ class EnginePipelinedTemporalFusion:
     context already votes round k+1.  Ordering is by dsi_context_wait_for only; the host never
     blocks in submit().  The accumulator is double-buffered and aliased in both contexts."""
 
-    def __init__(self, ctx_main, ctx_side, dims, mode, num_slices, allreduce, extract=None, depth=2):
+    def __init__(self, ctx_main, ctx_side, dims, mode, num_slices, allreduce, extract=None, depth=2, scattered=None):
+        """scattered = (mapper_in_side_context, comm): the round's collective is the reduce-scatter form
+        (MapperEMVS.computeDepthMapReduceScattered: reduce-scatter by planes, finalize + arg-max of the owned
+        planes, all-reduce(MAX) of keys) instead of all-reduce + finalize + extract; the depth map lands in that
+        mapper's buffers, the fused DSI is not completed on any rank."""
         from .engine import Grid3D, acc_reduce_op
         nx, ny, nz = dims
         self.ctx_main, self.ctx_side = ctx_main, ctx_side
         self.mode, self.n, self.allreduce, self.extract = int(mode), int(num_slices), allreduce, extract
+        self.scattered = scattered
         self.op = acc_reduce_op(self.mode)
         self.slots = []
         for _ in range(depth):
@@ -312,10 +324,14 @@ class EnginePipelinedTemporalFusion:
         main.accumulateBegin(self.mode)
         main.accumulate(fused, self.mode)
         self.ctx_side.wait_for(self.ctx_main)
-        self.allreduce(side, self.op)
-        side.finalize(self.mode, self.n)
-        if self.extract is not None:
-            self.extract(side)
+        if self.scattered is not None:
+            mapper, comm = self.scattered
+            mapper.computeDepthMapReduceScattered(side, comm, self.mode, self.n)
+        else:
+            self.allreduce(side, self.op)
+            side.finalize(self.mode, self.n)
+            if self.extract is not None:
+                self.extract(side)
         self.k += 1
         return side
 

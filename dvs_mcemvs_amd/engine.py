@@ -21,7 +21,7 @@ import numpy as np
 PACKET_SIZE = 1024
 
 FUSE_MIN, FUSE_HM, FUSE_GM, FUSE_AM, FUSE_RMS, FUSE_MAX = 1, 2, 3, 4, 5, 6
-ACC_SUM, ACC_INV_SUM, ACC_LOG_SUM, ACC_SQ_SUM, ACC_MIN, ACC_MAX = 0, 1, 2, 3, 4, 5
+ACC_SUM, ACC_INV_SUM, ACC_LOG_SUM, ACC_SQ_SUM, ACC_MIN, ACC_MAX, ACC_GM_TREE = 0, 1, 2, 3, 4, 5, 6
 REDUCE_SUM, REDUCE_MIN, REDUCE_MAX = 0, 1, 2
 VOTE_AUTO, VOTE_GLOBAL_ATOMIC, VOTE_LDS_BANDS, VOTE_FUSED_ARGMAX = 0, 1, 2, 3
 
@@ -161,6 +161,9 @@ def load_library():
         "dsi_grid_allreduce_all": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int]),
         "dsi_mapper_depth_map_sharded": (C.c_int, [vp, vp, vp]),
         "dsi_mapper_depth_map_sharded_all": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_int]),
+        "dsi_mapper_depth_map_reduce_scattered": (C.c_int, [vp, vp, vp, C.c_int, C.c_int]),
+        "dsi_mapper_depth_map_reduce_scattered_all": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_int,
+                                                              C.c_int, C.c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here = the .so does not export the ABI
@@ -348,6 +351,15 @@ def allreduce_all(comms, grids, op):
     cs = (C.c_void_p * n)(*[c._h for c in comms])
     gs = (C.c_void_p * n)(*[g._h for g in grids])
     _check(load_library().dsi_grid_allreduce_all(cs, gs, n, int(op)))
+
+
+def depth_map_reduce_scattered_all(mappers, accs, comms, mode, n_maps):
+    """One process, several GPUs: MapperEMVS.computeDepthMapReduceScattered on every rank in one group call."""
+    n = len(comms)
+    hm = (C.c_void_p * n)(*[m._h for m in mappers])
+    hg = (C.c_void_p * n)(*[g._h for g in accs])
+    hc = (C.c_void_p * n)(*[c._h for c in comms])
+    _check(load_library().dsi_mapper_depth_map_reduce_scattered_all(hm, hg, hc, n, int(mode), int(n_maps)))
 
 
 def depth_map_sharded_all(mappers, grids, comms):
@@ -765,6 +777,13 @@ class MapperEMVS:
         packed (confidence, index) keys, index -> depth over the full depth vector; fetchDepthMap()
         then returns the unsharded result on every rank."""
         _check(load_library().dsi_mapper_depth_map_sharded(self._h, (grid or self.dsi_)._h, comm._h))
+
+    def computeDepthMapReduceScattered(self, acc, comm, mode, n_maps):
+        """Temporal fusion's last step across GPUs with a reduce-scatter instead of an all-reduce: `acc` (this
+        rank's accumulated slices, mode = ACC_*) is reduced by plane ranges, every rank finalises and arg-maxes
+        its planes, one all-reduce(MAX) of packed keys -> the fused depth map on every rank (fetchDepthMap).
+        `acc` is consumed."""
+        _check(load_library().dsi_mapper_depth_map_reduce_scattered(self._h, acc._h, comm._h, int(mode), int(n_maps)))
 
     def fetchDepthMapAsync(self, depth, conf, idx):
         """Queue the device -> host copies into PinnedArray-backed arrays (any may be None) on the copy

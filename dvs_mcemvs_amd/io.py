@@ -155,8 +155,10 @@ def parse_rosbag_gt(path, topic=None, tmin=0.0, tmax=float("inf")):
         return True
 
     _scan_bag(path, on_message)
-    # the reference keeps them in a std::map keyed by stamp: ascending
-    out.sort(key=lambda tp: tp[0])
+    # the reference keeps them in a std::map<ros::Time, Transformation> filled with insert(): ascending by stamp,
+    # and of several poses with the SAME stamp only the first one is kept (insert does not overwrite)
+    out.sort(key=lambda tp: tp[0])          # stable: equal stamps stay in bag order
+    out = [tp for i, tp in enumerate(out) if i == 0 or tp[0] != out[i - 1][0]]
     times = np.array([t for t, _ in out], np.float64)
     poses = np.array([p for _, p in out], np.float64).reshape(-1, 7)
     return times, poses

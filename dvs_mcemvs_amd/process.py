@@ -174,8 +174,11 @@ def window_bounds(start_time_s, stop_time_s, duration, out_skip):
 
 
 def window_events(events, t_start, t_stop):
-    """Events of one camera with t_start <= ts <= t_stop (parse_rosbag, data_loading.cpp:272-285,
-    on an already time-sorted array)."""
+    """Events of one camera with t_start <= ts <= t_stop, on an already time-sorted array.
+    NOT identical to parse_rosbag (data_loading.cpp:272-285) on a real bag: the reference tests its stop flag only
+    at the NEXT EventArray message, so it also keeps the first event past t_stop and the rest of that message
+    (a few hundred events; the 1024-event packetisation can shift by one packet).  Message boundaries do not
+    exist in an event array; io.read_event_bag reproduces the message-granular cut when reading a bag."""
     x, y, ts = events
     a = int(np.searchsorted(ts, t_start, side="left"))
     b = int(np.searchsorted(ts, t_stop, side="right"))

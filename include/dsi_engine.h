@@ -84,7 +84,13 @@ typedef enum {
     DSI_ACC_LOG_SUM = 2, /* n-ary geometricMeanTwoGrids               cartesian3dgrid.h:150-156 */
     DSI_ACC_SQ_SUM = 3,  /* n-ary rmsTwoGrids                         cartesian3dgrid.h:141-148 */
     DSI_ACC_MIN = 4,     /* n-ary minTwoGrids                         cartesian3dgrid.h:111-117 */
-    DSI_ACC_MAX = 5      /* n-ary maxTwoGrids                         cartesian3dgrid.h:184-190 */
+    DSI_ACC_MAX = 5,     /* n-ary maxTwoGrids                         cartesian3dgrid.h:184-190 */
+    /* Only for the one-pass forms dsi_grid_fuse_n / dsi_mapper_depth_map_of_fusion_n with n = 2, 4 or 8 (not an
+     * accumulation: dsi_grid_accumulate* / _finalize reject it): the geometric mean as the balanced TREE of the
+     * reference's own 2-ary op, sqrt(sqrt(a b) sqrt(c d)) for n = 4 -- what calling geometricMeanTwoGrids
+     * (cartesian3dgrid.h:150-156) on pairs of grids and then on the results gives, bit for bit (n = 2 IS that
+     * member).  A plain HBM stream (~2 fp32 operations per source), where LOG_SUM costs ~100 fp64 operations. */
+    DSI_ACC_GM_TREE = 6
 } dsi_acc_mode_t;
 
 /* how an accumulator of a given mode combines across GPUs */
@@ -365,6 +371,20 @@ DSI_API int dsi_mapper_fetch_wait(dsi_mapper_t *m);
 DSI_API int dsi_mapper_depth_map_sharded(dsi_mapper_t *m, dsi_grid_t *g, dsi_comm_t *comm);
 DSI_API int dsi_mapper_depth_map_sharded_all(dsi_mapper_t *const *mappers, dsi_grid_t *const *grids,
                                              dsi_comm_t *const *comms, int n);
+
+/* The last step of the temporal fusion across GPUs (process2.cpp:211-242 sharded by time slice) with half the
+ * xGMI bytes of dsi_grid_allreduce + dsi_grid_finalize + dsi_mapper_depth_map_of: the accumulator `acc` (every
+ * rank's local dsi_grid_accumulate results, mode = dsi_acc_mode_t) is REDUCE-SCATTERED by planes -- rank r of n
+ * receives the reduced planes [r q, (r+1) q), q = dimZ / n; the dimZ mod n planes left over are all-reduced --,
+ * each rank finalises (mode, n_maps) and arg-maxes the planes it owns, and one all-reduce(MAX) of the packed
+ * (confidence, plane) keys (8 bytes per pixel) gives every rank the depth map of the fused DSI
+ * (dsi_mapper_fetch_depth_map*).  `acc` is consumed: afterwards only the owned planes hold (finalised) values.
+ * The mapper must own the whole depth vector.  (reduce-scatter + local finalize / arg-max +
+ * gather of the small maps.) */
+DSI_API int dsi_mapper_depth_map_reduce_scattered(dsi_mapper_t *m, dsi_grid_t *acc, dsi_comm_t *comm, int mode,
+                                                  int n_maps);
+DSI_API int dsi_mapper_depth_map_reduce_scattered_all(dsi_mapper_t *const *mappers, dsi_grid_t *const *accs,
+                                                      dsi_comm_t *const *comms, int n, int mode, int n_maps);
 
 /* OptionsDepthMap (mapper_emvs_stereo.hpp:68-82), the fields the depth-map extraction reads */
 typedef struct {

@@ -219,6 +219,61 @@ void orc_fill_voxel_grid(const float *xy_z0, const float *centers, size_t n_pack
     }
 }
 
+/* The same loop restricted to rows [row_begin, row_begin + row_count) of every plane: every coordinate
+ * and every accept test is computed on the FULL grid exactly as above, only the four += of a vote are
+ * kept or dropped by their row, so `strip` ([nz][row_count][nx]) is bit-equal to those rows of the full
+ * DSI (same additions in the same order).  Test infrastructure for grids whose full DSI the CPU cannot
+ * afford (1024 x 1024 x 256 at 100 M events): the arg-max needs whole columns, not whole planes. */
+void orc_fill_voxel_grid_rows(const float *xy_z0, const float *centers, size_t n_packets,
+                              const float *raw_depths, int nz, const float *Kv, int nx, int ny,
+                              int row_begin, int row_count, float *strip)
+{
+    enum { N = 128 };
+    const float z0 = raw_depths[0];
+    const float vfx = Kv[0], vfy = Kv[1], vcx = Kv[2], vcy = Kv[3];
+    const int row_end = row_begin + row_count;
+
+#pragma omp parallel for
+    for (int depth_plane = 0; depth_plane < nz; ++depth_plane) {
+        const float *pe = xy_z0;
+        float *pgrid = strip + (size_t)depth_plane * nx * row_count;
+        for (size_t packet = 0; packet < n_packets; ++packet) {
+            const float *C = centers + 3 * packet;
+            const float zi = raw_depths[depth_plane];
+            const float a = z0 * (zi - C[2]);
+            const float bx = (z0 - zi) * (C[0] * vfx + C[2] * vcx);
+            const float by = (z0 - zi) * (C[1] * vfy + C[2] * vcy);
+            const float d = zi * (z0 - C[2]);
+            for (int batch = 0; batch < ORC_PACKET_SIZE / N; ++batch, pe += 2 * N) {
+                float X[N], Y[N];
+                for (int i = 0; i < N; ++i) {
+                    X[i] = (pe[2 * i] * a + bx) / d;
+                    Y[i] = (pe[2 * i + 1] * a + by) / d;
+                }
+                for (int i = 0; i < N; ++i) {
+                    const float x_f = X[i], y_f = Y[i];
+                    if (x_f >= 0.f && y_f >= 0.f && x_f < (float)(nx - 1) && y_f < (float)(ny - 1)) { /* orc_vote */
+                        const int x = (int)x_f, y = (int)y_f;
+                        if (y + 1 < row_begin || y >= row_end)
+                            continue;
+                        const float fx = x_f - x, fy = y_f - y, fx1 = 1.f - fx, fy1 = 1.f - fy;
+                        if (y >= row_begin) {
+                            float *g = pgrid + x + (size_t)(y - row_begin) * nx;
+                            g[0] += fx1 * fy1;
+                            g[1] += fx * fy1;
+                        }
+                        if (y + 1 < row_end) {
+                            float *g = pgrid + x + (size_t)(y + 1 - row_begin) * nx;
+                            g[0] += fx1 * fy;
+                            g[1] += fx * fy;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 /* ---- packetisation: mapper_emvs_stereo.cpp:67-99 ------------------------ */
 long orc_packetize(size_t n_events, const uint8_t *pose_ok, size_t *first_event,
                    size_t *mid_event)

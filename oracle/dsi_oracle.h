@@ -80,6 +80,10 @@ void orc_warp_z0(const uint16_t *ex, const uint16_t *ey, size_t n_events,
 void orc_fill_voxel_grid(const float *xy_z0, const float *centers,
                          size_t n_packets, const float *raw_depths, int nz,
                          const float *Kv, int nx, int ny, float *dsi);
+/* rows [row_begin, row_begin + row_count) of every plane of the same DSI, bit-equal to the full one's */
+void orc_fill_voxel_grid_rows(const float *xy_z0, const float *centers, size_t n_packets,
+                              const float *raw_depths, int nz, const float *Kv, int nx, int ny,
+                              int row_begin, int row_count, float *strip);
 
 /* cartesian3dgrid.h:253-273 (single vote into one plane). */
 void orc_vote(float x_f, float y_f, float *plane, int nx, int ny);

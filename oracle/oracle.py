@@ -60,6 +60,8 @@ def _load(path):
     L.orc_warp_z0.argtypes = [u16p, u16p, C.c_size_t, f32p, f32p, C.c_int, f32p]
     L.orc_fill_voxel_grid.argtypes = [f32p, f32p, C.c_size_t, f32p, C.c_int, f32p,
                                       C.c_int, C.c_int, f32p]
+    L.orc_fill_voxel_grid_rows.argtypes = [f32p, f32p, C.c_size_t, f32p, C.c_int, f32p, C.c_int, C.c_int, C.c_int,
+                                           C.c_int, f32p]
     L.orc_vote.argtypes = [C.c_float, C.c_float, f32p, C.c_int, C.c_int]
     L.orc_packetize.argtypes = [C.c_size_t, u8p, szp, szp]
     L.orc_packetize.restype = C.c_long
@@ -154,6 +156,22 @@ def fill_voxel_grid(xy_z0, centers, raw_depths, Kv, nx, ny, dsi=None):
     return dsi
 
 
+def fill_voxel_grid_rows(xy_z0, centers, raw_depths, Kv, nx, ny, row_begin, row_count, strip=None):
+    """Rows [row_begin, row_begin + row_count) of every plane of fill_voxel_grid's DSI (bit-equal to them)."""
+    xy_z0 = _f32(xy_z0).reshape(-1, 2)
+    centers = _f32(centers).reshape(-1, 3)
+    raw_depths = _f32(raw_depths)
+    Kv = _f32(Kv)
+    npk = centers.shape[0]
+    assert xy_z0.shape[0] == npk * PACKET and 0 <= row_begin and row_begin + row_count <= ny
+    nz = raw_depths.shape[0]
+    if strip is None:
+        strip = np.zeros((nz, row_count, nx), np.float32)
+    lib().orc_fill_voxel_grid_rows(_p(xy_z0, C.c_float), _p(centers, C.c_float), npk, _p(raw_depths, C.c_float), nz,
+                                   _p(Kv, C.c_float), nx, ny, int(row_begin), int(row_count), _p(strip, C.c_float))
+    return strip
+
+
 def vote(x_f, y_f, plane):
     ny, nx = plane.shape
     lib().orc_vote(np.float32(x_f), np.float32(y_f), _p(plane, C.c_float), nx, ny)
@@ -208,6 +226,18 @@ def fuse_nary(grids, mode):
     for g in grids:
         acc = accumulate(acc, g, mode)
     return finalize(acc, mode, len(grids))
+
+
+def fuse_gm_tree(grids):
+    """Geometric mean of 2, 4 or 8 grids as the balanced tree of the reference's 2-ary op
+    (Grid3D::geometricMeanTwoGrids, cartesian3dgrid.h:150-156): pairs (0,1), (2,3), ... then pairs of the
+    results -- nothing but repeated calls of the restated reference member (fuse2 op 3)."""
+    level = [_f32(g) for g in grids]
+    if len(level) not in (2, 4, 8):
+        raise ValueError("the tree form needs 2, 4 or 8 grids")
+    while len(level) > 1:
+        level = [fuse2(level[i], level[i + 1], 3) for i in range(0, len(level), 2)]
+    return level[0]
 
 
 def finalize(acc, mode, n_maps):

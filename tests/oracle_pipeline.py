@@ -54,6 +54,12 @@ class OracleMapper:
         orc.fill_voxel_grid(xy, centers, self.planes, self.Kv, self.nx, self.ny, self.dsi)
         return xy, centers
 
+    def evaluate_packets_rows(self, x, y, first, Rt, row_begin, row_count):
+        """Rows [row_begin, row_begin + row_count) of every plane of the DSI evaluate_packets builds, bit-equal to
+        them (oracle.fill_voxel_grid_rows): for grids whose full DSI the CPU cannot afford."""
+        xy, centers = self.stage_a(x, y, first, Rt)
+        return orc.fill_voxel_grid_rows(xy, centers, self.planes, self.Kv, self.nx, self.ny, row_begin, row_count)
+
     def evaluateDSI(self, events, trajectory, T_rv_w):
         x, y, ts = events
         pk = self.packetize(ts, trajectory, T_rv_w)

@@ -285,3 +285,114 @@ def test_engine_rccl_communicator_single_rank(ctx):
     assert np.array_equal(i3, gidx) and np.array_equal(c3, conf) and np.array_equal(d3, depth)
     for o in (m, shard, g, comm):
         o.close()
+
+
+def test_engine_collectives_over_every_device(ctx):
+    """One process, EVERY GPU of the box (dsi_device_count(): 1 on a single-GPU lease, 8 on the scaling node --
+    there this is the first correctness run of RCCL with more than one rank): dsi_comm_create_all, then
+      * dsi_grid_allreduce_all (sum / min / max) against numpy on integer-valued volumes (exact in any order),
+      * time-slice sharding: every device builds the stereo DSI of its own slice, camera HM, temporal HM by
+        all-reduce + finalize + arg-max  AND  by reduce-scatter + owned-plane finalize / arg-max + key all-reduce;
+        both against the single-device loop over the same slices,
+      * plane sharding: every device votes all events into its plane range, dsi_mapper_depth_map_sharded_all
+        against the unsharded single-device depth map, bit for bit."""
+    import dvs_mcemvs_amd as d
+    from dvs_mcemvs_amd import distributed as dd, synthetic as syn
+    n = d.device_count()
+    assert n >= 1
+    ctxs = [ctx] + [d.Context(i) for i in range(1, n)]
+    comms = d.Comm.create_all(ctxs)
+    assert [c.rank for c in comms] == list(range(n)) and all(c.size == n for c in comms)
+    # ---- all-reduce
+    rng = np.random.default_rng(5)
+    nx, ny, nz = 96, 72, 21                     # 21 planes: not a multiple of 2, 4 or 8 (remainder planes)
+    vols = [rng.integers(0, 1000, (nz, ny, nx)).astype(np.float32) for _ in range(n)]
+    grids = [d.Grid3D(c, nx, ny, nz) for c in ctxs]
+    for op, ref in ((d.REDUCE_SUM, np.sum(vols, axis=0)), (d.REDUCE_MIN, np.min(vols, axis=0)),
+                    (d.REDUCE_MAX, np.max(vols, axis=0))):
+        for g, v in zip(grids, vols):
+            g.upload(v)
+        d.allreduce_all(comms, grids, op)
+        for g in grids:
+            assert np.array_equal(g.download(), ref.astype(np.float32))
+    # ---- time slices: slice k on device k
+    rig = syn.stereo_rig(n * 40_000, width=nx, height=ny, duration=0.1 * n, seed=21, n_points=800)
+    shape = d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0)
+    per = rig["events"][0][0].shape[0] // n
+    T = rig["T_rv_w"]
+
+    def slice_fused(c_, k):
+        ms = [d.MapperEMVS(c_, rig["cam"], shape) for _ in range(2)]
+        for cam in range(2):
+            ev = tuple(a[k * per:(k + 1) * per] for a in rig["events"][cam])
+            assert ms[cam].evaluateDSI(ev, rig["trajectories"][cam], T)
+        f = d.Grid3D(c_, nx, ny, nz)
+        f.setToFusionOf(ms[0].dsi_, ms[1].dsi_, d.FUSE_HM)
+        for m_ in ms:
+            m_.close()
+        return f
+
+    single = dd.EngineTemporalFusion(ctx, (nx, ny, nz), d.ACC_INV_SUM, n, dd.engine_allreduce(None))
+    for k in range(n):
+        f = slice_fused(ctx, k)
+        single.add(f)
+        f.close()
+    ref_mapper = d.MapperEMVS(ctx, rig["cam"], shape)
+    ref_fused = single.finish()
+    ref_mapper.computeDepthMap(ref_fused)
+    ref_depth, ref_conf, ref_idx = ref_mapper.fetchDepthMap()
+    ref_vol = ref_fused.download()
+    assert ref_conf.max() > 0.5
+    for variant in ("allreduce", "reduce_scatter"):
+        accs, mappers = [], []
+        for r, c_ in enumerate(ctxs):
+            acc = d.Grid3D(c_, nx, ny, nz)
+            acc.accumulateBegin(d.ACC_INV_SUM)
+            f = slice_fused(c_, r)
+            acc.accumulate(f, d.ACC_INV_SUM)
+            f.close()
+            accs.append(acc)
+            mappers.append(d.MapperEMVS(c_, rig["cam"], shape))
+        if variant == "allreduce":
+            d.allreduce_all(comms, accs, d.REDUCE_SUM)
+            for acc, m_ in zip(accs, mappers):
+                acc.finalize(d.ACC_INV_SUM, n)
+                m_.computeDepthMap(acc)
+        else:
+            d.depth_map_reduce_scattered_all(mappers, accs, comms, d.ACC_INV_SUM, n)
+        outs = [m_.fetchDepthMap() for m_ in mappers]
+        for r in range(1, n):                                   # every rank has the same map
+            for a_, b_ in zip(outs[r], outs[0]):
+                assert np.array_equal(a_, b_)
+        depth, conf, idx = outs[0]
+        if n <= 2:                                              # a two-term sum has one order
+            assert np.array_equal(idx, ref_idx) and np.array_equal(conf, ref_conf) and np.array_equal(depth, ref_depth)
+        else:                                                   # ring order: sums differ in the last bits
+            assert np.allclose(conf, ref_conf, rtol=1e-5, atol=1e-6)
+            picked = np.take_along_axis(ref_vol, idx[None].astype(np.int64), axis=0)[0]
+            assert np.all(picked >= ref_conf * (1 - 1e-5) - 1e-6)
+        assert np.array_equal(depth, mappers[0].raw_depths_vec_[idx])
+        for o in accs + mappers:
+            o.close()
+    # ---- plane sharding
+    ranges = dd.plane_ranges(nz, n)
+    ms, shards = [], []
+    ev0 = rig["events"][0]
+    for r, c_ in enumerate(ctxs):
+        m_ = d.MapperEMVS(c_, rig["cam"], shape, plane_range=ranges[r])
+        assert m_.evaluateDSI(ev0, rig["trajectories"][0], T)
+        ms.append(m_)
+        shards.append(m_.dsi_)
+    d.depth_map_sharded_all(ms, shards, comms)
+    whole = d.MapperEMVS(ctx, rig["cam"], shape)
+    assert whole.evaluateDSI(ev0, rig["trajectories"][0], T)
+    whole.computeDepthMap()
+    want = whole.fetchDepthMap()
+    for m_ in ms:
+        for a_, b_ in zip(m_.fetchDepthMap(), want):
+            assert np.array_equal(a_, b_)
+    for o in ms + [whole, ref_mapper] + grids + comms:
+        o.close()
+    single.close()
+    for c_ in ctxs[1:]:
+        c_.close()

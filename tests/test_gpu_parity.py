@@ -341,6 +341,65 @@ def test_nary_fusion_modes_bit_exact(ctx, n_maps):
         o.close()
 
 
+@pytest.mark.parametrize("n_maps", [2, 4, 8])
+def test_gm_tree_is_the_reference_op_applied_pairwise(ctx, n_maps):
+    """ACC_GM_TREE: the n-ary geometric mean rooted in the reference -- the balanced tree of its own 2-ary
+    sqrt(a*g) (Grid3D::geometricMeanTwoGrids, cartesian3dgrid.h:150-156).  Bit-equal to the oracle's repeated
+    2-ary calls; for n = 2 bit-equal to the 2-ary member itself (the LOG_SUM form is only within 16 ulp);
+    the arg-max-fused form gives the same bits as fuse-then-collapse; within 1e-5 of exp(mean(log))."""
+    rng = np.random.default_rng(60 + n_maps)
+    nx, ny, nz = 67, 33, 6
+    maps = []
+    for k in range(n_maps):
+        v = rng.gamma(2.0, 8.0, (nz, ny, nx)).astype(np.float32)
+        v.flat[k::13] = 0.0
+        v.flat[3 + k::97] = np.float32(1e-41)
+        v.flat[5 + k::101] = np.float32(3e37)          # a product of two overflows to inf: sqrt(inf) = inf on both sides
+        maps.append(v)
+    G = [d.Grid3D(ctx, nx, ny, nz) for _ in range(n_maps)]
+    for g, v in zip(G, maps):
+        g.upload(v)
+    A = d.Grid3D(ctx, nx, ny, nz)
+    A.setToFusionOfN(G, d.ACC_GM_TREE)
+    got = A.download()
+    ref = orc.fuse_gm_tree(maps)
+    same = (got.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(got) & np.isnan(ref))
+    assert same.all(), "%d voxels differ" % (~same).sum()
+    if n_maps == 2:
+        A.upload(maps[0])
+        A.geometricMeanTwoGrids(G[1])                 # the 2-ary member on the GPU
+        assert np.array_equal(A.download().view(np.uint32), got.view(np.uint32))
+        assert np.array_equal(orc.fuse2(maps[0], maps[1], 3).view(np.uint32), got.view(np.uint32))
+    lo, hi = 2.0 ** -20, 2.0 ** 20
+    ok = np.ones(got.shape, bool)
+    for v in maps:
+        ok &= (v >= lo) & (v <= hi)
+    logs = orc.fuse_nary(maps, d.ACC_LOG_SUM)
+    assert ok.sum() > 1000 and np.allclose(got[ok], logs[ok], rtol=1e-5)
+    # inside the arg-max kernel
+    m = d.MapperEMVS(ctx, (nx, ny, 50.0, 50.0, 33.0, 16.0), d.ShapeDSI(0, 0, nz, 1.0, 5.0, 0.0))
+    finite = [np.where(np.isfinite(v) & (v < 1e30), v, 0).astype(np.float32) for v in maps]
+    for g, v in zip(G, finite):
+        g.upload(v)
+    A.setToFusionOfN(G, d.ACC_GM_TREE)
+    m.computeDepthMap(A)
+    want = m.fetchDepthMap()
+    m.computeDepthMapOfFusionN(G, d.ACC_GM_TREE)
+    have = m.fetchDepthMap()
+    for a_, b_ in zip(have, want):
+        assert np.array_equal(a_, b_)
+    # not an accumulation, and only for 2 / 4 / 8 grids
+    from dvs_mcemvs_amd import engine
+    with pytest.raises(d.DsiError) as e:
+        A.accumulate(G[0], d.ACC_GM_TREE)
+    assert e.value.code == engine.ERR_BAD_OP
+    with pytest.raises(d.DsiError) as e:
+        A.setToFusionOfN(G[:1] + G[:1] + G[:1], d.ACC_GM_TREE)
+    assert e.value.code == engine.ERR_BAD_OP
+    for o in G + [A, m]:
+        o.close()
+
+
 @pytest.mark.parametrize("n_maps", [1, 3, 4, 8])
 def test_depth_map_of_nary_fusion_equals_fuse_then_collapse(ctx, n_maps):
     """dsi_mapper_depth_map_of_fusion_n (the n-camera fusion inside the arg-max kernel) = setToFusionOfN
@@ -595,6 +654,77 @@ def test_configs4_camera_at_full_size(ctx):
     assert err.max() < 2e-6, err.max()
     for o in (full, acc, m):
         o.close()
+
+
+def test_configs4_end_to_end_at_full_size(ctx):
+    """BASELINE.json configs[4] END TO END at full size on one GPU: 4 cameras x 100 M events, 1024x1024x256 (1 GiB
+    per DSI), n-ary geometric mean, arg-max + depth.
+      (a) every plane of every camera DSI holds at most as many votes as there are events, most of them all;
+      (b) the camera fusion computed INSIDE the arg-max kernel gives the depth map of fuse-then-collapse bit
+          for bit, for both GM forms (tree of the reference's 2-ary op; exp(mean(log)));
+      (c) against the CPU oracle on a 64-row strip (all 256 planes, all 4 x 100 M events -- what the oracle
+          can afford at this size): every voxel of the four camera DSIs and of the fused DSI within the stated
+          tolerance, and for EVERY pixel of the strip the GPU's plane is the oracle's or a provable near-tie."""
+    nx = ny = 1024
+    nz, parts, n_cams = 256, 10, 4
+    r0, rows = 480, 64
+    rig = syn.stereo_rig(10_000_000, width=nx, height=ny, t0=10.0, duration=0.5, seed=1234, n_cams=n_cams)
+    mappers, batches, host = [], [], []
+    for c in range(n_cams):
+        x, y, ts = rig["events"][c]
+        first, Rt = d.packetize(ts, rig["trajectories"][c], rig["T_rv_w"])
+        n = first.shape[0] * 1024
+        assert np.array_equal(first, np.arange(first.shape[0], dtype=np.uint32) * 1024)
+        rts = []
+        for i in range(parts):       # the same pixels seen from a rig that has moved on: ten different tenths
+            r = Rt.copy()
+            r[:, 9] += 0.02 * i
+            r[:, 11] += 0.01 * i
+            rts.append(r)
+        X, Y, R = np.tile(x[:n], parts), np.tile(y[:n], parts), np.concatenate(rts)
+        m = d.MapperEMVS(ctx, rig["cam"], d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0))
+        b = d.EventBatch(ctx, X, Y, R)
+        m.evaluateDSI_batch(b)
+        assert m.last_vote_info()["n_packets"] * 1024 == 99_993_600
+        mappers.append(m)
+        batches.append(b)
+        host.append((X, Y, R))
+    dsis = [m.dsi_ for m in mappers]
+    fused = d.Grid3D(ctx, nx, ny, nz)
+    idx_tree = None
+    for mode in (d.ACC_GM_TREE, d.ACC_LOG_SUM):                                         # (b)
+        fused.setToFusionOfN(dsis, mode)
+        mappers[0].computeDepthMap(fused)
+        want = mappers[0].fetchDepthMap()
+        mappers[0].computeDepthMapOfFusionN(dsis, mode)
+        got = mappers[0].fetchDepthMap()
+        for g, w, name in zip(got, want, ("depth", "confidence", "index")):
+            assert np.array_equal(g, w), "mode %d: %s differs at %d pixels" % (mode, name, (g != w).sum())
+        assert want[1].max() > 10.0
+        if mode == d.ACC_GM_TREE:
+            idx_tree, conf_tree, depth_tree = want[2], want[1], want[0]
+    assert np.array_equal(depth_tree, mappers[0].raw_depths_vec_[idx_tree])
+    fused.setToFusionOfN(dsis, d.ACC_GM_TREE)
+    fused_strip = fused.download()[:, r0:r0 + rows, :]
+    strips = []
+    first_all = np.arange(host[0][2].shape[0], dtype=np.int64) * 1024
+    for c in range(n_cams):                                                             # (a), (c)
+        vol = mappers[c].dsi_.download()
+        sums = vol.reshape(nz, -1).sum(axis=1, dtype=np.float64)
+        assert (sums <= 99_993_600 + 64).all() and sums.max() > 0.9 * 99_993_600
+        o = OracleMapper(rig["cam"], dimZ=nz, min_depth=4.0, max_depth=200.0)
+        ref = o.evaluate_packets_rows(host[c][0], host[c][1], first_all, host[c][2], r0, rows)
+        assert_dsi_close(vol[:, r0:r0 + rows, :], ref)
+        assert ref.max() > 50.0
+        strips.append(ref)
+        del vol
+    ref_fused = orc.fuse_gm_tree(strips)
+    assert_dsi_close(fused_strip, ref_fused, tol=4 * DSI_TOL)      # GM of four values each within DSI_TOL
+    rep = argmax_report(idx_tree[r0:r0 + rows], ref_fused, 4 * DSI_TOL)
+    print("configs[4] full size, rows %d..%d: %r" % (r0, r0 + rows, rep))
+    assert rep["violations"] == 0 and rep["argmax_agree_frac"] > 0.9, rep
+    for o_ in mappers + batches + [fused]:
+        o_.close()
 
 
 def test_fuse_into_equals_reference_sequence(ctx):

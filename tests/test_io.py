@@ -60,6 +60,20 @@ def test_parse_rosbag_gt_relative_stamps_and_window(tmp_path):
     assert np.array_equal(p[:, 0], np.arange(10, 22))
 
 
+def test_parse_rosbag_gt_keeps_the_first_of_equal_stamps(tmp_path):
+    """The reference stores poses with std::map::insert (data_loading.cpp:303-420): a repeated stamp keeps the
+    FIRST pose and adds no control point."""
+    times = np.array([5.0, 5.1, 5.1, 5.2, 5.2, 5.2, 5.3])
+    poses = np.zeros((7, 7))
+    poses[:, 0] = np.arange(7)
+    poses[:, 3] = 1.0
+    io.write_pose_bag(tmp_path / "pose.bag", times, poses, topic="/pose")
+    t, p = io.parse_rosbag_gt(tmp_path / "pose.bag", topic="/pose")
+    assert np.allclose(t, [0.0, 0.1, 0.2, 0.3], atol=1e-9)
+    assert np.array_equal(p[:, 0], [0, 1, 3, 6])
+    assert np.all(np.diff(t) > 0)
+
+
 @pytest.mark.skipif(not os.path.exists(REF_BAG), reason="reference checkout not present on this box")
 def test_reads_the_reference_dsec_odometry_bag():
     """The only real data in the reference repo: LiDAR-IMU odometry of

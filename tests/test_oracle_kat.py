@@ -387,3 +387,40 @@ def test_c_oracle_equals_the_independent_numpy_restatement_bit_for_bit():
     conf_c, idx_c = orc.collapse_max_z(dsi_c)
     conf_n, idx_n = ind.collapse_max_z(dsi_c)
     assert np.array_equal(conf_c, conf_n) and np.array_equal(idx_c, idx_n)
+
+
+def test_gm_tree_is_repeated_two_ary_geometric_mean():
+    """oracle.fuse_gm_tree = Grid3D::geometricMeanTwoGrids (cartesian3dgrid.h:150-156) on pairs, then on the
+    results: equal to float32 numpy sqrt of float32 products level by level, and to (a b c d)^(1/4) in float64
+    within a few ulp."""
+    rng = np.random.default_rng(2)
+    maps = [rng.gamma(2.0, 5.0, (3, 8, 9)).astype(np.float32) for _ in range(4)]
+    maps[1][0, 0, 0] = 0.0
+    got = orc.fuse_gm_tree(maps)
+    l0 = np.sqrt(maps[0] * maps[1])
+    l1 = np.sqrt(maps[2] * maps[3])
+    assert np.array_equal(got, np.sqrt(l0 * l1))
+    assert got[0, 0, 0] == 0.0
+    exact = (maps[0].astype(np.float64) * maps[1] * maps[2] * maps[3]) ** 0.25
+    assert np.allclose(got, exact, rtol=4e-7)
+    assert np.array_equal(orc.fuse_gm_tree(maps[:2]), orc.fuse2(maps[0], maps[1], 3))
+    with pytest.raises(ValueError):
+        orc.fuse_gm_tree(maps[:3])
+
+
+def test_row_strip_oracle_equals_the_rows_of_the_full_dsi():
+    """oracle.fill_voxel_grid_rows (test infrastructure for 1024 x 1024 x 256 at 100 M events) is bit-equal to the
+    corresponding rows of fill_voxel_grid, including the strip's first and last row (half votes from outside)."""
+    rng = np.random.default_rng(9)
+    nx, ny = 70, 60
+    planes = orc.depth_planes(1.0, 5.0, 7)
+    Kv = np.array([50, 50, 35, 30], np.float32)
+    xy = rng.uniform(-8, 78, (6 * 1024, 2)).astype(np.float32)
+    xy[:40] = [[3.0, 17.0], [3.5, 16.999], [60.25, 28.0], [1.0, 29.5]] * 10     # on the strip's edges at plane 0
+    centers = rng.normal(0, 0.2, (6, 3)).astype(np.float32)
+    centers[0] = 0
+    full = orc.fill_voxel_grid(xy, centers, planes, Kv, nx, ny)
+    for r0, rows in ((0, 60), (17, 13), (59, 1), (0, 1)):
+        strip = orc.fill_voxel_grid_rows(xy, centers, planes, Kv, nx, ny, r0, rows)
+        assert np.array_equal(strip, full[:, r0:r0 + rows, :]), (r0, rows)
+    assert full[:, 17:30].sum() > 100
