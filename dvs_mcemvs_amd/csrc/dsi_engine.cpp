@@ -364,7 +364,9 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
     if (chunks <= 0) {
         // Work items = chunks x bands x planes: ~8 per CU keep the tail of the last round short; every
         // chunk beyond the first costs a partial volume to write and to reduce.
-        const long items_target = 8L * 256;
+        // (round 3: a chunk's partial volume holds raw 64-bit sums, 8 bytes per voxel to write and to read back, so
+        //  fewer chunks than in round 2: 346x260x100, 10 M events: 1 / 2 / 4 chunks 2.695 / 2.668 / 2.717 ms per step)
+        const long items_target = 4L * 256;
         chunks = (int)std::max<long>(1, (items_target + (long)bands * g.nz - 1) / ((long)bands * g.nz));
         // below ~8 M events one chunk is faster when the planes alone fill the chip 1.5 times: no
         // partial volumes to write and reduce, fewer workgroup set-ups (measured at 346x260x100:
@@ -379,7 +381,7 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
                            // 0.3 ms per step for it); the pairs beyond the last whole group are dealt plane
                            // by plane over all XCDs anyway
             const int rounded = ((chunks + step - 1) / step) * step;
-            if (rounded <= chunks + chunks / 2 + 1) chunks = rounded;
+            if (rounded <= chunks + chunks / 2) chunks = rounded;
         }
         chunks = (int)std::min<size_t>((size_t)chunks, std::max<size_t>(1, n_packets));
         const size_t vol_bytes = (size_t)g.nx * g.ny * g.nz * sizeof(float);
@@ -652,11 +654,14 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
                                    direct ? (void*)g->data : (void*)m->partials.p, m->seam.p));
     vt.stop();
     }
-    // seam rows of every chunk volume from the exact 64-bit sums, then the sum over the chunks
-    HIP_TRY(dsi::launch_seam_rows(ctx->stream, m->seam.p, bp.chunks, geom, bp, direct ? (void*)g->data : (void*)m->partials.p));
+    // seam rows from the exact 64-bit sums of the two bands that meet there; then (several chunks, or accumulation) the
+    // sum over the chunks' raw partial volumes -- which takes the seam rows straight from the bands' sums when it can
+    const bool fold = !direct && dsi::reduce_can_fold_seams(geom, g->n);
+    if (!fold)
+        HIP_TRY(dsi::launch_seam_rows(ctx->stream, m->seam.p, bp.chunks, geom, bp, direct ? (void*)g->data : (void*)m->partials.p));
     if (!direct)
-        HIP_TRY(dsi::launch_reduce_partials(ctx->stream, m->partials.p, bp.chunks, g->n, g->data,
-                                            accumulate ? 1 : 0));
+        HIP_TRY(dsi::launch_reduce_partials(ctx->stream, m->partials.p, bp.chunks, g->n, g->data, accumulate ? 1 : 0,
+                                            fold ? m->seam.p : nullptr, &geom, &bp));
     return vote_done(m);
 }
 

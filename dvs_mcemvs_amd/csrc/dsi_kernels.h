@@ -101,8 +101,13 @@ hipError_t launch_group_cuts(hipStream_t s, const uint32_t* prow, const uint16_t
 hipError_t launch_vote_groups(hipStream_t s, const EvRec* sxy, const uint8_t* spk,
                               const PlaneCoef* coef, const uint32_t* gcuts, const uint32_t* slow_any,
                               int np, int S, const Geom& g, const BandPlan& bp, void* out, unsigned long long* seam);
+// dsi (+)= fl(sum of the chunks' raw partial volumes).  seam != nullptr (with g, bp; needs an even nx and < 2^32 voxels:
+// reduce_can_fold_seams): the seam rows are read from the bands' head / carry sums instead, i.e. launch_seam_rows is
+// folded in and must NOT be run on the partial volumes first
 hipError_t launch_reduce_partials(hipStream_t s, const unsigned long long* partials, int chunks, size_t n,
-                                  float* dsi, int accumulate);
+                                  float* dsi, int accumulate, const unsigned long long* seam = nullptr,
+                                  const Geom* g = nullptr, const BandPlan* bp = nullptr);
+inline bool reduce_can_fold_seams(const Geom& g, size_t n) { return (g.nx & 1) == 0 && n <= 0xffffffffull; }
 // ---- stage B fused with the camera fusion and the arg-max (no DSI leaves the CU) ----
 // the per-camera tables of the banded vote (k_sort_packets / k_plane_coef outputs, built with bp.halo = 1)
 struct FusedCamera {

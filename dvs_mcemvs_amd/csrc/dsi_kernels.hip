@@ -2779,18 +2779,42 @@ __global__ __launch_bounds__(256) void k_seam_rows(const acc_t* __restrict__ sea
 // exact and order-free, so the DSI does not depend on the number of chunks.  Two voxels per thread.
 __global__ __launch_bounds__(256) void k_reduce_partials(const acc_t* __restrict__ partials,
                                                          int chunks, size_t n,
-                                                         float* __restrict__ dsi, int accumulate)
+                                                         float* __restrict__ dsi, int accumulate,
+                                                         const acc_t* __restrict__ seam, int nx, int ny, int nz, int bands,
+                                                         int band_rows)
 {
+    // seam != nullptr: the seam rows (first row of every band but the first) are taken from the bands' head and
+    // carry sums instead of the partial volumes (k_seam_rows folded in: one launch less per evaluateDSI);
+    // requires an even nx (two voxels per thread never straddle a row)
     const size_t n2 = n / 2;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t vs = partial_stride(n);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
         ulonglong2 acc = make_ulonglong2(0ull, 0ull);
-        for (int c = 0; c < chunks; ++c) {
-            const ulonglong2 v = reinterpret_cast<const ulonglong2*>(partials + (size_t)c * vs)[i];
-            acc.x += v.x;
-            acc.y += v.y;
+        bool from_seam = false;
+        if (seam) {
+            const unsigned v = (unsigned)(2 * i);          // voxel index < 2^32 (checked by the launcher)
+            const unsigned rowi = v / (unsigned)nx;        // z * ny + y
+            const unsigned y = rowi % (unsigned)ny;
+            const unsigned j = y / (unsigned)band_rows;
+            if (j >= 1 && y == j * (unsigned)band_rows) {
+                from_seam = true;
+                const unsigned z = rowi / (unsigned)ny, x = v - rowi * (unsigned)nx;
+                for (int c = 0; c < chunks; ++c) {
+                    const size_t row = ((size_t)c * nz + z) * bands;
+                    const ulonglong2 h = *reinterpret_cast<const ulonglong2*>(seam + ((row + j) * 2) * nx + x);
+                    const ulonglong2 k = *reinterpret_cast<const ulonglong2*>(seam + ((row + j - 1) * 2 + 1) * nx + x);
+                    acc.x += h.x + k.x;
+                    acc.y += h.y + k.y;
+                }
+            }
         }
+        if (!from_seam)
+            for (int c = 0; c < chunks; ++c) {
+                const ulonglong2 v = reinterpret_cast<const ulonglong2*>(partials + (size_t)c * vs)[i];
+                acc.x += v.x;
+                acc.y += v.y;
+            }
         float2 r = make_float2(fix_to_float(acc.x), fix_to_float(acc.y));
         float2* d2 = reinterpret_cast<float2*>(dsi) + i;  // (grids are 16-byte aligned, also wrapped ones)
         if (accumulate) {
@@ -3768,10 +3792,14 @@ hipError_t launch_seam_rows(hipStream_t s, const unsigned long long* seam, int c
 }
 
 hipError_t launch_reduce_partials(hipStream_t s, const unsigned long long* partials, int chunks, size_t n,
-                                  float* dsi, int accumulate)
+                                  float* dsi, int accumulate, const unsigned long long* seam, const Geom* g, const BandPlan* bp)
 {
+    // the seam rows can be folded in when two voxels never straddle a row and 32-bit voxel indices suffice
+    const bool fold = seam && g && bp && bp->bands >= 2 && (g->nx & 1) == 0 && n <= 0xffffffffull;
+    if (seam && !fold && bp && bp->bands >= 2) return hipErrorInvalidValue;  // the caller must run launch_seam_rows instead
     hipLaunchKernelGGL(k_reduce_partials, dim3(grid_for(n / 2 + 1, 256)), dim3(256), 0, s,
-                       partials, chunks, n, dsi, accumulate);
+                       partials, chunks, n, dsi, accumulate, fold ? seam : nullptr, g ? g->nx : 0, g ? g->ny : 0, g ? g->nz : 0,
+                       bp ? bp->bands : 0, bp ? bp->band_rows : 0);
     return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
