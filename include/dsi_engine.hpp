@@ -448,6 +448,7 @@ public:
         cfg.inverse_depth = inverse_depth ? 1 : 0;
         cfg.lut = cam.rectified_points.empty() ? nullptr : cam.rectified_points.data();
         dsi::check(dsi_mapper_create(ctx.handle(), &cfg, &h_));
+        ctx_ = ctx.handle();
         dsi_ = Grid3D::view(dsi_mapper_grid(h_));
     }
     ~MapperEMVS()
@@ -533,6 +534,7 @@ public:
     }
     size_t eventsVoted() const { return events_voted_; }
     dsi_mapper_t* handle() const { return h_; }
+    dsi_context_t* context() const { return ctx_; }
 
     Grid3D dsi_;       // public member, as in the reference (mapper_emvs_stereo.hpp:116)
     std::string name;  // mapper_emvs_stereo.hpp:117
@@ -546,6 +548,7 @@ private:
         return c;
     }
     dsi_mapper_t* h_ = nullptr;
+    dsi_context_t* ctx_ = nullptr;
     std::vector<uint16_t> xs_, ys_;
     std::vector<double> ts_;
     size_t events_voted_ = 0;

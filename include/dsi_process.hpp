@@ -3,6 +3,8 @@
 // output):
 //
 //   process_1   mapper_emvs_stereo/src/process1.cpp:28-224   one DSI per camera, camera fusion
+//   process_1_depth_map                                      the same + the arg-max of getDepthMapFromDSI, without
+//                                                            writing any DSI (one fused kernel)
 //   process_2   mapper_emvs_stereo/src/process2.cpp:28-302   sub-intervals: camera fusion then
 //                                                            temporal fusion, and the converse order
 //   process_5   mapper_emvs_stereo/src/process5.cpp:28-260   process_2 with the right camera's
@@ -105,6 +107,71 @@ inline dsi::Transformation process_1(const LinearTrajectory& trajectory0, const 
         else if (fusion_method == 6) mapper_fused.dsi_.maxTwoGrids(mapper2.dsi_);
         // 3, 4, 5: the reference silently ignores the third camera
     }
+    return T_rv_w;
+}
+
+// Alg. 1 for callers that keep only the depth map (the --full_seq loop, main.cpp:177-302: process_1 followed by
+// getDepthMapFromDSI's arg-max): the same result as process_1(...) + mapper_fused.getDepthMapFromDSI(depth_map,
+// confidence_map, depth_cell_indices), bit for bit, but through ONE kernel that votes both cameras band by band in LDS,
+// fuses them per voxel and keeps the running arg-max on the CU (dsi_mapper_depth_map_of_events): no DSI is written.
+// mapper0 / mapper1 supply the cameras' geometry and scratch; their dsi_ members are NOT updated.  Two cameras.
+inline dsi::Transformation process_1_depth_map(const LinearTrajectory& trajectory0, const LinearTrajectory& trajectory1,
+                                               const std::vector<dsi::Event>& events0, const std::vector<dsi::Event>& events1,
+                                               EMVS::MapperEMVS& mapper_out, EMVS::MapperEMVS& mapper0,
+                                               EMVS::MapperEMVS& mapper1, double ts, int fusion_method,
+                                               dsi::Image<float>& depth_map, dsi::Image<float>& confidence_map,
+                                               dsi::Image<uint8_t>& depth_cell_indices, double rv_pos = 0.0)
+{
+    dsi::Transformation T_w_l;
+    if (!trajectory0.getPoseAt(ts, T_w_l)) throw dsi::Error(DSI_ERR_INVALID, "no pose at the reference timestamp");
+    dsi::Transformation baseline;
+    baseline.t[0] = rv_pos;
+    const dsi::Transformation T_rv_w = dsi::inverse(T_w_l * baseline);  // process1.cpp:56-68
+    double T7[7];
+    T_rv_w.to7(T7);
+    const std::vector<dsi::Event>* evs[2] = {&events0, &events1};
+    const LinearTrajectory* trs[2] = {&trajectory0, &trajectory1};
+    dsi_mapper_t* ms[2] = {mapper0.handle(), mapper1.handle()};
+    dsi_batch_t* bs[2] = {nullptr, nullptr};
+    std::vector<uint16_t> xs, ys;
+    std::vector<double> tss;
+    std::vector<uint32_t> first;
+    std::vector<float> Rt;
+    dsi_context_t* ctx = nullptr;
+    try {
+        for (int c = 0; c < 2; ++c) {
+            const size_t n = evs[c]->size();
+            xs.resize(n);
+            ys.resize(n);
+            tss.resize(n);
+            for (size_t i = 0; i < n; ++i) {
+                xs[i] = (*evs[c])[i].x;
+                ys[i] = (*evs[c])[i].y;
+                tss[i] = (*evs[c])[i].ts;
+            }
+            first.assign(n / DSI_PACKET_SIZE + 1, 0u);
+            Rt.assign(12 * first.size(), 0.f);
+            size_t np = 0;
+            const int rc = dsi_packetize(tss.data(), n, trs[c]->times().data(), trs[c]->poses7().data(), trs[c]->times().size(),
+                                         T7, first.data(), Rt.data(), &np);
+            if (rc == DSI_ERR_TOO_FEW_EVENTS) np = 0;  // evaluateDSI returns false: an all-zero DSI (mapper_emvs_stereo.cpp:71-75)
+            else dsi::check(rc);
+            ctx = mapper_out.context();
+            dsi::check(dsi_batch_create(ctx, xs.data(), ys.data(), n, first.data(), Rt.data(), np, &bs[c]));
+        }
+        dsi::check(dsi_mapper_depth_map_of_events(mapper_out.handle(), ms, bs, 2, fusion_method));
+        int nx, ny, nz;
+        mapper_out.dsi_.getDimensions(&nx, &ny, &nz);
+        depth_map = dsi::Image<float>(ny, nx);
+        confidence_map = dsi::Image<float>(ny, nx);
+        depth_cell_indices = dsi::Image<uint8_t>(ny, nx);
+        dsi::check(dsi_mapper_fetch_depth_map(mapper_out.handle(), depth_map.data.data(), confidence_map.data.data(),
+                                              depth_cell_indices.data.data()));
+    } catch (...) {
+        for (dsi_batch_t* b : bs) dsi_batch_destroy(b);
+        throw;
+    }
+    for (dsi_batch_t* b : bs) dsi_batch_destroy(b);
     return T_rv_w;
 }
 

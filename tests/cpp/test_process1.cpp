@@ -229,6 +229,21 @@ int main()
             std::vector<float> a = ref0;
             orc_fuse2(a.data(), ref1.data(), a.size(), 3);
             if (max_rel_err(mapper_fused.dsi_.download(), a) > 3e-4) return 61;
+            // the depth-map-only form (one fused kernel, no DSI written) gives the depth map of process_1 +
+            // getDepthMapFromDSI bit for bit, for every fusion method
+            for (int method = 1; method <= 6; ++method) {
+                process_1(trajectory0, trajectory1, trajectory1, events0, events1, none, mapper_fused, mapper0, mapper1, mapper1,
+                          0.5, method);
+                dsi::Image<float> d1, c1, d2, c2;
+                dsi::Image<uint8_t> i1, i2;
+                mapper_fused.getDepthMapFromDSI(d1, c1, i1);
+                EMVS::MapperEMVS cam_a(ctx, cam, dsi_shape), cam_b(ctx, cam, dsi_shape);
+                process_1_depth_map(trajectory0, trajectory1, events0, events1, mapper_fused, cam_a, cam_b, 0.5, method, d2, c2, i2);
+                if (d1.data != d2.data || c1.data != c2.data || i1.data != i2.data) {
+                    std::printf("process_1_depth_map differs for fusion method %d\n", method);
+                    return 64;
+                }
+            }
             try {
                 process_1(trajectory0, trajectory1, trajectory1, events0, events1, none, mapper_fused, mapper0,
                           mapper1, mapper2, 0.5, 9);
