@@ -124,6 +124,45 @@ def test_fused_camera_without_packets(ctx):
         o.close()
 
 
+@pytest.mark.parametrize("packed", [1, 5])
+def test_fused_with_slow_planes_unequal_cameras_and_a_lut(ctx, packed):
+    """The paths a plain rig does not reach: a rectification LUT with huge and NaN entries (locations above 2^40
+    make every plane of their packet take the IEEE-divide stream; NaN locations are dropped), cameras with
+    different packet counts, inverse depth planes, a virtual camera from a field of view.  Still bit-identical to
+    vote -> fuse -> collapse."""
+    nx, ny, nz = 120, 90, 24
+    rig = syn.stereo_rig(50_000, width=nx, height=ny, duration=0.3, seed=5, n_points=700)
+    lut = syn.radial_lut(rig["cam"])
+    lut[7 * nx + 11] = (3.0e13, 5.0)          # |x0| > 2^40 after the warp: the "slow" stream
+    lut[20 * nx + 40] = (np.nan, 1.0)
+    lut[33 * nx + 3] = (2.0, -np.inf)
+    shape = d.ShapeDSI(100, 80, nz, 3.0, 150.0, 70.0)
+    ev = [rig["events"][0], tuple(a[:31_000] for a in rig["events"][1])]
+    for e in ev:                               # make sure the special pixels fire in several packets
+        e[0][::997] = 11
+        e[1][::997] = 7
+        e[0][5::1013] = 40
+        e[1][5::1013] = 20
+    batches = []
+    for c in range(2):
+        first, Rt = d.packetize(ev[c][2], rig["trajectories"][c], rig["T_rv_w"])
+        batches.append(d.EventBatch(ctx, ev[c][0], ev[c][1], Rt, first))
+    assert batches[0].n_packets != batches[1].n_packets
+    mk = lambda: [d.MapperEMVS(ctx, rig["cam"], shape, lut=lut, inverse_depth=True) for _ in range(2)]
+    ref_m, fus_m = mk(), mk()
+    for m in fus_m:
+        m.set_packed_lanes(packed)
+    for op in (d.FUSE_HM, d.FUSE_GM, d.FUSE_MAX):
+        want = unfused(ctx, ref_m, batches, op)
+        fus_m[1].computeDepthMapOfEvents(fus_m, batches, op)
+        got = fus_m[1].fetchDepthMap()
+        for g, w, name in zip(got, want, ("depth", "confidence", "index")):
+            assert np.array_equal(g, w), "op %d %s differs at %d pixels" % (op, name, (g != w).sum())
+    assert want[1].max() > 1.0 and np.isfinite(want[1]).all()
+    for o in ref_m + fus_m + batches:
+        o.close()
+
+
 def test_fused_rejects_bad_arguments(ctx):
     rig = syn.stereo_rig(5_000, width=64, height=48, duration=0.1, seed=1)
     a = d.MapperEMVS(ctx, rig["cam"], d.ShapeDSI(0, 0, 8, 4.0, 100.0, 0.0))
