@@ -120,6 +120,14 @@ def test_fused_camera_without_packets(ctx):
     want = ms[1].fetchDepthMap()
     for g, w in zip(got, want):
         assert np.array_equal(g, w)
+    # the empty camera first
+    ms[0].computeDepthMapOfEvents(ms, [empty, b0], d.FUSE_MAX)
+    for g, w in zip(ms[0].fetchDepthMap(), want):
+        assert np.array_equal(g, w)
+    # both empty: an all-zero fused DSI
+    ms[0].computeDepthMapOfEvents(ms, [empty, empty], d.FUSE_AM)
+    depth, conf, idx = ms[0].fetchDepthMap()
+    assert not conf.any() and not idx.any()
     for o in ms + [b0, empty]:
         o.close()
 

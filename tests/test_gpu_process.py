@@ -5,7 +5,7 @@ import pytest
 
 import dvs_mcemvs_amd as d
 from dvs_mcemvs_amd import process, synthetic as syn
-from oracle_pipeline import OracleMapper, oracle_process_1, oracle_process_2
+from oracle_pipeline import OracleMapper, argmax_report, oracle_process_1, oracle_process_2
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-4
@@ -81,5 +81,37 @@ def test_process_5_shuffled_right_camera(ctx):
     sel = process.shuffled_subintervals(18037, 4)
     assert sel[0][0] == 2 * (18037 // 4) and len(sel[1]) == 18037 // 4
     assert any(s[-1] < s[0] for s in sel)                       # one sub-interval wraps: tail then head
+    fused.close()
+    cam_time.close()
+
+
+def test_configs3_eight_time_slices_at_full_size(ctx):
+    """BASELINE.json configs[3] at FULL size on one GPU: "Stereo DSEC, 8 independent time-slice DSIs" -- 10 M
+    events per camera cut into 8 sub-intervals of 1.25 M by event count (process2.cpp:46-47), per slice the two
+    camera DSIs and their harmonic mean, temporal harmonic mean over the slices (Alg. 2, process2.cpp:98-249),
+    arg-max.  Against the oracle's process_2: every voxel of the left / right / fused temporal DSIs and of the
+    converse (camera fusion of the temporal DSIs) within tolerance, and for EVERY pixel the GPU's plane is the
+    oracle's or a provable near-tie.  (The multi-rank tests shard exactly these slices over ranks, with smaller
+    slices; the sums they all-reduce are these accumulators.)"""
+    rig = syn.stereo_rig(10_000_000, seed=1234)
+    shape = d.ShapeDSI(0, 0, 100, 4.0, 200.0, 0.0)
+    fused = d.MapperEMVS(ctx, rig["cam"], shape)
+    cam_time = d.MapperEMVS(ctx, rig["cam"], shape)
+    ts = rig["t1"]
+    out = process.process_2(ctx, [rig["cam"]] * 2, shape, rig["events"], rig["trajectories"], 8, fused, cam_time, ts, 2, 2)
+    ref = oracle_process_2(lambda: OracleMapper(rig["cam"], dimZ=100, min_depth=4.0, max_depth=200.0),
+                           rig["events"], rig["trajectories"], 8, ts, 2, 2)
+    close(out["left"].download(), ref["left"])
+    close(out["right"].download(), ref["right"])
+    got = fused.dsi_.download()
+    close(got, ref["fused"])
+    close(cam_time.dsi_.download(), ref["camera_time"], 4e-4)
+    assert ref["fused"].max() > 1.0
+    fused.computeDepthMap()
+    depth, conf, idx = fused.fetchDepthMap()
+    rep = argmax_report(idx, ref["fused"], TOL)
+    print("configs[3] full size: %r" % rep)
+    assert rep["violations"] == 0 and rep["argmax_agree_frac"] > 0.99, rep
+    assert np.array_equal(depth, fused.raw_depths_vec_[idx])
     fused.close()
     cam_time.close()
