@@ -1824,33 +1824,47 @@ __device__ __forceinline__ void vfill_stream_asm(const EvRec* __restrict__ sxy,
     if (Ui - 1 < Li) return;  // the band accepts no row (the unsigned range test needs Ui-1-Li >= 0)
     const int pass = 1 << lg_pass;
     const int p_begin = p_begin_of_wg;
-    const int npass = (p_end - p_begin + pass - 1) / pass;
-    const int j0 = (p_first - p_begin) / pass;       // this wave's first pass
     (void)stride;
-    // Passes are DEALT, not pre-assigned: wave w starts with pass w and draws every further one from a
-    // counter in LDS (set to the number of waves by the item's set-up).  A pass holds 64 packets'
-    // records of this band and plane -- anything from a few hundred to a few thousand slots -- and an
-    // item has only ~2-10 passes per wave, so with fixed assignments the workgroup waited for its
-    // unluckiest wave.  (The sums are integer: which wave votes a pass does not change a bit.)
-    auto draw = [&]() {
-        int v = 0;
-        if (lane == 0) v = atomicAdd(pass_counter, 1);
+    // Passes are DEALT, not pre-assigned, in UNITS of half a pass: wave w starts with units 2w and 2w + 1 and
+    // draws every further stretch from a counter in LDS (set to twice the number of waves by the item's set-up).
+    // A pass holds 64 packets' records of this band and plane -- anything from a few hundred to a few thousand
+    // slots -- and an item has only ~2-10 passes per wave, so with fixed assignments the workgroup waited for its
+    // unluckiest wave.  A draw takes two units (a whole pass: the per-pass set-up is amortised over 64 packets)
+    // until few are left, then one (guided: the waves finish within half a pass of each other).  (The sums are
+    // integer: which wave votes a pass does not change a bit.)
+    const int half = pass >> 1;
+    const int n_units = (p_end - p_begin + half - 1) / half;
+    // single units once fewer than kGuided per wave remain (variant 100, experiments builds only: never, i.e. whole
+    // passes to the end as in round 2, for same-box A/B runs)
+    const int kGuided = (variant >= 100 && variant <= 108) ? variant - 100 : 4;
+    const int n_waves_wg = (int)(blockDim.x >> 6);
+    auto draw = [&](int& take) {
+        int v = 0, t = 2;
+        if (lane == 0) {
+            const int seen = __hip_atomic_load(pass_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            t = (kGuided == 0 || n_units - seen > kGuided * n_waves_wg) ? 2 : 1;
+            v = atomicAdd(pass_counter, t);
+        }
+        take = __builtin_amdgcn_readfirstlane(t);
         return __builtin_amdgcn_readfirstlane(v);
     };
-    // lane l = packet l of pass j.  (Tried: interleaved passes -- lane l = packet p_begin + l * npass + j,
-    // so that the 3-4 packets a batch mixes are far apart in time and a scene point's votes do not meet in
-    // one wave instruction: -1 % ... +3 %, not adopted.  Tried: the ds_bpermute look-ups issued a further
-    // iteration ahead, waited for with lgkmcnt(6): no change, 5.01 vs 5.00 ms.)
-    auto packet_of = [&](int j) { return p_begin + j * pass + lane; };
+    // lane l = packet l of the stretch that starts at unit u.  (Tried: interleaved passes -- lane l = packet
+    // p_begin + l * npass + j, so that the 3-4 packets a batch mixes are far apart in time and a scene point's
+    // votes do not meet in one wave instruction: -1 % ... +3 %, not adopted.  Tried: the ds_bpermute look-ups
+    // issued a further iteration ahead, waited for with lgkmcnt(6): no change, 5.01 vs 5.00 ms.)
+    auto packet_of = [&](int u) { return p_begin + u * half + lane; };
+    const int u0 = 2 * ((p_first - p_begin) / pass);  // this wave's first stretch: a whole pass
     uint32_t cu_next = 0;
-    if (j0 < npass && lane < pass && packet_of(j0) < p_end) cu_next = cutz[packet_of(j0)];
-    for (int j = j0, jn; j < npass; j = jn) {
-        const int p = packet_of(j);
+    if (u0 < n_units && lane < pass && packet_of(u0) < p_end) cu_next = cutz[packet_of(u0)];
+    int take = 2, tn = 2;
+    for (int u = u0, un; u < n_units; u = un, take = tn) {
+        const int p = packet_of(u);
         const uint32_t cu = cu_next;
-        // the next pass is drawn now and its cut words travel while this pass is voted
-        jn = draw();
+        (void)take;  // (lanes beyond the stretch loaded no cut word: length 0)
+        // the next stretch is drawn now and its cut words travel while this one is voted
+        un = draw(tn);
         cu_next = 0;
-        if (jn < npass && lane < pass && packet_of(jn) < p_end) cu_next = cutz[packet_of(jn)];
+        if (un < n_units && lane < tn * half && packet_of(un) < p_end) cu_next = cutz[packet_of(un)];
         const int lo = (int)(cu & 0xffffu), hi = (int)(cu >> 16);
         const int len = max(hi - lo, 0);
         const int incl = wave_incl_scan(len, lane);
@@ -2156,7 +2170,7 @@ __device__ __forceinline__ void vote_bands_packed_body(const EvRec* __restrict__
     if (work_counters) {
         if (threadIdx.x == 0) {
             s_item = (int)atomicAdd(&work_counters[cls], 1u) * 8 + cls;
-            s_pass = BLOCK / kWave;
+            s_pass = 2 * (BLOCK / kWave);  // (vector fill: units of half a pass, two pre-assigned per wave)
         }
         __syncthreads();  // also: the previous item's flush has cleared the band
     }
@@ -2178,7 +2192,7 @@ __device__ __forceinline__ void vote_bands_packed_body(const EvRec* __restrict__
     const int cells = (r1 - r0 + 1) * nx;  // owned rows + the carry row
     if (!work_counters) {
         for (int i = threadIdx.x; i < cells; i += BLOCK) band[i] = 0;
-        if (threadIdx.x == 0) s_pass = BLOCK / kWave;
+        if (threadIdx.x == 0) s_pass = 2 * (BLOCK / kWave);
         __syncthreads();
     }
 
@@ -2336,8 +2350,8 @@ __global__ __launch_bounds__(1024) void k_vote_fuse_argmax(FusedCameras cams, Ge
     constexpr int BLOCK = 1024;
     extern __shared__ acc_t band[];
     __shared__ int s_pass;  // the next pass of the item to hand out
-    // (the vector fill pre-assigns one pass per wave, the dealt packed stream two)
-    constexpr int kPass0 = (MAPPING == 5 || MAPPING == 6) ? BLOCK / kWave : 2 * (BLOCK / kWave);
+    // (the vector fill pre-assigns two units = one pass per wave, the dealt packed stream two passes)
+    constexpr int kPass0 = 2 * (BLOCK / kWave);
     const int nx = g.nx;
     // Workgroup b runs on XCD b % 8: each XCD gets one contiguous eighth of the (band-major) pair list,
     // so that a band's records stream through at most two XCDs' L2s, and splits it evenly over its
