@@ -59,7 +59,8 @@ def parse():
     ap.add_argument("--points", type=int, default=5000, help="scene points of the synthetic rig (SURVEY 8d: 2000-20000)")
     ap.add_argument("--packed", type=int, default=-1,
                     help="lane mapping: -1 auto, 0 per-packet waves, 1 packed (hand-scheduled), 2 packet groups, "
-                         "3 packed (compiled), 4 groups (hand-scheduled), 5 packed + vector fill, 6 = 5 compiled")
+                         "3 packed (compiled), 4 groups (hand-scheduled), 5 packed + vector fill, 6 = 5 compiled, 7 = 1 with dealt passes")
+    ap.add_argument("--pass-lg", type=int, default=0, help="tuning: log2 of the packets per pass of the voting streams (0 = automatic)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-host-fed", action="store_true",
                     help="skip the host-fed (PCIe-inclusive) measurements and the 512x512x200 stream-kernel timings "
@@ -230,7 +231,7 @@ def roofline_block(info, kern_ms, kt_n, accepted, ev_per_launch, nz, traffic, re
     the SURVEY 8(d) "algorithmic bytes" figure (32*Nz+8 B per event as if every vote were an HBM
     read-modify-write), which is NOT a bound for this kernel (it exceeds the HBM peak)."""
     kernel = {0: "k_vote_bands", 1: "k_vote_bands_packed", 2: "k_vote_groups", 3: "k_vote_bands_packed",
-              4: "k_vote_groups", 5: "k_vote_bands_vfill", 6: "k_vote_bands_vfill"}[info["packed"]] \
+              4: "k_vote_groups", 5: "k_vote_bands_vfill", 6: "k_vote_bands_vfill", 7: "k_vote_bands_packed"}[info["packed"]] \
         if info["algo"] == 2 else ("k_vote_fuse_argmax" if info["algo"] == 3 else "k_vote_global")
     if not kt_n:
         return {"bound": "lds_atomic", "achieved": None, "peak": None, "unit": "G adds/s", "frac": None,
@@ -452,6 +453,11 @@ def main():
         m.set_vote_algo(args.algo)
         m.set_band_params(*args.band)
         m.set_packed_lanes(args.packed)
+        if args.pass_lg:
+            import ctypes
+            L = d.load_library()
+            L.dsi_test_pass_lg.argtypes = [ctypes.c_void_p, ctypes.c_int]
+            L.dsi_test_pass_lg(m._h, args.pass_lg)
         return m
 
     t_gen = time.time()

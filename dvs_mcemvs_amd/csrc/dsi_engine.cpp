@@ -285,11 +285,15 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
     if (packed < 0) {
         const long rows_full = std::max<long>(1, (long)(dsi::max_dynamic_lds() / row_bytes) - 1);
         const long rows_half = (long)((dsi::max_dynamic_lds() / 2) / row_bytes) - 1;
+        // (round 3: wherever the packed mapping is chosen it is lane mapping 7 -- the same hand-scheduled loop with
+        //  DEALT passes: 10 M events, same box, mapping 1 / 7: 346x260x100 1.198 / 1.187 ms, 240x180x100 1.187 / 1.150,
+        //  512x512x200 2.80 / 2.53; the vector fill keeps its range: 640x480x100 1.40 (5) vs 1.46 (7), 800x600x128
+        //  1.78 vs 2.07, 1024x1024x256 4.32 vs 6.42)
         if (rows_half >= 4 && 1024L * (rows_half + 1) / g.ny >= 56) {
-            packed = 1;
+            packed = 7;
             auto_two_per_cu = true;
         } else {
-            packed = 1024L * (rows_full + 1) / g.ny < 72 ? 5 : 1;
+            packed = 1024L * (rows_full + 1) / g.ny < 72 ? 5 : 7;
         }
     }
     // lane mapping 5 keeps 64 tail-bit words per wave behind the band
@@ -336,7 +340,7 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
     // 0.232 -> 0.222 ms).  With two per CU the hardware dispatcher already overlaps them and the item
     // loop only adds a barrier and an atomic (346x260x100: 1.175 ms plain, 1.204 ms persistent).
     const bool two_per_cu = bp->lds_bytes * 2 <= dsi::max_dynamic_lds() && bp->block_threads <= 1024;
-    bp->persistent = ((bp->packed == 1 || bp->packed == 3 || bp->packed == 5 || bp->packed == 6) && !two_per_cu) ? 1 : 0;
+    bp->persistent = ((bp->packed == 1 || bp->packed == 3 || bp->packed == 5 || bp->packed == 6 || bp->packed == 7) && !two_per_cu) ? 1 : 0;
     bp->experiment = 0;
     bp->pass_lg = (m->want_pass_lg >= 1 && m->want_pass_lg <= 6) ? m->want_pass_lg : 0;  // test hook dsi_test_pass_lg
 #ifdef DSI_TIMING_EXPERIMENTS
@@ -345,7 +349,7 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
     // not be able to change -- DSI_EXPERIMENT: corrupt -- the results of the production library).
     if (const char* e = std::getenv("DSI_PERSISTENT")) {  // A/B: 0 off, 1 on wherever the kernel supports it
         const int v = std::atoi(e);
-        bp->persistent = (v != 0 && (bp->packed == 1 || bp->packed == 3 || bp->packed == 5 || bp->packed == 6)) ? 1 : 0;
+        bp->persistent = (v != 0 && (bp->packed == 1 || bp->packed == 3 || bp->packed == 5 || bp->packed == 6 || bp->packed == 7)) ? 1 : 0;
     }
     if (const char* e = std::getenv("DSI_EXPERIMENT")) {  // 1 no votes, 2 no flush: WRONG results, timing only
         bp->experiment = std::atoi(e);
@@ -591,7 +595,7 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
     // the hand-scheduled loops address records with 32-bit byte offsets (12 B per record):
     // beyond 2^32 / 12 records (349,525 packets = 358 M events in ONE call) use the compiled loops
     if ((np + 1) * dsi::kPacket * sizeof(dsi::EvRec) > 0xffffffffull) {
-        if (bp.packed == 1) bp.packed = 3;
+        if (bp.packed == 1 || bp.packed == 7) bp.packed = 3;
         if (bp.packed == 4) bp.packed = 2;
         if (bp.packed == 5) bp.packed = 6;
     }
@@ -1226,7 +1230,7 @@ int dsi_mapper_set_band_params(dsi_mapper_t* m, int band_rows, int chunks, int b
 int dsi_mapper_set_packed_lanes(dsi_mapper_t* m, int mode)
 {
     REQUIRE(m, DSI_ERR_INVALID, "mapper is null");
-    REQUIRE(mode >= -1 && mode <= 6, DSI_ERR_INVALID, "mode must be -1 (auto) or 0..6");
+    REQUIRE(mode >= -1 && mode <= 7, DSI_ERR_INVALID, "mode must be -1 (auto) or 0..7");
     m->want_packed = mode;
     return DSI_OK;
 }

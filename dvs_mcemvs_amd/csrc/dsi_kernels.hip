@@ -2067,7 +2067,7 @@ __device__ __forceinline__ void group_stream_asm(const EvRec* sxy, const uint4* 
 // LDS: every wave of the workgroup streams its share of the packets.  LDS row 0 of the band is grid
 // row `row_base`; the item accepts events with floor(Y) in [Li, Ui - 1].
 // MAPPING = the lane mapping (1 packed / hand-scheduled, 3 packed / compiled, 5 vector fill /
-// hand-scheduled, 6 vector fill / compiled).  TWO_SETS: the vector fill keeps two instead of three batches of
+// hand-scheduled, 6 vector fill / compiled, 7 packed / hand-scheduled with dealt passes).  TWO_SETS: the vector fill keeps two instead of three batches of
 // gathers in flight (32 instead of 40 named registers; the fused kernel needs the difference).  DEAL: the hand-scheduled
 // packed stream draws its passes from *s_pass instead of taking every kWaves-th one.
 template <int BLOCK, int MAPPING, bool TWO_SETS = false, bool DEAL = false>
@@ -2124,10 +2124,20 @@ __device__ __forceinline__ void stream_item(const EvRec* __restrict__ sxy, const
         else if constexpr (MAPPING == 3)
             packed_stream<false>(sxy, coef4, cutz, band_bytes, p_begin + wave * group, p_end, lg_group,
                                  kWaves * group, lane, nx, Li, Ui, row_base, dummy_eo);
-        else if constexpr (DEAL)
-            // (*s_pass = 2 * kWaves, set by the item's set-up; passes of 4 packets unless bp.pass_lg says otherwise)
-            packed_stream_asm_dealt(sxy, coef4, cutz, band_bytes, p_begin, p_end, bp.pass_lg > 0 ? bp.pass_lg : 2, wave, kWaves,
+        else if constexpr (DEAL || MAPPING == 7) {
+            // (*s_pass = 2 * kWaves, set by the item's set-up.)  Packets per pass: enough passes per wave for the dealing
+            // to balance the waves (>= ~16), few enough switches (each costs a wait for the wave's outstanding LDS
+            // operations): 4 at a 50 ms window's 489 packets (measured 4 / 8 / 16: 446 / 455 / 471 us for the fused kernel),
+            // 16 at 4,900 (346x260x100: 1.190 / 1.182 / 1.179 ms for 4 / 8 / 16), 16-32 at 9,800 (512x512x200, 10 M
+            // events: 2.76 / 2.62 / 2.55 ms for 4 / 8 / 16)
+            int lg = 2;
+            while (lg < 5 && (p_end - p_begin) >= ((kWaves * 16) << (lg + 1))) ++lg;
+            if (bp.pass_lg > 0) lg = bp.pass_lg;
+            if constexpr (!DEAL)  // nobody loaded the wave's first cut words ahead of time (the fused kernel does)
+                first_cuts = p_end > p_begin ? cutz[min(p_begin + (wave << lg) + lane, p_end - 1)] : 0u;
+            packed_stream_asm_dealt(sxy, coef4, cutz, band_bytes, p_begin, p_end, lg, wave, kWaves,
                                     lane, nx, Li, Ui, row_base, dummy_eo, s_pass, first_cuts);
+        }
         else
             packed_stream_asm(sxy, coef4, cutz, band_bytes, p_begin + wave * group, p_end, lg_group,
                               kWaves * group, lane, nx, Li, Ui, row_base, dummy_eo);
@@ -2388,7 +2398,9 @@ __global__ __launch_bounds__(1024) void k_vote_fuse_argmax(FusedCameras cams, Ge
         const FusedCamera& cam = cams.cam[c];
         if (cam.np <= 0) return 0u;
         const int j = q / g.nz, z = q - j * g.nz;
-        const int lg = bp.pass_lg > 0 ? bp.pass_lg : 2;
+        int lg = 2;  // (the rule of stream_item's dealt stream)
+        while (lg < 5 && cam.np >= (((BLOCK / kWave) * 16) << (lg + 1))) ++lg;
+        if (bp.pass_lg > 0) lg = bp.pass_lg;
         const int p = min((int)((threadIdx.x / kWave) << lg) + (int)(threadIdx.x & 63), cam.np - 1);
         return cam.cuts[((size_t)j * g.nz + z) * cam.np + p];
     };
@@ -3633,6 +3645,7 @@ static hipError_t launch_vote_bands_b(hipStream_t s, const EvRec* sxy, const Pla
     case 3: return launch_vote_bands_t<BLOCK, 3>(s, sxy, coef, cuts, slow_any, np, g, bp, out, seam);
     case 5: return launch_vote_bands_t<BLOCK, 5>(s, sxy, coef, cuts, slow_any, np, g, bp, out, seam);
     case 6: return launch_vote_bands_t<BLOCK, 6>(s, sxy, coef, cuts, slow_any, np, g, bp, out, seam);
+    case 7: return launch_vote_bands_t<BLOCK, 7>(s, sxy, coef, cuts, slow_any, np, g, bp, out, seam);
     default: return hipErrorInvalidValue;
     }
 }

@@ -255,13 +255,15 @@ DSI_API int dsi_mapper_set_vote_algo(dsi_mapper_t *m, int algo);
 DSI_API int dsi_mapper_set_band_params(dsi_mapper_t *m, int band_rows, int chunks, int block_threads);
 /* DSI_VOTE_LDS_BANDS has two lane mappings: one packet's run per wave pass (long runs) or the
  * runs of 64 packets packed back to back into the lanes (short runs: wide / tall grids).
- * mode -1 = automatic (by expected run length), 0 = per packet, 1 = packed,
+ * mode -1 = automatic (by expected run length: 7 or 5), 0 = per packet, 1 = packed,
  * 2 = groups of consecutive packets sorted together (one long run per group),
  * 3 = packed with the compiled (not hand-scheduled) wave loop, for A/B tests,
  * 4 = groups with the hand-scheduled wave loop (long runs for wide grids),
  * 5 = packed with a vector (prefix-sum + tail-bit) slot -> record mapping instead of the scalar run
  *     bookkeeping (short runs: wide grids), hand-scheduled batches,
- * 6 = mapping 5 all compiled, for A/B tests. */
+ * 6 = mapping 5 all compiled, for A/B tests,
+ * 7 = mapping 1 with DEALT passes: the waves of a workgroup draw their passes from a counter instead of taking
+ *     every 16th one (the automatic choice wherever mapping 1 used to be chosen). */
 DSI_API int dsi_mapper_set_packed_lanes(dsi_mapper_t *m, int mode);
 
 /* MapperEMVS::fillVoxelGrid(event_locations_z0, camera_centers)

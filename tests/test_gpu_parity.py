@@ -748,7 +748,7 @@ def test_fuse_into_equals_reference_sequence(ctx):
         A.setToFusionOf(A, G, 2)
 
 
-@pytest.mark.parametrize("packed", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("packed", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("shape,band", [((64, 48, 16), None), ((346, 260, 12), (26, 4, 1024)),
                                         ((130, 97, 7), (5, 3, 256)), ((70, 48, 9), (48, 2, 512)),
                                         ((40, 30, 6), (9, 2, 256))])
@@ -772,7 +772,7 @@ def test_both_lane_mappings_match_oracle(ctx, shape, band, packed):
     m.close()
 
 
-@pytest.mark.parametrize("packed", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("packed", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("n_pixels", [1, 7, 300, 5000])
 def test_duplicate_events_in_a_packet(ctx, packed, n_pixels):
     """Events of a packet drawn from a few pixels (hot pixels, bursts): the packet sort merges
@@ -864,7 +864,7 @@ def test_hand_scheduled_loops_equal_the_compiled_loop_bit_for_bit(ctx, seed):
     # every voxel is fl(exact 64-bit sum) whatever the lane mapping, band height or packet chunking (round 3: the
     # chunks' partial volumes are raw 64-bit sums), so ALL seven mappings give the same bits -- the grouped
     # mappings 2 / 4 too, although they cut the packets into chunks at other places
-    for packed in (3, 1, 0, 5, 6, 2, 4):
+    for packed in (3, 1, 7, 0, 5, 6, 2, 4):
         m = make_mapper(ctx, cam, nz, 0.8, m_max, d.VOTE_LDS_BANDS, band=band, packed=packed)
         m.fillVoxelGrid(xy, centers)
         got = m.dsi_.download()
