@@ -375,7 +375,9 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
         // below ~8 M events one chunk is faster when the planes alone fill the chip 1.5 times: no
         // partial volumes to write and reduce, fewer workgroup set-ups (measured at 346x260x100:
         // 1.85x at 0.1 M events, 1.25x at 1 M, 1.03x at 5 M, 0.99x at 10 M)
-        if ((long)bands * g.nz >= 768 && n_packets < 8192) chunks = 1;
+        // (round 3, dealt passes + raw partial volumes: one chunk also at 10 M events -- 346x260x100, same box,
+        //  1 / 2 / 3 / 4 chunks: 2.633 / 2.675 / 2.717 / 2.751 ms per step)
+        if ((long)bands * g.nz >= 768) chunks = 1;
         // keep (chunks * bands) a multiple of 8 so that all XCDs get the same number of pairs
         int step = 8;
         for (int f = 2; f <= 8; f *= 2)
