@@ -690,6 +690,39 @@ __device__ __forceinline__ acc_t* seam_rows(acc_t* seam, int c, int z, int j, co
 // accumulation) or, raw != 0, the chunk's PARTIAL volume of raw 64-bit sums, which k_reduce_partials adds up
 // exactly over the chunks before the one rounding to fp32: the DSI is fl(exact sum of all votes) for any
 // number of chunks as well.
+// Work item b -> (pair q = (chunk, band), plane z); false: the block has nothing to do.
+// Block b runs on XCD b % 8 (observed dispatch rule).  Groups of 8 pairs: XCD x walks the planes of pair 8k + x, so
+// that pair's events stream through that XCD's L2 once instead of once per plane.  The pairs % 8 pairs left over:
+// 1, 2 or 4 of them share the XCDs evenly (8, 4 or 2 XCDs each, the planes dealt among those: their events
+// stream through 8 / L L2s); any other count is dealt plane by plane over all XCDs (round 2's rule for all).
+__device__ __forceinline__ bool item_of(int b, int pairs, int nz, int& q, int& z, bool spread_all = false)
+{
+    const int full_pairs = (pairs / 8) * 8, full = full_pairs * nz;
+    if (b < full) {
+        const int xcd = b & 7, s = b >> 3;
+        q = (s / nz) * 8 + xcd;
+        z = s % nz;
+        return true;
+    }
+    const int r = b - full, L = pairs - full_pairs;
+    if ((L == 1 || L == 2 || L == 4) && !spread_all) {  // (spread_all: round 2's rule, experiments builds only)
+        const int per = 8 / L, xcd = r & 7, s = r >> 3;  // (full is a multiple of 8: r & 7 == b & 7)
+        q = full_pairs + xcd / per;
+        z = s * per + xcd % per;
+        return z < nz;
+    }
+    q = full_pairs + r / nz;
+    z = r % nz;
+    return q < pairs;
+}
+
+__host__ __device__ inline int item_count(int pairs, int nz, bool spread_all = false)
+{
+    const int full_pairs = (pairs / 8) * 8, L = pairs - full_pairs;
+    if ((L == 1 || L == 2 || L == 4) && !spread_all) return full_pairs * nz + 8 * ((nz + 8 / L - 1) / (8 / L));
+    return pairs * nz;
+}
+
 template <int BLOCK, bool CLEAR>
 __device__ __forceinline__ void flush_band_t(acc_t* __restrict__ band, int nx, int n_out, void* __restrict__ out, size_t off,
                                              int raw, acc_t* __restrict__ seam_j, int j, int bands)
@@ -743,17 +776,8 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands(const EvRec* __restrict__ 
     // XCDs so that no XCD idles (their events then stream through every L2).
     const int b = blockIdx.x;
     const int pairs = bp.chunks * bp.bands;
-    const int full = (pairs / 8) * 8 * g.nz;
     int q, z;
-    if (b < full) {
-        const int xcd = b & 7, s = b >> 3;
-        q = (s / g.nz) * 8 + xcd;
-        z = s % g.nz;
-    } else {
-        const int r = b - full;
-        q = (pairs / 8) * 8 + r / g.nz;
-        z = r % g.nz;
-    }
+    if (!item_of(b, pairs, g.nz, q, z, bp.experiment == 200)) return;
     const int c = q / bp.bands, j = q % bp.bands;
     const int r0 = j * bp.band_rows;
     const int r1 = min(g.ny, r0 + bp.band_rows);
@@ -2161,8 +2185,7 @@ __device__ __forceinline__ void vote_bands_packed_body(const EvRec* __restrict__
     __shared__ int s_item;
     __shared__ int s_pass;  // mapping 5: the next pass of the item to hand out (vfill_stream_asm)
     const int pairs = bp.chunks * bp.bands;
-    const int full = (pairs / 8) * 8 * g.nz;
-    const int total = pairs * g.nz;
+    const int total = item_count(pairs, g.nz, bp.experiment == 200);
     const int nx = g.nx;
     // PERSISTENT workgroups (work_counters != nullptr): the grid is only as large as the chip holds
     // at once and every workgroup pulls work items until none is left -- a 1024-thread workgroup
@@ -2187,14 +2210,10 @@ __device__ __forceinline__ void vote_bands_packed_body(const EvRec* __restrict__
     const int b = work_counters ? s_item : (int)blockIdx.x;
     if (b >= total) break;
     int q, z;
-    if (b < full) {
-        const int xcd = b & 7, s = b >> 3;
-        q = (s / g.nz) * 8 + xcd;
-        z = s % g.nz;
-    } else {
-        const int r = b - full;
-        q = (pairs / 8) * 8 + r / g.nz;
-        z = r % g.nz;
+    if (!item_of(b, pairs, g.nz, q, z, bp.experiment == 200)) {  // (a leftover slot beyond the last plane)
+        if (!work_counters) break;
+        __syncthreads();  // every thread has read s_item before thread 0 draws again
+        continue;
     }
     const int c = q / bp.bands, j = q % bp.bands;
     const int r0 = j * bp.band_rows;
@@ -2649,17 +2668,8 @@ __global__ __launch_bounds__(BLOCK) void k_vote_groups(const EvRec* __restrict__
     extern __shared__ acc_t band[];
     const int b = blockIdx.x;
     const int pairs = bp.chunks * bp.bands;
-    const int full = (pairs / 8) * 8 * g.nz;
     int q, z;
-    if (b < full) {
-        const int xcd = b & 7, s = b >> 3;
-        q = (s / g.nz) * 8 + xcd;
-        z = s % g.nz;
-    } else {
-        const int r = b - full;
-        q = (pairs / 8) * 8 + r / g.nz;
-        z = r % g.nz;
-    }
+    if (!item_of(b, pairs, g.nz, q, z, bp.experiment == 200)) return;
     const int c = q / bp.bands, j = q % bp.bands;
     const int r0 = j * bp.band_rows;
     const int r1 = min(g.ny, r0 + bp.band_rows);
@@ -3608,7 +3618,7 @@ static hipError_t launch_vote_bands_t(hipStream_t s, const EvRec* sxy, const Pla
                      : PACKED ? reinterpret_cast<const void*>(&k_vote_bands_packed<BLOCK, (PACKED && !VFILL ? MAPPING : 1)>)
                               : reinterpret_cast<const void*>(&k_vote_bands<BLOCK>);
     if (hipError_t e = allow_dynamic_lds(kern, bp.lds_bytes)) return e;
-    unsigned blocks = (unsigned)(bp.chunks * bp.bands) * (unsigned)g.nz;
+    unsigned blocks = (unsigned)item_count(bp.chunks * bp.bands, g.nz, bp.experiment == 200);
     uint32_t* counters = nullptr;
     if (PACKED && bp.persistent) {
         // as many workgroups as are resident at once: per CU, what the LDS and the 2048-thread limit allow
@@ -3786,7 +3796,7 @@ static hipError_t launch_vote_groups_t(hipStream_t s, const EvRec* sxy, const ui
     if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_vote_groups<BLOCK>), bp.lds_bytes))
         return e;
     const int ngroups = (np + S - 1) / S;
-    const unsigned blocks = (unsigned)(bp.chunks * bp.bands) * (unsigned)g.nz;
+    const unsigned blocks = (unsigned)item_count(bp.chunks * bp.bands, g.nz, bp.experiment == 200);
     hipLaunchKernelGGL(k_vote_groups<BLOCK>, dim3(blocks), dim3(BLOCK), bp.lds_bytes, s, sxy, spk,
                        coef, gcuts, slow_any, np, ngroups, S, g, bp, out, seam);
     return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
