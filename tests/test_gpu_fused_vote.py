@@ -171,6 +171,39 @@ def test_fused_with_slow_planes_unequal_cameras_and_a_lut(ctx, packed):
         o.close()
 
 
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_fused_fuzz_over_shapes_bands_and_mappings(ctx, seed):
+    """Random grids (odd widths, one-row bands, a single plane, 256 planes, more rows than events), band heights,
+    lane mappings, fusion ops and event counts: the fused kernel always gives the bits of vote -> fuse -> collapse."""
+    rng = np.random.default_rng(900 + seed)
+    nx = int(rng.choice([2, 3, 17, 64, 129, 346, 700]))
+    ny = int(rng.choice([2, 5, 48, 97, 260]))
+    nz = int(rng.choice([1, 2, 7, 33, 256]))
+    if nx * ny * nz > 6_000_000:
+        nz = 7
+    n_ev = int(rng.choice([1025, 3000, 20_000, 70_000]))
+    rig = syn.stereo_rig(n_ev, width=max(nx, 8), height=max(ny, 8), duration=0.2, seed=50 + seed, n_points=300)
+    shape = d.ShapeDSI(nx, ny, nz, 2.0, float(rng.uniform(20.0, 200.0)), float(rng.choice([0.0, 60.0])))
+    packed = int(rng.choice([-1, 1, 3, 5, 6]))
+    band_rows = int(rng.choice([0, 1, 2, 3, 9, 40]))
+    op = int(rng.integers(1, 7))
+    batches = rig_batches(ctx, rig)
+    ref_m = [d.MapperEMVS(ctx, rig["cam"], shape) for _ in range(2)]
+    fus_m = [d.MapperEMVS(ctx, rig["cam"], shape) for _ in range(2)]
+    for m in fus_m:
+        m.set_packed_lanes(packed)
+        if band_rows:
+            m.set_band_params(band_rows, 0, 0)
+    want = unfused(ctx, ref_m, batches, op)
+    fus_m[0].computeDepthMapOfEvents(fus_m, batches, op)
+    got = fus_m[0].fetchDepthMap()
+    for g, w, name in zip(got, want, ("depth", "confidence", "index")):
+        assert np.array_equal(g, w), "seed %d (%dx%dx%d, %d events, mapping %d, band %d, op %d): %s differs at %d pixels" % (
+            seed, nx, ny, nz, n_ev, packed, band_rows, op, name, (g != w).sum())
+    for o in ref_m + fus_m + batches:
+        o.close()
+
+
 def test_fused_rejects_bad_arguments(ctx):
     rig = syn.stereo_rig(5_000, width=64, height=48, duration=0.1, seed=1)
     a = d.MapperEMVS(ctx, rig["cam"], d.ShapeDSI(0, 0, 8, 4.0, 100.0, 0.0))
