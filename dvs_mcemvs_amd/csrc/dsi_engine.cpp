@@ -1673,21 +1673,28 @@ int dsi_mapper_vote_kernel_time(dsi_mapper_t* m, float* total_ms, int* launches)
     return DSI_OK;
 }
 
-int dsi_mapper_get_depth_map_from_dsi(dsi_mapper_t* m, dsi_grid_t* g, const dsi_depthmap_options_t* opts,
-                                      float* depth_host, float* conf_host, uint8_t* mask_host,
-                                      uint8_t* idx_filtered_host)
+static int check_depthmap_options(const dsi_depthmap_options_t* opts)
 {
-    REQUIRE(m && opts, DSI_ERR_INVALID, "null argument");
     REQUIRE(opts->adaptive_threshold_kernel_size >= 1 && (opts->adaptive_threshold_kernel_size & 1) &&
                 opts->adaptive_threshold_kernel_size <= 63,
             DSI_ERR_INVALID, "adaptive_threshold_kernel_size must be odd and in 1..63");
     REQUIRE(opts->median_filter_size >= 1 && (opts->median_filter_size & 1) && opts->median_filter_size <= 31,
             DSI_ERR_INVALID, "median_filter_size must be odd and in 1..31 (median_filtering.cpp:44)");
-    if (!g) g = m->grid;
-    if (int rc = dsi_mapper_depth_map_of(m, g)) return rc;  // collapseMaxZSlice, :368 (acquires the buffers)
+    return DSI_OK;
+}
+
+int dsi_mapper_filter_depth_map(dsi_mapper_t* m, const dsi_depthmap_options_t* opts, float* depth_host,
+                                float* conf_host, uint8_t* mask_host, uint8_t* idx_filtered_host)
+{
+    REQUIRE(m && opts, DSI_ERR_INVALID, "null argument");
+    if (int rc = check_depthmap_options(opts)) return rc;
+    REQUIRE(m->depth_valid, DSI_ERR_INVALID,
+            "no raw depth map on this mapper: call one of dsi_mapper_depth_map_of* first (a filtered map "
+            "cannot be filtered again: the confidence image was normalised in place)");
     dsi_context* ctx = m->ctx;
     const int nx = m->geom.nx, ny = m->geom.ny;
     const size_t npix = (size_t)nx * ny;
+    if (int rc = depth_buffers_acquire(m)) return rc;  // an asynchronous fetch of the raw map may be reading them
     HIP_TRY(m->conf8.reserve(npix));
     HIP_TRY(m->mask.reserve(npix));
     HIP_TRY(m->idx_filtered.reserve(npix));
@@ -1706,6 +1713,17 @@ int dsi_mapper_get_depth_map_from_dsi(dsi_mapper_t* m, dsi_grid_t* g, const dsi_
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     m->depth_valid = false;  // m->depth now holds the filtered map, m->conf has (0,0) overwritten
     return DSI_OK;
+}
+
+int dsi_mapper_get_depth_map_from_dsi(dsi_mapper_t* m, dsi_grid_t* g, const dsi_depthmap_options_t* opts,
+                                      float* depth_host, float* conf_host, uint8_t* mask_host,
+                                      uint8_t* idx_filtered_host)
+{
+    REQUIRE(m && opts, DSI_ERR_INVALID, "null argument");
+    if (int rc = check_depthmap_options(opts)) return rc;
+    if (!g) g = m->grid;
+    if (int rc = dsi_mapper_depth_map_of(m, g)) return rc;  // collapseMaxZSlice, :368 (acquires the buffers)
+    return dsi_mapper_filter_depth_map(m, opts, depth_host, conf_host, mask_host, idx_filtered_host);
 }
 
 int dsi_mapper_last_vote_info(const dsi_mapper_t* m, dsi_vote_info_t* info)

@@ -147,6 +147,7 @@ def load_library():
         "dsi_mapper_depth_map_of_events": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int]),
         "dsi_mapper_get_depth_map_from_dsi": (C.c_int, [vp, vp, C.POINTER(_DepthMapOptions), f32p, f32p,
                                                        u8p, u8p]),
+        "dsi_mapper_filter_depth_map": (C.c_int, [vp, C.POINTER(_DepthMapOptions), f32p, f32p, u8p, u8p]),
         "dsi_mapper_last_vote_info": (C.c_int, [vp, C.POINTER(_VoteInfo)]),
         "dsi_mapper_set_kernel_timing": (C.c_int, [vp, C.c_int]),
         "dsi_mapper_vote_kernel_time": (C.c_int, [vp, f32p, intp]),
@@ -746,6 +747,23 @@ class MapperEMVS:
             return depth, conf, mask
         _check(L.dsi_mapper_depth_map_of(self._h, (grid or self.dsi_)._h))
         return self.fetchDepthMap()
+
+    def filterDepthMap(self, options_depth_map):
+        """mapper_emvs_stereo.cpp:390-437 -- everything getDepthMapFromDSI does after
+        collapseMaxZSlice -- on the raw depth map this mapper holds from the last computeDepthMap /
+        computeDepthMapOfFusion / computeDepthMapOfEvents call: (depth_map, confidence_map, mask).
+        The way to the reference's filtered per-window outputs when no DSI is materialised."""
+        o = options_depth_map
+        opts = _DepthMapOptions(o.adaptive_threshold_kernel_size_, o.adaptive_threshold_c_,
+                                o.median_filter_size_, o.max_confidence)
+        depth = np.empty((self.dimY, self.dimX), np.float32)
+        conf = np.empty((self.dimY, self.dimX), np.float32)
+        mask = np.empty((self.dimY, self.dimX), np.uint8)
+        self.depth_cell_indices_filtered = np.empty((self.dimY, self.dimX), np.uint8)
+        _check(load_library().dsi_mapper_filter_depth_map(
+            self._h, C.byref(opts), _ptr(depth, C.c_float), _ptr(conf, C.c_float), _ptr(mask, C.c_uint8),
+            _ptr(self.depth_cell_indices_filtered, C.c_uint8)))
+        return depth, conf, mask
 
     def computeDepthMap(self, grid=None):
         """Asynchronous half of getDepthMapFromDSI; pair with fetchDepthMap()."""

@@ -283,8 +283,14 @@ class WindowStream:
         self.k += 1
         return slot
 
-    def fetch(self, slot):
-        """(depth, confidence, indices) of the window submitted into `slot` (synchronises)."""
+    def fetch(self, slot, options_depth_map=None):
+        """(depth, confidence, indices) of the window submitted into `slot` (synchronises).  With
+        options_depth_map (OptionsDepthMap): the reference's per-window outputs instead --
+        (depth_map, confidence_map, mask) after the adaptive threshold, masked median and border removal
+        of getDepthMapFromDSI (main.cpp:281 -> mapper_emvs_stereo.cpp:390-437), whichever way the
+        window's arg-max was produced."""
+        if options_depth_map is not None:
+            return self.extract[slot].filterDepthMap(options_depth_map)
         return self.extract[slot].fetchDepthMap()
 
     def fused_grid(self, slot):
@@ -307,9 +313,10 @@ class WindowStream:
 
 
 def full_sequence(ctx, cams, dsi_shape, events, trajectories, start_time_s, stop_time_s, duration,
-                  out_skip, fusion_method=E.FUSE_HM, forward_looking=True, rv_pos=0.0, **kw):
+                  out_skip, fusion_method=E.FUSE_HM, forward_looking=True, rv_pos=0.0, options_depth_map=None, **kw):
     """Generator over the windows of main.cpp:177-302: yields (ts, depth, confidence, indices) per
-    window, pipelined one window deep."""
+    window, pipelined one window deep; with options_depth_map, (ts, depth_map, confidence_map, mask)
+    -- the filtered outputs the reference saves per window."""
     ws = WindowStream(ctx, cams, dsi_shape, fusion_method, **kw)
     pending = None
     try:
@@ -318,9 +325,9 @@ def full_sequence(ctx, cams, dsi_shape, events, trajectories, start_time_s, stop
             ev = [window_events(events[c], t0, t1) for c in range(2)]
             slot = ws.submit(ev, trajectories, ts, rv_pos)
             if pending is not None:
-                yield (pending[0],) + ws.fetch(pending[1])
+                yield (pending[0],) + ws.fetch(pending[1], options_depth_map)
             pending = (ts, slot)
         if pending is not None:
-            yield (pending[0],) + ws.fetch(pending[1])
+            yield (pending[0],) + ws.fetch(pending[1], options_depth_map)
     finally:
         ws.close()

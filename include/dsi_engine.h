@@ -409,6 +409,17 @@ DSI_API int dsi_mapper_get_depth_map_from_dsi(dsi_mapper_t *m, dsi_grid_t *g, co
                                       float *depth_host, float *conf_host, uint8_t *mask_host,
                                       uint8_t *idx_filtered_host);
 
+/* The part of getDepthMapFromDSI after collapseMaxZSlice (mapper_emvs_stereo.cpp:390-437), applied to
+ * the raw depth map this mapper holds on the device -- the result of the last
+ * dsi_mapper_depth_map_of / _of_fusion / _of_fusion_n / _of_events call.  This is how a window loop
+ * that never materialises a DSI (dsi_mapper_depth_map_of_events, mode DSI_VOTE_FUSED_ARGMAX) obtains
+ * the reference's filtered per-window outputs (main.cpp:177-302 calls getDepthMapFromDSI on the fused
+ * DSI).  Same outputs and bits as dsi_mapper_get_depth_map_from_dsi on the same arg-max.  The raw map
+ * is consumed (confidence normalised in place): DSI_ERR_INVALID if there is none, or on a second
+ * call.  Synchronises. */
+DSI_API int dsi_mapper_filter_depth_map(dsi_mapper_t *m, const dsi_depthmap_options_t *opts, float *depth_host,
+                                        float *conf_host, uint8_t *mask_host, uint8_t *idx_filtered_host);
+
 /* HIP-event stopwatch around the voting kernel (the replacement of fillVoxelGrid's hot
  * loop, mapper_emvs_stereo.cpp:168-203) on the context's stream: enable, run any number of
  * evaluate/fill calls, then read the summed kernel time and launch count (synchronises and

@@ -524,6 +524,26 @@ public:
                                                      confidence_map.data.data(), mask.data.data(), nullptr));
     }
 
+    // The filters of getDepthMapFromDSI (mapper_emvs_stereo.cpp:390-437) on the raw depth map this mapper already
+    // holds on the device -- after dsi::process_1_depth_map, which votes, fuses and takes the arg-max without ever
+    // writing the DSI the reference would call getDepthMapFromDSI on.  Same outputs as the overload above.
+    void filterDepthMap(dsi::Image<float>& depth_map, dsi::Image<float>& confidence_map, dsi::Image<uint8_t>& mask,
+                        const OptionsDepthMap& options_depth_map)
+    {
+        int nx, ny, nz;
+        dsi_.getDimensions(&nx, &ny, &nz);
+        depth_map = dsi::Image<float>(ny, nx);
+        confidence_map = dsi::Image<float>(ny, nx);
+        mask = dsi::Image<uint8_t>(ny, nx);
+        dsi_depthmap_options_t o{};
+        o.adaptive_threshold_kernel_size = options_depth_map.adaptive_threshold_kernel_size_;
+        o.adaptive_threshold_c = options_depth_map.adaptive_threshold_c_;
+        o.median_filter_size = options_depth_map.median_filter_size_;
+        o.max_confidence = options_depth_map.max_confidence;
+        dsi::check(dsi_mapper_filter_depth_map(h_, &o, depth_map.data.data(), confidence_map.data.data(),
+                                               mask.data.data(), nullptr));
+    }
+
     std::vector<float> depthPlanes() const
     {
         int nz = 0;

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <memory>
 #include <vector>
 
@@ -242,6 +243,19 @@ int main()
                 if (d1.data != d2.data || c1.data != c2.data || i1.data != i2.data) {
                     std::printf("process_1_depth_map differs for fusion method %d\n", method);
                     return 64;
+                }
+                // main.cpp:281: the window ends in getDepthMapFromDSI(depth, confidence, mask, options); after
+                // process_1_depth_map there is no DSI, filterDepthMap runs the same filters on the device-held arg-max
+                EMVS::OptionsDepthMap opts;
+                dsi::Image<float> fd1, fc1, fd2, fc2;
+                dsi::Image<uint8_t> m1, m2;
+                mapper_fused.getDepthMapFromDSI(fd1, fc1, m1, opts);   // process_1 left the fused DSI in mapper_fused
+                process_1_depth_map(trajectory0, trajectory1, events0, events1, cam_a, mapper0, mapper1, 0.5, method, d2, c2, i2);
+                cam_a.filterDepthMap(fd2, fc2, m2, opts);
+                if (std::memcmp(fd1.data.data(), fd2.data.data(), fd1.data.size() * sizeof(float)) != 0 ||
+                    fc1.data != fc2.data || m1.data != m2.data) {
+                    std::printf("filterDepthMap differs for fusion method %d\n", method);
+                    return 65;
                 }
             }
             try {

@@ -272,3 +272,36 @@ def test_window_stream_fused_vote_is_bit_identical(ctx):
     assert info["algo"] == d.VOTE_FUSED_ARGMAX and info["bands"] == 14 and info["band_rows"] == 37
     a.close()
     b.close()
+
+
+def test_window_stream_filtered_outputs_without_a_dsi(ctx):
+    """main.cpp:281: every window ends in getDepthMapFromDSI(depth, confidence, mask, options).  The
+    fused-vote stream has no DSI to hand to it; fetch(slot, options) applies the same filters
+    (mapper_emvs_stereo.cpp:390-437) to the arg-max the fused kernel produced -- identical to
+    getDepthMapFromDSI on the materialised fused DSI, for the concurrent stream too."""
+    NX, NY, NZ, EV, DUR, NWIN = 346, 260, 100, 120_000, 0.05, 3
+    t0 = 3.0
+    rig = syn.stereo_rig(NWIN * EV, width=346, height=260, t0=t0, duration=NWIN * DUR, seed=5, n_points=3000)
+    shape = d.ShapeDSI(NX, NY, NZ, 4.0, 120.0, 0.0)
+    opts = d.OptionsDepthMap()
+    opts.max_confidence = 0
+    bounds = proc.window_bounds(t0, t0 + NWIN * DUR + 1e-9, DUR, DUR)
+    a = proc.WindowStream(ctx, (rig["cam"],) * 2, shape, d.FUSE_HM)
+    streams = [proc.WindowStream(ctx, (rig["cam"],) * 2, shape, d.FUSE_HM, fused_vote=True, concurrent=conc)
+               for conc in (False, True)]
+    for (lo, hi) in bounds:
+        ev = [proc.window_events(rig["events"][c], lo, hi) for c in range(2)]
+        slot = a.submit(ev, rig["trajectories"], hi)
+        want = a.extract[slot].getDepthMapFromDSI(a.fused_grid(slot), opts)
+        assert want[2].sum() > 100                      # the mask keeps something
+        for b in streams:
+            got = b.fetch(b.submit(ev, rig["trajectories"], hi), opts)
+            for g, w, name in zip(got, want, ("depth", "confidence", "mask")):
+                assert np.array_equal(g, w, equal_nan=True), "%s differs at %d pixels" % (name, (g != w).sum())
+    # the raw map was consumed by the filters: a second pass has nothing to work on
+    with pytest.raises(d.DsiError) as e:
+        streams[0].extract[(streams[0].k - 1) % 2].filterDepthMap(opts)
+    assert e.value.code == engine.ERR_INVALID
+    a.close()
+    for b in streams:
+        b.close()
