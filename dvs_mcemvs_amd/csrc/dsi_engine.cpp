@@ -217,6 +217,7 @@ struct dsi_mapper {
     DevBuf<uint8_t> idx, conf8, mask, idx_filtered;
     DevBuf<uint32_t> minmax;
     bool depth_valid = false;
+    bool fused_keys_dirty = false;  // the fused kernel may have written keys that no unpack cleared
     // The depth map leaves the device on the context's COPY stream, so that fetching window w's map
     // does not queue behind window w+1's kernels on the compute stream: "ready" (compute stream, after
     // the arg-max) gates the copies, "read" (copy stream, after them) gates the next arg-max into the
@@ -1565,7 +1566,7 @@ int dsi_mapper_depth_map_of_events(dsi_mapper_t* out, dsi_mapper_t* const* mappe
         }
         prep[i] = dsi::PrepCameraArgs{b->Rt, b->x, b->y, b->first, m->lut_dev, m->sensor_w, m->sensor_h, m->centers.p, (int)np,
                                       m->sxy.p, m->nvalid.p, m->rowstart.p, m->planes_dev, m->coef.p, m->cuts.p,
-                                      balance ? m->pair_work.p : nullptr};
+                                      balance ? m->pair_work.p : nullptr, m->geom};
         cams.cam[i] = dsi::FusedCamera{m->sxy.p, m->coef.p, m->cuts.p, m->nvalid.p + np, (int)np};
         m->info = dsi_vote_info_t{};
         m->info.algo = DSI_VOTE_FUSED_ARGMAX;
@@ -1596,10 +1597,12 @@ int dsi_mapper_depth_map_of_events(dsi_mapper_t* out, dsi_mapper_t* const* mappe
     HIP_TRY(out->idx.reserve(npix));
     if (int rc = depth_buffers_acquire(out)) return rc;
     // one key per pixel, zero before the kernel: zeroed once when (re)allocated, then by every unpack
-    if (out->fused_keys.cap < npix) {
+    // (or after a call that failed between the voting kernel and the unpack)
+    if (out->fused_keys.cap < npix || out->fused_keys_dirty) {
         HIP_TRY(out->fused_keys.reserve(npix));
         HIP_TRY(hipMemsetAsync(out->fused_keys.p, 0, out->fused_keys.cap * sizeof(unsigned long long), st));
     }
+    out->fused_keys_dirty = true;
     {
         VoteTimer vt(mappers[0]);
         HIP_TRY(dsi::launch_vote_fuse_argmax(st, cams, geom, bp, op, splits, out->fused_keys.p,
@@ -1607,8 +1610,9 @@ int dsi_mapper_depth_map_of_events(dsi_mapper_t* out, dsi_mapper_t* const* mappe
         vt.stop();
     }
     // keys -> confidence, index, depth over the planes the cameras voted (mapper_emvs_stereo.cpp:302-313)
-    HIP_TRY(dsi::launch_unpack_argmax(st, out->fused_keys.p, (int)npix, mappers[0]->planes_dev, out->conf.p, out->idx.p,
+    HIP_TRY(dsi::launch_unpack_argmax(st, out->fused_keys.p, (int)npix, out->planes_dev, out->conf.p, out->idx.p,
                                       out->depth.p, /*clear=*/1));
+    out->fused_keys_dirty = false;
     return depth_buffers_ready(out);
 }
 
@@ -1694,6 +1698,7 @@ int dsi_mapper_filter_depth_map(dsi_mapper_t* m, const dsi_depthmap_options_t* o
     dsi_context* ctx = m->ctx;
     const int nx = m->geom.nx, ny = m->geom.ny;
     const size_t npix = (size_t)nx * ny;
+    if (int rc = set_device(ctx)) return rc;
     if (int rc = depth_buffers_acquire(m)) return rc;  // an asynchronous fetch of the raw map may be reading them
     HIP_TRY(m->conf8.reserve(npix));
     HIP_TRY(m->mask.reserve(npix));

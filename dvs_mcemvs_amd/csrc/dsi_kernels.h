@@ -138,6 +138,8 @@ struct PrepCameraArgs {
     PlaneCoef* coef;
     uint32_t* cuts;
     uint32_t* pair_work;  // [bands * nz] or nullptr
+    Geom g;               // this camera's own intrinsics, virtual camera and z0 (process1.cpp:73-110: one mapper
+                          // per camera, each built from its own calibration); nx, ny, nz equal for all cameras
 };
 hipError_t launch_prepare_cameras(hipStream_t s, const PrepCameraArgs* cams, int n, const Geom& g, const BandPlan& bp);
 // splits[fused_grid_blocks() + 1] <- cuts of the pair list into stretches of equal cost (records + fixed_per_pair

@@ -612,13 +612,13 @@ __global__ __launch_bounds__(1024) void k_plane_coef(const float* __restrict__ c
 
 // the coefficient / cut tables of up to two cameras in one launch; camera 1's blocks start at blocks0
 template <bool STAGED>
-__global__ __launch_bounds__(1024) void k_plane_coef_multi(PrepCameras cams, Geom g, BandPlan bp, unsigned blocks0)
+__global__ __launch_bounds__(1024) void k_plane_coef_multi(PrepCameras cams, BandPlan bp, unsigned blocks0)
 {
     unsigned bid = blockIdx.x;
     const int c = (cams.n > 1 && bid >= blocks0) ? 1 : 0;
     if (c) bid -= blocks0;
     const PrepCamera& pc = cams.cam[c];
-    plane_coef_body<STAGED>(bid, pc.raw.centers, pc.planes, pc.rowstart, pc.nvalid, pc.np, g, bp, pc.coef, pc.cuts, pc.pair_work);
+    plane_coef_body<STAGED>(bid, pc.raw.centers, pc.planes, pc.rowstart, pc.nvalid, pc.np, pc.raw.g, bp, pc.coef, pc.cuts, pc.pair_work);
 }
 
 // (3) the voting kernel.  Work item = (packet chunk c, band j, plane z): the band's
@@ -3683,7 +3683,7 @@ hipError_t launch_prepare_cameras(hipStream_t s, const PrepCameraArgs* args, int
     cams.n = n;
     for (int c = 0; c < n; ++c) {
         const PrepCameraArgs& a = args[c];
-        cams.cam[c].raw = RawEvents{a.Rt, a.ex, a.ey, a.packet_first, a.lut, a.sensor_w, a.sensor_h, g, a.centers, 0};
+        cams.cam[c].raw = RawEvents{a.Rt, a.ex, a.ey, a.packet_first, a.lut, a.sensor_w, a.sensor_h, a.g, a.centers, 0};
         cams.cam[c].np = a.np;
         cams.cam[c].sxy = a.sxy;
         cams.cam[c].nvalid = a.nvalid;
@@ -3711,9 +3711,9 @@ hipError_t launch_prepare_cameras(hipStream_t s, const PrepCameraArgs* args, int
     }
     if (staged) {
         if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_plane_coef_multi<true>), table_bytes)) return e;
-        hipLaunchKernelGGL(k_plane_coef_multi<true>, dim3(blocks[0] + blocks[1]), dim3(1024), table_bytes, s, cams, g, bp, blocks[0]);
+        hipLaunchKernelGGL(k_plane_coef_multi<true>, dim3(blocks[0] + blocks[1]), dim3(1024), table_bytes, s, cams, bp, blocks[0]);
     } else {
-        hipLaunchKernelGGL(k_plane_coef_multi<false>, dim3(blocks[0] + blocks[1]), dim3(256), 0, s, cams, g, bp, blocks[0]);
+        hipLaunchKernelGGL(k_plane_coef_multi<false>, dim3(blocks[0] + blocks[1]), dim3(256), 0, s, cams, bp, blocks[0]);
     }
     return hipExtGetLastError();
 }

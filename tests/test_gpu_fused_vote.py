@@ -305,3 +305,35 @@ def test_window_stream_filtered_outputs_without_a_dsi(ctx):
     a.close()
     for b in streams:
         b.close()
+
+
+def test_fused_cameras_with_their_own_calibration(ctx):
+    """process1.cpp:73-110 builds one mapper per camera from that camera's own calibration: sensor intrinsics K_
+    (mapper_emvs_stereo.cpp:46-48), the virtual camera derived from its fx (:219-239), its LUT, its depth planes.
+    The fused call takes all of that per camera -- not from camera 0 -- and converts indices to depths with the
+    OUTPUT mapper's planes, like mapper_fused.getDepthMapFromDSI does."""
+    nx, ny, nz = 160, 120, 40
+    rig = syn.stereo_rig(60_000, width=nx, height=ny, duration=0.3, seed=9, n_points=900)
+    w, h, fx, fy, cx, cy = rig["cam"]
+    cams = [rig["cam"], (w, h, fx * 1.04, fy * 0.97, cx + 3.5, cy - 2.25)]
+    shapes = [d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0), d.ShapeDSI(0, 0, nz, 3.0, 120.0, 0.0)]   # own z0 and planes too
+    out_shape = d.ShapeDSI(0, 0, nz, 5.0, 90.0, 0.0)
+    batches = rig_batches(ctx, rig)
+    mk = lambda: [d.MapperEMVS(ctx, cams[c], shapes[c]) for c in range(2)] + [d.MapperEMVS(ctx, cams[0], out_shape)]
+    ref_m, fus_m = mk(), mk()
+    for op in (d.FUSE_HM, d.FUSE_MIN, d.FUSE_AM):
+        for m, b in zip(ref_m[:2], batches):
+            m.evaluateDSI_batch(b)
+        ref_m[2].computeDepthMapOfFusion(ref_m[0].dsi_, ref_m[1].dsi_, op)
+        want = ref_m[2].fetchDepthMap()
+        fus_m[2].computeDepthMapOfEvents(fus_m[:2], batches, op)
+        got = fus_m[2].fetchDepthMap()
+        for g, w_, name in zip(got, want, ("depth", "confidence", "index")):
+            assert np.array_equal(g, w_), "op %d: %s differs at %d pixels" % (op, name, (g != w_).sum())
+        assert want[1].max() > 1.0
+    # and the calibration matters: camera 1 voted with camera 0's intrinsics gives another map
+    same = [d.MapperEMVS(ctx, cams[0], shapes[c]) for c in range(2)]
+    fus_m[2].computeDepthMapOfEvents(same, batches, d.FUSE_AM)
+    assert not np.array_equal(fus_m[2].fetchDepthMap()[1], want[1])
+    for o in ref_m + fus_m + same + batches:
+        o.close()

@@ -1,3 +1,3 @@
 #!/bin/bash
 cd "$(dirname "$0")/../.."
-timeout 900 python -m pytest tests/test_gpu_fused_vote.py tests/test_cpp_adapter.py tests/test_depthmap_filters.py tests/test_gpu_process.py -m gpu -x -q 2>&1 | tail -8
+timeout 900 python -m pytest tests/test_gpu_fused_vote.py tests/test_cpp_adapter.py tests/test_gpu_process.py -m gpu -x -q 2>&1 | tail -12
