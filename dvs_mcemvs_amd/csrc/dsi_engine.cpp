@@ -1523,7 +1523,7 @@ int dsi_mapper_depth_map_of_events(dsi_mapper_t* out, dsi_mapper_t* const* mappe
                                    int op)
 {
     REQUIRE(out && mappers && batches, DSI_ERR_INVALID, "null argument");
-    REQUIRE(n == 1 || n == 2, DSI_ERR_INVALID, "1 or 2 cameras (got %d)", n);
+    REQUIRE(n >= 1 && n <= dsi::kFusedMaxCameras, DSI_ERR_INVALID, "1, 2 or 3 cameras (got %d)", n);
     REQUIRE(n == 1 || (op >= 1 && op <= 6), DSI_ERR_BAD_OP, "improper fusion method %d (expected 1..6)", op);
     dsi_context* ctx = out->ctx;
     size_t np_max = 0;
@@ -1532,9 +1532,13 @@ int dsi_mapper_depth_map_of_events(dsi_mapper_t* out, dsi_mapper_t* const* mappe
         REQUIRE(mappers[i]->ctx == ctx && batches[i]->ctx == ctx, DSI_ERR_CONTEXT,
                 "mappers, batches and the output mapper must share one context");
         REQUIRE(same_shape(out->grid, mappers[i]->grid), DSI_ERR_SHAPE, "camera %d: DSI shape differs from the output mapper's", i);
-        REQUIRE(i == 0 || mappers[i] != mappers[0], DSI_ERR_INVALID, "the cameras need distinct mappers (their tables are per mapper)");
-        np_max = std::max(np_max, batches[i]->n_packets);
+        for (int k = 0; k < i; ++k)
+            REQUIRE(mappers[i] != mappers[k], DSI_ERR_INVALID, "the cameras need distinct mappers (their tables are per mapper)");
     }
+    // process1.cpp:169-191: the third camera enters only through min (1), harmonicMeanTwoGrids(g, 3) (2) and max (6);
+    // "case 3: break; case 4: break; case 5: break;" -- its DSI is built and then ignored, so it is not built here
+    if (n == 3 && (op == 3 || op == 4 || op == 5)) n = 2;
+    for (int i = 0; i < n; ++i) np_max = std::max(np_max, batches[i]->n_packets);
     REQUIRE(out->geom.nz <= 256, DSI_ERR_INVALID, "arg-max indices are u8: dimZ must be <= 256 (got %d)", out->geom.nz);
     if (int rc = set_device(ctx)) return rc;
     dsi::BandPlan bp{};
@@ -1543,9 +1547,9 @@ int dsi_mapper_depth_map_of_events(dsi_mapper_t* out, dsi_mapper_t* const* mappe
     hipStream_t st = ctx->stream;
     dsi::FusedCameras cams{};
     cams.n = n;
-    dsi::PrepCameraArgs prep[2] = {};
+    dsi::PrepCameraArgs prep[dsi::kFusedMaxCameras] = {};
     const int n_pairs = bp.bands * geom.nz;
-    const bool balance = n_pairs <= dsi::fused_max_pairs() && out->fused_fixed_cost >= 0;
+    const bool balance = n <= 2 && n_pairs <= dsi::fused_max_pairs() && out->fused_fixed_cost >= 0;
     for (int i = 0; i < n; ++i) {
         dsi_mapper* m = mappers[i];
         const dsi_batch* b = batches[i];

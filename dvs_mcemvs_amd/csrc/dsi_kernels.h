@@ -117,11 +117,13 @@ struct FusedCamera {
     const uint32_t* slow_any;
     int np;
 };
+constexpr int kFusedMaxCameras = 3;
 struct FusedCameras {
-    FusedCamera cam[2];
-    int n;  // 1 (vote -> arg-max) or 2 (vote x 2 -> op -> arg-max)
+    FusedCamera cam[kFusedMaxCameras];
+    int n;  // 1 (vote -> arg-max), 2 (vote x 2 -> op -> arg-max) or 3 (process1.cpp:169-191: the trinocular rig --
+            // op 1 min, 2 harmonicMeanTwoGrids(g, 3), 6 max of the two-camera result and camera 2)
 };
-// The preparation of up to two cameras in two launches instead of four (stage A + packet sort; coefficient /
+// The preparation of up to three cameras in two launches instead of two per camera (stage A + packet sort; coefficient /
 // cut tables), optionally counting the records per (band, plane) pair for launch_fused_splits.
 struct PrepCameraArgs {
     const float* Rt;

@@ -275,7 +275,7 @@ struct PrepCamera {
     uint32_t* pair_work;  // [bands][nz]: records the voting kernel will look at per (band, plane), or nullptr
 };
 struct PrepCameras {
-    PrepCamera cam[2];
+    PrepCamera cam[kFusedMaxCameras];
     int n;
 };
 
@@ -448,9 +448,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_sort_packets_multi(PrepCameras cams, int ny, int nz, int pad,
                                                                                                        int n_pairs)
 {
-    int k = (int)blockIdx.x;
-    const int c = (cams.n > 1 && k >= cams.cam[0].np) ? 1 : 0;
-    if (c) k -= cams.cam[0].np;
+    int k = (int)blockIdx.x, c = 0;
+    while (c + 1 < cams.n && k >= cams.cam[c].np) k -= cams.cam[c++].np;
     const PrepCamera& pc = cams.cam[c];
     sort_packets_body<true>(k, nullptr, pc.raw, pc.np, ny, nz, pad, pc.sxy, pc.nvalid, pc.rowstart, pc.pair_work, n_pairs);
 }
@@ -610,13 +609,21 @@ __global__ __launch_bounds__(1024) void k_plane_coef(const float* __restrict__ c
     plane_coef_body<STAGED>(blockIdx.x, centers, planes, rowstart, nvalid, np, g, bp, coef, cuts, nullptr);
 }
 
-// the coefficient / cut tables of up to two cameras in one launch; camera 1's blocks start at blocks0
+// the coefficient / cut tables of up to three cameras in one launch; camera 1's blocks start at blocks0, camera 2's
+// blocks1 further
 template <bool STAGED>
-__global__ __launch_bounds__(1024) void k_plane_coef_multi(PrepCameras cams, BandPlan bp, unsigned blocks0)
+__global__ __launch_bounds__(1024) void k_plane_coef_multi(PrepCameras cams, BandPlan bp, unsigned blocks0, unsigned blocks1)
 {
     unsigned bid = blockIdx.x;
-    const int c = (cams.n > 1 && bid >= blocks0) ? 1 : 0;
-    if (c) bid -= blocks0;
+    int c = 0;
+    if (cams.n > 1 && bid >= blocks0) {
+        bid -= blocks0;
+        c = 1;
+        if (cams.n > 2 && bid >= blocks1) {
+            bid -= blocks1;
+            c = 2;
+        }
+    }
     const PrepCamera& pc = cams.cam[c];
     plane_coef_body<STAGED>(bid, pc.raw.centers, pc.planes, pc.rowstart, pc.nvalid, pc.np, pc.raw.g, bp, pc.coef, pc.cuts, pc.pair_work);
 }
@@ -2267,6 +2274,14 @@ __global__ __launch_bounds__(BLOCK) void k_vote_bands_vfill(
 
 // the 2-ary camera-fusion ops of Grid3D (cartesian3dgrid.h:111-192), used by the fused kernel below and by
 // the Grid3D kernels further down
+// Grid3D::harmonicMeanTwoGrids(grid2, n) (cartesian3dgrid.h:130-139); fn = n, fn1 = n - 1
+__device__ __forceinline__ float harmonic_mean_n(float a, float g, float fn, float fn1)
+{
+    const float av = a / fn1;
+    const float prod = av * g, sum = av + g;
+    return fn * prod / (sum + 0.1f);
+}
+
 template <int OP>
 __device__ __forceinline__ float fuse_op(float a, float g)
 {
@@ -2317,7 +2332,13 @@ struct FusedBest {
 // control flow per cell -- out-of-range lanes read the last owned cell and "zero" a halo cell that is zeroed
 // anyway -- so that the CELLS / 2 LDS reads of a half are in flight together: with a branch per cell every
 // read was waited for on its own, and the read-back took 3 us per phase (tools/fused_trace.py).
-template <int CELLS, int OP, bool LAST, bool TWO>
+// MODE: what a phase does with the band it has just voted
+enum { FUSED_KEEP = 0,   // camera 0 of several: keep the values
+       FUSED_MID = 1,    // camera 1 of 3: the two-camera op, result kept (process1.cpp:126-158)
+       FUSED_LAST2 = 2,  // camera 1 of 2: the two-camera op, then the running arg-max
+       FUSED_LAST1 = 3,  // the only camera: arg-max of its own values
+       FUSED_LAST3 = 4 };// camera 2 of 3: the third-camera op (process1.cpp:169-191: 1 min, 2 HM with n = 3, 6 max), arg-max
+template <int CELLS, int OP, int MODE>
 __device__ __forceinline__ void fused_consume(acc_t* __restrict__ band, int nx, int n_own, int rows_lds,
                                               float* __restrict__ va, FusedBest<CELLS>& fb, int z)
 {
@@ -2350,11 +2371,16 @@ __device__ __forceinline__ void fused_consume(acc_t* __restrict__ band, int nx, 
             const float v = big ? (float)((double)raw[k] * kFixInv)
                                 : (float)(__longlong_as_double((long long)(raw[k] | 0x4140000000000000ull)) - 2097152.0);
             const int kk = h + k;
-            if (!LAST) {
+            if (MODE == FUSED_KEEP) {
                 va[kk] = v;
+            } else if (MODE == FUSED_MID) {
+                va[kk] = fuse_op<OP>(0.f + va[kk], v);
             } else {
                 // process1.cpp:126-158: fused = 0; fused += dsi0; fused.<op>TwoGrids(dsi1)
-                const float f = TWO ? fuse_op<OP>(0.f + va[kk], v) : v;
+                // process1.cpp:169-191: fused.minTwoGrids / harmonicMeanTwoGrids(dsi2, 3) / maxTwoGrids(dsi2)
+                const float f = MODE == FUSED_LAST2   ? fuse_op<OP>(0.f + va[kk], v)
+                                : MODE == FUSED_LAST3 ? (OP == 2 ? harmonic_mean_n(va[kk], v, 3.f, 2.f) : fuse_op<OP>(va[kk], v))
+                                                      : v;
                 const bool better = fb.best[kk] < f;  // strict: the first maximum wins (cartesian3dgrid.cpp:132-134)
                 fb.best[kk] = better ? f : fb.best[kk];
                 const int sh = (kk & 3) * 8;
@@ -2407,6 +2433,21 @@ __global__ __launch_bounds__(1024) void k_vote_fuse_argmax(FusedCameras cams, Ge
     }
     __syncthreads();
 
+    // The cameras' table is read where it lies, in the kernel-argument segment, with scalar loads at the (uniform)
+    // camera index: indexing the by-value array dynamically made the compiler keep all three cameras' pointers in
+    // registers next to the ~40 the voting loops name (or copy the table to scratch).  `cams` is the FIRST argument,
+    // so cam[0] starts the segment.
+    typedef const FusedCamera __attribute__((address_space(4))) * KernargCameras;
+    const KernargCameras kcam = (KernargCameras)__builtin_amdgcn_kernarg_segment_ptr();
+    auto camera = [&](int c) -> FusedCamera {
+        FusedCamera o;
+        o.sxy = kcam[c].sxy;
+        o.coef = kcam[c].coef;
+        o.cuts = kcam[c].cuts;
+        o.slow_any = kcam[c].slow_any;
+        o.np = kcam[c].np;
+        return o;
+    };
     float va[CELLS];
     FusedBest<CELLS> fb;
     int cur_j = -1, r0 = 0, r1 = 0, n_own = 0;
@@ -2414,7 +2455,7 @@ __global__ __launch_bounds__(1024) void k_vote_fuse_argmax(FusedCameras cams, Ge
     constexpr bool kPrefetchCuts = MAPPING == 1;
     auto first_cuts_of = [&](int q, int c) -> uint32_t {
         if (!kPrefetchCuts) return 0u;
-        const FusedCamera& cam = cams.cam[c];
+        const FusedCamera cam = camera(c);
         if (cam.np <= 0) return 0u;
         const int j = q / g.nz, z = q - j * g.nz;
         int lg = 2;  // (the rule of stream_item's dealt stream)
@@ -2455,8 +2496,9 @@ __global__ __launch_bounds__(1024) void k_vote_fuse_argmax(FusedCameras cams, Ge
         const int rows_lds = r1 - r0 + 2;
         // events with floor(Y) in [r0 - 1, r1 - 1] (and in [0, ny - 2], cartesian3dgrid.h:255-259)
         const int Li = max(r0 - 1, 0), Ui = min(r1, g.ny - 1);
+#pragma nounroll
         for (int c = 0; c < cams.n; ++c) {
-            const FusedCamera& cam = cams.cam[c];
+            const FusedCamera cam = camera(c);
             // development aid (test hook dsi_test_fused_trace_*): 100 MHz time stamps per (workgroup, phase, wave):
             // stream begins, stream ends, after the barrier + the read-back / clear, after the closing barrier
             int tr = -1;  // (wave-uniform: lives in a scalar register)
@@ -2479,17 +2521,31 @@ __global__ __launch_bounds__(1024) void k_vote_fuse_argmax(FusedCameras cams, Ge
             if (threadIdx.x == 0) s_pass = kPass0;
             const bool last = c == cams.n - 1;
             if (!last) {
-                fused_consume<CELLS, 1, false, true>(band, nx, n_own, rows_lds, va, fb, z);
+                if (c == 0) {
+                    fused_consume<CELLS, 1, FUSED_KEEP>(band, nx, n_own, rows_lds, va, fb, z);
+                } else {  // camera 1 of 3: only the ops whose third step exists get here (1, 2, 6)
+                    switch (op) {
+                    case 1: fused_consume<CELLS, 1, FUSED_MID>(band, nx, n_own, rows_lds, va, fb, z); break;
+                    case 2: fused_consume<CELLS, 2, FUSED_MID>(band, nx, n_own, rows_lds, va, fb, z); break;
+                    default: fused_consume<CELLS, 6, FUSED_MID>(band, nx, n_own, rows_lds, va, fb, z); break;
+                    }
+                }
             } else if (cams.n == 1) {
-                fused_consume<CELLS, 1, true, false>(band, nx, n_own, rows_lds, va, fb, z);
+                fused_consume<CELLS, 1, FUSED_LAST1>(band, nx, n_own, rows_lds, va, fb, z);
+            } else if (cams.n == 2) {
+                switch (op) {
+                case 1: fused_consume<CELLS, 1, FUSED_LAST2>(band, nx, n_own, rows_lds, va, fb, z); break;
+                case 2: fused_consume<CELLS, 2, FUSED_LAST2>(band, nx, n_own, rows_lds, va, fb, z); break;
+                case 3: fused_consume<CELLS, 3, FUSED_LAST2>(band, nx, n_own, rows_lds, va, fb, z); break;
+                case 4: fused_consume<CELLS, 4, FUSED_LAST2>(band, nx, n_own, rows_lds, va, fb, z); break;
+                case 5: fused_consume<CELLS, 5, FUSED_LAST2>(band, nx, n_own, rows_lds, va, fb, z); break;
+                default: fused_consume<CELLS, 6, FUSED_LAST2>(band, nx, n_own, rows_lds, va, fb, z); break;
+                }
             } else {
                 switch (op) {
-                case 1: fused_consume<CELLS, 1, true, true>(band, nx, n_own, rows_lds, va, fb, z); break;
-                case 2: fused_consume<CELLS, 2, true, true>(band, nx, n_own, rows_lds, va, fb, z); break;
-                case 3: fused_consume<CELLS, 3, true, true>(band, nx, n_own, rows_lds, va, fb, z); break;
-                case 4: fused_consume<CELLS, 4, true, true>(band, nx, n_own, rows_lds, va, fb, z); break;
-                case 5: fused_consume<CELLS, 5, true, true>(band, nx, n_own, rows_lds, va, fb, z); break;
-                default: fused_consume<CELLS, 6, true, true>(band, nx, n_own, rows_lds, va, fb, z); break;
+                case 1: fused_consume<CELLS, 1, FUSED_LAST3>(band, nx, n_own, rows_lds, va, fb, z); break;
+                case 2: fused_consume<CELLS, 2, FUSED_LAST3>(band, nx, n_own, rows_lds, va, fb, z); break;
+                default: fused_consume<CELLS, 6, FUSED_LAST3>(band, nx, n_own, rows_lds, va, fb, z); break;
                 }
             }
             if (tr >= 0 && (threadIdx.x & 63) == 0) trace[tr + 2] = wall_clock64();
@@ -3023,11 +3079,7 @@ __device__ __forceinline__ float det_expf(double y)
 template <int KIND>
 __device__ __forceinline__ float ew_op(float a, float g, float fn, float fn1, const double2* __restrict__ log_tab = nullptr)
 {
-    if (KIND == EW_HM_N) {  // cartesian3dgrid.h:130-139
-        const float av = a / fn1;
-        const float prod = av * g, sum = av + g;
-        return fn * prod / (sum + 0.1f);
-    }
+    if (KIND == EW_HM_N) return harmonic_mean_n(a, g, fn, fn1);  // cartesian3dgrid.h:130-139
     if (KIND == EW_ADD) return a + g;                       // :68
     if (KIND == EW_ADD_INV) return a + 1.0f / (0.01f + g);  // :76, eps = 1e-2f
     if (KIND == EW_FIN_AM) return a / fn;                   // :91
@@ -3677,7 +3729,7 @@ int fused_max_pairs() { return 1024 * kSplitSlice; }
 
 hipError_t launch_prepare_cameras(hipStream_t s, const PrepCameraArgs* args, int n, const Geom& g, const BandPlan& bp)
 {
-    if (n < 1 || n > 2) return hipErrorInvalidValue;
+    if (n < 1 || n > kFusedMaxCameras) return hipErrorInvalidValue;
     const int n_pairs = bp.bands * g.nz;
     PrepCameras cams{};
     cams.n = n;
@@ -3704,16 +3756,17 @@ hipError_t launch_prepare_cameras(hipStream_t s, const PrepCameraArgs* args, int
     const size_t table_bytes = ((size_t)kCoefTilePackets * (size_t)(g.ny + 2 * bp.row_pad + 3) * sizeof(uint16_t) + 7) & ~(size_t)7;
     const bool staged = table_bytes <= max_dynamic_lds();
     const unsigned zdiv = staged ? 64u : 16u;
-    unsigned blocks[2] = {0, 0};
+    unsigned blocks[kFusedMaxCameras] = {0, 0, 0};
     for (int c = 0; c < cams.n; ++c) {
         const unsigned tiles_p = (unsigned)((cams.cam[c].np + kCoefTilePackets - 1) / kCoefTilePackets);
         blocks[c] = (tiles_p * (((unsigned)g.nz + zdiv - 1) / zdiv) + 63u) & ~63u;
     }
     if (staged) {
         if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_plane_coef_multi<true>), table_bytes)) return e;
-        hipLaunchKernelGGL(k_plane_coef_multi<true>, dim3(blocks[0] + blocks[1]), dim3(1024), table_bytes, s, cams, bp, blocks[0]);
+        hipLaunchKernelGGL(k_plane_coef_multi<true>, dim3(blocks[0] + blocks[1] + blocks[2]), dim3(1024), table_bytes, s, cams, bp, blocks[0],
+                           blocks[1]);
     } else {
-        hipLaunchKernelGGL(k_plane_coef_multi<false>, dim3(blocks[0] + blocks[1]), dim3(256), 0, s, cams, bp, blocks[0]);
+        hipLaunchKernelGGL(k_plane_coef_multi<false>, dim3(blocks[0] + blocks[1] + blocks[2]), dim3(256), 0, s, cams, bp, blocks[0], blocks[1]);
     }
     return hipExtGetLastError();
 }
@@ -3754,7 +3807,7 @@ int fused_grid_blocks()
 hipError_t launch_vote_fuse_argmax(hipStream_t s, const FusedCameras& cams, const Geom& g, const BandPlan& bp, int op,
                                    const uint32_t* splits, unsigned long long* keys, unsigned long long* trace)
 {
-    if (cams.n < 1 || cams.n > 2 || bp.block_threads != 1024 || bp.chunks != 1 || !bp.halo) return hipErrorInvalidValue;
+    if (cams.n < 1 || cams.n > kFusedMaxCameras || bp.block_threads != 1024 || bp.chunks != 1 || !bp.halo) return hipErrorInvalidValue;
     const unsigned blocks = (unsigned)fused_grid_blocks();
     switch (bp.packed) {
     case 1: return launch_vote_fuse_argmax_t<1>(s, cams, g, bp, op, splits, blocks, keys, trace);

@@ -781,10 +781,12 @@ class MapperEMVS:
         _check(load_library().dsi_mapper_depth_map_of_fusion_n(self._h, hs, len(grids), int(mode)))
 
     def computeDepthMapOfEvents(self, mappers, batches, fusion_method=FUSE_HM):
-        """Depth map of 1 or 2 cameras' events without building their DSIs: one kernel votes each
+        """Depth map of 1, 2 or 3 cameras' events without building their DSIs: one kernel votes each
         (band, plane) of every camera into LDS, fuses the cameras per voxel and keeps the running
         arg-max in registers (dsi_mapper_depth_map_of_events).  Bit-identical to evaluateDSI_batch on
-        every mapper + computeDepthMapOfFusion (or computeDepthMap for one camera); the mappers' DSIs
+        every mapper + computeDepthMapOfFusion (or computeDepthMap for one camera; for three, the
+        trinocular sequence of process1.cpp:126-191: the 2-ary op, then min / harmonicMeanTwoGrids(g, 3) /
+        max with camera 2 -- ops 3, 4, 5 ignore it like the reference); the mappers' DSIs
         are not touched.  Results land in THIS mapper's depth-map buffers (fetchDepthMap)."""
         hm = (C.c_void_p * len(mappers))(*[m._h for m in mappers])
         hb = (C.c_void_p * len(batches))(*[b._h for b in batches])

@@ -341,10 +341,14 @@ DSI_API int dsi_mapper_depth_map_of_fusion(dsi_mapper_t *m, const dsi_grid_t *a,
  * generalisation of process1.cpp:126-191, SURVEY 8d cfg 5) without materialising the fused DSI --
  * the same per-voxel operations in the same order, so the same bits as fuse-then-collapse. */
 DSI_API int dsi_mapper_depth_map_of_fusion_n(dsi_mapper_t *m, const dsi_grid_t *const *srcs, int n, int mode);
-/* The depth map of n = 1 or 2 cameras' events WITHOUT building their DSIs: bit for bit what
+/* The depth map of n = 1, 2 or 3 cameras' events WITHOUT building their DSIs: bit for bit what
  *     for c in 0..n-1: dsi_mapper_evaluate_batch(mappers[c], batches[c]);                 (process1.cpp:76-117)
  *     n == 2: dsi_mapper_depth_map_of_fusion(out, grid(mappers[0]), grid(mappers[1]), op);  (:126-166, :222 -> mapper_emvs_stereo.cpp:368)
  *     n == 1: dsi_mapper_depth_map_of(out, grid(mappers[0]))
+ *     n == 3: the trinocular rig of process1.cpp:105-117, :169-191 -- fused = op(grid 0, grid 1), then
+ *             op 1: min(fused, grid 2), op 2: harmonicMeanTwoGrids(grid 2, 3), op 6: max(fused, grid 2),
+ *             ops 3, 4, 5: camera 2 is ignored like the reference does ("case 3: break;"), its events are
+ *             not even voted -- followed by dsi_mapper_depth_map_of(out, fused)
  * leaves in out's depth-map buffers (dsi_mapper_fetch_depth_map*), computed by one kernel that votes a
  * (band, plane) of each camera into LDS, applies the 2-ary op per voxel and keeps the running arg-max
  * in registers -- no DSI is written or read (at 512x512x200 a window saves 840 MB of HBM traffic).  For

@@ -112,54 +112,52 @@ inline dsi::Transformation process_1(const LinearTrajectory& trajectory0, const 
 
 // Alg. 1 for callers that keep only the depth map (the --full_seq loop, main.cpp:177-302: process_1 followed by
 // getDepthMapFromDSI's arg-max): the same result as process_1(...) + mapper_fused.getDepthMapFromDSI(depth_map,
-// confidence_map, depth_cell_indices), bit for bit, but through ONE kernel that votes both cameras band by band in LDS,
+// confidence_map, depth_cell_indices), bit for bit, but through ONE kernel that votes the cameras band by band in LDS,
 // fuses them per voxel and keeps the running arg-max on the CU (dsi_mapper_depth_map_of_events): no DSI is written.
-// mapper0 / mapper1 supply the cameras' geometry and scratch; their dsi_ members are NOT updated.  Two cameras.
-inline dsi::Transformation process_1_depth_map(const LinearTrajectory& trajectory0, const LinearTrajectory& trajectory1,
-                                               const std::vector<dsi::Event>& events0, const std::vector<dsi::Event>& events1,
-                                               EMVS::MapperEMVS& mapper_out, EMVS::MapperEMVS& mapper0,
-                                               EMVS::MapperEMVS& mapper1, double ts, int fusion_method,
-                                               dsi::Image<float>& depth_map, dsi::Image<float>& confidence_map,
-                                               dsi::Image<uint8_t>& depth_cell_indices, double rv_pos = 0.0)
+// The mappers supply the cameras' geometry and scratch; their dsi_ members are NOT updated.  n cameras (1..3).
+inline dsi::Transformation process_1_depth_map_n(const LinearTrajectory* const* trs, const std::vector<dsi::Event>* const* evs,
+                                                 EMVS::MapperEMVS* const* mappers, int n, EMVS::MapperEMVS& mapper_out, double ts,
+                                                 int fusion_method, dsi::Image<float>& depth_map,
+                                                 dsi::Image<float>& confidence_map, dsi::Image<uint8_t>& depth_cell_indices,
+                                                 double rv_pos = 0.0)
 {
+    if (n < 1 || n > 3) throw dsi::Error(DSI_ERR_INVALID, "process_1_depth_map: 1 to 3 cameras");
     dsi::Transformation T_w_l;
-    if (!trajectory0.getPoseAt(ts, T_w_l)) throw dsi::Error(DSI_ERR_INVALID, "no pose at the reference timestamp");
+    if (!trs[0]->getPoseAt(ts, T_w_l)) throw dsi::Error(DSI_ERR_INVALID, "no pose at the reference timestamp");
     dsi::Transformation baseline;
     baseline.t[0] = rv_pos;
     const dsi::Transformation T_rv_w = dsi::inverse(T_w_l * baseline);  // process1.cpp:56-68
     double T7[7];
     T_rv_w.to7(T7);
-    const std::vector<dsi::Event>* evs[2] = {&events0, &events1};
-    const LinearTrajectory* trs[2] = {&trajectory0, &trajectory1};
-    dsi_mapper_t* ms[2] = {mapper0.handle(), mapper1.handle()};
-    dsi_batch_t* bs[2] = {nullptr, nullptr};
+    dsi_mapper_t* ms[3] = {nullptr, nullptr, nullptr};
+    dsi_batch_t* bs[3] = {nullptr, nullptr, nullptr};
     std::vector<uint16_t> xs, ys;
     std::vector<double> tss;
     std::vector<uint32_t> first;
     std::vector<float> Rt;
-    dsi_context_t* ctx = nullptr;
+    dsi_context_t* ctx = mapper_out.context();
     try {
-        for (int c = 0; c < 2; ++c) {
-            const size_t n = evs[c]->size();
-            xs.resize(n);
-            ys.resize(n);
-            tss.resize(n);
-            for (size_t i = 0; i < n; ++i) {
+        for (int c = 0; c < n; ++c) {
+            ms[c] = mappers[c]->handle();
+            const size_t ne = evs[c]->size();
+            xs.resize(ne);
+            ys.resize(ne);
+            tss.resize(ne);
+            for (size_t i = 0; i < ne; ++i) {
                 xs[i] = (*evs[c])[i].x;
                 ys[i] = (*evs[c])[i].y;
                 tss[i] = (*evs[c])[i].ts;
             }
-            first.assign(n / DSI_PACKET_SIZE + 1, 0u);
+            first.assign(ne / DSI_PACKET_SIZE + 1, 0u);
             Rt.assign(12 * first.size(), 0.f);
             size_t np = 0;
-            const int rc = dsi_packetize(tss.data(), n, trs[c]->times().data(), trs[c]->poses7().data(), trs[c]->times().size(),
+            const int rc = dsi_packetize(tss.data(), ne, trs[c]->times().data(), trs[c]->poses7().data(), trs[c]->times().size(),
                                          T7, first.data(), Rt.data(), &np);
             if (rc == DSI_ERR_TOO_FEW_EVENTS) np = 0;  // evaluateDSI returns false: an all-zero DSI (mapper_emvs_stereo.cpp:71-75)
             else dsi::check(rc);
-            ctx = mapper_out.context();
-            dsi::check(dsi_batch_create(ctx, xs.data(), ys.data(), n, first.data(), Rt.data(), np, &bs[c]));
+            dsi::check(dsi_batch_create(ctx, xs.data(), ys.data(), ne, first.data(), Rt.data(), np, &bs[c]));
         }
-        dsi::check(dsi_mapper_depth_map_of_events(mapper_out.handle(), ms, bs, 2, fusion_method));
+        dsi::check(dsi_mapper_depth_map_of_events(mapper_out.handle(), ms, bs, n, fusion_method));
         int nx, ny, nz;
         mapper_out.dsi_.getDimensions(&nx, &ny, &nz);
         depth_map = dsi::Image<float>(ny, nx);
@@ -173,6 +171,40 @@ inline dsi::Transformation process_1_depth_map(const LinearTrajectory& trajector
     }
     for (dsi_batch_t* b : bs) dsi_batch_destroy(b);
     return T_rv_w;
+}
+
+// two cameras (process1.cpp:76-166)
+inline dsi::Transformation process_1_depth_map(const LinearTrajectory& trajectory0, const LinearTrajectory& trajectory1,
+                                               const std::vector<dsi::Event>& events0, const std::vector<dsi::Event>& events1,
+                                               EMVS::MapperEMVS& mapper_out, EMVS::MapperEMVS& mapper0,
+                                               EMVS::MapperEMVS& mapper1, double ts, int fusion_method,
+                                               dsi::Image<float>& depth_map, dsi::Image<float>& confidence_map,
+                                               dsi::Image<uint8_t>& depth_cell_indices, double rv_pos = 0.0)
+{
+    const LinearTrajectory* trs[2] = {&trajectory0, &trajectory1};
+    const std::vector<dsi::Event>* evs[2] = {&events0, &events1};
+    EMVS::MapperEMVS* ms[2] = {&mapper0, &mapper1};
+    return process_1_depth_map_n(trs, evs, ms, 2, mapper_out, ts, fusion_method, depth_map, confidence_map, depth_cell_indices,
+                                 rv_pos);
+}
+
+// process_1's own argument order with the third camera (process1.cpp:28-41; EVIMO2): events2 empty = two cameras
+// (:105, :169), otherwise the third camera enters through min / harmonicMeanTwoGrids(g, 3) / max (:169-191) and is
+// ignored by fusion methods 3, 4, 5 like in the reference
+inline dsi::Transformation process_1_depth_map(const LinearTrajectory& trajectory0, const LinearTrajectory& trajectory1,
+                                               const LinearTrajectory& trajectory2, const std::vector<dsi::Event>& events0,
+                                               const std::vector<dsi::Event>& events1, const std::vector<dsi::Event>& events2,
+                                               EMVS::MapperEMVS& mapper_out, EMVS::MapperEMVS& mapper0,
+                                               EMVS::MapperEMVS& mapper1, EMVS::MapperEMVS& mapper2, double ts,
+                                               int fusion_method, dsi::Image<float>& depth_map,
+                                               dsi::Image<float>& confidence_map, dsi::Image<uint8_t>& depth_cell_indices,
+                                               double rv_pos = 0.0)
+{
+    const LinearTrajectory* trs[3] = {&trajectory0, &trajectory1, &trajectory2};
+    const std::vector<dsi::Event>* evs[3] = {&events0, &events1, &events2};
+    EMVS::MapperEMVS* ms[3] = {&mapper0, &mapper1, &mapper2};
+    return process_1_depth_map_n(trs, evs, ms, events2.empty() ? 2 : 3, mapper_out, ts, fusion_method, depth_map,
+                                 confidence_map, depth_cell_indices, rv_pos);
 }
 
 struct Process2Result {

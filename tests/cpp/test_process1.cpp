@@ -258,6 +258,24 @@ int main()
                     return 65;
                 }
             }
+            // three cameras (process1.cpp:105-117, :169-191): the right camera's second half of events plays camera 2
+            {
+                const std::vector<dsi::Event> events2(events1.begin() + (long)(events1.size() / 2), events1.end());
+                EMVS::MapperEMVS out3(ctx, cam, dsi_shape);
+                for (int method = 1; method <= 6; ++method) {
+                    process_1(trajectory0, trajectory1, trajectory1, events0, events1, events2, mapper_fused, mapper0, mapper1,
+                              mapper2, 0.5, method);
+                    dsi::Image<float> d1, c1, d2, c2;
+                    dsi::Image<uint8_t> i1, i2;
+                    mapper_fused.getDepthMapFromDSI(d1, c1, i1);
+                    process_1_depth_map(trajectory0, trajectory1, trajectory1, events0, events1, events2, out3, mapper0, mapper1,
+                                        mapper2, 0.5, method, d2, c2, i2);
+                    if (d1.data != d2.data || c1.data != c2.data || i1.data != i2.data) {
+                        std::printf("three-camera process_1_depth_map differs for fusion method %d\n", method);
+                        return 66;
+                    }
+                }
+            }
             try {
                 process_1(trajectory0, trajectory1, trajectory1, events0, events1, none, mapper_fused, mapper0,
                           mapper1, mapper2, 0.5, 9);

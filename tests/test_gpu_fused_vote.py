@@ -337,3 +337,58 @@ def test_fused_cameras_with_their_own_calibration(ctx):
     assert not np.array_equal(fus_m[2].fetchDepthMap()[1], want[1])
     for o in ref_m + fus_m + same + batches:
         o.close()
+
+
+@pytest.mark.parametrize("packed", [-1, 3, 5])
+def test_fused_three_cameras_follow_process_1(ctx, packed):
+    """The trinocular rig (EVIMO2; process1.cpp:105-117, :169-191): fused = op(dsi0, dsi1), then min /
+    harmonicMeanTwoGrids(dsi2, 3) / max with the third camera -- and nothing for ops 3, 4, 5, which the reference's
+    switch lets fall through.  The fused kernel with three cameras gives the depth map of that sequence + arg-max bit
+    for bit; different packet counts per camera, one band height that leaves a ragged last band."""
+    nx, ny, nz = 140, 100, 36
+    rig = syn.stereo_rig(45_000, width=nx, height=ny, duration=0.3, seed=21, n_points=800, n_cams=3)
+    rig["events"][2] = tuple(a[:28_000] for a in rig["events"][2])
+    shape = d.ShapeDSI(0, 0, nz, 4.0, 150.0, 0.0)
+    batches = rig_batches(ctx, rig, 3)
+    assert batches[2].n_packets < batches[0].n_packets
+    ref_m = [d.MapperEMVS(ctx, rig["cam"], shape) for _ in range(4)]
+    fus_m = [d.MapperEMVS(ctx, rig["cam"], shape) for _ in range(4)]
+    for m in fus_m[:3]:
+        m.set_packed_lanes(packed)
+        m.set_band_params(9, 0, 0)
+    for m, b in zip(ref_m[:3], batches):
+        m.evaluateDSI_batch(b)
+    two = {}
+    for op in range(1, 7):
+        fused = ref_m[3].dsi_
+        fused.resetGrid()                                   # process1.cpp:126-127
+        fused.addTwoGrids(ref_m[0].dsi_)
+        proc._fuse_cameras(fused, ref_m[1].dsi_, op)        # :136-158
+        if op == 1:                                         # :169-191
+            fused.minTwoGrids(ref_m[2].dsi_)
+        elif op == 2:
+            fused.harmonicMeanTwoGrids(ref_m[2].dsi_, 3)
+        elif op == 6:
+            fused.maxTwoGrids(ref_m[2].dsi_)
+        want = ref_m[3].getDepthMapFromDSI()
+        fus_m[3].computeDepthMapOfEvents(fus_m[:3], batches, op)
+        got = fus_m[3].fetchDepthMap()
+        for g, w, name in zip(got, want, ("depth", "confidence", "index")):
+            assert np.array_equal(g, w), "op %d: %s differs at %d pixels" % (op, name, (g != w).sum())
+        assert want[1].max() > 0.5
+        fus_m[3].computeDepthMapOfEvents(fus_m[:2], batches[:2], op)
+        two[op] = fus_m[3].fetchDepthMap()[1]
+        # the third camera changes the map exactly for the ops whose third step exists
+        assert np.array_equal(two[op], want[1]) == (op in (3, 4, 5))
+    # a third camera without packets (evaluateDSI returned false: an all-zero DSI): min wipes the map, max keeps it
+    empty = d.EventBatch(ctx, np.zeros(0, np.uint16), np.zeros(0, np.uint16), np.zeros((0, 12), np.float32),
+                         np.zeros(0, np.uint32))
+    fus_m[3].computeDepthMapOfEvents(fus_m[:3], batches[:2] + [empty], d.FUSE_MIN)
+    assert not fus_m[3].fetchDepthMap()[1].any()
+    fus_m[3].computeDepthMapOfEvents(fus_m[:3], batches[:2] + [empty], d.FUSE_MAX)
+    assert np.array_equal(fus_m[3].fetchDepthMap()[1], two[d.FUSE_MAX])
+    with pytest.raises(d.DsiError) as e:
+        fus_m[3].computeDepthMapOfEvents(fus_m[:3] + [ref_m[0]], batches + [batches[0]], d.FUSE_HM)
+    assert e.value.code == engine.ERR_INVALID
+    for o in ref_m + fus_m + batches + [empty]:
+        o.close()
