@@ -2161,7 +2161,10 @@ __device__ __forceinline__ void stream_item(const EvRec* __restrict__ sxy, const
             // operations): 4 at a 50 ms window's 489 packets (measured 4 / 8 / 16: 446 / 455 / 471 us for the fused kernel),
             // 16 at 4,900 (346x260x100: 1.190 / 1.182 / 1.179 ms for 4 / 8 / 16), 16-32 at 9,800 (512x512x200, 10 M
             // events: 2.76 / 2.62 / 2.55 ms for 4 / 8 / 16)
-            int lg = 2;
+            // Re-measured at the end of round 3 (passes of 4 / 8 / 16 packets, kernel time): 976 packets 346x260x100
+            // 146.5 / 143.6 / 143.4 us; 3,906 packets 497 / 491 / 492 us, at 512x512x200 1.138 / 1.095 / 1.088 ms; a window's
+            // 489 packets in the fused kernel 431.9 / 430.6 / 458.5 us (2 packets: 450.9) -- 8 is never worse than 4.
+            int lg = (p_end - p_begin) >= kWaves * 16 ? 3 : 2;
             while (lg < 5 && (p_end - p_begin) >= ((kWaves * 16) << (lg + 1))) ++lg;
             if (bp.pass_lg > 0) lg = bp.pass_lg;
             if constexpr (!DEAL)  // nobody loaded the wave's first cut words ahead of time (the fused kernel does)
@@ -2458,7 +2461,7 @@ __global__ __launch_bounds__(1024) void k_vote_fuse_argmax(FusedCameras cams, Ge
         const FusedCamera cam = camera(c);
         if (cam.np <= 0) return 0u;
         const int j = q / g.nz, z = q - j * g.nz;
-        int lg = 2;  // (the rule of stream_item's dealt stream)
+        int lg = cam.np >= (BLOCK / kWave) * 16 ? 3 : 2;  // (the rule of stream_item's dealt stream)
         while (lg < 5 && cam.np >= (((BLOCK / kWave) * 16) << (lg + 1))) ++lg;
         if (bp.pass_lg > 0) lg = bp.pass_lg;
         const int p = min((int)((threadIdx.x / kWave) << lg) + (int)(threadIdx.x & 63), cam.np - 1);

@@ -78,6 +78,12 @@ names = ["start skew", "first wave done", "median wave done", "last wave done", 
 for k, nm in enumerate(names):
     print("%-18s mean %7.2f us   p10 %7.2f   p90 %7.2f" % (nm, ph[:, k].mean(), np.percentile(ph[:, k], 10), np.percentile(ph[:, k], 90)))
 print("phases: %d; sum of phase totals / workgroups = %.1f us" % (len(ph), ph[:, 6].sum() / wg_valid.sum()))
+fin = np.where(wg_valid, t[..., 3].max(axis=(1, 2)) - t0, np.nan)
+sta = np.where(wg_valid, np.where(valid, t[..., 0], np.inf).min(axis=(1, 2)) - t0, np.nan)
+for x in range(8):
+    sel = np.arange(fin.shape[0]) % 8 == x
+    print("xcd %d: workgroups start %.1f..%.1f us, finish min %.1f mean %.1f max %.1f us" %
+          (x, np.nanmin(sta[sel]), np.nanmax(sta[sel]), np.nanmin(fin[sel]), np.nanmean(fin[sel]), np.nanmax(fin[sel])))
 # the slowest and the fastest workgroups: phases, mean stream time, first / last stamp
 order = np.argsort(-np.where(wg_valid, t[..., 3].max(axis=(1, 2)), 0))
 for w in list(order[:6]) + list(order[wg_valid.sum() - 3:wg_valid.sum()]):
