@@ -72,6 +72,8 @@ def parse():
                     help="windows: vote, fuse the cameras and keep the arg-max in ONE kernel, no DSI written "
                          "(dsi_mapper_depth_map_of_events); default for the windows workload")
     ap.add_argument("--no-fused-vote", dest="fused_vote", action="store_false")
+    ap.add_argument("--window-depth", type=int, default=2,
+                    help="windows: windows in flight (each on its own stream when not --serial-windows); 1, 2, 3 or 4")
     ap.add_argument("--serial-windows", action="store_true",
                     help="windows: all windows on ONE stream (no overlap of consecutive windows); for rocprofv3 runs, "
                          "whose per-kernel durations otherwise include the time a kernel waits for the previous "
@@ -522,7 +524,8 @@ def main():
 
     elif args.workload == "windows":
         # ---- configs[2]: 8 distinct 50 ms windows (cycled), resident in HBM as packetised batches ----
-        n_distinct = 8
+        depth = max(1, min(4, args.window_depth))
+        n_distinct = 12 if depth == 3 else 8          # (a multiple of the depth: window wi always lands in slot wi % depth)
         dur = args.events / 10.0e6                    # 10 Mev/s per camera
         rig = syn.stereo_rig(n_distinct * args.events, width=640, height=480, t0=10.0 + 10.0 * rank,
                              duration=n_distinct * dur, seed=77 + rank, n_points=max(args.points, 6000))
@@ -530,7 +533,7 @@ def main():
         fused_vote = (args.fused_vote is not False) and not args.materialize_fused and args.algo in (0, 2)
         concurrent = fused_vote and not args.serial_windows
         ws = proc.WindowStream(ctx, (rig["cam"],) * 2, shape, d.FUSE_HM, materialize_fused=args.materialize_fused,
-                               fused_vote=fused_vote, concurrent=concurrent)
+                               fused_vote=fused_vote, concurrent=concurrent, depth=depth)
         for ms_ in ws.mapper_sets:
             for m in ms_:
                 tune(m)
@@ -543,27 +546,25 @@ def main():
             for c in range(2):
                 ev = proc.window_events(rig["events"][c], a, b)
                 first, Rt = d.packetize(ev[2], rig["trajectories"][c], T_rv_w)
-                # (window wi always lands in slot wi % 2: n_distinct is even; its batches live in that slot's context)
-                per_cam.append(d.EventBatch(ws.context_of_slot(wi % 2), ev[0], ev[1], Rt, first))
+                # (its batches live in its slot's context)
+                per_cam.append(d.EventBatch(ws.context_of_slot(wi % depth), ev[0], ev[1], Rt, first))
                 host.append(ev)
             wins.append((per_cam, b))
             host_wins.append((host, b))
             closers += per_cam
         closers.append(ws)
-        state = {"w": 0, "pending": None}
+        state = {"w": 0, "pending": []}
 
         def step():
             per_cam, ts = wins[state["w"] % len(wins)]
-            slot = ws.submit(None, rig["trajectories"], ts, batches=per_cam)
-            if state["pending"] is not None:
-                ws.fetch(state["pending"])            # depth map of the previous window (device -> host)
-            state["pending"] = slot
+            state["pending"].append(ws.submit(None, rig["trajectories"], ts, batches=per_cam))
+            while len(state["pending"]) >= depth:
+                ws.fetch(state["pending"].pop(0))     # depth map of the oldest window in flight (device -> host)
             state["w"] += 1
 
         def sync():
-            if state["pending"] is not None:
-                ws.fetch(state["pending"])
-                state["pending"] = None
+            while state["pending"]:
+                ws.fetch(state["pending"].pop(0))
             for c_ in ws.contexts:
                 c_.synchronize()
 
