@@ -69,15 +69,16 @@ for w in np.nonzero(wg_valid)[0]:
         ph.append((s[:, 0].max() - start,                 # skew of the stream starts
                    s[:, 1].min() - start,                 # first wave done
                    np.median(s[:, 1]) - start,
+                   s[:, 1].mean() - start,                # mean wave done = the work per wave, pass switches included
                    s[:, 1].max() - start,                 # last wave done
                    s[:, 2].max() - s[:, 1].max(),         # barrier + read-back
                    s[:, 3].max() - s[:, 2].max(),         # closing barrier
                    s[:, 3].max() - start))
 ph = np.array(ph)
-names = ["start skew", "first wave done", "median wave done", "last wave done", "barrier+consume", "closing barrier", "phase total"]
+names = ["start skew", "first wave done", "median wave done", "mean wave done", "last wave done", "barrier+consume", "closing barrier", "phase total"]
 for k, nm in enumerate(names):
     print("%-18s mean %7.2f us   p10 %7.2f   p90 %7.2f" % (nm, ph[:, k].mean(), np.percentile(ph[:, k], 10), np.percentile(ph[:, k], 90)))
-print("phases: %d; sum of phase totals / workgroups = %.1f us" % (len(ph), ph[:, 6].sum() / wg_valid.sum()))
+print("phases: %d; sum of phase totals / workgroups = %.1f us" % (len(ph), ph[:, 7].sum() / wg_valid.sum()))
 fin = np.where(wg_valid, t[..., 3].max(axis=(1, 2)) - t0, np.nan)
 sta = np.where(wg_valid, np.where(valid, t[..., 0], np.inf).min(axis=(1, 2)) - t0, np.nan)
 for x in range(8):
