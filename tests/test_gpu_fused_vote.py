@@ -171,10 +171,36 @@ def test_fused_with_slow_planes_unequal_cameras_and_a_lut(ctx, packed):
         o.close()
 
 
-@pytest.mark.parametrize("seed", list(range(12)))
+def _reference_sequence(ctx, mappers, out, batches, op):
+    """evaluateDSI per camera, then process1.cpp:126-191 with Grid3D calls, then the arg-max -- the unfused path."""
+    for m, bt in zip(mappers, batches):
+        if bt.n_packets:
+            m.evaluateDSI_batch(bt)
+        else:
+            m.dsi_.resetGrid()          # fewer than 1024 events: evaluateDSI returns false, the DSI stays all zero (:71-75)
+    if len(mappers) == 1:
+        out.computeDepthMap(mappers[0].dsi_)
+        return out.fetchDepthMap()
+    fused = out.dsi_
+    fused.resetGrid()
+    fused.addTwoGrids(mappers[0].dsi_)
+    proc._fuse_cameras(fused, mappers[1].dsi_, op)
+    if len(mappers) == 3:
+        if op == 1:
+            fused.minTwoGrids(mappers[2].dsi_)
+        elif op == 2:
+            fused.harmonicMeanTwoGrids(mappers[2].dsi_, 3)
+        elif op == 6:
+            fused.maxTwoGrids(mappers[2].dsi_)
+    out.computeDepthMap(fused)
+    return out.fetchDepthMap()
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
 def test_fused_fuzz_over_shapes_bands_and_mappings(ctx, seed):
     """Random grids (odd widths, one-row bands, a single plane, 256 planes, more rows than events), band heights,
-    lane mappings, fusion ops and event counts: the fused kernel always gives the bits of vote -> fuse -> collapse."""
+    lane mappings, fusion ops, event counts per camera, one to three cameras, each with its own intrinsics and depth
+    range: the fused kernel always gives the bits of the reference's sequence of calls."""
     rng = np.random.default_rng(900 + seed)
     nx = int(rng.choice([2, 3, 17, 64, 129, 346, 700]))
     ny = int(rng.choice([2, 5, 48, 97, 260]))
@@ -182,25 +208,38 @@ def test_fused_fuzz_over_shapes_bands_and_mappings(ctx, seed):
     if nx * ny * nz > 6_000_000:
         nz = 7
     n_ev = int(rng.choice([1025, 3000, 20_000, 70_000]))
-    rig = syn.stereo_rig(n_ev, width=max(nx, 8), height=max(ny, 8), duration=0.2, seed=50 + seed, n_points=300)
-    shape = d.ShapeDSI(nx, ny, nz, 2.0, float(rng.uniform(20.0, 200.0)), float(rng.choice([0.0, 60.0])))
+    n_cams = int(rng.choice([1, 2, 2, 3]))
+    rig = syn.stereo_rig(n_ev, width=max(nx, 8), height=max(ny, 8), duration=0.2, seed=50 + seed, n_points=300, n_cams=max(n_cams, 2))
+    far, fov = float(rng.uniform(20.0, 200.0)), float(rng.choice([0.0, 60.0]))
     packed = int(rng.choice([-1, 1, 3, 5, 6]))
     band_rows = int(rng.choice([0, 1, 2, 3, 9, 40]))
     op = int(rng.integers(1, 7))
-    batches = rig_batches(ctx, rig)
-    ref_m = [d.MapperEMVS(ctx, rig["cam"], shape) for _ in range(2)]
-    fus_m = [d.MapperEMVS(ctx, rig["cam"], shape) for _ in range(2)]
+    w, h, fx, fy, cx, cy = rig["cam"]
+    cams, shapes, batches = [], [], []
+    for c in range(n_cams):
+        own = bool(rng.integers(0, 2)) and c > 0          # this camera has a calibration of its own
+        cams.append((w, h, fx * float(rng.uniform(0.95, 1.05)), fy * float(rng.uniform(0.95, 1.05)),
+                     cx + float(rng.uniform(-3, 3)), cy + float(rng.uniform(-3, 3))) if own else rig["cam"])
+        shapes.append(d.ShapeDSI(nx, ny, nz, 2.0 if not own else 2.5, far if not own else far * 0.8, fov))
+        keep = n_ev if c == 0 else int(rng.choice([n_ev, max(1025, n_ev // 2), 700]))   # 700 < 1024: evaluateDSI returns false
+        ev = tuple(a[:keep] for a in rig["events"][c])
+        pk = d.packetize(ev[2], rig["trajectories"][c], rig["T_rv_w"])
+        first, Rt = pk if pk is not None else (np.zeros(0, np.uint32), np.zeros((0, 12), np.float32))
+        batches.append(d.EventBatch(ctx, ev[0], ev[1], Rt, first))
+    mk = lambda: [d.MapperEMVS(ctx, cams[c], shapes[c]) for c in range(n_cams)]
+    ref_m, fus_m = mk(), mk()
+    ref_out, fus_out = d.MapperEMVS(ctx, cams[0], shapes[0]), d.MapperEMVS(ctx, cams[0], shapes[0])
     for m in fus_m:
         m.set_packed_lanes(packed)
         if band_rows:
             m.set_band_params(band_rows, 0, 0)
-    want = unfused(ctx, ref_m, batches, op)
-    fus_m[0].computeDepthMapOfEvents(fus_m, batches, op)
-    got = fus_m[0].fetchDepthMap()
-    for g, w, name in zip(got, want, ("depth", "confidence", "index")):
-        assert np.array_equal(g, w), "seed %d (%dx%dx%d, %d events, mapping %d, band %d, op %d): %s differs at %d pixels" % (
-            seed, nx, ny, nz, n_ev, packed, band_rows, op, name, (g != w).sum())
-    for o in ref_m + fus_m + batches:
+    want = _reference_sequence(ctx, ref_m, ref_out, batches, op)
+    fus_out.computeDepthMapOfEvents(fus_m, batches, op)
+    got = fus_out.fetchDepthMap()
+    for g, w_, name in zip(got, want, ("depth", "confidence", "index")):
+        assert np.array_equal(g, w_), "seed %d (%dx%dx%d, %d events, %d cameras, mapping %d, band %d, op %d): %s differs at %d pixels" % (
+            seed, nx, ny, nz, n_ev, n_cams, packed, band_rows, op, name, (g != w_).sum())
+    for o in ref_m + fus_m + batches + [ref_out, fus_out]:
         o.close()
 
 
