@@ -431,3 +431,53 @@ def test_fused_three_cameras_follow_process_1(ctx, packed):
     assert e.value.code == engine.ERR_INVALID
     for o in ref_m + fus_m + batches + [empty]:
         o.close()
+
+
+def test_distinct_contexts_from_distinct_threads(ctx):
+    """include/dsi_engine.h: "Distinct contexts may be used from distinct threads" (the reference's evaluateDSI is not
+    re-entrant: function-static scratch, mapper_emvs_stereo.cpp:79-83).  Four host threads, each with its own context,
+    mappers and batches, run the unfused and the fused path concurrently; every thread gets the bits the main thread
+    got alone."""
+    import threading
+    nx, ny, nz = 200, 150, 48
+    rigs = [syn.stereo_rig(40_000 + 5_000 * k, width=nx, height=ny, duration=0.25, seed=70 + k, n_points=900) for k in range(4)]
+    shape = d.ShapeDSI(0, 0, nz, 4.0, 180.0, 0.0)
+
+    def work(context, rig, rounds):
+        batches = rig_batches(context, rig)
+        ms = [d.MapperEMVS(context, rig["cam"], shape) for _ in range(2)]
+        out = d.MapperEMVS(context, rig["cam"], shape)
+        res = []
+        for it in range(rounds):
+            op = (d.FUSE_HM, d.FUSE_MIN, d.FUSE_AM)[it % 3]
+            a = unfused(context, ms, batches, op)
+            out.computeDepthMapOfEvents(ms, batches, op)
+            b = out.fetchDepthMap()
+            res.append((a, b))
+        for o in ms + [out] + batches:
+            o.close()
+        return res
+
+    want = [work(ctx, rig, 3) for rig in rigs]
+    got, errors = [None] * 4, []
+
+    def run(k):
+        try:
+            c = d.Context(0)
+            got[k] = work(c, rigs[k], 3)
+            c.close()
+        except Exception as e:      # noqa: BLE001 -- reported below, from the main thread
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in range(4):
+        for it, ((wa, wb), (ga, gb)) in enumerate(zip(want[k], got[k])):
+            for w_, g_, name in zip(wa + wb, ga + gb, ("depth", "confidence", "index") * 2):
+                assert np.array_equal(w_, g_), "thread %d round %d: %s differs" % (k, it, name)
+            for x, y in zip(ga, gb):
+                assert np.array_equal(x, y)     # and fused == unfused there too
