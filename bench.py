@@ -16,6 +16,14 @@ resident in HBM):
            harmonic accumulator (process2.cpp:217-226): local 1/(0.01+v), ONE RCCL all-reduce(sum)
            of the volume over xGMI -- issued by the ENGINE (C ABI, dsi_grid_allreduce) on a second
            HIP stream so that it overlaps the next step's voting -- local n/acc, arg-max.
+
+N > 1 is always N processes, one per GPU, whoever starts them: under a launcher (`python -m
+torch.distributed.run --nproc-per-node N bench.py --gpus N ...`: RANK / WORLD_SIZE in the environment) this
+process is one rank; without one (`python bench.py --gpus N ...`) it starts the N ranks itself
+(dvs_mcemvs_amd/launch.py) and relays rank 0's JSON line.  Fewer than N devices, a WORLD_SIZE that contradicts
+--gpus, or an RCCL communicator that cannot be formed are ERRORS (non-zero exit): there is no fallback to fewer
+ranks or to another collective.  The line proves its rank count: `rccl_ranks` is ncclCommCount of the engine's
+communicator, `ranks` lists every rank's device as RCCL reports it.
   windows  configs[2]: stream of 50 ms windows, 2 cameras x 500 k events each, sensor 640x480, DSI
            512x512x200 (main.cpp:174-302 with process_method 1): a step = one window = reset +
            vote x2 + HM + arg-max; the depth map of window w is fetched while w+1 is queued.
@@ -79,7 +87,7 @@ def parse():
                          "whose per-kernel durations otherwise include the time a kernel waits for the previous "
                          "window's workgroups to leave the CUs")
     ap.add_argument("--temporal-collective", choices=["allreduce", "reduce_scatter"], default="allreduce",
-                    help="stereo, N > 1, --collective engine: the time slices' temporal fusion as ONE all-reduce of the "
+                    help="stereo, N > 1: the time slices' temporal fusion as ONE all-reduce of the "
                          "accumulator + finalize + arg-max on every rank (default), or as a reduce-scatter by planes + "
                          "finalize / arg-max of the owned planes + all-reduce(MAX) of 8-byte keys (half the xGMI bytes; "
                          "the fused DSI is not completed on any rank)")
@@ -89,9 +97,9 @@ def parse():
     ap.add_argument("--no-extra", action="store_true",
                     help="default (stereo, 1 GPU) run only: do not append the one-GPU lines of the windows and "
                          "cameras4 workloads (each is a sub-run of this script) to the JSON line")
-    ap.add_argument("--collective", choices=["engine", "torch"], default="engine",
-                    help="N > 1: who issues the all-reduce: the engine's own RCCL communicator (C ABI) or "
-                         "torch.distributed")
+    ap.add_argument("--no-sensitivity", action="store_true",
+                    help="default (stereo, 1 GPU) run only: skip the input-sensitivity sub-records (the voting kernel on "
+                         "uniformly random pixels, on a dense scene and on the recorded zurich_city_04 trajectory)")
     a = ap.parse_args()
     defaults = {"stereo": ((346, 260, 100), 10_000_000, 100, 5), "windows": ((512, 512, 200), 500_000, 100, 8),
                 "cameras4": ((1024, 1024, 256), 2_000_000, 5, 1)}[a.workload]
@@ -102,115 +110,24 @@ def parse():
     return a
 
 
-class Dist:
-    """Rendezvous / barrier / scalar max over the ranks.  torch.distributed is plumbing here: with
-    --collective engine it runs on gloo (CPU) and only carries the RCCL unique id, the barriers and
-    two scalars; the data-path collective is the engine's."""
-
-    def __init__(self, args):
-        self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        self.rank = int(os.environ.get("RANK", "0"))
-        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        # (plumbing tests on a one-GPU box: DSI_BENCH_DEVICE=0 puts every rank on GPU 0 -- RCCL then refuses
-        #  the communicator, which is the point of such a test)
-        self.local_rank = int(os.environ.get("DSI_BENCH_DEVICE", self.local_rank))
-        self.dist = self.torch = None
-        self.backend = None
-        if self.world > 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
-            if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
-                # one node: RCCL's bootstrap sockets on the loopback interface (the container's
-                # hostname may not resolve)
-                os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
-            import torch
-            import torch.distributed as dist
-            self.torch, self.dist = torch, dist
-            if args.collective == "torch":
-                torch.cuda.set_device(self.local_rank)
-                dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
-                                        device_id=torch.device("cuda", self.local_rank))
-                self.backend = "nccl"
-            else:
-                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
-                self.backend = "gloo"
-
-    def barrier(self):
-        if self.dist is not None:
-            if self.backend == "nccl":
-                self.torch.cuda.synchronize()
-            self.dist.barrier()
-
-    def _dev(self):
-        return "cuda" if self.backend == "nccl" else "cpu"
-
-    def max(self, v):
-        if self.dist is None:
-            return float(v)
-        t = self.torch.tensor([float(v)], dtype=self.torch.float64, device=self._dev())
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.item())
-
-    def min(self, v):
-        if self.dist is None:
-            return float(v)
-        t = self.torch.tensor([float(v)], dtype=self.torch.float64, device=self._dev())
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
-        return float(t.item())
-
-    def sum(self, v):
-        if self.dist is None:
-            return float(v)
-        t = self.torch.tensor([float(v)], dtype=self.torch.float64, device=self._dev())
-        self.dist.all_reduce(t)
-        return float(t.item())
-
-    def broadcast_bytes(self, b):
-        if self.dist is None:
-            return b
-        obj = [b]
-        self.dist.broadcast_object_list(obj, src=0)
-        return obj[0]
-
-    def close(self):
-        if self.dist is not None:
-            self.dist.barrier()
-            self.dist.destroy_process_group()
-
-
-def make_comm(d, dd, ctx, D, args):
-    """(allreduce callable or None, engine comm or None, description, torch group or None).
-    The engine's own RCCL communicator is the default; if it cannot be initialised on every rank
-    the torch.distributed (nccl) path takes over -- loudly: the JSON line's config.collective says so."""
+def make_comm(d, dd, ctx, D):
+    """(allreduce callable, engine communicator or None, description).  N > 1: the engine's own RCCL communicator
+    (dsi_comm_create_rank; the 128-byte unique id travels over the gloo side channel) or an error -- there is no
+    other collective backend."""
     if D.world == 1:
-        return dd.engine_allreduce(None), None, "none (1 rank)", None
-    why = "requested with --collective torch"
-    if args.collective == "engine":
-        uid, err, comm = None, "", None
-        if D.rank == 0:
-            try:
-                uid = d.Comm.unique_id()
-            except d.DsiError as e:
-                err = str(e)
-        uid, err = D.broadcast_bytes((uid, err))
-        ok = 0
-        if uid is not None:
-            try:
-                comm = d.Comm(ctx, uid, D.world, D.rank)
-                ok = 1
-            except d.DsiError as e:
-                err = str(e)
-        if D.min(ok) >= 1.0:
-            return dd.engine_allreduce(comm), comm, "RCCL from the engine's C ABI (dsi_grid_allreduce)", None
+        return dd.engine_allreduce(None), None, "none (1 rank)"
+    uid = D.broadcast(d.Comm.unique_id() if D.rank == 0 else None)
+    try:
+        comm = d.Comm(ctx, uid, D.world, D.rank)
+        ok, err = 1, ""
+    except d.DsiError as e:
+        comm, ok, err = None, 0, str(e)
+    if D.min(ok) < 1.0:
         if comm is not None:
             comm.close()
-        why = "FALLBACK, the engine's RCCL communicator failed on some rank: %s" % (err or "see other ranks")
-        print("bench.py rank %d: %s" % (D.rank, why), file=sys.stderr)
-    if D.backend == "nccl":
-        return None, None, "torch.distributed nccl (%s)" % why, None
-    D.torch.cuda.set_device(D.local_rank)
-    group = D.dist.new_group(backend="nccl")
-    return None, None, "torch.distributed nccl (%s)" % why, group
+        raise SystemExit("bench.py rank %d: the engine's RCCL communicator could not be formed on every rank (%s); "
+                         "no fallback collective exists" % (D.rank, err or "see the other ranks"))
+    return dd.engine_allreduce(comm), comm, "RCCL from the engine's C ABI (dsi_comm_create_rank, dsi_grid_allreduce)"
 
 
 def kernel_source_sha16():
@@ -414,6 +331,68 @@ def parity_block(d, rig, dims, mappers, batches, fused):
     return rep
 
 
+def sensitivity_block(d, syn, ctx, args, dims, tune):
+    """How much the dominant kernel's time depends on the INPUT, at the headline size (one camera, `--events` events,
+    the headline grid): the scene decides how many events of a packet share a pixel (merged into one record by the
+    packet sort: fewer atomics) and how often two lanes of a wave instruction hit the same voxel.  Three inputs beside
+    the headline's (5,000 scene points + 10 % noise):
+      uniform_pixels      every event on a uniformly random pixel (no structure, hardly any duplicate: the most
+                          atomics per event),
+      dense_scene         200,000 scene points (SURVEY 8d's range is 2,000-20,000),
+      zurich_city_04      the recorded vehicle trajectory of DSEC zurich_city_04, 10-15 s
+                          (tests/golden/zurich_city_04_poses_9_16s.npz, from the reference's pose.bag), 5 s window as
+                          in cfg/DSEC/zurich_04_a_full/dsec.conf:13-14.
+    Each sub-record carries its own kernel time (HIP events, `reps` launches), fractions of the LDS roof and
+    duplicate-merge ratio; `quote` names the slowest -- the number to quote for this kernel."""
+    nx, ny, nz = dims
+    shape = d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0)
+    n_ev, reps = args.events, 8
+    cases = []
+
+    def uniform():
+        rig = syn.stereo_rig(2048, width=nx, height=ny, t0=10.0, duration=0.5, seed=4321, n_cams=1)   # poses only
+        rng = np.random.default_rng(4321)
+        ev = (rng.integers(0, nx, n_ev).astype(np.uint16), rng.integers(0, ny, n_ev).astype(np.uint16),
+              np.sort(rng.uniform(rig["t0"], rig["t1"], n_ev)))
+        return rig, ev, "uniformly random pixels, analytic rig trajectory"
+
+    def dense():
+        rig = syn.stereo_rig(n_ev, width=nx, height=ny, t0=10.0, duration=0.5, seed=4322, n_cams=1, n_points=200_000)
+        return rig, rig["events"][0], "200,000 scene points + 10 % noise, analytic rig trajectory"
+
+    def zurich():
+        z = np.load(os.path.join(ROOT, "tests", "golden", "zurich_city_04_poses_9_16s.npz"))
+        rig = syn.stereo_rig(n_ev, width=nx, height=ny, t0=10.0, duration=5.0, seed=4323, n_cams=1,
+                             n_points=args.points, pose_fn=syn.recorded_rig(z["times"], z["poses"]))
+        return rig, rig["events"][0], ("%d scene points + 10 %% noise along the recorded zurich_city_04 trajectory, 10-15 s"
+                                       % args.points)
+
+    for name, make in (("uniform_pixels", uniform), ("dense_scene", dense), ("zurich_city_04", zurich)):
+        t1 = time.perf_counter()
+        rig, ev, what = make()
+        first, Rt = d.packetize(ev[2], rig["trajectories"][0], rig["T_rv_w"])
+        batch = d.EventBatch(ctx, ev[0], ev[1], Rt, first)
+        m = tune(d.MapperEMVS(ctx, rig["cam"], shape))
+        m.evaluateDSI_batch(batch)                      # warm-up (allocations)
+        m.set_kernel_timing(True)
+        m.vote_kernel_time()
+        for _ in range(reps):
+            m.evaluateDSI_batch(batch)
+        ms, n = m.vote_kernel_time()
+        m.set_kernel_timing(False)
+        accepted, records = m.vote_statistics(batch)
+        rb = roofline_block(m.last_vote_info(), ms / max(1, n), n, accepted, first.shape[0] * d.PACKET_SIZE, nz, None, records)
+        cases.append({"case": name, "input": what, "events": int(first.shape[0] * d.PACKET_SIZE),
+                      "kernel": rb["kernel"], "kernel_avg_ms": rb["kernel_avg_ms"], "kernel_launches": n,
+                      "kernel_Mevents_per_s": rb["kernel_Mevents_per_s"], "frac": rb["frac"],
+                      "frac_issued": rb.get("frac_issued"),
+                      "records_per_accepted_event_plane": rb.get("records_per_accepted_event_plane"),
+                      "accepted_event_planes_per_launch": accepted, "prepare_s": time.perf_counter() - t1})
+        m.close()
+        batch.close()
+    return cases
+
+
 def other_workloads():
     """The one-GPU lines of BASELINE configs[2] (stream of 50 ms windows) and of the configs[4] shape (4 cameras,
     1024x1024x256, n-ary GM), each a sub-run of this script with its own roofline block, so that the driver's
@@ -435,10 +414,25 @@ def other_workloads():
 
 def main():
     args = parse()
-    D = Dist(args)
+    from dvs_mcemvs_amd import launch
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if not launch.launched_by_a_launcher():
+        if args.gpus > 1:
+            # nobody started the ranks: start them here, one process per GPU (never a smaller job)
+            import __graft_entry__ as ge
+            ge.build()
+            import dvs_mcemvs_amd as d0
+            n_dev = d0.device_count()
+            sys.exit(launch.spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                        n_devices=n_dev))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d contradicts WORLD_SIZE=%s of the launcher; refusing to guess"
+                         % (args.gpus, os.environ["WORLD_SIZE"]))
+    # (plumbing tests on a one-GPU box: DSI_BENCH_DEVICE=0 puts every rank on GPU 0 -- RCCL then refuses the
+    #  communicator and the run fails, which is the point of such a test)
+    D = launch.Dist(device=os.environ.get("DSI_BENCH_DEVICE"))
     world, rank = D.world, D.rank
-    if args.gpus != world and rank == 0:
-        print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -448,18 +442,28 @@ def main():
     from dvs_mcemvs_amd import distributed as dd, process as proc, synthetic as syn
 
     nx, ny, nz = args.dims
+    n_dev = d.device_count()
+    if D.local_rank >= n_dev:
+        raise SystemExit("bench.py rank %d: device %d requested but this node has %d GPU device(s); one rank per "
+                         "device, no fallback" % (rank, D.local_rank, n_dev))
     ctx = d.Context(D.local_rank)
-    allreduce, comm, collective, torch_group = make_comm(d, dd, ctx, D, args)
+    allreduce, comm, collective = make_comm(d, dd, ctx, D)
+    # the proof of the rank count: what RCCL itself reports for the communicator, gathered from every rank
+    rccl = comm.query() if comm is not None else None
+    ranks = D.gather({"rank": rank, "pid": os.getpid(), "hip_device": ctx.device,
+                      "rccl_nranks": rccl[0] if rccl else None, "rccl_rank": rccl[1] if rccl else None,
+                      "rccl_device": rccl[2] if rccl else None})
 
     def tune(m):
         m.set_vote_algo(args.algo)
         m.set_band_params(*args.band)
         m.set_packed_lanes(args.packed)
         if args.pass_lg:
-            import ctypes
-            L = d.load_library()
-            L.dsi_test_pass_lg.argtypes = [ctypes.c_void_p, ctypes.c_int]
-            L.dsi_test_pass_lg(m._h, args.pass_lg)
+            from dvs_mcemvs_amd import engine as eng
+            if not eng.experiments_requested():
+                raise SystemExit("--pass-lg is a knob of the experiments flavour of the engine: build it (python -m "
+                                 "dvs_mcemvs_amd.build --experiments) and run with DSI_ENGINE_EXPERIMENTS=1")
+            d.load_library().dsi_test_pass_lg(m._h, args.pass_lg)
         return m
 
     t_gen = time.time()
@@ -487,14 +491,9 @@ def main():
         if world > 1:
             ctx_side = d.Context(D.local_rank)
             mapper_fused = d.MapperEMVS(ctx_side, rig["cam"], shape)
-            if allreduce is not None:
-                temporal = dd.EnginePipelinedTemporalFusion(
-                    ctx, ctx_side, (nx, ny, nz), d.ACC_INV_SUM, world, allreduce, extract=mapper_fused.computeDepthMap,
-                    scattered=(mapper_fused, comm) if (args.temporal_collective == "reduce_scatter" and comm is not None)
-                    else None)
-            else:
-                temporal = dd.PipelinedTemporalFusion.on_gpu(ctx, ctx_side, (nx, ny, nz), d.ACC_INV_SUM, world,
-                                                             extract=mapper_fused.computeDepthMap, group=torch_group)
+            temporal = dd.EnginePipelinedTemporalFusion(
+                ctx, ctx_side, (nx, ny, nz), d.ACC_INV_SUM, world, allreduce, extract=mapper_fused.computeDepthMap,
+                scattered=(mapper_fused, comm) if args.temporal_collective == "reduce_scatter" else None)
             fused.resetGrid()
             temporal.submit(fused)      # one un-timed round: set-up problems show up here on every rank
             temporal.drain()
@@ -534,10 +533,10 @@ def main():
         concurrent = fused_vote and not args.serial_windows
         ws = proc.WindowStream(ctx, (rig["cam"],) * 2, shape, d.FUSE_HM, materialize_fused=args.materialize_fused,
                                fused_vote=fused_vote, concurrent=concurrent, depth=depth)
-        for ms_ in ws.mapper_sets:
-            for m in ms_:
-                tune(m)
-        vote_mappers = [m for ms_ in ws.mapper_sets for m in ms_]
+        for m in [m for ms_ in ws.mapper_sets for m in ms_] + ws.extract:
+            tune(m)
+        # (the fused kernel reads its knobs and its timer from the OUTPUT mapper of the call)
+        vote_mappers = ws.extract if fused_vote else [m for ms_ in ws.mapper_sets for m in ms_]
         bounds = proc.window_bounds(rig["t0"], rig["t1"] + 1e-9, dur, dur)[:n_distinct]
         wins, host_wins = [], []
         for wi, (a, b) in enumerate(bounds):
@@ -603,9 +602,6 @@ def main():
         extra["batch0"] = batches[0]
         fused = d.Grid3D(ctx, nx, ny, count)
         closers += mappers + batches + [fused]
-        if world > 1 and comm is None:
-            raise RuntimeError("cameras4 with N > 1 needs --collective engine")
-
         gm_mode = d.ACC_GM_TREE if args.gm == "tree" else d.ACC_LOG_SUM
 
         def step():
@@ -680,35 +676,40 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = voted_all * args.steps / elapsed / 1e6      # Mevents/s, whole job
     kern_ms = kt_ms / max(1, kt_n)
-    # accepted event-planes of one launch = sum of the DSI it wrote (the 4 bilinear weights of a vote sum to 1)
-    # records the voting kernel ACCEPTED in one launch (one record = up to `multiplicity` merged events of a packet
-    # with the same pixel = 4 LDS atomics actually issued): the same launch with every multiplicity forced to 1
-    def issued_records(pairs):
-        total = 0.0
-        for m, b in pairs:
-            m._unit_multiplicity(True)
-            m.evaluateDSI_batch(b)
-            total += float(np.sum(m.dsi_.download(), dtype=np.float64))
-            m._unit_multiplicity(False)
-        return total
-
+    # accepted event-planes of one launch = sum of the DSI it writes (the 4 bilinear weights of a vote sum to 1);
+    # accepted RECORDS = the same after the packet sort merged same-pixel events of a packet (one record = 4 LDS
+    # atomics actually issued): dsi_mapper_vote_statistics, outside the timed region
     if extra.get("fused_vote"):
-        # the fused kernel writes no DSI: build the two camera DSIs of one window once, outside the timed
-        # region, to count the accepted event-planes of a launch (both cameras are voted by one launch)
-        accepted = 0.0
-        lm = extra["last_mappers"]
-        for m, b in zip(lm, extra["last_window"]):
-            m.evaluateDSI_batch(b)
-            accepted += float(np.sum(m.dsi_.download(), dtype=np.float64))
-        records = issued_records(zip(lm, extra["last_window"]))
-        lm[0].computeDepthMapOfEvents(lm, extra["last_window"], d.FUSE_HM)   # restores last_vote_info
-        sync()
-        info = lm[0].last_vote_info()
+        # the fused kernel writes no DSI: the two camera DSIs of one window are built here, once, to count the work
+        # of a launch (both cameras are voted by one launch)
+        accepted = records = 0.0
+        for m, b in zip(extra["last_mappers"], extra["last_window"]):
+            a_, r_ = m.vote_statistics(b)
+            accepted += a_
+            records += r_
+    elif "batch0" in extra:
+        accepted, records = vote_mappers[0].vote_statistics(extra["batch0"])
     else:
-        accepted = float(np.sum(vote_mappers[0].dsi_.download(), dtype=np.float64))
-        records = issued_records([(vote_mappers[0], extra["batch0"])]) if "batch0" in extra else None
-        if records is not None:
-            vote_mappers[0].evaluateDSI_batch(extra["batch0"])          # back to the real DSI
+        accepted, records = float(np.sum(vote_mappers[0].dsi_.download(), dtype=np.float64)), None
+
+    # the collective alone (N > 1, stereo): K un-overlapped all-reduces of the accumulator-sized volume on the compute
+    # stream, all ranks in step -- the xGMI cost the pipelined run hides behind the next step's voting
+    collective_block = None
+    if comm is not None and args.workload == "stereo":
+        reps = 10
+        allreduce(fused, d.REDUCE_SUM)
+        barrier()
+        ctx.timer_start()
+        for _ in range(reps):
+            allreduce(fused, d.REDUCE_SUM)
+        coll_ms = D.max(ctx.timer_stop() / reps)
+        nbytes = 4.0 * nx * ny * nz
+        collective_block = {"op": "all-reduce(sum) of the inverse-sum accumulator, fp32 [%d][%d][%d]" % (nz, ny, nx),
+                            "bytes_per_rank": nbytes, "avg_ms_alone": coll_ms, "reps": reps,
+                            "algbw_GBps": nbytes / (coll_ms * 1e-3) / 1e9,
+                            "busbw_GBps": nbytes / (coll_ms * 1e-3) / 1e9 * 2.0 * (world - 1) / world,
+                            "per_step": "1 (on the side stream, overlapped with the next step's voting)",
+                            "form": args.temporal_collective}
 
     out = None
     if rank == 0:
@@ -819,6 +820,19 @@ def main():
         if not args.no_cpu and args.workload == "stereo" and world == 1:
             parity = parity_block(d, rig, (nx, ny, nz), mappers, batches, fused)
 
+        sensitivity = None
+        if args.workload == "stereo" and world == 1 and not args.no_sensitivity and not args.no_host_fed:
+            cases = sensitivity_block(d, syn, ctx, args, (nx, ny, nz), tune)
+            head = {"case": "headline", "input": "%d scene points + 10 %% noise, analytic rig trajectory" % args.points,
+                    "kernel_avg_ms": roofline.get("kernel_avg_ms"), "frac": roofline.get("frac"),
+                    "frac_issued": roofline.get("frac_issued"),
+                    "records_per_accepted_event_plane": roofline.get("records_per_accepted_event_plane")}
+            slowest = max(cases + [head], key=lambda c: c["kernel_avg_ms"] or 0.0)
+            sensitivity = {"cases": cases, "headline": head,
+                           "quote": {"case": slowest["case"], "kernel_avg_ms": slowest["kernel_avg_ms"],
+                                     "frac": slowest["frac"], "frac_issued": slowest["frac_issued"],
+                                     "note": "the slowest input: the figure to quote for this kernel"}}
+
         others = args.workload == "stereo" and world == 1 and not args.no_extra and not args.no_host_fed
         out = {
             "metric": "Mevents/s into DSI (346x260x100) + DSI-fuse GB/s",
@@ -828,7 +842,13 @@ def main():
             "config": {"workload": workload, "events_voted_per_step": voted_all, "vote_algo": info["algo"],
                        "bands": info["bands"], "band_rows": info["band_rows"], "chunks": info["chunks"],
                        "block_threads": info["block_threads"], "lds_bytes": info["lds_bytes"],
-                       "packed_lanes": info["packed"], "parallelism": parallelism, "collective": collective},
+                       "packed_lanes": info["packed"], "parallelism": parallelism, "collective": collective,
+                       "launched_by": ("a launcher (RANK / WORLD_SIZE in the environment)" if not D.spawned else
+                                       "bench.py itself (dvs_mcemvs_amd.launch.spawn_ranks), one process per GPU")
+                       if world > 1 else "single process"},
+            "rccl_ranks": rccl[0] if rccl else 1,
+            "ranks": ranks,
+            "collective": collective_block,
             "dsi_fuse_GBps": streams["dsi_fuse"]["GBps"] if streams else None,
             "dsi_fuse_ms": streams["dsi_fuse"]["ms"] if streams else None,
             "dsi_fuse_frac_of_hbm_peak": streams["dsi_fuse"]["frac_of_hbm_peak"] if streams else None,
@@ -843,6 +863,7 @@ def main():
                         (" of slot 0 (with two streams a step's events bracket parts of two windows)" if overlapped else "")}
             if step_ms.shape[0] else None,
             "parity": parity,
+            "sensitivity": sensitivity,
         }
         if others:
             out["other_workloads_pending"] = True

@@ -11,6 +11,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libdsi_engine.so")
+# the EXPERIMENTS flavour (-DDSI_TIMING_EXPERIMENTS: environment knobs + dsi_test_* hooks, some of which corrupt the
+# DSIs on purpose) is a DIFFERENT file, loaded only by an explicit opt-in (engine.load_library: DSI_ENGINE_EXPERIMENTS=1)
+OUT_EXPERIMENTS = os.path.join(HERE, "libdsi_engine_experiments.so")
 SOURCES = ["dsi_kernels.hip", "dsi_engine.cpp"]
 HEADERS = ["dsi_kernels.h", "dsi_host.hpp", os.path.join("..", "..", "include", "dsi_engine.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
@@ -24,27 +27,29 @@ def hipcc():
     raise RuntimeError("hipcc not found: cannot build the gfx950 DSI engine")
 
 
-def needs_build():
-    if not os.path.exists(OUT):
+def needs_build(out=OUT):
+    if not os.path.exists(out):
         return True
-    t = os.path.getmtime(OUT)
+    t = os.path.getmtime(out)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force=False, verbose=False, experiments=False):
-    """experiments=True (`--experiments`): also compile the environment knobs of the timing experiments quoted in
-    DESIGN.md (DSI_EXPERIMENT, DSI_PERSISTENT, DSI_PASS_LG, DSI_GROUP_PACKETS, DSI_PREP_OVERLAP).  The production
-    library does not read the environment."""
-    if not force and not experiments and not needs_build():
-        return OUT
+    """Builds the production library; experiments=True (`--experiments`) builds the experiments flavour INSTEAD, into
+    its own file (libdsi_engine_experiments.so): the environment knobs of the timing experiments quoted in DESIGN.md
+    (DSI_EXPERIMENT, DSI_PERSISTENT, DSI_PASS_LG, DSI_GROUP_PACKETS, DSI_PREP_OVERLAP) and the dsi_test_* hooks exist
+    only there.  The production library reads no environment and exports no test hook."""
+    out = OUT_EXPERIMENTS if experiments else OUT
+    if not force and not needs_build(out):
+        return out
     cmd = ([hipcc()] + FLAGS + (["-DDSI_TIMING_EXPERIMENTS"] if experiments else []) +
-           [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT + ".tmp"])
+           [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out + ".tmp"])
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    os.replace(OUT + ".tmp", OUT)
-    return OUT
+    os.replace(out + ".tmp", out)
+    return out
 
 
 if __name__ == "__main__":

@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -108,6 +109,9 @@ struct dsi_context {
     // i.e. no device synchronisation -- per call)
     void* collapse_scratch = nullptr;
     size_t collapse_scratch_bytes = 0;
+    // grids, mappers and batches created from this context and not yet destroyed: each holds a pointer to it, so the
+    // context refuses to go while any is alive (destroying it first was a use-after-free in their destroy)
+    std::atomic<int> children{0};
 };
 
 bool pool_take(dsi_context* ctx, size_t bytes, dsi_context::PoolBlock* out)
@@ -177,7 +181,7 @@ struct dsi_mapper {
     DevBuf<unsigned long long> fused_keys;   // dsi_mapper_depth_map_of_events: one arg-max key per pixel, kept zero between calls
     DevBuf<unsigned long long> fused_trace;  // test hook: time stamps of the fused kernel's phases
     bool fused_trace_on = false;
-    int unit_multiplicity = 0;  // test hook (dsi_test_unit_multiplicity)
+    int unit_multiplicity = 0;  // set only inside dsi_mapper_vote_statistics
     // fused kernel: records per (band, plane) pair of this camera's tables; the balanced partition; the cost of
     // a phase's set-up, pass switches, barriers and read-back in record units (measured with tools/fused_trace.py at
     // 512 x 512 x 200: a phase without records takes 8.6 us, a full one 18.7 us for ~38 k records)
@@ -726,6 +730,9 @@ int dsi_context_create(int device_id, dsi_context_t** out)
 int dsi_context_destroy(dsi_context_t* ctx)
 {
     if (!ctx) return DSI_OK;
+    REQUIRE(ctx->children.load() == 0, DSI_ERR_CONTEXT,
+            "%d object(s) created from this context (grids, mappers, batches) are still alive: destroy them first",
+            ctx->children.load());
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
@@ -840,6 +847,7 @@ static int grid_make(dsi_context_t* ctx, int nx, int ny, int nz, void* wrap, dsi
         }
         g->owned = true;
     }
+    ++ctx->children;
     *out = g;
     return DSI_OK;
 }
@@ -864,6 +872,7 @@ int dsi_grid_destroy(dsi_grid_t* g)
     (void)hipSetDevice(g->ctx->device);
     (void)hipStreamSynchronize(g->ctx->stream);
     if (g->owned && g->data) (void)hipFree(g->data);
+    --g->ctx->children;
     delete g;
     return DSI_OK;
 }
@@ -1080,6 +1089,7 @@ int dsi_mapper_create(dsi_context_t* ctx, const dsi_mapper_config_t* cfg, dsi_ma
     dsi_mapper* m = new (std::nothrow) dsi_mapper();
     REQUIRE(m, DSI_ERR_INVALID, "out of host memory");
     m->ctx = ctx;
+    ++ctx->children;
     m->sensor_w = cfg->sensor_width;
     m->sensor_h = cfg->sensor_height;
     dsi::Geom& g = m->geom;
@@ -1177,6 +1187,7 @@ int dsi_mapper_destroy(dsi_mapper_t* m)
         (void)hipEventDestroy(pr.second);
     }
     for (hipEvent_t e : m->timing_pool) (void)hipEventDestroy(e);
+    --m->ctx->children;
     delete m;
     return DSI_OK;
 }
@@ -1276,6 +1287,7 @@ static int batch_create(dsi_context_t* ctx, const uint16_t* x, const uint16_t* y
     dsi_batch* b = new (std::nothrow) dsi_batch();
     REQUIRE(b, DSI_ERR_INVALID, "out of host memory");
     b->ctx = ctx;
+    ++ctx->children;
     b->n_events = n_events;
     b->n_packets = n_packets;
     // one block: Rt | first | x | y (256-byte aligned parts), uploaded on the context's stream
@@ -1284,6 +1296,7 @@ static int batch_create(dsi_context_t* ctx, const uint16_t* x, const uint16_t* y
     const size_t first_bytes = packet_first ? up(std::max<size_t>(n_packets, 1) * sizeof(uint32_t)) : 0;
     const size_t ev_bytes = up(std::max<size_t>(n_events, 1) * sizeof(uint16_t));
     if (!pool_take(ctx, rt_bytes + first_bytes + 2 * ev_bytes, &b->block)) {
+        --ctx->children;
         delete b;
         return fail(DSI_ERR_HIP, "batch allocation of %zu bytes failed", rt_bytes + first_bytes + 2 * ev_bytes);
     }
@@ -1358,6 +1371,7 @@ int dsi_batch_destroy(dsi_batch_t* b)
     if (b->ready) (void)hipStreamWaitEvent(b->ctx->stream, b->ready, 0);
     pool_give(b->ctx, b->block);  // no wait: the block's "freed" event orders its reuse
     if (b->ready) (void)hipEventDestroy(b->ready);
+    --b->ctx->children;
     delete b;
     return DSI_OK;
 }
@@ -1542,7 +1556,9 @@ int dsi_mapper_depth_map_of_events(dsi_mapper_t* out, dsi_mapper_t* const* mappe
     REQUIRE(out->geom.nz <= 256, DSI_ERR_INVALID, "arg-max indices are u8: dimZ must be <= 256 (got %d)", out->geom.nz);
     if (int rc = set_device(ctx)) return rc;
     dsi::BandPlan bp{};
-    REQUIRE(plan_fused(mappers[0], np_max, &bp), DSI_ERR_INVALID, "grid rows of %d floats do not fit the fused kernel", out->geom.nx);
+    // every knob of this path (lane mapping, band height, the kernel timer, the experiments flavour's pass size, partition
+    // cost and tracing) is read from ONE object, the output mapper; the vote info is recorded on it and on the cameras
+    REQUIRE(plan_fused(out, np_max, &bp), DSI_ERR_INVALID, "grid rows of %d floats do not fit the fused kernel", out->geom.nx);
     const dsi::Geom& geom = mappers[0]->geom;
     hipStream_t st = ctx->stream;
     dsi::FusedCameras cams{};
@@ -1583,6 +1599,8 @@ int dsi_mapper_depth_map_of_events(dsi_mapper_t* out, dsi_mapper_t* const* mappe
         m->info.packed = bp.packed;
         m->info.group_packets = 1;
     }
+    out->info = mappers[0]->info;
+    out->info.n_packets = np_max;
     // stage A + packet sort of all cameras in one launch, their coefficient / cut tables in another
     // (a window's ~490 packets per camera do not fill the chip: two launches each would only add latency)
     HIP_TRY(dsi::launch_prepare_cameras(st, prep, n, geom, bp));
@@ -1608,9 +1626,9 @@ int dsi_mapper_depth_map_of_events(dsi_mapper_t* out, dsi_mapper_t* const* mappe
     }
     out->fused_keys_dirty = true;
     {
-        VoteTimer vt(mappers[0]);
+        VoteTimer vt(out);
         HIP_TRY(dsi::launch_vote_fuse_argmax(st, cams, geom, bp, op, splits, out->fused_keys.p,
-                                             mappers[0]->fused_trace_on ? mappers[0]->fused_trace.p : nullptr));
+                                             out->fused_trace_on ? out->fused_trace.p : nullptr));
         vt.stop();
     }
     // keys -> confidence, index, depth over the planes the cameras voted (mapper_emvs_stereo.cpp:302-313)
@@ -1742,6 +1760,44 @@ int dsi_mapper_last_vote_info(const dsi_mapper_t* m, dsi_vote_info_t* info)
     return DSI_OK;
 }
 
+/* Diagnostics of the voting kernel's work on one batch (bench.py: roofline.achieved / frac_issued).  Votes the batch
+ * twice: once with every merged record counted once -- the sum of that DSI is the number of RECORDS the voting kernel
+ * accepted, a quarter of the LDS atomics it issues -- and once as dsi_mapper_evaluate_batch does, whose DSI sums to the
+ * accepted event-planes (the four bilinear weights of a vote sum to 1) and is what the mapper's grid holds afterwards.
+ * The switch that makes the first pass is internal: no caller can leave it on.  Synchronises. */
+int dsi_mapper_vote_statistics(dsi_mapper_t* m, const dsi_batch_t* batch, double* accepted_event_planes, double* accepted_records)
+{
+    REQUIRE(m && batch && accepted_event_planes && accepted_records, DSI_ERR_INVALID, "null argument");
+    std::vector<float> host(m->grid->n);
+    double sums[2] = {0.0, 0.0};
+    for (int pass = 0; pass < 2; ++pass) {
+        m->unit_multiplicity = pass == 0 ? 1 : 0;
+        const int rc = dsi_mapper_evaluate_batch(m, batch);
+        m->unit_multiplicity = 0;
+        if (rc != DSI_OK) return rc;
+        if (int rc2 = dsi_grid_download(m->grid, host.data())) return rc2;
+        double t = 0.0;
+        for (float v : host) t += (double)v;
+        sums[pass] = t;
+    }
+    *accepted_records = sums[0];
+    *accepted_event_planes = sums[1];
+    return DSI_OK;
+}
+
+int dsi_build_flavour(void)
+{
+#ifdef DSI_TIMING_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
+
+#ifdef DSI_TIMING_EXPERIMENTS
+/* Everything from here to the #endif exists only in the EXPERIMENTS flavour of the library
+ * (libdsi_engine_experiments.so, `python -m dvs_mcemvs_amd.build --experiments`): hooks of the timing experiments and
+ * development tools quoted in DESIGN.md.  The production library exports no dsi_test_* symbol (tests/test_abi.py). */
 /* test hook (not in the public header): packets per pass of the voting streams, as a power of two (0 = automatic) */
 DSI_API int dsi_test_pass_lg(dsi_mapper_t* m, int lg)
 {
@@ -1756,16 +1812,6 @@ DSI_API int dsi_test_fused_fixed_cost(dsi_mapper_t* m, int records)
 {
     REQUIRE(m, DSI_ERR_INVALID, "mapper is null");
     m->fused_fixed_cost = records;
-    return DSI_OK;
-}
-
-/* test hook (not in the public header): with flag != 0 the packet sort gives every merged record the
- * multiplicity 1 instead of the number of events it stands for, so that the sum of the DSI counts the
- * RECORDS the voting kernel accepted = a quarter of the LDS atomics it issued (bench.py: roofline.frac_issued) */
-DSI_API int dsi_test_unit_multiplicity(dsi_mapper_t* m, int flag)
-{
-    REQUIRE(m, DSI_ERR_INVALID, "mapper is null");
-    m->unit_multiplicity = flag != 0;
     return DSI_OK;
 }
 
@@ -1841,6 +1887,7 @@ DSI_API int dsi_test_div_probe(dsi_context_t* ctx, const float* n, const float* 
     if (e != hipSuccess) return fail(DSI_ERR_HIP, "div probe failed: %s", hipGetErrorString(e));
     return DSI_OK;
 }
+#endif  // DSI_TIMING_EXPERIMENTS
 
 }  // extern "C"
 
@@ -1860,6 +1907,9 @@ struct Rccl {
                                   hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;     // what RCCL itself says about a communicator
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;  // (bench.py prints it: proof of the rank count)
+    ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string error;
 };
@@ -1910,6 +1960,9 @@ Rccl* load_rccl()
         r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
         r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
+        r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(sym("ncclCommUserRank"));
+        r.CommCuDevice = reinterpret_cast<decltype(r.CommCuDevice)>(sym("ncclCommCuDevice"));
     });
     return &r;
 }
@@ -2111,7 +2164,7 @@ static int sharded_prepare(dsi_mapper_t* m, dsi_grid_t* g)
                                        nullptr));
     HIP_TRY(dsi::launch_pack_argmax(m->ctx->stream, m->conf.p, m->idx.p, (int)npix, m->plane_begin,
                                     m->argmax_keys.p, 0));
-    return DSI_OK;
+    return release_to(g->ctx, m->ctx);  // the collapse READ g on the mapper's stream
 }
 
 static int sharded_finish(dsi_mapper_t* m)
@@ -2182,28 +2235,31 @@ static int scattered_check(dsi_mapper_t* m, dsi_grid_t* acc, dsi_comm_t* c, int 
     return DSI_OK;
 }
 
-// the two collectives on the accumulator (callers bracket several ranks with ncclGroupStart / End)
+// the two collectives on the accumulator (callers bracket several ranks with ncclGroupStart / End); which planes go
+// where is dsi::host::scatter_plan's business (shared with the host-staged tests)
 static ncclResult_t scattered_reduce(Rccl* r, dsi_grid_t* acc, dsi_comm_t* c, ncclRedOp_t nop)
 {
     const size_t plane = (size_t)acc->nx * acc->ny;
-    const int q = acc->nz / c->size, rem = acc->nz - q * c->size;
+    dsi::host::ScatterPlan sp;
+    if (!dsi::host::scatter_plan(acc->nz, c->size, c->rank, &sp)) return ncclInvalidArgument;
     ncclResult_t e = ncclSuccess;
-    if (q > 0)  // in place: the receive buffer is this rank's stretch of the send buffer
-        e = r->ReduceScatter(acc->data, acc->data + (size_t)c->rank * q * plane, (size_t)q * plane, ncclFloat32, nop, c->comm,
+    if (sp.q > 0)  // in place: the receive buffer is this rank's stretch of the send buffer
+        e = r->ReduceScatter(acc->data, acc->data + (size_t)sp.own_begin * plane, (size_t)sp.q * plane, ncclFloat32, nop, c->comm,
                              acc->ctx->stream);
-    if (e == ncclSuccess && rem > 0) {
-        float* tail = acc->data + (size_t)q * c->size * plane;
-        e = r->AllReduce(tail, tail, (size_t)rem * plane, ncclFloat32, nop, c->comm, acc->ctx->stream);
+    if (e == ncclSuccess && sp.tail_count > 0) {
+        float* tail = acc->data + (size_t)sp.tail_begin * plane;
+        e = r->AllReduce(tail, tail, (size_t)sp.tail_count * plane, ncclFloat32, nop, c->comm, acc->ctx->stream);
     }
     return e;
 }
 
-// finalize + arg-max of the planes this rank owns -> packed keys (on the mapper's stream)
-static int scattered_local(dsi_mapper_t* m, dsi_grid_t* acc, dsi_comm_t* c, int mode, int n_maps)
+// finalize + arg-max of the planes rank `rank` of `nranks` owns -> packed keys (on the mapper's stream)
+static int scattered_local(dsi_mapper_t* m, dsi_grid_t* acc, int nranks, int rank, int mode, int n_maps)
 {
     if (int rc = set_device(m->ctx)) return rc;
     const size_t plane = (size_t)acc->nx * acc->ny;
-    const int q = acc->nz / c->size, rem = acc->nz - q * c->size;
+    dsi::host::ScatterPlan sp;
+    REQUIRE(dsi::host::scatter_plan(acc->nz, nranks, rank, &sp), DSI_ERR_INVALID, "rank %d of %d", rank, nranks);
     HIP_TRY(m->conf.reserve(plane));
     HIP_TRY(m->depth.reserve(plane));
     HIP_TRY(m->idx.reserve(plane));
@@ -2212,7 +2268,7 @@ static int scattered_local(dsi_mapper_t* m, dsi_grid_t* acc, dsi_comm_t* c, int 
     if (int rc = dsi_context_wait_for(m->ctx, acc->ctx)) return rc;
     if (int rc = depth_buffers_acquire(m)) return rc;
     hipStream_t st = m->ctx->stream;
-    const int begin[2] = {c->rank * q, q * c->size}, count[2] = {q, rem};
+    const int begin[2] = {sp.own_begin, sp.tail_begin}, count[2] = {sp.own_count, sp.tail_count};
     bool first = true;
     for (int k = 0; k < 2; ++k) {
         if (count[k] <= 0) continue;
@@ -2223,7 +2279,9 @@ static int scattered_local(dsi_mapper_t* m, dsi_grid_t* acc, dsi_comm_t* c, int 
         first = false;
     }
     if (first) HIP_TRY(hipMemsetAsync(m->argmax_keys.p, 0, plane * sizeof(unsigned long long), st));  // owns no plane
-    return DSI_OK;
+    // finalize WROTE the accumulator on the mapper's stream: whatever the accumulator's context queues next (the
+    // next round's accumulateBegin) must come after it
+    return release_to(acc->ctx, m->ctx);
 }
 
 int dsi_mapper_depth_map_reduce_scattered(dsi_mapper_t* m, dsi_grid_t* acc, dsi_comm_t* c, int mode, int n_maps)
@@ -2239,7 +2297,7 @@ int dsi_mapper_depth_map_reduce_scattered(dsi_mapper_t* m, dsi_grid_t* acc, dsi_
     const ncclResult_t e2 = r->GroupEnd();
     if (e != ncclSuccess) return fail(DSI_ERR_COMM, "reduce-scatter failed: %s", r->GetErrorString(e));
     if (e2 != ncclSuccess) return fail(DSI_ERR_COMM, "ncclGroupEnd failed: %s", r->GetErrorString(e2));
-    if (int rc = scattered_local(m, acc, c, mode, n_maps)) return rc;
+    if (int rc = scattered_local(m, acc, c->size, c->rank, mode, n_maps)) return rc;
     const size_t npix = (size_t)acc->nx * acc->ny;
     RCCL_TRY(r, r->AllReduce(m->argmax_keys.p, m->argmax_keys.p, npix, ncclUint64, ncclMax, c->comm, m->ctx->stream));
     return sharded_finish(m);
@@ -2268,7 +2326,7 @@ int dsi_mapper_depth_map_reduce_scattered_all(dsi_mapper_t* const* ms, dsi_grid_
     if (bad != ncclSuccess) return fail(DSI_ERR_COMM, "reduce-scatter failed: %s", r->GetErrorString(bad));
     if (e2 != ncclSuccess) return fail(DSI_ERR_COMM, "ncclGroupEnd failed: %s", r->GetErrorString(e2));
     for (int i = 0; i < n; ++i)
-        if (int rc = scattered_local(ms[i], accs[i], cs[i], mode, n_maps)) return rc;
+        if (int rc = scattered_local(ms[i], accs[i], cs[i]->size, cs[i]->rank, mode, n_maps)) return rc;
     const size_t npix = (size_t)accs[0]->nx * accs[0]->ny;
     RCCL_TRY(r, r->GroupStart());
     for (int i = 0; i < n; ++i) {
@@ -2282,6 +2340,123 @@ int dsi_mapper_depth_map_reduce_scattered_all(dsi_mapper_t* const* ms, dsi_grid_
     if (e2 != ncclSuccess) return fail(DSI_ERR_COMM, "ncclGroupEnd failed: %s", r->GetErrorString(e2));
     for (int i = 0; i < n; ++i)
         if (int rc = sharded_finish(ms[i])) return rc;
+    return DSI_OK;
+}
+
+/* ---- the same three steps with the transport left to the caller (host-staged tests, other transports) ---- */
+int dsi_scatter_plan(int nz, int nranks, int rank, dsi_scatter_plan_t* out)
+{
+    REQUIRE(out, DSI_ERR_INVALID, "out is null");
+    dsi::host::ScatterPlan sp;
+    REQUIRE(dsi::host::scatter_plan(nz, nranks, rank, &sp), DSI_ERR_INVALID, "bad partition: %d planes, rank %d of %d", nz, rank,
+            nranks);
+    out->q = sp.q;
+    out->own_begin = sp.own_begin;
+    out->own_count = sp.own_count;
+    out->tail_begin = sp.tail_begin;
+    out->tail_count = sp.tail_count;
+    return DSI_OK;
+}
+
+int dsi_plane_range(int nz, int nranks, int rank, int* begin, int* count)
+{
+    REQUIRE(begin && count, DSI_ERR_INVALID, "null argument");
+    REQUIRE(dsi::host::plane_range(nz, nranks, rank, begin, count), DSI_ERR_INVALID, "bad partition: %d planes, rank %d of %d",
+            nz, rank, nranks);
+    return DSI_OK;
+}
+
+int dsi_argmax_keys_pack(const float* conf, const uint8_t* idx_local, size_t n, int plane_begin, uint64_t* keys)
+{
+    REQUIRE(n == 0 || (conf && idx_local && keys), DSI_ERR_INVALID, "null argument");
+    REQUIRE(plane_begin >= 0 && plane_begin <= 255, DSI_ERR_INVALID, "plane_begin %d outside 0..255", plane_begin);
+    for (size_t i = 0; i < n; ++i) {
+        const int gp = (int)idx_local[i] + plane_begin;
+        REQUIRE(gp <= 255, DSI_ERR_INVALID, "global plane index %d does not fit the key's 8 bits", gp);
+        keys[i] = dsi::host::argmax_key(conf[i], gp);
+    }
+    return DSI_OK;
+}
+
+int dsi_argmax_keys_unpack(const uint64_t* keys, size_t n, float* conf, uint8_t* idx)
+{
+    REQUIRE(n == 0 || (keys && conf && idx), DSI_ERR_INVALID, "null argument");
+    for (size_t i = 0; i < n; ++i) {
+        int gp = 0;
+        dsi::host::argmax_unkey(keys[i], &conf[i], &gp);
+        idx[i] = (uint8_t)gp;
+    }
+    return DSI_OK;
+}
+
+int dsi_mapper_depth_map_scattered_local(dsi_mapper_t* m, dsi_grid_t* acc, int nranks, int rank, int mode, int n_maps)
+{
+    REQUIRE(m && acc, DSI_ERR_INVALID, "null argument");
+    REQUIRE(valid_acc_mode(mode), DSI_ERR_BAD_OP, "bad accumulate mode %d", mode);
+    REQUIRE(m->ctx->device == acc->ctx->device, DSI_ERR_CONTEXT, "mapper and accumulator must live on one device");
+    REQUIRE(same_shape(m->grid, acc), DSI_ERR_SHAPE, "accumulator shape differs from the mapper's DSI");
+    REQUIRE(m->plane_begin == 0 && (int)m->planes_full.size() == acc->nz, DSI_ERR_INVALID,
+            "the mapper must own the whole depth vector (time slices shard by time, not by plane)");
+    REQUIRE(acc->nz <= 256, DSI_ERR_INVALID, "arg-max indices are u8: dimZ must be <= 256 (got %d)", acc->nz);
+    REQUIRE(n_maps >= 1, DSI_ERR_INVALID, "number of maps must be >= 1 (got %d)", n_maps);
+    return scattered_local(m, acc, nranks, rank, mode, n_maps);
+}
+
+int dsi_mapper_argmax_keys_download(dsi_mapper_t* m, uint64_t* host)
+{
+    REQUIRE(m && host, DSI_ERR_INVALID, "null argument");
+    const size_t npix = (size_t)m->geom.nx * m->geom.ny;
+    REQUIRE(m->argmax_keys.cap >= npix, DSI_ERR_INVALID, "this mapper holds no arg-max keys");
+    if (int rc = set_device(m->ctx)) return rc;
+    HIP_TRY(hipMemcpyAsync(host, m->argmax_keys.p, npix * sizeof(uint64_t), hipMemcpyDeviceToHost, m->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+    return DSI_OK;
+}
+
+int dsi_mapper_argmax_keys_upload(dsi_mapper_t* m, const uint64_t* host)
+{
+    REQUIRE(m && host, DSI_ERR_INVALID, "null argument");
+    const size_t npix = (size_t)m->geom.nx * m->geom.ny;
+    if (int rc = set_device(m->ctx)) return rc;
+    HIP_TRY(m->argmax_keys.reserve(npix));
+    HIP_TRY(hipMemcpyAsync(m->argmax_keys.p, host, npix * sizeof(uint64_t), hipMemcpyHostToDevice, m->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(m->ctx->stream));  // the source is pageable host memory
+    return DSI_OK;
+}
+
+int dsi_mapper_depth_map_from_keys(dsi_mapper_t* m)
+{
+    REQUIRE(m, DSI_ERR_INVALID, "mapper is null");
+    const size_t npix = (size_t)m->geom.nx * m->geom.ny;
+    REQUIRE(m->argmax_keys.cap >= npix, DSI_ERR_INVALID, "this mapper holds no arg-max keys");
+    if (int rc = set_device(m->ctx)) return rc;
+    HIP_TRY(m->conf.reserve(npix));
+    HIP_TRY(m->depth.reserve(npix));
+    HIP_TRY(m->idx.reserve(npix));
+    if (int rc = ensure_planes_full_dev(m)) return rc;
+    if (int rc = depth_buffers_acquire(m)) return rc;
+    return sharded_finish(m);
+}
+
+int dsi_comm_query(const dsi_comm_t* c, int* nranks, int* rank, int* device)
+{
+    REQUIRE(c && c->comm, DSI_ERR_INVALID, "communicator is null");
+    Rccl* r = nullptr;
+    if (int rc = rccl_ready(&r)) return rc;
+    REQUIRE(r->CommCount && r->CommUserRank && r->CommCuDevice, DSI_ERR_COMM, "librccl lacks the communicator queries");
+    int v = 0;
+    if (nranks) {
+        RCCL_TRY(r, r->CommCount(c->comm, &v));
+        *nranks = v;
+    }
+    if (rank) {
+        RCCL_TRY(r, r->CommUserRank(c->comm, &v));
+        *rank = v;
+    }
+    if (device) {
+        RCCL_TRY(r, r->CommCuDevice(c->comm, &v));
+        *device = v;
+    }
     return DSI_OK;
 }
 

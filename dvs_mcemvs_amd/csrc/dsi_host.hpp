@@ -155,5 +155,66 @@ inline bool packetize(const double* ts, size_t n_events, const double* times, co
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Multi-GPU partition arithmetic.  Pure functions: the RCCL path (dsi_engine.cpp), the
+// host-staged 2-rank GPU tests and the CPU tests all take their offsets from here, so that on an
+// 8-GPU node only the nccl* calls themselves are new code.
+
+// Temporal fusion as a reduce-scatter by planes: rank r of n reduces planes [r q, (r+1) q), q = nz / n
+// (ncclReduceScatter needs equal counts); the nz mod n planes left over are all-reduced, so EVERY rank
+// owns them as a second range.  A rank's arg-max runs over its two ranges; the keys' MAX over the ranks
+// is the arg-max over all planes.
+struct ScatterPlan {
+    int q = 0;           // planes per rank in the reduce-scatter part
+    int own_begin = 0;   // first plane of this rank's reduce-scatter range (own_count == q)
+    int own_count = 0;
+    int tail_begin = 0;  // planes [tail_begin, tail_begin + tail_count) are all-reduced (owned by every rank)
+    int tail_count = 0;
+};
+
+inline bool scatter_plan(int nz, int nranks, int rank, ScatterPlan* out)
+{
+    if (nz < 1 || nranks < 1 || rank < 0 || rank >= nranks) return false;
+    ScatterPlan p;
+    p.q = nz / nranks;
+    p.own_begin = rank * p.q;
+    p.own_count = p.q;
+    p.tail_begin = p.q * nranks;
+    p.tail_count = nz - p.tail_begin;
+    *out = p;
+    return true;
+}
+
+// Plane sharding of one big DSI (configs[4]): contiguous, balanced ranges; the first nz mod n ranks own
+// one plane more.  (Ranges may be empty when n > nz.)
+inline bool plane_range(int nz, int nranks, int rank, int* begin, int* count)
+{
+    if (nz < 1 || nranks < 1 || rank < 0 || rank >= nranks) return false;
+    const int base = nz / nranks, extra = nz % nranks;
+    *begin = rank * base + (rank < extra ? rank : extra);
+    *count = base + (rank < extra ? 1 : 0);
+    return true;
+}
+
+// One arg-max key per pixel: (confidence bits << 8) | (255 - global plane index).  MAX over shards =
+// Grid3D::collapseMaxZSlice over all planes (cartesian3dgrid.cpp:115-137, std::max_element: the larger
+// confidence wins and, on equal confidence, the smaller plane index).  DSI values are >= 0 and never
+// -0.0, so their bit patterns order like the floats.  The device kernels (k_pack_argmax,
+// k_unpack_argmax, the fused vote) build the same word.
+inline uint64_t argmax_key(float conf, int global_plane)
+{
+    uint32_t bits;
+    static_assert(sizeof bits == sizeof conf, "fp32");
+    __builtin_memcpy(&bits, &conf, sizeof bits);
+    return ((uint64_t)bits << 8) | (uint64_t)(255 - global_plane);
+}
+
+inline void argmax_unkey(uint64_t key, float* conf, int* global_plane)
+{
+    const uint32_t bits = (uint32_t)(key >> 8);
+    __builtin_memcpy(conf, &bits, sizeof bits);
+    *global_plane = 255 - (int)(key & 255u);
+}
+
 }  // namespace host
 }  // namespace dsi

@@ -123,6 +123,17 @@ struct FusedCameras {
     int n;  // 1 (vote -> arg-max), 2 (vote x 2 -> op -> arg-max) or 3 (process1.cpp:169-191: the trinocular rig --
             // op 1 min, 2 harmonicMeanTwoGrids(g, 3), 6 max of the two-camera result and camera 2)
 };
+// LAYOUT LOCK: k_vote_fuse_argmax reads cam[c] with scalar loads straight from the kernel-argument segment
+// (__builtin_amdgcn_kernarg_segment_ptr), which holds because (i) `cams` is the kernel's FIRST parameter, so cam[0]
+// sits at offset 0 of the segment, and (ii) a by-value struct parameter keeps its host layout there (code object v5:
+// by-value aggregates are copied verbatim, aligned to their natural alignment).  Reordering the kernel's parameters or
+// these fields breaks (i) / (ii); the asserts below and the one in the kernel catch the second kind at compile time.
+static_assert(sizeof(FusedCamera) == 40 && alignof(FusedCamera) == 8, "FusedCamera: 4 pointers + int, 8-byte aligned");
+static_assert(offsetof(FusedCamera, sxy) == 0 && offsetof(FusedCamera, coef) == 8 && offsetof(FusedCamera, cuts) == 16 &&
+                  offsetof(FusedCamera, slow_any) == 24 && offsetof(FusedCamera, np) == 32,
+              "FusedCamera field offsets are read from the kernarg segment");
+static_assert(offsetof(FusedCameras, cam) == 0 && sizeof(FusedCameras) == kFusedMaxCameras * sizeof(FusedCamera) + 8,
+              "FusedCameras: the camera table starts the struct (and so the kernel-argument segment)");
 // The preparation of up to three cameras in two launches instead of two per camera (stage A + packet sort; coefficient /
 // cut tables), optionally counting the records per (band, plane) pair for launch_fused_splits.
 struct PrepCameraArgs {

@@ -2440,6 +2440,7 @@ __global__ __launch_bounds__(1024) void k_vote_fuse_argmax(FusedCameras cams, Ge
     // camera index: indexing the by-value array dynamically made the compiler keep all three cameras' pointers in
     // registers next to the ~40 the voting loops name (or copy the table to scratch).  `cams` is the FIRST argument,
     // so cam[0] starts the segment.
+    // (layout lock: dsi_kernels.h, next to FusedCameras)
     typedef const FusedCamera __attribute__((address_space(4))) * KernargCameras;
     const KernargCameras kcam = (KernargCameras)__builtin_amdgcn_kernarg_segment_ptr();
     auto camera = [&](int c) -> FusedCamera {
@@ -2502,15 +2503,20 @@ __global__ __launch_bounds__(1024) void k_vote_fuse_argmax(FusedCameras cams, Ge
 #pragma nounroll
         for (int c = 0; c < cams.n; ++c) {
             const FusedCamera cam = camera(c);
-            // development aid (test hook dsi_test_fused_trace_*): 100 MHz time stamps per (workgroup, phase, wave):
-            // stream begins, stream ends, after the barrier + the read-back / clear, after the closing barrier
+#ifdef DSI_TIMING_EXPERIMENTS
+            // development aid (experiments flavour only, dsi_test_fused_trace_*): 100 MHz time stamps per (workgroup,
+            // phase, wave): stream begins, stream ends, after the barrier + the read-back / clear, after the closing barrier
             int tr = -1;  // (wave-uniform: lives in a scalar register)
             if (trace) {
                 const int phase = (q - q_begin) * cams.n + c;
                 if (phase < kFusedTracePhases)
                     tr = __builtin_amdgcn_readfirstlane((((int)blockIdx.x * kFusedTracePhases + phase) * (BLOCK / kWave) + (int)(threadIdx.x / kWave)) * 4);
-                if (tr >= 0 && (threadIdx.x & 63) == 0) trace[tr] = wall_clock64();
             }
+#define DSI_FUSED_STAMP(k) do { if (tr >= 0 && (threadIdx.x & 63) == 0) trace[tr + (k)] = wall_clock64(); } while (0)
+#else
+#define DSI_FUSED_STAMP(k) do { } while (0)
+#endif
+            DSI_FUSED_STAMP(0);
             const uint32_t cuts_now = cuts_next;
             stream_item<BLOCK, MAPPING, true, true>(cam.sxy, cam.coef, cam.cuts, cam.slow_any, cam.np, g, bp, j, z, 0, cam.np,
                                         reinterpret_cast<char*>(band), Li, Ui, r0 - 1, &s_pass, cuts_now);
@@ -2519,7 +2525,7 @@ __global__ __launch_bounds__(1024) void k_vote_fuse_argmax(FusedCameras cams, Ge
                 cuts_next = first_cuts_of(q, c + 1);
             else if (q + 1 < q_end)
                 cuts_next = first_cuts_of(q + 1, 0);
-            if (tr >= 0 && (threadIdx.x & 63) == 0) trace[tr + 1] = wall_clock64();
+            DSI_FUSED_STAMP(1);
             __syncthreads();
             if (threadIdx.x == 0) s_pass = kPass0;
             const bool last = c == cams.n - 1;
@@ -2551,12 +2557,13 @@ __global__ __launch_bounds__(1024) void k_vote_fuse_argmax(FusedCameras cams, Ge
                 default: fused_consume<CELLS, 6, FUSED_LAST3>(band, nx, n_own, rows_lds, va, fb, z); break;
                 }
             }
-            if (tr >= 0 && (threadIdx.x & 63) == 0) trace[tr + 2] = wall_clock64();
+            DSI_FUSED_STAMP(2);
             __syncthreads();
-            if (tr >= 0 && (threadIdx.x & 63) == 0) trace[tr + 3] = wall_clock64();
+            DSI_FUSED_STAMP(3);
         }
     }
     emit();
+#undef DSI_FUSED_STAMP
 }
 
 // Balanced partition of the (band-major) pair list for the fused kernel: pair q costs work0[q] + work1[q]

@@ -1,27 +1,34 @@
 """Multi-GPU sharding of the DSI path: one process per GPU.
 
-The collective itself is the engine's (include/dsi_engine.h "multi-GPU": RCCL called from the C
-ABI, `Comm` / `Grid3D.allReduce` here); the Engine* classes below take the collective as a callable
-`allreduce(grid, op)` so that the same orchestration runs over RCCL (production), over a
-host-staged gloo all-reduce (2-rank tests on one GPU: RCCL allows one rank per device) or over
-nothing (one rank).  The older torch.distributed classes (tensor aliases + ExternalStream) remain
-for callers that already live in torch.
+The data-path collective is the ENGINE's (include/dsi_engine.h "multi-GPU": RCCL called from the C ABI,
+`Comm` / `Grid3D.allReduce` / `MapperEMVS.computeDepthMapSharded` / `...ReduceScattered`).  The orchestration
+classes below take it as a callable `allreduce(grid, op)`, so that the same code runs over RCCL (production,
+`engine_allreduce(comm)`), over a host-staged gloo exchange (`host_staged_allreduce()`: tests that put two
+ranks on ONE GPU, which RCCL refuses, and CPU tests with stand-in grids) or over nothing (one rank).  There is
+no second GPU collective backend: torch.distributed appears only as the side channel of tests and of bench.py
+(rendezvous, barriers, the RCCL unique id, a few scalars) -- see launch.py.
 
-What shards: time slices.  Alg. 2 of the reference (process2.cpp:98-249)
-splits an event stream into `num_subintervals` sub-intervals BY EVENT COUNT, builds one
-DSI per sub-interval and fuses them voxel-wise over time with
+What shards:
 
-    HM:  acc += 1/(0.01 + dsi_k)  for every k,  then  n/acc      (cartesian3dgrid.h:72-86)
-    AM:  acc += dsi_k,                          then  acc/n      (cartesian3dgrid.h:64-70, 87-93)
+* time slices -- Alg. 2 of the reference (process2.cpp:98-249) splits an event stream into
+  `num_subintervals` sub-intervals BY EVENT COUNT, builds one DSI per sub-interval and fuses them voxel-wise
+  over time with
+      HM:  acc += 1/(0.01 + dsi_k)  for every k,  then  n/acc      (cartesian3dgrid.h:72-86)
+      AM:  acc += dsi_k,                          then  acc/n      (cartesian3dgrid.h:64-70, 87-93)
+  Both accumulators are plain sums, so with slice k on rank k % world the whole temporal fusion is: local
+  accumulate -> ONE all-reduce(sum) of the volume -> local finalize (or: reduce-scatter by planes -> finalize
+  + arg-max of the owned planes -> all-reduce(MAX) of packed keys).  Events never move between GPUs.
+* planes -- one DSI too big for one GPU (configs[4]): rank r owns a contiguous plane range of every camera's
+  DSI, votes ALL events into it, fuses the cameras voxel-wise locally; the only exchange is one
+  all-reduce(MAX) of packed (confidence, plane) keys.
 
-Both accumulators are plain sums, so with slice k on rank k % world the whole temporal
-fusion is: local accumulate -> ONE all-reduce(sum) of the volume -> local finalize.  No
-other collective is on the data path (events never move between GPUs).
-
-This module holds only the partitioning arithmetic and the collective call; the
-accumulate / finalize maps are the engine's kernels (Grid3D.addInverseOfTwoGrids, ...).
+The partition arithmetic (which planes / slices a rank owns, the key word) lives in the engine
+(csrc/dsi_host.hpp, exported as dsi_scatter_plan / dsi_plane_range / dsi_argmax_keys_*): the functions here
+call it, they do not restate it.
 """
 import numpy as np
+
+from . import engine as E
 
 
 def subinterval_bounds(n_events, num_subintervals):
@@ -36,203 +43,26 @@ def slices_of_rank(num_slices, world_size, rank):
     return [k for k in range(int(num_slices)) if k % int(world_size) == int(rank)]
 
 
-def allreduce_sum_(tensor, group=None):
-    """In-place all-reduce(sum) of a volume accumulator.  `tensor` is a torch tensor on the
-    process's device (for the GPU path it aliases a Grid3D through Grid3D(device_ptr=...))."""
-    import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return tensor
-    dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group)
-    return tensor
-
-
-def allreduce_max_scalar(value, device=None, group=None):
-    """max over ranks of a python float (bench timing)."""
-    import torch
-    import torch.distributed as dist
-    if not dist.is_initialized():
-        return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-    return float(t.item())
-
-
 # ---------------------------------------------------------------- plane sharding (one big DSI)
 def plane_ranges(num_planes, world_size):
-    """Contiguous, balanced plane ranges [(begin, count)] per rank (the reference layout
+    """Contiguous, balanced plane ranges [(begin, count)] per rank (dsi_plane_range; the reference layout
     [z][y][x] makes a plane range a contiguous slab of the volume)."""
-    base, extra = divmod(int(num_planes), int(world_size))
-    out, b = [], 0
-    for r in range(int(world_size)):
-        c = base + (1 if r < extra else 0)
-        out.append((b, c))
-        b += c
-    return out
+    return [E.plane_range(num_planes, world_size, r) for r in range(int(world_size))]
 
 
 def pack_argmax_keys(conf, idx_local, plane_begin):
-    """(confidence, plane index) of a shard's collapseMaxZSlice -> one int64 per pixel whose MAX over
-    shards is the unsharded result: Grid3D::collapseMaxZSlice takes the FIRST maximum
-    (std::max_element, cartesian3dgrid.cpp:115-137), i.e. the larger confidence wins and, on equal
-    confidence, the smaller global plane index.  DSI values are >= 0, so their IEEE bit patterns
-    order like the floats."""
-    conf = np.ascontiguousarray(conf, np.float32)
-    bits = conf.view(np.uint32).astype(np.int64)
-    gidx = np.asarray(idx_local).astype(np.int64) + int(plane_begin)
-    return (bits << 8) | (255 - gidx)
+    """(confidence, plane index) of a shard's collapseMaxZSlice -> one 64-bit word per pixel whose MAX over
+    shards is the unsharded result: Grid3D::collapseMaxZSlice takes the FIRST maximum (std::max_element,
+    cartesian3dgrid.cpp:115-137), i.e. the larger confidence wins and, on equal confidence, the smaller global
+    plane index.  dsi_argmax_keys_pack -- the word k_pack_argmax builds on the device."""
+    return E.argmax_keys_pack(conf, idx_local, plane_begin)
 
 
 def unpack_argmax_keys(keys):
-    keys = np.asarray(keys, np.int64)
-    conf = (keys >> 8).astype(np.uint32).view(np.float32)
-    idx = (255 - (keys & 255)).astype(np.uint8)
-    return conf, idx
+    return E.argmax_keys_unpack(keys)
 
 
-def allreduce_argmax(conf, idx_local, plane_begin, device=None, group=None):
-    """The one collective of plane sharding: all-reduce(MAX) of the packed (confidence, index)
-    keys (8 B per pixel; 8 MB at 1024x1024).  Returns (conf f32, global idx u8) on every rank."""
-    import torch
-    import torch.distributed as dist
-    keys = pack_argmax_keys(conf, idx_local, plane_begin)
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
-        t = torch.from_numpy(keys)
-        if device is not None:
-            t = t.to(device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-        keys = t.cpu().numpy()
-    return unpack_argmax_keys(keys)
-
-
-class TemporalFusion:
-    """Temporal fusion of per-slice DSIs across ranks.
-
-    acc_grid : engine Grid3D that aliases `acc_tensor` (same device memory)
-    mode     : ACC_INV_SUM (temporal_fusion = 2, HM) or ACC_SUM (temporal_fusion = 4, AM)
-    """
-
-    def __init__(self, ctx, acc_grid, acc_tensor, mode, num_slices, group=None):
-        self.ctx, self.acc, self.tensor = ctx, acc_grid, acc_tensor
-        self.mode, self.n, self.group = int(mode), int(num_slices), group
-
-    def reset(self):
-        self.acc.resetGrid()
-
-    def add(self, dsi):
-        if self.mode == 1:
-            self.acc.addInverseOfTwoGrids(dsi)   # process2.cpp:218-220
-        else:
-            self.acc.addTwoGrids(dsi)            # process2.cpp:231-233
-
-    def finish(self):
-        """all-reduce the accumulator and finalize (process2.cpp:221-225 / :234-238).
-        On a GPU the collective is issued with the engine's HIP stream as torch's current stream,
-        so it is ordered after the accumulate kernels and before the finalize kernel on the
-        device; the host does not wait."""
-        if getattr(self.tensor, "is_cuda", False):
-            import torch
-            with torch.cuda.stream(torch.cuda.ExternalStream(self.ctx.stream)):
-                allreduce_sum_(self.tensor, self.group)
-        else:
-            allreduce_sum_(self.tensor, self.group)
-        if self.mode == 1:
-            self.acc.computeHMfromSumOfInv(self.n)
-        else:
-            self.acc.computeAMfromSum(self.n)
-        return self.acc
-
-
-class PipelinedTemporalFusion:
-    """TemporalFusion for a STREAM of fusion rounds (sliding windows, main.cpp:177; bench steps):
-    round k's all-reduce + finalize + depth-map extraction run on a second HIP stream while the
-    main stream already votes round k+1.  The volume accumulator is double-buffered.
-
-        main stream :  ... vote, camera-fuse(k) | acc[k%2] = f(fused)      | vote, camera-fuse(k+1) ...
-        side stream :                            wait | all-reduce(acc[k%2]), finalize, arg-max |
-
-    Device-side ordering only (events); the host never blocks in submit().
-
-    slots   : list of dicts {"tensor": torch tensor [Nz][Ny][Nx], "acc_main": Grid3D aliasing it in
-              the main context, "acc_side": Grid3D aliasing it in the side context}
-    streams : (main, side) torch streams wrapping the two contexts' HIP streams, or None to run
-              everything in program order (CPU tests)
-    extract : optional callable(acc_side_grid) run on the side stream after finalize
-              (e.g. mapper_fused.computeDepthMap)
-    """
-
-    def __init__(self, slots, mode, num_slices, streams=None, extract=None, group=None):
-        self.slots, self.mode, self.n = slots, int(mode), int(num_slices)
-        self.streams, self.extract, self.group = streams, extract, group
-        self.k = 0
-        for s in self.slots:
-            s["used"] = False
-            if streams is not None:
-                import torch
-                s["filled"], s["free"] = torch.cuda.Event(), torch.cuda.Event()
-
-    @classmethod
-    def on_gpu(cls, ctx_main, ctx_side, dims, mode, num_slices, extract=None, depth=2, group=None):
-        import torch
-        from .engine import Grid3D
-        nx, ny, nz = dims
-        slots = []
-        for _ in range(depth):
-            t = torch.empty((nz, ny, nx), dtype=torch.float32, device="cuda")
-            slots.append({"tensor": t,
-                          "acc_main": Grid3D(ctx_main, nx, ny, nz, device_ptr=t.data_ptr()),
-                          "acc_side": Grid3D(ctx_side, nx, ny, nz, device_ptr=t.data_ptr())})
-        streams = (torch.cuda.ExternalStream(ctx_main.stream), torch.cuda.ExternalStream(ctx_side.stream))
-        obj = cls(slots, mode, num_slices, streams, extract, group)
-        obj._ctxs = (ctx_main, ctx_side)
-        return obj
-
-    def submit(self, fused):
-        """Round k: accumulate `fused` (main stream), then all-reduce / finalize / extract on the
-        side stream.  Returns the slot's side-context grid (valid after drain() or after the
-        slot's "free" event)."""
-        s = self.slots[self.k % len(self.slots)]
-        main, side = self.streams if self.streams is not None else (None, None)
-        if main is not None and s["used"]:
-            main.wait_event(s["free"])            # round k - depth has left this buffer
-        s["acc_main"].resetGrid()
-        if self.mode == 1:
-            s["acc_main"].addInverseOfTwoGrids(fused)   # process2.cpp:218-220
-        else:
-            s["acc_main"].addTwoGrids(fused)            # process2.cpp:231-233
-        if main is not None:
-            import torch
-            s["filled"].record(main)
-            side.wait_event(s["filled"])
-            with torch.cuda.stream(side):
-                allreduce_sum_(s["tensor"], self.group)
-        else:
-            allreduce_sum_(s["tensor"], self.group)
-        if self.mode == 1:
-            s["acc_side"].computeHMfromSumOfInv(self.n)
-        else:
-            s["acc_side"].computeAMfromSum(self.n)
-        if self.extract is not None:
-            self.extract(s["acc_side"])
-        if main is not None:
-            s["free"].record(side)
-        s["used"] = True
-        self.k += 1
-        return s["acc_side"]
-
-    def drain(self):
-        """Host waits for both streams."""
-        if self.streams is not None:
-            for c in self._ctxs:
-                c.synchronize()
-
-    def close(self):
-        for s in self.slots:
-            for key in ("acc_main", "acc_side"):
-                if hasattr(s[key], "close"):
-                    s[key].close()
-
-
-# ------------------------------------------------------------------ engine-native orchestration
+# ------------------------------------------------------------------ the collective as a callable
 def engine_allreduce(comm):
     """allreduce(grid, op) over an engine communicator (RCCL from the C ABI, on the grid's stream)."""
     def f(grid, op):
@@ -241,34 +71,81 @@ def engine_allreduce(comm):
     return f
 
 
+def _gloo_op(op):
+    import torch.distributed as dist
+    return {E.REDUCE_SUM: dist.ReduceOp.SUM, E.REDUCE_MIN: dist.ReduceOp.MIN, E.REDUCE_MAX: dist.ReduceOp.MAX}[int(op)]
+
+
 def host_staged_allreduce(group=None):
-    """allreduce(grid, op) through host memory and torch.distributed (gloo): for tests that put
-    several ranks on ONE GPU, which RCCL refuses.  Synchronises the grid's stream."""
+    """allreduce(grid, op) through host memory and a torch.distributed (gloo) group: the TEST transport, for
+    several ranks on one GPU (RCCL admits one rank per device) and for CPU stand-in grids.  `grid` needs
+    download() / upload(); synchronises the grid's stream."""
     def f(grid, op):
         import torch
         import torch.distributed as dist
         if not dist.is_initialized() or dist.get_world_size(group) == 1:
             return
-        t = torch.from_numpy(grid.download())
-        dist.all_reduce(t, op={0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MIN, 2: dist.ReduceOp.MAX}[int(op)],
-                        group=group)
+        t = torch.from_numpy(np.ascontiguousarray(grid.download()))
+        dist.all_reduce(t, op=_gloo_op(op), group=group)
         grid.upload(t.numpy())
     return f
 
 
+def host_staged_allreduce_keys(keys, group=None):
+    """MAX over the ranks of packed arg-max keys (uint64 words below 2^40, so int64 orders them alike)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return keys
+    t = torch.from_numpy(np.ascontiguousarray(keys).view(np.int64).copy())
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return t.numpy().view(np.uint64)
+
+
+def host_staged_reduce_scatter(acc, world, rank, op, group=None):
+    """The exchange of dsi_mapper_depth_map_reduce_scattered's first step over the test transport, with the RCCL
+    path's own partition (dsi_scatter_plan): afterwards planes [own_begin, +own_count) and the tail planes of
+    `acc` hold the reduced values on this rank -- and, like after ncclReduceScatter in place, the other planes
+    hold whatever this rank had (here: its own partial sums)."""
+    import torch
+    import torch.distributed as dist
+    sp = E.scatter_plan(acc.shape[0], world, rank)
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return sp
+    mine = acc.download()
+    t = torch.from_numpy(mine.copy())
+    dist.all_reduce(t, op=_gloo_op(op), group=group)
+    full = t.numpy()
+    for b, c in ((sp["own_begin"], sp["own_count"]), (sp["tail_begin"], sp["tail_count"])):
+        mine[b:b + c] = full[b:b + c]
+    acc.upload(mine)
+    return sp
+
+
+def host_staged_depth_map_reduce_scattered(mapper, acc, world, rank, mode, n_maps, group=None):
+    """MapperEMVS.computeDepthMapReduceScattered with both exchanges carried through host memory: the SAME partition
+    (dsi_scatter_plan), local step (dsi_mapper_depth_map_scattered_local) and key unpacking
+    (dsi_mapper_depth_map_from_keys) the RCCL path runs, so that on a multi-GPU node only the nccl* calls are new."""
+    host_staged_reduce_scatter(acc, world, rank, E.acc_reduce_op(mode), group)
+    mapper.computeDepthMapScatteredLocal(acc, world, rank, mode, n_maps)
+    mapper.setArgmaxKeys(host_staged_allreduce_keys(mapper.argmaxKeys(), group))
+    mapper.computeDepthMapFromKeys()
+
+
+# ------------------------------------------------------------------ engine-native orchestration
 class EngineTemporalFusion:
     """Time-slice sharding (configs[3]; process2.cpp:211-242 across GPUs): every rank accumulates the
     slices it owns, ONE all-reduce of the accumulator, local finalize.  `mode` is any
     dsi_acc_mode_t (ACC_INV_SUM = the reference's temporal HM, ACC_SUM = its temporal AM; the n-ary
     GM / RMS / min / max modes reduce the same way).  The accumulator starts at the mode's identity,
-    so a rank that owns no slice contributes nothing."""
+    so a rank that owns no slice contributes nothing.
+    make_grid: factory of the accumulator (default: an engine Grid3D in `ctx`; CPU tests pass a stand-in)."""
 
-    def __init__(self, ctx, dims, mode, num_slices, allreduce):
-        from .engine import Grid3D, acc_reduce_op
+    def __init__(self, ctx, dims, mode, num_slices, allreduce, make_grid=None):
         nx, ny, nz = dims
-        self.acc = Grid3D(ctx, nx, ny, nz)
+        self.acc = make_grid() if make_grid is not None else E.Grid3D(ctx, nx, ny, nz)
         self.mode, self.n, self.allreduce = int(mode), int(num_slices), allreduce
-        self.op = acc_reduce_op(self.mode)
+        self.op = E.acc_reduce_op(self.mode)
         self.reset()
 
     def reset(self):
@@ -294,26 +171,35 @@ class EngineTemporalFusion:
 
 
 class EnginePipelinedTemporalFusion:
-    """EngineTemporalFusion for a stream of rounds (bench steps, sliding windows): round k's
+    """EngineTemporalFusion for a stream of rounds (bench steps, sliding windows, main.cpp:177): round k's
     all-reduce + finalize + depth-map extraction run on the side context's stream while the main
     context already votes round k+1.  Ordering is by dsi_context_wait_for only; the host never
-    blocks in submit().  The accumulator is double-buffered and aliased in both contexts."""
+    blocks in submit().  The accumulator is double-buffered and aliased in both contexts.
 
-    def __init__(self, ctx_main, ctx_side, dims, mode, num_slices, allreduce, extract=None, depth=2, scattered=None):
+        main stream :  ... vote, camera-fuse(k) | acc[k%2] = f(fused)      | vote, camera-fuse(k+1) ...
+        side stream :                            wait | all-reduce(acc[k%2]), finalize, arg-max |
+
+    make_slot: factory of one (main, side) pair of accumulator views (default: an engine Grid3D in ctx_main
+    and an alias of its memory in ctx_side; CPU tests pass stand-ins and contexts whose wait_for is a no-op)."""
+
+    def __init__(self, ctx_main, ctx_side, dims, mode, num_slices, allreduce, extract=None, depth=2, scattered=None,
+                 make_slot=None):
         """scattered = (mapper_in_side_context, comm): the round's collective is the reduce-scatter form
         (MapperEMVS.computeDepthMapReduceScattered: reduce-scatter by planes, finalize + arg-max of the owned
         planes, all-reduce(MAX) of keys) instead of all-reduce + finalize + extract; the depth map lands in that
         mapper's buffers, the fused DSI is not completed on any rank."""
-        from .engine import Grid3D, acc_reduce_op
         nx, ny, nz = dims
         self.ctx_main, self.ctx_side = ctx_main, ctx_side
         self.mode, self.n, self.allreduce, self.extract = int(mode), int(num_slices), allreduce, extract
         self.scattered = scattered
-        self.op = acc_reduce_op(self.mode)
+        self.op = E.acc_reduce_op(self.mode)
         self.slots = []
         for _ in range(depth):
-            main = Grid3D(ctx_main, nx, ny, nz)
-            side = Grid3D(ctx_side, nx, ny, nz, device_ptr=main.device_ptr)
+            if make_slot is not None:
+                self.slots.append(make_slot())
+                continue
+            main = E.Grid3D(ctx_main, nx, ny, nz)
+            side = E.Grid3D(ctx_side, nx, ny, nz, device_ptr=main.device_ptr)
             self.slots.append((main, side))
         self.k = 0
 
@@ -341,18 +227,20 @@ class EnginePipelinedTemporalFusion:
 
     def close(self):
         for main, side in self.slots:
-            side.close()
+            if side is not main:
+                side.close()
             main.close()
 
 
 def plane_sharded_depth_map(mapper, fused_shard, comm=None, group=None):
     """collapseMaxZSlice of a plane-sharded DSI (configs[4]).  With an engine communicator: ONE
     RCCL all-reduce(MAX) of packed keys on the device (dsi_mapper_depth_map_sharded).  Without:
-    the same keys through torch.distributed `group` on the host (gloo tests).  Returns
-    (depth, conf, global idx) -- identical on every rank."""
+    the same keys over the test transport (host-staged gloo `group`).  Returns (depth, conf, global idx) --
+    identical on every rank."""
     if comm is not None:
         mapper.computeDepthMapSharded(fused_shard, comm)
         return mapper.fetchDepthMap()
     conf, idx = fused_shard.collapseMaxZSlice()
-    conf, gidx = allreduce_argmax(conf, idx, mapper.plane_begin, group=group)
+    keys = host_staged_allreduce_keys(pack_argmax_keys(conf, idx, mapper.plane_begin), group)
+    conf, gidx = unpack_argmax_keys(keys)
     return mapper.full_depths_[gidx], conf, gidx

@@ -52,14 +52,27 @@ class _DepthMapOptions(C.Structure):
                 ("median_filter_size", C.c_int), ("max_confidence", C.c_double)]
 
 
+class _ScatterPlan(C.Structure):
+    _fields_ = [("q", C.c_int), ("own_begin", C.c_int), ("own_count", C.c_int), ("tail_begin", C.c_int),
+                ("tail_count", C.c_int)]
+
+
 class _VoteInfo(C.Structure):
     _fields_ = [("algo", C.c_int), ("bands", C.c_int), ("band_rows", C.c_int),
                 ("chunks", C.c_int), ("block_threads", C.c_int), ("lds_bytes", C.c_size_t),
                 ("n_packets", C.c_size_t), ("packed", C.c_int), ("group_packets", C.c_int)]
 
 
+def experiments_requested():
+    """DSI_ENGINE_EXPERIMENTS=1 in the environment of THIS process: load the experiments flavour of the library
+    (libdsi_engine_experiments.so: environment knobs + dsi_test_* hooks of the timing experiments, some of which make
+    the DSIs wrong on purpose).  An explicit opt-in of development tools and of the tests of those hooks; nothing in the
+    product sets it."""
+    return os.environ.get("DSI_ENGINE_EXPERIMENTS", "0") not in ("", "0")
+
+
 def library_path():
-    return os.path.join(_HERE, "libdsi_engine.so")
+    return os.path.join(_HERE, "libdsi_engine_experiments.so" if experiments_requested() else "libdsi_engine.so")
 
 
 def load_library():
@@ -71,13 +84,19 @@ def load_library():
     path = library_path()
     if not os.path.exists(path):
         raise ImportError(
-            "%s is missing: build the HIP engine first (python -m dvs_mcemvs_amd.build). "
-            "dvs_mcemvs_amd has no CPU fallback." % path)
+            "%s is missing: build the HIP engine first (python -m dvs_mcemvs_amd.build%s). "
+            "dvs_mcemvs_amd has no CPU fallback." % (path, " --experiments" if experiments_requested() else ""))
     L = C.CDLL(path)
+    L.dsi_build_flavour.restype = C.c_int
+    if bool(L.dsi_build_flavour()) != experiments_requested():
+        raise ImportError("%s is the %s flavour of the engine but the %s one was asked for: rebuild it "
+                          "(python -m dvs_mcemvs_amd.build --force)" %
+                          (path, "experiments" if L.dsi_build_flavour() else "production",
+                           "experiments" if experiments_requested() else "production"))
     vp, f32p, u8p, u16p, u32p, f64p = (C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint8),
                                        C.POINTER(C.c_uint16), C.POINTER(C.c_uint32),
                                        C.POINTER(C.c_double))
-    intp, szp = C.POINTER(C.c_int), C.POINTER(C.c_size_t)
+    intp, szp, u64p = C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)
     sig = {
         "dsi_last_error": (C.c_char_p, []),
         "dsi_abi_version": (C.c_int, []),
@@ -94,7 +113,8 @@ def load_library():
         "dsi_context_timer_stop": (C.c_int, [vp, f32p]),
         "dsi_context_timeline_mark": (C.c_int, [vp]),
         "dsi_context_timeline_read": (C.c_int, [vp, f32p, C.c_size_t, szp]),
-        "dsi_test_unit_multiplicity": (C.c_int, [vp, C.c_int]),
+        "dsi_build_flavour": (C.c_int, []),
+        "dsi_mapper_vote_statistics": (C.c_int, [vp, vp, f64p, f64p]),
         "dsi_grid_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
         "dsi_grid_wrap": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp)]),
         "dsi_grid_destroy": (C.c_int, [vp]),
@@ -151,7 +171,6 @@ def load_library():
         "dsi_mapper_last_vote_info": (C.c_int, [vp, C.POINTER(_VoteInfo)]),
         "dsi_mapper_set_kernel_timing": (C.c_int, [vp, C.c_int]),
         "dsi_mapper_vote_kernel_time": (C.c_int, [vp, f32p, intp]),
-        "dsi_test_div_probe": (C.c_int, [vp, f32p, f32p, C.c_size_t, f32p, f32p]),
         "dsi_comm_unique_id": (C.c_int, [u8p]),
         "dsi_comm_create_rank": (C.c_int, [vp, u8p, C.c_int, C.c_int, C.POINTER(vp)]),
         "dsi_comm_create_all": (C.c_int, [C.POINTER(vp), C.c_int, C.POINTER(vp)]),
@@ -165,7 +184,25 @@ def load_library():
         "dsi_mapper_depth_map_reduce_scattered": (C.c_int, [vp, vp, vp, C.c_int, C.c_int]),
         "dsi_mapper_depth_map_reduce_scattered_all": (C.c_int, [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_int,
                                                               C.c_int, C.c_int]),
+        "dsi_comm_query": (C.c_int, [vp, intp, intp, intp]),
+        "dsi_scatter_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_ScatterPlan)]),
+        "dsi_plane_range": (C.c_int, [C.c_int, C.c_int, C.c_int, intp, intp]),
+        "dsi_argmax_keys_pack": (C.c_int, [f32p, u8p, C.c_size_t, C.c_int, u64p]),
+        "dsi_argmax_keys_unpack": (C.c_int, [u64p, C.c_size_t, f32p, u8p]),
+        "dsi_mapper_depth_map_scattered_local": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+        "dsi_mapper_argmax_keys_download": (C.c_int, [vp, u64p]),
+        "dsi_mapper_argmax_keys_upload": (C.c_int, [vp, u64p]),
+        "dsi_mapper_depth_map_from_keys": (C.c_int, [vp]),
     }
+    if experiments_requested():     # hooks that exist only in the experiments flavour
+        sig.update({
+            "dsi_test_div_probe": (C.c_int, [vp, f32p, f32p, C.c_size_t, f32p, f32p]),
+            "dsi_test_pass_lg": (C.c_int, [vp, C.c_int]),
+            "dsi_test_fused_fixed_cost": (C.c_int, [vp, C.c_int]),
+            "dsi_test_fused_trace_enable": (C.c_int, [vp, szp]),
+            "dsi_test_fused_trace_read": (C.c_int, [vp, vp, C.c_size_t]),
+            "dsi_test_run_length_total": (C.c_int, [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
+        })
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError here = the .so does not export the ABI
         fn.restype = res
@@ -337,6 +374,12 @@ class Comm:
     def size(self):
         return load_library().dsi_comm_size(self._h)
 
+    def query(self):
+        """(nranks, rank, device) as RCCL itself reports them (ncclCommCount / ncclCommUserRank / ncclCommCuDevice)."""
+        n, r, dev = C.c_int(), C.c_int(), C.c_int()
+        _check(load_library().dsi_comm_query(self._h, C.byref(n), C.byref(r), C.byref(dev)))
+        return n.value, r.value, dev.value
+
     def close(self):
         if self._h:
             load_library().dsi_comm_destroy(self._h)
@@ -344,6 +387,39 @@ class Comm:
 
     def __del__(self):
         _safe_del(self)
+
+
+def scatter_plan(dim_z, nranks, rank):
+    """dsi_scatter_plan: which planes rank `rank` of `nranks` owns when the temporal fusion's collective is a
+    reduce-scatter: dict(q, own_begin, own_count, tail_begin, tail_count) -- the arithmetic the RCCL path uses."""
+    sp = _ScatterPlan()
+    _check(load_library().dsi_scatter_plan(int(dim_z), int(nranks), int(rank), C.byref(sp)))
+    return {k: getattr(sp, k) for k, _ in _ScatterPlan._fields_}
+
+
+def plane_range(dim_z, nranks, rank):
+    """dsi_plane_range: (begin, count) of rank's planes under plane sharding."""
+    b, c = C.c_int(), C.c_int()
+    _check(load_library().dsi_plane_range(int(dim_z), int(nranks), int(rank), C.byref(b), C.byref(c)))
+    return b.value, c.value
+
+
+def argmax_keys_pack(conf, idx_local, plane_begin):
+    conf = _arr(conf, np.float32)
+    idx_local = _arr(idx_local, np.uint8)
+    keys = np.empty(conf.shape, np.uint64)
+    _check(load_library().dsi_argmax_keys_pack(_ptr(conf, C.c_float), _ptr(idx_local, C.c_uint8), conf.size,
+                                               int(plane_begin), _ptr(keys, C.c_uint64)))
+    return keys
+
+
+def argmax_keys_unpack(keys):
+    keys = _arr(keys, np.uint64)
+    conf = np.empty(keys.shape, np.float32)
+    idx = np.empty(keys.shape, np.uint8)
+    _check(load_library().dsi_argmax_keys_unpack(_ptr(keys, C.c_uint64), keys.size, _ptr(conf, C.c_float),
+                                                 _ptr(idx, C.c_uint8)))
+    return conf, idx
 
 
 def allreduce_all(comms, grids, op):
@@ -678,10 +754,13 @@ class MapperEMVS:
         _check(load_library().dsi_mapper_last_vote_info(self._h, C.byref(info)))
         return {k: getattr(info, k) for k, _ in _VoteInfo._fields_}
 
-    def _unit_multiplicity(self, flag):
-        """Test hook: merged records vote once instead of `multiplicity` times (the DSI then counts the
-        records the voting kernel accepted)."""
-        _check(load_library().dsi_test_unit_multiplicity(self._h, int(bool(flag))))
+    def vote_statistics(self, batch):
+        """(accepted event-planes, accepted records) of voting `batch`: the DSI's sum, and the same count after the
+        packet sort merged same-pixel events of a packet (= LDS atomics issued / 4).  Votes twice; the DSI is left as
+        evaluateDSI_batch leaves it."""
+        a, r = C.c_double(), C.c_double()
+        _check(load_library().dsi_mapper_vote_statistics(self._h, batch._h, C.byref(a), C.byref(r)))
+        return a.value, r.value
 
     def set_kernel_timing(self, enable=True):
         _check(load_library().dsi_mapper_set_kernel_timing(self._h, 1 if enable else 0))
@@ -804,6 +883,28 @@ class MapperEMVS:
         its planes, one all-reduce(MAX) of packed keys -> the fused depth map on every rank (fetchDepthMap).
         `acc` is consumed."""
         _check(load_library().dsi_mapper_depth_map_reduce_scattered(self._h, acc._h, comm._h, int(mode), int(n_maps)))
+
+    def computeDepthMapScatteredLocal(self, acc, nranks, rank, mode, n_maps):
+        """The local step of computeDepthMapReduceScattered for a caller-provided transport: finalize + arg-max of
+        the planes scatter_plan(dimZ, nranks, rank) gives this rank -> packed keys on the device (argmaxKeys)."""
+        _check(load_library().dsi_mapper_depth_map_scattered_local(self._h, acc._h, int(nranks), int(rank), int(mode),
+                                                                   int(n_maps)))
+
+    def argmaxKeys(self):
+        ny, nx = self.dsi_.shape[1:]
+        keys = np.empty((ny, nx), np.uint64)
+        _check(load_library().dsi_mapper_argmax_keys_download(self._h, _ptr(keys, C.c_uint64)))
+        return keys
+
+    def setArgmaxKeys(self, keys):
+        keys = _arr(keys, np.uint64)
+        ny, nx = self.dsi_.shape[1:]
+        assert keys.shape == (ny, nx)
+        _check(load_library().dsi_mapper_argmax_keys_upload(self._h, _ptr(keys, C.c_uint64)))
+
+    def computeDepthMapFromKeys(self):
+        """keys (after the caller's MAX over the ranks) -> confidence / index / depth (fetchDepthMap)."""
+        _check(load_library().dsi_mapper_depth_map_from_keys(self._h))
 
     def fetchDepthMapAsync(self, depth, conf, idx):
         """Queue the device -> host copies into PinnedArray-backed arrays (any may be None) on the copy

@@ -297,7 +297,10 @@ class WindowStream:
         return self.fused[slot]
 
     def context_of_slot(self, slot):
-        """The context window `slot` runs in (pre-uploaded batches must live there)."""
+        """The context window `slot` runs in (pre-uploaded batches must live there).  Lifetime: with concurrent=True
+        the stream OWNS the contexts of slots >= 1 and close() destroys them -- after closing every object still alive
+        in them (Context.close() does that: a caller's EventBatch created here is closed with the stream; closing it
+        again later is a no-op).  At the C level dsi_context_destroy refuses while children are alive."""
         return self.contexts[slot % len(self.contexts)]
 
     def close(self):

@@ -51,12 +51,43 @@ def rig_pose(t, speed=3.6, lateral=0.1, yaw_amp=0.01, pitch_amp=0.004):
     return pos, q
 
 
-def trajectory(t0, t1, cam_offset_x=0.0, rate_hz=10.0, **kw):
-    """Control poses T_w_cam at rate_hz covering [t0, t1] with margin.
+def recorded_rig(times, poses):
+    """pose_fn(t) -> (position [...,3], quaternion [...,4]) of a RECORDED trajectory (control poses T_w_rig as
+    {tx,ty,tz,qw,qx,qy,qz} at ascending times, e.g. tests/golden/zurich_city_04_poses_9_16s.npz): translation
+    interpolated linearly, rotation by normalised linear interpolation of the quaternions -- an input generator,
+    not LinearTrajectory::getPoseAt (the engine's pose pipeline interpolates the control poses its own way; the
+    events only have to be plausible).  `pose_fn.control` = (times, poses) for trajectory()."""
+    times = np.asarray(times, np.float64)
+    poses = np.asarray(poses, np.float64).copy()
+    for i in range(1, poses.shape[0]):                   # keep neighbouring quaternions in one hemisphere
+        if np.dot(poses[i, 3:], poses[i - 1, 3:]) < 0:
+            poses[i, 3:] = -poses[i, 3:]
+
+    def pose_fn(t):
+        t = np.asarray(t, np.float64)
+        k = np.clip(np.searchsorted(times, t, side="right") - 1, 0, times.shape[0] - 2)
+        w = ((t - times[k]) / (times[k + 1] - times[k]))[..., None]
+        pos = (1 - w) * poses[k, :3] + w * poses[k + 1, :3]
+        q = (1 - w) * poses[k, 3:] + w * poses[k + 1, 3:]
+        return pos, q / np.linalg.norm(q, axis=-1, keepdims=True)
+
+    pose_fn.control = (times, poses)
+    return pose_fn
+
+
+def trajectory(t0, t1, cam_offset_x=0.0, rate_hz=10.0, pose_fn=None, **kw):
+    """Control poses T_w_cam at rate_hz covering [t0, t1] with margin (a recorded rig: its own control poses).
     Returns (times float64[m], poses float64[m][7] = tx,ty,tz,qw,qx,qy,qz)."""
+    if pose_fn is not None and hasattr(pose_fn, "control"):
+        times = pose_fn.control[0]
+        pos, q = pose_fn.control[1][:, :3], pose_fn.control[1][:, 3:]
+        n = times.shape[0]
+        off = np.zeros((n, 3))
+        off[:, 0] = cam_offset_x
+        return times.copy(), np.concatenate([pos + quat_rotate(q, off), q], axis=1)
     n = int(np.ceil((t1 - t0) * rate_hz)) + 3
     times = t0 - 1.0 / rate_hz + np.arange(n) / rate_hz
-    pos, q = rig_pose(times, **kw)
+    pos, q = (pose_fn or rig_pose)(times, **kw)
     off = np.zeros((n, 3))
     off[:, 0] = cam_offset_x
     pos = pos + quat_rotate(q, off)
@@ -71,9 +102,11 @@ def pose_inverse(p):
 
 
 def make_events(n_events, cam, t0, t1, seed, cam_offset_x=0.0, n_points=5000,
-                depth_range=(4.8, 160.0), noise_frac=0.10, **kw):
-    """Events of one camera: (x uint16[n], y uint16[n], ts float64[n]), time-sorted."""
+                depth_range=(4.8, 160.0), noise_frac=0.10, pose_fn=None, **kw):
+    """Events of one camera: (x uint16[n], y uint16[n], ts float64[n]), time-sorted.
+    pose_fn: the rig's pose as a function of time (default: the analytic rig_pose; recorded_rig() for a real one)."""
     width, height, fx, fy, cx, cy = cam
+    rig_pose = pose_fn or globals()["rig_pose"]
     rng = np.random.default_rng(seed)
     # scene points in the frustum of the view at the middle of the interval
     tm = 0.5 * (t0 + t1)
@@ -137,7 +170,7 @@ def radial_lut(cam, k1=-0.09, k2=0.19):
 
 
 def stereo_rig(n_events_per_cam, width=346, height=260, t0=10.0, duration=0.5, baseline=0.6,
-               n_cams=2, seed=1234, n_points=5000, noise_frac=0.10, **kw):
+               n_cams=2, seed=1234, n_points=5000, noise_frac=0.10, pose_fn=None, **kw):
     """A synthetic multi-camera recording: dict with cam, per-camera events and
     trajectories, and the reference-view pose T_rv_w (left camera at the END of the
     interval, i.e. --forward_looking=true as in cfg/DSEC/zurich_04_a_full/dsec.conf)."""
@@ -147,9 +180,9 @@ def stereo_rig(n_events_per_cam, width=346, height=260, t0=10.0, duration=0.5, b
     events, trajs = [], []
     for i, off in enumerate(offsets):
         events.append(make_events(n_events_per_cam, cam, t0, t1, seed + i, cam_offset_x=off,
-                                  n_points=n_points, noise_frac=noise_frac, **kw))
-        trajs.append(trajectory(t0, t1, cam_offset_x=off, **kw))
-    pos, q = rig_pose(np.array(t1), **kw)
+                                  n_points=n_points, noise_frac=noise_frac, pose_fn=pose_fn, **kw))
+        trajs.append(trajectory(t0, t1, cam_offset_x=off, pose_fn=pose_fn, **kw))
+    pos, q = (pose_fn or rig_pose)(np.array(t1), **kw)
     T_w_rv = np.concatenate([pos, q])
     return {"cam": cam, "events": events, "trajectories": trajs, "T_rv_w": pose_inverse(T_w_rv),
             "t0": t0, "t1": t1}

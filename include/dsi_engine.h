@@ -39,7 +39,7 @@ extern "C" {
 #define DSI_API
 #endif
 
-#define DSI_ENGINE_ABI_VERSION 5
+#define DSI_ENGINE_ABI_VERSION 6
 #define DSI_PACKET_SIZE 1024 /* mapper_emvs_stereo.hpp:152 packet_size_ */
 
 typedef enum {
@@ -112,11 +112,18 @@ typedef struct dsi_batch dsi_batch_t;     /* device-resident, packetised events 
 
 DSI_API const char *dsi_last_error(void);
 DSI_API int dsi_abi_version(void);
+/* 0: the production library (libdsi_engine.so).  1: the EXPERIMENTS flavour (libdsi_engine_experiments.so, built with
+ * -DDSI_TIMING_EXPERIMENTS by `python -m dvs_mcemvs_amd.build --experiments`), which also reads the environment knobs
+ * of the timing experiments quoted in DESIGN.md and exports dsi_test_* hooks -- some of which make the DSIs WRONG on
+ * purpose; never ship or benchmark it.  The production library reads no environment and exports no dsi_test_*. */
+DSI_API int dsi_build_flavour(void);
 /* number of HIP devices visible, or 0 (never fails) */
 DSI_API int dsi_device_count(void);
 
 /* ------------------------------------------------------------------ context */
 DSI_API int dsi_context_create(int device_id, dsi_context_t **out);
+/* fails with DSI_ERR_CONTEXT (and destroys nothing) while grids, mappers or batches created from the context are
+ * alive: each holds a pointer to it.  Destroy them first. */
 DSI_API int dsi_context_destroy(dsi_context_t *ctx);
 DSI_API int dsi_context_synchronize(dsi_context_t *ctx);
 /* the hipStream_t all work of this context is issued on */
@@ -208,6 +215,9 @@ DSI_API int dsi_comm_create_all(dsi_context_t *const *contexts, int n, dsi_comm_
 DSI_API int dsi_comm_destroy(dsi_comm_t *comm);
 DSI_API int dsi_comm_rank(const dsi_comm_t *comm);
 DSI_API int dsi_comm_size(const dsi_comm_t *comm);
+/* what RCCL ITSELF reports for this communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice), as opposed
+ * to what it was created with: bench.py prints it per rank as the proof of the rank count.  Any pointer may be NULL. */
+DSI_API int dsi_comm_query(const dsi_comm_t *comm, int *nranks, int *rank, int *device);
 /* in-place all-reduce of a grid over the communicator, op = dsi_reduce_op_t (use
  * dsi_acc_reduce_op(mode) for an accumulator).  The grid must live on the communicator's device. */
 DSI_API int dsi_grid_allreduce(dsi_comm_t *comm, dsi_grid_t *g, int op);
@@ -392,6 +402,37 @@ DSI_API int dsi_mapper_depth_map_reduce_scattered(dsi_mapper_t *m, dsi_grid_t *a
 DSI_API int dsi_mapper_depth_map_reduce_scattered_all(dsi_mapper_t *const *mappers, dsi_grid_t *const *accs,
                                                       dsi_comm_t *const *comms, int n, int mode, int n_maps);
 
+/* The same three steps with the transport left to the caller, and the partition arithmetic they share (pure host
+ * functions, no GPU needed): dsi_mapper_depth_map_reduce_scattered is
+ *     reduce (sum / min / max over the ranks) of planes [own_begin, +own_count) to their owner and of planes
+ *         [tail_begin, +tail_count) to everybody                                  <- dsi_scatter_plan, ncclReduceScatter + ncclAllReduce
+ *     dsi_mapper_depth_map_scattered_local: finalize + arg-max of the owned planes -> packed keys
+ *     MAX of the keys over the ranks                                              <- ncclAllReduce(MAX)
+ *     dsi_mapper_depth_map_from_keys: keys -> confidence / index / depth
+ * so that a caller with another transport (the 2-rank tests carry the two exchanges through host memory; MPI) runs
+ * exactly the code the RCCL path runs around its collectives. */
+typedef struct {
+    int q;          /* planes per rank of the reduce-scatter part: dimZ / nranks */
+    int own_begin;  /* this rank's reduce-scatter range: [rank q, (rank + 1) q) */
+    int own_count;
+    int tail_begin; /* the dimZ mod nranks planes left over: all-reduced, every rank owns them */
+    int tail_count;
+} dsi_scatter_plan_t;
+DSI_API int dsi_scatter_plan(int dim_z, int nranks, int rank, dsi_scatter_plan_t *out);
+/* plane sharding (dsi_mapper_config_t.plane_begin / plane_count): contiguous balanced ranges, the first
+ * dimZ mod nranks ranks own one plane more */
+DSI_API int dsi_plane_range(int dim_z, int nranks, int rank, int *begin, int *count);
+/* the arg-max key of a pixel, confidence bits << 8 | 255 - (idx_local + plane_begin), on host arrays: what
+ * k_pack_argmax / k_unpack_argmax compute on the device (MAX over shards = collapseMaxZSlice over all planes) */
+DSI_API int dsi_argmax_keys_pack(const float *conf, const uint8_t *idx_local, size_t n, int plane_begin, uint64_t *keys);
+DSI_API int dsi_argmax_keys_unpack(const uint64_t *keys, size_t n, float *conf, uint8_t *idx_global);
+DSI_API int dsi_mapper_depth_map_scattered_local(dsi_mapper_t *m, dsi_grid_t *acc, int nranks, int rank, int mode,
+                                                 int n_maps);
+/* the mapper's packed arg-max keys (dimY * dimX words), host <-> device; synchronise */
+DSI_API int dsi_mapper_argmax_keys_download(dsi_mapper_t *m, uint64_t *keys_host);
+DSI_API int dsi_mapper_argmax_keys_upload(dsi_mapper_t *m, const uint64_t *keys_host);
+DSI_API int dsi_mapper_depth_map_from_keys(dsi_mapper_t *m);
+
 /* OptionsDepthMap (mapper_emvs_stereo.hpp:68-82), the fields the depth-map extraction reads */
 typedef struct {
     int adaptive_threshold_kernel_size; /* --adaptive_threshold_kernel_size, default 5 (main.cpp:73) */
@@ -430,6 +471,14 @@ DSI_API int dsi_mapper_filter_depth_map(dsi_mapper_t *m, const dsi_depthmap_opti
  * clears).  bench.py derives the roofline figure of the dominant kernel from this. */
 DSI_API int dsi_mapper_set_kernel_timing(dsi_mapper_t *m, int enable);
 DSI_API int dsi_mapper_vote_kernel_time(dsi_mapper_t *m, float *total_ms, int *launches);
+
+/* Work the voting kernel does on one batch (bench.py's roofline): accepted_event_planes = events x planes that passed
+ * the accept test of Grid3D::accumulateGridValueAt (cartesian3dgrid.h:255-259) = the sum of the DSI (the four
+ * bilinear weights of a vote sum to 1); accepted_records = the same count after the packet sort has merged the
+ * events of a packet that share a pixel into one record = a quarter of the LDS atomics actually issued.  Votes the
+ * batch twice and leaves the mapper's DSI as dsi_mapper_evaluate_batch does.  Synchronises. */
+DSI_API int dsi_mapper_vote_statistics(dsi_mapper_t *m, const dsi_batch_t *batch, double *accepted_event_planes,
+                                       double *accepted_records);
 
 /* diagnostics of the last evaluate/fill call: which kernel ran, bands, chunks */
 typedef struct {

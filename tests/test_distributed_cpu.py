@@ -1,63 +1,47 @@
-"""world_size-2 gloo test (CPU) of the multi-GPU orchestration: slice partitioning +
-the single all-reduce(sum) that implements the reference's temporal fusion
-(process2.cpp:211-242).  Per-slice DSIs come from the CPU oracle here (tests may use it);
-on GPUs they come from the engine and the tensor aliases a Grid3D."""
+"""CPU tests (gloo, world 2 and 3) of the multi-GPU orchestration and of the rank launcher.
+
+What runs here is the code a multi-GPU node runs, minus the GPU: the partition arithmetic is the engine's
+(dsi_scatter_plan / dsi_plane_range / dsi_argmax_keys_*), the orchestration classes are
+`distributed.EngineTemporalFusion` / `EnginePipelinedTemporalFusion`, the ranks are started by
+`launch.spawn_ranks` (what `bench.py --gpus N` calls when no launcher started them) and joined by `launch.Dist`;
+the voxel arithmetic comes from the CPU oracle through stand-in grids, and the one collective goes through the
+host-staged test transport instead of RCCL.  Reference: process2.cpp:211-242 (temporal fusion), SURVEY 8(e)."""
+import json
 import os
-import socket
+import subprocess
 import sys
 
 import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "distributed_cpu_worker.py")
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
-def _worker(rank, world, port, mode, out_dir):
-    sys.path.insert(0, ROOT)
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import torch
-    import torch.distributed as dist
-    from dvs_mcemvs_amd import distributed as dd, synthetic as syn
-    from oracle import oracle as orc
-    from oracle_pipeline import OracleMapper
-
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    rig = syn.stereo_rig(9000, width=40, height=30, duration=0.3, seed=17)
-    x, y, ts = rig["events"][0]
-    n_slices = 4
-    bounds = dd.subinterval_bounds(x.shape[0], n_slices)
-    acc = np.zeros((8, 30, 40), np.float32)
-    for k in dd.slices_of_rank(n_slices, world, rank):
-        a, b = bounds[k]
-        m = OracleMapper(rig["cam"], dimZ=8, min_depth=4.0, max_depth=100.0)
-        assert m.evaluateDSI((x[a:b], y[a:b], ts[a:b]), rig["trajectories"][0], rig["T_rv_w"])
-        acc = orc.accumulate(acc, m.dsi, mode)
-    t = torch.from_numpy(acc)
-    dd.allreduce_sum_(t)
-    fused = orc.finalize(t.numpy(), mode, n_slices)
-    tmax = dd.allreduce_max_scalar(1.0 + rank)
-    assert tmax == float(world)
-    np.save(os.path.join(out_dir, "fused_rank%d.npy" % rank), fused)
-    dist.destroy_process_group()
+def run_ranks(world, job, out_dir, extra=()):
+    """`world` ranks of tests/distributed_cpu_worker.py through launch.spawn_ranks, in a child interpreter (so that
+    the ranks' stderr is a real file).  Returns (status, rank-0 stdout)."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from dvs_mcemvs_amd import launch\n"
+            "sys.exit(launch.spawn_ranks(%d, [sys.executable, %r, %r, %r] + %r, n_devices=%d, timeout=300))\n"
+            % (ROOT, world, WORKER, job, str(out_dir), list(extra), world))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    return r.returncode, r.stdout, r.stderr
 
 
 @pytest.mark.parametrize("mode", [0, 1])
 def test_two_rank_temporal_fusion_equals_single_process(tmp_path, mode):
-    import torch.multiprocessing as mp
     from dvs_mcemvs_amd import distributed as dd, synthetic as syn
     from oracle import oracle as orc
     from oracle_pipeline import OracleMapper
 
-    port = _free_port()
-    mp.spawn(_worker, args=(2, port, mode, str(tmp_path)), nprocs=2, join=True)
+    rc, out, err = run_ranks(2, "temporal", tmp_path, [str(mode)])
+    assert rc == 0, err[-3000:]
+    line = json.loads([ln for ln in out.splitlines() if ln.startswith("{")][-1])
+    # the launcher's aggregation: rank 0 prints ONE line; units summed over ranks, time = max over ranks
+    assert line["world"] == 2 and line["units_all_ranks"] == 4 and line["spawned"] is True
+    assert line["elapsed_max"] >= max(line["elapsed_each"]) - 1e-12
     # single-process reference: all 4 slices in order (process2.cpp:98-242)
     rig = syn.stereo_rig(9000, width=40, height=30, duration=0.3, seed=17)
     x, y, ts = rig["events"][0]
@@ -84,66 +68,13 @@ def test_partitioning():
     assert owned == list(range(7))
 
 
-class _NumpyGrid:
-    """Stand-in for an engine Grid3D that aliases a torch CPU tensor (oracle arithmetic)."""
-
-    def __init__(self, tensor):
-        self.a = tensor.numpy()
-
-    def resetGrid(self):
-        self.a[...] = 0
-
-    def addInverseOfTwoGrids(self, g):
-        from oracle import oracle as orc
-        self.a[...] = orc.accumulate(self.a.copy(), g, 1)
-
-    def addTwoGrids(self, g):
-        from oracle import oracle as orc
-        self.a[...] = orc.accumulate(self.a.copy(), g, 0)
-
-    def computeHMfromSumOfInv(self, n):
-        from oracle import oracle as orc
-        self.a[...] = orc.finalize(self.a.copy(), 1, n)
-
-    def computeAMfromSum(self, n):
-        from oracle import oracle as orc
-        self.a[...] = orc.finalize(self.a.copy(), 0, n)
-
-
-def _pipelined_worker(rank, world, port, out_dir):
-    sys.path.insert(0, ROOT)
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import torch
-    import torch.distributed as dist
-    from dvs_mcemvs_amd import distributed as dd
-
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    rng = np.random.default_rng(5)                      # same stream on every rank
-    rounds = [rng.uniform(0, 3, (world, 4, 6, 5)).astype(np.float32) for _ in range(5)]
-    slots = []
-    for _ in range(2):
-        t = torch.zeros((4, 6, 5), dtype=torch.float32)
-        g = _NumpyGrid(t)
-        slots.append({"tensor": t, "acc_main": g, "acc_side": g})
-    seen = []
-    pipe = dd.PipelinedTemporalFusion(slots, 1, world, streams=None,
-                                      extract=lambda grid: seen.append(grid.a.copy()))
-    for r in rounds:
-        pipe.submit(r[rank])                            # this rank's slice of the round
-    pipe.drain()
-    assert len(seen) == 5 and pipe.k == 5
-    np.save(os.path.join(out_dir, "pipe_rank%d.npy" % rank), np.stack(seen))
-    dist.destroy_process_group()
-
-
 def test_pipelined_temporal_fusion_rounds(tmp_path):
-    """Five fusion rounds through the double-buffered PipelinedTemporalFusion (program-order mode
-    on CPU): every round equals the single-process harmonic fusion of that round's slices."""
-    import torch.multiprocessing as mp
+    """Five fusion rounds through the double-buffered EnginePipelinedTemporalFusion (stand-in grids, program
+    order on the CPU): every round equals the single-process harmonic fusion of that round's slices."""
     from oracle import oracle as orc
 
-    port = _free_port()
-    mp.spawn(_pipelined_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    rc, out, err = run_ranks(2, "pipelined", tmp_path)
+    assert rc == 0, err[-3000:]
     r0 = np.load(tmp_path / "pipe_rank0.npy")
     r1 = np.load(tmp_path / "pipe_rank1.npy")
     assert np.array_equal(r0, r1)
@@ -156,7 +87,7 @@ def test_pipelined_temporal_fusion_rounds(tmp_path):
         assert np.allclose(r0[k], orc.finalize(acc, 1, 2), rtol=1e-6, atol=1e-7)
 
 
-def test_plane_ranges_and_argmax_keys():
+def test_plane_ranges_and_argmax_keys(built):
     from dvs_mcemvs_amd import distributed as dd
     from oracle import oracle as orc
     assert dd.plane_ranges(256, 8) == [(32 * r, 32) for r in range(8)]
@@ -175,40 +106,15 @@ def test_plane_ranges_and_argmax_keys():
     assert np.array_equal(c2, conf) and np.array_equal(i2, idx) and i2[1, 1] == 5 and i2[0, 0] == 0
 
 
-def _plane_worker(rank, world, port, out_dir):
-    sys.path.insert(0, ROOT)
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import torch.distributed as dist
-    from dvs_mcemvs_amd import distributed as dd, synthetic as syn
-    from oracle import oracle as orc
-    from oracle_pipeline import OracleMapper
-
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    rig = syn.stereo_rig(6000, width=40, height=30, duration=0.3, seed=23)
-    nz = 13
-    b, c = dd.plane_ranges(nz, world)[rank]
-    fused = None
-    for cam in range(2):                                 # every rank reads ALL events, owns planes [b, b+c)
-        m = OracleMapper(rig["cam"], dimZ=nz, min_depth=4.0, max_depth=100.0)
-        assert m.evaluateDSI(rig["events"][cam], rig["trajectories"][cam], rig["T_rv_w"])
-        shard = m.dsi[b:b + c]                           # planes are independent (mapper_emvs_stereo.cpp:168)
-        fused = shard.copy() if fused is None else orc.fuse2(fused, shard, 3)   # GM, voxel-wise: local
-    conf_l, idx_l = orc.collapse_max_z(fused)
-    conf, idx = dd.allreduce_argmax(conf_l, idx_l, b)    # the only collective
-    np.savez(os.path.join(out_dir, "plane_rank%d.npz" % rank), conf=conf, idx=idx)
-    dist.destroy_process_group()
-
-
 def test_plane_sharded_argmax_equals_single_process(tmp_path):
     """configs[4]-style sharding (one big DSI, planes split over ranks, voxel-wise camera fusion local,
     ONE all-reduce(MAX) of packed (confidence, index) keys) gives the unsharded depth-map inputs."""
-    import torch.multiprocessing as mp
     from dvs_mcemvs_amd import synthetic as syn
     from oracle import oracle as orc
     from oracle_pipeline import OracleMapper
 
-    port = _free_port()
-    mp.spawn(_plane_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    rc, out, err = run_ranks(3, "planes", tmp_path)
+    assert rc == 0, err[-3000:]
     rig = syn.stereo_rig(6000, width=40, height=30, duration=0.3, seed=23)
     fused = None
     for cam in range(2):
@@ -220,3 +126,61 @@ def test_plane_sharded_argmax_equals_single_process(tmp_path):
         z = np.load(tmp_path / ("plane_rank%d.npz" % r))
         assert np.array_equal(z["conf"], conf) and np.array_equal(z["idx"], idx)
     assert conf.max() > 0
+
+
+@pytest.mark.parametrize("world,nz", [(2, 21), (3, 8), (3, 2)])
+def test_reduce_scattered_depth_map_on_stand_in_grids(tmp_path, world, nz):
+    """The reduce-scatter form of the temporal fusion with the ENGINE's partition (dsi_scatter_plan): owned planes
+    + all-reduced remainder planes, finalize and arg-max of what a rank owns, MAX of the packed keys -- equals
+    all-reduce + finalize + arg-max.  dimZ = 21 over 2 ranks and 8 over 3 leave remainder planes; 2 over 3 gives
+    q = 0 (every plane is a remainder plane)."""
+    from oracle import oracle as orc
+    rc, out, err = run_ranks(world, "scattered", tmp_path, [str(nz)])
+    assert rc == 0, err[-3000:]
+    rng = np.random.default_rng(31)
+    slices = rng.uniform(0, 3, (world, nz, 6, 7)).astype(np.float32)
+    slices[:, :, 0, 0] = 0.0
+    acc = np.zeros((nz, 6, 7), np.float32)
+    for s in slices:
+        acc = orc.accumulate(acc, s, 1)
+    conf, idx = orc.collapse_max_z(orc.finalize(acc, 1, world))
+    for r in range(world):
+        z = np.load(tmp_path / ("scattered_rank%d.npz" % r))
+        assert np.array_equal(z["idx"], idx), r
+        assert np.allclose(z["conf"], conf, rtol=1e-6)
+
+
+def test_launcher_refuses_a_smaller_job_and_reports_a_failed_rank(tmp_path):
+    """`bench.py --gpus N` on a node with fewer than N devices must fail, not run fewer ranks; a rank that dies
+    takes the job down with its status."""
+    from dvs_mcemvs_amd import launch
+    with open(tmp_path / "err.txt", "w+") as err, open(tmp_path / "out.txt", "w+") as out:
+        assert launch.spawn_ranks(2, [sys.executable, "-c", "print('never')"], n_devices=1, out=out, err=err) == 2
+        assert launch.spawn_ranks(0, [sys.executable, "-c", "print('never')"], out=out, err=err) == 2
+        err.seek(0)
+        msg = err.read()
+        assert "refusing to run a smaller job" in msg and "1 GPU device" in msg
+        out.seek(0)
+        assert out.read() == ""
+        code = "import os, sys, time; r = int(os.environ['RANK']); print('rank', r); time.sleep(0 if r == 1 else 30); sys.exit(7 if r == 1 else 0)"
+        t0 = __import__("time").time()
+        assert launch.spawn_ranks(3, [sys.executable, "-c", code], n_devices=3, out=out, err=err) == 7
+        assert __import__("time").time() - t0 < 20          # the sleeping ranks were stopped, not waited for
+    # bench.py itself: a launcher's WORLD_SIZE that contradicts --gpus is an error, not a note
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode != 0 and "contradicts WORLD_SIZE" in r.stderr
+
+
+def test_bench_refuses_more_ranks_than_devices(built):
+    """On this box (no GPU; on the 1-GPU lease the GPU test repeats it with --gpus 2) `python bench.py --gpus 2`
+    exits non-zero with a message that names the device count, and prints no JSON line."""
+    import dvs_mcemvs_amd as d
+    n_dev = d.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(max(2, n_dev + 1)), "--steps", "1",
+                        "--warmup", "0"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 2, r.stderr[-2000:]
+    assert "refusing to run a smaller job" in r.stderr and ("%d GPU device" % n_dev) in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -46,11 +46,11 @@ def test_fused_equals_vote_fuse_collapse(ctx, packed, shape, band_rows):
     batches = rig_batches(ctx, rig)
     ref_m = [d.MapperEMVS(ctx, rig["cam"], dsi_shape) for _ in range(2)]
     fus_m = [d.MapperEMVS(ctx, rig["cam"], dsi_shape) for _ in range(2)]
-    for m in fus_m:
+    out = d.MapperEMVS(ctx, rig["cam"], dsi_shape)
+    for m in fus_m + [out]:          # (the fused path reads its knobs from the OUTPUT mapper of the call)
         m.set_packed_lanes(packed)
         if band_rows:
             m.set_band_params(band_rows, 0, 0)
-    out = d.MapperEMVS(ctx, rig["cam"], dsi_shape)
     for op in (d.FUSE_MIN, d.FUSE_HM, d.FUSE_GM, d.FUSE_AM, d.FUSE_RMS, d.FUSE_MAX):
         want = unfused(ctx, ref_m, batches, op)
         out.computeDepthMapOfEvents(fus_m, batches, op)
@@ -229,7 +229,7 @@ def test_fused_fuzz_over_shapes_bands_and_mappings(ctx, seed):
     mk = lambda: [d.MapperEMVS(ctx, cams[c], shapes[c]) for c in range(n_cams)]
     ref_m, fus_m = mk(), mk()
     ref_out, fus_out = d.MapperEMVS(ctx, cams[0], shapes[0]), d.MapperEMVS(ctx, cams[0], shapes[0])
-    for m in fus_m:
+    for m in fus_m + [fus_out]:
         m.set_packed_lanes(packed)
         if band_rows:
             m.set_band_params(band_rows, 0, 0)
@@ -392,7 +392,7 @@ def test_fused_three_cameras_follow_process_1(ctx, packed):
     assert batches[2].n_packets < batches[0].n_packets
     ref_m = [d.MapperEMVS(ctx, rig["cam"], shape) for _ in range(4)]
     fus_m = [d.MapperEMVS(ctx, rig["cam"], shape) for _ in range(4)]
-    for m in fus_m[:3]:
+    for m in fus_m:                  # fus_m[3] is the output mapper of the calls below
         m.set_packed_lanes(packed)
         m.set_band_params(9, 0, 0)
     for m, b in zip(ref_m[:3], batches):

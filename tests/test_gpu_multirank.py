@@ -232,6 +232,103 @@ def test_two_ranks_real_engine_four_cameras_plane_sharded_gm(ctx, tmp_path):
     assert np.array_equal(r[0]["depth"], planes[r[0]["idx"]])
 
 
+# ------------------------------------------------------------------ reduce-scatter form, the RCCL path's own code
+DIMS_RS = (128, 96, 21)      # 21 planes over 2 ranks: q = 10 and ONE remainder plane, owned by both
+
+
+def _worker_scattered(rank, world, port, out_dir):
+    dist = _init(rank, world, port)
+    import dvs_mcemvs_amd as d
+    from dvs_mcemvs_amd import distributed as dd, synthetic as syn
+    nx, ny, nz = DIMS_RS
+    rig = syn.stereo_rig(world * 60_000, width=nx, height=ny, duration=0.2, seed=61, n_points=900)
+    per = rig["events"][0][0].shape[0] // world
+    ctx = d.Context(0)
+    shape = d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0)
+    ms = [d.MapperEMVS(ctx, rig["cam"], shape) for _ in range(2)]
+    for c in range(2):
+        ev = tuple(a[rank * per:(rank + 1) * per] for a in rig["events"][c])
+        assert ms[c].evaluateDSI(ev, rig["trajectories"][c], rig["T_rv_w"])
+    sub = d.Grid3D(ctx, nx, ny, nz)
+    sub.setToFusionOf(ms[0].dsi_, ms[1].dsi_, d.FUSE_HM)
+    out = {}
+    for variant in ("allreduce", "reduce_scatter"):
+        acc = d.Grid3D(ctx, nx, ny, nz)
+        acc.accumulateBegin(d.ACC_INV_SUM)
+        acc.accumulate(sub, d.ACC_INV_SUM)
+        if variant == "allreduce":
+            dd.host_staged_allreduce()(acc, d.REDUCE_SUM)
+            acc.finalize(d.ACC_INV_SUM, world)
+            ms[0].computeDepthMap(acc)
+        else:
+            # dsi_scatter_plan + dsi_mapper_depth_map_scattered_local + dsi_mapper_depth_map_from_keys: what
+            # dsi_mapper_depth_map_reduce_scattered runs around its two nccl calls
+            dd.host_staged_depth_map_reduce_scattered(ms[0], acc, world, rank, d.ACC_INV_SUM, world)
+            out["acc_after"] = acc.download()
+        out[variant] = ms[0].fetchDepthMap()
+        acc.close()
+    np.savez(os.path.join(out_dir, "rs_rank%d.npz" % rank), acc_after=out["acc_after"],
+             **{"%s_%s" % (v, n): out[v][j] for v in ("allreduce", "reduce_scatter") for j, n in enumerate(("depth", "conf", "idx"))})
+    for o in ms + [sub]:
+        o.close()
+    ctx.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_reduce_scattered_depth_map_runs_the_rccl_paths_code(ctx, tmp_path):
+    """the reduce-scatter form of the temporal fusion at N = 2 with the real engine, both
+    exchanges carried through host memory; the plane partition (remainder plane included), the local finalize /
+    arg-max / key packing and the unpacking are the functions the RCCL entry point calls.  Bit-equal to
+    all-reduce + finalize + arg-max (a two-term sum has one order), identical on both ranks."""
+    import torch.multiprocessing as mp
+    from dvs_mcemvs_amd import engine
+    mp.spawn(_worker_scattered, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r = [np.load(tmp_path / ("rs_rank%d.npz" % k)) for k in range(2)]
+    for k in range(2):
+        for n in ("depth", "conf", "idx"):
+            assert np.array_equal(r[k]["reduce_scatter_" + n], r[k]["allreduce_" + n]), (k, n)
+            assert np.array_equal(r[k]["reduce_scatter_" + n], r[0]["reduce_scatter_" + n])
+    assert r[0]["allreduce_conf"].max() > 0.5
+    # only the owned planes (and the shared remainder plane) were finalised on a rank: the accumulator is consumed
+    sp = [engine.scatter_plan(DIMS_RS[2], 2, k) for k in range(2)]
+    assert sp[0]["tail_count"] == 1 and sp[0]["own_count"] == 10
+    tb = sp[0]["tail_begin"]
+    assert np.array_equal(r[0]["acc_after"][tb], r[1]["acc_after"][tb])
+    b0, b1 = sp[0]["own_begin"], sp[1]["own_begin"]
+    assert not np.array_equal(r[0]["acc_after"][b0:b0 + 10], r[1]["acc_after"][b0:b0 + 10])
+    assert not np.array_equal(r[0]["acc_after"][b1:b1 + 10], r[1]["acc_after"][b1:b1 + 10])
+
+
+def test_bench_gpus_2_is_two_rccl_ranks_or_an_error(built):
+    """`python bench.py --gpus 2` with no launcher: on a box with >= 2 GPUs it starts two ranks itself and the JSON
+    line proves it (rccl_ranks = ncclCommCount = 2, two distinct devices); on the one-GPU lease it exits non-zero
+    with a message naming the device count -- never a one-rank number labelled 2."""
+    import json
+    import subprocess
+    import dvs_mcemvs_amd as d
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DSI_BENCH_DEVICE")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu",
+           "--no-host-fed", "--events", "2000000"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=1200)
+    if d.device_count() < 2:
+        assert r.returncode == 2, r.stderr[-2000:]
+        assert "refusing to run a smaller job" in r.stderr and "1 GPU device" in r.stderr
+        assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        # and two ranks forced onto ONE device (a launcher's doing) fail in RCCL, loudly, instead of falling back
+        env2 = dict(env, DSI_BENCH_DEVICE="0")
+        r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                             "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + cmd[1:],
+                            capture_output=True, text=True, env=env2, timeout=1200)
+        assert r2.returncode != 0 and "no fallback collective" in r2.stderr, r2.stderr[-3000:]
+        return
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2
+    assert sorted(k["rccl_device"] for k in line["ranks"]) == [0, 1] and len({k["pid"] for k in line["ranks"]}) == 2
+    assert line["collective"]["avg_ms_alone"] > 0 and "spawn_ranks" in line["config"]["launched_by"]
+
+
 # ------------------------------------------------------------------ the engine's RCCL communicator
 def test_engine_rccl_communicator_single_rank(ctx):
     """dsi_comm_* / dsi_grid_allreduce* / dsi_mapper_depth_map_sharded* with one rank: RCCL is loaded
@@ -252,6 +349,7 @@ def test_engine_rccl_communicator_single_rank(ctx):
         assert np.array_equal(g.download(), vol)
     comms[0].close()
     comm = d.Comm(ctx, d.Comm.unique_id(), 1, 0)
+    assert comm.query() == (1, 0, ctx.device)     # ncclCommCount / UserRank / CuDevice: what bench.py prints as proof
     g.upload(vol)
     g.allReduce(comm, d.REDUCE_SUM)
     assert np.array_equal(g.download(), vol)

@@ -9,6 +9,8 @@ Stated tolerances
   * fusion ops, arg-max, index->depth: bit-exact on identical inputs.
   * mean square (double accumulation, different order): rel 1e-12.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -518,26 +520,43 @@ def test_depth_map_of_fusion_equals_fuse_then_collapse(ctx, shape):
         o.close()
 
 
-def test_residual_corrected_division_is_ieee(ctx):
+_DIV_PROBE = r'''
+import ctypes as C, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import dvs_mcemvs_amd as d
+ctx = d.Context(0)
+rng = np.random.default_rng(77)
+n = 1 << 22
+num = (rng.uniform(-1, 1, n) * np.exp2(rng.uniform(-30, 30, n))).astype(np.float32)
+den = (rng.choice([-1.0, 1.0], n) * rng.uniform(1, 2, n) * np.exp2(rng.integers(-40, 40, n))).astype(np.float32)
+num[:8] = [0.0, -0.0, 1.0, 3.0, 1e-38, 16777215.0, 0.1, 346.0]
+q = np.empty(n, np.float32)
+ref = np.empty(n, np.float32)
+L = d.load_library()
+assert L.dsi_build_flavour() == 1
+f32p = C.POINTER(C.c_float)
+rc = L.dsi_test_div_probe(ctx._h, num.ctypes.data_as(f32p), den.ctypes.data_as(f32p), n, q.ctypes.data_as(f32p),
+                          ref.ctypes.data_as(f32p))
+assert rc == 0
+assert np.array_equal(ref, num / den)          # the GPU's '/' is IEEE
+same = (q == ref) | ((q == 0) & (ref == 0))    # sign of zero may differ; votes identical
+assert same.all(), "%%d mismatches" %% (~same).sum()
+print("DIV_PROBE_OK")
+'''
+
+
+def test_residual_corrected_division_is_ieee(built):
     """The banded kernel's 5-op division must equal the IEEE divide bit for bit wherever it
-    is used (2^-40 <= |d| <= 2^40), otherwise its coordinates would not be the oracle's."""
-    import ctypes as C
-    rng = np.random.default_rng(77)
-    n = 1 << 22
-    num = (rng.uniform(-1, 1, n) * np.exp2(rng.uniform(-30, 30, n))).astype(np.float32)
-    den = (rng.choice([-1.0, 1.0], n) * rng.uniform(1, 2, n) * np.exp2(rng.integers(-40, 40, n))).astype(np.float32)
-    num[:8] = [0.0, -0.0, 1.0, 3.0, 1e-38, 16777215.0, 0.1, 346.0]
-    q = np.empty(n, np.float32)
-    ref = np.empty(n, np.float32)
-    L = d.load_library()
-    rc = L.dsi_test_div_probe(ctx._h, num.ctypes.data_as(C.POINTER(C.c_float)),
-                              den.ctypes.data_as(C.POINTER(C.c_float)), n,
-                              q.ctypes.data_as(C.POINTER(C.c_float)),
-                              ref.ctypes.data_as(C.POINTER(C.c_float)))
-    assert rc == 0
-    assert np.array_equal(ref, num / den)          # the GPU's '/' is IEEE
-    same = (q == ref) | ((q == 0) & (ref == 0))    # sign of zero may differ; votes identical
-    assert same.all(), "%d mismatches" % (~same).sum()
+    is used (2^-40 <= |d| <= 2^40), otherwise its coordinates would not be the oracle's.  The probe kernel is a
+    hook of the EXPERIMENTS flavour of the library (same kernel source; the production library exports no test
+    hook), loaded by a child process that opts in with DSI_ENGINE_EXPERIMENTS=1."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _DIV_PROBE % {"root": root}], capture_output=True, text=True,
+                       env=dict(os.environ, DSI_ENGINE_EXPERIMENTS="1"), timeout=600)
+    assert r.returncode == 0 and "DIV_PROBE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 def test_full_size_properties(ctx):

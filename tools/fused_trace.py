@@ -8,6 +8,7 @@ Usage (GPU box): python tools/fused_trace.py [events_per_window] [packed] [fixed
 import ctypes as C
 import os
 import sys
+os.environ["DSI_ENGINE_EXPERIMENTS"] = "1"   # the hooks used below exist only in the experiments flavour (build.py --experiments)
 
 import numpy as np
 

@@ -8,7 +8,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python bench.py --no-cpu"
+BENCH="python bench.py --no-cpu --no-sensitivity --no-extra"
 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH --steps 10 --warmup 2 > $OUT/trace.log 2>&1
 echo "trace rc=$?"
 i=0

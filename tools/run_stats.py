@@ -1,5 +1,6 @@
 """How tight are the runs the banded kernel walks?  total run length vs accepted votes."""
 import ctypes as C, sys, os
+os.environ["DSI_ENGINE_EXPERIMENTS"] = "1"   # the hooks used below exist only in the experiments flavour (build.py --experiments)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import dvs_mcemvs_amd as d
