@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -81,6 +82,16 @@ struct DevBuf {
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
+    }
+};
+
+template <typename T>
+struct TmpDev {  // call-scoped device memory
+    T* p = nullptr;
+    hipError_t alloc(size_t n) { return hipMalloc(reinterpret_cast<void**>(&p), (n ? n : 1) * sizeof(T)); }
+    ~TmpDev()
+    {
+        if (p) (void)hipFree(p);
     }
 };
 
@@ -1636,6 +1647,171 @@ int dsi_mapper_depth_map_of_events(dsi_mapper_t* out, dsi_mapper_t* const* mappe
                                       out->depth.p, /*clear=*/1));
     out->fused_keys_dirty = false;
     return depth_buffers_ready(out);
+}
+
+/* ---- exact tie resolver (include/dsi_engine.h) ---- */
+int dsi_mapper_resolve_near_ties(dsi_mapper_t* out, dsi_mapper_t* const* mappers, const dsi_batch_t* const* batches, int n,
+                                 int op, dsi_resolve_info_t* info)
+{
+    REQUIRE(out && mappers && batches && info, DSI_ERR_INVALID, "null argument");
+    REQUIRE(n == 1 || n == 2, DSI_ERR_INVALID, "1 or 2 cameras (got %d)", n);
+    REQUIRE(n == 1 || (op >= 1 && op <= 6), DSI_ERR_BAD_OP, "improper fusion method %d (expected 1..6)", op);
+    const float rel_gap = info->rel_gap > 0.f ? info->rel_gap : 1e-3f;
+    REQUIRE(rel_gap < 0.5f, DSI_ERR_INVALID, "rel_gap %g is not a rounding-sized gap", (double)rel_gap);
+    dsi_context* ctx = out->ctx;
+    for (int i = 0; i < n; ++i) {
+        REQUIRE(mappers[i] && batches[i], DSI_ERR_INVALID, "camera %d: null mapper or batch", i);
+        REQUIRE(mappers[i]->ctx == ctx && batches[i]->ctx == ctx, DSI_ERR_CONTEXT,
+                "mappers, batches and the output mapper must share one context");
+        REQUIRE(same_shape(out->grid, mappers[i]->grid), DSI_ERR_SHAPE, "camera %d: DSI shape differs from the output mapper's", i);
+    }
+    REQUIRE(out->depth_valid, DSI_ERR_INVALID, "the output mapper holds no raw depth map to resolve");
+    const dsi::Geom& g0 = out->geom;
+    const int npix = g0.nx * g0.ny, nz = g0.nz;
+    const size_t nvox = (size_t)npix * nz;
+    REQUIRE(nvox < ((size_t)1 << 32), DSI_ERR_INVALID, "the resolver addresses voxels with 32 bits");
+    if (int rc = set_device(ctx)) return rc;
+    hipStream_t st = ctx->stream;
+    const auto t_begin = std::chrono::steady_clock::now();
+    *info = dsi_resolve_info_t{};
+    info->rel_gap = rel_gap;
+
+    // 1. the contending voxels
+    std::vector<uint32_t> cand;
+    unsigned counters[2] = {0, 0};
+    {
+        size_t cap = std::min<size_t>(nvox, (size_t)1 << 20);
+        for (;;) {
+            TmpDev<uint32_t> d_cand;
+            TmpDev<unsigned> d_cnt;
+            HIP_TRY(d_cand.alloc(cap));
+            HIP_TRY(d_cnt.alloc(2));
+            HIP_TRY(hipMemsetAsync(d_cnt.p, 0, 2 * sizeof(unsigned), st));
+            HIP_TRY(dsi::launch_tie_candidates(st, mappers[0]->grid->data, n == 2 ? mappers[1]->grid->data : nullptr, op, npix, nz,
+                                               rel_gap, d_cnt.p, d_cand.p, (uint32_t)std::min<size_t>(cap, 0xffffffffu)));
+            HIP_TRY(hipMemcpyAsync(counters, d_cnt.p, sizeof counters, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (counters[0] <= cap) {
+                cand.resize(counters[0]);
+                if (counters[0]) HIP_TRY(hipMemcpy(cand.data(), d_cand.p, counters[0] * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                break;
+            }
+            REQUIRE(cap < nvox, DSI_ERR_INVALID, "more contending voxels than voxels");
+            cap = std::min<size_t>(nvox, (size_t)counters[0]);
+        }
+    }
+    info->near_tie_pixels = (int)counters[1];
+    info->candidate_voxels = (int)cand.size();
+    auto finish = [&]() {
+        info->elapsed_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+        return DSI_OK;
+    };
+    if (cand.empty()) return finish();
+
+    // 2. sorted voxel list (rank = id), the planes involved, the bitmap
+    std::vector<uint32_t> sv(cand);
+    std::sort(sv.begin(), sv.end());
+    std::vector<int> zlist;
+    for (uint32_t v : sv) {
+        const int z = (int)(v / (uint32_t)npix);
+        if (zlist.empty() || zlist.back() != z) zlist.push_back(z);
+    }
+    info->candidate_planes = (int)zlist.size();
+    TmpDev<uint32_t> d_sv, d_bitmap;
+    TmpDev<int> d_zlist;
+    TmpDev<unsigned long long> d_hits_n;
+    const size_t bitmap_words = (nvox + 31) / 32 + 1;
+    HIP_TRY(d_sv.alloc(sv.size()));
+    HIP_TRY(d_bitmap.alloc(bitmap_words));
+    HIP_TRY(d_zlist.alloc(zlist.size()));
+    HIP_TRY(d_hits_n.alloc(1));
+    HIP_TRY(hipMemcpyAsync(d_sv.p, sv.data(), sv.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_zlist.p, zlist.data(), zlist.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(d_bitmap.p, 0, bitmap_words * sizeof(uint32_t), st));
+    HIP_TRY(dsi::launch_tie_mark(st, d_sv.p, (int)sv.size(), d_bitmap.p));
+
+    // 3. per camera: the votes that land on a contending voxel, in the reference's order; sequential fp32 sums
+    std::vector<float> exact[2];
+    for (int c = 0; c < n; ++c) {
+        dsi_mapper* m = mappers[c];
+        const dsi_batch* b = batches[c];
+        const size_t np = b->n_packets;
+        exact[c].assign(sv.size(), 0.f);
+        if (np == 0) continue;  // evaluateDSI returned false: an all-zero DSI
+        HIP_TRY(m->H.reserve(np * 9));
+        HIP_TRY(m->xy.reserve(np * dsi::kPacket));
+        HIP_TRY(m->centers.reserve(np * 3));
+        if (b->ready) HIP_TRY(hipStreamWaitEvent(st, b->ready, 0));
+        HIP_TRY(dsi::launch_packet_geometry(st, b->Rt, (int)np, m->geom, m->centers.p, m->H.p));
+        HIP_TRY(dsi::launch_warp_z0(st, b->x, b->y, b->first, (int)np, m->H.p, m->lut_dev, m->sensor_w, m->sensor_h, m->xy.p));
+        unsigned long long n_hits = 0;
+        HIP_TRY(hipMemsetAsync(d_hits_n.p, 0, sizeof(unsigned long long), st));
+        HIP_TRY(dsi::launch_tie_hits(st, m->xy.p, m->centers.p, m->planes_dev, m->geom, (int)np, d_zlist.p, (int)zlist.size(), d_bitmap.p,
+                                     d_sv.p, (int)sv.size(), d_hits_n.p, nullptr, 0));
+        HIP_TRY(hipMemcpyAsync(&n_hits, d_hits_n.p, sizeof n_hits, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        info->votes += (long long)n_hits;
+        if (n_hits == 0) continue;
+        REQUIRE(n_hits < ((unsigned long long)1 << 31), DSI_ERR_INVALID, "%llu votes to re-sum: rel_gap is not a rounding-sized gap here", n_hits);
+        TmpDev<dsi::TieHit> d_hits;
+        HIP_TRY(d_hits.alloc((size_t)n_hits));
+        HIP_TRY(hipMemsetAsync(d_hits_n.p, 0, sizeof(unsigned long long), st));
+        HIP_TRY(dsi::launch_tie_hits(st, m->xy.p, m->centers.p, m->planes_dev, m->geom, (int)np, d_zlist.p, (int)zlist.size(), d_bitmap.p,
+                                     d_sv.p, (int)sv.size(), d_hits_n.p, d_hits.p, n_hits));
+        std::vector<dsi::TieHit> hits((size_t)n_hits);
+        HIP_TRY(hipMemcpyAsync(hits.data(), d_hits.p, (size_t)n_hits * sizeof(dsi::TieHit), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        std::sort(hits.begin(), hits.end(), [](const dsi::TieHit& a, const dsi::TieHit& b_) {
+            return a.cid != b_.cid ? a.cid < b_.cid : a.order < b_.order;
+        });
+        size_t i = 0;
+        while (i < hits.size()) {
+            const uint32_t cid = hits[i].cid;
+            float sum = 0.f;  // resetGrid (mapper_emvs_stereo.cpp:145), then "+=" per vote in event order (cartesian3dgrid.h:261-270)
+            size_t cnt = 0;
+            for (; i < hits.size() && hits[i].cid == cid; ++i, ++cnt) sum += hits[i].w;
+            exact[c][cid] = sum;
+            if (cnt > 1) info->max_rel_bound = std::max(info->max_rel_bound, (double)(cnt - 1) * 5.9604644775390625e-8);
+        }
+    }
+
+    // 4. fuse, first maximum per column, patch
+    std::vector<uint32_t> pix;
+    std::vector<uint8_t> new_idx;
+    std::vector<float> new_conf;
+    std::vector<uint8_t> old_idx((size_t)npix);
+    HIP_TRY(hipMemcpy(old_idx.data(), out->idx.p, (size_t)npix, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < cand.size();) {
+        const uint32_t p = cand[i] % (uint32_t)npix;
+        float best = 0.f;
+        int best_z = -1;
+        for (; i < cand.size() && cand[i] % (uint32_t)npix == p; ++i) {  // a column's run, planes ascending
+            const size_t cid = (size_t)(std::lower_bound(sv.begin(), sv.end(), cand[i]) - sv.begin());
+            const float v = n == 2 ? dsi::host::fuse2(op, exact[0][cid], exact[1][cid]) : exact[0][cid];
+            if (best_z < 0 || best < v) {  // std::max_element: the first maximum wins (cartesian3dgrid.cpp:132-134)
+                best = v;
+                best_z = (int)(cand[i] / (uint32_t)npix);
+            }
+        }
+        pix.push_back(p);
+        new_idx.push_back((uint8_t)best_z);
+        new_conf.push_back(best);
+        if (old_idx[p] != (uint8_t)best_z) ++info->changed_pixels;
+    }
+    TmpDev<uint32_t> d_pix;
+    TmpDev<uint8_t> d_idx;
+    TmpDev<float> d_conf;
+    HIP_TRY(d_pix.alloc(pix.size()));
+    HIP_TRY(d_idx.alloc(pix.size()));
+    HIP_TRY(d_conf.alloc(pix.size()));
+    HIP_TRY(hipMemcpyAsync(d_pix.p, pix.data(), pix.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_idx.p, new_idx.data(), pix.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_conf.p, new_conf.data(), pix.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    if (int rc = depth_buffers_acquire(out)) return rc;
+    HIP_TRY(dsi::launch_tie_patch(st, d_pix.p, d_idx.p, d_conf.p, (int)pix.size(), out->planes_dev, out->conf.p, out->idx.p, out->depth.p));
+    if (int rc = depth_buffers_ready(out)) return rc;
+    HIP_TRY(hipStreamSynchronize(st));
+    return finish();
 }
 
 int dsi_mapper_fetch_depth_map(dsi_mapper_t* m, float* depth_host, float* conf_host, uint8_t* idx_host)

@@ -216,5 +216,28 @@ inline void argmax_unkey(uint64_t key, float* conf, int* global_plane)
     *global_plane = 255 - (int)(key & 255u);
 }
 
+// The 2-ary camera-fusion ops on the host, for the handful of voxels the exact tie resolver re-sums
+// (dsi_mapper_resolve_near_ties): the same operations in the same order as the device's fuse_op (dsi_kernels.hip),
+// i.e. as Grid3D::minTwoGrids ... maxTwoGrids (cartesian3dgrid.h:111-190) applied to a grid that was initialised by
+// resetGrid(); addTwoGrids(a) (process1.cpp:126-127: 0 + a).  Compiled without FMA contraction.
+inline float fuse2(int op, float a0, float g)
+{
+    const float a = 0.f + a0;
+    switch (op) {
+    case 1: return (g < a) ? g : a;  // std::min, :115
+    case 2: {                        // :119-127
+        const float prod = a * g, sum = a + g;
+        return 2.f * prod / (sum + 0.1f);
+    }
+    case 3: return std::sqrt(a * g);  // :154
+    case 4: return (float)(0.5 * (double)(a + g));  // :162
+    case 5: {                                       // :145-146
+        const float ms = (float)(0.5 * ((double)a * (double)a + (double)g * (double)g));
+        return std::sqrt(ms);
+    }
+    default: return (a < g) ? g : a;  // std::max, :188
+    }
+}
+
 }  // namespace host
 }  // namespace dsi

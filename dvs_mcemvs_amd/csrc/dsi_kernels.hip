@@ -3556,6 +3556,118 @@ __global__ void k_div_probe(const float* __restrict__ n, const float* __restrict
     ref[i] = n[i] / d[i];
 }
 
+// ---------------------------------------------------------------- exact tie resolver --
+// The banded kernels sum a voxel's votes exactly (64-bit fixed point, one rounding); the reference adds them in
+// fp32, in event order, rounding after every vote (cartesian3dgrid.h:261-270 inside mapper_emvs_stereo.cpp:197-201).
+// Both are within ~1e-5 of each other, so the arg-max over Z can differ only where a column's two best planes are
+// closer than that.  For those columns the resolver re-sums the contending voxels in the REFERENCE's order:
+//   k_tie_candidates   per pixel: planes whose (fused) value lies within rel_gap of the column's maximum, if >= 2
+//   k_tie_mark         one bit per contending voxel
+//   k_tie_hits         every event x contending plane: the reference's coordinates (IEEE divide), accept test and
+//                      four weights, as k_vote_global computes them; a vote that lands on a marked voxel is recorded
+//                      as (voxel, event order, weight)
+// the host sorts the records by (voxel, event order), adds them up in fp32 one by one, applies the camera fusion and
+// picks the first maximum (cartesian3dgrid.cpp:132-134); k_tie_patch writes the few changed pixels.
+template <int OP>
+__device__ __forceinline__ float tie_value(const float* __restrict__ a, const float* __restrict__ b, size_t i)
+{
+    if (OP == 0) return a[i];
+    return fuse_op<OP>(0.f + a[i], b[i]);  // as k_collapse_max_z_fused / k_fuse2_into compute the fused voxel
+}
+
+template <int OP>
+__global__ __launch_bounds__(256) void k_tie_candidates(const float* __restrict__ a, const float* __restrict__ b, int npix,
+                                                        int nz, float rel_gap, unsigned* __restrict__ counters,
+                                                        uint32_t* __restrict__ cand, uint32_t cap)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    float best = tie_value<OP>(a, b, p);
+    for (int k = 1; k < nz; ++k) {
+        const float v = tie_value<OP>(a, b, (size_t)k * npix + p);
+        if (best < v) best = v;
+    }
+    if (!(best > 0.f)) return;  // an empty column is exactly zero in either summation order
+    const float thr = best - rel_gap * best;
+    int cnt = 0;
+    for (int k = 0; k < nz; ++k) cnt += tie_value<OP>(a, b, (size_t)k * npix + p) >= thr ? 1 : 0;
+    if (cnt < 2) return;
+    const unsigned base = atomicAdd(&counters[0], (unsigned)cnt);
+    atomicAdd(&counters[1], 1u);
+    if ((unsigned long long)base + (unsigned)cnt > cap) return;  // the host sees counters[0] > cap and retries larger
+    int j = 0;
+    for (int k = 0; k < nz; ++k)  // a pixel's contenders: one contiguous run, planes ascending
+        if (tie_value<OP>(a, b, (size_t)k * npix + p) >= thr) cand[base + j++] = (uint32_t)((size_t)k * npix + p);
+}
+
+__global__ __launch_bounds__(256) void k_tie_mark(const uint32_t* __restrict__ sv, int n, uint32_t* __restrict__ bitmap)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicOr(&bitmap[sv[i] >> 5], 1u << (sv[i] & 31u));
+}
+
+// block = (packet, group of kVgPlanes contending planes); thread t owns events t, t + 256, ... of the packet
+__global__ __launch_bounds__(256) void k_tie_hits(const float2* __restrict__ xy, const float* __restrict__ centers,
+                                                  const float* __restrict__ planes, Geom g, const int* __restrict__ zlist,
+                                                  int nzl, const uint32_t* __restrict__ bitmap,
+                                                  const uint32_t* __restrict__ sv, int nsv,
+                                                  unsigned long long* __restrict__ hit_counter, TieHit* __restrict__ hits,
+                                                  unsigned long long cap)
+{
+    const int k = blockIdx.x;
+    const int lbeg = blockIdx.y * kVgPlanes;
+    const int lend = min(nzl, lbeg + kVgPlanes);
+    const float cx_ = centers[3 * k], cy_ = centers[3 * k + 1], cz_ = centers[3 * k + 2];
+    float2 e[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = xy[(size_t)k * kPacket + threadIdx.x + 256 * i];
+    const float xmax = (float)(g.nx - 1), ymax = (float)(g.ny - 1);
+    const size_t plane_sz = (size_t)g.nx * g.ny;
+    for (int l = lbeg; l < lend; ++l) {
+        const int z = zlist[l];
+        float a, bx, by, d;
+        plane_coefficients(cx_, cy_, cz_, planes[z], g, a, bx, by, d);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float X = (e[i].x * a + bx) / d;  // mapper_emvs_stereo.cpp:194-195
+            const float Y = (e[i].y * a + by) / d;
+            if (!(X >= 0.f && Y >= 0.f && X < xmax && Y < ymax)) continue;  // cartesian3dgrid.h:255-259 (see vote_global)
+            const int xi = (int)X, yi = (int)Y;
+            const float fx = X - (float)xi, fy = Y - (float)yi, fx1 = 1.f - fx, fy1 = 1.f - fy;
+            const float w[4] = {fx1 * fy1, fx * fy1, fx1 * fy, fx * fy};  // :261-270
+            const uint32_t v0 = (uint32_t)((size_t)z * plane_sz + (size_t)yi * g.nx + xi);
+            const uint32_t v[4] = {v0, v0 + 1u, v0 + (uint32_t)g.nx, v0 + (uint32_t)g.nx + 1u};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (!((bitmap[v[c] >> 5] >> (v[c] & 31u)) & 1u)) continue;
+                int lo = 0, hi = nsv;  // the voxel's rank among the contenders (sorted, unique)
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (sv[mid] < v[c])
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                const unsigned long long slot = atomicAdd(hit_counter, 1ull);
+                if (hits && slot < cap) hits[slot] = TieHit{(uint32_t)lo, (uint32_t)k * (uint32_t)kPacket + (uint32_t)(threadIdx.x + 256 * i), w[c]};
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tie_patch(const uint32_t* __restrict__ pix, const uint8_t* __restrict__ new_idx,
+                                                   const float* __restrict__ new_conf, int n,
+                                                   const float* __restrict__ planes, float* __restrict__ conf,
+                                                   uint8_t* __restrict__ idx, float* __restrict__ depth)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = pix[i];
+    conf[p] = new_conf[i];
+    idx[p] = new_idx[i];
+    depth[p] = planes[new_idx[i]];  // mapper_emvs_stereo.cpp:302-313
+}
+
 int grid_for(size_t work_items, int block, int max_blocks = 256 * 8)
 {
     size_t b = (work_items + block - 1) / block;
@@ -4170,6 +4282,48 @@ hipError_t launch_div_probe(hipStream_t s, const float* n, const float* d, size_
     hipLaunchKernelGGL(k_div_probe, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, n, d,
                        count, q, ref);
     return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
+}
+
+hipError_t launch_tie_candidates(hipStream_t s, const float* a, const float* b, int op, int npix, int nz, float rel_gap,
+                                 unsigned* counters, uint32_t* cand, uint32_t cap)
+{
+    const dim3 grid((npix + 255) / 256), block(256);
+    switch (b ? op : 0) {
+    case 0: hipLaunchKernelGGL(k_tie_candidates<0>, grid, block, 0, s, a, b, npix, nz, rel_gap, counters, cand, cap); break;
+    case 1: hipLaunchKernelGGL(k_tie_candidates<1>, grid, block, 0, s, a, b, npix, nz, rel_gap, counters, cand, cap); break;
+    case 2: hipLaunchKernelGGL(k_tie_candidates<2>, grid, block, 0, s, a, b, npix, nz, rel_gap, counters, cand, cap); break;
+    case 3: hipLaunchKernelGGL(k_tie_candidates<3>, grid, block, 0, s, a, b, npix, nz, rel_gap, counters, cand, cap); break;
+    case 4: hipLaunchKernelGGL(k_tie_candidates<4>, grid, block, 0, s, a, b, npix, nz, rel_gap, counters, cand, cap); break;
+    case 5: hipLaunchKernelGGL(k_tie_candidates<5>, grid, block, 0, s, a, b, npix, nz, rel_gap, counters, cand, cap); break;
+    case 6: hipLaunchKernelGGL(k_tie_candidates<6>, grid, block, 0, s, a, b, npix, nz, rel_gap, counters, cand, cap); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipExtGetLastError();
+}
+
+hipError_t launch_tie_mark(hipStream_t s, const uint32_t* sv, int n, uint32_t* bitmap)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_tie_mark, dim3((n + 255) / 256), dim3(256), 0, s, sv, n, bitmap);
+    return hipExtGetLastError();
+}
+
+hipError_t launch_tie_hits(hipStream_t s, const float2* xy, const float* centers, const float* planes, const Geom& g, int np,
+                           const int* zlist, int nzl, const uint32_t* bitmap, const uint32_t* sv, int nsv,
+                           unsigned long long* hit_counter, TieHit* hits, unsigned long long cap)
+{
+    if (np <= 0 || nzl <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_tie_hits, dim3(np, (nzl + kVgPlanes - 1) / kVgPlanes), dim3(256), 0, s, xy, centers, planes, g, zlist,
+                       nzl, bitmap, sv, nsv, hit_counter, hits, cap);
+    return hipExtGetLastError();
+}
+
+hipError_t launch_tie_patch(hipStream_t s, const uint32_t* pix, const uint8_t* new_idx, const float* new_conf, int n,
+                            const float* planes, float* conf, uint8_t* idx, float* depth)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_tie_patch, dim3((n + 255) / 256), dim3(256), 0, s, pix, new_idx, new_conf, n, planes, conf, idx, depth);
+    return hipExtGetLastError();
 }
 
 }  // namespace dsi

@@ -57,6 +57,12 @@ class _ScatterPlan(C.Structure):
                 ("tail_count", C.c_int)]
 
 
+class _ResolveInfo(C.Structure):
+    _fields_ = [("rel_gap", C.c_float), ("near_tie_pixels", C.c_int), ("candidate_voxels", C.c_int),
+                ("candidate_planes", C.c_int), ("votes", C.c_longlong), ("changed_pixels", C.c_int),
+                ("max_rel_bound", C.c_double), ("elapsed_ms", C.c_float)]
+
+
 class _VoteInfo(C.Structure):
     _fields_ = [("algo", C.c_int), ("bands", C.c_int), ("band_rows", C.c_int),
                 ("chunks", C.c_int), ("block_threads", C.c_int), ("lds_bytes", C.c_size_t),
@@ -193,6 +199,8 @@ def load_library():
         "dsi_mapper_argmax_keys_download": (C.c_int, [vp, u64p]),
         "dsi_mapper_argmax_keys_upload": (C.c_int, [vp, u64p]),
         "dsi_mapper_depth_map_from_keys": (C.c_int, [vp]),
+        "dsi_mapper_resolve_near_ties": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int,
+                                                  C.POINTER(_ResolveInfo)]),
     }
     if experiments_requested():     # hooks that exist only in the experiments flavour
         sig.update({
@@ -870,6 +878,19 @@ class MapperEMVS:
         hm = (C.c_void_p * len(mappers))(*[m._h for m in mappers])
         hb = (C.c_void_p * len(batches))(*[b._h for b in batches])
         _check(load_library().dsi_mapper_depth_map_of_events(self._h, hm, hb, len(mappers), int(fusion_method)))
+
+    def resolveNearTies(self, mappers, batches, fusion_method=FUSE_HM, rel_gap=0.0):
+        """Exact tie resolver (dsi_mapper_resolve_near_ties): after the mappers' DSIs were built from `batches`
+        (evaluateDSI_batch) and this mapper holds the depth map of their fusion, re-sum the contending voxels of the
+        near-tie columns in the REFERENCE's summation order (fp32, event order) and re-pick the first maximum, so that
+        the plane index map equals the CPU reference's on every pixel.  Returns the call's statistics (dict)."""
+        n = len(mappers)
+        hm = (C.c_void_p * n)(*[m._h for m in mappers])
+        hb = (C.c_void_p * n)(*[b._h for b in batches])
+        info = _ResolveInfo()
+        info.rel_gap = float(rel_gap)
+        _check(load_library().dsi_mapper_resolve_near_ties(self._h, hm, hb, n, int(fusion_method), C.byref(info)))
+        return {k: getattr(info, k) for k, _ in _ResolveInfo._fields_}
 
     def computeDepthMapSharded(self, grid, comm):
         """Plane-sharded arg-max: local collapse of this rank's plane range, ONE all-reduce(MAX) of

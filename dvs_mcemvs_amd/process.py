@@ -194,14 +194,21 @@ class WindowStream:
     window (main.cpp:262-275); here they are reused -- evaluateDSI resets the DSI anyway (:145)."""
 
     def __init__(self, ctx, cams, dsi_shape, fusion_method=E.FUSE_HM, luts=(None, None),
-                 inverse_depth=False, depth=2, materialize_fused=True, fused_vote=False, concurrent=False):
+                 inverse_depth=False, depth=2, materialize_fused=True, fused_vote=False, concurrent=False,
+                 exact_ties=False):
         """materialize_fused=False: the fused DSI (the reference's mapper_fused.dsi_) is not written;
         the camera fusion happens inside the arg-max kernel (same bits, one pass less over the
         volume) -- for streams that only keep the depth maps.
         fused_vote=True (implies materialize_fused=False): not even the camera DSIs are written -- one
         kernel votes, fuses and keeps the running arg-max on the CU (MapperEMVS.computeDepthMapOfEvents;
-        the same depth maps bit for bit)."""
+        the same depth maps bit for bit).
+        exact_ties=True: every window's arg-max goes through the exact tie resolver (MapperEMVS.resolveNearTies), so
+        that its plane index map equals the CPU reference's on every pixel; it needs the camera DSIs, so it excludes
+        fused_vote; the call's statistics (and cost) are in `last_resolve`."""
         self.ctx = ctx
+        self.exact_ties = bool(exact_ties)
+        self.last_resolve = None
+        fused_vote = bool(fused_vote) and not self.exact_ties
         self.fused_vote = bool(fused_vote)
         self.materialize_fused = bool(materialize_fused) and not self.fused_vote
         self.fusion_method = int(fusion_method)
@@ -246,7 +253,7 @@ class WindowStream:
         ctx = self.contexts[slot % len(self.contexts)]
         mappers = self.mapper_sets[slot % len(self.mapper_sets)]
         T_rv_w = reference_view_process1(trajectories[0], ts, rv_pos)
-        own, fused_batches = [], []
+        own, fused_batches, all_batches = [], [], []
         for c in range(2):
             if batches is not None:
                 b = batches[c]
@@ -265,6 +272,7 @@ class WindowStream:
                     Rt, first = pr.a[:Rt.shape[0]], pf.a[:first.shape[0]]
                 b = E.EventBatch(ctx, events[c][0], events[c][1], Rt, first, asynchronous=asynchronous)
                 own.append(b)
+            all_batches.append(b)
             if self.fused_vote:
                 fused_batches.append(b)
             else:
@@ -278,6 +286,8 @@ class WindowStream:
         else:
             self.extract[slot].computeDepthMapOfFusion(mappers[0].dsi_, mappers[1].dsi_,
                                                        self.fusion_method)
+        if self.exact_ties and len(all_batches) == 2:
+            self.last_resolve = self.extract[slot].resolveNearTies(mappers, all_batches, self.fusion_method)
         for b in own:
             b.close()                               # the block returns to the pool once its readers are done
         self.k += 1

@@ -433,6 +433,35 @@ DSI_API int dsi_mapper_argmax_keys_download(dsi_mapper_t *m, uint64_t *keys_host
 DSI_API int dsi_mapper_argmax_keys_upload(dsi_mapper_t *m, const uint64_t *keys_host);
 DSI_API int dsi_mapper_depth_map_from_keys(dsi_mapper_t *m);
 
+/* Exact tie resolver: makes the arg-max index map identical to the reference's on EVERY pixel.
+ * The engine sums a voxel's votes exactly (64-bit fixed point, rounded once); the reference adds them in fp32 in event
+ * order, rounding after every vote (cartesian3dgrid.h:261-270 inside mapper_emvs_stereo.cpp:197-201).  The two sums
+ * agree to ~1e-5, so the first-maximum plane (cartesian3dgrid.cpp:132-134) can differ only in columns whose best
+ * planes are closer than that -- and there the depth is off by a whole plane.  This call finds the columns of the
+ * fused DSI  op(grid(mappers[0]), grid(mappers[1]))  (n == 1: of grid(mappers[0])) that have two or more planes within
+ * rel_gap of the column's maximum, re-sums exactly those voxels of every camera in the REFERENCE's order (one pass
+ * over the batch's events on the contending planes: the reference's coordinates, accept test and weights; the
+ * recorded votes sorted by event index and added one by one in fp32), re-applies the fusion op, re-picks the first
+ * maximum and patches confidence / index / depth in `out`'s depth-map buffers.
+ * Preconditions: grid(mappers[i]) holds dsi_mapper_evaluate_batch(mappers[i], batches[i]); `out` holds the depth map
+ * of that fusion (dsi_mapper_depth_map_of / _of_fusion / _of_events).  n = 1 or 2; op = dsi_fuse_op_t.
+ * rel_gap 0 = 1e-3 (60x the largest difference observed between the two summation orders, 10x the tolerance every
+ * voxel is tested to); max_rel_bound reports, for the re-summed voxels, the rigorous bound (votes - 1) * 2^-24 on
+ * the relative difference of the two orders.  Optional and off the throughput path: costs one event pass per camera
+ * per call over the contending planes only (elapsed_ms).  Synchronises. */
+typedef struct {
+    float rel_gap;          /* in */
+    int near_tie_pixels;    /* out: columns with >= 2 contending planes */
+    int candidate_voxels;   /*      contending voxels re-summed (per camera) */
+    int candidate_planes;   /*      distinct planes among them */
+    long long votes;        /*      votes re-summed, all cameras */
+    int changed_pixels;     /*      pixels whose plane index changed */
+    double max_rel_bound;   /*      see above */
+    float elapsed_ms;       /*      wall time of the call */
+} dsi_resolve_info_t;
+DSI_API int dsi_mapper_resolve_near_ties(dsi_mapper_t *out, dsi_mapper_t *const *mappers,
+                                         const dsi_batch_t *const *batches, int n, int op, dsi_resolve_info_t *info);
+
 /* OptionsDepthMap (mapper_emvs_stereo.hpp:68-82), the fields the depth-map extraction reads */
 typedef struct {
     int adaptive_threshold_kernel_size; /* --adaptive_threshold_kernel_size, default 5 (main.cpp:73) */

@@ -1,0 +1,151 @@
+"""The exact tie resolver (dsi_mapper_resolve_near_ties): "depth map equal to the CPU reference" on EVERY pixel.
+
+The engine sums a voxel's votes exactly and rounds once; the reference adds them in fp32 in event order
+(cartesian3dgrid.h:261-270 inside mapper_emvs_stereo.cpp:197-201).  Where a column's best planes are closer than
+that difference the first-maximum plane (cartesian3dgrid.cpp:132-134) can differ -- by a whole plane of depth.  The
+resolver re-sums the contending voxels in the reference's order; afterwards the index map must equal the oracle's
+with `array_equal`, no "safe pixel" mask."""
+import numpy as np
+import pytest
+
+import dvs_mcemvs_amd as d
+from dvs_mcemvs_amd import process as proc, synthetic as syn
+from oracle import oracle as orc
+from oracle_pipeline import OracleMapper
+
+pytestmark = pytest.mark.gpu
+
+
+def _batches(ctx, rig, n):
+    out = []
+    for c in range(n):
+        first, Rt = d.packetize(rig["events"][c][2], rig["trajectories"][c], rig["T_rv_w"])
+        out.append(d.EventBatch(ctx, rig["events"][c][0], rig["events"][c][1], Rt, first))
+    return out
+
+
+def _oracle_fused(rig, n, op, dims, lut=None, inverse=False, depths=(4.0, 200.0)):
+    nx, ny, nz = dims
+    dsis = []
+    for c in range(n):
+        r = OracleMapper(rig["cam"], dimX=nx, dimY=ny, dimZ=nz, min_depth=depths[0], max_depth=depths[1], lut=lut,
+                         inverse_depth=inverse)
+        assert r.evaluateDSI(rig["events"][c], rig["trajectories"][c], rig["T_rv_w"])
+        dsis.append(r.dsi)
+    ref = dsis[0] if n == 1 else orc.fuse2(dsis[0].copy(), dsis[1], op)
+    return ref, r.planes
+
+
+@pytest.mark.parametrize("n_cams,op", [(1, 0), (2, d.FUSE_HM), (2, d.FUSE_MIN), (2, d.FUSE_GM), (2, d.FUSE_AM),
+                                       (2, d.FUSE_RMS), (2, d.FUSE_MAX)])
+@pytest.mark.parametrize("events", [12_000, 150_000])
+def test_resolved_index_map_equals_the_oracles(ctx, n_cams, op, events):
+    """Few events: most columns hold a handful of votes and many planes tie exactly or nearly; many events: ties
+    are rare but real.  Either way the resolved map is the oracle's, pixel for pixel."""
+    nx, ny, nz = 96, 72, 32
+    rig = syn.stereo_rig(events, width=nx, height=ny, duration=0.3, seed=5 + events % 7, n_points=700)
+    shape = d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0)
+    batches = _batches(ctx, rig, n_cams)
+    ms = [d.MapperEMVS(ctx, rig["cam"], shape) for _ in range(n_cams)]
+    for m, b in zip(ms, batches):
+        m.evaluateDSI_batch(b)
+    out = d.MapperEMVS(ctx, rig["cam"], shape)
+    if n_cams == 1:
+        out.computeDepthMap(ms[0].dsi_)
+    else:
+        out.computeDepthMapOfFusion(ms[0].dsi_, ms[1].dsi_, op)
+    _, conf0, idx0 = out.fetchDepthMap()
+    ref, planes = _oracle_fused(rig, n_cams, op, (nx, ny, nz))
+    rconf, ridx = orc.collapse_max_z(ref)
+    info = out.resolveNearTies(ms, batches, op)
+    depth, conf, idx = out.fetchDepthMap()
+    assert np.array_equal(idx, ridx), "%d of %d pixels differ after the resolver (%d before); %r" % (
+        (idx != ridx).sum(), idx.size, (idx0 != ridx).sum(), info)
+    assert np.array_equal(depth, planes[ridx])
+    assert info["changed_pixels"] == int((idx0 != idx).sum())
+    assert info["near_tie_pixels"] > 0 and info["candidate_voxels"] >= 2 * info["near_tie_pixels"]
+    # the patched pixels carry the reference-order confidence (exactly the oracle's); the others the exact-sum one
+    changed = idx0 != idx
+    assert np.array_equal(conf[changed], rconf[changed])
+    assert np.allclose(conf, rconf, rtol=1e-4, atol=1e-6)
+    assert info["max_rel_bound"] < info["rel_gap"] / 2            # the re-summed voxels' own rigorous bound
+    for o in ms + [out] + batches:
+        o.close()
+
+
+def test_resolver_with_lut_inverse_depth_and_the_fused_vote_kernel(ctx):
+    """Distortion LUT + inverse depth planes; the depth map to resolve comes from the fused vote -> fusion -> arg-max
+    kernel (no DSI written by it; the camera DSIs the resolver reads are built by evaluateDSI_batch)."""
+    nx, ny, nz = 120, 90, 40
+    rig = syn.stereo_rig(80_000, width=nx, height=ny, duration=0.3, seed=3, n_points=900)
+    lut = syn.radial_lut(rig["cam"])
+    shape = d.ShapeDSI(0, 0, nz, 3.0, 60.0, 0.0)
+    batches = _batches(ctx, rig, 2)
+    ms = [d.MapperEMVS(ctx, rig["cam"], shape, lut=lut, inverse_depth=True) for _ in range(2)]
+    for m, b in zip(ms, batches):
+        m.evaluateDSI_batch(b)
+    out = d.MapperEMVS(ctx, rig["cam"], shape, lut=lut, inverse_depth=True)
+    out.computeDepthMapOfEvents(ms, batches, d.FUSE_HM)
+    ref, planes = _oracle_fused(rig, 2, d.FUSE_HM, (nx, ny, nz), lut=lut, inverse=True, depths=(3.0, 60.0))
+    rconf, ridx = orc.collapse_max_z(ref)
+    info = out.resolveNearTies(ms, batches, d.FUSE_HM)
+    depth, conf, idx = out.fetchDepthMap()
+    assert np.array_equal(idx, ridx), info
+    assert np.array_equal(depth, planes[ridx])
+    # a second call finds the same contenders and changes nothing
+    again = out.resolveNearTies(ms, batches, d.FUSE_HM)
+    assert again["changed_pixels"] == 0 and again["candidate_voxels"] == info["candidate_voxels"]
+    for o in ms + [out] + batches:
+        o.close()
+
+
+def test_resolver_argument_checks(ctx):
+    rig = syn.stereo_rig(5_000, width=64, height=48, duration=0.1, seed=1)
+    shape = d.ShapeDSI(0, 0, 8, 4.0, 100.0, 0.0)
+    batches = _batches(ctx, rig, 2)
+    ms = [d.MapperEMVS(ctx, rig["cam"], shape) for _ in range(2)]
+    out = d.MapperEMVS(ctx, rig["cam"], shape)
+    with pytest.raises(d.DsiError):                      # no depth map to resolve yet
+        out.resolveNearTies(ms, batches, d.FUSE_HM)
+    for m, b in zip(ms, batches):
+        m.evaluateDSI_batch(b)
+    out.computeDepthMapOfFusion(ms[0].dsi_, ms[1].dsi_, d.FUSE_HM)
+    with pytest.raises(d.DsiError):
+        out.resolveNearTies(ms, batches, 9)
+    with pytest.raises(d.DsiError):
+        out.resolveNearTies(ms, batches, d.FUSE_HM, rel_gap=0.9)
+    with pytest.raises(d.DsiError):
+        out.resolveNearTies(ms + ms[:1], batches + batches[:1], d.FUSE_HM)
+    other = d.MapperEMVS(ctx, rig["cam"], d.ShapeDSI(0, 0, 9, 4.0, 100.0, 0.0))
+    with pytest.raises(d.DsiError):
+        out.resolveNearTies([ms[0], other], batches, d.FUSE_HM)
+    for o in ms + [out, other] + batches:
+        o.close()
+
+
+def test_window_stream_with_exact_ties_equals_the_oracle_on_every_pixel(ctx):
+    """BASELINE configs[2] shape (512x512x200, 2 x 500 k events per 50 ms window, camera HM): with
+    WindowStream(exact_ties=True) the plane index map of a window equals the oracle's arg-max of ITS fused volume
+    on every one of the 262,144 pixels."""
+    NX, NY, NZ, EV, DUR = 512, 512, 200, 500_000, 0.05
+    t0 = 10.0
+    rig = syn.stereo_rig(2 * EV, width=640, height=480, t0=t0, duration=2 * DUR, seed=77, n_points=6000)
+    shape = d.ShapeDSI(NX, NY, NZ, 4.0, 200.0, 0.0)
+    ws = proc.WindowStream(ctx, (rig["cam"],) * 2, shape, d.FUSE_HM, materialize_fused=False, exact_ties=True)
+    lo, hi = proc.window_bounds(t0, t0 + 2 * DUR + 1e-9, DUR, DUR)[1]
+    ev = [proc.window_events(rig["events"][c], lo, hi) for c in range(2)]
+    depth, conf, idx = ws.fetch(ws.submit(ev, rig["trajectories"], hi))
+    info = ws.last_resolve
+    T_rv_w = proc.reference_view_process1(rig["trajectories"][0], hi)
+    dsis = []
+    for c in range(2):
+        r = OracleMapper(rig["cam"], dimX=NX, dimY=NY, dimZ=NZ, min_depth=4.0, max_depth=200.0)
+        assert r.evaluateDSI(ev[c], rig["trajectories"][c], T_rv_w)
+        dsis.append(r.dsi)
+    ref = orc.fuse2(dsis[0].copy(), dsis[1], 2)
+    rconf, ridx = orc.collapse_max_z(ref)
+    print("configs[2] window, exact ties: %r" % (info,))
+    assert np.array_equal(idx, ridx), "%d pixels differ; %r" % ((idx != ridx).sum(), info)
+    assert np.array_equal(depth, r.planes[ridx])
+    assert np.allclose(conf, rconf, rtol=1e-4, atol=1e-6)
+    ws.close()

@@ -988,5 +988,18 @@ def test_configs1_against_the_oracle_at_full_size(ctx):
     print("configs[1] depth map, all %d pixels: %r" % (rep["pixels"], rep))
     assert rep["violations"] == 0, rep
     assert np.array_equal(depth, orc.indices_to_depth(idx, cpu[0].planes))   # depth = plane of the index, exactly
-    for o in gpu + [fused]:
+    # ... and with the exact tie resolver the index map IS the oracle's, on all 89,960 pixels:
+    # the contending voxels of the near-tie columns re-summed in the reference's order (fp32, event order)
+    batches = []
+    for c in range(2):
+        first, Rt = d.packetize(rig["events"][c][2], rig["trajectories"][c], rig["T_rv_w"])
+        batches.append(d.EventBatch(ctx, rig["events"][c][0], rig["events"][c][1], Rt, first))
+    info = gpu[0].resolveNearTies(gpu, batches, d.FUSE_HM)
+    depth2, conf2, idx2 = gpu[0].fetchDepthMap()
+    print("configs[1] exact tie resolver: %r; %d pixels differed before" % (info, int((idx != ridx).sum())))
+    assert np.array_equal(idx2, ridx)
+    assert np.array_equal(depth2, orc.indices_to_depth(ridx, cpu[0].planes))
+    assert np.array_equal(conf2[idx != ridx], rconf[idx != ridx])
+    assert info["changed_pixels"] == int((idx != ridx).sum())
+    for o in gpu + [fused] + batches:
         o.close()
