@@ -322,7 +322,15 @@ def parity_block(d, rig, dims, mappers, batches, fused):
     gf = fused.download()
     ferr = float((np.abs(gf.astype(np.float64) - ref) / np.maximum(1.0, np.abs(ref))).max())
     tol = 3e-4                                               # HM of two volumes each within 1e-4
+    unresolved = argmax_report(idx, ref, tol)
+    # the exact tie resolver (dsi_mapper_resolve_near_ties, optional, off the timed path): the contending voxels of the
+    # near-tie columns re-summed in the reference's order, after which the index map must BE the oracle's
+    res = mappers[0].resolveNearTies(mappers, batches, d.FUSE_HM)
+    depth, conf, idx = mappers[0].fetchDepthMap()
     rep = argmax_report(idx, ref, tol)
+    rep["index_map_equals_oracle"] = bool(np.array_equal(idx, ref.argmax(axis=0)))
+    rep["exact_tie_resolver"] = res
+    rep["without_resolver"] = {k: unresolved[k] for k in ("argmax_agree_frac", "near_tie_frac", "violations")}
     planes = mappers[0].raw_depths_vec_
     rep.update({"dsi_max_rel_err": errs, "fused_max_rel_err": ferr, "dsi_tolerance": 1e-4, "fused_tolerance": tol,
                 "depth_is_plane_of_index": bool(np.array_equal(depth, planes[idx])),

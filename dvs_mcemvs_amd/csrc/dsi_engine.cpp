@@ -1656,7 +1656,7 @@ int dsi_mapper_resolve_near_ties(dsi_mapper_t* out, dsi_mapper_t* const* mappers
     REQUIRE(out && mappers && batches && info, DSI_ERR_INVALID, "null argument");
     REQUIRE(n == 1 || n == 2, DSI_ERR_INVALID, "1 or 2 cameras (got %d)", n);
     REQUIRE(n == 1 || (op >= 1 && op <= 6), DSI_ERR_BAD_OP, "improper fusion method %d (expected 1..6)", op);
-    const float rel_gap = info->rel_gap > 0.f ? info->rel_gap : 1e-3f;
+    const float rel_gap = info->rel_gap > 0.f ? info->rel_gap : 2.5e-4f;
     REQUIRE(rel_gap < 0.5f, DSI_ERR_INVALID, "rel_gap %g is not a rounding-sized gap", (double)rel_gap);
     dsi_context* ctx = out->ctx;
     for (int i = 0; i < n; ++i) {
@@ -1730,8 +1730,16 @@ int dsi_mapper_resolve_near_ties(dsi_mapper_t* out, dsi_mapper_t* const* mappers
     HIP_TRY(hipMemsetAsync(d_bitmap.p, 0, bitmap_words * sizeof(uint32_t), st));
     HIP_TRY(dsi::launch_tie_mark(st, d_sv.p, (int)sv.size(), d_bitmap.p));
 
-    // 3. per camera: the votes that land on a contending voxel, in the reference's order; sequential fp32 sums
+    // 3. per camera: the votes that land on a contending voxel, sorted on the device into the reference's order
+    //    (voxel, event index), added one by one in fp32 by one thread per voxel
     std::vector<float> exact[2];
+    TmpDev<float> d_exact, d_gpu;
+    TmpDev<uint32_t> d_count;
+    HIP_TRY(d_exact.alloc(sv.size()));
+    HIP_TRY(d_gpu.alloc(sv.size()));
+    HIP_TRY(d_count.alloc(sv.size()));
+    unsigned cid_bits = 1;
+    while (cid_bits < 32 && ((size_t)1 << cid_bits) < sv.size()) ++cid_bits;
     for (int c = 0; c < n; ++c) {
         dsi_mapper* m = mappers[c];
         const dsi_batch* b = batches[c];
@@ -1747,31 +1755,43 @@ int dsi_mapper_resolve_near_ties(dsi_mapper_t* out, dsi_mapper_t* const* mappers
         unsigned long long n_hits = 0;
         HIP_TRY(hipMemsetAsync(d_hits_n.p, 0, sizeof(unsigned long long), st));
         HIP_TRY(dsi::launch_tie_hits(st, m->xy.p, m->centers.p, m->planes_dev, m->geom, (int)np, d_zlist.p, (int)zlist.size(), d_bitmap.p,
-                                     d_sv.p, (int)sv.size(), d_hits_n.p, nullptr, 0));
+                                     d_sv.p, (int)sv.size(), d_hits_n.p, nullptr, nullptr, 0));
         HIP_TRY(hipMemcpyAsync(&n_hits, d_hits_n.p, sizeof n_hits, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         info->votes += (long long)n_hits;
-        if (n_hits == 0) continue;
         REQUIRE(n_hits < ((unsigned long long)1 << 31), DSI_ERR_INVALID, "%llu votes to re-sum: rel_gap is not a rounding-sized gap here", n_hits);
-        TmpDev<dsi::TieHit> d_hits;
-        HIP_TRY(d_hits.alloc((size_t)n_hits));
-        HIP_TRY(hipMemsetAsync(d_hits_n.p, 0, sizeof(unsigned long long), st));
-        HIP_TRY(dsi::launch_tie_hits(st, m->xy.p, m->centers.p, m->planes_dev, m->geom, (int)np, d_zlist.p, (int)zlist.size(), d_bitmap.p,
-                                     d_sv.p, (int)sv.size(), d_hits_n.p, d_hits.p, n_hits));
-        std::vector<dsi::TieHit> hits((size_t)n_hits);
-        HIP_TRY(hipMemcpyAsync(hits.data(), d_hits.p, (size_t)n_hits * sizeof(dsi::TieHit), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        std::sort(hits.begin(), hits.end(), [](const dsi::TieHit& a, const dsi::TieHit& b_) {
-            return a.cid != b_.cid ? a.cid < b_.cid : a.order < b_.order;
-        });
-        size_t i = 0;
-        while (i < hits.size()) {
-            const uint32_t cid = hits[i].cid;
-            float sum = 0.f;  // resetGrid (mapper_emvs_stereo.cpp:145), then "+=" per vote in event order (cartesian3dgrid.h:261-270)
-            size_t cnt = 0;
-            for (; i < hits.size() && hits[i].cid == cid; ++i, ++cnt) sum += hits[i].w;
-            exact[c][cid] = sum;
-            if (cnt > 1) info->max_rel_bound = std::max(info->max_rel_bound, (double)(cnt - 1) * 5.9604644775390625e-8);
+        TmpDev<unsigned long long> d_keys, d_keys2;
+        TmpDev<float> d_w, d_w2;
+        TmpDev<char> d_tmp;
+        const unsigned long long* keys_sorted = nullptr;
+        const float* w_sorted = nullptr;
+        if (n_hits) {
+            HIP_TRY(d_keys.alloc((size_t)n_hits));
+            HIP_TRY(d_keys2.alloc((size_t)n_hits));
+            HIP_TRY(d_w.alloc((size_t)n_hits));
+            HIP_TRY(d_w2.alloc((size_t)n_hits));
+            HIP_TRY(hipMemsetAsync(d_hits_n.p, 0, sizeof(unsigned long long), st));
+            HIP_TRY(dsi::launch_tie_hits(st, m->xy.p, m->centers.p, m->planes_dev, m->geom, (int)np, d_zlist.p, (int)zlist.size(),
+                                         d_bitmap.p, d_sv.p, (int)sv.size(), d_hits_n.p, d_keys.p, d_w.p, n_hits));
+            size_t tmp_bytes = 0;
+            HIP_TRY(dsi::tie_sort_pairs(st, d_keys.p, d_keys2.p, d_w.p, d_w2.p, (size_t)n_hits, 32 + cid_bits, nullptr, &tmp_bytes));
+            HIP_TRY(d_tmp.alloc(tmp_bytes));
+            HIP_TRY(dsi::tie_sort_pairs(st, d_keys.p, d_keys2.p, d_w.p, d_w2.p, (size_t)n_hits, 32 + cid_bits, d_tmp.p, &tmp_bytes));
+            keys_sorted = d_keys2.p;
+            w_sorted = d_w2.p;
+        }
+        HIP_TRY(dsi::launch_tie_sums(st, keys_sorted, w_sorted, n_hits, d_sv.p, (int)sv.size(), m->grid->data, d_exact.p, d_count.p,
+                                     d_gpu.p));
+        std::vector<uint32_t> count(sv.size());
+        std::vector<float> gpu(sv.size());
+        HIP_TRY(hipMemcpyAsync(exact[c].data(), d_exact.p, sv.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(count.data(), d_count.p, sv.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(gpu.data(), d_gpu.p, sv.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));  // (also: the scratch above is freed only after its kernels are done)
+        for (size_t i = 0; i < sv.size(); ++i) {
+            if (count[i] > 1) info->max_rel_bound = std::max(info->max_rel_bound, (double)(count[i] - 1) * 5.9604644775390625e-8);
+            const double ref = (double)exact[c][i];
+            info->max_order_diff = std::max(info->max_order_diff, std::fabs((double)gpu[i] - ref) / std::max(1.0, std::fabs(ref)));
         }
     }
 

@@ -195,21 +195,25 @@ hipError_t launch_collapse_max_z_fused_n(hipStream_t s, const float* const* srcs
 hipError_t launch_mean_square(hipStream_t s, const float* dsi, size_t n, double* accum);
 
 // ---- exact tie resolver (dsi_mapper_resolve_near_ties): see the kernels' comment ----
-struct TieHit {
-    uint32_t cid;    // rank of the voxel among the sorted contenders
-    uint32_t order;  // packet * 1024 + slot: the position of the vote in the reference's loop over events
-    float w;         // the bilinear weight the reference adds (cartesian3dgrid.h:261-270)
-};
 // cand[<= cap] <- voxel indices (z * npix + p) of every plane whose value is within rel_gap of its column's maximum, for
 // the columns that have >= 2 such planes, a column's run contiguous and ascending in z; counters[0] = voxels (may exceed
 // cap: nothing beyond cap is written), counters[1] = columns.  b == nullptr: the values of `a`; else op(a, b)
 hipError_t launch_tie_candidates(hipStream_t s, const float* a, const float* b, int op, int npix, int nz, float rel_gap,
                                  unsigned* counters, uint32_t* cand, uint32_t cap);
 hipError_t launch_tie_mark(hipStream_t s, const uint32_t* sv, int n, uint32_t* bitmap);
-// hits == nullptr: count only
+// every vote of the contending planes that lands on a marked voxel: keys[] <- (rank of the voxel among sv) << 32 | position of
+// the vote in the reference's loop over events (packet * 1024 + slot), wts[] <- the bilinear weight the reference adds
+// (cartesian3dgrid.h:261-270).  keys == nullptr: count only
 hipError_t launch_tie_hits(hipStream_t s, const float2* xy, const float* centers, const float* planes, const Geom& g, int np,
                            const int* zlist, int nzl, const uint32_t* bitmap, const uint32_t* sv, int nsv,
-                           unsigned long long* hit_counter, TieHit* hits, unsigned long long cap);
+                           unsigned long long* hit_counter, unsigned long long* keys, float* wts, unsigned long long cap);
+// (key, weight) pairs sorted by key on the device (rocPRIM radix sort over the low key_bits bits; dsi_tie_sort.hip).
+// tmp == nullptr: *tmp_bytes <- the scratch the sort needs
+hipError_t tie_sort_pairs(hipStream_t s, unsigned long long* keys_in, unsigned long long* keys_out, float* w_in, float* w_out,
+                          size_t n, unsigned key_bits, void* tmp, size_t* tmp_bytes);
+// per contending voxel: its sorted votes added one by one in fp32, their number, and the engine's own value grid[sv[c]]
+hipError_t launch_tie_sums(hipStream_t s, const unsigned long long* keys, const float* wts, unsigned long long n,
+                           const uint32_t* sv, int nsv, const float* grid, float* exact, uint32_t* count, float* gpu);
 hipError_t launch_tie_patch(hipStream_t s, const uint32_t* pix, const uint8_t* new_idx, const float* new_conf, int n,
                             const float* planes, float* conf, uint8_t* idx, float* depth);
 

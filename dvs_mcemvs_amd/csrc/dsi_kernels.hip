@@ -3611,7 +3611,8 @@ __global__ __launch_bounds__(256) void k_tie_hits(const float2* __restrict__ xy,
                                                   const float* __restrict__ planes, Geom g, const int* __restrict__ zlist,
                                                   int nzl, const uint32_t* __restrict__ bitmap,
                                                   const uint32_t* __restrict__ sv, int nsv,
-                                                  unsigned long long* __restrict__ hit_counter, TieHit* __restrict__ hits,
+                                                  unsigned long long* __restrict__ hit_counter,
+                                                  unsigned long long* __restrict__ keys, float* __restrict__ wts,
                                                   unsigned long long cap)
 {
     const int k = blockIdx.x;
@@ -3649,10 +3650,41 @@ __global__ __launch_bounds__(256) void k_tie_hits(const float2* __restrict__ xy,
                         hi = mid;
                 }
                 const unsigned long long slot = atomicAdd(hit_counter, 1ull);
-                if (hits && slot < cap) hits[slot] = TieHit{(uint32_t)lo, (uint32_t)k * (uint32_t)kPacket + (uint32_t)(threadIdx.x + 256 * i), w[c]};
+                if (keys && slot < cap) {
+                    // key = (voxel's rank, position of the vote in the reference's loop over events): sorting by it
+                    // puts a voxel's votes in one run, in the order the reference adds them
+                    keys[slot] = ((unsigned long long)lo << 32) | ((unsigned long long)k * kPacket + (unsigned)(threadIdx.x + 256 * i));
+                    wts[slot] = w[c];
+                }
             }
         }
     }
+}
+
+// thread = contending voxel: its run of the sorted votes added one by one in fp32 -- resetGrid (mapper_emvs_stereo.cpp:145),
+// then "grid[i] += w" per vote in event order (cartesian3dgrid.h:261-270); gpu[] <- the engine's own value of the voxel
+__global__ __launch_bounds__(64) void k_tie_sums(const unsigned long long* __restrict__ keys, const float* __restrict__ wts,
+                                                 unsigned long long n, const uint32_t* __restrict__ sv, int nsv,
+                                                 const float* __restrict__ grid, float* __restrict__ exact,
+                                                 uint32_t* __restrict__ count, float* __restrict__ gpu)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nsv) return;
+    unsigned long long lo = 0, hi = n;  // first vote of voxel c
+    const unsigned long long want = (unsigned long long)c << 32;
+    while (lo < hi) {
+        const unsigned long long mid = (lo + hi) >> 1;
+        if (keys[mid] < want)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    float sum = 0.f;
+    uint32_t cnt = 0;
+    for (unsigned long long i = lo; i < n && (keys[i] >> 32) == (unsigned long long)c; ++i, ++cnt) sum += wts[i];
+    exact[c] = sum;
+    count[c] = cnt;
+    gpu[c] = grid[sv[c]];
 }
 
 __global__ __launch_bounds__(256) void k_tie_patch(const uint32_t* __restrict__ pix, const uint8_t* __restrict__ new_idx,
@@ -4310,11 +4342,19 @@ hipError_t launch_tie_mark(hipStream_t s, const uint32_t* sv, int n, uint32_t* b
 
 hipError_t launch_tie_hits(hipStream_t s, const float2* xy, const float* centers, const float* planes, const Geom& g, int np,
                            const int* zlist, int nzl, const uint32_t* bitmap, const uint32_t* sv, int nsv,
-                           unsigned long long* hit_counter, TieHit* hits, unsigned long long cap)
+                           unsigned long long* hit_counter, unsigned long long* keys, float* wts, unsigned long long cap)
 {
     if (np <= 0 || nzl <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_tie_hits, dim3(np, (nzl + kVgPlanes - 1) / kVgPlanes), dim3(256), 0, s, xy, centers, planes, g, zlist,
-                       nzl, bitmap, sv, nsv, hit_counter, hits, cap);
+                       nzl, bitmap, sv, nsv, hit_counter, keys, wts, cap);
+    return hipExtGetLastError();
+}
+
+hipError_t launch_tie_sums(hipStream_t s, const unsigned long long* keys, const float* wts, unsigned long long n,
+                           const uint32_t* sv, int nsv, const float* grid, float* exact, uint32_t* count, float* gpu)
+{
+    if (nsv <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_tie_sums, dim3((nsv + 63) / 64), dim3(64), 0, s, keys, wts, n, sv, nsv, grid, exact, count, gpu);
     return hipExtGetLastError();
 }
 

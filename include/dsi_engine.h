@@ -445,10 +445,13 @@ DSI_API int dsi_mapper_depth_map_from_keys(dsi_mapper_t *m);
  * maximum and patches confidence / index / depth in `out`'s depth-map buffers.
  * Preconditions: grid(mappers[i]) holds dsi_mapper_evaluate_batch(mappers[i], batches[i]); `out` holds the depth map
  * of that fusion (dsi_mapper_depth_map_of / _of_fusion / _of_events).  n = 1 or 2; op = dsi_fuse_op_t.
- * rel_gap 0 = 1e-3 (60x the largest difference observed between the two summation orders, 10x the tolerance every
- * voxel is tested to); max_rel_bound reports, for the re-summed voxels, the rigorous bound (votes - 1) * 2^-24 on
- * the relative difference of the two orders.  Optional and off the throughput path: costs one event pass per camera
- * per call over the contending planes only (elapsed_ms).  Synchronises. */
+ * rel_gap 0 = 2.5e-4: 15x the largest difference ever observed between the two summation orders (1.6e-5) and 2.5x the
+ * tolerance every voxel of every parity test is held to.  The call checks its own premise: max_order_diff is the
+ * largest |engine value - reference-order value| / max(1, value) over the voxels it re-summed -- the most-voted voxels
+ * of the volume are among them -- and must stay far below rel_gap / 2 (the tests assert 8x); max_rel_bound is the
+ * rigorous worst case (votes - 1) * 2^-24 for the same voxels.  Optional and off the throughput path: two event
+ * passes per camera over the contending planes, a device sort of the recorded votes and one thread per voxel adding
+ * them up (elapsed_ms).  Synchronises. */
 typedef struct {
     float rel_gap;          /* in */
     int near_tie_pixels;    /* out: columns with >= 2 contending planes */
@@ -457,6 +460,7 @@ typedef struct {
     long long votes;        /*      votes re-summed, all cameras */
     int changed_pixels;     /*      pixels whose plane index changed */
     double max_rel_bound;   /*      see above */
+    double max_order_diff;  /*      see above */
     float elapsed_ms;       /*      wall time of the call */
 } dsi_resolve_info_t;
 DSI_API int dsi_mapper_resolve_near_ties(dsi_mapper_t *out, dsi_mapper_t *const *mappers,
