@@ -3649,7 +3649,15 @@ __global__ __launch_bounds__(256) void k_tie_hits(const float2* __restrict__ xy,
                     else
                         hi = mid;
                 }
-                const unsigned long long slot = atomicAdd(hit_counter, 1ull);
+                // one atomic per wave instruction, not per vote (the lanes that got here together share it)
+                const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
+                const int leader = __builtin_ctzll(active);
+                const int lane_id = (int)(threadIdx.x & 63);
+                unsigned long long base = 0;
+                if (lane_id == leader) base = atomicAdd(hit_counter, (unsigned long long)__builtin_popcountll(active));
+                base = ((unsigned long long)__builtin_amdgcn_readlane((int)(base >> 32), leader) << 32) |
+                       (unsigned)__builtin_amdgcn_readlane((int)(unsigned)base, leader);
+                const unsigned long long slot = base + (unsigned)__builtin_popcountll(active & ((1ull << lane_id) - 1ull));
                 if (keys && slot < cap) {
                     // key = (voxel's rank, position of the vote in the reference's loop over events): sorting by it
                     // puts a voxel's votes in one run, in the order the reference adds them

@@ -3,6 +3,7 @@
 // output):
 //
 //   process_1   mapper_emvs_stereo/src/process1.cpp:28-224   one DSI per camera, camera fusion
+//   process_1_exact_depth_map                                process_1 + arg-max whose index map equals the CPU reference's on every pixel
 //   process_1_depth_map                                      the same + the arg-max of getDepthMapFromDSI, without
 //                                                            writing any DSI (one fused kernel)
 //   process_2   mapper_emvs_stereo/src/process2.cpp:28-302   sub-intervals: camera fusion then
@@ -170,6 +171,82 @@ inline dsi::Transformation process_1_depth_map_n(const LinearTrajectory* const* 
         throw;
     }
     for (dsi_batch_t* b : bs) dsi_batch_destroy(b);
+    return T_rv_w;
+}
+
+// Alg. 1 + the arg-max of getDepthMapFromDSI with the EXACT TIE RESOLVER (dsi_mapper_resolve_near_ties): what
+// process_1(...) + mapper_fused.getDepthMapFromDSI(depth_map, confidence_map, depth_cell_indices) gives, except that the
+// plane index map equals the CPU reference's on EVERY pixel: the engine sums a voxel's votes exactly and rounds once, the
+// reference adds them in fp32 in event order (cartesian3dgrid.h:261-270), so the first-maximum plane
+// (cartesian3dgrid.cpp:132-134) can differ where a column's best planes are closer than that rounding; those columns'
+// contending voxels are re-summed in the reference's order.  Two cameras; the camera DSIs and the fused DSI are written
+// (mapper0.dsi_, mapper1.dsi_, mapper_fused.dsi_) like process_1 does.  info (optional): the resolver's statistics.
+inline dsi::Transformation process_1_exact_depth_map(const LinearTrajectory& trajectory0, const LinearTrajectory& trajectory1,
+                                                     const std::vector<dsi::Event>& events0, const std::vector<dsi::Event>& events1,
+                                                     EMVS::MapperEMVS& mapper_fused, EMVS::MapperEMVS& mapper0,
+                                                     EMVS::MapperEMVS& mapper1, double ts, int fusion_method,
+                                                     dsi::Image<float>& depth_map, dsi::Image<float>& confidence_map,
+                                                     dsi::Image<uint8_t>& depth_cell_indices, dsi_resolve_info_t* info = nullptr,
+                                                     double rv_pos = 0.0)
+{
+    dsi::Transformation T_w_l;
+    if (!trajectory0.getPoseAt(ts, T_w_l)) throw dsi::Error(DSI_ERR_INVALID, "no pose at the reference timestamp");
+    dsi::Transformation baseline;
+    baseline.t[0] = rv_pos;
+    const dsi::Transformation T_rv_w = dsi::inverse(T_w_l * baseline);  // process1.cpp:56-68
+    double T7[7];
+    T_rv_w.to7(T7);
+    const LinearTrajectory* trs[2] = {&trajectory0, &trajectory1};
+    const std::vector<dsi::Event>* evs[2] = {&events0, &events1};
+    dsi_mapper_t* ms[2] = {mapper0.handle(), mapper1.handle()};
+    dsi_batch_t* bs[2] = {nullptr, nullptr};
+    dsi_context_t* ctx = mapper_fused.context();
+    auto release = [&]() {
+        for (dsi_batch_t* b : bs) dsi_batch_destroy(b);
+    };
+    try {
+        std::vector<uint16_t> xs, ys;
+        std::vector<double> tss;
+        std::vector<uint32_t> first;
+        std::vector<float> Rt;
+        for (int c = 0; c < 2; ++c) {
+            const size_t ne = evs[c]->size();
+            xs.resize(ne);
+            ys.resize(ne);
+            tss.resize(ne);
+            for (size_t i = 0; i < ne; ++i) {
+                xs[i] = (*evs[c])[i].x;
+                ys[i] = (*evs[c])[i].y;
+                tss[i] = (*evs[c])[i].ts;
+            }
+            first.assign(ne / DSI_PACKET_SIZE + 1, 0u);
+            Rt.assign(12 * first.size(), 0.f);
+            size_t np = 0;
+            const int rc = dsi_packetize(tss.data(), ne, trs[c]->times().data(), trs[c]->poses7().data(), trs[c]->times().size(),
+                                         T7, first.data(), Rt.data(), &np);
+            if (rc == DSI_ERR_TOO_FEW_EVENTS) np = 0;  // evaluateDSI returns false (mapper_emvs_stereo.cpp:71-75)
+            else dsi::check(rc);
+            dsi::check(dsi_batch_create(ctx, xs.data(), ys.data(), ne, first.data(), Rt.data(), np, &bs[c]));
+            dsi::check(dsi_mapper_evaluate_batch(ms[c], bs[c]));  // process1.cpp:76, :94
+        }
+        mapper_fused.dsi_.resetGrid();                 // :126
+        mapper_fused.dsi_.addTwoGrids(mapper0.dsi_);   // :127
+        dsi::fuseTwoGrids(mapper_fused.dsi_, mapper1.dsi_, fusion_method, "Improper fusion method selected");
+        dsi::check(dsi_mapper_depth_map_of(mapper_fused.handle(), mapper_fused.dsi_.handle()));  // :222 -> collapseMaxZSlice
+        dsi_resolve_info_t local{};
+        dsi::check(dsi_mapper_resolve_near_ties(mapper_fused.handle(), ms, bs, 2, fusion_method, info ? info : &local));
+        int nx, ny, nz;
+        mapper_fused.dsi_.getDimensions(&nx, &ny, &nz);
+        depth_map = dsi::Image<float>(ny, nx);
+        confidence_map = dsi::Image<float>(ny, nx);
+        depth_cell_indices = dsi::Image<uint8_t>(ny, nx);
+        dsi::check(dsi_mapper_fetch_depth_map(mapper_fused.handle(), depth_map.data.data(), confidence_map.data.data(),
+                                              depth_cell_indices.data.data()));
+    } catch (...) {
+        release();
+        throw;
+    }
+    release();
     return T_rv_w;
 }
 

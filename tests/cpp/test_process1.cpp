@@ -258,6 +258,32 @@ int main()
                     return 65;
                 }
             }
+            // the exact tie resolver: the index map of process_1_exact_depth_map IS the oracle's arg-max of the oracle's
+            // fused volume (first maximum, cartesian3dgrid.cpp:132-134), on every pixel, for every fusion method
+            for (int method = 1; method <= 6; ++method) {
+                dsi::Image<float> d3, c3;
+                dsi::Image<uint8_t> i3;
+                dsi_resolve_info_t rinfo{};
+                process_1_exact_depth_map(trajectory0, trajectory1, events0, events1, mapper_fused, mapper0, mapper1, 0.5, method, d3,
+                                          c3, i3, &rinfo);
+                std::vector<float> of = ref0;
+                for (float& v : of) v = 0.f + v;
+                orc_fuse2(of.data(), ref1.data(), of.size(), method);
+                const size_t npix = i3.data.size();
+                const size_t planes_n = of.size() / npix;
+                size_t differ = 0;
+                for (size_t p = 0; p < npix; ++p) {
+                    size_t best = 0;
+                    for (size_t z = 1; z < planes_n; ++z)
+                        if (of[best * npix + p] < of[z * npix + p]) best = z;
+                    differ += (size_t)i3.data[p] != best;
+                }
+                if (differ != 0 || rinfo.near_tie_pixels <= 0) {
+                    std::printf("process_1_exact_depth_map: %zu pixels differ from the oracle for fusion method %d (%d near-tie columns)\n",
+                                differ, method, rinfo.near_tie_pixels);
+                    return 67;
+                }
+            }
             // three cameras (process1.cpp:105-117, :169-191): the right camera's second half of events plays camera 2
             {
                 const std::vector<dsi::Event> events2(events1.begin() + (long)(events1.size() / 2), events1.end());
