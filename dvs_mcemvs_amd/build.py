@@ -37,7 +37,7 @@ def needs_build(out=OUT):
 
 def build(force=False, verbose=False, experiments=False):
     """Builds the production library; experiments=True (`--experiments`) builds the experiments flavour INSTEAD, into
-    its own file (libdsi_engine_experiments.so): the environment knobs of the timing experiments quoted in DESIGN.md
+    its own file (libdsi_engine_experiments.so): the environment knobs of the timing experiments quoted in NOTEBOOK.md
     (DSI_EXPERIMENT, DSI_PERSISTENT, DSI_PASS_LG, DSI_GROUP_PACKETS, DSI_PREP_OVERLAP) and the dsi_test_* hooks exist
     only there.  The production library reads no environment and exports no test hook."""
     out = OUT_EXPERIMENTS if experiments else OUT

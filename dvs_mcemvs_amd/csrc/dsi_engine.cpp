@@ -360,7 +360,7 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
     bp->experiment = 0;
     bp->pass_lg = (m->want_pass_lg >= 1 && m->want_pass_lg <= 6) ? m->want_pass_lg : 0;  // test hook dsi_test_pass_lg
 #ifdef DSI_TIMING_EXPERIMENTS
-    // Environment knobs of the timing experiments quoted in DESIGN.md.  They are compiled in ONLY by
+    // Environment knobs of the timing experiments quoted in NOTEBOOK.md.  They are compiled in ONLY by
     // `python -m dvs_mcemvs_amd.build --experiments` (a stray variable in a job's environment must
     // not be able to change -- DSI_EXPERIMENT: corrupt -- the results of the production library).
     if (const char* e = std::getenv("DSI_PERSISTENT")) {  // A/B: 0 off, 1 on wherever the kernel supports it
@@ -1993,7 +1993,7 @@ int dsi_build_flavour(void)
 #ifdef DSI_TIMING_EXPERIMENTS
 /* Everything from here to the #endif exists only in the EXPERIMENTS flavour of the library
  * (libdsi_engine_experiments.so, `python -m dvs_mcemvs_amd.build --experiments`): hooks of the timing experiments and
- * development tools quoted in DESIGN.md.  The production library exports no dsi_test_* symbol (tests/test_abi.py). */
+ * development tools quoted in NOTEBOOK.md.  The production library exports no dsi_test_* symbol (tests/test_abi.py). */
 /* test hook (not in the public header): packets per pass of the voting streams, as a power of two (0 = automatic) */
 DSI_API int dsi_test_pass_lg(dsi_mapper_t* m, int lg)
 {

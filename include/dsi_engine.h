@@ -114,7 +114,7 @@ DSI_API const char *dsi_last_error(void);
 DSI_API int dsi_abi_version(void);
 /* 0: the production library (libdsi_engine.so).  1: the EXPERIMENTS flavour (libdsi_engine_experiments.so, built with
  * -DDSI_TIMING_EXPERIMENTS by `python -m dvs_mcemvs_amd.build --experiments`), which also reads the environment knobs
- * of the timing experiments quoted in DESIGN.md and exports dsi_test_* hooks -- some of which make the DSIs WRONG on
+ * of the timing experiments quoted in NOTEBOOK.md and exports dsi_test_* hooks -- some of which make the DSIs WRONG on
  * purpose; never ship or benchmark it.  The production library reads no environment and exports no dsi_test_*. */
 DSI_API int dsi_build_flavour(void);
 /* number of HIP devices visible, or 0 (never fails) */
