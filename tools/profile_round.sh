@@ -23,7 +23,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_s
 done
 python tools/rocpd_summary.py $OUT/trace/*.db > $OUT/kernel_trace_stats.txt 2>&1
 python tools/rocpd_summary.py $OUT/pmc*/*.db > $OUT/pmc_counters.txt 2>&1
-tail -1 $OUT/trace.log > $OUT/bench_line_under_rocprof.json
+grep "^{" $OUT/trace.log | tail -1 > $OUT/bench_line_under_rocprof.json
 python tools/make_traffic_json.py $OUT/pmc_counters.txt 512 512 200 > $OUT/traffic.json
 rm -rf $OUT/trace $OUT/pmc[0-9]*  # keep the summaries (the .db files are large)
 ls -la $OUT

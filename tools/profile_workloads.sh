@@ -20,7 +20,7 @@ one() {  # TAG "bench args for the trace" "bench args for the PMC passes" groups
   timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python bench.py --no-cpu --no-extra $TARGS > $OUT/trace.log 2>&1
   echo "$TAG trace rc=$?"
   python tools/rocpd_summary.py $OUT/trace/*.db > $OUT/kernel_trace_stats.txt 2>&1
-  tail -1 $OUT/trace.log > $OUT/bench_line_under_rocprof.json
+  grep "^{" $OUT/trace.log | tail -1 > $OUT/bench_line_under_rocprof.json
   local i=0
   for grp in "$@"; do
     i=$((i+1))
