@@ -181,8 +181,23 @@ struct dsi_batch {
     size_t n_events = 0, n_packets = 0;
 };
 
+// grow-only device scratch of the exact tie resolver (dsi_mapper_resolve_near_ties), owned by the output mapper
+struct TieScratch {
+    DevBuf<uint32_t> cand, sv, bitmap, count;
+    DevBuf<int> zlist;
+    DevBuf<unsigned long long> counters, keys, keys2;
+    DevBuf<float> w, w2, exact, gpu;
+    DevBuf<char> tmp;
+    void release()
+    {
+        cand.release(); sv.release(); bitmap.release(); count.release(); zlist.release(); counters.release();
+        keys.release(); keys2.release(); w.release(); w2.release(); exact.release(); gpu.release(); tmp.release();
+    }
+};
+
 struct dsi_mapper {
     dsi_context* ctx = nullptr;
+    TieScratch tie;
     int sensor_w = 0, sensor_h = 0;
     dsi::Geom geom{};
     std::vector<float> planes;  // raw_depths_vec_ (of the planes this mapper owns)
@@ -1167,6 +1182,7 @@ int dsi_mapper_destroy(dsi_mapper_t* m)
     if (m->planes_dev) (void)hipFree(m->planes_dev);
     if (m->planes_full_dev) (void)hipFree(m->planes_full_dev);
     m->argmax_keys.release();
+    m->tie.release();
     if (m->lut_dev) (void)hipFree(m->lut_dev);
     m->centers.release();
     m->H.release();
@@ -1675,25 +1691,25 @@ int dsi_mapper_resolve_near_ties(dsi_mapper_t* out, dsi_mapper_t* const* mappers
     const auto t_begin = std::chrono::steady_clock::now();
     *info = dsi_resolve_info_t{};
     info->rel_gap = rel_gap;
+    TieScratch& ts = out->tie;  // grow-only scratch of the output mapper: a stream of calls allocates nothing
 
     // 1. the contending voxels
     std::vector<uint32_t> cand;
     unsigned counters[2] = {0, 0};
+    HIP_TRY(ts.counters.reserve(4));
     {
-        size_t cap = std::min<size_t>(nvox, (size_t)1 << 20);
+        size_t cap = std::max<size_t>(ts.cand.cap, std::min<size_t>(nvox, (size_t)1 << 20));
         for (;;) {
-            TmpDev<uint32_t> d_cand;
-            TmpDev<unsigned> d_cnt;
-            HIP_TRY(d_cand.alloc(cap));
-            HIP_TRY(d_cnt.alloc(2));
-            HIP_TRY(hipMemsetAsync(d_cnt.p, 0, 2 * sizeof(unsigned), st));
+            HIP_TRY(ts.cand.reserve(cap));
+            HIP_TRY(hipMemsetAsync(ts.counters.p, 0, 4 * sizeof(unsigned long long), st));
+            unsigned* d_cnt = reinterpret_cast<unsigned*>(ts.counters.p);
             HIP_TRY(dsi::launch_tie_candidates(st, mappers[0]->grid->data, n == 2 ? mappers[1]->grid->data : nullptr, op, npix, nz,
-                                               rel_gap, d_cnt.p, d_cand.p, (uint32_t)std::min<size_t>(cap, 0xffffffffu)));
-            HIP_TRY(hipMemcpyAsync(counters, d_cnt.p, sizeof counters, hipMemcpyDeviceToHost, st));
+                                               rel_gap, d_cnt, ts.cand.p, (uint32_t)std::min<size_t>(cap, 0xffffffffu)));
+            HIP_TRY(hipMemcpyAsync(counters, d_cnt, sizeof counters, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             if (counters[0] <= cap) {
                 cand.resize(counters[0]);
-                if (counters[0]) HIP_TRY(hipMemcpy(cand.data(), d_cand.p, counters[0] * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                if (counters[0]) HIP_TRY(hipMemcpy(cand.data(), ts.cand.p, counters[0] * sizeof(uint32_t), hipMemcpyDeviceToHost));
                 break;
             }
             REQUIRE(cap < nvox, DSI_ERR_INVALID, "more contending voxels than voxels");
@@ -1717,27 +1733,22 @@ int dsi_mapper_resolve_near_ties(dsi_mapper_t* out, dsi_mapper_t* const* mappers
         if (zlist.empty() || zlist.back() != z) zlist.push_back(z);
     }
     info->candidate_planes = (int)zlist.size();
-    TmpDev<uint32_t> d_sv, d_bitmap;
-    TmpDev<int> d_zlist;
-    TmpDev<unsigned long long> d_hits_n;
     const size_t bitmap_words = (nvox + 31) / 32 + 1;
-    HIP_TRY(d_sv.alloc(sv.size()));
-    HIP_TRY(d_bitmap.alloc(bitmap_words));
-    HIP_TRY(d_zlist.alloc(zlist.size()));
-    HIP_TRY(d_hits_n.alloc(1));
-    HIP_TRY(hipMemcpyAsync(d_sv.p, sv.data(), sv.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_zlist.p, zlist.data(), zlist.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(d_bitmap.p, 0, bitmap_words * sizeof(uint32_t), st));
-    HIP_TRY(dsi::launch_tie_mark(st, d_sv.p, (int)sv.size(), d_bitmap.p));
+    HIP_TRY(ts.sv.reserve(sv.size()));
+    HIP_TRY(ts.bitmap.reserve(bitmap_words));
+    HIP_TRY(ts.zlist.reserve(zlist.size()));
+    HIP_TRY(ts.exact.reserve(sv.size()));
+    HIP_TRY(ts.gpu.reserve(sv.size()));
+    HIP_TRY(ts.count.reserve(sv.size()));
+    HIP_TRY(hipMemcpyAsync(ts.sv.p, sv.data(), sv.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ts.zlist.p, zlist.data(), zlist.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(ts.bitmap.p, 0, bitmap_words * sizeof(uint32_t), st));
+    HIP_TRY(dsi::launch_tie_mark(st, ts.sv.p, (int)sv.size(), ts.bitmap.p));
+    unsigned long long* d_hits_n = ts.counters.p + 2;
 
     // 3. per camera: the votes that land on a contending voxel, sorted on the device into the reference's order
     //    (voxel, event index), added one by one in fp32 by one thread per voxel
     std::vector<float> exact[2];
-    TmpDev<float> d_exact, d_gpu;
-    TmpDev<uint32_t> d_count;
-    HIP_TRY(d_exact.alloc(sv.size()));
-    HIP_TRY(d_gpu.alloc(sv.size()));
-    HIP_TRY(d_count.alloc(sv.size()));
     unsigned cid_bits = 1;
     while (cid_bits < 32 && ((size_t)1 << cid_bits) < sv.size()) ++cid_bits;
     for (int c = 0; c < n; ++c) {
@@ -1752,42 +1763,45 @@ int dsi_mapper_resolve_near_ties(dsi_mapper_t* out, dsi_mapper_t* const* mappers
         if (b->ready) HIP_TRY(hipStreamWaitEvent(st, b->ready, 0));
         HIP_TRY(dsi::launch_packet_geometry(st, b->Rt, (int)np, m->geom, m->centers.p, m->H.p));
         HIP_TRY(dsi::launch_warp_z0(st, b->x, b->y, b->first, (int)np, m->H.p, m->lut_dev, m->sensor_w, m->sensor_h, m->xy.p));
+        // ONE pass into the scratch the mapper already holds (4 M votes to begin with); a pass that overflows it only
+        // counts what it would have written, and is repeated once with the exact size
         unsigned long long n_hits = 0;
-        HIP_TRY(hipMemsetAsync(d_hits_n.p, 0, sizeof(unsigned long long), st));
-        HIP_TRY(dsi::launch_tie_hits(st, m->xy.p, m->centers.p, m->planes_dev, m->geom, (int)np, d_zlist.p, (int)zlist.size(), d_bitmap.p,
-                                     d_sv.p, (int)sv.size(), d_hits_n.p, nullptr, nullptr, 0));
-        HIP_TRY(hipMemcpyAsync(&n_hits, d_hits_n.p, sizeof n_hits, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        size_t cap = std::max<size_t>(ts.keys.cap, (size_t)1 << 22);
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            HIP_TRY(ts.keys.reserve(cap));
+            HIP_TRY(ts.keys2.reserve(cap));
+            HIP_TRY(ts.w.reserve(cap));
+            HIP_TRY(ts.w2.reserve(cap));
+            HIP_TRY(hipMemsetAsync(d_hits_n, 0, sizeof(unsigned long long), st));
+            HIP_TRY(dsi::launch_tie_hits(st, m->xy.p, m->centers.p, m->planes_dev, m->geom, (int)np, ts.zlist.p, (int)zlist.size(),
+                                         ts.bitmap.p, ts.sv.p, (int)sv.size(), d_hits_n, ts.keys.p, ts.w.p, cap));
+            HIP_TRY(hipMemcpyAsync(&n_hits, d_hits_n, sizeof n_hits, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            REQUIRE(n_hits < ((unsigned long long)1 << 31), DSI_ERR_INVALID,
+                    "%llu votes to re-sum: rel_gap is not a rounding-sized gap here", n_hits);
+            if (n_hits <= cap) break;
+            REQUIRE(attempt == 0, DSI_ERR_INVALID, "the vote count changed between two passes");
+            cap = (size_t)n_hits;
+        }
         info->votes += (long long)n_hits;
-        REQUIRE(n_hits < ((unsigned long long)1 << 31), DSI_ERR_INVALID, "%llu votes to re-sum: rel_gap is not a rounding-sized gap here", n_hits);
-        TmpDev<unsigned long long> d_keys, d_keys2;
-        TmpDev<float> d_w, d_w2;
-        TmpDev<char> d_tmp;
         const unsigned long long* keys_sorted = nullptr;
         const float* w_sorted = nullptr;
         if (n_hits) {
-            HIP_TRY(d_keys.alloc((size_t)n_hits));
-            HIP_TRY(d_keys2.alloc((size_t)n_hits));
-            HIP_TRY(d_w.alloc((size_t)n_hits));
-            HIP_TRY(d_w2.alloc((size_t)n_hits));
-            HIP_TRY(hipMemsetAsync(d_hits_n.p, 0, sizeof(unsigned long long), st));
-            HIP_TRY(dsi::launch_tie_hits(st, m->xy.p, m->centers.p, m->planes_dev, m->geom, (int)np, d_zlist.p, (int)zlist.size(),
-                                         d_bitmap.p, d_sv.p, (int)sv.size(), d_hits_n.p, d_keys.p, d_w.p, n_hits));
             size_t tmp_bytes = 0;
-            HIP_TRY(dsi::tie_sort_pairs(st, d_keys.p, d_keys2.p, d_w.p, d_w2.p, (size_t)n_hits, 32 + cid_bits, nullptr, &tmp_bytes));
-            HIP_TRY(d_tmp.alloc(tmp_bytes));
-            HIP_TRY(dsi::tie_sort_pairs(st, d_keys.p, d_keys2.p, d_w.p, d_w2.p, (size_t)n_hits, 32 + cid_bits, d_tmp.p, &tmp_bytes));
-            keys_sorted = d_keys2.p;
-            w_sorted = d_w2.p;
+            HIP_TRY(dsi::tie_sort_pairs(st, ts.keys.p, ts.keys2.p, ts.w.p, ts.w2.p, (size_t)n_hits, 32 + cid_bits, nullptr, &tmp_bytes));
+            HIP_TRY(ts.tmp.reserve(tmp_bytes));
+            HIP_TRY(dsi::tie_sort_pairs(st, ts.keys.p, ts.keys2.p, ts.w.p, ts.w2.p, (size_t)n_hits, 32 + cid_bits, ts.tmp.p, &tmp_bytes));
+            keys_sorted = ts.keys2.p;
+            w_sorted = ts.w2.p;
         }
-        HIP_TRY(dsi::launch_tie_sums(st, keys_sorted, w_sorted, n_hits, d_sv.p, (int)sv.size(), m->grid->data, d_exact.p, d_count.p,
-                                     d_gpu.p));
+        HIP_TRY(dsi::launch_tie_sums(st, keys_sorted, w_sorted, n_hits, ts.sv.p, (int)sv.size(), m->grid->data, ts.exact.p, ts.count.p,
+                                     ts.gpu.p));
         std::vector<uint32_t> count(sv.size());
         std::vector<float> gpu(sv.size());
-        HIP_TRY(hipMemcpyAsync(exact[c].data(), d_exact.p, sv.size() * sizeof(float), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(count.data(), d_count.p, sv.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(gpu.data(), d_gpu.p, sv.size() * sizeof(float), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));  // (also: the scratch above is freed only after its kernels are done)
+        HIP_TRY(hipMemcpyAsync(exact[c].data(), ts.exact.p, sv.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(count.data(), ts.count.p, sv.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(gpu.data(), ts.gpu.p, sv.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
         for (size_t i = 0; i < sv.size(); ++i) {
             if (count[i] > 1) info->max_rel_bound = std::max(info->max_rel_bound, (double)(count[i] - 1) * 5.9604644775390625e-8);
             const double ref = (double)exact[c][i];
@@ -1818,19 +1832,15 @@ int dsi_mapper_resolve_near_ties(dsi_mapper_t* out, dsi_mapper_t* const* mappers
         new_conf.push_back(best);
         if (old_idx[p] != (uint8_t)best_z) ++info->changed_pixels;
     }
-    TmpDev<uint32_t> d_pix;
-    TmpDev<uint8_t> d_idx;
-    TmpDev<float> d_conf;
-    HIP_TRY(d_pix.alloc(pix.size()));
-    HIP_TRY(d_idx.alloc(pix.size()));
-    HIP_TRY(d_conf.alloc(pix.size()));
-    HIP_TRY(hipMemcpyAsync(d_pix.p, pix.data(), pix.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_idx.p, new_idx.data(), pix.size(), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_conf.p, new_conf.data(), pix.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    // (the patch lists reuse the scratch the sums no longer need: pix <- count, conf <- exact, idx <- gpu)
+    HIP_TRY(hipMemcpyAsync(ts.count.p, pix.data(), pix.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ts.exact.p, new_conf.data(), pix.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ts.gpu.p, new_idx.data(), pix.size(), hipMemcpyHostToDevice, st));
     if (int rc = depth_buffers_acquire(out)) return rc;
-    HIP_TRY(dsi::launch_tie_patch(st, d_pix.p, d_idx.p, d_conf.p, (int)pix.size(), out->planes_dev, out->conf.p, out->idx.p, out->depth.p));
+    HIP_TRY(dsi::launch_tie_patch(st, ts.count.p, reinterpret_cast<const uint8_t*>(ts.gpu.p), ts.exact.p, (int)pix.size(),
+                                  out->planes_dev, out->conf.p, out->idx.p, out->depth.p));
     if (int rc = depth_buffers_ready(out)) return rc;
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipStreamSynchronize(st));  // the host vectors above are pageable
     return finish();
 }
 
