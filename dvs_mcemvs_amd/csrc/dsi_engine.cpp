@@ -1666,6 +1666,134 @@ int dsi_mapper_depth_map_of_events(dsi_mapper_t* out, dsi_mapper_t* const* mappe
 }
 
 /* ---- exact tie resolver (include/dsi_engine.h) ---- */
+// The values the REFERENCE's summation order gives the voxels `sv` (sorted, unique, linear indices z * npix + p) of the
+// DSI mapper m builds from batch b: one pass over the events on the planes that occur in sv with the reference's
+// coordinates, accept test and weights (k_tie_hits), the recorded votes sorted on the device by (voxel, event index),
+// added one by one in fp32 by one thread per voxel.  count[i] = votes of voxel i; gpu[i] = what m's grid holds there now.
+static int tie_exact_values(TieScratch& ts, dsi_mapper* m, const dsi_batch* b, const std::vector<uint32_t>& sv,
+                            std::vector<float>* exact, std::vector<uint32_t>* count, std::vector<float>* gpu, long long* votes)
+{
+    hipStream_t st = m->ctx->stream;
+    const int npix = m->geom.nx * m->geom.ny;
+    const size_t nvox = (size_t)npix * m->geom.nz;
+    exact->assign(sv.size(), 0.f);
+    count->assign(sv.size(), 0u);
+    gpu->assign(sv.size(), 0.f);
+    *votes = 0;
+    if (sv.empty()) return DSI_OK;
+    std::vector<int> zlist;
+    for (uint32_t v : sv) {
+        const int z = (int)(v / (uint32_t)npix);
+        if (zlist.empty() || zlist.back() != z) zlist.push_back(z);
+    }
+    const size_t bitmap_words = (nvox + 31) / 32 + 1;
+    HIP_TRY(ts.counters.reserve(4));
+    HIP_TRY(ts.sv.reserve(sv.size()));
+    HIP_TRY(ts.bitmap.reserve(bitmap_words));
+    HIP_TRY(ts.zlist.reserve(zlist.size()));
+    HIP_TRY(ts.exact.reserve(sv.size()));
+    HIP_TRY(ts.gpu.reserve(sv.size()));
+    HIP_TRY(ts.count.reserve(sv.size()));
+    HIP_TRY(hipMemcpyAsync(ts.sv.p, sv.data(), sv.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ts.zlist.p, zlist.data(), zlist.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(ts.bitmap.p, 0, bitmap_words * sizeof(uint32_t), st));
+    HIP_TRY(dsi::launch_tie_mark(st, ts.sv.p, (int)sv.size(), ts.bitmap.p));
+    unsigned long long* d_hits_n = ts.counters.p + 2;
+    unsigned cid_bits = 1;
+    while (cid_bits < 32 && ((size_t)1 << cid_bits) < sv.size()) ++cid_bits;
+    const size_t np = b->n_packets;
+    unsigned long long n_hits = 0;
+    if (np) {
+        HIP_TRY(m->H.reserve(np * 9));
+        HIP_TRY(m->xy.reserve(np * dsi::kPacket));
+        HIP_TRY(m->centers.reserve(np * 3));
+        if (b->ready) HIP_TRY(hipStreamWaitEvent(st, b->ready, 0));
+        HIP_TRY(dsi::launch_packet_geometry(st, b->Rt, (int)np, m->geom, m->centers.p, m->H.p));
+        HIP_TRY(dsi::launch_warp_z0(st, b->x, b->y, b->first, (int)np, m->H.p, m->lut_dev, m->sensor_w, m->sensor_h, m->xy.p));
+        // ONE pass into the scratch already held (4 M votes to begin with); a pass that overflows it only counts what it
+        // would have written, and is repeated once with the exact size
+        size_t cap = std::max<size_t>(ts.keys.cap, (size_t)1 << 22);
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            HIP_TRY(ts.keys.reserve(cap));
+            HIP_TRY(ts.keys2.reserve(cap));
+            HIP_TRY(ts.w.reserve(cap));
+            HIP_TRY(ts.w2.reserve(cap));
+            HIP_TRY(hipMemsetAsync(d_hits_n, 0, sizeof(unsigned long long), st));
+            HIP_TRY(dsi::launch_tie_hits(st, m->xy.p, m->centers.p, m->planes_dev, m->geom, (int)np, ts.zlist.p, (int)zlist.size(),
+                                         ts.bitmap.p, ts.sv.p, (int)sv.size(), d_hits_n, ts.keys.p, ts.w.p, cap));
+            HIP_TRY(hipMemcpyAsync(&n_hits, d_hits_n, sizeof n_hits, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            REQUIRE(n_hits < ((unsigned long long)1 << 31), DSI_ERR_INVALID, "%llu votes to re-sum: too many voxels asked for", n_hits);
+            if (n_hits <= cap) break;
+            REQUIRE(attempt == 0, DSI_ERR_INVALID, "the vote count changed between two passes");
+            cap = (size_t)n_hits;
+        }
+    }
+    *votes = (long long)n_hits;
+    const unsigned long long* keys_sorted = nullptr;
+    const float* w_sorted = nullptr;
+    if (n_hits) {
+        size_t tmp_bytes = 0;
+        HIP_TRY(dsi::tie_sort_pairs(st, ts.keys.p, ts.keys2.p, ts.w.p, ts.w2.p, (size_t)n_hits, 32 + cid_bits, nullptr, &tmp_bytes));
+        HIP_TRY(ts.tmp.reserve(tmp_bytes));
+        HIP_TRY(dsi::tie_sort_pairs(st, ts.keys.p, ts.keys2.p, ts.w.p, ts.w2.p, (size_t)n_hits, 32 + cid_bits, ts.tmp.p, &tmp_bytes));
+        keys_sorted = ts.keys2.p;
+        w_sorted = ts.w2.p;
+    }
+    HIP_TRY(dsi::launch_tie_sums(st, keys_sorted, w_sorted, n_hits, ts.sv.p, (int)sv.size(), m->grid->data, ts.exact.p, ts.count.p,
+                                 ts.gpu.p));
+    HIP_TRY(hipMemcpyAsync(exact->data(), ts.exact.p, sv.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(count->data(), ts.count.p, sv.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(gpu->data(), ts.gpu.p, sv.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return DSI_OK;
+}
+
+// columns of op(a, b) (b == nullptr: of a) with >= 2 planes within rel_gap of the column's maximum: their voxels, a column's
+// run contiguous and ascending in z (k_tie_candidates)
+static int tie_candidates(TieScratch& ts, hipStream_t st, const float* a, const float* b, int op, int npix, int nz, float rel_gap,
+                          std::vector<uint32_t>* cand, unsigned* n_columns)
+{
+    const size_t nvox = (size_t)npix * nz;
+    unsigned counters[2] = {0, 0};
+    HIP_TRY(ts.counters.reserve(4));
+    size_t cap = std::max<size_t>(ts.cand.cap, std::min<size_t>(nvox, (size_t)1 << 20));
+    for (;;) {
+        HIP_TRY(ts.cand.reserve(cap));
+        HIP_TRY(hipMemsetAsync(ts.counters.p, 0, 4 * sizeof(unsigned long long), st));
+        unsigned* d_cnt = reinterpret_cast<unsigned*>(ts.counters.p);
+        HIP_TRY(dsi::launch_tie_candidates(st, a, b, op, npix, nz, rel_gap, d_cnt, ts.cand.p, (uint32_t)std::min<size_t>(cap, 0xffffffffu)));
+        HIP_TRY(hipMemcpyAsync(counters, d_cnt, sizeof counters, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (counters[0] <= cap) break;
+        REQUIRE(cap < nvox, DSI_ERR_INVALID, "more contending voxels than voxels");
+        cap = std::min<size_t>(nvox, (size_t)counters[0]);
+    }
+    cand->resize(counters[0]);
+    if (counters[0]) HIP_TRY(hipMemcpy(cand->data(), ts.cand.p, counters[0] * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    *n_columns = counters[1];
+    return DSI_OK;
+}
+
+static int patch_depth_map(dsi_mapper_t* m, TieScratch& ts, const uint32_t* pix, const uint8_t* idx, const float* conf, size_t n)
+{
+    if (n == 0) return DSI_OK;
+    hipStream_t st = m->ctx->stream;
+    HIP_TRY(ts.count.reserve(n));
+    HIP_TRY(ts.exact.reserve(n));
+    HIP_TRY(ts.gpu.reserve(n));
+    // (the patch lists reuse the scratch the sums no longer need: pix <- count, conf <- exact, idx <- gpu)
+    HIP_TRY(hipMemcpyAsync(ts.count.p, pix, n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ts.exact.p, conf, n * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ts.gpu.p, idx, n, hipMemcpyHostToDevice, st));
+    if (int rc = depth_buffers_acquire(m)) return rc;
+    HIP_TRY(dsi::launch_tie_patch(st, ts.count.p, reinterpret_cast<const uint8_t*>(ts.gpu.p), ts.exact.p, (int)n, m->planes_dev,
+                                  m->conf.p, m->idx.p, m->depth.p));
+    if (int rc = depth_buffers_ready(m)) return rc;
+    HIP_TRY(hipStreamSynchronize(st));  // the host arrays are pageable
+    return DSI_OK;
+}
+
 int dsi_mapper_resolve_near_ties(dsi_mapper_t* out, dsi_mapper_t* const* mappers, const dsi_batch_t* const* batches, int n,
                                  int op, dsi_resolve_info_t* info)
 {
@@ -1695,28 +1823,11 @@ int dsi_mapper_resolve_near_ties(dsi_mapper_t* out, dsi_mapper_t* const* mappers
 
     // 1. the contending voxels
     std::vector<uint32_t> cand;
-    unsigned counters[2] = {0, 0};
-    HIP_TRY(ts.counters.reserve(4));
-    {
-        size_t cap = std::max<size_t>(ts.cand.cap, std::min<size_t>(nvox, (size_t)1 << 20));
-        for (;;) {
-            HIP_TRY(ts.cand.reserve(cap));
-            HIP_TRY(hipMemsetAsync(ts.counters.p, 0, 4 * sizeof(unsigned long long), st));
-            unsigned* d_cnt = reinterpret_cast<unsigned*>(ts.counters.p);
-            HIP_TRY(dsi::launch_tie_candidates(st, mappers[0]->grid->data, n == 2 ? mappers[1]->grid->data : nullptr, op, npix, nz,
-                                               rel_gap, d_cnt, ts.cand.p, (uint32_t)std::min<size_t>(cap, 0xffffffffu)));
-            HIP_TRY(hipMemcpyAsync(counters, d_cnt, sizeof counters, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            if (counters[0] <= cap) {
-                cand.resize(counters[0]);
-                if (counters[0]) HIP_TRY(hipMemcpy(cand.data(), ts.cand.p, counters[0] * sizeof(uint32_t), hipMemcpyDeviceToHost));
-                break;
-            }
-            REQUIRE(cap < nvox, DSI_ERR_INVALID, "more contending voxels than voxels");
-            cap = std::min<size_t>(nvox, (size_t)counters[0]);
-        }
-    }
-    info->near_tie_pixels = (int)counters[1];
+    unsigned n_columns = 0;
+    if (int rc = tie_candidates(ts, st, mappers[0]->grid->data, n == 2 ? mappers[1]->grid->data : nullptr, op, npix, nz, rel_gap, &cand,
+                                &n_columns))
+        return rc;
+    info->near_tie_pixels = (int)n_columns;
     info->candidate_voxels = (int)cand.size();
     auto finish = [&]() {
         info->elapsed_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
@@ -1724,84 +1835,25 @@ int dsi_mapper_resolve_near_ties(dsi_mapper_t* out, dsi_mapper_t* const* mappers
     };
     if (cand.empty()) return finish();
 
-    // 2. sorted voxel list (rank = id), the planes involved, the bitmap
+    // 2 + 3. per camera: the contending voxels' values in the reference's summation order
     std::vector<uint32_t> sv(cand);
     std::sort(sv.begin(), sv.end());
-    std::vector<int> zlist;
-    for (uint32_t v : sv) {
-        const int z = (int)(v / (uint32_t)npix);
-        if (zlist.empty() || zlist.back() != z) zlist.push_back(z);
+    {
+        int planes = 0, last = -1;
+        for (uint32_t v : sv) {
+            const int z = (int)(v / (uint32_t)npix);
+            if (z != last) ++planes;
+            last = z;
+        }
+        info->candidate_planes = planes;
     }
-    info->candidate_planes = (int)zlist.size();
-    const size_t bitmap_words = (nvox + 31) / 32 + 1;
-    HIP_TRY(ts.sv.reserve(sv.size()));
-    HIP_TRY(ts.bitmap.reserve(bitmap_words));
-    HIP_TRY(ts.zlist.reserve(zlist.size()));
-    HIP_TRY(ts.exact.reserve(sv.size()));
-    HIP_TRY(ts.gpu.reserve(sv.size()));
-    HIP_TRY(ts.count.reserve(sv.size()));
-    HIP_TRY(hipMemcpyAsync(ts.sv.p, sv.data(), sv.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(ts.zlist.p, zlist.data(), zlist.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(ts.bitmap.p, 0, bitmap_words * sizeof(uint32_t), st));
-    HIP_TRY(dsi::launch_tie_mark(st, ts.sv.p, (int)sv.size(), ts.bitmap.p));
-    unsigned long long* d_hits_n = ts.counters.p + 2;
-
-    // 3. per camera: the votes that land on a contending voxel, sorted on the device into the reference's order
-    //    (voxel, event index), added one by one in fp32 by one thread per voxel
     std::vector<float> exact[2];
-    unsigned cid_bits = 1;
-    while (cid_bits < 32 && ((size_t)1 << cid_bits) < sv.size()) ++cid_bits;
     for (int c = 0; c < n; ++c) {
-        dsi_mapper* m = mappers[c];
-        const dsi_batch* b = batches[c];
-        const size_t np = b->n_packets;
-        exact[c].assign(sv.size(), 0.f);
-        if (np == 0) continue;  // evaluateDSI returned false: an all-zero DSI
-        HIP_TRY(m->H.reserve(np * 9));
-        HIP_TRY(m->xy.reserve(np * dsi::kPacket));
-        HIP_TRY(m->centers.reserve(np * 3));
-        if (b->ready) HIP_TRY(hipStreamWaitEvent(st, b->ready, 0));
-        HIP_TRY(dsi::launch_packet_geometry(st, b->Rt, (int)np, m->geom, m->centers.p, m->H.p));
-        HIP_TRY(dsi::launch_warp_z0(st, b->x, b->y, b->first, (int)np, m->H.p, m->lut_dev, m->sensor_w, m->sensor_h, m->xy.p));
-        // ONE pass into the scratch the mapper already holds (4 M votes to begin with); a pass that overflows it only
-        // counts what it would have written, and is repeated once with the exact size
-        unsigned long long n_hits = 0;
-        size_t cap = std::max<size_t>(ts.keys.cap, (size_t)1 << 22);
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            HIP_TRY(ts.keys.reserve(cap));
-            HIP_TRY(ts.keys2.reserve(cap));
-            HIP_TRY(ts.w.reserve(cap));
-            HIP_TRY(ts.w2.reserve(cap));
-            HIP_TRY(hipMemsetAsync(d_hits_n, 0, sizeof(unsigned long long), st));
-            HIP_TRY(dsi::launch_tie_hits(st, m->xy.p, m->centers.p, m->planes_dev, m->geom, (int)np, ts.zlist.p, (int)zlist.size(),
-                                         ts.bitmap.p, ts.sv.p, (int)sv.size(), d_hits_n, ts.keys.p, ts.w.p, cap));
-            HIP_TRY(hipMemcpyAsync(&n_hits, d_hits_n, sizeof n_hits, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            REQUIRE(n_hits < ((unsigned long long)1 << 31), DSI_ERR_INVALID,
-                    "%llu votes to re-sum: rel_gap is not a rounding-sized gap here", n_hits);
-            if (n_hits <= cap) break;
-            REQUIRE(attempt == 0, DSI_ERR_INVALID, "the vote count changed between two passes");
-            cap = (size_t)n_hits;
-        }
-        info->votes += (long long)n_hits;
-        const unsigned long long* keys_sorted = nullptr;
-        const float* w_sorted = nullptr;
-        if (n_hits) {
-            size_t tmp_bytes = 0;
-            HIP_TRY(dsi::tie_sort_pairs(st, ts.keys.p, ts.keys2.p, ts.w.p, ts.w2.p, (size_t)n_hits, 32 + cid_bits, nullptr, &tmp_bytes));
-            HIP_TRY(ts.tmp.reserve(tmp_bytes));
-            HIP_TRY(dsi::tie_sort_pairs(st, ts.keys.p, ts.keys2.p, ts.w.p, ts.w2.p, (size_t)n_hits, 32 + cid_bits, ts.tmp.p, &tmp_bytes));
-            keys_sorted = ts.keys2.p;
-            w_sorted = ts.w2.p;
-        }
-        HIP_TRY(dsi::launch_tie_sums(st, keys_sorted, w_sorted, n_hits, ts.sv.p, (int)sv.size(), m->grid->data, ts.exact.p, ts.count.p,
-                                     ts.gpu.p));
-        std::vector<uint32_t> count(sv.size());
-        std::vector<float> gpu(sv.size());
-        HIP_TRY(hipMemcpyAsync(exact[c].data(), ts.exact.p, sv.size() * sizeof(float), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(count.data(), ts.count.p, sv.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(gpu.data(), ts.gpu.p, sv.size() * sizeof(float), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        std::vector<uint32_t> count;
+        std::vector<float> gpu;
+        long long votes = 0;
+        if (int rc = tie_exact_values(ts, mappers[c], batches[c], sv, &exact[c], &count, &gpu, &votes)) return rc;
+        info->votes += votes;
         for (size_t i = 0; i < sv.size(); ++i) {
             if (count[i] > 1) info->max_rel_bound = std::max(info->max_rel_bound, (double)(count[i] - 1) * 5.9604644775390625e-8);
             const double ref = (double)exact[c][i];
@@ -1832,16 +1884,92 @@ int dsi_mapper_resolve_near_ties(dsi_mapper_t* out, dsi_mapper_t* const* mappers
         new_conf.push_back(best);
         if (old_idx[p] != (uint8_t)best_z) ++info->changed_pixels;
     }
-    // (the patch lists reuse the scratch the sums no longer need: pix <- count, conf <- exact, idx <- gpu)
-    HIP_TRY(hipMemcpyAsync(ts.count.p, pix.data(), pix.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(ts.exact.p, new_conf.data(), pix.size() * sizeof(float), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(ts.gpu.p, new_idx.data(), pix.size(), hipMemcpyHostToDevice, st));
-    if (int rc = depth_buffers_acquire(out)) return rc;
-    HIP_TRY(dsi::launch_tie_patch(st, ts.count.p, reinterpret_cast<const uint8_t*>(ts.gpu.p), ts.exact.p, (int)pix.size(),
-                                  out->planes_dev, out->conf.p, out->idx.p, out->depth.p));
-    if (int rc = depth_buffers_ready(out)) return rc;
-    HIP_TRY(hipStreamSynchronize(st));  // the host vectors above are pageable
+    if (int rc = patch_depth_map(out, ts, pix.data(), new_idx.data(), new_conf.data(), pix.size())) return rc;
     return finish();
+}
+
+int dsi_grid_near_tie_voxels(dsi_mapper_t* scratch, dsi_grid_t* g, float rel_gap, uint32_t* voxels, size_t capacity,
+                             size_t* n_voxels, size_t* n_columns)
+{
+    REQUIRE(scratch && g && n_voxels, DSI_ERR_INVALID, "null argument");
+    REQUIRE(capacity == 0 || voxels, DSI_ERR_INVALID, "null output");
+    REQUIRE(scratch->ctx == g->ctx, DSI_ERR_CONTEXT, "the scratch mapper must live in the grid's context");
+    REQUIRE(same_shape(scratch->grid, g), DSI_ERR_SHAPE, "the scratch mapper's DSI shape differs from the grid's");
+    if (!(rel_gap > 0.f)) rel_gap = 2.5e-4f;
+    REQUIRE(rel_gap < 0.5f, DSI_ERR_INVALID, "rel_gap %g is not a rounding-sized gap", (double)rel_gap);
+    REQUIRE(g->n < ((size_t)1 << 32), DSI_ERR_INVALID, "voxels are addressed with 32 bits");
+    if (int rc = set_device(g->ctx)) return rc;
+    std::vector<uint32_t> cand;
+    unsigned cols = 0;
+    if (int rc = tie_candidates(scratch->tie, g->ctx->stream, g->data, nullptr, 0, g->nx * g->ny, g->nz, rel_gap, &cand, &cols)) return rc;
+    *n_voxels = cand.size();
+    if (n_columns) *n_columns = cols;
+    if (cand.size() <= capacity && !cand.empty()) std::memcpy(voxels, cand.data(), cand.size() * sizeof(uint32_t));
+    return DSI_OK;
+}
+
+int dsi_mapper_exact_voxels(dsi_mapper_t* m, const dsi_batch_t* batch, const uint32_t* voxels, size_t n, float* values,
+                            uint32_t* votes)
+{
+    REQUIRE(m && batch, DSI_ERR_INVALID, "null argument");
+    REQUIRE(n == 0 || (voxels && values), DSI_ERR_INVALID, "null array");
+    REQUIRE(m->ctx == batch->ctx, DSI_ERR_CONTEXT, "mapper and batch belong to different contexts");
+    const size_t nvox = (size_t)m->geom.nx * m->geom.ny * m->geom.nz;
+    REQUIRE(nvox < ((size_t)1 << 32), DSI_ERR_INVALID, "voxels are addressed with 32 bits");
+    for (size_t i = 0; i < n; ++i) REQUIRE(voxels[i] < nvox, DSI_ERR_INVALID, "voxel %zu (%u) outside the DSI", i, voxels[i]);
+    if (int rc = set_device(m->ctx)) return rc;
+    std::vector<uint32_t> sv(voxels, voxels + n);
+    std::sort(sv.begin(), sv.end());
+    sv.erase(std::unique(sv.begin(), sv.end()), sv.end());
+    std::vector<float> exact, gpu;
+    std::vector<uint32_t> count;
+    long long total = 0;
+    if (int rc = tie_exact_values(m->tie, m, batch, sv, &exact, &count, &gpu, &total)) return rc;
+    for (size_t i = 0; i < n; ++i) {
+        const size_t c = (size_t)(std::lower_bound(sv.begin(), sv.end(), voxels[i]) - sv.begin());
+        values[i] = exact[c];
+        if (votes) votes[i] = count[c];
+    }
+    return DSI_OK;
+}
+
+int dsi_reference_fuse2(int op, const float* a, const float* g, size_t n, float* out)
+{
+    REQUIRE(n == 0 || (a && g && out), DSI_ERR_INVALID, "null array");
+    REQUIRE(op >= 1 && op <= 6, DSI_ERR_BAD_OP, "improper fusion method %d (expected 1..6)", op);
+    for (size_t i = 0; i < n; ++i) out[i] = dsi::host::fuse2(op, a[i], g[i]);
+    return DSI_OK;
+}
+
+int dsi_reference_accumulate(int mode, float* acc, const float* g, size_t n)
+{
+    REQUIRE(n == 0 || (acc && g), DSI_ERR_INVALID, "null array");
+    REQUIRE(mode == DSI_ACC_SUM || mode == DSI_ACC_INV_SUM, DSI_ERR_BAD_OP, "the reference accumulates sums (0) or inverse sums (1)");
+    for (size_t i = 0; i < n; ++i) acc[i] = dsi::host::accumulate1(mode, acc[i], g[i]);
+    return DSI_OK;
+}
+
+int dsi_reference_finalize(int mode, float* acc, size_t n, int n_maps)
+{
+    REQUIRE(n == 0 || acc, DSI_ERR_INVALID, "null array");
+    REQUIRE(mode == DSI_ACC_SUM || mode == DSI_ACC_INV_SUM, DSI_ERR_BAD_OP, "the reference accumulates sums (0) or inverse sums (1)");
+    REQUIRE(n_maps >= 1, DSI_ERR_INVALID, "number of maps must be >= 1 (got %d)", n_maps);
+    for (size_t i = 0; i < n; ++i) acc[i] = dsi::host::finalize1(mode, acc[i], n_maps);
+    return DSI_OK;
+}
+
+int dsi_mapper_patch_depth_map(dsi_mapper_t* m, const uint32_t* pixels, const uint8_t* idx, const float* conf, size_t n)
+{
+    REQUIRE(m, DSI_ERR_INVALID, "mapper is null");
+    REQUIRE(n == 0 || (pixels && idx && conf), DSI_ERR_INVALID, "null array");
+    REQUIRE(m->depth_valid, DSI_ERR_INVALID, "the mapper holds no raw depth map to patch");
+    const size_t npix = (size_t)m->geom.nx * m->geom.ny;
+    for (size_t i = 0; i < n; ++i) {
+        REQUIRE(pixels[i] < npix, DSI_ERR_INVALID, "pixel %zu (%u) outside the image", i, pixels[i]);
+        REQUIRE((int)idx[i] < m->geom.nz, DSI_ERR_INVALID, "plane index %d outside the depth vector", (int)idx[i]);
+    }
+    if (int rc = set_device(m->ctx)) return rc;
+    return patch_depth_map(m, m->tie, pixels, idx, conf, n);
 }
 
 int dsi_mapper_fetch_depth_map(dsi_mapper_t* m, float* depth_host, float* conf_host, uint8_t* idx_host)

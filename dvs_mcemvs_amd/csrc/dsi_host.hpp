@@ -239,5 +239,11 @@ inline float fuse2(int op, float a0, float g)
     }
 }
 
+// Grid3D::addTwoGrids / addInverseOfTwoGrids (cartesian3dgrid.h:64-78) and computeAMfromSum / computeHMfromSumOfInv
+// (:80-93) for one voxel: mode 0 = DSI_ACC_SUM, 1 = DSI_ACC_INV_SUM -- as the device's k_elementwise<EW_ADD / EW_ADD_INV /
+// EW_FIN_AM / EW_FIN_HM> compute them
+inline float accumulate1(int mode, float acc, float g) { return mode == 1 ? acc + 1.0f / (0.01f + g) : acc + g; }
+inline float finalize1(int mode, float acc, int n) { return mode == 1 ? (float)n / acc : acc / (float)n; }
+
 }  // namespace host
 }  // namespace dsi

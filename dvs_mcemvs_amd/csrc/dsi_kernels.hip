@@ -3615,6 +3615,12 @@ __global__ __launch_bounds__(256) void k_tie_hits(const float2* __restrict__ xy,
                                                   unsigned long long* __restrict__ keys, float* __restrict__ wts,
                                                   unsigned long long cap)
 {
+    // Output slots: the block walks its (packet, planes) TWICE -- first counting its hits in LDS, then, after ONE global
+    // atomic has reserved its range, writing them (slots within the range from the same LDS counter).  Millions of
+    // atomics on one global address (one per hit, or even one per wave instruction) serialise at the L2 and cost far
+    // more than redoing the arithmetic.
+    __shared__ unsigned s_count;
+    __shared__ unsigned long long s_base;
     const int k = blockIdx.x;
     const int lbeg = blockIdx.y * kVgPlanes;
     const int lend = min(nzl, lbeg + kVgPlanes);
@@ -3624,47 +3630,53 @@ __global__ __launch_bounds__(256) void k_tie_hits(const float2* __restrict__ xy,
     for (int i = 0; i < 4; ++i) e[i] = xy[(size_t)k * kPacket + threadIdx.x + 256 * i];
     const float xmax = (float)(g.nx - 1), ymax = (float)(g.ny - 1);
     const size_t plane_sz = (size_t)g.nx * g.ny;
-    for (int l = lbeg; l < lend; ++l) {
-        const int z = zlist[l];
-        float a, bx, by, d;
-        plane_coefficients(cx_, cy_, cz_, planes[z], g, a, bx, by, d);
+    if (threadIdx.x == 0) s_count = 0u;
+    __syncthreads();
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int l = lbeg; l < lend; ++l) {
+            const int z = zlist[l];
+            float a, bx, by, d;
+            plane_coefficients(cx_, cy_, cz_, planes[z], g, a, bx, by, d);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float X = (e[i].x * a + bx) / d;  // mapper_emvs_stereo.cpp:194-195
-            const float Y = (e[i].y * a + by) / d;
-            if (!(X >= 0.f && Y >= 0.f && X < xmax && Y < ymax)) continue;  // cartesian3dgrid.h:255-259 (see vote_global)
-            const int xi = (int)X, yi = (int)Y;
-            const float fx = X - (float)xi, fy = Y - (float)yi, fx1 = 1.f - fx, fy1 = 1.f - fy;
-            const float w[4] = {fx1 * fy1, fx * fy1, fx1 * fy, fx * fy};  // :261-270
-            const uint32_t v0 = (uint32_t)((size_t)z * plane_sz + (size_t)yi * g.nx + xi);
-            const uint32_t v[4] = {v0, v0 + 1u, v0 + (uint32_t)g.nx, v0 + (uint32_t)g.nx + 1u};
+            for (int i = 0; i < 4; ++i) {
+                const float X = (e[i].x * a + bx) / d;  // mapper_emvs_stereo.cpp:194-195
+                const float Y = (e[i].y * a + by) / d;
+                if (!(X >= 0.f && Y >= 0.f && X < xmax && Y < ymax)) continue;  // cartesian3dgrid.h:255-259 (see vote_global)
+                const int xi = (int)X, yi = (int)Y;
+                const float fx = X - (float)xi, fy = Y - (float)yi, fx1 = 1.f - fx, fy1 = 1.f - fy;
+                const float w[4] = {fx1 * fy1, fx * fy1, fx1 * fy, fx * fy};  // :261-270
+                const uint32_t v0 = (uint32_t)((size_t)z * plane_sz + (size_t)yi * g.nx + xi);
+                const uint32_t v[4] = {v0, v0 + 1u, v0 + (uint32_t)g.nx, v0 + (uint32_t)g.nx + 1u};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (!((bitmap[v[c] >> 5] >> (v[c] & 31u)) & 1u)) continue;
-                int lo = 0, hi = nsv;  // the voxel's rank among the contenders (sorted, unique)
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (sv[mid] < v[c])
-                        lo = mid + 1;
-                    else
-                        hi = mid;
-                }
-                // one atomic per wave instruction, not per vote (the lanes that got here together share it)
-                const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
-                const int leader = __builtin_ctzll(active);
-                const int lane_id = (int)(threadIdx.x & 63);
-                unsigned long long base = 0;
-                if (lane_id == leader) base = atomicAdd(hit_counter, (unsigned long long)__builtin_popcountll(active));
-                base = ((unsigned long long)__builtin_amdgcn_readlane((int)(base >> 32), leader) << 32) |
-                       (unsigned)__builtin_amdgcn_readlane((int)(unsigned)base, leader);
-                const unsigned long long slot = base + (unsigned)__builtin_popcountll(active & ((1ull << lane_id) - 1ull));
-                if (keys && slot < cap) {
-                    // key = (voxel's rank, position of the vote in the reference's loop over events): sorting by it
-                    // puts a voxel's votes in one run, in the order the reference adds them
+                for (int c = 0; c < 4; ++c) {
+                    if (!((bitmap[v[c] >> 5] >> (v[c] & 31u)) & 1u)) continue;
+                    const unsigned my = atomicAdd(&s_count, 1u);  // (LDS)
+                    if (pass == 0 || !keys) continue;
+                    const unsigned long long slot = s_base + my;
+                    if (slot >= cap) continue;
+                    int lo = 0, hi = nsv;  // the voxel's rank among the contenders (sorted, unique)
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (sv[mid] < v[c])
+                            lo = mid + 1;
+                        else
+                            hi = mid;
+                    }
+                    // key = (voxel's rank, position of the vote in the reference's loop over events): sorting by it puts a
+                    // voxel's votes in one run, in the order the reference adds them
                     keys[slot] = ((unsigned long long)lo << 32) | ((unsigned long long)k * kPacket + (unsigned)(threadIdx.x + 256 * i));
                     wts[slot] = w[c];
                 }
             }
+        }
+        __syncthreads();
+        if (pass == 0) {
+            if (threadIdx.x == 0) {
+                s_base = s_count ? atomicAdd(hit_counter, (unsigned long long)s_count) : 0ull;
+                s_count = 0u;
+            }
+            __syncthreads();
+            if (!keys) break;  // counting only
         }
     }
 }

@@ -201,6 +201,12 @@ def load_library():
         "dsi_mapper_depth_map_from_keys": (C.c_int, [vp]),
         "dsi_mapper_resolve_near_ties": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int,
                                                   C.POINTER(_ResolveInfo)]),
+        "dsi_grid_near_tie_voxels": (C.c_int, [vp, vp, C.c_float, u32p, C.c_size_t, szp, szp]),
+        "dsi_mapper_exact_voxels": (C.c_int, [vp, vp, u32p, C.c_size_t, f32p, u32p]),
+        "dsi_reference_fuse2": (C.c_int, [C.c_int, f32p, f32p, C.c_size_t, f32p]),
+        "dsi_reference_accumulate": (C.c_int, [C.c_int, f32p, f32p, C.c_size_t]),
+        "dsi_reference_finalize": (C.c_int, [C.c_int, f32p, C.c_size_t, C.c_int]),
+        "dsi_mapper_patch_depth_map": (C.c_int, [vp, u32p, u8p, f32p, C.c_size_t]),
     }
     if experiments_requested():     # hooks that exist only in the experiments flavour
         sig.update({
@@ -428,6 +434,29 @@ def argmax_keys_unpack(keys):
     _check(load_library().dsi_argmax_keys_unpack(_ptr(keys, C.c_uint64), keys.size, _ptr(conf, C.c_float),
                                                  _ptr(idx, C.c_uint8)))
     return conf, idx
+
+
+def reference_fuse2(op, a, g):
+    """The reference's 2-ary camera-fusion op on host arrays (dsi_reference_fuse2: cartesian3dgrid.h:111-190 applied to
+    a grid initialised by resetGrid(); addTwoGrids(a)), bit for bit what the device computes."""
+    a, g = _arr(a, np.float32), _arr(g, np.float32)
+    out = np.empty(a.shape, np.float32)
+    _check(load_library().dsi_reference_fuse2(int(op), _ptr(a, C.c_float), _ptr(g, C.c_float), a.size, _ptr(out, C.c_float)))
+    return out
+
+
+def reference_accumulate(mode, acc, g):
+    """acc + g (ACC_SUM) / acc + 1/(0.01 + g) (ACC_INV_SUM) on host arrays (cartesian3dgrid.h:64-78); returns a new array."""
+    acc, g = np.array(acc, np.float32, order="C"), _arr(g, np.float32)
+    _check(load_library().dsi_reference_accumulate(int(mode), _ptr(acc, C.c_float), _ptr(g, C.c_float), acc.size))
+    return acc
+
+
+def reference_finalize(mode, acc, n_maps):
+    """acc / n (ACC_SUM) / n / acc (ACC_INV_SUM) on a host array (cartesian3dgrid.h:80-93); returns a new array."""
+    acc = np.array(acc, np.float32, order="C")
+    _check(load_library().dsi_reference_finalize(int(mode), _ptr(acc, C.c_float), acc.size, int(n_maps)))
+    return acc
 
 
 def allreduce_all(comms, grids, op):
@@ -891,6 +920,37 @@ class MapperEMVS:
         info.rel_gap = float(rel_gap)
         _check(load_library().dsi_mapper_resolve_near_ties(self._h, hm, hb, n, int(fusion_method), C.byref(info)))
         return {k: getattr(info, k) for k, _ in _ResolveInfo._fields_}
+
+    def nearTieVoxels(self, grid=None, rel_gap=0.0):
+        """dsi_grid_near_tie_voxels of `grid` (default: this mapper's DSI): the voxels (linear indices z*Ny*Nx + y*Nx + x)
+        within rel_gap of their column's maximum, for columns with >= 2 of them; a column's run contiguous, planes
+        ascending.  Returns (voxels uint32[n], n_columns)."""
+        g = self.dsi_ if grid is None else grid
+        cap = 1 << 16
+        while True:
+            vox = np.empty(cap, np.uint32)
+            n, cols = C.c_size_t(), C.c_size_t()
+            _check(load_library().dsi_grid_near_tie_voxels(self._h, g._h, float(rel_gap), _ptr(vox, C.c_uint32), cap,
+                                                           C.byref(n), C.byref(cols)))
+            if n.value <= cap:
+                return vox[:n.value].copy(), cols.value
+            cap = n.value
+
+    def exactVoxels(self, batch, voxels):
+        """dsi_mapper_exact_voxels: (values float32[n], votes uint32[n]) of the listed voxels of the DSI this mapper
+        builds from `batch`, summed the way the reference sums (fp32, event order)."""
+        voxels = _arr(voxels, np.uint32)
+        values = np.empty(voxels.shape, np.float32)
+        votes = np.empty(voxels.shape, np.uint32)
+        _check(load_library().dsi_mapper_exact_voxels(self._h, batch._h, _ptr(voxels, C.c_uint32), voxels.size,
+                                                      _ptr(values, C.c_float), _ptr(votes, C.c_uint32)))
+        return values, votes
+
+    def patchDepthMap(self, pixels, idx, conf):
+        """dsi_mapper_patch_depth_map: overwrite pixels (y*Nx + x) of the raw depth map held on the device."""
+        pixels, idx, conf = _arr(pixels, np.uint32), _arr(idx, np.uint8), _arr(conf, np.float32)
+        _check(load_library().dsi_mapper_patch_depth_map(self._h, _ptr(pixels, C.c_uint32), _ptr(idx, C.c_uint8),
+                                                         _ptr(conf, C.c_float), pixels.size))
 
     def computeDepthMapSharded(self, grid, comm):
         """Plane-sharded arg-max: local collapse of this rank's plane range, ONE all-reduce(MAX) of

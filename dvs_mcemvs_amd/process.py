@@ -144,6 +144,92 @@ def process_2(ctx, cams, dsi_shape, events, trajectories, num_subintervals, mapp
     return {"left": left, "right": right, "T_rv_w": T_rv_w}
 
 
+def exact_depth_map_process_2(ctx, cams, dsi_shape, events, trajectories, num_subintervals, mapper_fused, ts,
+                              stereo_fusion, temporal_fusion, luts=(None, None), inverse_depth=False, rel_gap=0.0):
+    """Alg. 2's fused DSI (camera fusion per sub-interval, then temporal fusion; process2.cpp:98-249) and its arg-max
+    with the plane index map EQUAL TO THE CPU REFERENCE'S ON EVERY PIXEL (BASELINE configs[3]).  The engine's exact
+    vote sums and the reference's fp32, event-ordered sums agree to ~1e-5, so the first-maximum plane can differ in
+    near-tie columns; dsi_mapper_resolve_near_ties covers Alg. 1's topology (one camera fusion), this is the same idea
+    built from its public pieces for the camera-then-time topology:
+      1. Alg. 2 on the device as process_2 does it, every sub-interval's event batches kept;
+      2. near-tie columns of the FINAL fused DSI (Grid3D near-tie voxels);
+      3. those voxels of every (sub-interval, camera) DSI re-summed in the reference's order (MapperEMVS.exactVoxels);
+      4. the reference's scalar ops on the host (engine.reference_fuse2 / _accumulate / _finalize) in process_2's
+         order, the first maximum per column (cartesian3dgrid.cpp:132-134), and the few pixels patched.
+    mapper_fused.dsi_ holds the fused DSI afterwards, mapper_fused's depth map (fetchDepthMap) the resolved arg-max.
+    temporal_fusion 2 (harmonic) or 4 (arithmetic), like the reference (anything else leaves the fused DSI zero).
+    Returns the statistics of the resolution."""
+    mappers = [E.MapperEMVS(ctx, cams[c], dsi_shape, lut=luts[c], inverse_depth=inverse_depth) for c in range(2)]
+    dims = mappers[0].dsi_.getDimensions()
+    sub = E.Grid3D(ctx, *dims)
+    T_rv_w = reference_view_process2(trajectories[0], ts)
+    per = [int(events[c][0].shape[0]) // int(num_subintervals) for c in range(2)]
+    mode = {2: E.ACC_INV_SUM, 4: E.ACC_SUM}.get(int(temporal_fusion))
+    mapper_fused.dsi_.resetGrid()
+    batches = []
+    for k in range(num_subintervals):
+        pair = []
+        for c in range(2):
+            ev = tuple(a[k * per[c]:(k + 1) * per[c]] for a in events[c])
+            pk = E.packetize(ev[2], trajectories[c], T_rv_w)
+            first, Rt = pk if pk is not None else (np.zeros(0, np.uint32), np.zeros((0, 12), np.float32))
+            b = E.EventBatch(ctx, ev[0], ev[1], Rt, first)
+            if pk is None:
+                mappers[c].dsi_.resetGrid()          # evaluateDSI returns false: the DSI keeps its reset state
+            else:
+                mappers[c].evaluateDSI_batch(b)
+            pair.append(b)
+        batches.append(pair)
+        sub.resetGrid()
+        sub.addTwoGrids(mappers[0].dsi_)
+        _fuse_cameras(sub, mappers[1].dsi_, stereo_fusion)
+        if mode is not None:
+            mapper_fused.dsi_.accumulate(sub, mode)
+            if k == num_subintervals - 1:
+                mapper_fused.dsi_.finalize(mode, num_subintervals)
+    mapper_fused.computeDepthMap()
+    info = {"near_tie_pixels": 0, "candidate_voxels": 0, "votes": 0, "changed_pixels": 0, "max_order_diff": 0.0}
+    if mode is not None:
+        vox, cols = mapper_fused.nearTieVoxels(rel_gap=rel_gap)
+        info["near_tie_pixels"], info["candidate_voxels"] = int(cols), int(vox.size)
+        if vox.size:
+            acc = np.zeros(vox.shape, np.float32)
+            for k in range(num_subintervals):
+                vals = []
+                for c in range(2):
+                    v, n = mappers[c].exactVoxels(batches[k][c], vox)
+                    info["votes"] += int(n.sum())
+                    vals.append(v)
+                acc = E.reference_accumulate(mode, acc, E.reference_fuse2(stereo_fusion, vals[0], vals[1]))
+            final = E.reference_finalize(mode, acc, num_subintervals)
+            nx, ny, nz = dims
+            npix = nx * ny
+            pix_of = vox % npix
+            z_of = (vox // npix).astype(np.int64)
+            starts = np.flatnonzero(np.r_[True, pix_of[1:] != pix_of[:-1]])      # a column's run is contiguous
+            ends = np.r_[starts[1:], vox.size]
+            _, conf0, idx0 = mapper_fused.fetchDepthMap()
+            pix, new_idx, new_conf = [], [], []
+            for a, b in zip(starts, ends):
+                j = a + int(np.argmax(final[a:b]))                                # first maximum, planes ascending
+                pix.append(pix_of[a])
+                new_idx.append(z_of[j])
+                new_conf.append(final[j])
+            pix = np.array(pix, np.uint32)
+            new_idx = np.array(new_idx, np.uint8)
+            info["changed_pixels"] = int((idx0.reshape(-1)[pix] != new_idx).sum())
+            fused_now = mapper_fused.dsi_.download().reshape(-1)[vox]
+            info["max_order_diff"] = float(np.max(np.abs(fused_now.astype(np.float64) - final) /
+                                                  np.maximum(1.0, np.abs(final))))
+            mapper_fused.patchDepthMap(pix, new_idx, np.array(new_conf, np.float32))
+    for pair in batches:
+        for b in pair:
+            b.close()
+    for o in mappers + [sub]:
+        o.close()
+    return info
+
+
 def process_5(*args, **kw):
     """process5.cpp:28-260: process_2 with the right camera's sub-intervals circularly shifted."""
     kw["shuffle_right"] = True

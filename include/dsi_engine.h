@@ -466,6 +466,32 @@ typedef struct {
 DSI_API int dsi_mapper_resolve_near_ties(dsi_mapper_t *out, dsi_mapper_t *const *mappers,
                                          const dsi_batch_t *const *batches, int n, int op, dsi_resolve_info_t *info);
 
+/* The resolver's building blocks, for fusion topologies it does not cover itself (Alg. 2's camera-then-time fusion,
+ * process2.cpp:98-249; n cameras): find the near-tie columns of ANY grid, get the reference-order value of ANY list of
+ * voxels of the DSI a mapper builds from a batch, recombine them on the host with the reference's scalar ops, patch
+ * the depth map.  dvs_mcemvs_amd/process.py::exact_depth_map_process_2 is Alg. 2 done that way.
+ *  - dsi_grid_near_tie_voxels: the voxels (z * dimY * dimX + y * dimX + x) of g within rel_gap of their column's
+ *    maximum, for the columns that have >= 2 of them; a column's run contiguous, planes ascending.  *n_voxels may
+ *    exceed capacity (then nothing beyond capacity was written: call again with more room).  scratch: any mapper of
+ *    g's context and shape (its resolver scratch is used).
+ *  - dsi_mapper_exact_voxels: values[i] <- the value voxel voxels[i] of the DSI of (m, batch) has when its votes are
+ *    added in fp32 in event order (resetGrid, then += per vote: mapper_emvs_stereo.cpp:145, :197-201,
+ *    cartesian3dgrid.h:261-270); votes[i] (optional) <- their number.  m's grid is not touched.  voxels: any order,
+ *    duplicates allowed.
+ *  - dsi_reference_fuse2 / _accumulate / _finalize: the reference's voxel-wise ops on host arrays (op = dsi_fuse_op_t;
+ *    mode = DSI_ACC_SUM or DSI_ACC_INV_SUM), bit for bit what the device kernels compute.
+ *  - dsi_mapper_patch_depth_map: overwrite n pixels (y * dimX + x) of the raw depth map m holds: index, confidence,
+ *    depth = plane of the index. */
+DSI_API int dsi_grid_near_tie_voxels(dsi_mapper_t *scratch, dsi_grid_t *g, float rel_gap, uint32_t *voxels, size_t capacity,
+                                     size_t *n_voxels, size_t *n_columns);
+DSI_API int dsi_mapper_exact_voxels(dsi_mapper_t *m, const dsi_batch_t *batch, const uint32_t *voxels, size_t n,
+                                    float *values, uint32_t *votes);
+DSI_API int dsi_reference_fuse2(int op, const float *a, const float *g, size_t n, float *out);
+DSI_API int dsi_reference_accumulate(int mode, float *acc, const float *g, size_t n);
+DSI_API int dsi_reference_finalize(int mode, float *acc, size_t n, int n_maps);
+DSI_API int dsi_mapper_patch_depth_map(dsi_mapper_t *m, const uint32_t *pixels, const uint8_t *idx, const float *conf,
+                                       size_t n);
+
 /* OptionsDepthMap (mapper_emvs_stereo.hpp:68-82), the fields the depth-map extraction reads */
 typedef struct {
     int adaptive_threshold_kernel_size; /* --adaptive_threshold_kernel_size, default 5 (main.cpp:73) */

@@ -113,5 +113,85 @@ def test_configs3_eight_time_slices_at_full_size(ctx):
     print("configs[3] full size: %r" % rep)
     assert rep["violations"] == 0 and rep["argmax_agree_frac"] > 0.99, rep
     assert np.array_equal(depth, fused.raw_depths_vec_[idx])
+    # ... and through the resolver's building blocks (process.exact_depth_map_process_2: near-tie columns of the final
+    # fused DSI, their voxels of all 16 (slice, camera) DSIs re-summed in the reference's order, process_2's scalar
+    # ops on the host) the plane index map IS the oracle's on all 89,960 pixels
+    exact = d.MapperEMVS(ctx, rig["cam"], shape)
+    info = process.exact_depth_map_process_2(ctx, [rig["cam"]] * 2, shape, rig["events"], rig["trajectories"], 8, exact, ts, 2, 2)
+    depth2, conf2, idx2 = exact.fetchDepthMap()
+    ridx = ref["fused"].argmax(axis=0)
+    print("configs[3] exact: %r; %d pixels differed before" % (info, int((idx != ridx).sum())))
+    assert np.array_equal(exact.dsi_.download(), got)                   # the same fused DSI as process_2's
+    assert np.array_equal(idx2, ridx), "%d pixels differ" % (idx2 != ridx).sum()
+    assert np.array_equal(depth2, fused.raw_depths_vec_[ridx])
+    assert info["changed_pixels"] == int((idx != ridx).sum()) and 8 * info["max_order_diff"] < 2.5e-4
+    exact.close()
     fused.close()
     cam_time.close()
+
+
+@pytest.mark.parametrize("stereo_fusion,temporal_fusion", [(2, 2), (3, 4), (6, 2), (4, 3)])
+def test_exact_depth_map_process_2_small(ctx, stereo_fusion, temporal_fusion):
+    """Alg. 2 with few events: most columns tie exactly or nearly; the resolved index map equals the oracle's
+    process_2 + first-maximum arg-max on every pixel (temporal_fusion 3 does nothing in the reference: zero DSI)."""
+    rig = syn.stereo_rig(30_000, width=64, height=48, duration=0.3, seed=47, n_points=500)
+    shape = d.ShapeDSI(0, 0, 14, 4.0, 150.0, 0.0)
+    exact = d.MapperEMVS(ctx, rig["cam"], shape)
+    ts = rig["t0"] + 0.15
+    info = process.exact_depth_map_process_2(ctx, [rig["cam"]] * 2, shape, rig["events"], rig["trajectories"], 4, exact, ts,
+                                             stereo_fusion, temporal_fusion)
+    ref = oracle_process_2(lambda: OracleMapper(rig["cam"], dimZ=14, min_depth=4.0, max_depth=150.0),
+                           rig["events"], rig["trajectories"], 4, ts, stereo_fusion, temporal_fusion)
+    depth, conf, idx = exact.fetchDepthMap()
+    assert np.array_equal(idx, ref["fused"].argmax(axis=0)), info
+    close(exact.dsi_.download(), ref["fused"])
+    if temporal_fusion in (2, 4):
+        assert info["near_tie_pixels"] > 0
+    exact.close()
+
+
+def test_resolver_building_blocks(ctx):
+    """dsi_mapper_exact_voxels on arbitrary voxels (any order, duplicates) = the oracle's DSI at those voxels, bit for
+    bit; the host reference ops = the device's; dsi_mapper_patch_depth_map writes what it is told."""
+    from dvs_mcemvs_amd import engine
+    from oracle import oracle as orc
+    nx, ny, nz = 80, 60, 20
+    rig = syn.stereo_rig(40_000, width=nx, height=ny, duration=0.25, seed=19, n_points=600)
+    shape = d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0)
+    first, Rt = d.packetize(rig["events"][0][2], rig["trajectories"][0], rig["T_rv_w"])
+    batch = d.EventBatch(ctx, rig["events"][0][0], rig["events"][0][1], Rt, first)
+    m = d.MapperEMVS(ctx, rig["cam"], shape)
+    r = OracleMapper(rig["cam"], dimZ=nz, min_depth=4.0, max_depth=200.0)
+    assert r.evaluateDSI(rig["events"][0], rig["trajectories"][0], rig["T_rv_w"])
+    rng = np.random.default_rng(3)
+    vox = rng.integers(0, nx * ny * nz, 5000).astype(np.uint32)
+    vox[:50] = vox[50:100]                                   # duplicates
+    top = np.argsort(r.dsi.reshape(-1))[-200:].astype(np.uint32)   # the most-voted voxels
+    vox = np.concatenate([vox, top])
+    values, votes = m.exactVoxels(batch, vox)               # (the mapper's grid was never evaluated: not needed)
+    assert np.array_equal(values, r.dsi.reshape(-1)[vox])
+    assert votes[-1] > 10 and (votes[values == 0] == 0).all()
+    a = rng.uniform(0, 50, 4096).astype(np.float32)
+    g = rng.uniform(0, 50, 4096).astype(np.float32)
+    a[:8] = 0
+    for op in range(1, 7):
+        assert np.array_equal(engine.reference_fuse2(op, a, g), orc.fuse2(a.copy(), g, op))
+    for mode in (0, 1):
+        acc = engine.reference_accumulate(mode, a, g)
+        assert np.array_equal(acc, orc.accumulate(a.copy(), g, mode))
+        assert np.array_equal(engine.reference_finalize(mode, acc, 5), orc.finalize(acc.copy(), mode, 5))
+    m.evaluateDSI_batch(batch)
+    m.computeDepthMap()
+    depth0, conf0, idx0 = m.fetchDepthMap()
+    m.patchDepthMap([5, 7 * nx + 3], [4, 19], [1.5, 2.5])
+    depth1, conf1, idx1 = m.fetchDepthMap()
+    assert idx1.reshape(-1)[5] == 4 and idx1[7, 3] == 19 and conf1[7, 3] == 2.5
+    assert depth1[7, 3] == m.raw_depths_vec_[19]
+    idx1.reshape(-1)[[5, 7 * nx + 3]] = idx0.reshape(-1)[[5, 7 * nx + 3]]
+    assert np.array_equal(idx1, idx0)
+    with pytest.raises(d.DsiError):
+        m.patchDepthMap([nx * ny], [0], [1.0])
+    with pytest.raises(d.DsiError):
+        m.exactVoxels(batch, [nx * ny * nz])
+    m.close()
+    batch.close()
