@@ -203,25 +203,13 @@ def exact_depth_map_process_2(ctx, cams, dsi_shape, events, trajectories, num_su
                 acc = E.reference_accumulate(mode, acc, E.reference_fuse2(stereo_fusion, vals[0], vals[1]))
             final = E.reference_finalize(mode, acc, num_subintervals)
             nx, ny, nz = dims
-            npix = nx * ny
-            pix_of = vox % npix
-            z_of = (vox // npix).astype(np.int64)
-            starts = np.flatnonzero(np.r_[True, pix_of[1:] != pix_of[:-1]])      # a column's run is contiguous
-            ends = np.r_[starts[1:], vox.size]
+            pix, new_idx, new_conf = _first_maxima(vox, final, nx * ny)
             _, conf0, idx0 = mapper_fused.fetchDepthMap()
-            pix, new_idx, new_conf = [], [], []
-            for a, b in zip(starts, ends):
-                j = a + int(np.argmax(final[a:b]))                                # first maximum, planes ascending
-                pix.append(pix_of[a])
-                new_idx.append(z_of[j])
-                new_conf.append(final[j])
-            pix = np.array(pix, np.uint32)
-            new_idx = np.array(new_idx, np.uint8)
             info["changed_pixels"] = int((idx0.reshape(-1)[pix] != new_idx).sum())
             fused_now = mapper_fused.dsi_.download().reshape(-1)[vox]
             info["max_order_diff"] = float(np.max(np.abs(fused_now.astype(np.float64) - final) /
                                                   np.maximum(1.0, np.abs(final))))
-            mapper_fused.patchDepthMap(pix, new_idx, np.array(new_conf, np.float32))
+            mapper_fused.patchDepthMap(pix, new_idx, new_conf)
     for pair in batches:
         for b in pair:
             b.close()
@@ -247,6 +235,59 @@ def process_1_nary(mappers, events, trajectories, mapper_fused, ts, mode, rv_pos
         m.evaluateDSI(ev, tr, T_rv_w)
     mapper_fused.dsi_.setToFusionOfN([m.dsi_ for m in mappers], mode)
     return T_rv_w
+
+
+def _first_maxima(vox, values, npix):
+    """Per column of the (pixel-major, planes ascending) voxel list: pixel, first-maximum plane, its value."""
+    pix_of = vox % npix
+    z_of = (vox // npix).astype(np.int64)
+    starts = np.flatnonzero(np.r_[True, pix_of[1:] != pix_of[:-1]])
+    ends = np.r_[starts[1:], vox.size]
+    j = np.array([a + int(np.argmax(values[a:b])) for a, b in zip(starts, ends)], np.int64)   # argmax: the first maximum
+    return pix_of[starts].astype(np.uint32), z_of[j].astype(np.uint8), values[j].astype(np.float32)
+
+
+def exact_depth_map_nary(mapper_fused, mappers, batches, mode, rel_gap=0.0, fused_grid=None):
+    """The n-camera counterpart of MapperEMVS.resolveNearTies (BASELINE configs[4]): mapper_fused.dsi_ holds
+    setToFusionOfN([m.dsi_ for m in mappers], mode) of the DSIs the mappers built from `batches`, and mapper_fused
+    the depth map of it; the near-tie columns' voxels are re-summed per camera in the reference's order, fused on the
+    host with the reference's scalar ops and the first maximum re-picked.  mode: ACC_GM_TREE (the balanced tree of the
+    reference's 2-ary sqrt(a*b); n = 2, 4, 8), ACC_MIN, ACC_MAX, ACC_SUM (arithmetic mean).  fused_grid: the grid that
+    holds the fusion when it is not mapper_fused.dsi_.  Returns statistics."""
+    n = len(mappers)
+    nx, ny, nz = mapper_fused.dsi_.getDimensions()
+    vox, cols = mapper_fused.nearTieVoxels(grid=fused_grid, rel_gap=rel_gap)
+    info = {"near_tie_pixels": int(cols), "candidate_voxels": int(vox.size), "votes": 0, "changed_pixels": 0}
+    if not vox.size:
+        return info
+    vals = []
+    for m, b in zip(mappers, batches):
+        v, cnt = m.exactVoxels(b, vox)
+        info["votes"] += int(cnt.sum())
+        vals.append(v)
+    if mode == E.ACC_GM_TREE:
+        if n not in (2, 4, 8):
+            raise E.DsiError(E.ERR_BAD_OP, "ACC_GM_TREE needs 2, 4 or 8 cameras")
+        level = vals
+        while len(level) > 1:       # geometricMeanTwoGrids on pairs, then on the results (cartesian3dgrid.h:150-156)
+            level = [E.reference_fuse2(E.FUSE_GM, level[i], level[i + 1]) for i in range(0, len(level), 2)]
+        final = level[0]
+    elif mode in (E.ACC_MIN, E.ACC_MAX):
+        final = vals[0]
+        for v in vals[1:]:
+            final = E.reference_fuse2(E.FUSE_MIN if mode == E.ACC_MIN else E.FUSE_MAX, final, v)
+    elif mode == E.ACC_SUM:
+        acc = np.zeros(vox.shape, np.float32)
+        for v in vals:
+            acc = E.reference_accumulate(E.ACC_SUM, acc, v)
+        final = E.reference_finalize(E.ACC_SUM, acc, n)
+    else:
+        raise E.DsiError(E.ERR_BAD_OP, "exact_depth_map_nary: mode %r has no host restatement" % (mode,))
+    pix, new_idx, new_conf = _first_maxima(vox, final, nx * ny)
+    _, _, idx0 = mapper_fused.fetchDepthMap()
+    info["changed_pixels"] = int((idx0.reshape(-1)[pix] != new_idx).sum())
+    mapper_fused.patchDepthMap(pix, new_idx, new_conf)
+    return info
 
 
 def window_bounds(start_time_s, stop_time_s, duration, out_skip):

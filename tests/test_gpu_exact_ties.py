@@ -100,6 +100,41 @@ def test_resolver_with_lut_inverse_depth_and_the_fused_vote_kernel(ctx):
         o.close()
 
 
+@pytest.mark.parametrize("mode", ["gm_tree", "min", "max", "am"])
+def test_exact_depth_map_of_four_cameras(ctx, mode):
+    """configs[4]'s topology (4 cameras, n-ary fusion) at a size the oracle covers whole: after
+    process.exact_depth_map_nary the index map equals the arg-max of the oracle's n-ary fusion on every pixel."""
+    nx, ny, nz = 96, 72, 24
+    rig = syn.stereo_rig(60_000, width=nx, height=ny, duration=0.3, seed=13, n_cams=4, n_points=600)
+    shape = d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0)
+    batches = _batches(ctx, rig, 4)
+    ms = [d.MapperEMVS(ctx, rig["cam"], shape) for _ in range(4)]
+    for m, b in zip(ms, batches):
+        m.evaluateDSI_batch(b)
+    fused = d.MapperEMVS(ctx, rig["cam"], shape)
+    acc = {"gm_tree": d.ACC_GM_TREE, "min": d.ACC_MIN, "max": d.ACC_MAX, "am": d.ACC_SUM}[mode]
+    fused.dsi_.setToFusionOfN([m.dsi_ for m in ms], acc)
+    fused.computeDepthMap()
+    _, _, idx0 = fused.fetchDepthMap()
+    dsis = []
+    for c in range(4):
+        r = OracleMapper(rig["cam"], dimX=nx, dimY=ny, dimZ=nz, min_depth=4.0, max_depth=200.0)
+        assert r.evaluateDSI(rig["events"][c], rig["trajectories"][c], rig["T_rv_w"])
+        dsis.append(r.dsi)
+    ref = orc.fuse_gm_tree(dsis) if mode == "gm_tree" else orc.fuse_nary(dsis, acc)
+    ridx = ref.argmax(axis=0)
+    info = process_nary(fused, ms, batches, acc)
+    _, conf, idx = fused.fetchDepthMap()
+    assert np.array_equal(idx, ridx), "%d pixels differ (%d before); %r" % ((idx != ridx).sum(), (idx0 != ridx).sum(), info)
+    assert info["changed_pixels"] == int((idx0 != idx).sum()) and info["near_tie_pixels"] > 0
+    for o in ms + [fused] + batches:
+        o.close()
+
+
+def process_nary(fused, ms, batches, acc):
+    return proc.exact_depth_map_nary(fused, ms, batches, acc)
+
+
 def test_resolver_argument_checks(ctx):
     rig = syn.stereo_rig(5_000, width=64, height=48, duration=0.1, seed=1)
     shape = d.ShapeDSI(0, 0, 8, 4.0, 100.0, 0.0)

@@ -742,6 +742,17 @@ def test_configs4_end_to_end_at_full_size(ctx):
     rep = argmax_report(idx_tree[r0:r0 + rows], ref_fused, 4 * DSI_TOL)
     print("configs[4] full size, rows %d..%d: %r" % (r0, r0 + rows, rep))
     assert rep["violations"] == 0 and rep["argmax_agree_frac"] > 0.9, rep
+    # (d) the n-camera exact resolution (process.exact_depth_map_nary: near-tie columns of the fused DSI, their voxels of
+    #     all four camera DSIs re-summed in the reference's order over the 4 x 100 M events, the GM tree on the host):
+    #     on the strip the oracle covers, the plane index map IS the oracle's
+    from dvs_mcemvs_amd import process
+    mappers[0].computeDepthMap(fused)
+    info = process.exact_depth_map_nary(mappers[0], mappers, batches, d.ACC_GM_TREE, fused_grid=fused)
+    _, _, idx_exact = mappers[0].fetchDepthMap()
+    ridx = ref_fused.argmax(axis=0)
+    before = int((idx_tree[r0:r0 + rows] != ridx).sum())
+    print("configs[4] exact n-ary resolution: %r; on the strip %d pixels differed before" % (info, before))
+    assert np.array_equal(idx_exact[r0:r0 + rows], ridx), "%d pixels of the strip differ" % (idx_exact[r0:r0 + rows] != ridx).sum()
     for o_ in mappers + batches + [fused]:
         o_.close()
 
