@@ -469,6 +469,10 @@ bool plan_fused(const dsi_mapper* m, size_t n_packets_max, dsi::BandPlan* bp)
     bp->persistent = 0;
     bp->halo = 1;
     bp->experiment = 0;
+#ifdef DSI_TIMING_EXPERIMENTS
+    if (const char* e = std::getenv("DSI_FUSED_2CU"))  // 0: a small band still runs one workgroup per CU (A/B)
+        if (std::atoi(e) == 0) bp->experiment = 300;
+#endif
     return true;
 }
 

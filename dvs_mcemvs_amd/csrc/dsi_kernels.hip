@@ -651,6 +651,7 @@ using acc_t = unsigned long long;
 // thread.  20 cover the whole LDS (160 KB of 8-byte cells); the vector-fill mappings leave fewer registers: 16.
 constexpr int kFusedTracePhases = 64;
 __host__ __device__ constexpr int fused_cells_per_thread(int mapping) { return (mapping == 5 || mapping == 6) ? 16 : 20; }
+constexpr int kFusedCellsTwoPerCu = 10;  // k_vote_fuse_argmax_2cu: half the LDS per workgroup = 10 x 1024 cells
 constexpr float kFixScale = 2147483648.f;      // 2^31
 constexpr double kFixInv = 1.0 / 2147483648.0;  // 2^-31
 
@@ -2400,10 +2401,10 @@ __device__ __forceinline__ void fused_consume(acc_t* __restrict__ band, int nx, 
 }
 
 template <int MAPPING, int CELLS>
-__global__ __launch_bounds__(1024) void k_vote_fuse_argmax(FusedCameras cams, Geom g, BandPlan bp, int op,
-                                                           const uint32_t* __restrict__ splits,
-                                                           unsigned long long* __restrict__ keys,
-                                                           unsigned long long* __restrict__ trace)
+__device__ __forceinline__ void vote_fuse_argmax_body(const FusedCameras& cams, const Geom& g, const BandPlan& bp, int op,
+                                                      const uint32_t* __restrict__ splits,
+                                                      unsigned long long* __restrict__ keys,
+                                                      unsigned long long* __restrict__ trace)
 {
     constexpr int BLOCK = 1024;
     extern __shared__ acc_t band[];
@@ -2564,6 +2565,27 @@ __global__ __launch_bounds__(1024) void k_vote_fuse_argmax(FusedCameras cams, Ge
     }
     emit();
 #undef DSI_FUSED_STAMP
+}
+
+// one workgroup per CU: the band takes (almost) the whole LDS, up to 128 VGPRs
+template <int MAPPING, int CELLS>
+__global__ __launch_bounds__(1024) void k_vote_fuse_argmax(FusedCameras cams, Geom g, BandPlan bp, int op,
+                                                           const uint32_t* __restrict__ splits,
+                                                           unsigned long long* __restrict__ keys,
+                                                           unsigned long long* __restrict__ trace)
+{
+    vote_fuse_argmax_body<MAPPING, CELLS>(cams, g, bp, op, splits, keys, trace);
+}
+
+// TWO workgroups per CU (round 4): bands of at most half the LDS, half the cells per thread, <= 64 VGPRs -- while one
+// workgroup's 16 waves stand at a phase barrier or read a band back, the other's vote.  Same body, same bits.
+// (`cams` stays the FIRST parameter: the body reads the camera table from the start of the kernel-argument segment.)
+template <int MAPPING, int CELLS>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_vote_fuse_argmax_2cu(
+    FusedCameras cams, Geom g, BandPlan bp, int op, const uint32_t* __restrict__ splits,
+    unsigned long long* __restrict__ keys, unsigned long long* __restrict__ trace)
+{
+    vote_fuse_argmax_body<MAPPING, CELLS>(cams, g, bp, op, splits, keys, trace);
 }
 
 // Balanced partition of the (band-major) pair list for the fused kernel: pair q costs work0[q] + work1[q]
@@ -3961,6 +3983,19 @@ static hipError_t launch_vote_fuse_argmax_t(hipStream_t s, const FusedCameras& c
 {
     constexpr int CELLS = fused_cells_per_thread(MAPPING);
     if ((size_t)(bp.band_rows + 2) * g.nx > (size_t)CELLS * 1024) return hipErrorInvalidValue;
+    if constexpr (MAPPING == 1 || MAPPING == 3) {
+        // a band of at most half the LDS and half the cells: two workgroups per CU, the variant with <= 64 VGPRs
+        constexpr int HALF = kFusedCellsTwoPerCu;
+        // (bp.experiment 300: experiments flavour, DSI_FUSED_2CU=0 -- the same small band with ONE workgroup per CU, for A/B)
+        if (bp.experiment != 300 && bp.lds_bytes * 2 <= max_dynamic_lds() && (size_t)(bp.band_rows + 2) * g.nx <= (size_t)HALF * 1024) {
+            const void* kern2 = reinterpret_cast<const void*>(&k_vote_fuse_argmax_2cu<MAPPING, HALF>);
+            if (hipError_t e = allow_dynamic_lds(kern2, bp.lds_bytes)) return e;
+            // (the balanced partition, an experiments-flavour option, is laid out for one workgroup per CU: not used here)
+            hipLaunchKernelGGL((k_vote_fuse_argmax_2cu<MAPPING, HALF>), dim3(2 * blocks), dim3(1024), bp.lds_bytes, s, cams, g, bp, op,
+                               nullptr, keys, trace);
+            return hipExtGetLastError();
+        }
+    }
     const void* kern = reinterpret_cast<const void*>(&k_vote_fuse_argmax<MAPPING, CELLS>);
     if (hipError_t e = allow_dynamic_lds(kern, bp.lds_bytes)) return e;
     hipLaunchKernelGGL((k_vote_fuse_argmax<MAPPING, CELLS>), dim3(blocks), dim3(1024), bp.lds_bytes, s, cams, g, bp, op, splits, keys, trace);
@@ -3969,7 +4004,7 @@ static hipError_t launch_vote_fuse_argmax_t(hipStream_t s, const FusedCameras& c
 
 size_t fused_max_cells(int mapping) { return (size_t)fused_cells_per_thread(mapping) * 1024; }
 
-size_t fused_trace_words() { return (size_t)fused_grid_blocks() * kFusedTracePhases * 16 * 4; }
+size_t fused_trace_words() { return (size_t)2 * fused_grid_blocks() * kFusedTracePhases * 16 * 4; }  // (two workgroups per CU at most)
 
 int fused_grid_blocks()
 {

@@ -35,6 +35,14 @@ def test_vote_kernels_do_not_spill(tmp_path):
         seen += 1
         val = lambda key: int(re.search(r"\.%s:\s+(\d+)" % key, block).group(1))
         vector_fill = "k_vote_bands_vfill" in name or "k_vote_fuse_argmax" in name
+        if "k_vote_fuse_argmax_2cu" in name:
+            # the two-workgroups-per-CU variant of the fused kernel (bands of at most half the LDS): 64 VGPRs hold the
+            # wave loops' ~30 named registers OR the per-cell state (10 + 10 + 3) plus the read-back's temporaries, so
+            # the compiler parks part of the state in scratch AROUND the assembly blocks -- once per phase, never inside
+            # a wave loop (the loops are single asm statements).  Bounded here so that it cannot grow unnoticed.
+            assert val("vgpr_count") <= 64, name
+            assert val("vgpr_spill_count") <= 32 and val("private_segment_fixed_size") <= 64, name
+            continue
         if vector_fill:
             # lane mappings 5 / 6 run where ONE workgroup fills a CU (wide grids): 4 waves per SIMD, up to
             # 128 VGPRs -- the third register set of gathers in flight lives there; the fused vote -> fusion
