@@ -97,6 +97,10 @@ def parse():
     ap.add_argument("--no-extra", action="store_true",
                     help="default (stereo, 1 GPU) run only: do not append the one-GPU lines of the windows and "
                          "cameras4 workloads (each is a sub-run of this script) to the JSON line")
+    ap.add_argument("--clock-ramp", type=int, default=None,
+                    help="untimed steps run BEFORE the --warmup steps to bring the GPU's clocks up after the idle stretch in "
+                         "which the host generated the inputs (default: ~0.25 s worth: 100 stereo steps, 600 windows, 40 "
+                         "cameras4 steps; 0 = none).  The same count on every rank (steps contain collectives)")
     ap.add_argument("--no-sensitivity", action="store_true",
                     help="default (stereo, 1 GPU) run only: skip the input-sensitivity sub-records (the voting kernel on "
                          "uniformly random pixels, on a dense scene and on the recorded zurich_city_04 trajectory)")
@@ -107,6 +111,8 @@ def parse():
     a.events = a.events or defaults[1]
     a.steps = a.steps if a.steps is not None else defaults[2]
     a.warmup = a.warmup if a.warmup is not None else defaults[3]
+    if a.clock_ramp is None:
+        a.clock_ramp = {"stereo": 100, "windows": 600, "cameras4": 40}[a.workload]
     return a
 
 
@@ -649,6 +655,16 @@ def main():
         D.barrier()
         sync()
 
+    # clock ramp (untimed, before the contract's W warm-up steps): the GPU idled for seconds while the host generated the
+    # inputs, and the first launches after an idle stretch run 1-2 % slow (measured: stereo 2.623 -> 2.589 ms per step,
+    # windows 0.451 -> 0.443, cameras4 6.51 -> 6.37 with a long warm-up); a stream of real windows never idles
+    t_ramp = time.perf_counter()
+    for i in range(args.clock_ramp):
+        step()
+        if i % 16 == 15:
+            sync()
+    sync()
+    t_ramp = time.perf_counter() - t_ramp
     for _ in range(args.warmup):
         step()
     barrier()
@@ -870,6 +886,8 @@ def main():
             "stream_kernels": streams,
             "gpu_ms_per_step_hip_events": gpu_ms / args.steps,
             "timed_region_s": elapsed,
+            "clock_ramp": {"steps": args.clock_ramp, "seconds": t_ramp,
+                           "note": "untimed steps before the warm-up steps: brings the clocks up after the idle input generation"},
             "host_fed": h2d, "roofline": roofline, "cpu_baseline": cpu, "input_gen_s": t_gen,
             "step_ms": {"min": float(step_ms.min()), "median": float(np.median(step_ms)), "max": float(step_ms.max()),
                         "n": int(step_ms.shape[0]), "source": "HIP events between consecutive steps on the compute stream" +
