@@ -841,7 +841,7 @@ def main():
                     cy.close()
 
         cpu = None
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:      # (the CPU baseline is a rank-0, N = 1 figure; at N > 1 the other ranks would only wait for it)
             cpu = cpu_baseline(d, rig, (nx, ny, nz) if args.workload != "windows" else (nx, ny, nz),
                                10_000_000 if args.workload == "stereo" else 1_000_000)
 
