@@ -97,6 +97,11 @@ def parse():
     ap.add_argument("--no-extra", action="store_true",
                     help="default (stereo, 1 GPU) run only: do not append the one-GPU lines of the windows and "
                          "cameras4 workloads (each is a sub-run of this script) to the JSON line")
+    ap.add_argument("--camera-streams", type=int, default=2,
+                    help="cameras4: contexts (HIP streams) the cameras are dealt over, 1 or 2.  With 2, camera c+1's packet "
+                         "sort / coefficient tables and the first workgroups of its voting kernel start on the CUs camera c's "
+                         "persistent voting kernel has already left (its workgroups fill a CU's LDS, so nothing else runs "
+                         "beside them)")
     ap.add_argument("--clock-ramp", type=int, default=None,
                     help="untimed steps run BEFORE the --warmup steps to bring the GPU's clocks up after the idle stretch in "
                          "which the host generated the inputs (default: ~0.25 s worth: 100 stereo steps, 600 windows, 40 "
@@ -611,16 +616,19 @@ def main():
         shape = d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0)
         begin, count = dd.plane_ranges(nz, world)[rank]
         mappers, batches, voted = [], [], 0
+        # cameras dealt over one or two contexts of this GPU (the arg-max / fusion waits for both and releases them)
+        cam_ctxs = [ctx] + ([d.Context(D.local_rank)] if args.camera_streams >= 2 else [])
         for c in range(4):
-            m = tune(d.MapperEMVS(ctx, rig["cam"], shape, plane_range=(begin, count)))
+            cc = cam_ctxs[c % len(cam_ctxs)]
+            m = tune(d.MapperEMVS(cc, rig["cam"], shape, plane_range=(begin, count)))
             first, Rt = d.packetize(rig["events"][c][2], rig["trajectories"][c], rig["T_rv_w"])
-            batches.append(d.EventBatch(ctx, rig["events"][c][0], rig["events"][c][1], Rt, first))
+            batches.append(d.EventBatch(cc, rig["events"][c][0], rig["events"][c][1], Rt, first))
             voted += first.shape[0] * d.PACKET_SIZE
             mappers.append(m)
         vote_mappers = mappers
         extra["batch0"] = batches[0]
         fused = d.Grid3D(ctx, nx, ny, count)
-        closers += mappers + batches + [fused]
+        closers += mappers + batches + [fused] + cam_ctxs[1:]
         gm_mode = d.ACC_GM_TREE if args.gm == "tree" else d.ACC_LOG_SUM
 
         def step():
@@ -630,14 +638,31 @@ def main():
                 # n-ary GM inside the arg-max kernel: same bits, the fused volume is never written
                 mappers[0].computeDepthMapOfFusionN([m.dsi_ for m in mappers], gm_mode)
                 return
+            for cc in cam_ctxs[1:]:
+                ctx.wait_for(cc)                                                 # the fusion reads grids voted on the other stream
             fused.setToFusionOfN([m.dsi_ for m in mappers], gm_mode)           # n-ary GM, voxel-wise, local
+            for cc in cam_ctxs[1:]:
+                cc.wait_for(ctx)                                                 # ... whose next votes must not overtake it
             if comm is None:
                 mappers[0].computeDepthMap(fused)
             else:
                 mappers[0].computeDepthMapSharded(fused, comm)                  # ONE all-reduce(MAX) of keys
 
         def sync():
-            ctx.synchronize()
+            for cc in cam_ctxs:
+                cc.synchronize()
+
+        if len(cam_ctxs) > 1:
+            # an event pair around a kernel also times its wait for the other stream's workgroups to leave the CUs: the
+            # dominant kernel's duration is measured on un-overlapped steps after the timed region (like the windows)
+            extra["concurrent"] = True
+
+            def serial_step():
+                for c in range(4):
+                    mappers[c].evaluateDSI_batch(batches[c])
+                    sync()
+            extra["serial_step"] = (serial_step, sync)
+            extra["camera_streams"] = len(cam_ctxs)
 
         # every rank votes ALL events into its plane range: the job's events are counted once
         voted_per_step = voted if rank == 0 else 0.0
@@ -645,7 +670,8 @@ def main():
                     % (args.events, nx, ny, nz,
                        "tree of the reference's 2-ary sqrt(a*b)" if args.gm == "tree" else "exp(mean(log))",
                        (" (fused DSI written)" if args.materialize_fused else " in one kernel (fused DSI not written)")
-                       if world == 1 else ", planes sharded over %d GPUs" % world))
+                       if world == 1 else ", planes sharded over %d GPUs" % world) +
+                    ("; cameras dealt over %d streams" % len(cam_ctxs) if len(cam_ctxs) > 1 else ""))
         parallelism, scaling = ("1 GPU" if world == 1 else "plane-shard x%d" % world), "strong"
         ev_per_launch = voted / 4.0
     t_gen = time.time() - t_gen
@@ -759,7 +785,8 @@ def main():
                                   records)
         if overlapped:
             roofline["kernel_timing"] = ("HIP events around %d un-overlapped launches after the timed region (in the "
-                                         "timed region consecutive windows overlap on two streams)" % kt_n)
+                                         "timed region consecutive %s overlap on two streams)"
+                                         % (kt_n, "windows" if args.workload == "windows" else "cameras' kernels"))
         streams = stream_kernels(d, ctx) if not args.no_host_fed else None
 
         # ---- host-buffer (PCIe-inclusive) rates, reported beside `value`, never as it ----
