@@ -3,6 +3,7 @@
 // output):
 //
 //   process_1   mapper_emvs_stereo/src/process1.cpp:28-224   one DSI per camera, camera fusion
+//   process_2_exact_depth_map                                Alg. 2's fused DSI + an arg-max whose index map equals the CPU reference's on every pixel
 //   process_1_exact_depth_map                                process_1 + arg-max whose index map equals the CPU reference's on every pixel
 //   process_1_depth_map                                      the same + the arg-max of getDepthMapFromDSI, without
 //                                                            writing any DSI (one fused kernel)
@@ -453,6 +454,152 @@ inline Process2MultiResult process_2_multi_gpu(const std::vector<dsi::Context*>&
     dsi::fuseTwoGrids(out.camera_time, out.right[0], converse[stereo_fusion], "Improper stereo fusion method selected");
     for (int i = 0; i < ndev; ++i) ctxs[i]->synchronize();  // the mappers go out of scope
     return out;
+}
+
+// ---- Alg. 2 with a plane index map equal to the CPU reference's on EVERY pixel (BASELINE configs[3]) ----
+// The resolver (dsi_mapper_resolve_near_ties) covers Alg. 1's topology; Alg. 2 fuses cameras per sub-interval and then
+// over time (process2.cpp:98-249), so it is resolved from the same building blocks: the near-tie columns of the FINAL
+// fused DSI (dsi_grid_near_tie_voxels), those voxels of every (sub-interval, camera) DSI re-summed in the reference's
+// order (dsi_mapper_exact_voxels: fp32, event order, cartesian3dgrid.h:261-270), the reference's scalar ops on the host
+// in process_2's order (dsi_reference_fuse2 / _accumulate / _finalize), the first maximum per column
+// (cartesian3dgrid.cpp:132-134), and the few pixels patched (dsi_mapper_patch_depth_map).
+namespace dsi {
+
+struct ExactDepthMapInfo {
+    size_t near_tie_pixels = 0, candidate_voxels = 0;
+    long long votes = 0;
+    int changed_pixels = 0;
+};
+
+// events [begin, end) of one camera as a resident batch for the reference view T7 (packetisation + pose pipeline of
+// mapper_emvs_stereo.cpp:67-105); a batch without packets when evaluateDSI would return false
+inline dsi_batch_t* make_batch(dsi_context_t* ctx, const std::vector<Event>& ev, size_t begin, size_t end,
+                               const LinearTrajectory& tr, const double* T7)
+{
+    const size_t ne = end - begin;
+    std::vector<uint16_t> xs(ne), ys(ne);
+    std::vector<double> tss(ne);
+    for (size_t i = 0; i < ne; ++i) {
+        xs[i] = ev[begin + i].x;
+        ys[i] = ev[begin + i].y;
+        tss[i] = ev[begin + i].ts;
+    }
+    std::vector<uint32_t> first(ne / DSI_PACKET_SIZE + 1, 0u);
+    std::vector<float> Rt(12 * first.size(), 0.f);
+    size_t np = 0;
+    const int rc = dsi_packetize(tss.data(), ne, tr.times().data(), tr.poses7().data(), tr.times().size(), T7, first.data(),
+                                 Rt.data(), &np);
+    if (rc == DSI_ERR_TOO_FEW_EVENTS) np = 0;
+    else check(rc);
+    dsi_batch_t* b = nullptr;
+    check(dsi_batch_create(ctx, xs.data(), ys.data(), ne, first.data(), Rt.data(), np, &b));
+    return b;
+}
+
+}  // namespace dsi
+
+inline dsi::ExactDepthMapInfo process_2_exact_depth_map(dsi::Context& ctx, const dsi::PinholeCameraModel& cam0,
+                                                        const dsi::PinholeCameraModel& cam1,
+                                                        const LinearTrajectory& trajectory0, const LinearTrajectory& trajectory1,
+                                                        const std::vector<dsi::Event>& events0,
+                                                        const std::vector<dsi::Event>& events1,
+                                                        const EMVS::ShapeDSI& dsi_shape, const int num_subintervals,
+                                                        EMVS::MapperEMVS& mapper_fused, double ts, int stereo_fusion,
+                                                        int temporal_fusion, dsi::Image<float>& depth_map,
+                                                        dsi::Image<float>& confidence_map,
+                                                        dsi::Image<uint8_t>& depth_cell_indices, float rel_gap = 0.f)
+{
+    EMVS::MapperEMVS mapper0(ctx, cam0, dsi_shape), mapper1(ctx, cam1, dsi_shape);
+    EMVS::MapperEMVS* mappers[2] = {&mapper0, &mapper1};
+    const std::vector<dsi::Event>* evs[2] = {&events0, &events1};
+    const LinearTrajectory* trs[2] = {&trajectory0, &trajectory1};
+    int nx, ny, nz;
+    mapper0.dsi_.getDimensions(&nx, &ny, &nz);
+    Grid3D sub(ctx, nx, ny, nz);
+    dsi::Transformation T_w_l;
+    if (!trajectory0.getPoseAt(ts, T_w_l)) throw dsi::Error(DSI_ERR_INVALID, "no pose at the reference timestamp");
+    double T7[7];
+    dsi::inverse(T_w_l).to7(T7);  // process2.cpp:79-81
+    const int mode = temporal_fusion == 2 ? DSI_ACC_INV_SUM : (temporal_fusion == 4 ? DSI_ACC_SUM : -1);
+    std::vector<dsi_batch_t*> batches;  // [sub-interval][camera]
+    dsi::ExactDepthMapInfo info;
+    auto release = [&]() {
+        for (dsi_batch_t* b : batches) dsi_batch_destroy(b);
+        batches.clear();
+    };
+    try {
+        mapper_fused.dsi_.resetGrid();  // :90
+        for (int k = 0; k < num_subintervals; ++k) {
+            for (int c = 0; c < 2; ++c) {
+                const size_t per = evs[c]->size() / (size_t)num_subintervals;  // :46-47
+                dsi_batch_t* b = dsi::make_batch(ctx.handle(), *evs[c], (size_t)k * per, (size_t)(k + 1) * per, *trs[c], T7);
+                batches.push_back(b);
+                // :100-101 resetGrid + :119 / :146 evaluateDSI (a batch without packets -- evaluateDSI returned false -- leaves
+                // the reset DSI: the vote of zero packets writes zeros)
+                dsi::check(dsi_mapper_evaluate_batch(mappers[c]->handle(), b));
+            }
+            sub.resetGrid();  // :159-160
+            sub.addTwoGrids(mapper0.dsi_);
+            dsi::fuseTwoGrids(sub, mapper1.dsi_, stereo_fusion, "Improper stereo fusion method selected");  // :168-189
+            if (mode >= 0) {
+                mapper_fused.dsi_.accumulate(sub, mode);                                            // :218-220 / :231-233
+                if (k == num_subintervals - 1) mapper_fused.dsi_.finalize(mode, num_subintervals);  // :221-225
+            }
+        }
+        dsi::check(dsi_mapper_depth_map_of(mapper_fused.handle(), mapper_fused.dsi_.handle()));
+        const size_t npix = (size_t)nx * ny;
+        depth_map = dsi::Image<float>(ny, nx);
+        confidence_map = dsi::Image<float>(ny, nx);
+        depth_cell_indices = dsi::Image<uint8_t>(ny, nx);
+        if (mode >= 0) {
+            std::vector<uint32_t> vox(1 << 16);
+            size_t n_vox = 0, n_cols = 0;
+            for (;;) {
+                dsi::check(dsi_grid_near_tie_voxels(mapper_fused.handle(), mapper_fused.dsi_.handle(), rel_gap, vox.data(), vox.size(),
+                                                    &n_vox, &n_cols));
+                if (n_vox <= vox.size()) break;
+                vox.resize(n_vox);
+            }
+            vox.resize(n_vox);
+            info.near_tie_pixels = n_cols;
+            info.candidate_voxels = n_vox;
+            if (n_vox) {
+                std::vector<float> acc(n_vox, 0.f), a(n_vox), g(n_vox), f(n_vox);
+                std::vector<uint32_t> votes(n_vox);
+                for (int k = 0; k < num_subintervals; ++k) {
+                    dsi::check(dsi_mapper_exact_voxels(mapper0.handle(), batches[2 * k], vox.data(), n_vox, a.data(), votes.data()));
+                    for (uint32_t v : votes) info.votes += v;
+                    dsi::check(dsi_mapper_exact_voxels(mapper1.handle(), batches[2 * k + 1], vox.data(), n_vox, g.data(), votes.data()));
+                    for (uint32_t v : votes) info.votes += v;
+                    dsi::check(dsi_reference_fuse2(stereo_fusion, a.data(), g.data(), n_vox, f.data()));
+                    dsi::check(dsi_reference_accumulate(mode, acc.data(), f.data(), n_vox));
+                }
+                dsi::check(dsi_reference_finalize(mode, acc.data(), n_vox, num_subintervals));
+                dsi::check(dsi_mapper_fetch_depth_map(mapper_fused.handle(), nullptr, nullptr, depth_cell_indices.data.data()));
+                std::vector<uint32_t> pix;
+                std::vector<uint8_t> idx;
+                std::vector<float> conf;
+                for (size_t i = 0; i < n_vox;) {  // a column's run is contiguous, planes ascending
+                    const uint32_t p = vox[i] % (uint32_t)npix;
+                    size_t best = i;
+                    for (size_t j = i; j < n_vox && vox[j] % (uint32_t)npix == p; ++j, ++i)
+                        if (acc[best] < acc[j]) best = j;  // the first maximum wins
+                    pix.push_back(p);
+                    idx.push_back((uint8_t)(vox[best] / (uint32_t)npix));
+                    conf.push_back(acc[best]);
+                    if (depth_cell_indices.data[p] != idx.back()) ++info.changed_pixels;
+                }
+                dsi::check(dsi_mapper_patch_depth_map(mapper_fused.handle(), pix.data(), idx.data(), conf.data(), pix.size()));
+            }
+        }
+        dsi::check(dsi_mapper_fetch_depth_map(mapper_fused.handle(), depth_map.data.data(), confidence_map.data.data(),
+                                              depth_cell_indices.data.data()));
+    } catch (...) {
+        release();
+        throw;
+    }
+    release();
+    return info;
 }
 
 inline Process2Result process_5(dsi::Context& ctx, const dsi::PinholeCameraModel& cam0,

@@ -359,6 +359,28 @@ int main()
             std::printf("%s: left %.3g right %.3g fused %.3g camera-time %.3g\n", shuffle ? "process_5" : "process_2",
                         el, er, ef, ec);
             if (el > 3e-4 || er > 3e-4 || ef > 1e-3 || ec > 1e-3) return 70 + variant;
+            if (!shuffle) {
+                // Alg. 2 through the resolver's building blocks: the plane index map IS the arg-max (first maximum) of the
+                // oracle's time-fused volume, on every pixel
+                EMVS::MapperEMVS exact(ctx, cam, dsi_shape);
+                dsi::Image<float> de, ce;
+                dsi::Image<uint8_t> ie;
+                const dsi::ExactDepthMapInfo xi = process_2_exact_depth_map(ctx, cam, cam, trajectory0, trajectory1, events0, events1,
+                                                                            dsi_shape, n_sub, exact, 0.5, stereo, temporal, de, ce, ie);
+                const size_t npix = ie.data.size(), nplanes = n / npix;
+                size_t differ = 0;
+                for (size_t p = 0; p < npix; ++p) {
+                    size_t best = 0;
+                    for (size_t z = 1; z < nplanes; ++z)
+                        if (ofused[best * npix + p] < ofused[z * npix + p]) best = z;
+                    differ += (size_t)ie.data[p] != best;
+                    if ((size_t)ie.data[p] == best && de.data[p] != planes[best]) return 75;
+                }
+                std::printf("process_2_exact_depth_map: %zu near-tie columns, %zu voxels, %lld votes re-summed, %d pixels changed, %zu differ\n",
+                            xi.near_tie_pixels, xi.candidate_voxels, xi.votes, xi.changed_pixels, differ);
+                if (differ != 0 || xi.near_tie_pixels == 0) return 74;
+                if (exact.dsi_.download() != mapper_fused.dsi_.download()) return 76;  // the same fused DSI as process_2's
+            }
         }
         // ---- process_2 over every GPU of the node (one here on the test box, eight under the driver's
         //      multi-GPU run): sub-interval -> device, ONE RCCL all-reduce per accumulator issued by the
