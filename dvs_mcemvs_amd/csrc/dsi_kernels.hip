@@ -2206,26 +2206,32 @@ __device__ __forceinline__ void vote_bands_packed_body(const EvRec* __restrict__
     // mapping relies on): class x takes items x, x + 8, x + 16, ... in order, through one atomic
     // counter per class, so the load stays balanced like the hardware's own dispatch.
     const int cls = blockIdx.x & 7;
+    __shared__ int s_next;  // persistent: the item AFTER the current one, drawn while the current one is voted
     if (work_counters) {
         const int all_cells = (bp.band_rows + 1) * nx;
         for (int i = threadIdx.x; i < all_cells; i += BLOCK) band[i] = 0;
-    }
-    for (;;) {
-    if (work_counters) {
         if (threadIdx.x == 0) {
             s_item = (int)atomicAdd(&work_counters[cls], 1u) * 8 + cls;
             s_pass = 2 * (BLOCK / kWave);  // (vector fill: units of half a pass, two pre-assigned per wave)
         }
-        __syncthreads();  // also: the previous item's flush has cleared the band
+        __syncthreads();
     }
+    for (;;) {
     const int b = work_counters ? s_item : (int)blockIdx.x;
     if (b >= total) break;
     int q, z;
     if (!item_of(b, pairs, g.nz, q, z, bp.experiment == 200)) {  // (a leftover slot beyond the last plane)
         if (!work_counters) break;
         __syncthreads();  // every thread has read s_item before thread 0 draws again
+        if (threadIdx.x == 0) s_item = (int)atomicAdd(&work_counters[cls], 1u) * 8 + cls;
+        __syncthreads();
         continue;
     }
+    // Round 4: the NEXT item is drawn now, at the start of this one.  Only thread 0's wave waits for the atomic's round
+    // trip (~1 us); the other 15 waves are already voting, and because the waves of a workgroup draw their passes from a
+    // counter, a wave that enters the stream late simply takes fewer passes.  Drawn after the flush (rounds 2-3), the
+    // round trip stood between two items with all 16 waves idle: 61 items per CU at 1024x1024x256.
+    if (work_counters && threadIdx.x == 0) s_next = (int)atomicAdd(&work_counters[cls], 1u) * 8 + cls;
     const int c = q / bp.bands, j = q % bp.bands;
     const int r0 = j * bp.band_rows;
     const int r1 = min(g.ny, r0 + bp.band_rows);
@@ -2251,7 +2257,11 @@ __device__ __forceinline__ void vote_bands_packed_body(const EvRec* __restrict__
     }
     if (bp.experiment != 2)  // (2: timing experiment without the flush)
         flush_band_and_clear<BLOCK>(band, nx, (r1 - r0) * nx, out, off, bp.raw_out, seam_rows(seam, c, z, j, g, bp), j, bp.bands);
-    __syncthreads();  // every thread has read s_item and cleared its cells before thread 0 draws again
+    if (threadIdx.x == 0) {  // (every thread read s_item before the stream's barrier; s_pass is idle between the barriers)
+        s_item = s_next;
+        s_pass = 2 * (BLOCK / kWave);
+    }
+    __syncthreads();  // the band is clear and the next item known before anybody goes on
     }
 }
 
