@@ -34,6 +34,6 @@ want stereo && one ${R}_stereo "--no-host-fed --steps 50 --warmup 5" "--no-sensi
 want stereo && python tools/make_traffic_json.py gpurun_out/profiles_${R}_stereo/pmc_counters.txt 512 512 200 > gpurun_out/profiles_${R}_stereo/traffic.json
 want windows && one ${R}_windows "--workload windows --serial-windows --no-host-fed --steps 50 --warmup 5" "--workload windows --serial-windows --no-host-fed --steps 3 --warmup 1" "$SQ1" "$SQ2" "$SQ3" "FETCH_SIZE" "WRITE_SIZE"
 want windows_two_streams && one ${R}_windows_two_streams "--workload windows --no-host-fed --steps 50 --warmup 5" "" 
-want cameras4 && one ${R}_cameras4 "--workload cameras4 --no-host-fed --steps 10 --warmup 2" "--workload cameras4 --no-host-fed --steps 3 --warmup 1" "$SQ1" "$SQ3"
+want cameras4 && one ${R}_cameras4 "--workload cameras4 --camera-streams 1 --no-host-fed --steps 10 --warmup 2" "--workload cameras4 --camera-streams 1 --no-host-fed --steps 3 --warmup 1 --clock-ramp 0" "$SQ1" "$SQ3"
 want 1024 && one ${R}_1024 "--dims 1024 1024 256 --events 10000000 --no-host-fed --steps 10 --warmup 2" "--dims 1024 1024 256 --events 10000000 --no-host-fed --steps 3 --warmup 1" "$SQ1" "$SQ2" "$SQ3"
 ls -la gpurun_out/profiles_${R}_*
