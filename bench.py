@@ -98,7 +98,7 @@ def parse():
                     help="default (stereo, 1 GPU) run only: do not append the one-GPU lines of the windows and "
                          "cameras4 workloads (each is a sub-run of this script) to the JSON line")
     ap.add_argument("--camera-streams", type=int, default=2,
-                    help="cameras4: contexts (HIP streams) the cameras are dealt over, 1 or 2.  With 2, camera c+1's packet "
+                    help="cameras4: contexts (HIP streams) the cameras are dealt over, 1 to 4.  With 2, camera c+1's packet "
                          "sort / coefficient tables and the first workgroups of its voting kernel start on the CUs camera c's "
                          "persistent voting kernel has already left (its workgroups fill a CU's LDS, so nothing else runs "
                          "beside them)")
@@ -617,7 +617,7 @@ def main():
         begin, count = dd.plane_ranges(nz, world)[rank]
         mappers, batches, voted = [], [], 0
         # cameras dealt over one or two contexts of this GPU (the arg-max / fusion waits for both and releases them)
-        cam_ctxs = [ctx] + ([d.Context(D.local_rank)] if args.camera_streams >= 2 else [])
+        cam_ctxs = [ctx] + [d.Context(D.local_rank) for _ in range(max(0, min(4, args.camera_streams) - 1))]
         for c in range(4):
             cc = cam_ctxs[c % len(cam_ctxs)]
             m = tune(d.MapperEMVS(cc, rig["cam"], shape, plane_range=(begin, count)))
