@@ -7,6 +7,8 @@
 //   process_1_exact_depth_map                                process_1 + arg-max whose index map equals the CPU reference's on every pixel
 //   process_1_depth_map                                      the same + the arg-max of getDepthMapFromDSI, without
 //                                                            writing any DSI (one fused kernel)
+//   dsi::full_sequence_depth_maps   main.cpp:177-302          the --full_seq loop (process_method 1) as a stream of
+//                                                            windows, `depth` of them in flight, one fused kernel each
 //   process_2   mapper_emvs_stereo/src/process2.cpp:28-302   sub-intervals: camera fusion then
 //                                                            temporal fusion, and the converse order
 //   process_5   mapper_emvs_stereo/src/process5.cpp:28-260   process_2 with the right camera's
@@ -22,6 +24,7 @@
 #ifndef DSI_PROCESS_HPP
 #define DSI_PROCESS_HPP
 
+#include <cstring>
 #include <memory>
 #include <vector>
 
@@ -284,6 +287,188 @@ inline dsi::Transformation process_1_depth_map(const LinearTrajectory& trajector
     return process_1_depth_map_n(trs, evs, ms, events2.empty() ? 2 : 3, mapper_out, ts, fusion_method, depth_map,
                                  confidence_map, depth_cell_indices, rv_pos);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The --full_seq loop of main.cpp:177-302 with process_method 1, for callers that keep the windows' depth maps, as a
+// STREAM: for (t = start; t + duration <= stop; t += out_skip) { events of [t, t + duration] of both cameras; reference
+// view at t + duration (forward_looking) or at the middle; process_1; arg-max of getDepthMapFromDSI }.  The reference
+// builds fresh mappers per window (main.cpp:262-275) and runs the windows one after the other; here `depth` windows are
+// in flight, each in its own context (HIP streams) with its own mappers and page-locked result buffers: window w+1's
+// uploads, packet sort and tables and the first workgroups of its voting kernel run while window w's kernel drains and
+// its depth map travels to the host.  Per window ONE kernel votes both cameras band by band in LDS, fuses them and keeps
+// the running arg-max (dsi_mapper_depth_map_of_events): the depth maps are those of process_1(...) +
+// mapper_fused.getDepthMapFromDSI(...) before the filters, bit for bit (process_1_depth_map above is the one-window form).
+//
+// on_window(const dsi::WindowDepthMap&) is called once per window, in window order, from the calling thread.
+namespace dsi {
+
+struct WindowDepthMap {
+    int index = 0;                    // 0, 1, ... in the order of main.cpp:177
+    double t_start = 0, t_stop = 0;   // the interval
+    double ts = 0;                    // the reference view's timestamp (main.cpp:184-188)
+    Transformation T_rv_w;            // process1.cpp:56-68
+    size_t n_events[2] = {0, 0};      // events of the interval per camera (a camera with < 1024 votes nothing: :71-75)
+    Image<float> depth_map, confidence_map;  // the raw arg-max (mapper_emvs_stereo.cpp:302-313), before the filters
+    Image<uint8_t> depth_cell_indices;
+};
+
+// events of a time-sorted vector with t_start <= ts <= t_stop: [begin, end)
+// (a rosbag is cut at message granularity instead, data_loading.cpp:272-285: a few hundred events more)
+inline void window_event_range(const std::vector<Event>& ev, double t_start, double t_stop, size_t* begin, size_t* end)
+{
+    size_t lo = 0, hi = ev.size();
+    while (lo < hi) {  // first event with ts >= t_start
+        const size_t mid = (lo + hi) / 2;
+        if (ev[mid].ts < t_start) lo = mid + 1; else hi = mid;
+    }
+    *begin = lo;
+    hi = ev.size();
+    while (lo < hi) {  // first event with ts > t_stop
+        const size_t mid = (lo + hi) / 2;
+        if (ev[mid].ts <= t_stop) lo = mid + 1; else hi = mid;
+    }
+    *end = lo;
+}
+
+template <typename OnWindow>
+inline size_t full_sequence_depth_maps(int device, const PinholeCameraModel& cam0, const PinholeCameraModel& cam1,
+                                       const EMVS::ShapeDSI& dsi_shape, const LinearTrajectory& trajectory0,
+                                       const LinearTrajectory& trajectory1, const std::vector<Event>& events0,
+                                       const std::vector<Event>& events1, double start_time_s, double stop_time_s,
+                                       double duration, double out_skip, bool forward_looking, int fusion_method,
+                                       OnWindow&& on_window, int depth = 2, double rv_pos = 0.0)
+{
+    if (!(duration > 0) || !(out_skip > 0)) throw Error(DSI_ERR_INVALID, "full_sequence_depth_maps: duration and out_skip must be > 0");
+    if (depth < 1) depth = 1;
+    struct Slot {
+        Context ctx;
+        EMVS::MapperEMVS m0, m1, out;
+        dsi_batch_t* batch[2] = {nullptr, nullptr};
+        void* host[3] = {nullptr, nullptr, nullptr};  // page-locked depth, confidence, indices
+        // page-locked staging of the window's inputs (asynchronous uploads read them until the window is done)
+        void* in[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+        size_t in_events[2] = {0, 0}, in_packets[2] = {0, 0};
+        WindowDepthMap w;
+        bool busy = false;
+        Slot(int dev, const PinholeCameraModel& c0, const PinholeCameraModel& c1, const EMVS::ShapeDSI& sh)
+            : ctx(dev), m0(ctx, c0, sh), m1(ctx, c1, sh), out(ctx, c0, sh) {}
+        ~Slot()
+        {
+            if (busy) dsi_mapper_fetch_wait(out.handle());
+            for (dsi_batch_t* b : batch) dsi_batch_destroy(b);
+            for (void* p : host) dsi_host_free(p);
+            for (auto& cam : in)
+                for (void* p : cam) dsi_host_free(p);
+        }
+        void reserve_inputs(int c, size_t ne, size_t np)
+        {
+            if (ne > in_events[c] || !in[c][0]) {
+                const size_t cap = ne + ne / 4 + 1024;
+                dsi_host_free(in[c][0]);
+                dsi_host_free(in[c][1]);
+                in[c][0] = in[c][1] = nullptr;
+                check(dsi_host_alloc(cap * sizeof(uint16_t), &in[c][0]));
+                check(dsi_host_alloc(cap * sizeof(uint16_t), &in[c][1]));
+                in_events[c] = cap;
+            }
+            if (np > in_packets[c] || !in[c][2]) {
+                const size_t cap = np + np / 4 + 16;
+                dsi_host_free(in[c][2]);
+                dsi_host_free(in[c][3]);
+                in[c][2] = in[c][3] = nullptr;
+                check(dsi_host_alloc(cap * sizeof(uint32_t), &in[c][2]));
+                check(dsi_host_alloc(cap * 12 * sizeof(float), &in[c][3]));
+                in_packets[c] = cap;
+            }
+        }
+    };
+    std::vector<std::unique_ptr<Slot>> slots;
+    for (int k = 0; k < depth; ++k) slots.emplace_back(new Slot(device, cam0, cam1, dsi_shape));
+    int nx = 0, ny = 0, nz = 0;
+    slots[0]->out.dsi_.getDimensions(&nx, &ny, &nz);
+    const size_t npix = (size_t)nx * ny;
+    for (auto& s : slots) {
+        check(dsi_host_alloc(npix * sizeof(float), &s->host[0]));
+        check(dsi_host_alloc(npix * sizeof(float), &s->host[1]));
+        check(dsi_host_alloc(npix, &s->host[2]));
+    }
+    auto deliver = [&](Slot& s) {
+        check(dsi_mapper_fetch_wait(s.out.handle()));
+        for (dsi_batch_t*& b : s.batch) {
+            dsi_batch_destroy(b);
+            b = nullptr;
+        }
+        s.w.depth_map = Image<float>(ny, nx);
+        s.w.confidence_map = Image<float>(ny, nx);
+        s.w.depth_cell_indices = Image<uint8_t>(ny, nx);
+        std::memcpy(s.w.depth_map.data.data(), s.host[0], npix * sizeof(float));
+        std::memcpy(s.w.confidence_map.data.data(), s.host[1], npix * sizeof(float));
+        std::memcpy(s.w.depth_cell_indices.data.data(), s.host[2], npix);
+        s.busy = false;
+        on_window(static_cast<const WindowDepthMap&>(s.w));
+    };
+    const LinearTrajectory* trs[2] = {&trajectory0, &trajectory1};
+    const std::vector<Event>* evs[2] = {&events0, &events1};
+    std::vector<double> tss;
+    size_t n_windows = 0;
+    // main.cpp:177 (the loop variable is accumulated, like there)
+    for (double interval_start = start_time_s; interval_start + duration <= stop_time_s; interval_start += out_skip) {
+        Slot& s = *slots[n_windows % slots.size()];
+        if (s.busy) deliver(s);
+        const double interval_stop = interval_start + duration;
+        const double ts = forward_looking ? interval_stop : (interval_start + interval_stop) / 2;  // main.cpp:184-188
+        Transformation T_w_l;
+        if (!trajectory0.getPoseAt(ts, T_w_l)) throw Error(DSI_ERR_INVALID, "no pose at the reference timestamp of a window");
+        Transformation baseline;
+        baseline.t[0] = rv_pos;
+        s.w = WindowDepthMap{};
+        s.w.index = (int)n_windows;
+        s.w.t_start = interval_start;
+        s.w.t_stop = interval_stop;
+        s.w.ts = ts;
+        s.w.T_rv_w = inverse(T_w_l * baseline);  // process1.cpp:56-68
+        double T7[7];
+        s.w.T_rv_w.to7(T7);
+        dsi_mapper_t* ms[2] = {s.m0.handle(), s.m1.handle()};
+        for (int c = 0; c < 2; ++c) {
+            size_t a = 0, b = 0;
+            window_event_range(*evs[c], interval_start, interval_stop, &a, &b);
+            const size_t ne = b - a;
+            s.w.n_events[c] = ne;
+            s.reserve_inputs(c, ne, ne / DSI_PACKET_SIZE + 1);
+            uint16_t* xs = static_cast<uint16_t*>(s.in[c][0]);
+            uint16_t* ys = static_cast<uint16_t*>(s.in[c][1]);
+            uint32_t* first = static_cast<uint32_t*>(s.in[c][2]);
+            float* Rt = static_cast<float*>(s.in[c][3]);
+            tss.resize(ne);
+            for (size_t i = 0; i < ne; ++i) {
+                const Event& e = (*evs[c])[a + i];
+                xs[i] = e.x;
+                ys[i] = e.y;
+                tss[i] = e.ts;
+            }
+            size_t np = 0;
+            const int rc = dsi_packetize(tss.data(), ne, trs[c]->times().data(), trs[c]->poses7().data(), trs[c]->times().size(), T7,
+                                         first, Rt, &np);
+            if (rc == DSI_ERR_TOO_FEW_EVENTS) np = 0;  // evaluateDSI returns false: an all-zero DSI (mapper_emvs_stereo.cpp:71-75)
+            else check(rc);
+            check(dsi_batch_create_async(s.ctx.handle(), xs, ys, ne, first, Rt, np, &s.batch[c]));
+        }
+        check(dsi_mapper_depth_map_of_events(s.out.handle(), ms, s.batch, 2, fusion_method));
+        check(dsi_mapper_fetch_depth_map_async(s.out.handle(), static_cast<float*>(s.host[0]), static_cast<float*>(s.host[1]),
+                                               static_cast<uint8_t*>(s.host[2])));
+        s.busy = true;
+        ++n_windows;
+    }
+    // the windows still in flight, oldest first
+    for (size_t k = 0; k < slots.size(); ++k) {
+        Slot& s = *slots[(n_windows + k) % slots.size()];
+        if (s.busy) deliver(s);
+    }
+    return n_windows;
+}
+
+}  // namespace dsi
 
 struct Process2Result {
     dsi::Transformation T_rv_w;

@@ -429,6 +429,78 @@ int main()
             for (int i = 0; i < ndev; ++i)
                 if (max_rel_err(gs[i].download(), scaled) > 1e-6) return 93;
         }
+        // ---- the --full_seq loop as a stream (main.cpp:177-302, process_method 1): every window's depth map equals
+        //      process_1_depth_map on the window's events, bit for bit, whatever the number of windows in flight;
+        //      windows arrive in order; a window with < 1024 events of one camera still gives a (defined) map
+        {
+            struct Got {
+                int index;
+                double ts;
+                size_t n0, n1;
+                std::vector<float> depth, conf;
+                std::vector<uint8_t> idx;
+            };
+            const double start = 0.0, stop = 0.97, duration = 0.4, skip = 0.14;  // windows [0, .4], [.14, .54], ..., [.56, .96]
+            std::vector<Got> runs[3];
+            const int depths[3] = {1, 2, 3};
+            for (int r = 0; r < 3; ++r) {
+                const size_t n = dsi::full_sequence_depth_maps(
+                    0, cam, cam, dsi_shape, trajectory0, trajectory1, events0, events1, start, stop, duration, skip,
+                    /*forward_looking=*/false, /*fusion_method=*/2,
+                    [&](const dsi::WindowDepthMap& w) {
+                        runs[r].push_back(Got{w.index, w.ts, w.n_events[0], w.n_events[1], w.depth_map.data, w.confidence_map.data,
+                                              w.depth_cell_indices.data});
+                    },
+                    depths[r]);
+                if (n != 5 || runs[r].size() != 5) {
+                    std::printf("full_sequence_depth_maps: %zu windows, %zu delivered (expected 5)\n", n, runs[r].size());
+                    return 100;
+                }
+                for (int i = 0; i < 5; ++i)
+                    if (runs[r][i].index != i) return 101;  // in order
+            }
+            for (int r = 1; r < 3; ++r)
+                for (int i = 0; i < 5; ++i)
+                    if (runs[r][i].depth != runs[0][i].depth || runs[r][i].conf != runs[0][i].conf || runs[r][i].idx != runs[0][i].idx)
+                        return 102;  // the number of windows in flight does not change a bit
+            EMVS::MapperEMVS cam_a(ctx, cam, dsi_shape), cam_b(ctx, cam, dsi_shape), out_w(ctx, cam, dsi_shape);
+            double t = start;
+            for (int i = 0; i < 5; ++i, t += skip) {
+                size_t a0, b0, a1, b1;
+                dsi::window_event_range(events0, t, t + duration, &a0, &b0);
+                dsi::window_event_range(events1, t, t + duration, &a1, &b1);
+                if (b0 - a0 != runs[0][i].n0 || b1 - a1 != runs[0][i].n1 || b0 - a0 < 3000) return 103;
+                const std::vector<dsi::Event> w0(events0.begin() + (long)a0, events0.begin() + (long)b0);
+                const std::vector<dsi::Event> w1(events1.begin() + (long)a1, events1.begin() + (long)b1);
+                dsi::Image<float> d, c;
+                dsi::Image<uint8_t> ix;
+                const double ts = (t + (t + duration)) / 2;
+                if (ts != runs[0][i].ts) return 104;
+                process_1_depth_map(trajectory0, trajectory1, w0, w1, out_w, cam_a, cam_b, ts, 2, d, c, ix);
+                if (d.data != runs[0][i].depth || c.data != runs[0][i].conf || ix.data != runs[0][i].idx) {
+                    std::printf("full_sequence_depth_maps: window %d differs from process_1_depth_map\n", i);
+                    return 105;
+                }
+            }
+            // forward-looking reference view (main.cpp:184-185) and a right camera that has too few events in the windows
+            const std::vector<dsi::Event> few(events1.begin(), events1.begin() + 500);
+            int seen = 0;
+            dsi::full_sequence_depth_maps(0, cam, cam, dsi_shape, trajectory0, trajectory1, events0, few, 0.1, 0.95, 0.4, 0.4, true, 6,
+                                          [&](const dsi::WindowDepthMap& w) {
+                                              ++seen;
+                                              if (w.ts != w.t_stop) seen = -100;
+                                              dsi::Image<float> d, c;
+                                              dsi::Image<uint8_t> ix;
+                                              size_t a0, b0, a1, b1;
+                                              dsi::window_event_range(events0, w.t_start, w.t_stop, &a0, &b0);
+                                              dsi::window_event_range(few, w.t_start, w.t_stop, &a1, &b1);
+                                              const std::vector<dsi::Event> w0(events0.begin() + (long)a0, events0.begin() + (long)b0);
+                                              const std::vector<dsi::Event> w1(few.begin() + (long)a1, few.begin() + (long)b1);
+                                              process_1_depth_map(trajectory0, trajectory1, w0, w1, out_w, cam_a, cam_b, w.ts, 6, d, c, ix);
+                                              if (d.data != w.depth_map.data || ix.data != w.depth_cell_indices.data) seen = -100;
+                                          });
+            if (seen != 2) return 106;
+        }
         if (const char* out = std::getenv("DSI_TEST_NPY")) {  // for tests/test_cpp_adapter.py
             if (mapper_fused.dsi_.writeGridNpy(out) != 0) return 80;
             double sum = 0;
