@@ -299,7 +299,8 @@ inline dsi::Transformation process_1_depth_map(const LinearTrajectory& trajector
 // the running arg-max (dsi_mapper_depth_map_of_events): the depth maps are those of process_1(...) +
 // mapper_fused.getDepthMapFromDSI(...) before the filters, bit for bit (process_1_depth_map above is the one-window form).
 //
-// on_window(const dsi::WindowDepthMap&) is called once per window, in window order, from the calling thread.
+// on_window(const dsi::WindowDepthMap&) is called once per window, in window order, from the calling thread; with
+// options_depth_map it also carries the filtered outputs of main.cpp:281.
 namespace dsi {
 
 struct WindowDepthMap {
@@ -310,6 +311,10 @@ struct WindowDepthMap {
     size_t n_events[2] = {0, 0};      // events of the interval per camera (a camera with < 1024 votes nothing: :71-75)
     Image<float> depth_map, confidence_map;  // the raw arg-max (mapper_emvs_stereo.cpp:302-313), before the filters
     Image<uint8_t> depth_cell_indices;
+    // with options_depth_map: what main.cpp:281's getDepthMapFromDSI(depth_map, confidence_map, mask, options) returns for
+    // the window (adaptive threshold, masked median, border removal: mapper_emvs_stereo.cpp:390-437)
+    Image<float> filtered_depth_map, filtered_confidence_map;
+    Image<uint8_t> semidense_mask;
 };
 
 // events of a time-sorted vector with t_start <= ts <= t_stop: [begin, end)
@@ -336,7 +341,8 @@ inline size_t full_sequence_depth_maps(int device, const PinholeCameraModel& cam
                                        const LinearTrajectory& trajectory1, const std::vector<Event>& events0,
                                        const std::vector<Event>& events1, double start_time_s, double stop_time_s,
                                        double duration, double out_skip, bool forward_looking, int fusion_method,
-                                       OnWindow&& on_window, int depth = 2, double rv_pos = 0.0)
+                                       OnWindow&& on_window, int depth = 2, double rv_pos = 0.0,
+                                       const EMVS::OptionsDepthMap* options_depth_map = nullptr)
 {
     if (!(duration > 0) || !(out_skip > 0)) throw Error(DSI_ERR_INVALID, "full_sequence_depth_maps: duration and out_skip must be > 0");
     if (depth < 1) depth = 1;
@@ -405,6 +411,8 @@ inline size_t full_sequence_depth_maps(int device, const PinholeCameraModel& cam
         std::memcpy(s.w.confidence_map.data.data(), s.host[1], npix * sizeof(float));
         std::memcpy(s.w.depth_cell_indices.data.data(), s.host[2], npix);
         s.busy = false;
+        if (options_depth_map)  // the filters run on the arg-max the slot's mapper still holds on the device
+            s.out.filterDepthMap(s.w.filtered_depth_map, s.w.filtered_confidence_map, s.w.semidense_mask, *options_depth_map);
         on_window(static_cast<const WindowDepthMap&>(s.w));
     };
     const LinearTrajectory* trs[2] = {&trajectory0, &trajectory1};

@@ -500,6 +500,34 @@ int main()
                                               if (d.data != w.depth_map.data || ix.data != w.depth_cell_indices.data) seen = -100;
                                           });
             if (seen != 2) return 106;
+            // main.cpp:281: the filtered outputs of a window = filterDepthMap after process_1_depth_map on its events
+            {
+                EMVS::OptionsDepthMap opts;
+                opts.adaptive_threshold_c_ = 4.;
+                int bad = 0, n_w = 0;
+                dsi::full_sequence_depth_maps(
+                    0, cam, cam, dsi_shape, trajectory0, trajectory1, events0, events1, 0.1, 0.95, 0.4, 0.4, false, 2,
+                    [&](const dsi::WindowDepthMap& w) {
+                        ++n_w;
+                        size_t a0, b0, a1, b1;
+                        dsi::window_event_range(events0, w.t_start, w.t_stop, &a0, &b0);
+                        dsi::window_event_range(events1, w.t_start, w.t_stop, &a1, &b1);
+                        const std::vector<dsi::Event> w0(events0.begin() + (long)a0, events0.begin() + (long)b0);
+                        const std::vector<dsi::Event> w1(events1.begin() + (long)a1, events1.begin() + (long)b1);
+                        dsi::Image<float> d, c, fd, fc;
+                        dsi::Image<uint8_t> ix, mk;
+                        process_1_depth_map(trajectory0, trajectory1, w0, w1, out_w, cam_a, cam_b, w.ts, 2, d, c, ix);
+                        out_w.filterDepthMap(fd, fc, mk, opts);
+                        if (std::memcmp(fd.data.data(), w.filtered_depth_map.data.data(), fd.data.size() * sizeof(float)) != 0 ||
+                            fc.data != w.filtered_confidence_map.data || mk.data != w.semidense_mask.data)
+                            ++bad;
+                        size_t kept = 0;
+                        for (uint8_t v : mk.data) kept += v != 0;
+                        if (kept == 0) ++bad;  // a mask that keeps nothing would prove nothing
+                    },
+                    2, 0.0, &opts);
+                if (bad || n_w != 2) return 107;
+            }
         }
         if (const char* out = std::getenv("DSI_TEST_NPY")) {  // for tests/test_cpp_adapter.py
             if (mapper_fused.dsi_.writeGridNpy(out) != 0) return 80;
