@@ -46,12 +46,13 @@ from .engine import (  # noqa: F401
     library_path,
     load_library,
     packetize,
+    packetize_strided,
     pose_at,
 )
 
 __all__ = [
     "Comm", "allreduce_all", "depth_map_sharded_all", "depth_map_reduce_scattered_all", "Context", "Grid3D", "MapperEMVS", "ShapeDSI", "OptionsDepthMap", "EventBatch", "PinnedArray", "DsiError", "device_count",
-    "library_path", "load_library", "packetize", "pose_at", "PACKET_SIZE",
+    "library_path", "load_library", "packetize", "packetize_strided", "pose_at", "PACKET_SIZE",
     "FUSE_MIN", "FUSE_HM", "FUSE_GM", "FUSE_AM", "FUSE_RMS", "FUSE_MAX", "ACC_SUM", "ACC_INV_SUM", "ACC_LOG_SUM", "ACC_SQ_SUM", "ACC_MIN", "ACC_MAX", "ACC_GM_TREE",
     "REDUCE_SUM", "REDUCE_MIN", "REDUCE_MAX", "acc_reduce_op",
     "VOTE_AUTO", "VOTE_GLOBAL_ATOMIC", "VOTE_LDS_BANDS", "VOTE_FUSED_ARGMAX",

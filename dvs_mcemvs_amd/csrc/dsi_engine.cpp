@@ -1456,6 +1456,31 @@ int dsi_packetize(const double* ts, size_t n_events, const double* traj_times, c
     return DSI_OK;
 }
 
+int dsi_packetize_strided(const void* ts_first, size_t stride_bytes, size_t n_events, const double* traj_times,
+                          const double* traj_poses, size_t n_poses, const double* T_rv_w, uint32_t* packet_first, float* Rt,
+                          size_t* n_packets)
+{
+    REQUIRE(n_packets && T_rv_w && traj_times && traj_poses, DSI_ERR_INVALID, "null argument");
+    REQUIRE(n_events == 0 || ts_first, DSI_ERR_INVALID, "null timestamps");
+    REQUIRE(stride_bytes >= sizeof(double), DSI_ERR_INVALID, "stride of %zu bytes is smaller than a timestamp", stride_bytes);
+    REQUIRE(n_events < ((size_t)1 << 32), DSI_ERR_INVALID, "at most 2^32-1 events");
+    *n_packets = 0;
+    std::vector<uint32_t> first;
+    std::vector<float> rt;
+    const char* base = static_cast<const char*>(ts_first);
+    auto ts_of = [base, stride_bytes](size_t i) {
+        double t;
+        std::memcpy(&t, base + i * stride_bytes, sizeof t);  // (no alignment assumed)
+        return t;
+    };
+    if (!dsi::host::packetize_with(ts_of, n_events, traj_times, traj_poses, n_poses, dsi::host::Pose::from7(T_rv_w), &first, &rt))
+        return fail(DSI_ERR_TOO_FEW_EVENTS, "number of events (%zu) < packet size (%d)", n_events, DSI_PACKET_SIZE);
+    *n_packets = first.size();
+    if (packet_first && !first.empty()) std::memcpy(packet_first, first.data(), first.size() * sizeof(uint32_t));
+    if (Rt && !rt.empty()) std::memcpy(Rt, rt.data(), rt.size() * sizeof(float));
+    return DSI_OK;
+}
+
 int dsi_mapper_evaluate(dsi_mapper_t* m, const uint16_t* x, const uint16_t* y, const double* ts,
                         size_t n_events, const double* traj_times, const double* traj_poses, size_t n_poses,
                         const double* T_rv_w, size_t* n_voted)

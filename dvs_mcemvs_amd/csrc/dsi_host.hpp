@@ -132,9 +132,11 @@ inline void event_pose_Rt(const Pose& T_rv_w, const Pose& T_w_ev, float* Rt)
 
 // The while-loop of mapper_emvs_stereo.cpp:88-99: returns false when the reference
 // returns false (fewer events than one packet, :71-75).
-inline bool packetize(const double* ts, size_t n_events, const double* times, const double* poses,
-                      size_t n_poses, const Pose& T_rv_w, std::vector<uint32_t>* first,
-                      std::vector<float>* Rt)
+// ts_of(i): timestamp of event i (a plain array, or a field of an array of structs read in place)
+template <typename TsOf>
+inline bool packetize_with(TsOf ts_of, size_t n_events, const double* times, const double* poses,
+                           size_t n_poses, const Pose& T_rv_w, std::vector<uint32_t>* first,
+                           std::vector<float>* Rt)
 {
     constexpr size_t kPacket = 1024;
     first->clear();
@@ -143,7 +145,7 @@ inline bool packetize(const double* ts, size_t n_events, const double* times, co
     size_t cur = 0;
     while (cur + kPacket < n_events) {  // strict '<': a final exactly-full packet is dropped
         Pose T_w_ev;
-        if (!pose_at(times, poses, n_poses, ts[cur + kPacket / 2], &T_w_ev)) {
+        if (!pose_at(times, poses, n_poses, ts_of(cur + kPacket / 2), &T_w_ev)) {
             ++cur;  // :95-99 slide by one event and retry
             continue;
         }
@@ -153,6 +155,13 @@ inline bool packetize(const double* ts, size_t n_events, const double* times, co
         cur += kPacket;
     }
     return true;
+}
+
+inline bool packetize(const double* ts, size_t n_events, const double* times, const double* poses,
+                      size_t n_poses, const Pose& T_rv_w, std::vector<uint32_t>* first,
+                      std::vector<float>* Rt)
+{
+    return packetize_with([ts](size_t i) { return ts[i]; }, n_events, times, poses, n_poses, T_rv_w, first, Rt);
 }
 
 // ---------------------------------------------------------------------------------------------

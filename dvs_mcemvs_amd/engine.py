@@ -164,6 +164,7 @@ def load_library():
                                           C.c_size_t, f64p, szp]),
         "dsi_packetize": (C.c_int, [f64p, C.c_size_t, f64p, f64p, C.c_size_t, f64p, u32p, f32p,
                                     szp]),
+        "dsi_packetize_strided": (C.c_int, [vp, C.c_size_t, C.c_size_t, f64p, f64p, C.c_size_t, f64p, u32p, f32p, szp]),
         "dsi_pose_at": (C.c_int, [f64p, f64p, C.c_size_t, C.c_double, f64p]),
         "dsi_mapper_depth_map": (C.c_int, [vp, f32p, f32p, u8p]),
         "dsi_mapper_depth_map_of": (C.c_int, [vp, vp]),
@@ -1025,6 +1026,31 @@ def packetize(ts, trajectory, T_rv_w):
         return None
     _check(rc)
     return first[:n.value].copy(), Rt[:n.value].copy()
+
+
+def packetize_strided(ts_view, trajectory, T_rv_w):
+    """packetize() with the timestamps read where they lie: ts_view is a 1-D float64 view with any stride -- a field of
+    a structured array of events, say -- and is not copied (dsi_packetize_strided: one timestamp per packet is read)."""
+    if ts_view.dtype != np.float64 or ts_view.ndim != 1:
+        raise ValueError("packetize_strided: a 1-D float64 view is required")
+    n = int(ts_view.shape[0])
+    stride = int(ts_view.strides[0]) if n else 8
+    if stride < 8:
+        raise ValueError("packetize_strided: stride %d is smaller than a timestamp" % stride)
+    times, poses = trajectory
+    times, poses = _arr(times, np.float64), _arr(poses, np.float64).reshape(-1, 7)
+    T = _arr(T_rv_w, np.float64)
+    cap = n // PACKET_SIZE + 1
+    first = np.empty(cap, np.uint32)
+    Rt = np.empty((cap, 12), np.float32)
+    npk = C.c_size_t()
+    rc = load_library().dsi_packetize_strided(C.c_void_p(ts_view.ctypes.data if n else 0), stride, n, _ptr(times, C.c_double),
+                                              _ptr(poses, C.c_double), times.shape[0], _ptr(T, C.c_double),
+                                              _ptr(first, C.c_uint32), _ptr(Rt, C.c_float), C.byref(npk))
+    if rc == ERR_TOO_FEW_EVENTS:
+        return None
+    _check(rc)
+    return first[:npk.value].copy(), Rt[:npk.value].copy()
 
 
 def pose_at(trajectory, t):

@@ -39,7 +39,7 @@ extern "C" {
 #define DSI_API
 #endif
 
-#define DSI_ENGINE_ABI_VERSION 6
+#define DSI_ENGINE_ABI_VERSION 7
 #define DSI_PACKET_SIZE 1024 /* mapper_emvs_stereo.hpp:152 packet_size_ */
 
 typedef enum {
@@ -331,6 +331,13 @@ DSI_API int dsi_mapper_evaluate(dsi_mapper_t *m, const uint16_t *x, const uint16
 DSI_API int dsi_packetize(const double *ts, size_t n_events, const double *traj_times,
                   const double *traj_poses, size_t n_poses, const double *T_rv_w,
                   uint32_t *packet_first, float *Rt, size_t *n_packets);
+/* the same with the timestamps read where they lie in an array of structs (the reference holds
+ * std::vector<dvs_msgs::Event>, mapper_emvs_stereo.cpp:91: events[current_event_ + packet_size_/2].ts): event i's
+ * timestamp is the double at ts_first + i * stride_bytes.  Only one timestamp per packet is read (mapper_emvs_stereo.cpp:88-99),
+ * so a caller need not copy n_events doubles out of its structs first. */
+DSI_API int dsi_packetize_strided(const void *ts_first, size_t stride_bytes, size_t n_events, const double *traj_times,
+                          const double *traj_poses, size_t n_poses, const double *T_rv_w,
+                          uint32_t *packet_first, float *Rt, size_t *n_packets);
 /* LinearTrajectory::getPoseAt (trajectory.hpp:92-126); returns DSI_ERR_INVALID when
  * the reference returns false (no extrapolation). out = 7 doubles. */
 DSI_API int dsi_pose_at(const double *traj_times, const double *traj_poses, size_t n_poses, double t, double *out);

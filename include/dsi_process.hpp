@@ -24,8 +24,14 @@
 #ifndef DSI_PROCESS_HPP
 #define DSI_PROCESS_HPP
 
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <exception>
+#include <functional>
 #include <memory>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "dsi_engine.hpp"
@@ -137,7 +143,6 @@ inline dsi::Transformation process_1_depth_map_n(const LinearTrajectory* const* 
     dsi_mapper_t* ms[3] = {nullptr, nullptr, nullptr};
     dsi_batch_t* bs[3] = {nullptr, nullptr, nullptr};
     std::vector<uint16_t> xs, ys;
-    std::vector<double> tss;
     std::vector<uint32_t> first;
     std::vector<float> Rt;
     dsi_context_t* ctx = mapper_out.context();
@@ -147,17 +152,15 @@ inline dsi::Transformation process_1_depth_map_n(const LinearTrajectory* const* 
             const size_t ne = evs[c]->size();
             xs.resize(ne);
             ys.resize(ne);
-            tss.resize(ne);
             for (size_t i = 0; i < ne; ++i) {
                 xs[i] = (*evs[c])[i].x;
                 ys[i] = (*evs[c])[i].y;
-                tss[i] = (*evs[c])[i].ts;
             }
             first.assign(ne / DSI_PACKET_SIZE + 1, 0u);
             Rt.assign(12 * first.size(), 0.f);
             size_t np = 0;
-            const int rc = dsi_packetize(tss.data(), ne, trs[c]->times().data(), trs[c]->poses7().data(), trs[c]->times().size(),
-                                         T7, first.data(), Rt.data(), &np);
+            const int rc = dsi_packetize_strided(ne ? &(*evs[c])[0].ts : nullptr, sizeof(dsi::Event), ne, trs[c]->times().data(),
+                                                 trs[c]->poses7().data(), trs[c]->times().size(), T7, first.data(), Rt.data(), &np);
             if (rc == DSI_ERR_TOO_FEW_EVENTS) np = 0;  // evaluateDSI returns false: an all-zero DSI (mapper_emvs_stereo.cpp:71-75)
             else dsi::check(rc);
             dsi::check(dsi_batch_create(ctx, xs.data(), ys.data(), ne, first.data(), Rt.data(), np, &bs[c]));
@@ -210,24 +213,21 @@ inline dsi::Transformation process_1_exact_depth_map(const LinearTrajectory& tra
     };
     try {
         std::vector<uint16_t> xs, ys;
-        std::vector<double> tss;
         std::vector<uint32_t> first;
         std::vector<float> Rt;
         for (int c = 0; c < 2; ++c) {
             const size_t ne = evs[c]->size();
             xs.resize(ne);
             ys.resize(ne);
-            tss.resize(ne);
             for (size_t i = 0; i < ne; ++i) {
                 xs[i] = (*evs[c])[i].x;
                 ys[i] = (*evs[c])[i].y;
-                tss[i] = (*evs[c])[i].ts;
             }
             first.assign(ne / DSI_PACKET_SIZE + 1, 0u);
             Rt.assign(12 * first.size(), 0.f);
             size_t np = 0;
-            const int rc = dsi_packetize(tss.data(), ne, trs[c]->times().data(), trs[c]->poses7().data(), trs[c]->times().size(),
-                                         T7, first.data(), Rt.data(), &np);
+            const int rc = dsi_packetize_strided(ne ? &(*evs[c])[0].ts : nullptr, sizeof(dsi::Event), ne, trs[c]->times().data(),
+                                                 trs[c]->poses7().data(), trs[c]->times().size(), T7, first.data(), Rt.data(), &np);
             if (rc == DSI_ERR_TOO_FEW_EVENTS) np = 0;  // evaluateDSI returns false (mapper_emvs_stereo.cpp:71-75)
             else dsi::check(rc);
             dsi::check(dsi_batch_create(ctx, xs.data(), ys.data(), ne, first.data(), Rt.data(), np, &bs[c]));
@@ -317,6 +317,17 @@ struct WindowDepthMap {
     Image<uint8_t> semidense_mask;
 };
 
+// where the calling thread of full_sequence_depth_maps spent its time (milliseconds, summed over the windows)
+struct WindowStreamStats {
+    double wait_prepare_ms = 0;  // waiting for the two preparation threads
+    double wait_gpu_ms = 0;      // waiting for a slot's window to complete (dsi_mapper_fetch_wait)
+    double wait_upload_ms = 0;   // waiting for a slot's previous uploads before its staging is overwritten
+    double deliver_ms = 0;       // copying a window's maps out of the page-locked buffers, the filters, on_window
+    double submit_ms = 0;        // queueing uploads, kernels and the asynchronous fetch
+    double total_ms = 0;
+    size_t windows = 0;
+};
+
 // events of a time-sorted vector with t_start <= ts <= t_stop: [begin, end)
 // (a rosbag is cut at message granularity instead, data_loading.cpp:272-285: a few hundred events more)
 inline void window_event_range(const std::vector<Event>& ev, double t_start, double t_stop, size_t* begin, size_t* end)
@@ -335,15 +346,85 @@ inline void window_event_range(const std::vector<Event>& ev, double t_start, dou
     *end = lo;
 }
 
+// host threads that turn a window's array of structs into the engine's arrays and look up the packets' poses while the
+// calling thread hands a finished window to the caller and queues the next one
+class WindowPrepWorker {
+public:
+    WindowPrepWorker() : th_([this] { loop(); }) {}
+    ~WindowPrepWorker()
+    {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        th_.join();
+    }
+    WindowPrepWorker(const WindowPrepWorker&) = delete;
+    WindowPrepWorker& operator=(const WindowPrepWorker&) = delete;
+    void start(std::function<void()> job)
+    {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            job_ = std::move(job);
+            has_ = true;
+            done_ = false;
+        }
+        cv_.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> l(m_);
+        cv_.wait(l, [&] { return done_; });
+        if (err_) {
+            std::exception_ptr e = err_;
+            err_ = nullptr;
+            std::rethrow_exception(e);
+        }
+    }
+
+private:
+    void loop()
+    {
+        for (;;) {
+            std::unique_lock<std::mutex> l(m_);
+            cv_.wait(l, [&] { return has_ || stop_; });
+            if (stop_) return;
+            std::function<void()> job = std::move(job_);
+            has_ = false;
+            l.unlock();
+            try {
+                job();
+            } catch (...) {
+                err_ = std::current_exception();
+            }
+            l.lock();
+            done_ = true;
+            cv_.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::function<void()> job_;
+    bool has_ = false, done_ = true, stop_ = false;
+    std::exception_ptr err_ = nullptr;
+    std::thread th_;  // (last: the thread starts when every other member exists)
+};
+
 template <typename OnWindow>
 inline size_t full_sequence_depth_maps(int device, const PinholeCameraModel& cam0, const PinholeCameraModel& cam1,
                                        const EMVS::ShapeDSI& dsi_shape, const LinearTrajectory& trajectory0,
                                        const LinearTrajectory& trajectory1, const std::vector<Event>& events0,
                                        const std::vector<Event>& events1, double start_time_s, double stop_time_s,
                                        double duration, double out_skip, bool forward_looking, int fusion_method,
-                                       OnWindow&& on_window, int depth = 2, double rv_pos = 0.0,
-                                       const EMVS::OptionsDepthMap* options_depth_map = nullptr)
+                                       OnWindow&& on_window, int depth = 3, double rv_pos = 0.0,
+                                       const EMVS::OptionsDepthMap* options_depth_map = nullptr,
+                                       WindowStreamStats* stats = nullptr)
 {
+    using clock = std::chrono::steady_clock;
+    const clock::time_point t_call = clock::now();
+    WindowStreamStats st;
+    auto since = [](clock::time_point t0) { return std::chrono::duration<double, std::milli>(clock::now() - t0).count(); };
     if (!(duration > 0) || !(out_skip > 0)) throw Error(DSI_ERR_INVALID, "full_sequence_depth_maps: duration and out_skip must be > 0");
     if (depth < 1) depth = 1;
     struct Slot {
@@ -351,10 +432,14 @@ inline size_t full_sequence_depth_maps(int device, const PinholeCameraModel& cam
         EMVS::MapperEMVS m0, m1, out;
         dsi_batch_t* batch[2] = {nullptr, nullptr};
         void* host[3] = {nullptr, nullptr, nullptr};  // page-locked depth, confidence, indices
-        // page-locked staging of the window's inputs (asynchronous uploads read them until the window is done)
+        // page-locked staging of the window's inputs (asynchronous uploads read them until the window is done):
+        // x, y, packet_first, Rt per camera
         void* in[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
         size_t in_events[2] = {0, 0}, in_packets[2] = {0, 0};
-        WindowDepthMap w;
+        WindowDepthMap w;     // the window in flight (or just completed) in this slot
+        WindowDepthMap next;  // the window being prepared for it
+        size_t np[2] = {0, 0};
+        int prc[2] = {DSI_OK, DSI_OK};
         bool busy = false;
         Slot(int dev, const PinholeCameraModel& c0, const PinholeCameraModel& c1, const EMVS::ShapeDSI& sh)
             : ctx(dev), m0(ctx, c0, sh), m1(ctx, c1, sh), out(ctx, c0, sh) {}
@@ -398,80 +483,144 @@ inline size_t full_sequence_depth_maps(int device, const PinholeCameraModel& cam
         check(dsi_host_alloc(npix * sizeof(float), &s->host[1]));
         check(dsi_host_alloc(npix, &s->host[2]));
     }
-    auto deliver = [&](Slot& s) {
+    // the slot's window is complete on the device and in s.host: wait for it, release its inputs
+    auto complete = [&](Slot& s) {
+        const clock::time_point t0 = clock::now();
         check(dsi_mapper_fetch_wait(s.out.handle()));
+        st.wait_gpu_ms += since(t0);
         for (dsi_batch_t*& b : s.batch) {
             dsi_batch_destroy(b);
             b = nullptr;
         }
+        s.busy = false;
+    };
+    // ... and goes to the caller (s.w still describes it)
+    auto deliver = [&](Slot& s) {
+        const clock::time_point t0 = clock::now();
         s.w.depth_map = Image<float>(ny, nx);
         s.w.confidence_map = Image<float>(ny, nx);
         s.w.depth_cell_indices = Image<uint8_t>(ny, nx);
         std::memcpy(s.w.depth_map.data.data(), s.host[0], npix * sizeof(float));
         std::memcpy(s.w.confidence_map.data.data(), s.host[1], npix * sizeof(float));
         std::memcpy(s.w.depth_cell_indices.data.data(), s.host[2], npix);
-        s.busy = false;
         if (options_depth_map)  // the filters run on the arg-max the slot's mapper still holds on the device
             s.out.filterDepthMap(s.w.filtered_depth_map, s.w.filtered_confidence_map, s.w.semidense_mask, *options_depth_map);
         on_window(static_cast<const WindowDepthMap&>(s.w));
+        st.deliver_ms += since(t0);
     };
     const LinearTrajectory* trs[2] = {&trajectory0, &trajectory1};
     const std::vector<Event>* evs[2] = {&events0, &events1};
-    std::vector<double> tss;
-    size_t n_windows = 0;
-    // main.cpp:177 (the loop variable is accumulated, like there)
-    for (double interval_start = start_time_s; interval_start + duration <= stop_time_s; interval_start += out_skip) {
-        Slot& s = *slots[n_windows % slots.size()];
-        if (s.busy) deliver(s);
-        const double interval_stop = interval_start + duration;
+    std::vector<double> starts;  // main.cpp:177 (the loop variable is accumulated, like there)
+    for (double interval_start = start_time_s; interval_start + duration <= stop_time_s; interval_start += out_skip)
+        starts.push_back(interval_start);
+    const size_t n_windows = starts.size();
+    constexpr int kPrepSplit = 2;  // host threads per camera (a window's 500 k 24-byte events take one core 0.4-0.7 ms)
+    WindowPrepWorker workers[2 * kPrepSplit];
+    // prepare(i): window i's interval, reference view and event ranges, then the preparation threads fill the slot's
+    // INPUT staging.  That staging was last read by the uploads of the window the slot holds (window i - depth), which
+    // are long over -- they are waited for, not the window itself: its results are collected later, before submit(i).
+    auto prepare = [&](size_t i) {
+        Slot& s = *slots[i % slots.size()];
+        {
+            const clock::time_point t0 = clock::now();
+            for (dsi_batch_t* b : s.batch)
+                while (b && !dsi_batch_uploaded(b)) std::this_thread::yield();
+            st.wait_upload_ms += since(t0);
+        }
+        const double interval_start = starts[i], interval_stop = interval_start + duration;
         const double ts = forward_looking ? interval_stop : (interval_start + interval_stop) / 2;  // main.cpp:184-188
         Transformation T_w_l;
         if (!trajectory0.getPoseAt(ts, T_w_l)) throw Error(DSI_ERR_INVALID, "no pose at the reference timestamp of a window");
         Transformation baseline;
         baseline.t[0] = rv_pos;
-        s.w = WindowDepthMap{};
-        s.w.index = (int)n_windows;
-        s.w.t_start = interval_start;
-        s.w.t_stop = interval_stop;
-        s.w.ts = ts;
-        s.w.T_rv_w = inverse(T_w_l * baseline);  // process1.cpp:56-68
+        s.next = WindowDepthMap{};
+        s.next.index = (int)i;
+        s.next.t_start = interval_start;
+        s.next.t_stop = interval_stop;
+        s.next.ts = ts;
+        s.next.T_rv_w = inverse(T_w_l * baseline);  // process1.cpp:56-68
         double T7[7];
-        s.w.T_rv_w.to7(T7);
-        dsi_mapper_t* ms[2] = {s.m0.handle(), s.m1.handle()};
+        s.next.T_rv_w.to7(T7);
         for (int c = 0; c < 2; ++c) {
             size_t a = 0, b = 0;
             window_event_range(*evs[c], interval_start, interval_stop, &a, &b);
             const size_t ne = b - a;
-            s.w.n_events[c] = ne;
+            s.next.n_events[c] = ne;
             s.reserve_inputs(c, ne, ne / DSI_PACKET_SIZE + 1);
+            const Event* src = evs[c]->data() + a;
             uint16_t* xs = static_cast<uint16_t*>(s.in[c][0]);
             uint16_t* ys = static_cast<uint16_t*>(s.in[c][1]);
             uint32_t* first = static_cast<uint32_t*>(s.in[c][2]);
             float* Rt = static_cast<float*>(s.in[c][3]);
-            tss.resize(ne);
-            for (size_t i = 0; i < ne; ++i) {
-                const Event& e = (*evs[c])[a + i];
-                xs[i] = e.x;
-                ys[i] = e.y;
-                tss[i] = e.ts;
+            const LinearTrajectory* tr = trs[c];
+            size_t* np_c = &s.np[c];
+            int* rc_c = &s.prc[c];
+            for (int part = 0; part < kPrepSplit; ++part) {
+                const size_t k0 = ne * (size_t)part / kPrepSplit, k1 = ne * (size_t)(part + 1) / kPrepSplit;
+                workers[c * kPrepSplit + part].start([=] {
+                    for (size_t k = k0; k < k1; ++k) {
+                        xs[k] = src[k].x;
+                        ys[k] = src[k].y;
+                    }
+                    // (one timestamp per packet is read, in place: mapper_emvs_stereo.cpp:88-99)
+                    if (part == 0)
+                        *rc_c = dsi_packetize_strided(ne ? &src[0].ts : nullptr, sizeof(Event), ne, tr->times().data(),
+                                                      tr->poses7().data(), tr->times().size(), T7, first, Rt, np_c);
+                });
             }
-            size_t np = 0;
-            const int rc = dsi_packetize(tss.data(), ne, trs[c]->times().data(), trs[c]->poses7().data(), trs[c]->times().size(), T7,
-                                         first, Rt, &np);
-            if (rc == DSI_ERR_TOO_FEW_EVENTS) np = 0;  // evaluateDSI returns false: an all-zero DSI (mapper_emvs_stereo.cpp:71-75)
-            else check(rc);
-            check(dsi_batch_create_async(s.ctx.handle(), xs, ys, ne, first, Rt, np, &s.batch[c]));
+        }
+    };
+    auto submit = [&](Slot& s) {
+        const clock::time_point t0 = clock::now();
+        s.w = s.next;
+        dsi_mapper_t* ms[2] = {s.m0.handle(), s.m1.handle()};
+        for (int c = 0; c < 2; ++c) {
+            if (s.prc[c] == DSI_ERR_TOO_FEW_EVENTS) s.np[c] = 0;  // evaluateDSI returns false: an all-zero DSI (mapper_emvs_stereo.cpp:71-75)
+            else if (s.prc[c] != DSI_OK) throw Error(s.prc[c], "dsi_packetize failed for a window (preparation thread)");
+            check(dsi_batch_create_async(s.ctx.handle(), static_cast<uint16_t*>(s.in[c][0]), static_cast<uint16_t*>(s.in[c][1]),
+                                         s.w.n_events[c], static_cast<uint32_t*>(s.in[c][2]), static_cast<float*>(s.in[c][3]), s.np[c],
+                                         &s.batch[c]));
         }
         check(dsi_mapper_depth_map_of_events(s.out.handle(), ms, s.batch, 2, fusion_method));
         check(dsi_mapper_fetch_depth_map_async(s.out.handle(), static_cast<float*>(s.host[0]), static_cast<float*>(s.host[1]),
                                                static_cast<uint8_t*>(s.host[2])));
         s.busy = true;
-        ++n_windows;
+        st.submit_ms += since(t0);
+    };
+    auto wait_workers = [&]() {
+        const clock::time_point t0 = clock::now();
+        for (WindowPrepWorker& w : workers) w.wait();
+        st.wait_prepare_ms += since(t0);
+    };
+    // Three things run side by side: the preparation threads turn window i+1's events into the engine's arrays, the GPU
+    // works on windows i-1, i-2, ..., and this thread collects window i-depth from slot i's buffers, hands it to the caller
+    // and queues window i.  (With ONE slot the next window's staging is the current window's: everything is serial.)
+    const bool ahead = slots.size() >= 2;
+    if (n_windows) prepare(0);
+    for (size_t i = 0; i < n_windows; ++i) {
+        Slot& s = *slots[i % slots.size()];
+        wait_workers();
+        if (ahead && i + 1 < n_windows) prepare(i + 1);
+        if (s.busy) {  // the window this slot holds (s.w, s.host), before submit() replaces it
+            complete(s);
+            deliver(s);
+        }
+        submit(s);
+        if (!ahead && i + 1 < n_windows) prepare(i + 1);
     }
+    wait_workers();
     // the windows still in flight, oldest first
     for (size_t k = 0; k < slots.size(); ++k) {
         Slot& s = *slots[(n_windows + k) % slots.size()];
-        if (s.busy) deliver(s);
+        if (s.busy) {
+            complete(s);
+            deliver(s);
+        }
+    }
+    if (stats) {
+        st.total_ms = since(t_call);
+        st.windows = n_windows;
+        *stats = st;
     }
     return n_windows;
 }
@@ -671,17 +820,15 @@ inline dsi_batch_t* make_batch(dsi_context_t* ctx, const std::vector<Event>& ev,
 {
     const size_t ne = end - begin;
     std::vector<uint16_t> xs(ne), ys(ne);
-    std::vector<double> tss(ne);
     for (size_t i = 0; i < ne; ++i) {
         xs[i] = ev[begin + i].x;
         ys[i] = ev[begin + i].y;
-        tss[i] = ev[begin + i].ts;
     }
     std::vector<uint32_t> first(ne / DSI_PACKET_SIZE + 1, 0u);
     std::vector<float> Rt(12 * first.size(), 0.f);
     size_t np = 0;
-    const int rc = dsi_packetize(tss.data(), ne, tr.times().data(), tr.poses7().data(), tr.times().size(), T7, first.data(),
-                                 Rt.data(), &np);
+    const int rc = dsi_packetize_strided(ne ? &ev[begin].ts : nullptr, sizeof(Event), ne, tr.times().data(), tr.poses7().data(),
+                                         tr.times().size(), T7, first.data(), Rt.data(), &np);
     if (rc == DSI_ERR_TOO_FEW_EVENTS) np = 0;
     else check(rc);
     dsi_batch_t* b = nullptr;

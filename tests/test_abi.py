@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(built):
     lib = ctypes.CDLL(d.library_path())
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, "not exported: %s" % missing
-    assert lib.dsi_abi_version() == 6
+    assert lib.dsi_abi_version() == 7
     # the Python binding declares a signature for every exported entry point
     L = d.load_library()
     unbound = [s for s in syms if getattr(L, s).argtypes is None]
@@ -179,6 +179,30 @@ def test_host_packetize_matches_oracle(built):
     # no pose at all: true with zero packets (the reference returns true, votes nothing)
     got = d.packetize(ts, (times + 100.0, poses), rig["T_rv_w"])
     assert got is not None and got[0].shape[0] == 0
+
+
+def test_packetize_strided_reads_timestamps_in_place(built):
+    """dsi_packetize_strided (the C++ adapter's route: timestamps of a std::vector<Event> read where they lie) gives what
+    dsi_packetize gives on the copied-out timestamps, pose misses included."""
+    rig = syn.stereo_rig(7000, width=48, height=36, duration=0.3, seed=6)
+    x, y, ts = rig["events"][0]
+    times, poses = rig["trajectories"][0]
+    ev = np.zeros(ts.shape[0], dtype=np.dtype([("x", "<u2"), ("y", "<u2"), ("ts", "<f8"), ("p", "u1")], align=True))
+    assert ev.dtype.itemsize == 24                      # the layout of dsi::Event (include/dsi_engine.hpp)
+    ev["x"], ev["y"], ev["ts"] = x, y, ts
+    for n in (1023, 1024, 1025, 2049, 7000):
+        a = d.packetize(ts[:n], (times, poses), rig["T_rv_w"])
+        b = d.packetize_strided(ev["ts"][:n], (times, poses), rig["T_rv_w"])
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    keep = times > ts[800]
+    a = d.packetize(ts, (times[keep], poses[keep]), rig["T_rv_w"])
+    b = d.packetize_strided(ev["ts"], (times[keep], poses[keep]), rig["T_rv_w"])
+    assert a[0][0] % 1024 != 0 and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert d.packetize_strided(ev["ts"][:0], (times, poses), rig["T_rv_w"]) is None
+    with pytest.raises(ValueError):
+        d.packetize_strided(ts.astype(np.float32), (times, poses), rig["T_rv_w"])
 
 
 def test_argument_validation_without_gpu(built):

@@ -21,7 +21,7 @@ def build_exe():
         return
     pkg = os.path.join(ROOT, "dvs_mcemvs_amd")
     orc = os.path.join(ROOT, "oracle")
-    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", src, "-I" + os.path.join(ROOT, "include"), "-I" + orc,
+    cmd = ["g++", "-std=c++17", "-O2", "-pthread", "-Wall", "-Wextra", src, "-I" + os.path.join(ROOT, "include"), "-I" + orc,
            "-L" + pkg, "-ldsi_engine", "-L" + orc, "-ldsi_oracle", "-Wl,-rpath," + pkg, "-Wl,-rpath," + orc,
            "-Wl,-rpath,/opt/rocm/lib", "-o", EXE]
     subprocess.check_call(cmd)
@@ -59,7 +59,7 @@ def build_ref_types_exe():
     if os.path.exists(EXE_REF_TYPES) and all(os.path.getmtime(EXE_REF_TYPES) > os.path.getmtime(p) for p in deps):
         return
     pkg = os.path.join(ROOT, "dvs_mcemvs_amd")
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", src, "-I" + os.path.join(ROOT, "include"),
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", "-Wall", "-Wextra", src, "-I" + os.path.join(ROOT, "include"),
                            "-L" + pkg, "-ldsi_engine", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib", "-o",
                            EXE_REF_TYPES])
 
