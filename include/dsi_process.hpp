@@ -32,6 +32,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "dsi_engine.hpp"
@@ -411,8 +412,11 @@ private:
     std::thread th_;  // (last: the thread starts when every other member exists)
 };
 
+// devices: slot k (window k, k + depth, ...) lives on devices[k % devices.size()] -- windows are independent (fresh
+// mappers per window in the reference, main.cpp:262-275), so several GPUs of a node take them in turn, no collective
+// ("replicas"); depth >= devices.size() to use them all.
 template <typename OnWindow>
-inline size_t full_sequence_depth_maps(int device, const PinholeCameraModel& cam0, const PinholeCameraModel& cam1,
+inline size_t full_sequence_depth_maps(const std::vector<int>& devices, const PinholeCameraModel& cam0, const PinholeCameraModel& cam1,
                                        const EMVS::ShapeDSI& dsi_shape, const LinearTrajectory& trajectory0,
                                        const LinearTrajectory& trajectory1, const std::vector<Event>& events0,
                                        const std::vector<Event>& events1, double start_time_s, double stop_time_s,
@@ -427,6 +431,7 @@ inline size_t full_sequence_depth_maps(int device, const PinholeCameraModel& cam
     auto since = [](clock::time_point t0) { return std::chrono::duration<double, std::milli>(clock::now() - t0).count(); };
     if (!(duration > 0) || !(out_skip > 0)) throw Error(DSI_ERR_INVALID, "full_sequence_depth_maps: duration and out_skip must be > 0");
     if (depth < 1) depth = 1;
+    if (devices.empty()) throw Error(DSI_ERR_INVALID, "full_sequence_depth_maps: no device");
     struct Slot {
         Context ctx;
         EMVS::MapperEMVS m0, m1, out;
@@ -474,7 +479,7 @@ inline size_t full_sequence_depth_maps(int device, const PinholeCameraModel& cam
         }
     };
     std::vector<std::unique_ptr<Slot>> slots;
-    for (int k = 0; k < depth; ++k) slots.emplace_back(new Slot(device, cam0, cam1, dsi_shape));
+    for (int k = 0; k < depth; ++k) slots.emplace_back(new Slot(devices[(size_t)k % devices.size()], cam0, cam1, dsi_shape));
     int nx = 0, ny = 0, nz = 0;
     slots[0]->out.dsi_.getDimensions(&nx, &ny, &nz);
     const size_t npix = (size_t)nx * ny;
@@ -623,6 +628,22 @@ inline size_t full_sequence_depth_maps(int device, const PinholeCameraModel& cam
         *stats = st;
     }
     return n_windows;
+}
+
+// one GPU
+template <typename OnWindow>
+inline size_t full_sequence_depth_maps(int device, const PinholeCameraModel& cam0, const PinholeCameraModel& cam1,
+                                       const EMVS::ShapeDSI& dsi_shape, const LinearTrajectory& trajectory0,
+                                       const LinearTrajectory& trajectory1, const std::vector<Event>& events0,
+                                       const std::vector<Event>& events1, double start_time_s, double stop_time_s,
+                                       double duration, double out_skip, bool forward_looking, int fusion_method,
+                                       OnWindow&& on_window, int depth = 3, double rv_pos = 0.0,
+                                       const EMVS::OptionsDepthMap* options_depth_map = nullptr,
+                                       WindowStreamStats* stats = nullptr)
+{
+    return full_sequence_depth_maps(std::vector<int>{device}, cam0, cam1, dsi_shape, trajectory0, trajectory1, events0, events1,
+                                    start_time_s, stop_time_s, duration, out_skip, forward_looking, fusion_method,
+                                    std::forward<OnWindow>(on_window), depth, rv_pos, options_depth_map, stats);
 }
 
 }  // namespace dsi

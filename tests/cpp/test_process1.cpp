@@ -482,6 +482,20 @@ int main()
                     return 105;
                 }
             }
+            // the device-list form (slot k on devices[k % n]; here every slot on device 0) gives the same windows
+            {
+                std::vector<Got> again;
+                dsi::full_sequence_depth_maps(std::vector<int>{0, 0}, cam, cam, dsi_shape, trajectory0, trajectory1, events0, events1,
+                                              start, stop, duration, skip, false, 2,
+                                              [&](const dsi::WindowDepthMap& w) {
+                                                  again.push_back(Got{w.index, w.ts, w.n_events[0], w.n_events[1], w.depth_map.data,
+                                                                      w.confidence_map.data, w.depth_cell_indices.data});
+                                              },
+                                              4);
+                if (again.size() != 5) return 108;
+                for (int i = 0; i < 5; ++i)
+                    if (again[i].index != i || again[i].depth != runs[0][i].depth || again[i].idx != runs[0][i].idx) return 109;
+            }
             // forward-looking reference view (main.cpp:184-185) and a right camera that has too few events in the windows
             const std::vector<dsi::Event> few(events1.begin(), events1.begin() + 500);
             int seen = 0;
