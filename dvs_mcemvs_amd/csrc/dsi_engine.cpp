@@ -1716,17 +1716,20 @@ static int tie_exact_values(TieScratch& ts, dsi_mapper* m, const dsi_batch* b, c
         if (zlist.empty() || zlist.back() != z) zlist.push_back(z);
     }
     const size_t bitmap_words = (nvox + 31) / 32 + 1;
+    // behind the voxel bits: one bit per (plane, 8 x 8 tile) that holds a vote location reaching a contending voxel
+    const size_t tile_words = (size_t)dsi::tie_tile_words_of(m->geom.nx, m->geom.ny) * (size_t)m->geom.nz;
     HIP_TRY(ts.counters.reserve(4));
     HIP_TRY(ts.sv.reserve(sv.size()));
-    HIP_TRY(ts.bitmap.reserve(bitmap_words));
+    HIP_TRY(ts.bitmap.reserve(bitmap_words + tile_words));
     HIP_TRY(ts.zlist.reserve(zlist.size()));
     HIP_TRY(ts.exact.reserve(sv.size()));
     HIP_TRY(ts.gpu.reserve(sv.size()));
     HIP_TRY(ts.count.reserve(sv.size()));
     HIP_TRY(hipMemcpyAsync(ts.sv.p, sv.data(), sv.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(ts.zlist.p, zlist.data(), zlist.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(ts.bitmap.p, 0, bitmap_words * sizeof(uint32_t), st));
-    HIP_TRY(dsi::launch_tie_mark(st, ts.sv.p, (int)sv.size(), ts.bitmap.p));
+    HIP_TRY(hipMemsetAsync(ts.bitmap.p, 0, (bitmap_words + tile_words) * sizeof(uint32_t), st));
+    uint32_t* tiles = ts.bitmap.p + bitmap_words;
+    HIP_TRY(dsi::launch_tie_mark(st, ts.sv.p, (int)sv.size(), ts.bitmap.p, tiles, m->geom.nx, m->geom.ny));
     unsigned long long* d_hits_n = ts.counters.p + 2;
     unsigned cid_bits = 1;
     while (cid_bits < 32 && ((size_t)1 << cid_bits) < sv.size()) ++cid_bits;
@@ -1749,7 +1752,7 @@ static int tie_exact_values(TieScratch& ts, dsi_mapper* m, const dsi_batch* b, c
             HIP_TRY(ts.w2.reserve(cap));
             HIP_TRY(hipMemsetAsync(d_hits_n, 0, sizeof(unsigned long long), st));
             HIP_TRY(dsi::launch_tie_hits(st, m->xy.p, m->centers.p, m->planes_dev, m->geom, (int)np, ts.zlist.p, (int)zlist.size(),
-                                         ts.bitmap.p, ts.sv.p, (int)sv.size(), d_hits_n, ts.keys.p, ts.w.p, cap));
+                                         ts.bitmap.p, tiles, ts.sv.p, (int)sv.size(), d_hits_n, ts.keys.p, ts.w.p, cap));
             HIP_TRY(hipMemcpyAsync(&n_hits, d_hits_n, sizeof n_hits, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             REQUIRE(n_hits < ((unsigned long long)1 << 31), DSI_ERR_INVALID, "%llu votes to re-sum: too many voxels asked for", n_hits);

@@ -200,12 +200,13 @@ hipError_t launch_mean_square(hipStream_t s, const float* dsi, size_t n, double*
 // cap: nothing beyond cap is written), counters[1] = columns.  b == nullptr: the values of `a`; else op(a, b)
 hipError_t launch_tie_candidates(hipStream_t s, const float* a, const float* b, int op, int npix, int nz, float rel_gap,
                                  unsigned* counters, uint32_t* cand, uint32_t cap);
-hipError_t launch_tie_mark(hipStream_t s, const uint32_t* sv, int n, uint32_t* bitmap);
+int tie_tile_words_of(int nx, int ny);  // 32-bit words of tile bits per plane
+hipError_t launch_tie_mark(hipStream_t s, const uint32_t* sv, int n, uint32_t* bitmap, uint32_t* tiles, int nx, int ny);
 // every vote of the contending planes that lands on a marked voxel: keys[] <- (rank of the voxel among sv) << 32 | position of
 // the vote in the reference's loop over events (packet * 1024 + slot), wts[] <- the bilinear weight the reference adds
 // (cartesian3dgrid.h:261-270).  keys == nullptr: count only
 hipError_t launch_tie_hits(hipStream_t s, const float2* xy, const float* centers, const float* planes, const Geom& g, int np,
-                           const int* zlist, int nzl, const uint32_t* bitmap, const uint32_t* sv, int nsv,
+                           const int* zlist, int nzl, const uint32_t* bitmap, const uint32_t* tiles, const uint32_t* sv, int nsv,
                            unsigned long long* hit_counter, unsigned long long* keys, float* wts, unsigned long long cap);
 // (key, weight) pairs sorted by key on the device (rocPRIM radix sort over the low key_bits bits; dsi_tie_sort.hip).
 // tmp == nullptr: *tmp_bytes <- the scratch the sort needs

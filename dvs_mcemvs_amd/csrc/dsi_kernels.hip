@@ -3671,16 +3671,40 @@ __global__ __launch_bounds__(256) void k_tie_candidates(const float* __restrict_
         if (tie_value<OP>(a, b, (size_t)k * npix + p) >= thr) cand[base + j++] = (uint32_t)((size_t)k * npix + p);
 }
 
-__global__ __launch_bounds__(256) void k_tie_mark(const uint32_t* __restrict__ sv, int n, uint32_t* __restrict__ bitmap)
+// tiles: one bit per (plane, 8 x 8 pixel tile) that holds the integer location (xi, yi) of a vote which can reach a
+// contending voxel (x, y): xi in {x - 1, x}, yi in {y - 1, y} -- k_tie_hits looks its four voxels up only for those
+constexpr int kTieTile = 3;  // log2 of the tile side
+__host__ __device__ inline int tie_tiles_x(int nx) { return (nx + (1 << kTieTile) - 1) >> kTieTile; }
+__host__ __device__ inline int tie_tile_words(int nx, int ny)
+{
+    return (tie_tiles_x(nx) * ((ny + (1 << kTieTile) - 1) >> kTieTile) + 31) / 32;
+}
+
+__global__ __launch_bounds__(256) void k_tie_mark(const uint32_t* __restrict__ sv, int n, uint32_t* __restrict__ bitmap,
+                                                  uint32_t* __restrict__ tiles, int nx, int ny)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) atomicOr(&bitmap[sv[i] >> 5], 1u << (sv[i] & 31u));
+    if (i >= n) return;
+    const uint32_t v = sv[i];
+    atomicOr(&bitmap[v >> 5], 1u << (v & 31u));
+    if (!tiles) return;
+    const uint32_t npix = (uint32_t)nx * (uint32_t)ny;
+    const int z = (int)(v / npix), p = (int)(v - (uint32_t)z * npix), y = p / nx, x = p - y * nx;
+    const int tx = tie_tiles_x(nx), tw = tie_tile_words(nx, ny);
+    for (int dy = -1; dy <= 0; ++dy)
+        for (int dx = -1; dx <= 0; ++dx) {
+            const int xi = x + dx, yi = y + dy;
+            if (xi < 0 || yi < 0) continue;
+            const int t = (yi >> kTieTile) * tx + (xi >> kTieTile);
+            atomicOr(&tiles[(size_t)z * tw + (t >> 5)], 1u << (t & 31));
+        }
 }
 
 // block = (packet, group of kVgPlanes contending planes); thread t owns events t, t + 256, ... of the packet
 __global__ __launch_bounds__(256) void k_tie_hits(const float2* __restrict__ xy, const float* __restrict__ centers,
                                                   const float* __restrict__ planes, Geom g, const int* __restrict__ zlist,
                                                   int nzl, const uint32_t* __restrict__ bitmap,
+                                                  const uint32_t* __restrict__ tiles, int tile_words,
                                                   const uint32_t* __restrict__ sv, int nsv,
                                                   unsigned long long* __restrict__ hit_counter,
                                                   unsigned long long* __restrict__ keys, float* __restrict__ wts,
@@ -3692,6 +3716,7 @@ __global__ __launch_bounds__(256) void k_tie_hits(const float2* __restrict__ xy,
     // more than redoing the arithmetic.
     __shared__ unsigned s_count;
     __shared__ unsigned long long s_base;
+    extern __shared__ uint32_t s_tiles[];  // the tile bits of this block's planes (tile_words > 0)
     const int k = blockIdx.x;
     const int lbeg = blockIdx.y * kVgPlanes;
     const int lend = min(nzl, lbeg + kVgPlanes);
@@ -3701,19 +3726,34 @@ __global__ __launch_bounds__(256) void k_tie_hits(const float2* __restrict__ xy,
     for (int i = 0; i < 4; ++i) e[i] = xy[(size_t)k * kPacket + threadIdx.x + 256 * i];
     const float xmax = (float)(g.nx - 1), ymax = (float)(g.ny - 1);
     const size_t plane_sz = (size_t)g.nx * g.ny;
+    const int tiles_x = tie_tiles_x(g.nx);
     if (threadIdx.x == 0) s_count = 0u;
+    for (int i = threadIdx.x; i < (lend - lbeg) * tile_words; i += 256)
+        s_tiles[i] = tiles[(size_t)zlist[lbeg + i / tile_words] * tile_words + i % tile_words];
     __syncthreads();
+    // bit (l - lbeg) * 4 + i: event i of this thread passed the accept and tile tests on plane l in the first walk; the second
+    // walk redoes only those (a few per cent)
+    static_assert(kVgPlanes * 4 <= 32, "one bit per (plane of the block, event of the thread)");
+    uint32_t live = 0xffffffffu;
     for (int pass = 0; pass < 2; ++pass) {
+        uint32_t seen = 0u;
         for (int l = lbeg; l < lend; ++l) {
+            if (!((live >> ((l - lbeg) * 4)) & 0xfu)) continue;
             const int z = zlist[l];
             float a, bx, by, d;
             plane_coefficients(cx_, cy_, cz_, planes[z], g, a, bx, by, d);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
+                if (!((live >> ((l - lbeg) * 4 + i)) & 1u)) continue;
                 const float X = (e[i].x * a + bx) / d;  // mapper_emvs_stereo.cpp:194-195
                 const float Y = (e[i].y * a + by) / d;
                 if (!(X >= 0.f && Y >= 0.f && X < xmax && Y < ymax)) continue;  // cartesian3dgrid.h:255-259 (see vote_global)
                 const int xi = (int)X, yi = (int)Y;
+                if (tile_words) {  // a tile without a bit holds no vote that reaches a contending voxel
+                    const int t = (yi >> kTieTile) * tiles_x + (xi >> kTieTile);
+                    if (!((s_tiles[(l - lbeg) * tile_words + (t >> 5)] >> (t & 31)) & 1u)) continue;
+                }
+                seen |= 1u << ((l - lbeg) * 4 + i);
                 const float fx = X - (float)xi, fy = Y - (float)yi, fx1 = 1.f - fx, fy1 = 1.f - fy;
                 const float w[4] = {fx1 * fy1, fx * fy1, fx1 * fy, fx * fy};  // :261-270
                 const uint32_t v0 = (uint32_t)((size_t)z * plane_sz + (size_t)yi * g.nx + xi);
@@ -3740,6 +3780,7 @@ __global__ __launch_bounds__(256) void k_tie_hits(const float2* __restrict__ xy,
                 }
             }
         }
+        live = seen;
         __syncthreads();
         if (pass == 0) {
             if (threadIdx.x == 0) {
@@ -3770,11 +3811,29 @@ __global__ __launch_bounds__(64) void k_tie_sums(const unsigned long long* __res
         else
             hi = mid;
     }
+    const unsigned long long first = lo;
+    hi = n;  // first vote of the next voxel: the run's length is known before the additions, so their loads pipeline
+    const unsigned long long next = (unsigned long long)(c + 1) << 32;
+    while (lo < hi) {
+        const unsigned long long mid = (lo + hi) >> 1;
+        if (keys[mid] < next)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    const unsigned long long last = lo;
     float sum = 0.f;
-    uint32_t cnt = 0;
-    for (unsigned long long i = lo; i < n && (keys[i] >> 32) == (unsigned long long)c; ++i, ++cnt) sum += wts[i];
+    unsigned long long i = first;
+    for (; i + 8 <= last; i += 8) {
+        float w8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w8[j] = wts[i + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += w8[j];  // one by one, in order (no reassociation: -ffp-contract=off, no fast-math)
+    }
+    for (; i < last; ++i) sum += wts[i];
     exact[c] = sum;
-    count[c] = cnt;
+    count[c] = (uint32_t)(last - first);
     gpu[c] = grid[sv[c]];
 }
 
@@ -4437,20 +4496,25 @@ hipError_t launch_tie_candidates(hipStream_t s, const float* a, const float* b, 
     return hipExtGetLastError();
 }
 
-hipError_t launch_tie_mark(hipStream_t s, const uint32_t* sv, int n, uint32_t* bitmap)
+int tie_tile_words_of(int nx, int ny) { return tie_tile_words(nx, ny); }
+
+hipError_t launch_tie_mark(hipStream_t s, const uint32_t* sv, int n, uint32_t* bitmap, uint32_t* tiles, int nx, int ny)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_tie_mark, dim3((n + 255) / 256), dim3(256), 0, s, sv, n, bitmap);
+    hipLaunchKernelGGL(k_tie_mark, dim3((n + 255) / 256), dim3(256), 0, s, sv, n, bitmap, tiles, nx, ny);
     return hipExtGetLastError();
 }
 
 hipError_t launch_tie_hits(hipStream_t s, const float2* xy, const float* centers, const float* planes, const Geom& g, int np,
-                           const int* zlist, int nzl, const uint32_t* bitmap, const uint32_t* sv, int nsv,
+                           const int* zlist, int nzl, const uint32_t* bitmap, const uint32_t* tiles, const uint32_t* sv, int nsv,
                            unsigned long long* hit_counter, unsigned long long* keys, float* wts, unsigned long long cap)
 {
     if (np <= 0 || nzl <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_tie_hits, dim3(np, (nzl + kVgPlanes - 1) / kVgPlanes), dim3(256), 0, s, xy, centers, planes, g, zlist,
-                       nzl, bitmap, sv, nsv, hit_counter, keys, wts, cap);
+    // the tile bits of a block's planes sit in LDS; images too large for that (> 4 M pixels) go without the tile test
+    int tw = tiles ? tie_tile_words(g.nx, g.ny) : 0;
+    if ((size_t)tw * kVgPlanes * sizeof(uint32_t) > 48 * 1024) tw = 0;
+    hipLaunchKernelGGL(k_tie_hits, dim3(np, (nzl + kVgPlanes - 1) / kVgPlanes), dim3(256), (size_t)tw * kVgPlanes * sizeof(uint32_t), s,
+                       xy, centers, planes, g, zlist, nzl, bitmap, tiles, tw, sv, nsv, hit_counter, keys, wts, cap);
     return hipExtGetLastError();
 }
 

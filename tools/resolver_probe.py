@@ -1,0 +1,23 @@
+import sys, time
+sys.path.insert(0, ".")
+import numpy as np
+import dvs_mcemvs_amd as d
+from dvs_mcemvs_amd import synthetic as syn
+nx, ny, nz, ev = 346, 260, 100, 10_000_000
+rig = syn.stereo_rig(ev, width=nx, height=ny, t0=10.0, duration=0.5, seed=1234, n_points=5000)
+ctx = d.Context(0)
+shape = d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0)
+ms = [d.MapperEMVS(ctx, rig["cam"], shape) for _ in range(2)]
+bs = []
+for c in range(2):
+    first, Rt = d.packetize(rig["events"][c][2], rig["trajectories"][c], rig["T_rv_w"])
+    bs.append(d.EventBatch(ctx, rig["events"][c][0], rig["events"][c][1], Rt, first))
+    ms[c].evaluateDSI_batch(bs[c])
+fused = d.Grid3D(ctx, nx, ny, nz)
+for rep in range(3):
+    fused.setToFusionOf(ms[0].dsi_, ms[1].dsi_, d.FUSE_HM)
+    ms[0].computeDepthMap(fused)
+    ctx.synchronize()
+    t = time.perf_counter()
+    res = ms[0].resolveNearTies(ms, bs, d.FUSE_HM)
+    print("resolver wall %.1f ms" % (1e3 * (time.perf_counter() - t)), res)
