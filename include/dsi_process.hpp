@@ -32,6 +32,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -502,12 +503,17 @@ inline size_t full_sequence_depth_maps(const std::vector<int>& devices, const Pi
     // ... and goes to the caller (s.w still describes it)
     auto deliver = [&](Slot& s) {
         const clock::time_point t0 = clock::now();
-        s.w.depth_map = Image<float>(ny, nx);
-        s.w.confidence_map = Image<float>(ny, nx);
-        s.w.depth_cell_indices = Image<uint8_t>(ny, nx);
-        std::memcpy(s.w.depth_map.data.data(), s.host[0], npix * sizeof(float));
-        std::memcpy(s.w.confidence_map.data.data(), s.host[1], npix * sizeof(float));
-        std::memcpy(s.w.depth_cell_indices.data.data(), s.host[2], npix);
+        // (the slot's images keep their storage from window to window: one copy out of the page-locked buffers, no
+        //  allocation, no zero-fill)
+        auto fill = [&](auto& img, const void* src) {
+            using T = typename std::remove_reference<decltype(img.data)>::type::value_type;
+            img.rows = ny;
+            img.cols = nx;
+            img.data.assign(static_cast<const T*>(src), static_cast<const T*>(src) + npix);
+        };
+        fill(s.w.depth_map, s.host[0]);
+        fill(s.w.confidence_map, s.host[1]);
+        fill(s.w.depth_cell_indices, s.host[2]);
         if (options_depth_map)  // the filters run on the arg-max the slot's mapper still holds on the device
             s.out.filterDepthMap(s.w.filtered_depth_map, s.w.filtered_confidence_map, s.w.semidense_mask, *options_depth_map);
         on_window(static_cast<const WindowDepthMap&>(s.w));
@@ -577,7 +583,13 @@ inline size_t full_sequence_depth_maps(const std::vector<int>& devices, const Pi
     };
     auto submit = [&](Slot& s) {
         const clock::time_point t0 = clock::now();
-        s.w = s.next;
+        s.w.index = s.next.index;  // (the window's description; the images of s.w keep their storage)
+        s.w.t_start = s.next.t_start;
+        s.w.t_stop = s.next.t_stop;
+        s.w.ts = s.next.ts;
+        s.w.T_rv_w = s.next.T_rv_w;
+        s.w.n_events[0] = s.next.n_events[0];
+        s.w.n_events[1] = s.next.n_events[1];
         dsi_mapper_t* ms[2] = {s.m0.handle(), s.m1.handle()};
         for (int c = 0; c < 2; ++c) {
             if (s.prc[c] == DSI_ERR_TOO_FEW_EVENTS) s.np[c] = 0;  // evaluateDSI returns false: an all-zero DSI (mapper_emvs_stereo.cpp:71-75)
