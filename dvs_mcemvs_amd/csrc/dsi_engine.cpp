@@ -1375,7 +1375,8 @@ int dsi_batch_create_async(dsi_context_t* ctx, const uint16_t* x, const uint16_t
 int dsi_batch_uploaded(const dsi_batch_t* b)
 {
     if (!b || !b->ready) return 1;
-    return hipEventQuery(b->ready) == hipSuccess ? 1 : 0;
+    // (anything but "not ready" ends a caller's polling loop: a failed copy surfaces at the next synchronisation)
+    return hipEventQuery(b->ready) == hipErrorNotReady ? 0 : 1;
 }
 
 int dsi_host_alloc(size_t bytes, void** out)
