@@ -285,6 +285,80 @@ def test_event_pose_Rt_is_inverse_of_relative_pose():
     assert np.allclose(c_rv, expect, atol=1e-5)
 
 
+def test_pose_pipeline_against_scipy_rotations():
+    """Stage A's SE(3) arithmetic (quaternion products, inverse, the SO(3) log / exp of LinearTrajectory::getPoseAt,
+    trajectory.hpp:92-126, and the rotation matrix + translation of mapper_emvs_stereo.cpp:101-105) against a
+    third-party implementation nobody here wrote: scipy.spatial.transform.Rotation.  Random, LARGE rotations (up to
+    170 degrees between control poses, both quaternion signs) -- conventions (Hamilton product, w-first storage,
+    active rotation, T1 * T2 = (q1 q2, t1 + q1 t2)) that a small-angle test cannot tell apart.  The oracle and the
+    engine's host code (dsi_pose_at, dsi_packetize) are both checked."""
+    from scipy.spatial.transform import Rotation as R
+    import dvs_mcemvs_amd as d
+
+    rng = np.random.default_rng(42)
+
+    def rand_pose(max_angle=np.pi):
+        axis = rng.normal(size=3)
+        axis /= np.linalg.norm(axis)
+        ang = rng.uniform(0.05, max_angle)
+        q_xyzw = R.from_rotvec(axis * ang).as_quat()
+        q = np.array([q_xyzw[3], q_xyzw[0], q_xyzw[1], q_xyzw[2]])     # our storage: w, x, y, z
+        if rng.uniform() < 0.5:
+            q = -q                                                     # the other sign of the same rotation
+        return np.concatenate([rng.uniform(-3, 3, 3), q])
+
+    def rot(p):
+        return R.from_quat([p[4], p[5], p[6], p[3]])                   # scipy storage: x, y, z, w
+
+    for _ in range(200):
+        T0 = rand_pose()
+        # second control pose: T0 composed with a relative rotation of up to 170 degrees
+        rel = rand_pose(np.deg2rad(170))
+        r1 = rot(T0) * rot(rel)
+        q1 = r1.as_quat()
+        T1 = np.concatenate([T0[:3] + rot(T0).apply(rel[:3]), [q1[3], q1[0], q1[1], q1[2]]])
+        times = np.array([1.0, 3.0])
+        poses = np.stack([T0, T1])
+        t = rng.uniform(1.0, 3.0)
+        delta = (t - 1.0) / 2.0
+        # getPoseAt: T0 * exp(delta * log(T0^-1 T1)); minkindr's log / exp treat the translation linearly
+        r_rel = rot(T0).inv() * rot(T1)
+        t_rel = rot(T0).inv().apply(T1[:3] - T0[:3])
+        r_t = rot(T0) * R.from_rotvec(delta * r_rel.as_rotvec())
+        p_t = T0[:3] + rot(T0).apply(delta * t_rel)
+        for got in (orc.pose_at(times, poses, t), d.pose_at((times, poses), t)):
+            assert got is not None
+            assert np.allclose(got[:3], p_t, atol=1e-12)
+            assert abs(np.linalg.norm(got[3:]) - 1.0) < 1e-12
+            assert (rot(got) * r_t.inv()).magnitude() < 1e-12           # the same rotation, whatever the sign
+        # T_ev_rv = (T_rv_w * T_w_ev)^-1 as (R row-major, t) in float
+        T_rv_w = rand_pose()
+        T_w_ev = np.concatenate([p_t, [r_t.as_quat()[3], *r_t.as_quat()[:3]]])
+        r_c = rot(T_rv_w) * r_t
+        p_c = T_rv_w[:3] + rot(T_rv_w).apply(p_t)
+        R_inv, t_inv = r_c.inv().as_matrix(), -r_c.inv().apply(p_c)
+        Rt = orc.event_pose_Rt(T_rv_w, T_w_ev)
+        assert np.allclose(Rt[:9].reshape(3, 3), R_inv, atol=2e-7) and np.allclose(Rt[9:], t_inv, atol=2e-6)
+    # the packets of a whole camera: every Rt of dsi_packetize against scipy's interpolation at the packet's middle event
+    rig = syn.stereo_rig(6000, width=40, height=30, duration=0.3, seed=8)
+    x, y, ts = rig["events"][0]
+    times, poses = rig["trajectories"][0]
+    first, Rts = d.packetize(ts, (times, poses), rig["T_rv_w"])
+    assert first.shape[0] >= 4
+    for k in range(first.shape[0]):
+        t = ts[first[k] + 512]
+        i = int(np.searchsorted(times, t, side="right"))              # std::map::upper_bound (trajectory.hpp:98)
+        T0, T1 = poses[i - 1], poses[i]
+        delta = (t - times[i - 1]) / (times[i] - times[i - 1])
+        r_rel = rot(T0).inv() * rot(T1)
+        r_t = rot(T0) * R.from_rotvec(delta * r_rel.as_rotvec())
+        p_t = T0[:3] + rot(T0).apply(delta * rot(T0).inv().apply(T1[:3] - T0[:3]))
+        r_c = rot(rig["T_rv_w"]) * r_t
+        p_c = rig["T_rv_w"][:3] + rot(rig["T_rv_w"]).apply(p_t)
+        assert np.allclose(Rts[k][:9].reshape(3, 3), r_c.inv().as_matrix(), atol=2e-7)
+        assert np.allclose(Rts[k][9:], -r_c.inv().apply(p_c), atol=2e-6)
+
+
 def _ulp(x, y):
     return np.abs(x.view(np.int32).astype(np.int64) - y.view(np.int32).astype(np.int64))
 
