@@ -27,6 +27,22 @@ def pose_mul(a, b):
     return np.concatenate([t, [w, x, y, z]])
 
 
+def apply_transformation_right(trajectory, T):
+    """TrajectoryBase::applyTransformationRight (trajectory.hpp:57-63): every control pose becomes pose * T -- how
+    main.cpp:199-216 turns the recorded poses into a camera's (hand-eye calibration, then the inverse extrinsics of the
+    other cameras).  trajectory = (times, poses[n][7]); returns a new one."""
+    times, poses = trajectory
+    poses = np.asarray(poses, np.float64).reshape(-1, 7)
+    return np.asarray(times, np.float64), np.stack([pose_mul(p, T) for p in poses])
+
+
+def apply_transformation_left(trajectory, T):
+    """TrajectoryBase::applyTransformationLeft (trajectory.hpp:65-71): every control pose becomes T * pose."""
+    times, poses = trajectory
+    poses = np.asarray(poses, np.float64).reshape(-1, 7)
+    return np.asarray(times, np.float64), np.stack([pose_mul(T, p) for p in poses])
+
+
 def reference_view_process1(trajectory_left, ts, rv_pos=0.0):
     """process1.cpp:56-68: T_w_rv = T_w_l(ts) * baseline(rv_pos along x); returns T_rv_w."""
     T_w_l = E.pose_at(trajectory_left, ts)

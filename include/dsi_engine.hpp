@@ -230,6 +230,48 @@ private:
 
 }  // namespace dsi
 
+namespace dsi {
+
+// T_a * T_b and T^-1 for (translation, unit quaternion w,x,y,z) -- the two minkindr operations the
+// callers need to place the reference view (process1.cpp:56-68, process2.cpp:79-81)
+inline void quat_rotate(const double* q, const double* v, double* out)
+{
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    const double ux = 2 * (y * v[2] - z * v[1]), uy = 2 * (z * v[0] - x * v[2]), uz = 2 * (x * v[1] - y * v[0]);
+    out[0] = v[0] + w * ux + (y * uz - z * uy);
+    out[1] = v[1] + w * uy + (z * ux - x * uz);
+    out[2] = v[2] + w * uz + (x * uy - y * ux);
+}
+
+inline Transformation operator*(const Transformation& a, const Transformation& b)
+{
+    Transformation o;
+    const double *p = a.q, *r = b.q;
+    o.q[0] = p[0] * r[0] - p[1] * r[1] - p[2] * r[2] - p[3] * r[3];
+    o.q[1] = p[0] * r[1] + p[1] * r[0] + p[2] * r[3] - p[3] * r[2];
+    o.q[2] = p[0] * r[2] + p[2] * r[0] + p[3] * r[1] - p[1] * r[3];
+    o.q[3] = p[0] * r[3] + p[3] * r[0] + p[1] * r[2] - p[2] * r[1];
+    double rt[3];
+    quat_rotate(a.q, b.t, rt);
+    for (int i = 0; i < 3; ++i) o.t[i] = a.t[i] + rt[i];
+    return o;
+}
+
+inline Transformation inverse(const Transformation& T)
+{
+    Transformation o;
+    o.q[0] = T.q[0];
+    o.q[1] = -T.q[1];
+    o.q[2] = -T.q[2];
+    o.q[3] = -T.q[3];
+    double rt[3];
+    quat_rotate(o.q, T.t, rt);
+    for (int i = 0; i < 3; ++i) o.t[i] = -rt[i];
+    return o;
+}
+
+}  // namespace dsi
+
 // trajectory.hpp:81-128
 class LinearTrajectory {
 public:
@@ -267,6 +309,31 @@ public:
         typedef typename std::decay<decltype(T.getPosition())>::type Pos;
         T = PoseT(Rot(D.q[0], D.q[1], D.q[2], D.q[3]), Pos(D.t[0], D.t[1], D.t[2]));
         return true;
+    }
+    // TrajectoryBase::applyTransformationRight / Left (trajectory.hpp:57-71): every control pose becomes pose * T / T * pose
+    // -- how main.cpp:203-216 turns the recorded poses into the left camera's (hand-eye) and the other cameras' (extrinsics)
+    void applyTransformationRight(const dsi::Transformation& T)
+    {
+        for (size_t i = 0; i < times_.size(); ++i) (dsi::Transformation::from7(&poses_[7 * i]) * T).to7(&poses_[7 * i]);
+    }
+    void applyTransformationLeft(const dsi::Transformation& T)
+    {
+        for (size_t i = 0; i < times_.size(); ++i) (T * dsi::Transformation::from7(&poses_[7 * i])).to7(&poses_[7 * i]);
+    }
+    // ... with the reference's pose type (geometry_utils::Transformation)
+    template <typename PoseT>
+    auto applyTransformationRight(const PoseT& T) -> decltype(T.getRotation(), void())
+    {
+        double p[7];
+        dsi::to_pose7(T, p);
+        applyTransformationRight(dsi::Transformation::from7(p));
+    }
+    template <typename PoseT>
+    auto applyTransformationLeft(const PoseT& T) -> decltype(T.getRotation(), void())
+    {
+        double p[7];
+        dsi::to_pose7(T, p);
+        applyTransformationLeft(dsi::Transformation::from7(p));
     }
     size_t getNumControlPoses() const { return times_.size(); }
     const std::vector<double>& times() const { return times_; }

@@ -40,43 +40,7 @@
 
 namespace dsi {
 
-// T_a * T_b and T^-1 for (translation, unit quaternion w,x,y,z) -- the two minkindr operations the
-// callers need to place the reference view (process1.cpp:56-68, process2.cpp:79-81)
-inline void quat_rotate(const double* q, const double* v, double* out)
-{
-    const double w = q[0], x = q[1], y = q[2], z = q[3];
-    const double ux = 2 * (y * v[2] - z * v[1]), uy = 2 * (z * v[0] - x * v[2]), uz = 2 * (x * v[1] - y * v[0]);
-    out[0] = v[0] + w * ux + (y * uz - z * uy);
-    out[1] = v[1] + w * uy + (z * ux - x * uz);
-    out[2] = v[2] + w * uz + (x * uy - y * ux);
-}
-
-inline Transformation operator*(const Transformation& a, const Transformation& b)
-{
-    Transformation o;
-    const double *p = a.q, *r = b.q;
-    o.q[0] = p[0] * r[0] - p[1] * r[1] - p[2] * r[2] - p[3] * r[3];
-    o.q[1] = p[0] * r[1] + p[1] * r[0] + p[2] * r[3] - p[3] * r[2];
-    o.q[2] = p[0] * r[2] + p[2] * r[0] + p[3] * r[1] - p[1] * r[3];
-    o.q[3] = p[0] * r[3] + p[3] * r[0] + p[1] * r[2] - p[2] * r[1];
-    double rt[3];
-    quat_rotate(a.q, b.t, rt);
-    for (int i = 0; i < 3; ++i) o.t[i] = a.t[i] + rt[i];
-    return o;
-}
-
-inline Transformation inverse(const Transformation& T)
-{
-    Transformation o;
-    o.q[0] = T.q[0];
-    o.q[1] = -T.q[1];
-    o.q[2] = -T.q[2];
-    o.q[3] = -T.q[3];
-    double rt[3];
-    quat_rotate(o.q, T.t, rt);
-    for (int i = 0; i < 3; ++i) o.t[i] = -rt[i];
-    return o;
-}
+// (T_a * T_b and inverse(T) live in dsi_engine.hpp, next to dsi::Transformation)
 
 inline void fuseTwoGrids(Grid3D& dst, const Grid3D& g, int method, const char* what)
 {

@@ -215,9 +215,59 @@ static int check_camera_of()
     return 0;
 }
 
+// main.cpp:199-216: the recorded poses become the left camera's (hand-eye calibration) and the right camera's (extrinsics)
+// by TrajectoryBase::applyTransformationRight (trajectory.hpp:57-63), with the reference's pose type.  Host-only.
+int check_trajectory_transformations()
+{
+    std::map<ros::Time, geometry_utils::Transformation> interval_poses;
+    const double c = std::cos(0.35), s_ = std::sin(0.35);  // every control pose: rotation by 0.7 rad about y, x = 0.4 t
+    for (int k = 0; k <= 6; ++k)
+        interval_poses[ros::Time(0.5 * k)] =
+            geometry_utils::Transformation(kindr::minimal::RotationQuaternion(c, 0, s_, 0), kindr::minimal::Position(0.2 * k, 0, 1));
+    const geometry_utils::Transformation T_hand_eye(kindr::minimal::RotationQuaternion(std::cos(0.1), std::sin(0.1), 0, 0),
+                                                    kindr::minimal::Position(0.01, -0.02, 0.03));
+    const geometry_utils::Transformation T_extr(kindr::minimal::RotationQuaternion(1, 0, 0, 0), kindr::minimal::Position(-0.6, 0, 0));
+    LinearTrajectory trajectory0 = LinearTrajectory(interval_poses);   // main.cpp:199
+    trajectory0.applyTransformationRight(T_hand_eye);                  // :202
+    LinearTrajectory trajectory1 = LinearTrajectory(interval_poses);   // :204
+    trajectory1.applyTransformationRight(T_hand_eye);                  // :205
+    trajectory1.applyTransformationRight(T_extr.inverse());            // :207
+    LinearTrajectory left = LinearTrajectory(interval_poses);
+    left.applyTransformationLeft(T_extr);
+    // at a control time the interpolated pose IS the control pose: compare with the products formed by the pose type itself
+    const double t = 1.0;
+    const geometry_utils::Transformation P = interval_poses[ros::Time(t)];
+    const geometry_utils::Transformation want0 = P * T_hand_eye, want1 = P * T_hand_eye * T_extr.inverse(), wantL = T_extr * P;
+    const geometry_utils::Transformation* wants[3] = {&want0, &want1, &wantL};
+    const LinearTrajectory* trs[3] = {&trajectory0, &trajectory1, &left};
+    for (int i = 0; i < 3; ++i) {
+        geometry_utils::Transformation got;
+        if (!trs[i]->getPoseAt(ros::Time(t), got)) return 40 + i;
+        double a[7], b[7];
+        dsi::to_pose7(got, a);
+        dsi::to_pose7(*wants[i], b);
+        for (int k = 0; k < 7; ++k)
+            if (std::fabs(a[k] - b[k]) > 1e-12) {
+                std::printf("trajectory %d component %d: %.15g vs %.15g\n", i, k, a[k], b[k]);
+                return 50 + i;
+            }
+    }
+    // the right camera sits 0.6 m along the left camera's +x (T_extr^-1 applied on the right = in the camera frame)
+    dsi::Transformation l, r;
+    if (!trajectory0.getPoseAt(1.25, l) || !trajectory1.getPoseAt(1.25, r)) return 60;
+    double base[3] = {r.t[0] - l.t[0], r.t[1] - l.t[1], r.t[2] - l.t[2]}, x_axis[3];
+    const double ex[3] = {1, 0, 0};
+    dsi::quat_rotate(l.q, ex, x_axis);
+    for (int k = 0; k < 3; ++k)
+        if (std::fabs(base[k] - 0.6 * x_axis[k]) > 1e-12) return 61;
+    std::printf("applyTransformationRight / Left with the reference's pose type: OK\n");
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     if (argc > 1 && std::string(argv[1]) == "--camera-of") return check_camera_of();
+    if (argc > 1 && std::string(argv[1]) == "--trajectory") return check_trajectory_transformations();
     try {
         const int W = 80, H = 60;
         const image_geometry::PinholeCameraModel cam0(W, H, 70.0, 70.0, 40.0, 30.0), cam1 = cam0;

@@ -91,3 +91,13 @@ def test_camera_of_honours_the_distortion_model(built):
     r = subprocess.run([EXE_REF_TYPES, "--camera-of"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "OK" in r.stdout
+
+
+def test_trajectory_transformations_with_the_reference_pose_type(built):
+    """main.cpp:199-216: LinearTrajectory(interval_poses) + applyTransformationRight(T_hand_eye) +
+    applyTransformationRight(T_extr.inverse()) (TrajectoryBase, trajectory.hpp:57-71) compile and compute pose * T with
+    the reference's pose type; applyTransformationLeft likewise.  Host-only."""
+    build_ref_types_exe()
+    r = subprocess.run([EXE_REF_TYPES, "--trajectory"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OK" in r.stdout

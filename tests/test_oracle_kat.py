@@ -339,6 +339,18 @@ def test_pose_pipeline_against_scipy_rotations():
         R_inv, t_inv = r_c.inv().as_matrix(), -r_c.inv().apply(p_c)
         Rt = orc.event_pose_Rt(T_rv_w, T_w_ev)
         assert np.allclose(Rt[:9].reshape(3, 3), R_inv, atol=2e-7) and np.allclose(Rt[9:], t_inv, atol=2e-6)
+    # the callers' pose algebra (process.pose_mul, pose_inverse, TrajectoryBase::applyTransformationRight / Left)
+    from dvs_mcemvs_amd import process as proc
+    for _ in range(50):
+        A, B = rand_pose(), rand_pose()
+        AB = proc.pose_mul(A, B)
+        assert np.allclose(AB[:3], A[:3] + rot(A).apply(B[:3]), atol=1e-12)
+        assert (rot(AB) * (rot(A) * rot(B)).inv()).magnitude() < 1e-12
+        Ai = syn.pose_inverse(A)
+        assert np.allclose(proc.pose_mul(A, Ai)[:3], 0, atol=1e-12) and rot(proc.pose_mul(A, Ai)).magnitude() < 1e-12
+        tr = (np.array([0.0, 1.0]), np.stack([A, B]))
+        right, left = proc.apply_transformation_right(tr, B), proc.apply_transformation_left(tr, B)
+        assert np.allclose(right[1][0], proc.pose_mul(A, B)) and np.allclose(left[1][0], proc.pose_mul(B, A))
     # the packets of a whole camera: every Rt of dsi_packetize against scipy's interpolation at the packet's middle event
     rig = syn.stereo_rig(6000, width=40, height=30, duration=0.3, seed=8)
     x, y, ts = rig["events"][0]
