@@ -335,6 +335,19 @@ public:
         dsi::to_pose7(T, p);
         applyTransformationLeft(dsi::Transformation::from7(p));
     }
+    // TrajectoryBase::getFirstControlPose / getLastControlPose (trajectory.hpp:28-38)
+    void getFirstControlPose(dsi::Transformation* T, double* t) const
+    {
+        if (times_.empty()) throw dsi::Error(DSI_ERR_INVALID, "empty trajectory");
+        *t = times_.front();
+        *T = dsi::Transformation::from7(&poses_[0]);
+    }
+    void getLastControlPose(dsi::Transformation* T, double* t) const
+    {
+        if (times_.empty()) throw dsi::Error(DSI_ERR_INVALID, "empty trajectory");
+        *t = times_.back();
+        *T = dsi::Transformation::from7(&poses_[7 * (times_.size() - 1)]);
+    }
     size_t getNumControlPoses() const { return times_.size(); }
     const std::vector<double>& times() const { return times_; }
     const std::vector<double>& poses7() const { return poses_; }

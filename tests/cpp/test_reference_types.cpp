@@ -260,6 +260,13 @@ int check_trajectory_transformations()
     dsi::quat_rotate(l.q, ex, x_axis);
     for (int k = 0; k < 3; ++k)
         if (std::fabs(base[k] - 0.6 * x_axis[k]) > 1e-12) return 61;
+    {
+        dsi::Transformation T0, T1;
+        double t0 = -1, t1 = -1;
+        left.getFirstControlPose(&T0, &t0);
+        left.getLastControlPose(&T1, &t1);
+        if (t0 != 0.0 || t1 != 3.0 || left.getNumControlPoses() != 7 || std::fabs(T1.t[0] - T0.t[0] - 1.2) > 1e-12) return 62;
+    }
     std::printf("applyTransformationRight / Left with the reference's pose type: OK\n");
     return 0;
 }
