@@ -491,11 +491,20 @@ struct ShapeDSI {  // mapper_emvs_stereo.hpp:40-65
     float fov_ = 0.f;
 };
 
-struct OptionsDepthMap {  // mapper_emvs_stereo.hpp:68-82 (fields the extraction reads)
+struct OptionsDepthMap {  // mapper_emvs_stereo.hpp:68-82
+    // the fields the extraction reads
     int adaptive_threshold_kernel_size_ = 5;
     double adaptive_threshold_c_ = 5.;
     double max_confidence = 0.;
     int median_filter_size_ = 5;
+    // the fields main.cpp:163-171 also sets: carried for source compatibility -- they steer file output on the host
+    // (save_*, full_sequence) and the reference view along the baseline (rv_pos: process1.cpp:63, the rv_pos argument of
+    // process_1 / process_1_depth_map / full_sequence_depth_maps in dsi_process.hpp)
+    bool full_sequence = false;
+    bool save_conf_stats = false;
+    bool save_mono = false;
+    bool save_dsi = false;
+    double rv_pos = 0.;
 };
 
 typedef LinearTrajectory TrajectoryType;

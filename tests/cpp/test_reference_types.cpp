@@ -261,6 +261,23 @@ int check_trajectory_transformations()
     for (int k = 0; k < 3; ++k)
         if (std::fabs(base[k] - 0.6 * x_axis[k]) > 1e-12) return 61;
     {
+        // main.cpp:159-171, spelled as there
+        const int FLAGS_dimX = 0, FLAGS_dimY = 0, FLAGS_dimZ = 100;
+        const double FLAGS_min_depth = 0.3, FLAGS_max_depth = 5.0, FLAGS_fov_deg = 0.0;
+        EMVS::ShapeDSI dsi_shape(FLAGS_dimX, FLAGS_dimY, FLAGS_dimZ, FLAGS_min_depth, FLAGS_max_depth, FLAGS_fov_deg);
+        EMVS::OptionsDepthMap opts_depth_map;
+        opts_depth_map.max_confidence = 0;
+        opts_depth_map.adaptive_threshold_kernel_size_ = 5;
+        opts_depth_map.adaptive_threshold_c_ = 7;
+        opts_depth_map.median_filter_size_ = 5;
+        opts_depth_map.full_sequence = true;
+        opts_depth_map.save_conf_stats = false;
+        opts_depth_map.save_mono = false;
+        opts_depth_map.rv_pos = 0.0;
+        opts_depth_map.save_dsi = false;
+        if (dsi_shape.dimZ_ != 100 || opts_depth_map.adaptive_threshold_c_ != 7) return 63;
+    }
+    {
         dsi::Transformation T0, T1;
         double t0 = -1, t1 = -1;
         left.getFirstControlPose(&T0, &t0);
