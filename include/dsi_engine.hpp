@@ -12,7 +12,8 @@
 //   dvs_msgs::Event                      -> dsi::Event {x, y, ts (seconds), polarity}
 //   geometry_utils::Transformation       -> dsi::Transformation {t[3], q[4] = w,x,y,z}
 //   image_geometry::PinholeCameraModel   -> dsi::PinholeCameraModel {width,height,fx,fy,cx,cy,lut}
-//   cv::Mat (CV_32F / CV_8U)             -> dsi::Image<float> / dsi::Image<uint8_t>
+//   cv::Mat (CV_32F / CV_8U)             -> cv::Mat itself (anything with create / ptr<T> / isContinuous / release, see
+//                                           image_create below), or dsi::Image<float> / dsi::Image<uint8_t>
 // Where the reference glog-CHECK-aborts or throws std::out_of_range this adapter throws
 // dsi::Error (carrying the C status code).
 #pragma once
@@ -72,7 +73,7 @@ struct PinholeCameraModel {
 };
 
 template <typename T>
-struct Image {  // stands in for a single-channel cv::Mat
+struct Image {  // a single-channel image of T when the caller has no cv::Mat
     int rows = 0, cols = 0;
     std::vector<T> data;
     Image() = default;
@@ -80,6 +81,74 @@ struct Image {  // stands in for a single-channel cv::Mat
     T& at(int y, int x) { return data[(size_t)y * cols + x]; }
     const T& at(int y, int x) const { return data[(size_t)y * cols + x]; }
 };
+
+// How the image-typed OUTPUTS of the path (Grid3D::collapseMaxZSlice, cartesian3dgrid.h:207; MapperEMVS::getDepthMapFromDSI,
+// mapper_emvs_stereo.hpp:108-109) are written into the caller's image type -- the reference's is cv::Mat.  Every such
+// member of this header is a template over the image type and goes through these three customisation points:
+//   image_create<T>(img, rows, cols)  make img a rows x cols single-channel image of T, return its first pixel
+//                                     (rows * cols contiguous elements)
+//   image_data<T>(img)                first pixel of an existing image of T
+//   image_release(img)                make img empty (cv::Mat() / Image<T>())
+// Defaults: dsi::Image<T>, and any type with OpenCV's Mat members create(rows, cols, type), ptr<T>(row),
+// isContinuous(), release() -- i.e. cv::Mat itself, with no OpenCV header needed here: the depth codes are the
+// constants of <opencv2/core/hal/interface.h> (CV_8U 0, CV_32F 5; a single channel's type IS its depth code).
+// Overload them (in the image type's namespace, or in namespace dsi before this header) for anything else.
+template <typename T> struct cv_depth;
+template <> struct cv_depth<uint8_t> { enum { value = 0 }; };  // CV_8U
+template <> struct cv_depth<float> { enum { value = 5 }; };    // CV_32F
+
+template <typename T>
+inline T* image_create(Image<T>& img, int rows, int cols)
+{
+    img = Image<T>(rows, cols);
+    return img.data.data();
+}
+template <typename T, typename ImgT>
+inline auto image_create(ImgT& img, int rows, int cols)
+    -> decltype(img.create(rows, cols, 0), img.isContinuous(), img.template ptr<T>(0))
+{
+    img.create(rows, cols, (int)cv_depth<T>::value);  // cv::Mat::create: a fresh matrix is continuous
+    if (!img.isContinuous()) throw Error(DSI_ERR_INVALID, "image_create: the image type returned non-contiguous rows");
+    return img.template ptr<T>(0);
+}
+template <typename T>
+inline T* image_data(Image<T>& img)
+{
+    return img.data.data();
+}
+template <typename T, typename ImgT>
+inline auto image_data(ImgT& img) -> decltype(img.isContinuous(), img.template ptr<T>(0))
+{
+    if (!img.isContinuous()) throw Error(DSI_ERR_INVALID, "image_data: non-contiguous image");
+    return img.template ptr<T>(0);
+}
+template <typename T>
+inline void image_release(Image<T>& img)
+{
+    img = Image<T>();
+}
+template <typename ImgT>
+inline auto image_release(ImgT& img) -> decltype(img.release(), void())
+{
+    img.release();
+}
+
+// Customisation point for depth_map_dense, the 5th argument of getDepthMapFromDSI (mapper_emvs_stereo.cpp:430-436):
+//     cv::Mat inpaint_mask = 1 - mask;
+//     cv::inpaint(depth_cell_indices_filtered, inpaint_mask, depth_cell_indices_inpainted, 3, cv::INPAINT_TELEA);
+// Telea's fast-marching inpainting is OpenCV arithmetic (photo module) and stays on the host side of the boundary, like
+// the rectification of fisheye cameras above.  A maintainer with OpenCV adds, in namespace cv or in namespace dsi
+// before this header,
+//     inline bool inpaint_depth_cell_indices(const cv::Mat& filtered, const cv::Mat& inpaint_mask, cv::Mat& inpainted)
+//     { cv::inpaint(filtered, inpaint_mask, inpainted, 3, cv::INPAINT_TELEA); return true; }
+// and getDepthMapFromDSI then fills depth_map_dense with convertDepthIndicesToValues of the result (:436).  The default
+// returns false: depth_map_dense is left EMPTY (image_release), never a guess.
+template <typename ImgT>
+inline bool inpaint_depth_cell_indices(const ImgT& /*filtered u8*/, const ImgT& /*inpaint_mask u8 = 1 - mask*/,
+                                       ImgT& /*inpainted u8*/)
+{
+    return false;
+}
 
 // One GPU + one stream; shared by every Grid3D / MapperEMVS created from it.
 class Context {
@@ -422,14 +491,17 @@ public:
     void finalize(int mode, int n) { dsi::check(dsi_grid_finalize(h_, mode, n)); }
     void allReduce(dsi::Comm& comm, int op) { dsi::check(dsi_grid_allreduce(comm.handle(), h_, op)); }
 
-    // cartesian3dgrid.cpp:115-137
-    void collapseMaxZSlice(dsi::Image<float>* max_val, dsi::Image<uint8_t>* max_pos) const
+    // void collapseMaxZSlice(cv::Mat* max_val, cv::Mat* max_pos) const (cartesian3dgrid.h:207, cartesian3dgrid.cpp:115-137):
+    // max_val becomes dimY x dimX CV_32F, max_pos dimY x dimX CV_8U ("Max 256 depth layers", :120).  Any image type the
+    // dsi::image_create customisation point can write: cv::Mat (both arguments), dsi::Image<float> / <uint8_t>.
+    template <typename ValImg, typename PosImg>
+    void collapseMaxZSlice(ValImg* max_val, PosImg* max_pos) const
     {
         int nx, ny, nz;
         getDimensions(&nx, &ny, &nz);
-        *max_val = dsi::Image<float>(ny, nx);
-        *max_pos = dsi::Image<uint8_t>(ny, nx);
-        dsi::check(dsi_grid_collapse_max_z(h_, max_val->data.data(), max_pos->data.data()));
+        float* val = dsi::image_create<float>(*max_val, ny, nx);
+        uint8_t* pos = dsi::image_create<uint8_t>(*max_pos, ny, nx);
+        dsi::check(dsi_grid_collapse_max_z(h_, val, pos));
     }
     // cartesian3dgrid.cpp:164-174
     double computeMeanSquare() const
@@ -575,62 +647,88 @@ public:
         return true;
     }
 
-    // The device part of getDepthMapFromDSI (mapper_emvs_stereo.cpp:339-437): arg-max over Z
-    // (:368) and convertDepthIndicesToValues (:302-313) on the raw indices.  The adaptive
-    // threshold / median / inpaint post-filters stay on the host (OpenCV) and are fed from
-    // confidence_map and depth_cell_indices exactly as in the reference.
-    void getDepthMapFromDSI(dsi::Image<float>& depth_map, dsi::Image<float>& confidence_map,
-                            dsi::Image<uint8_t>& depth_cell_indices)
+    // The device part of getDepthMapFromDSI (mapper_emvs_stereo.cpp:339-437) WITHOUT its filters: arg-max over Z
+    // (:368) and convertDepthIndicesToValues (:302-313) on the raw indices -- the map SURVEY 8(a) A11/A12 and the
+    // "depth map equal to the CPU reference" statement are about.  Not a member of the reference (it keeps
+    // depth_cell_indices local); hence its own name's third argument is the index map, not a mask.
+    template <typename DepthImg, typename ConfImg, typename IdxImg>
+    void getDepthMapFromDSI(DepthImg& depth_map, ConfImg& confidence_map, IdxImg& depth_cell_indices)
     {
         int nx, ny, nz;
         dsi_.getDimensions(&nx, &ny, &nz);
-        depth_map = dsi::Image<float>(ny, nx);
-        confidence_map = dsi::Image<float>(ny, nx);
-        depth_cell_indices = dsi::Image<uint8_t>(ny, nx);
-        dsi::check(dsi_mapper_depth_map(h_, depth_map.data.data(), confidence_map.data.data(),
-                                        depth_cell_indices.data.data()));
+        float* depth = dsi::image_create<float>(depth_map, ny, nx);
+        float* conf = dsi::image_create<float>(confidence_map, ny, nx);
+        uint8_t* idx = dsi::image_create<uint8_t>(depth_cell_indices, ny, nx);
+        dsi::check(dsi_mapper_depth_map(h_, depth, conf, idx));
     }
 
-    // getDepthMapFromDSI(depth_map, confidence_map, mask, options) (mapper_emvs_stereo.cpp:339-437)
-    // on the device: arg-max, conf(0,0) = max_confidence + normalisation, Gaussian adaptive
-    // threshold, masked Huang median, removeMaskBoundary, index -> depth (inpainting excluded).
-    // grid: the DSI to extract from (the reference calls this on whichever mapper holds it).
-    void getDepthMapFromDSI(dsi::Image<float>& depth_map, dsi::Image<float>& confidence_map,
-                            dsi::Image<uint8_t>& mask, const OptionsDepthMap& options_depth_map,
-                            const Grid3D* grid = nullptr)
+    // void getDepthMapFromDSI(cv::Mat& depth_map, cv::Mat& confidence_map, cv::Mat& mask, const OptionsDepthMap&,
+    //                         int method = -1)                                   mapper_emvs_stereo.hpp:108, .cpp:331-335
+    // void getDepthMapFromDSI(cv::Mat& depth_map, cv::Mat& confidence_map, cv::Mat& mask, const OptionsDepthMap&,
+    //                         cv::Mat& depth_map_dense, int method = -1)         mapper_emvs_stereo.hpp:109, .cpp:338-437
+    // on the device, from the mapper's OWN dsi_ like the reference (process1.cpp:208-222, process2.cpp:123-299,
+    // process5.cpp:258, main.cpp:389-417 compile as spelled there): arg-max (:368), conf(0,0) = max_confidence +
+    // normalisation (:393-397), Gaussian adaptive threshold (:403-409), masked Huang median (:420-423),
+    // removeMaskBoundary (:426-427), index -> depth of the filtered indices (:435).  Outputs as the reference leaves
+    // them: depth_map CV_32F, confidence_map CV_32F (element (0,0) overwritten), mask CV_8U in {0, 1}.
+    // method: the reference's switch (:348-368) takes 0..4 to the focus-based collapses (collapseZSliceByLocalVar ...,
+    // never selected by any caller: every call site passes the default) and everything else to collapseMaxZSlice;
+    // 0..4 are refused with dsi::Error (DSI_ERR_BAD_OP) -- SURVEY 2 marks them out of scope -- anything else is the arg-max.
+    // depth_map_dense: see dsi::inpaint_depth_cell_indices above -- filled when the caller supplies OpenCV's inpainting,
+    // otherwise left empty.
+    template <typename DepthImg, typename ConfImg, typename MaskImg>
+    void getDepthMapFromDSI(DepthImg& depth_map, ConfImg& confidence_map, MaskImg& mask,
+                            const OptionsDepthMap& options_depth_map, int method = -1)
     {
-        int nx, ny, nz;
-        dsi_.getDimensions(&nx, &ny, &nz);
-        depth_map = dsi::Image<float>(ny, nx);
-        confidence_map = dsi::Image<float>(ny, nx);
-        mask = dsi::Image<uint8_t>(ny, nx);
-        dsi_depthmap_options_t o{};
-        o.adaptive_threshold_kernel_size = options_depth_map.adaptive_threshold_kernel_size_;
-        o.adaptive_threshold_c = options_depth_map.adaptive_threshold_c_;
-        o.median_filter_size = options_depth_map.median_filter_size_;
-        o.max_confidence = options_depth_map.max_confidence;
-        dsi::check(dsi_mapper_get_depth_map_from_dsi(h_, grid ? grid->handle() : nullptr, &o, depth_map.data.data(),
-                                                     confidence_map.data.data(), mask.data.data(), nullptr));
+        extract(nullptr, depth_map, confidence_map, mask, options_depth_map, (MaskImg*)nullptr, (DepthImg*)nullptr, method);
+    }
+    template <typename DepthImg, typename ConfImg, typename MaskImg, typename DenseImg,
+              typename = typename std::enable_if<!std::is_pointer<DenseImg>::value && !std::is_arithmetic<DenseImg>::value>::type>
+    void getDepthMapFromDSI(DepthImg& depth_map, ConfImg& confidence_map, MaskImg& mask,
+                            const OptionsDepthMap& options_depth_map, DenseImg& depth_map_dense, int method = -1)
+    {
+        MaskImg idx_filtered;
+        extract(nullptr, depth_map, confidence_map, mask, options_depth_map, &idx_filtered, &depth_map_dense, method);
+    }
+    // the same for a DSI other than the mapper's own (not in the reference, which copies the DSI into a mapper first)
+    template <typename DepthImg, typename ConfImg, typename MaskImg>
+    void getDepthMapFromDSI(DepthImg& depth_map, ConfImg& confidence_map, MaskImg& mask,
+                            const OptionsDepthMap& options_depth_map, const Grid3D* grid)
+    {
+        extract(grid, depth_map, confidence_map, mask, options_depth_map, (MaskImg*)nullptr, (DepthImg*)nullptr, -1);
     }
 
     // The filters of getDepthMapFromDSI (mapper_emvs_stereo.cpp:390-437) on the raw depth map this mapper already
     // holds on the device -- after dsi::process_1_depth_map, which votes, fuses and takes the arg-max without ever
-    // writing the DSI the reference would call getDepthMapFromDSI on.  Same outputs as the overload above.
-    void filterDepthMap(dsi::Image<float>& depth_map, dsi::Image<float>& confidence_map, dsi::Image<uint8_t>& mask,
-                        const OptionsDepthMap& options_depth_map)
+    // writing the DSI the reference would call getDepthMapFromDSI on.  Same outputs as the overloads above.
+    template <typename DepthImg, typename ConfImg, typename MaskImg>
+    void filterDepthMap(DepthImg& depth_map, ConfImg& confidence_map, MaskImg& mask, const OptionsDepthMap& options_depth_map)
     {
         int nx, ny, nz;
         dsi_.getDimensions(&nx, &ny, &nz);
-        depth_map = dsi::Image<float>(ny, nx);
-        confidence_map = dsi::Image<float>(ny, nx);
-        mask = dsi::Image<uint8_t>(ny, nx);
-        dsi_depthmap_options_t o{};
-        o.adaptive_threshold_kernel_size = options_depth_map.adaptive_threshold_kernel_size_;
-        o.adaptive_threshold_c = options_depth_map.adaptive_threshold_c_;
-        o.median_filter_size = options_depth_map.median_filter_size_;
-        o.max_confidence = options_depth_map.max_confidence;
-        dsi::check(dsi_mapper_filter_depth_map(h_, &o, depth_map.data.data(), confidence_map.data.data(),
-                                               mask.data.data(), nullptr));
+        float* depth = dsi::image_create<float>(depth_map, ny, nx);
+        float* conf = dsi::image_create<float>(confidence_map, ny, nx);
+        uint8_t* mk = dsi::image_create<uint8_t>(mask, ny, nx);
+        const dsi_depthmap_options_t o = options_of(options_depth_map);
+        dsi::check(dsi_mapper_filter_depth_map(h_, &o, depth, conf, mk, nullptr));
+    }
+
+    // MapperEMVS::convertDepthIndicesToValues (mapper_emvs_stereo.cpp:302-313) on host images: depth = cellIndexToDepth(index)
+    template <typename IdxImg, typename DepthImg>
+    void convertDepthIndicesToValues(IdxImg& depth_cell_indices, DepthImg& depth_map)
+    {
+        int nx, ny, nz;
+        dsi_.getDimensions(&nx, &ny, &nz);
+        int dim_z = 0;
+        dsi::check(dsi_mapper_full_depths(h_, nullptr, &dim_z));
+        std::vector<float> z((size_t)dim_z);
+        dsi::check(dsi_mapper_full_depths(h_, z.data(), nullptr));
+        const uint8_t* idx = dsi::image_data<uint8_t>(depth_cell_indices);
+        float* depth = dsi::image_create<float>(depth_map, ny, nx);
+        for (size_t i = 0; i < (size_t)nx * ny; ++i) {
+            if ((int)idx[i] >= dim_z) throw dsi::Error(DSI_ERR_INVALID, "convertDepthIndicesToValues: index beyond dimZ");
+            depth[i] = z[idx[i]];
+        }
     }
 
     std::vector<float> depthPlanes() const
@@ -649,6 +747,43 @@ public:
     std::string name;  // mapper_emvs_stereo.hpp:117
 
 private:
+    static dsi_depthmap_options_t options_of(const OptionsDepthMap& options_depth_map)
+    {
+        dsi_depthmap_options_t o{};
+        o.adaptive_threshold_kernel_size = options_depth_map.adaptive_threshold_kernel_size_;
+        o.adaptive_threshold_c = options_depth_map.adaptive_threshold_c_;
+        o.median_filter_size = options_depth_map.median_filter_size_;
+        o.max_confidence = options_depth_map.max_confidence;
+        return o;
+    }
+    template <typename DepthImg, typename ConfImg, typename MaskImg, typename DenseImg>
+    void extract(const Grid3D* grid, DepthImg& depth_map, ConfImg& confidence_map, MaskImg& mask,
+                 const OptionsDepthMap& options_depth_map, MaskImg* idx_filtered, DenseImg* depth_map_dense, int method)
+    {
+        if (method >= 0 && method <= 4)
+            throw dsi::Error(DSI_ERR_BAD_OP, "getDepthMapFromDSI: method " + std::to_string(method) +
+                                                 " is one of the focus-based collapses (collapseZSliceByLocalVar / "
+                                                 "LocalMeanSquare / GradMag / LaplacianMag / DoG, mapper_emvs_stereo.cpp:350-364), "
+                                                 "which this engine does not provide; pass the default (-1): collapseMaxZSlice");
+        int nx, ny, nz;
+        dsi_.getDimensions(&nx, &ny, &nz);
+        float* depth = dsi::image_create<float>(depth_map, ny, nx);
+        float* conf = dsi::image_create<float>(confidence_map, ny, nx);
+        uint8_t* mk = dsi::image_create<uint8_t>(mask, ny, nx);
+        uint8_t* filtered = idx_filtered ? dsi::image_create<uint8_t>(*idx_filtered, ny, nx) : nullptr;
+        const dsi_depthmap_options_t o = options_of(options_depth_map);
+        dsi::check(dsi_mapper_get_depth_map_from_dsi(h_, grid ? grid->handle() : nullptr, &o, depth, conf, mk, filtered));
+        if (!depth_map_dense) return;
+        // mapper_emvs_stereo.cpp:430-436
+        MaskImg inpaint_mask, inpainted;
+        uint8_t* im = dsi::image_create<uint8_t>(inpaint_mask, ny, nx);
+        for (size_t i = 0; i < (size_t)nx * ny; ++i) im[i] = (uint8_t)(1 - mk[i]);
+        using dsi::inpaint_depth_cell_indices;  // the default; an overload for MaskImg found by ADL wins over it
+        if (inpaint_depth_cell_indices(*idx_filtered, inpaint_mask, inpainted))
+            convertDepthIndicesToValues(inpainted, *depth_map_dense);
+        else
+            dsi::image_release(*depth_map_dense);
+    }
     template <typename CamT>
     static dsi::PinholeCameraModel convert(const CamT& cam)
     {

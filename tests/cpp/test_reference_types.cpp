@@ -17,7 +17,11 @@
 //   exit 0: ok      exit 3: no GPU      else: failure
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <map>
+#include <memory>
+#include <sstream>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -93,6 +97,12 @@ namespace geometry_utils {
 typedef kindr::minimal::QuatTransformation Transformation;  // geometry_utils.hpp:13
 }
 
+// OpenCV's depth codes are macros (<opencv2/core/hal/interface.h>)
+#define CV_8U 0
+#define CV_32F 5
+#define CV_8UC1 CV_8U
+#define CV_32FC1 CV_32F
+
 namespace cv {
 struct Size {
     int width = 0, height = 0;
@@ -102,7 +112,88 @@ struct Point2d {
     Point2d() = default;
     Point2d(double x_, double y_) : x(x_), y(y_) {}
 };
+// cv::Mat, single channel: the members the reference's call sites and the adapter's customisation points use
+// (rows, cols, type(), at<T>(), ptr<T>(), create, release, isContinuous, empty, Mat(rows, cols, type); copies share
+// the pixels like OpenCV's reference-counted header).  at<T>() and ptr<T>() check the element type like a debug
+// build of OpenCV does -- a float written into a CV_8U image fails here, not silently.
+class Mat {
+public:
+    int rows = 0, cols = 0;
+    Mat() = default;
+    Mat(int r, int c, int type) { create(r, c, type); }
+    void create(int r, int c, int type)
+    {
+        if (type != CV_8U && type != CV_32F) throw std::runtime_error("cv::Mat look-alike: type not CV_8U / CV_32F");
+        if (buf_ && r == rows && c == cols && type == type_) return;  // cv::Mat::create keeps a matching allocation
+        rows = r;
+        cols = c;
+        type_ = type;
+        buf_ = std::make_shared<std::vector<unsigned char>>((size_t)r * c * elemSize());
+    }
+    void release()
+    {
+        buf_.reset();
+        rows = cols = 0;
+    }
+    int type() const { return type_; }
+    size_t elemSize() const { return type_ == CV_32F ? 4 : 1; }
+    bool isContinuous() const { return true; }
+    bool empty() const { return !buf_ || rows == 0 || cols == 0; }
+    template <typename T>
+    T* ptr(int row = 0)
+    {
+        check<T>();
+        return reinterpret_cast<T*>(buf_->data()) + (size_t)row * cols;
+    }
+    template <typename T>
+    const T* ptr(int row = 0) const
+    {
+        check<T>();
+        return reinterpret_cast<const T*>(buf_->data()) + (size_t)row * cols;
+    }
+    template <typename T>
+    T& at(int y, int x)
+    {
+        if (y < 0 || y >= rows || x < 0 || x >= cols) throw std::out_of_range("cv::Mat::at");
+        return ptr<T>(y)[x];
+    }
+    template <typename T>
+    const T& at(int y, int x) const
+    {
+        if (y < 0 || y >= rows || x < 0 || x >= cols) throw std::out_of_range("cv::Mat::at");
+        return ptr<T>(y)[x];
+    }
+
+private:
+    template <typename T>
+    void check() const
+    {
+        if (!buf_) throw std::runtime_error("cv::Mat look-alike: empty matrix");
+        if (sizeof(T) != elemSize()) throw std::runtime_error("cv::Mat look-alike: element type does not match type()");
+    }
+    int type_ = CV_8U;
+    std::shared_ptr<std::vector<unsigned char>> buf_;
+};
+// What a maintainer with OpenCV adds for depth_map_dense (include/dsi_engine.hpp, dsi::inpaint_depth_cell_indices):
+//     cv::inpaint(filtered, inpaint_mask, inpainted, 3, cv::INPAINT_TELEA); return true;
+// OpenCV does not exist in this image, so a closed form stands in for Telea's inpainting: a masked-out pixel takes the
+// filtered index of the nearest kept pixel to its left in the row (0 if none).  The test then checks that
+// getDepthMapFromDSI's 5th argument is convertDepthIndicesToValues of whatever this hook returns
+// (mapper_emvs_stereo.cpp:430-436).
+inline bool inpaint_depth_cell_indices(const Mat& filtered, const Mat& inpaint_mask, Mat& inpainted)
+{
+    inpainted.create(filtered.rows, filtered.cols, CV_8U);
+    for (int y = 0; y < filtered.rows; ++y) {
+        unsigned char last = 0;
+        for (int x = 0; x < filtered.cols; ++x) {
+            if (inpaint_mask.at<unsigned char>(y, x) == 0) last = filtered.at<unsigned char>(y, x);
+            inpainted.at<unsigned char>(y, x) = last;
+        }
+    }
+    return true;
+}
 }  // namespace cv
+typedef unsigned char uchar;
 
 namespace image_geometry {
 class PinholeCameraModel {
@@ -185,6 +276,198 @@ void process_1_like_the_reference(const LinearTrajectory& trajectory0, const Lin
     case 6: mapper_fused.dsi_.maxTwoGrids(mapper1.dsi_); break;
     default: throw dsi::Error(DSI_ERR_BAD_OP, "Improper fusion method selected");
     }
+}
+
+// utils.cpp:107-117 saveDepthMaps writes files; here it keeps what it was handed, so that the test can compare
+struct Saved {
+    std::string suffix;
+    std::vector<float> depth, conf;
+    std::vector<uchar> mask;
+};
+std::vector<Saved> g_saved;
+void saveDepthMaps(const cv::Mat& depth_map, const cv::Mat& confidence_map, const cv::Mat& semidense_mask, const float, const float,
+                   const std::string& suffix, const std::string&)
+{
+    Saved s;
+    s.suffix = suffix;
+    const size_t n = (size_t)depth_map.rows * depth_map.cols;
+    s.depth.assign(depth_map.ptr<float>(0), depth_map.ptr<float>(0) + n);
+    s.conf.assign(confidence_map.ptr<float>(0), confidence_map.ptr<float>(0) + n);
+    s.mask.assign(semidense_mask.ptr<uchar>(0), semidense_mask.ptr<uchar>(0) + n);
+    g_saved.push_back(s);
+}
+
+// process1.cpp:203-222, spelled as there (events2 of the stereo rig is empty; mapper2 exists but is not voted)
+void process_1_outputs_like_the_reference(EMVS::MapperEMVS& mapper_fused, EMVS::MapperEMVS& mapper0, EMVS::MapperEMVS& mapper1,
+                                          EMVS::MapperEMVS& mapper2, const std::vector<dvs_msgs::Event>& events2,
+                                          const EMVS::OptionsDepthMap& opts_depth_map, const EMVS::ShapeDSI& dsi_shape,
+                                          int fusion_method)
+{
+    std::stringstream ss;
+    ss << "out/";
+  // 3. Extract semi-dense depth map from DSI
+  cv::Mat depth_map, confidence_map, semidense_mask;
+
+  if (opts_depth_map.save_mono){
+      // One DSI (voted by left-camera events)
+      mapper0.getDepthMapFromDSI(depth_map, confidence_map, semidense_mask, opts_depth_map);
+      saveDepthMaps(depth_map, confidence_map, semidense_mask, dsi_shape.min_depth_, dsi_shape.max_depth_, std::string("0"), ss.str());
+      // Another DSI (voted by right-camera events)
+      mapper1.getDepthMapFromDSI(depth_map, confidence_map, semidense_mask, opts_depth_map);
+      saveDepthMaps(depth_map, confidence_map, semidense_mask, dsi_shape.min_depth_, dsi_shape.max_depth_, std::string("1"), ss.str());
+
+      if(events2.size()>0){
+          // Another DSI (voted by 3rd camera events)
+          mapper2.getDepthMapFromDSI(depth_map, confidence_map, semidense_mask, opts_depth_map);
+          saveDepthMaps(depth_map, confidence_map, semidense_mask, dsi_shape.min_depth_, dsi_shape.max_depth_, std::string("2"), ss.str());
+        }
+    }
+
+  // Fused DSIs
+  mapper_fused.getDepthMapFromDSI(depth_map, confidence_map, semidense_mask, opts_depth_map);
+  saveDepthMaps(depth_map, confidence_map, semidense_mask, dsi_shape.min_depth_, dsi_shape.max_depth_, std::string("fused_" + std::to_string(fusion_method)), ss.str());
+}
+
+// process2.cpp:83, :253-263, :299, spelled as there (the mappers hold whatever DSIs the caller left in them: the
+// extraction reads each mapper's own dsi_)
+void process_2_outputs_like_the_reference(EMVS::MapperEMVS& mapper_fused, EMVS::MapperEMVS& mapper_fused_left,
+                                          EMVS::MapperEMVS& mapper_fused_right, EMVS::MapperEMVS& mapper_fused_camera_time,
+                                          const EMVS::OptionsDepthMap& opts_depth_map, const EMVS::ShapeDSI& dsi_shape,
+                                          int temporal_fusion)
+{
+    std::stringstream ss;
+  cv::Mat depth_map, confidence_map, semidense_mask;
+  if (!opts_depth_map.full_sequence) {
+      // Fused DSIs (using harmonic mean).
+      mapper_fused_left.getDepthMapFromDSI(depth_map, confidence_map, semidense_mask, opts_depth_map);
+      saveDepthMaps(depth_map, confidence_map, semidense_mask, dsi_shape.min_depth_, dsi_shape.max_depth_, std::string("left_temporal_" + std::to_string(temporal_fusion)), ss.str());
+      mapper_fused_right.getDepthMapFromDSI(depth_map, confidence_map, semidense_mask, opts_depth_map);
+      saveDepthMaps(depth_map, confidence_map, semidense_mask, dsi_shape.min_depth_, dsi_shape.max_depth_, std::string("right_temporal_" + std::to_string(temporal_fusion)), ss.str());
+    }
+  mapper_fused.getDepthMapFromDSI(depth_map, confidence_map, semidense_mask, opts_depth_map);
+  saveDepthMaps(depth_map, confidence_map, semidense_mask, dsi_shape.min_depth_, dsi_shape.max_depth_, std::string("stereo_temporal_" + std::to_string(temporal_fusion)), ss.str());
+
+  mapper_fused_camera_time.getDepthMapFromDSI(depth_map, confidence_map, semidense_mask, opts_depth_map);
+  saveDepthMaps(depth_map, confidence_map, semidense_mask, dsi_shape.min_depth_, dsi_shape.max_depth_, std::string("stereo_temporal_camera_time" + std::to_string(temporal_fusion)), ss.str());
+}
+
+bool same(const std::vector<float>& a, const float* b) { return std::memcmp(a.data(), b, a.size() * sizeof(float)) == 0; }
+bool same(const std::vector<uchar>& a, const uchar* b) { return std::memcmp(a.data(), b, a.size()) == 0; }
+
+// The image-typed members with cv::Mat: every call site of the reference, outputs memcmp-equal to the dsi::Image path.
+// mapper_fused / mapper0 / mapper1 hold the DSIs process_1_like_the_reference left.
+int check_image_typed_members(EMVS::MapperEMVS& mapper_fused, EMVS::MapperEMVS& mapper0, EMVS::MapperEMVS& mapper1,
+                              EMVS::MapperEMVS& mapper2, const EMVS::ShapeDSI& dsi_shape)
+{
+    EMVS::OptionsDepthMap opts_depth_map;  // main.cpp:163-171
+    opts_depth_map.max_confidence = 10;
+    opts_depth_map.adaptive_threshold_kernel_size_ = 5;
+    opts_depth_map.adaptive_threshold_c_ = 4;
+    opts_depth_map.median_filter_size_ = 5;
+    opts_depth_map.full_sequence = false;
+    opts_depth_map.save_mono = true;
+    const std::vector<dvs_msgs::Event> events2;
+    EMVS::MapperEMVS* all[3] = {&mapper0, &mapper1, &mapper_fused};
+    // the dsi::Image path (what tests/cpp/test_process1.cpp holds against the oracle's filters)
+    dsi::Image<float> want_depth[3], want_conf[3];
+    dsi::Image<uint8_t> want_mask[3];
+    for (int i = 0; i < 3; ++i) all[i]->getDepthMapFromDSI(want_depth[i], want_conf[i], want_mask[i], opts_depth_map);
+    size_t kept = 0;
+    for (uint8_t m : want_mask[2].data) kept += m;
+    if (kept == 0) return 70;  // the comparison must be about something
+
+    // ---- process1.cpp:203-222
+    g_saved.clear();
+    process_1_outputs_like_the_reference(mapper_fused, mapper0, mapper1, mapper2, events2, opts_depth_map, dsi_shape, 2);
+    if (g_saved.size() != 3 || g_saved[0].suffix != "0" || g_saved[1].suffix != "1" || g_saved[2].suffix != "fused_2") return 71;
+    for (int i = 0; i < 3; ++i)
+        if (!same(g_saved[i].depth, want_depth[i].data.data()) || !same(g_saved[i].conf, want_conf[i].data.data()) ||
+            !same(g_saved[i].mask, want_mask[i].data.data()))
+            return 72 + i;
+    // ---- process2.cpp:253-263, :299 (four mappers, each read through its own dsi_)
+    g_saved.clear();
+    process_2_outputs_like_the_reference(mapper_fused, mapper0, mapper1, mapper_fused, opts_depth_map, dsi_shape, 2);
+    if (g_saved.size() != 4 || g_saved[0].suffix != "left_temporal_2" || g_saved[3].suffix != "stereo_temporal_camera_time2") return 75;
+    const int who[4] = {0, 1, 2, 2};
+    for (int i = 0; i < 4; ++i)
+        if (!same(g_saved[i].depth, want_depth[who[i]].data.data()) || !same(g_saved[i].mask, want_mask[who[i]].data.data())) return 76;
+    // ---- main.cpp:388-389, :406, :417: the five-argument form
+    {
+        cv::Mat depth_map, confidence_map, semidense_mask;
+        cv::Mat depth_map_dense;
+        mapper_fused.getDepthMapFromDSI(depth_map, confidence_map, semidense_mask, opts_depth_map, depth_map_dense);
+        if (depth_map.type() != CV_32F || confidence_map.type() != CV_32F || semidense_mask.type() != CV_8U ||
+            depth_map.rows != want_depth[2].rows || depth_map.cols != want_depth[2].cols)
+            return 80;
+        if (std::memcmp(depth_map.ptr<float>(0), want_depth[2].data.data(), want_depth[2].data.size() * 4) != 0 ||
+            std::memcmp(confidence_map.ptr<float>(0), want_conf[2].data.data(), want_conf[2].data.size() * 4) != 0 ||
+            std::memcmp(semidense_mask.ptr<uchar>(0), want_mask[2].data.data(), want_mask[2].data.size()) != 0)
+            return 81;
+        // depth_map_dense = convertDepthIndicesToValues(inpaint(filtered indices, 1 - mask)) (mapper_emvs_stereo.cpp:430-436)
+        // with the hook above: on kept pixels the dense map IS the semi-dense one; elsewhere the nearest kept depth to the left
+        if (depth_map_dense.empty() || depth_map_dense.type() != CV_32F || depth_map_dense.rows != depth_map.rows) return 82;
+        const std::vector<float> planes = mapper_fused.depthPlanes();
+        for (int y = 0; y < depth_map.rows; ++y) {
+            float last = planes[0];
+            for (int x = 0; x < depth_map.cols; ++x) {
+                if (semidense_mask.at<uchar>(y, x)) last = depth_map.at<float>(y, x);
+                if (depth_map_dense.at<float>(y, x) != last) {
+                    std::printf("depth_map_dense(%d,%d) = %g, expected %g\n", y, x, depth_map_dense.at<float>(y, x), last);
+                    return 83;
+                }
+            }
+        }
+        mapper0.getDepthMapFromDSI(depth_map, confidence_map, semidense_mask, opts_depth_map, depth_map_dense);  // :406
+        if (std::memcmp(depth_map.ptr<float>(0), want_depth[0].data.data(), want_depth[0].data.size() * 4) != 0) return 84;
+        mapper1.getDepthMapFromDSI(depth_map, confidence_map, semidense_mask, opts_depth_map, depth_map_dense);  // :417
+        if (std::memcmp(depth_map.ptr<float>(0), want_depth[1].data.data(), want_depth[1].data.size() * 4) != 0) return 85;
+        // without a hook for the image type (dsi::Image has none) the dense map is left EMPTY, never a guess
+        dsi::Image<float> d, c, dense(3, 3);
+        dsi::Image<uint8_t> m;
+        mapper_fused.getDepthMapFromDSI(d, c, m, opts_depth_map, dense);
+        if (d.data != want_depth[2].data || dense.rows != 0 || !dense.data.empty()) return 86;
+    }
+    // ---- int method = -1 (mapper_emvs_stereo.hpp:108-109): -1 and anything outside 0..4 is collapseMaxZSlice (.cpp:348-368);
+    //      the focus collapses 0..4 are refused
+    {
+        cv::Mat depth_map, confidence_map, semidense_mask, depth_map_dense;
+        mapper_fused.getDepthMapFromDSI(depth_map, confidence_map, semidense_mask, opts_depth_map, -1);
+        if (std::memcmp(depth_map.ptr<float>(0), want_depth[2].data.data(), want_depth[2].data.size() * 4) != 0) return 87;
+        mapper_fused.getDepthMapFromDSI(depth_map, confidence_map, semidense_mask, opts_depth_map, depth_map_dense, 7);
+        if (std::memcmp(depth_map.ptr<float>(0), want_depth[2].data.data(), want_depth[2].data.size() * 4) != 0) return 88;
+        for (int method = 0; method <= 4; ++method) {
+            try {
+                mapper_fused.getDepthMapFromDSI(depth_map, confidence_map, semidense_mask, opts_depth_map, method);
+                return 89;
+            } catch (const dsi::Error& e) {
+                if (e.code != DSI_ERR_BAD_OP) return 90;
+            }
+        }
+    }
+    // ---- Grid3D::collapseMaxZSlice(cv::Mat*, cv::Mat*) (cartesian3dgrid.h:207; called at mapper_emvs_stereo.cpp:366)
+    {
+        cv::Mat confidence_map, depth_cell_indices;
+        mapper_fused.dsi_.collapseMaxZSlice(&confidence_map, &depth_cell_indices);
+        dsi::Image<float> c;
+        dsi::Image<uint8_t> i;
+        mapper_fused.dsi_.collapseMaxZSlice(&c, &i);
+        if (confidence_map.type() != CV_32F || depth_cell_indices.type() != CV_8U || confidence_map.rows != c.rows ||
+            confidence_map.cols != c.cols)
+            return 91;
+        if (std::memcmp(confidence_map.ptr<float>(0), c.data.data(), c.data.size() * 4) != 0 ||
+            std::memcmp(depth_cell_indices.ptr<uchar>(0), i.data.data(), i.data.size()) != 0)
+            return 92;
+        // MapperEMVS::convertDepthIndicesToValues (mapper_emvs_stereo.cpp:302-313) on cv::Mat
+        cv::Mat depth;
+        mapper_fused.convertDepthIndicesToValues(depth_cell_indices, depth);
+        dsi::Image<float> rd, rc;
+        dsi::Image<uint8_t> ri;
+        mapper_fused.getDepthMapFromDSI(rd, rc, ri);
+        if (std::memcmp(depth.ptr<float>(0), rd.data.data(), rd.data.size() * 4) != 0) return 93;
+    }
+    std::printf("cv::Mat-typed getDepthMapFromDSI (4- and 5-argument, method), collapseMaxZSlice, convertDepthIndicesToValues "
+                "== dsi::Image path, %zu semi-dense pixels: OK\n", kept);
+    return 0;
 }
 
 }  // namespace
@@ -363,7 +646,8 @@ int main(int argc, char** argv)
         }
         if (!(sum > 100.0)) return 13;
         std::printf("reference-typed call sequence == plain-typed call sequence, fused DSI sum %.6g: OK\n", sum);
-        return 0;
+        EMVS::MapperEMVS mapper2(cam0, dsi_shape);
+        return check_image_typed_members(mapper_fused, mapper0, mapper1, mapper2, dsi_shape);
     } catch (const dsi::Error& e) {
         std::printf("dsi::Error %d: %s\n", e.code, e.what());
         return e.code == DSI_ERR_NO_DEVICE ? 3 : 2;
