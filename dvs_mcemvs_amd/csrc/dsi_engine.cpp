@@ -183,15 +183,20 @@ struct dsi_batch {
 
 // grow-only device scratch of the exact tie resolver (dsi_mapper_resolve_near_ties), owned by the output mapper
 struct TieScratch {
-    DevBuf<uint32_t> cand, sv, bitmap, count;
-    DevBuf<int> zlist;
-    DevBuf<unsigned long long> counters, keys, keys2;
-    DevBuf<float> w, w2, exact, gpu;
+    DevBuf<uint32_t> cand, count;
+    DevBuf<uint2> desc;
+    DevBuf<uint4> cols;
+    // 32-bit words: [0] contending voxels, [1] near-tie columns (k_tie_candidates); [2] output segments handed out,
+    // [3] overflow flags (k_tie_hits_binned); [4] max order difference (float bits), [5] max votes of a voxel (k_tie_sums2);
+    // [6] changed pixels (k_tie_pick); [8..9] one 64-bit word: real votes recorded; [16..23] planes with a contender (k_tie_desc)
+    DevBuf<unsigned long long> counters;
+    DevBuf<unsigned long long> keys, keys2;
+    DevBuf<float> w, w2, exact;
     DevBuf<char> tmp;
     void release()
     {
-        cand.release(); sv.release(); bitmap.release(); count.release(); zlist.release(); counters.release();
-        keys.release(); keys2.release(); w.release(); w2.release(); exact.release(); gpu.release(); tmp.release();
+        cand.release(); count.release(); desc.release(); cols.release(); counters.release();
+        keys.release(); keys2.release(); w.release(); w2.release(); exact.release(); tmp.release();
     }
 };
 
@@ -1696,134 +1701,132 @@ int dsi_mapper_depth_map_of_events(dsi_mapper_t* out, dsi_mapper_t* const* mappe
 }
 
 /* ---- exact tie resolver (include/dsi_engine.h) ---- */
-// The values the REFERENCE's summation order gives the voxels `sv` (sorted, unique, linear indices z * npix + p) of the
-// DSI mapper m builds from batch b: one pass over the events on the planes that occur in sv with the reference's
-// coordinates, accept test and weights (k_tie_hits), the recorded votes sorted on the device by (voxel, event index),
-// added one by one in fp32 by one thread per voxel.  count[i] = votes of voxel i; gpu[i] = what m's grid holds there now.
-static int tie_exact_values(TieScratch& ts, dsi_mapper* m, const dsi_batch* b, const std::vector<uint32_t>& sv,
-                            std::vector<float>* exact, std::vector<uint32_t>* count, std::vector<float>* gpu, long long* votes)
+namespace {
+constexpr int kTieCounterWords = 24;  // 32-bit words of TieScratch::counters ([16..23]: one bit per plane with a contender)
+constexpr int kTieCounterPassWords = 16;  // the words an event pass starts from zero
+
+unsigned bits_for(unsigned long long values)  // bits that hold 0 .. values - 1
 {
-    hipStream_t st = m->ctx->stream;
-    const int npix = m->geom.nx * m->geom.ny;
-    const size_t nvox = (size_t)npix * m->geom.nz;
-    exact->assign(sv.size(), 0.f);
-    count->assign(sv.size(), 0u);
-    gpu->assign(sv.size(), 0.f);
+    unsigned b = 1;
+    while (b < 64 && ((unsigned long long)1 << b) < values) ++b;
+    return b;
+}
+}  // namespace
+
+// The values the REFERENCE's summation order gives the voxels ts.cand[0 .. nsv) (linear indices z * npix + p, any order, no
+// duplicates) of the DSIs mappers[c] build from batches[c], c < n (1 or 2): ts.exact[c * nsv + i], ts.count[c * nsv + i] on
+// the device.  Per camera one inverted event pass (k_tie_hits_binned: the packet's z0 locations binned by tile in LDS,
+// every voxel asks which of them the plane transfer can take into its 2 x 2 neighbourhood, those are voted with the
+// reference's coordinates, accept test and weights); the recorded votes of all cameras sorted on the device by (camera,
+// voxel, event index) and added one by one in fp32 by one thread per (camera, voxel).  grid_stats: also the maxima of
+// |grid value - reference-order value| and of the votes per voxel into ts.counters.  Host round trips: ONE read of two
+// counters (how many records to sort).
+static int tie_exact_values_dev(TieScratch& ts, hipStream_t st, dsi_mapper* const* ms, const dsi_batch* const* bs, int n, int nsv,
+                                bool grid_stats, long long* votes)
+{
     *votes = 0;
-    if (sv.empty()) return DSI_OK;
-    std::vector<int> zlist;
-    for (uint32_t v : sv) {
-        const int z = (int)(v / (uint32_t)npix);
-        if (zlist.empty() || zlist.back() != z) zlist.push_back(z);
-    }
-    const size_t bitmap_words = (nvox + 31) / 32 + 1;
-    // behind the voxel bits: one bit per (plane, 8 x 8 tile) that holds a vote location reaching a contending voxel
-    const size_t tile_words = (size_t)dsi::tie_tile_words_of(m->geom.nx, m->geom.ny) * (size_t)m->geom.nz;
-    HIP_TRY(ts.counters.reserve(4));
-    HIP_TRY(ts.sv.reserve(sv.size()));
-    HIP_TRY(ts.bitmap.reserve(bitmap_words + tile_words));
-    HIP_TRY(ts.zlist.reserve(zlist.size()));
-    HIP_TRY(ts.exact.reserve(sv.size()));
-    HIP_TRY(ts.gpu.reserve(sv.size()));
-    HIP_TRY(ts.count.reserve(sv.size()));
-    HIP_TRY(hipMemcpyAsync(ts.sv.p, sv.data(), sv.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(ts.zlist.p, zlist.data(), zlist.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(ts.bitmap.p, 0, (bitmap_words + tile_words) * sizeof(uint32_t), st));
-    uint32_t* tiles = ts.bitmap.p + bitmap_words;
-    HIP_TRY(dsi::launch_tie_mark(st, ts.sv.p, (int)sv.size(), ts.bitmap.p, tiles, m->geom.nx, m->geom.ny));
-    unsigned long long* d_hits_n = ts.counters.p + 2;
-    unsigned cid_bits = 1;
-    while (cid_bits < 32 && ((size_t)1 << cid_bits) < sv.size()) ++cid_bits;
-    const size_t np = b->n_packets;
-    unsigned long long n_hits = 0;
-    if (np) {
+    if (nsv <= 0) return DSI_OK;
+    const dsi::Geom& g0 = ms[0]->geom;
+    const int npix = g0.nx * g0.ny;
+    size_t np_max = 1;
+    for (int c = 0; c < n; ++c) np_max = std::max(np_max, bs[c]->n_packets);
+    const unsigned pos_bits = bits_for((unsigned long long)np_max * dsi::kPacket);
+    const unsigned rank_bits = bits_for((unsigned long long)n * nsv + 1);  // + 1: the sentinel rank of unused record slots
+    REQUIRE(pos_bits + rank_bits <= 64, DSI_ERR_INVALID, "too many voxels x events for a 64-bit sort key");
+    const unsigned sentinel = (unsigned)n * (unsigned)nsv;
+    const size_t seg = (size_t)dsi::tie_segment_records();
+    HIP_TRY(ts.counters.reserve(kTieCounterWords / 2));
+    HIP_TRY(ts.desc.reserve((size_t)nsv));
+    HIP_TRY(ts.exact.reserve((size_t)n * nsv));
+    HIP_TRY(ts.count.reserve((size_t)n * nsv));
+    unsigned* cnt = reinterpret_cast<unsigned*>(ts.counters.p);
+    HIP_TRY(hipMemsetAsync(cnt + kTieCounterPassWords, 0, (kTieCounterWords - kTieCounterPassWords) * sizeof(unsigned), st));
+    HIP_TRY(dsi::launch_tie_desc(st, ts.cand.p, nsv, g0.nx, npix, ts.desc.p, cnt + kTieCounterPassWords));
+    for (int c = 0; c < n; ++c) {
+        dsi_mapper* m = ms[c];
+        const size_t np = bs[c]->n_packets;
+        if (!np) continue;
         HIP_TRY(m->H.reserve(np * 9));
         HIP_TRY(m->xy.reserve(np * dsi::kPacket));
         HIP_TRY(m->centers.reserve(np * 3));
-        if (b->ready) HIP_TRY(hipStreamWaitEvent(st, b->ready, 0));
-        HIP_TRY(dsi::launch_packet_geometry(st, b->Rt, (int)np, m->geom, m->centers.p, m->H.p));
-        HIP_TRY(dsi::launch_warp_z0(st, b->x, b->y, b->first, (int)np, m->H.p, m->lut_dev, m->sensor_w, m->sensor_h, m->xy.p));
-        // ONE pass into the scratch already held (4 M votes to begin with); a pass that overflows it only counts what it
-        // would have written, and is repeated once with the exact size
-        size_t cap = std::max<size_t>(ts.keys.cap, (size_t)1 << 22);
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            HIP_TRY(ts.keys.reserve(cap));
-            HIP_TRY(ts.keys2.reserve(cap));
-            HIP_TRY(ts.w.reserve(cap));
-            HIP_TRY(ts.w2.reserve(cap));
-            HIP_TRY(hipMemsetAsync(d_hits_n, 0, sizeof(unsigned long long), st));
-            HIP_TRY(dsi::launch_tie_hits(st, m->xy.p, m->centers.p, m->planes_dev, m->geom, (int)np, ts.zlist.p, (int)zlist.size(),
-                                         ts.bitmap.p, tiles, ts.sv.p, (int)sv.size(), d_hits_n, ts.keys.p, ts.w.p, cap));
-            HIP_TRY(hipMemcpyAsync(&n_hits, d_hits_n, sizeof n_hits, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            REQUIRE(n_hits < ((unsigned long long)1 << 31), DSI_ERR_INVALID, "%llu votes to re-sum: too many voxels asked for", n_hits);
-            if (n_hits <= cap) break;
-            REQUIRE(attempt == 0, DSI_ERR_INVALID, "the vote count changed between two passes");
-            cap = (size_t)n_hits;
-        }
+        if (bs[c]->ready) HIP_TRY(hipStreamWaitEvent(st, bs[c]->ready, 0));
+        HIP_TRY(dsi::launch_packet_geometry(st, bs[c]->Rt, (int)np, m->geom, m->centers.p, m->H.p));
+        HIP_TRY(dsi::launch_warp_z0(st, bs[c]->x, bs[c]->y, bs[c]->first, (int)np, m->H.p, m->lut_dev, m->sensor_w, m->sensor_h, m->xy.p));
     }
-    *votes = (long long)n_hits;
+    // ONE pass per camera into the scratch already held (4 M records to begin with); a pass that runs out of segments only
+    // counts what it would have needed, and everything is repeated once with that much room
+    size_t cap = std::max<size_t>(ts.keys.cap, (size_t)1 << 22);
+    unsigned host_cnt[4] = {0, 0, 0, 0};  // segments, flags, votes (64 bits)
+    for (int attempt = 0;; ++attempt) {
+        cap = (cap + seg - 1) / seg * seg;
+        HIP_TRY(ts.keys.reserve(cap));
+        HIP_TRY(ts.keys2.reserve(cap));
+        HIP_TRY(ts.w.reserve(cap));
+        HIP_TRY(ts.w2.reserve(cap));
+        const unsigned cap_segs = (unsigned)std::min<size_t>(ts.keys.cap / seg, 0x7fffffffu);
+        HIP_TRY(hipMemsetAsync(cnt + 2, 0, (kTieCounterPassWords - 2) * sizeof(unsigned), st));
+        for (int c = 0; c < n; ++c) {
+            dsi_mapper* m = ms[c];
+            if (!bs[c]->n_packets) continue;
+            HIP_TRY(dsi::launch_tie_hits_binned(st, m->xy.p, m->centers.p, m->planes_dev, m->geom, (int)bs[c]->n_packets, ts.desc.p, nsv,
+                                                (unsigned)c * (unsigned)nsv, pos_bits, sentinel, cnt + 2, cap_segs, cnt + 3,
+                                                ts.counters.p + 4, ts.keys.p, ts.w.p));
+        }
+        HIP_TRY(hipMemcpyAsync(host_cnt, cnt + 2, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(host_cnt + 2, ts.counters.p + 4, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        REQUIRE(!(host_cnt[1] & 1u), DSI_ERR_INVALID, "a workgroup recorded more than 2 M votes: too many voxels asked for");
+        if (!(host_cnt[1] & 2u)) break;
+        REQUIRE(attempt == 0, DSI_ERR_INVALID, "the vote count changed between two passes");
+        cap = (size_t)host_cnt[0] * seg;
+        REQUIRE(cap < ((size_t)1 << 33), DSI_ERR_INVALID, "%zu votes to re-sum: too many voxels asked for", cap);
+    }
+    unsigned long long real_votes = 0;
+    std::memcpy(&real_votes, host_cnt + 2, sizeof real_votes);
+    *votes = (long long)real_votes;
+    const size_t n_rec = (size_t)host_cnt[0] * seg;  // with the sentinel tails of the blocks' last segments
     const unsigned long long* keys_sorted = nullptr;
     const float* w_sorted = nullptr;
-    if (n_hits) {
+    if (n_rec) {
         size_t tmp_bytes = 0;
-        HIP_TRY(dsi::tie_sort_pairs(st, ts.keys.p, ts.keys2.p, ts.w.p, ts.w2.p, (size_t)n_hits, 32 + cid_bits, nullptr, &tmp_bytes));
+        HIP_TRY(dsi::tie_sort_pairs(st, ts.keys.p, ts.keys2.p, ts.w.p, ts.w2.p, n_rec, pos_bits + rank_bits, nullptr, &tmp_bytes));
         HIP_TRY(ts.tmp.reserve(tmp_bytes));
-        HIP_TRY(dsi::tie_sort_pairs(st, ts.keys.p, ts.keys2.p, ts.w.p, ts.w2.p, (size_t)n_hits, 32 + cid_bits, ts.tmp.p, &tmp_bytes));
+        HIP_TRY(dsi::tie_sort_pairs(st, ts.keys.p, ts.keys2.p, ts.w.p, ts.w2.p, n_rec, pos_bits + rank_bits, ts.tmp.p, &tmp_bytes));
         keys_sorted = ts.keys2.p;
         w_sorted = ts.w2.p;
     }
-    HIP_TRY(dsi::launch_tie_sums(st, keys_sorted, w_sorted, n_hits, ts.sv.p, (int)sv.size(), m->grid->data, ts.exact.p, ts.count.p,
-                                 ts.gpu.p));
-    HIP_TRY(hipMemcpyAsync(exact->data(), ts.exact.p, sv.size() * sizeof(float), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(count->data(), ts.count.p, sv.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(gpu->data(), ts.gpu.p, sv.size() * sizeof(float), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(dsi::launch_tie_sums2(st, keys_sorted, w_sorted, n_rec, pos_bits, ts.cand.p, nsv, n, grid_stats ? ms[0]->grid->data : nullptr,
+                                  grid_stats && n > 1 ? ms[1]->grid->data : nullptr, ts.exact.p, ts.count.p,
+                                  grid_stats ? cnt + 4 : nullptr));
     return DSI_OK;
 }
 
-// columns of op(a, b) (b == nullptr: of a) with >= 2 planes within rel_gap of the column's maximum: their voxels, a column's
-// run contiguous and ascending in z (k_tie_candidates)
-static int tie_candidates(TieScratch& ts, hipStream_t st, const float* a, const float* b, int op, int npix, int nz, float rel_gap,
-                          std::vector<uint32_t>* cand, unsigned* n_columns)
+// columns of op(a, b) (b == nullptr: of a) with >= 2 planes within rel_gap of the column's maximum: their voxels into
+// ts.cand (a column's run contiguous and ascending in z), the columns into ts.cols (k_tie_candidates); counts to the host
+static int tie_candidates_dev(TieScratch& ts, hipStream_t st, const float* a, const float* b, int op, int npix, int nz, float rel_gap,
+                              unsigned* n_cand, unsigned* n_columns)
 {
     const size_t nvox = (size_t)npix * nz;
     unsigned counters[2] = {0, 0};
-    HIP_TRY(ts.counters.reserve(4));
+    HIP_TRY(ts.counters.reserve(kTieCounterWords / 2));
     size_t cap = std::max<size_t>(ts.cand.cap, std::min<size_t>(nvox, (size_t)1 << 20));
+    size_t cols_cap = std::max<size_t>(ts.cols.cap, std::min<size_t>((size_t)npix, (size_t)1 << 18));
     for (;;) {
         HIP_TRY(ts.cand.reserve(cap));
-        HIP_TRY(hipMemsetAsync(ts.counters.p, 0, 4 * sizeof(unsigned long long), st));
+        HIP_TRY(ts.cols.reserve(cols_cap));
+        HIP_TRY(hipMemsetAsync(ts.counters.p, 0, kTieCounterWords * sizeof(unsigned), st));
         unsigned* d_cnt = reinterpret_cast<unsigned*>(ts.counters.p);
-        HIP_TRY(dsi::launch_tie_candidates(st, a, b, op, npix, nz, rel_gap, d_cnt, ts.cand.p, (uint32_t)std::min<size_t>(cap, 0xffffffffu)));
+        HIP_TRY(dsi::launch_tie_candidates(st, a, b, op, npix, nz, rel_gap, d_cnt, ts.cand.p, (uint32_t)std::min<size_t>(cap, 0xffffffffu),
+                                           ts.cols.p, (uint32_t)std::min<size_t>(cols_cap, 0xffffffffu)));
         HIP_TRY(hipMemcpyAsync(counters, d_cnt, sizeof counters, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        if (counters[0] <= cap) break;
-        REQUIRE(cap < nvox, DSI_ERR_INVALID, "more contending voxels than voxels");
-        cap = std::min<size_t>(nvox, (size_t)counters[0]);
+        if (counters[0] <= cap && counters[1] <= cols_cap) break;
+        REQUIRE(cap < nvox || cols_cap < (size_t)npix, DSI_ERR_INVALID, "more contending voxels than voxels");
+        cap = std::min<size_t>(nvox, std::max<size_t>(cap, counters[0]));
+        cols_cap = std::min<size_t>((size_t)npix, std::max<size_t>(cols_cap, counters[1]));
     }
-    cand->resize(counters[0]);
-    if (counters[0]) HIP_TRY(hipMemcpy(cand->data(), ts.cand.p, counters[0] * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    *n_cand = counters[0];
     *n_columns = counters[1];
-    return DSI_OK;
-}
-
-static int patch_depth_map(dsi_mapper_t* m, TieScratch& ts, const uint32_t* pix, const uint8_t* idx, const float* conf, size_t n)
-{
-    if (n == 0) return DSI_OK;
-    hipStream_t st = m->ctx->stream;
-    HIP_TRY(ts.count.reserve(n));
-    HIP_TRY(ts.exact.reserve(n));
-    HIP_TRY(ts.gpu.reserve(n));
-    // (the patch lists reuse the scratch the sums no longer need: pix <- count, conf <- exact, idx <- gpu)
-    HIP_TRY(hipMemcpyAsync(ts.count.p, pix, n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(ts.exact.p, conf, n * sizeof(float), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(ts.gpu.p, idx, n, hipMemcpyHostToDevice, st));
-    if (int rc = depth_buffers_acquire(m)) return rc;
-    HIP_TRY(dsi::launch_tie_patch(st, ts.count.p, reinterpret_cast<const uint8_t*>(ts.gpu.p), ts.exact.p, (int)n, m->planes_dev,
-                                  m->conf.p, m->idx.p, m->depth.p));
-    if (int rc = depth_buffers_ready(m)) return rc;
-    HIP_TRY(hipStreamSynchronize(st));  // the host arrays are pageable
     return DSI_OK;
 }
 
@@ -1833,7 +1836,7 @@ int dsi_mapper_resolve_near_ties(dsi_mapper_t* out, dsi_mapper_t* const* mappers
     REQUIRE(out && mappers && batches && info, DSI_ERR_INVALID, "null argument");
     REQUIRE(n == 1 || n == 2, DSI_ERR_INVALID, "1 or 2 cameras (got %d)", n);
     REQUIRE(n == 1 || (op >= 1 && op <= 6), DSI_ERR_BAD_OP, "improper fusion method %d (expected 1..6)", op);
-    const float rel_gap = info->rel_gap > 0.f ? info->rel_gap : 2.5e-4f;
+    float rel_gap = info->rel_gap > 0.f ? info->rel_gap : 2.5e-4f;
     REQUIRE(rel_gap < 0.5f, DSI_ERR_INVALID, "rel_gap %g is not a rounding-sized gap", (double)rel_gap);
     dsi_context* ctx = out->ctx;
     for (int i = 0; i < n; ++i) {
@@ -1842,6 +1845,7 @@ int dsi_mapper_resolve_near_ties(dsi_mapper_t* out, dsi_mapper_t* const* mappers
                 "mappers, batches and the output mapper must share one context");
         REQUIRE(same_shape(out->grid, mappers[i]->grid), DSI_ERR_SHAPE, "camera %d: DSI shape differs from the output mapper's", i);
     }
+    REQUIRE(n == 1 || mappers[0] != mappers[1], DSI_ERR_INVALID, "the cameras need distinct mappers");
     REQUIRE(out->depth_valid, DSI_ERR_INVALID, "the output mapper holds no raw depth map to resolve");
     const dsi::Geom& g0 = out->geom;
     const int npix = g0.nx * g0.ny, nz = g0.nz;
@@ -1851,74 +1855,54 @@ int dsi_mapper_resolve_near_ties(dsi_mapper_t* out, dsi_mapper_t* const* mappers
     hipStream_t st = ctx->stream;
     const auto t_begin = std::chrono::steady_clock::now();
     *info = dsi_resolve_info_t{};
-    info->rel_gap = rel_gap;
     TieScratch& ts = out->tie;  // grow-only scratch of the output mapper: a stream of calls allocates nothing
-
-    // 1. the contending voxels
-    std::vector<uint32_t> cand;
-    unsigned n_columns = 0;
-    if (int rc = tie_candidates(ts, st, mappers[0]->grid->data, n == 2 ? mappers[1]->grid->data : nullptr, op, npix, nz, rel_gap, &cand,
-                                &n_columns))
-        return rc;
-    info->near_tie_pixels = (int)n_columns;
-    info->candidate_voxels = (int)cand.size();
     auto finish = [&]() {
         info->elapsed_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
         return DSI_OK;
     };
-    if (cand.empty()) return finish();
-
-    // 2 + 3. per camera: the contending voxels' values in the reference's summation order
-    std::vector<uint32_t> sv(cand);
-    std::sort(sv.begin(), sv.end());
-    {
-        int planes = 0, last = -1;
-        for (uint32_t v : sv) {
-            const int z = (int)(v / (uint32_t)npix);
-            if (z != last) ++planes;
-            last = z;
-        }
-        info->candidate_planes = planes;
-    }
-    std::vector<float> exact[2];
-    for (int c = 0; c < n; ++c) {
-        std::vector<uint32_t> count;
-        std::vector<float> gpu;
+    // The premise -- the two summation orders differ by far less than the gap whose columns are re-summed -- is CHECKED,
+    // not assumed: max_order_diff is measured on the re-summed voxels (the column maxima of the near-tie columns, among
+    // them the most-voted voxels of the volume), and a pass that finds it above rel_gap / 8 is repeated with a gap four
+    // times as wide (at most three times); premise_ok tells whether the last pass held it.
+    for (int widenings = 0;; ++widenings) {
+        info->rel_gap = rel_gap;
+        info->gap_widenings = widenings;
+        // 1. the contending voxels (device lists)
+        unsigned n_cand = 0, n_columns = 0;
+        if (int rc = tie_candidates_dev(ts, st, mappers[0]->grid->data, n == 2 ? mappers[1]->grid->data : nullptr, op, npix, nz, rel_gap,
+                                        &n_cand, &n_columns))
+            return rc;
+        info->near_tie_pixels = (int)n_columns;
+        info->candidate_voxels = (int)n_cand;
+        info->premise_ok = 1;
+        if (!n_cand) return finish();
+        // 2 + 3. per camera: the contending voxels' values in the reference's summation order (device)
         long long votes = 0;
-        if (int rc = tie_exact_values(ts, mappers[c], batches[c], sv, &exact[c], &count, &gpu, &votes)) return rc;
-        info->votes += votes;
-        for (size_t i = 0; i < sv.size(); ++i) {
-            if (count[i] > 1) info->max_rel_bound = std::max(info->max_rel_bound, (double)(count[i] - 1) * 5.9604644775390625e-8);
-            const double ref = (double)exact[c][i];
-            info->max_order_diff = std::max(info->max_order_diff, std::fabs((double)gpu[i] - ref) / std::max(1.0, std::fabs(ref)));
-        }
+        dsi_mapper* ms[2] = {mappers[0], n == 2 ? mappers[1] : nullptr};
+        const dsi_batch* bs[2] = {batches[0], n == 2 ? batches[1] : nullptr};
+        if (int rc = tie_exact_values_dev(ts, st, ms, bs, n, (int)n_cand, /*grid_stats=*/true, &votes)) return rc;
+        info->votes = votes;
+        // 4. fuse, first maximum per column, patch (device)
+        if (int rc = depth_buffers_acquire(out)) return rc;
+        unsigned* cnt = reinterpret_cast<unsigned*>(ts.counters.p);
+        HIP_TRY(dsi::launch_tie_pick(st, n == 2 ? op : 0, ts.cols.p, (int)n_columns, ts.cand.p, (int)n_cand, npix, ts.exact.p, out->planes_dev,
+                                     out->conf.p, out->idx.p, out->depth.p, cnt + 4));
+        if (int rc = depth_buffers_ready(out)) return rc;
+        unsigned stats[3] = {0, 0, 0}, plane_bits[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(stats, cnt + 4, sizeof stats, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(plane_bits, cnt + kTieCounterPassWords, sizeof plane_bits, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        info->candidate_planes = 0;
+        for (unsigned wbits : plane_bits) info->candidate_planes += __builtin_popcount(wbits);
+        float diff = 0.f;
+        std::memcpy(&diff, &stats[0], sizeof diff);
+        info->max_order_diff = std::max(info->max_order_diff, (double)diff);
+        info->max_rel_bound = stats[1] > 1 ? (double)(stats[1] - 1) * 5.9604644775390625e-8 : 0.0;
+        info->changed_pixels += (int)stats[2];
+        info->premise_ok = (8.0 * (double)diff < (double)rel_gap) ? 1 : 0;  // (false for a NaN difference, too)
+        if (info->premise_ok || widenings == 3 || rel_gap * 4.f >= 0.5f) return finish();
+        rel_gap *= 4.f;
     }
-
-    // 4. fuse, first maximum per column, patch
-    std::vector<uint32_t> pix;
-    std::vector<uint8_t> new_idx;
-    std::vector<float> new_conf;
-    std::vector<uint8_t> old_idx((size_t)npix);
-    HIP_TRY(hipMemcpy(old_idx.data(), out->idx.p, (size_t)npix, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < cand.size();) {
-        const uint32_t p = cand[i] % (uint32_t)npix;
-        float best = 0.f;
-        int best_z = -1;
-        for (; i < cand.size() && cand[i] % (uint32_t)npix == p; ++i) {  // a column's run, planes ascending
-            const size_t cid = (size_t)(std::lower_bound(sv.begin(), sv.end(), cand[i]) - sv.begin());
-            const float v = n == 2 ? dsi::host::fuse2(op, exact[0][cid], exact[1][cid]) : exact[0][cid];
-            if (best_z < 0 || best < v) {  // std::max_element: the first maximum wins (cartesian3dgrid.cpp:132-134)
-                best = v;
-                best_z = (int)(cand[i] / (uint32_t)npix);
-            }
-        }
-        pix.push_back(p);
-        new_idx.push_back((uint8_t)best_z);
-        new_conf.push_back(best);
-        if (old_idx[p] != (uint8_t)best_z) ++info->changed_pixels;
-    }
-    if (int rc = patch_depth_map(out, ts, pix.data(), new_idx.data(), new_conf.data(), pix.size())) return rc;
-    return finish();
 }
 
 int dsi_grid_near_tie_voxels(dsi_mapper_t* scratch, dsi_grid_t* g, float rel_gap, uint32_t* voxels, size_t capacity,
@@ -1932,12 +1916,11 @@ int dsi_grid_near_tie_voxels(dsi_mapper_t* scratch, dsi_grid_t* g, float rel_gap
     REQUIRE(rel_gap < 0.5f, DSI_ERR_INVALID, "rel_gap %g is not a rounding-sized gap", (double)rel_gap);
     REQUIRE(g->n < ((size_t)1 << 32), DSI_ERR_INVALID, "voxels are addressed with 32 bits");
     if (int rc = set_device(g->ctx)) return rc;
-    std::vector<uint32_t> cand;
-    unsigned cols = 0;
-    if (int rc = tie_candidates(scratch->tie, g->ctx->stream, g->data, nullptr, 0, g->nx * g->ny, g->nz, rel_gap, &cand, &cols)) return rc;
-    *n_voxels = cand.size();
+    unsigned n_cand = 0, cols = 0;
+    if (int rc = tie_candidates_dev(scratch->tie, g->ctx->stream, g->data, nullptr, 0, g->nx * g->ny, g->nz, rel_gap, &n_cand, &cols)) return rc;
+    *n_voxels = n_cand;
     if (n_columns) *n_columns = cols;
-    if (cand.size() <= capacity && !cand.empty()) std::memcpy(voxels, cand.data(), cand.size() * sizeof(uint32_t));
+    if (n_cand <= capacity && n_cand) HIP_TRY(hipMemcpy(voxels, scratch->tie.cand.p, (size_t)n_cand * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return DSI_OK;
 }
 
@@ -1950,14 +1933,25 @@ int dsi_mapper_exact_voxels(dsi_mapper_t* m, const dsi_batch_t* batch, const uin
     const size_t nvox = (size_t)m->geom.nx * m->geom.ny * m->geom.nz;
     REQUIRE(nvox < ((size_t)1 << 32), DSI_ERR_INVALID, "voxels are addressed with 32 bits");
     for (size_t i = 0; i < n; ++i) REQUIRE(voxels[i] < nvox, DSI_ERR_INVALID, "voxel %zu (%u) outside the DSI", i, voxels[i]);
+    if (n == 0) return DSI_OK;
     if (int rc = set_device(m->ctx)) return rc;
+    hipStream_t st = m->ctx->stream;
     std::vector<uint32_t> sv(voxels, voxels + n);
     std::sort(sv.begin(), sv.end());
     sv.erase(std::unique(sv.begin(), sv.end()), sv.end());
-    std::vector<float> exact, gpu;
-    std::vector<uint32_t> count;
+    REQUIRE(sv.size() < ((size_t)1 << 31), DSI_ERR_INVALID, "too many voxels");
+    TieScratch& ts = m->tie;
+    HIP_TRY(ts.cand.reserve(sv.size()));
+    HIP_TRY(hipMemcpyAsync(ts.cand.p, sv.data(), sv.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     long long total = 0;
-    if (int rc = tie_exact_values(m->tie, m, batch, sv, &exact, &count, &gpu, &total)) return rc;
+    dsi_mapper* ms[1] = {m};
+    const dsi_batch* bs[1] = {batch};
+    if (int rc = tie_exact_values_dev(ts, st, ms, bs, 1, (int)sv.size(), /*grid_stats=*/false, &total)) return rc;
+    std::vector<float> exact(sv.size());
+    std::vector<uint32_t> count(sv.size());
+    HIP_TRY(hipMemcpyAsync(exact.data(), ts.exact.p, sv.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(count.data(), ts.count.p, sv.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));  // (sv is pageable: its upload has completed by now, too)
     for (size_t i = 0; i < n; ++i) {
         const size_t c = (size_t)(std::lower_bound(sv.begin(), sv.end(), voxels[i]) - sv.begin());
         values[i] = exact[c];
@@ -1988,6 +1982,25 @@ int dsi_reference_finalize(int mode, float* acc, size_t n, int n_maps)
     REQUIRE(mode == DSI_ACC_SUM || mode == DSI_ACC_INV_SUM, DSI_ERR_BAD_OP, "the reference accumulates sums (0) or inverse sums (1)");
     REQUIRE(n_maps >= 1, DSI_ERR_INVALID, "number of maps must be >= 1 (got %d)", n_maps);
     for (size_t i = 0; i < n; ++i) acc[i] = dsi::host::finalize1(mode, acc[i], n_maps);
+    return DSI_OK;
+}
+
+static int patch_depth_map(dsi_mapper_t* m, TieScratch& ts, const uint32_t* pix, const uint8_t* idx, const float* conf, size_t n)
+{
+    if (n == 0) return DSI_OK;
+    hipStream_t st = m->ctx->stream;
+    HIP_TRY(ts.count.reserve(n));
+    HIP_TRY(ts.exact.reserve(n));
+    HIP_TRY(ts.tmp.reserve(n));
+    // (the patch lists reuse the resolver's scratch: pix <- count, conf <- exact, idx <- tmp)
+    HIP_TRY(hipMemcpyAsync(ts.count.p, pix, n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ts.exact.p, conf, n * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ts.tmp.p, idx, n, hipMemcpyHostToDevice, st));
+    if (int rc = depth_buffers_acquire(m)) return rc;
+    HIP_TRY(dsi::launch_tie_patch(st, ts.count.p, reinterpret_cast<const uint8_t*>(ts.tmp.p), ts.exact.p, (int)n, m->planes_dev,
+                                  m->conf.p, m->idx.p, m->depth.p));
+    if (int rc = depth_buffers_ready(m)) return rc;
+    HIP_TRY(hipStreamSynchronize(st));  // the host arrays are pageable
     return DSI_OK;
 }
 

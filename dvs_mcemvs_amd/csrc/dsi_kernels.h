@@ -198,8 +198,30 @@ hipError_t launch_mean_square(hipStream_t s, const float* dsi, size_t n, double*
 // cand[<= cap] <- voxel indices (z * npix + p) of every plane whose value is within rel_gap of its column's maximum, for
 // the columns that have >= 2 such planes, a column's run contiguous and ascending in z; counters[0] = voxels (may exceed
 // cap: nothing beyond cap is written), counters[1] = columns.  b == nullptr: the values of `a`; else op(a, b)
+// cols (optional, <= cols_cap entries) <- per near-tie column (first entry of its run in cand, pixel, contenders, 0)
 hipError_t launch_tie_candidates(hipStream_t s, const float* a, const float* b, int op, int npix, int nz, float rel_gap,
-                                 unsigned* counters, uint32_t* cand, uint32_t cap);
+                                 unsigned* counters, uint32_t* cand, uint32_t cap, uint4* cols = nullptr, uint32_t cols_cap = 0);
+// desc[c] <- (x | y << 16, z) of voxel vox[c]; plane_bits (optional, 8 zeroed words): bit z <- plane z holds one of them
+hipError_t launch_tie_desc(hipStream_t s, const uint32_t* vox, int n, int nx, int npix, uint2* desc, unsigned* plane_bits);
+// The resolver's event pass, inverted (see k_tie_hits_binned): every vote of the batch that lands on one of the voxels
+// `desc` -> keys[] = (rank_base + index of the voxel) << pos_bits | position of the vote in the reference's loop over events
+// (packet * 1024 + slot), wts[] = the bilinear weight the reference adds.  Output in segments of tie_segment_records()
+// records, *seg_counter of them handed out so far (it keeps counting beyond cap_segs: flags bit 1, nothing written there;
+// flags bit 0: a block overflowed its segment table); unused tails hold sentinel keys sentinel_rank << pos_bits.  Several
+// launches (cameras) may append to the same arrays.  *total_hits += the real votes
+int tie_segment_records();
+hipError_t launch_tie_hits_binned(hipStream_t s, const float2* xy, const float* centers, const float* planes, const Geom& g, int np,
+                                  const uint2* desc, int nsv, unsigned rank_base, unsigned pos_bits, unsigned sentinel_rank,
+                                  unsigned* seg_counter, unsigned cap_segs, unsigned* flags, unsigned long long* total_hits,
+                                  unsigned long long* keys, float* wts);
+// exact[cam * nsv + c], count[...] <- sequential fp32 sum / number of the sorted votes of voxel c of camera cam; stats
+// (optional): [0] = max float bits of |grid_cam[vox[c]] - exact| / max(1, |exact|), [1] = max votes
+hipError_t launch_tie_sums2(hipStream_t s, const unsigned long long* keys, const float* wts, unsigned long long n, unsigned pos_bits,
+                            const uint32_t* vox, int nsv, int n_cams, const float* grid0, const float* grid1, float* exact,
+                            uint32_t* count, unsigned* stats);
+// per near-tie column: op(exact camera 0, exact camera 1) (op 0: one camera), first maximum, patch; stats[2] += changed pixels
+hipError_t launch_tie_pick(hipStream_t s, int op, const uint4* cols, int n_cols, const uint32_t* vox, int nsv, int npix,
+                           const float* exact, const float* planes, float* conf, uint8_t* idx, float* depth, unsigned* stats);
 int tie_tile_words_of(int nx, int ny);  // 32-bit words of tile bits per plane
 hipError_t launch_tie_mark(hipStream_t s, const uint32_t* sv, int n, uint32_t* bitmap, uint32_t* tiles, int nx, int ny);
 // every vote of the contending planes that lands on a marked voxel: keys[] <- (rank of the voxel among sv) << 32 | position of

@@ -3649,7 +3649,8 @@ __device__ __forceinline__ float tie_value(const float* __restrict__ a, const fl
 template <int OP>
 __global__ __launch_bounds__(256) void k_tie_candidates(const float* __restrict__ a, const float* __restrict__ b, int npix,
                                                         int nz, float rel_gap, unsigned* __restrict__ counters,
-                                                        uint32_t* __restrict__ cand, uint32_t cap)
+                                                        uint32_t* __restrict__ cand, uint32_t cap,
+                                                        uint4* __restrict__ cols, uint32_t cols_cap)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= npix) return;
@@ -3664,7 +3665,8 @@ __global__ __launch_bounds__(256) void k_tie_candidates(const float* __restrict_
     for (int k = 0; k < nz; ++k) cnt += tie_value<OP>(a, b, (size_t)k * npix + p) >= thr ? 1 : 0;
     if (cnt < 2) return;
     const unsigned base = atomicAdd(&counters[0], (unsigned)cnt);
-    atomicAdd(&counters[1], 1u);
+    const unsigned col = atomicAdd(&counters[1], 1u);
+    if (cols && col < cols_cap) cols[col] = make_uint4(base, (unsigned)p, (unsigned)cnt, 0u);  // (the host retries with more room)
     if ((unsigned long long)base + (unsigned)cnt > cap) return;  // the host sees counters[0] > cap and retries larger
     int j = 0;
     for (int k = 0; k < nz; ++k)  // a pixel's contenders: one contiguous run, planes ascending
@@ -3848,6 +3850,357 @@ __global__ __launch_bounds__(256) void k_tie_patch(const uint32_t* __restrict__ 
     conf[p] = new_conf[i];
     idx[p] = new_idx[i];
     depth[p] = planes[new_idx[i]];  // mapper_emvs_stereo.cpp:302-313
+}
+
+// ---- the resolver's event pass, INVERTED: (packet, contending voxel) pairs instead of (event, contending plane) pairs ----
+// k_tie_hits above walks every event over every contending plane (1 G event-planes per configs[1] camera, two IEEE
+// divides each) to find the ~0.7 % of them that reach a contending voxel.  This kernel turns the loop around: a block
+// takes a packet, bins its 1024 z0 locations by 2-D tile in LDS (counting sort), and every thread asks, for one
+// contending voxel (x, y, z) at a time, WHICH z0 locations the transfer of mapper_emvs_stereo.cpp:177-195 can take into
+// the 2 x 2 integer locations whose bilinear vote touches that voxel: X = (x0 a + bx) / d is affine in x0, so the
+// pre-image of X in [x - 1, x + 1) is an interval of x0 (widened by a rigorous bound on the fp32 rounding of both
+// directions), i.e. a few tiles of the packet.  The records of those tiles are then voted EXACTLY -- the reference's
+// operations in the reference's order, IEEE divide, accept test of cartesian3dgrid.h:255-259, weights of :261-270 --
+// so the tile test only has to be a superset.  Work: voxels x packets cheap rejections (5.5 k x 9,765 at configs[1] =
+// 54 M, against 1 G event-planes) + the few records near a voxel.
+// A (packet, plane) whose transfer is degenerate (a = 0: every event lands on one location; non-finite or extreme
+// coefficients) scans all records of the packet; d = 0 gives no finite X: no votes.
+// Output: (key, weight) records, key = rank << pos_bits | position of the vote in the reference's loop over events
+// (packet * 1024 + slot); rank = rank_base + index of the voxel in `desc`.  Slots: a block owns SEGMENTS of kTieSeg
+// records; a hit takes the next position of its block's virtual cursor (one LDS atomic), the hit that opens a segment
+// reserves it with ONE global atomic (7.5 M hits -> ~8 k global atomics; one per hit or per wave instruction
+// serialises at the memory side, see k_tie_hits) and publishes its index in LDS, where the other hits of that segment
+// wait for it.  A block pads its last segment with sentinel keys (rank = sentinel_rank, beyond every voxel's), so that
+// the array [0, segments * kTieSeg) can be sorted as it is.
+constexpr int kTieSegShift = 10;
+constexpr int kTieSeg = 1 << kTieSegShift;
+constexpr int kTieMaxSegs = 2048;  // per block: 2 M hits
+constexpr unsigned kTieSegEmpty = 0xffffffffu;
+constexpr int kTieMaxTiles = 8192;
+
+struct TiePlane {  // per (packet, plane), in LDS
+    float a, bx, by, d;  // mapper_emvs_stereo.cpp:177-182
+    float ia, qx, qy;    // z0 location of integer X: x0 = X * ia + qx (ia = d / a, qx = -bx / a), same for y
+    float hw;            // half width of the pre-image of [X - 1, X + 1) in z0 pixels, rounding included; < 0: no votes;
+                         // +inf (with ia = qx = qy = 0): scan the whole packet
+};
+
+struct TieBinGeom {
+    int shift;         // log2 of the tile side
+    int margin;        // the tiles cover [-margin, n + margin) in x and y; locations outside clamp to the border tiles
+    int tx_n, ty_n;    // tiles per row / column
+};
+
+__host__ __device__ inline TieBinGeom tie_bin_geom(int nx, int ny)
+{
+    TieBinGeom b;
+    b.margin = 32;
+    for (b.shift = 3;; ++b.shift) {
+        b.tx_n = (nx + 2 * b.margin + (1 << b.shift) - 1) >> b.shift;
+        b.ty_n = (ny + 2 * b.margin + (1 << b.shift) - 1) >> b.shift;
+        if (b.tx_n * b.ty_n <= kTieMaxTiles) break;
+    }
+    return b;
+}
+
+__device__ __forceinline__ int tie_tile_coord(float v, int margin, float inv_tile, int n_tiles)
+{
+    // monotone in v (add, multiply by a positive constant, floor, clamp): lo <= v <= hi implies tile(lo) <= tile(v) <= tile(hi)
+    const float t = __builtin_floorf((v + (float)margin) * inv_tile);
+    return (int)fminf(fmaxf(t, 0.f), (float)(n_tiles - 1));
+}
+
+struct TieOut {
+    unsigned* s_vpos;          // LDS: the block's virtual cursor
+    unsigned* s_seg;           // LDS: segment table [kTieMaxSegs]
+    unsigned* seg_counter;     // global: segments handed out
+    unsigned* flags;           // global: bit 0 = a block ran out of table entries, bit 1 = out of segments (cap)
+    unsigned cap_segs;
+    unsigned long long* keys;
+    float* wts;
+};
+
+__device__ __forceinline__ void tie_emit(const TieOut& o, unsigned long long key, float w)
+{
+    const unsigned vp = atomicAdd(o.s_vpos, 1u);  // (LDS)
+    const unsigned j = vp >> kTieSegShift, off = vp & (unsigned)(kTieSeg - 1);
+    if (j >= (unsigned)kTieMaxSegs) {
+        atomicOr(o.flags, 1u);
+        return;
+    }
+    // step 1, all lanes of the wave that hit: the lane that opens a segment reserves and publishes it ...
+    if (off == 0u) {
+        const unsigned b = atomicAdd(o.seg_counter, 1u);
+        __hip_atomic_store(&o.s_seg[j], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    // ... step 2: everybody reads it.  A lane can only wait here for a lane of ANOTHER wave (one of its own wave has
+    // finished step 1 before any lane starts step 2), and that lane depends on nobody.
+    unsigned b;
+    while ((b = __hip_atomic_load(&o.s_seg[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == kTieSegEmpty)
+        __builtin_amdgcn_s_sleep(1);
+    if (b >= o.cap_segs) {
+        atomicOr(o.flags, 2u);
+        return;
+    }
+    const size_t at = ((size_t)b << kTieSegShift) + off;
+    o.keys[at] = key;
+    o.wts[at] = w;
+}
+
+// dynamic LDS: rec_x[1024] rec_y[1024] (f32) | rec_slot[1024] (u32) | tile_start[tiles + 1] (u32) | TiePlane[nz] |
+// seg[kTieMaxSegs] (u32)
+__host__ __device__ inline size_t tie_hits_lds_bytes(int tiles, int nz)
+{
+    return (size_t)kPacket * 12 + (size_t)(tiles + 1) * 4 + (size_t)nz * sizeof(TiePlane) + (size_t)kTieMaxSegs * 4;
+}
+
+__global__ __launch_bounds__(256) void k_tie_hits_binned(const float2* __restrict__ xy, const float* __restrict__ centers,
+                                                         const float* __restrict__ planes, Geom g, int np,
+                                                         const uint2* __restrict__ desc, int nsv, unsigned rank_base,
+                                                         unsigned pos_bits, unsigned sentinel_rank, TieBinGeom bg,
+                                                         unsigned* __restrict__ seg_counter, unsigned cap_segs,
+                                                         unsigned* __restrict__ flags,
+                                                         unsigned long long* __restrict__ total_hits,
+                                                         unsigned long long* __restrict__ keys, float* __restrict__ wts)
+{
+    extern __shared__ unsigned char s_raw[];
+    __shared__ unsigned s_vpos;
+    __shared__ unsigned s_wave_tot[4];
+    float* rec_x = reinterpret_cast<float*>(s_raw);
+    float* rec_y = rec_x + kPacket;
+    unsigned* rec_slot = reinterpret_cast<unsigned*>(rec_y + kPacket);
+    const int tiles = bg.tx_n * bg.ty_n;
+    unsigned* tstart = rec_slot + kPacket;  // [tiles + 1]
+    TiePlane* tp = reinterpret_cast<TiePlane*>(tstart + tiles + 1);
+    unsigned* s_seg = reinterpret_cast<unsigned*>(tp + g.nz);
+    const int tid = threadIdx.x;
+    const float inv_tile = 1.f / (float)(1 << bg.shift);
+    const float xmax = (float)(g.nx - 1), ymax = (float)(g.ny - 1);
+    TieOut out{&s_vpos, s_seg, seg_counter, flags, cap_segs, keys, wts};
+    if (tid == 0) s_vpos = 0u;
+    for (int i = tid; i < kTieMaxSegs; i += 256) s_seg[i] = kTieSegEmpty;
+
+    for (int k = blockIdx.x; k < np; k += gridDim.x) {
+        __syncthreads();  // the previous packet's voxel loop has left the tables
+        for (int i = tid; i <= tiles; i += 256) tstart[i] = 0u;
+        {
+            const float cx_ = centers[3 * k], cy_ = centers[3 * k + 1], cz_ = centers[3 * k + 2];
+            for (int z = tid; z < g.nz; z += 256) {
+                TiePlane P;
+                plane_coefficients(cx_, cy_, cz_, planes[z], g, P.a, P.bx, P.by, P.d);
+                P.ia = P.d / P.a;
+                P.qx = -P.bx / P.a;
+                P.qy = -P.by / P.a;
+                // |X~ - X| <= 3u (nx + 2 |bx / d| + 1), the centre x * ia + qx is off by <= 6u (nx + |bx / d|) |ia|, u = 2^-24:
+                // 2^-16 (...) is more than 16 times their sum
+                const float beta = fabsf(P.bx / P.d) + fabsf(P.by / P.d);
+                const float delta = 1.52587890625e-5f * ((float)(g.nx + g.ny + 2) + beta);
+                P.hw = fabsf(P.ia) * (1.f + delta) * 1.001f + 1e-6f;
+                const bool finite = __builtin_isfinite(P.a) && __builtin_isfinite(P.bx) && __builtin_isfinite(P.by) &&
+                                    __builtin_isfinite(P.d);
+                if (finite && P.d == 0.f) {
+                    P.hw = -1.f;  // n / 0 is +-inf or NaN: no event is accepted on this plane
+                } else if (!finite || !__builtin_isfinite(P.hw) || !__builtin_isfinite(P.qx) || !__builtin_isfinite(P.qy) ||
+                           !__builtin_isfinite(beta) || !(fabsf(P.ia) >= 1e-6f && fabsf(P.ia) <= 1e6f) || !(delta < 0.5f)) {
+                    P.ia = P.qx = P.qy = 0.f;
+                    P.hw = __builtin_inff();
+                }
+                tp[z] = P;
+            }
+        }
+        // the packet's z0 locations, counted per tile; a non-finite location votes on no plane
+        float2 e[4];
+        int tile[4];
+        unsigned off[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e[i] = xy[(size_t)k * kPacket + tid + 256 * i];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = __builtin_isfinite(e[i].x) && __builtin_isfinite(e[i].y);
+            tile[i] = ok ? tie_tile_coord(e[i].y, bg.margin, inv_tile, bg.ty_n) * bg.tx_n +
+                               tie_tile_coord(e[i].x, bg.margin, inv_tile, bg.tx_n)
+                         : -1;
+            off[i] = ok ? atomicAdd(&tstart[tile[i]], 1u) : 0u;  // (LDS)
+        }
+        __syncthreads();
+        // exclusive scan of the tile counts -> tile starts (thread t owns a contiguous stretch of tiles)
+        {
+            const int per = (tiles + 1 + 255) / 256;
+            const int t0 = tid * per, t1 = min(tiles + 1, t0 + per);
+            unsigned sum = 0u;
+            for (int t = t0; t < t1; ++t) sum += tstart[t];
+            unsigned incl = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned v = __shfl_up(incl, o, 64);
+                if ((tid & 63) >= o) incl += v;
+            }
+            if ((tid & 63) == 63) s_wave_tot[tid >> 6] = incl;
+            __syncthreads();
+            unsigned base = incl - sum;
+            for (int w = 0; w < (tid >> 6); ++w) base += s_wave_tot[w];
+            for (int t = t0; t < t1; ++t) {
+                const unsigned c = tstart[t];
+                tstart[t] = base;
+                base += c;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (tile[i] >= 0) {
+                const unsigned r = tstart[tile[i]] + off[i];
+                rec_x[r] = e[i].x;
+                rec_y[r] = e[i].y;
+                rec_slot[r] = (unsigned)(tid + 256 * i);
+            }
+        __syncthreads();
+        const unsigned n_rec = tstart[tiles];
+        // every contending voxel against this packet
+        for (int c = tid; c < nsv; c += 256) {
+            const uint2 dsc = desc[c];
+            const int vx = (int)(dsc.x & 0xffffu), vy = (int)(dsc.x >> 16), vz = (int)dsc.y;
+            const TiePlane P = tp[vz];
+            if (P.hw < 0.f) continue;
+            const float cx0 = (float)vx * P.ia + P.qx, cy0 = (float)vy * P.ia + P.qy;
+            const float xlo = cx0 - P.hw, xhi = cx0 + P.hw, ylo = cy0 - P.hw, yhi = cy0 + P.hw;
+            const int txlo = tie_tile_coord(xlo, bg.margin, inv_tile, bg.tx_n), txhi = tie_tile_coord(xhi, bg.margin, inv_tile, bg.tx_n);
+            const int tylo = tie_tile_coord(ylo, bg.margin, inv_tile, bg.ty_n), tyhi = tie_tile_coord(yhi, bg.margin, inv_tile, bg.ty_n);
+            const unsigned long long key_hi = (unsigned long long)(rank_base + (unsigned)c) << pos_bits;
+            for (int ty = tylo; ty <= tyhi; ++ty) {
+                const unsigned rb = tstart[ty * bg.tx_n + txlo], re = tstart[ty * bg.tx_n + txhi + 1];
+                for (unsigned r = rb; r < re; ++r) {
+                    const float x0 = rec_x[r], y0 = rec_y[r];
+                    // the exact pre-image test (the tiles are coarser); never true for NaN bounds -- there are none: ia, q, hw finite or hw = inf
+                    if (!(x0 >= xlo && x0 <= xhi && y0 >= ylo && y0 <= yhi)) continue;
+                    const float X = (x0 * P.a + P.bx) / P.d;  // mapper_emvs_stereo.cpp:194-195
+                    const float Y = (y0 * P.a + P.by) / P.d;
+                    if (!(X >= 0.f && Y >= 0.f && X < xmax && Y < ymax)) continue;  // cartesian3dgrid.h:255-259 (see vote_global)
+                    const int xi = (int)X, yi = (int)Y;
+                    const unsigned dx = (unsigned)(vx - xi), dy = (unsigned)(vy - yi);
+                    if (dx > 1u || dy > 1u) continue;
+                    const float fx = X - (float)xi, fy = Y - (float)yi, fx1 = 1.f - fx, fy1 = 1.f - fy;
+                    const float w = (dx ? fx : fx1) * (dy ? fy : fy1);  // :261-270: fx1*fy1, fx*fy1, fx1*fy, fx*fy
+                    tie_emit(out, key_hi | ((unsigned long long)k * kPacket + rec_slot[r]), w);
+                }
+            }
+        }
+        (void)n_rec;
+    }
+    __syncthreads();
+    // pad the last segment with sentinels; report the block's hits
+    const unsigned total = s_vpos;
+    if (total != 0u && total <= (unsigned)kTieMaxSegs * (unsigned)kTieSeg) {
+        const unsigned j = (total - 1u) >> kTieSegShift;
+        const unsigned b = s_seg[j];
+        const unsigned first = total - (j << kTieSegShift);  // records of the last segment in use: 1 .. kTieSeg
+        if (b != kTieSegEmpty && b < cap_segs)
+            for (unsigned o = first + (unsigned)tid; o < (unsigned)kTieSeg; o += 256u) {
+                keys[((size_t)b << kTieSegShift) + o] = (unsigned long long)sentinel_rank << pos_bits;
+                wts[((size_t)b << kTieSegShift) + o] = 0.f;
+            }
+    }
+    if (tid == 0 && total != 0u) atomicAdd(total_hits, (unsigned long long)total);
+}
+
+// desc[c] = (x | y << 16, z) of voxel vox[c] = z * npix + y * nx + x
+// plane_bits (optional, 8 words): bit z set for every plane that holds one of the voxels
+__global__ __launch_bounds__(256) void k_tie_desc(const uint32_t* __restrict__ vox, int n, int nx, int npix, uint2* __restrict__ desc,
+                                                  unsigned* __restrict__ plane_bits)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const uint32_t v = vox[c];
+    const uint32_t z = v / (uint32_t)npix, p = v - z * (uint32_t)npix, y = p / (uint32_t)nx, x = p - y * (uint32_t)nx;
+    desc[c] = make_uint2(x | (y << 16), z);
+    if (plane_bits && z < 256u && !((plane_bits[z >> 5] >> (z & 31u)) & 1u)) atomicOr(&plane_bits[z >> 5], 1u << (z & 31u));
+}
+
+// thread = (camera, contending voxel): its run of the sorted votes added one by one in fp32 -- resetGrid
+// (mapper_emvs_stereo.cpp:145), then "grid[i] += w" per vote in event order (cartesian3dgrid.h:261-270).  Virtual voxel
+// r = camera * nsv + c; keys = r << pos_bits | event position, sorted.  stats[0] = max over the voxels of the float bits of
+// |engine value - reference-order value| / max(1, |reference-order value|), stats[1] = max votes of a voxel
+__global__ __launch_bounds__(64) void k_tie_sums2(const unsigned long long* __restrict__ keys, const float* __restrict__ wts,
+                                                  unsigned long long n, unsigned pos_bits, const uint32_t* __restrict__ vox,
+                                                  int nsv, int n_cams, const float* __restrict__ grid0,
+                                                  const float* __restrict__ grid1, float* __restrict__ exact,
+                                                  uint32_t* __restrict__ count, unsigned* __restrict__ stats)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nsv * n_cams) return;
+    unsigned long long lo = 0, hi = n;  // first vote of virtual voxel r
+    const unsigned long long want = (unsigned long long)r << pos_bits;
+    while (lo < hi) {
+        const unsigned long long mid = (lo + hi) >> 1;
+        if (keys[mid] < want)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    const unsigned long long first = lo;
+    hi = n;  // first vote of the next one: the run's length is known before the additions, so their loads pipeline
+    const unsigned long long next = (unsigned long long)(r + 1) << pos_bits;
+    while (lo < hi) {
+        const unsigned long long mid = (lo + hi) >> 1;
+        if (keys[mid] < next)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    const unsigned long long last = lo;
+    float sum = 0.f;
+    unsigned long long i = first;
+    for (; i + 8 <= last; i += 8) {
+        float w8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w8[j] = wts[i + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += w8[j];  // one by one, in order (no reassociation: -ffp-contract=off, no fast-math)
+    }
+    for (; i < last; ++i) sum += wts[i];
+    exact[r] = sum;
+    count[r] = (uint32_t)(last - first);
+    if (stats) {
+        const int cam = r / nsv;
+        const float* grid = cam == 0 ? grid0 : grid1;
+        if (grid) {
+            const float have = grid[vox[r - cam * nsv]];
+            const float diff = fabsf(have - sum) / fmaxf(1.f, fabsf(sum));
+            atomicMax(&stats[0], __float_as_uint(diff));  // non-negative floats order like their bits (NaN: above everything)
+        }
+        atomicMax(&stats[1], (unsigned)(last - first));
+    }
+}
+
+// thread = near-tie column: camera fusion of the reference-order values (fuse_op, what k_fuse2_into computes), first
+// maximum over the column's contending planes (std::max_element, cartesian3dgrid.cpp:132-134), patch of the depth map
+// (index -> depth: mapper_emvs_stereo.cpp:302-313).  cols[j] = (first entry in vox / exact, pixel, contenders); a column's
+// contenders are contiguous there, planes ascending.  stats[2] += pixels whose plane changed
+template <int OP>
+__global__ __launch_bounds__(256) void k_tie_pick(const uint4* __restrict__ cols, int n_cols, const uint32_t* __restrict__ vox,
+                                                  int nsv, int npix, const float* __restrict__ exact,
+                                                  const float* __restrict__ planes, float* __restrict__ conf,
+                                                  uint8_t* __restrict__ idx, float* __restrict__ depth,
+                                                  unsigned* __restrict__ stats)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_cols) return;
+    const uint4 col = cols[j];
+    float best = 0.f;
+    int best_z = -1;
+    for (unsigned i = col.x; i < col.x + col.z; ++i) {
+        const float v = OP == 0 ? exact[i] : fuse_op<OP>(0.f + exact[i], exact[(size_t)nsv + i]);
+        if (best_z < 0 || best < v) {
+            best = v;
+            best_z = (int)(vox[i] / (uint32_t)npix);
+        }
+    }
+    const uint32_t p = col.y;
+    if (idx[p] != (uint8_t)best_z) atomicAdd(&stats[2], 1u);
+    conf[p] = best;
+    idx[p] = (uint8_t)best_z;
+    depth[p] = planes[best_z];
 }
 
 int grid_for(size_t work_items, int block, int max_blocks = 256 * 8)
@@ -4480,19 +4833,72 @@ hipError_t launch_div_probe(hipStream_t s, const float* n, const float* d, size_
 }
 
 hipError_t launch_tie_candidates(hipStream_t s, const float* a, const float* b, int op, int npix, int nz, float rel_gap,
-                                 unsigned* counters, uint32_t* cand, uint32_t cap)
+                                 unsigned* counters, uint32_t* cand, uint32_t cap, uint4* cols, uint32_t cols_cap)
 {
     const dim3 grid((npix + 255) / 256), block(256);
+#define DSI_TIE_CAND(OPV)                                                                                                   \
+    case OPV:                                                                                                               \
+        hipLaunchKernelGGL(k_tie_candidates<OPV>, grid, block, 0, s, a, b, npix, nz, rel_gap, counters, cand, cap, cols, cols_cap); \
+        break;
     switch (b ? op : 0) {
-    case 0: hipLaunchKernelGGL(k_tie_candidates<0>, grid, block, 0, s, a, b, npix, nz, rel_gap, counters, cand, cap); break;
-    case 1: hipLaunchKernelGGL(k_tie_candidates<1>, grid, block, 0, s, a, b, npix, nz, rel_gap, counters, cand, cap); break;
-    case 2: hipLaunchKernelGGL(k_tie_candidates<2>, grid, block, 0, s, a, b, npix, nz, rel_gap, counters, cand, cap); break;
-    case 3: hipLaunchKernelGGL(k_tie_candidates<3>, grid, block, 0, s, a, b, npix, nz, rel_gap, counters, cand, cap); break;
-    case 4: hipLaunchKernelGGL(k_tie_candidates<4>, grid, block, 0, s, a, b, npix, nz, rel_gap, counters, cand, cap); break;
-    case 5: hipLaunchKernelGGL(k_tie_candidates<5>, grid, block, 0, s, a, b, npix, nz, rel_gap, counters, cand, cap); break;
-    case 6: hipLaunchKernelGGL(k_tie_candidates<6>, grid, block, 0, s, a, b, npix, nz, rel_gap, counters, cand, cap); break;
+        DSI_TIE_CAND(0) DSI_TIE_CAND(1) DSI_TIE_CAND(2) DSI_TIE_CAND(3) DSI_TIE_CAND(4) DSI_TIE_CAND(5) DSI_TIE_CAND(6)
     default: return hipErrorInvalidValue;
     }
+#undef DSI_TIE_CAND
+    return hipExtGetLastError();
+}
+
+hipError_t launch_tie_desc(hipStream_t s, const uint32_t* vox, int n, int nx, int npix, uint2* desc, unsigned* plane_bits)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_tie_desc, dim3((n + 255) / 256), dim3(256), 0, s, vox, n, nx, npix, desc, plane_bits);
+    return hipExtGetLastError();
+}
+
+int tie_segment_records() { return kTieSeg; }
+
+hipError_t launch_tie_hits_binned(hipStream_t s, const float2* xy, const float* centers, const float* planes, const Geom& g, int np,
+                                  const uint2* desc, int nsv, unsigned rank_base, unsigned pos_bits, unsigned sentinel_rank,
+                                  unsigned* seg_counter, unsigned cap_segs, unsigned* flags, unsigned long long* total_hits,
+                                  unsigned long long* keys, float* wts)
+{
+    if (np <= 0 || nsv <= 0) return hipSuccess;
+    const TieBinGeom bg = tie_bin_geom(g.nx, g.ny);
+    const size_t lds = tie_hits_lds_bytes(bg.tx_n * bg.ty_n, g.nz);
+    if (lds > max_dynamic_lds() || g.nx > 0xffff || g.ny > 0xffff) return hipErrorInvalidValue;
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(k_tie_hits_binned), lds)) return e;
+    // blocks take packets in turn (the order of the hits does not matter: they are sorted); as many as fit the chip
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, max_dynamic_lds() / lds));
+    const int blocks = std::min(np, 256 * per_cu);
+    hipLaunchKernelGGL(k_tie_hits_binned, dim3(blocks), dim3(256), lds, s, xy, centers, planes, g, np, desc, nsv, rank_base, pos_bits,
+                       sentinel_rank, bg, seg_counter, cap_segs, flags, total_hits, keys, wts);
+    return hipExtGetLastError();
+}
+
+hipError_t launch_tie_sums2(hipStream_t s, const unsigned long long* keys, const float* wts, unsigned long long n, unsigned pos_bits,
+                            const uint32_t* vox, int nsv, int n_cams, const float* grid0, const float* grid1, float* exact,
+                            uint32_t* count, unsigned* stats)
+{
+    if (nsv <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_tie_sums2, dim3((nsv * n_cams + 63) / 64), dim3(64), 0, s, keys, wts, n, pos_bits, vox, nsv, n_cams, grid0,
+                       grid1, exact, count, stats);
+    return hipExtGetLastError();
+}
+
+hipError_t launch_tie_pick(hipStream_t s, int op, const uint4* cols, int n_cols, const uint32_t* vox, int nsv, int npix,
+                           const float* exact, const float* planes, float* conf, uint8_t* idx, float* depth, unsigned* stats)
+{
+    if (n_cols <= 0) return hipSuccess;
+    const dim3 grid((n_cols + 255) / 256), block(256);
+#define DSI_TIE_PICK(OPV)                                                                                                        \
+    case OPV:                                                                                                                    \
+        hipLaunchKernelGGL(k_tie_pick<OPV>, grid, block, 0, s, cols, n_cols, vox, nsv, npix, exact, planes, conf, idx, depth, stats); \
+        break;
+    switch (op) {
+        DSI_TIE_PICK(0) DSI_TIE_PICK(1) DSI_TIE_PICK(2) DSI_TIE_PICK(3) DSI_TIE_PICK(4) DSI_TIE_PICK(5) DSI_TIE_PICK(6)
+    default: return hipErrorInvalidValue;
+    }
+#undef DSI_TIE_PICK
     return hipExtGetLastError();
 }
 

@@ -39,7 +39,7 @@ extern "C" {
 #define DSI_API
 #endif
 
-#define DSI_ENGINE_ABI_VERSION 7
+#define DSI_ENGINE_ABI_VERSION 8
 #define DSI_PACKET_SIZE 1024 /* mapper_emvs_stereo.hpp:152 packet_size_ */
 
 typedef enum {
@@ -440,27 +440,30 @@ DSI_API int dsi_mapper_argmax_keys_download(dsi_mapper_t *m, uint64_t *keys_host
 DSI_API int dsi_mapper_argmax_keys_upload(dsi_mapper_t *m, const uint64_t *keys_host);
 DSI_API int dsi_mapper_depth_map_from_keys(dsi_mapper_t *m);
 
-/* Exact tie resolver: makes the arg-max index map identical to the reference's on EVERY pixel.
+/* Exact tie resolver: makes the arg-max index map the reference's on every pixel -- VERIFIED EMPIRICALLY per call, not
+ * guaranteed a priori (see premise_ok).
  * The engine sums a voxel's votes exactly (64-bit fixed point, rounded once); the reference adds them in fp32 in event
  * order, rounding after every vote (cartesian3dgrid.h:261-270 inside mapper_emvs_stereo.cpp:197-201).  The two sums
  * agree to ~1e-5, so the first-maximum plane (cartesian3dgrid.cpp:132-134) can differ only in columns whose best
  * planes are closer than that -- and there the depth is off by a whole plane.  This call finds the columns of the
  * fused DSI  op(grid(mappers[0]), grid(mappers[1]))  (n == 1: of grid(mappers[0])) that have two or more planes within
- * rel_gap of the column's maximum, re-sums exactly those voxels of every camera in the REFERENCE's order (one pass
- * over the batch's events on the contending planes: the reference's coordinates, accept test and weights; the
- * recorded votes sorted by event index and added one by one in fp32), re-applies the fusion op, re-picks the first
- * maximum and patches confidence / index / depth in `out`'s depth-map buffers.
+ * rel_gap of the column's maximum, re-sums exactly those voxels of every camera in the REFERENCE's order (per camera
+ * one pass that asks, per packet and contending voxel, which events the plane transfer takes into the voxel's 2 x 2
+ * neighbourhood and votes those with the reference's coordinates, accept test and weights; the recorded votes sorted
+ * by (voxel, event index) and added one by one in fp32), re-applies the fusion op, re-picks the first maximum and
+ * patches confidence / index / depth in `out`'s depth-map buffers -- all on the device; the host reads counters only.
  * Preconditions: grid(mappers[i]) holds dsi_mapper_evaluate_batch(mappers[i], batches[i]); `out` holds the depth map
  * of that fusion (dsi_mapper_depth_map_of / _of_fusion / _of_events).  n = 1 or 2; op = dsi_fuse_op_t.
  * rel_gap 0 = 2.5e-4: 15x the largest difference ever observed between the two summation orders (1.6e-5) and 2.5x the
- * tolerance every voxel of every parity test is held to.  The call checks its own premise: max_order_diff is the
- * largest |engine value - reference-order value| / max(1, value) over the voxels it re-summed -- the most-voted voxels
- * of the volume are among them -- and must stay far below rel_gap / 2 (the tests assert 8x); max_rel_bound is the
- * rigorous worst case (votes - 1) * 2^-24 for the same voxels.  Optional and off the throughput path: two event
- * passes per camera over the contending planes, a device sort of the recorded votes and one thread per voxel adding
- * them up (elapsed_ms).  Synchronises. */
+ * tolerance every voxel of every parity test is held to.  The rigorous worst case of a voxel, (votes - 1) * 2^-24
+ * (max_rel_bound), EXCEEDS that gap for voxels with more than ~4,200 votes, so the gap is a premise, and the call
+ * checks it: max_order_diff is the largest |engine value - reference-order value| / max(1, value) over the voxels it
+ * re-summed -- the column maxima of the near-tie columns, the most-voted voxels of the volume among them.  If it reaches
+ * rel_gap / 8 the pass is repeated with a four times wider gap (gap_widenings, at most 3); premise_ok = 0 when even the
+ * last pass did not hold it: the call still returns DSI_OK, the caller decides.  Optional and off the throughput path
+ * (elapsed_ms).  Synchronises. */
 typedef struct {
-    float rel_gap;          /* in */
+    float rel_gap;          /* in (0 = 2.5e-4); out: the gap of the last pass (wider than asked for after gap_widenings) */
     int near_tie_pixels;    /* out: columns with >= 2 contending planes */
     int candidate_voxels;   /*      contending voxels re-summed (per camera) */
     int candidate_planes;   /*      distinct planes among them */
@@ -469,6 +472,9 @@ typedef struct {
     double max_rel_bound;   /*      see above */
     double max_order_diff;  /*      see above */
     float elapsed_ms;       /*      wall time of the call */
+    int gap_widenings;      /*      passes repeated with a 4 x wider gap because max_order_diff reached rel_gap / 8 (0..3) */
+    int premise_ok;         /*      1: 8 * max_order_diff < rel_gap held in the last pass.  0: it did not even at the widest gap
+                                    tried -- the index map is then NOT known to equal the reference's */
 } dsi_resolve_info_t;
 DSI_API int dsi_mapper_resolve_near_ties(dsi_mapper_t *out, dsi_mapper_t *const *mappers,
                                          const dsi_batch_t *const *batches, int n, int op, dsi_resolve_info_t *info);
