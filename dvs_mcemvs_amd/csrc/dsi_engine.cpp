@@ -191,12 +191,22 @@ struct TieScratch {
     // [6] changed pixels (k_tie_pick); [8..9] one 64-bit word: real votes recorded; [16..23] planes with a contender (k_tie_desc)
     DevBuf<unsigned long long> counters;
     DevBuf<unsigned long long> keys, keys2;
-    DevBuf<float> w, w2, exact;
+    DevBuf<float> w, w2, exact, diff;
     DevBuf<char> tmp;
+    unsigned* host = nullptr;  // page-locked copy of the counters: the three reads of a call are plain DMAs
+    hipError_t host_counters(unsigned** out)
+    {
+        if (!host)
+            if (hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&host), 64 * sizeof(unsigned), hipHostMallocDefault)) return e;
+        *out = host;
+        return hipSuccess;
+    }
     void release()
     {
+        if (host) (void)hipHostFree(host);
+        host = nullptr;
         cand.release(); count.release(); desc.release(); cols.release(); counters.release();
-        keys.release(); keys2.release(); w.release(); w2.release(); exact.release(); tmp.release();
+        keys.release(); keys2.release(); w.release(); w2.release(); exact.release(); diff.release(); tmp.release();
     }
 };
 
@@ -1772,9 +1782,14 @@ static int tie_exact_values_dev(TieScratch& ts, hipStream_t st, dsi_mapper* cons
                                                 (unsigned)c * (unsigned)nsv, pos_bits, sentinel, cnt + 2, cap_segs, cnt + 3,
                                                 ts.counters.p + 4, ts.keys.p, ts.w.p));
         }
-        HIP_TRY(hipMemcpyAsync(host_cnt, cnt + 2, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(host_cnt + 2, ts.counters.p + 4, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        unsigned* pinned = nullptr;
+        HIP_TRY(ts.host_counters(&pinned));
+        HIP_TRY(hipMemcpyAsync(pinned, cnt, kTieCounterPassWords * sizeof(unsigned), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        host_cnt[0] = pinned[2];
+        host_cnt[1] = pinned[3];
+        host_cnt[2] = pinned[8];
+        host_cnt[3] = pinned[9];
         REQUIRE(!(host_cnt[1] & 1u), DSI_ERR_INVALID, "a workgroup recorded more than 2 M votes: too many voxels asked for");
         if (!(host_cnt[1] & 2u)) break;
         REQUIRE(attempt == 0, DSI_ERR_INVALID, "the vote count changed between two passes");
@@ -1795,9 +1810,10 @@ static int tie_exact_values_dev(TieScratch& ts, hipStream_t st, dsi_mapper* cons
         keys_sorted = ts.keys2.p;
         w_sorted = ts.w2.p;
     }
+    if (grid_stats) HIP_TRY(ts.diff.reserve((size_t)n * nsv));
     HIP_TRY(dsi::launch_tie_sums2(st, keys_sorted, w_sorted, n_rec, pos_bits, ts.cand.p, nsv, n, grid_stats ? ms[0]->grid->data : nullptr,
                                   grid_stats && n > 1 ? ms[1]->grid->data : nullptr, ts.exact.p, ts.count.p,
-                                  grid_stats ? cnt + 4 : nullptr));
+                                  grid_stats ? ts.diff.p : nullptr));
     return DSI_OK;
 }
 
@@ -1818,8 +1834,12 @@ static int tie_candidates_dev(TieScratch& ts, hipStream_t st, const float* a, co
         unsigned* d_cnt = reinterpret_cast<unsigned*>(ts.counters.p);
         HIP_TRY(dsi::launch_tie_candidates(st, a, b, op, npix, nz, rel_gap, d_cnt, ts.cand.p, (uint32_t)std::min<size_t>(cap, 0xffffffffu),
                                            ts.cols.p, (uint32_t)std::min<size_t>(cols_cap, 0xffffffffu)));
-        HIP_TRY(hipMemcpyAsync(counters, d_cnt, sizeof counters, hipMemcpyDeviceToHost, st));
+        unsigned* pinned = nullptr;
+        HIP_TRY(ts.host_counters(&pinned));
+        HIP_TRY(hipMemcpyAsync(pinned, d_cnt, sizeof counters, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        counters[0] = pinned[0];
+        counters[1] = pinned[1];
         if (counters[0] <= cap && counters[1] <= cols_cap) break;
         REQUIRE(cap < nvox || cols_cap < (size_t)npix, DSI_ERR_INVALID, "more contending voxels than voxels");
         cap = std::min<size_t>(nvox, std::max<size_t>(cap, counters[0]));
@@ -1885,15 +1905,17 @@ int dsi_mapper_resolve_near_ties(dsi_mapper_t* out, dsi_mapper_t* const* mappers
         // 4. fuse, first maximum per column, patch (device)
         if (int rc = depth_buffers_acquire(out)) return rc;
         unsigned* cnt = reinterpret_cast<unsigned*>(ts.counters.p);
-        HIP_TRY(dsi::launch_tie_pick(st, n == 2 ? op : 0, ts.cols.p, (int)n_columns, ts.cand.p, (int)n_cand, npix, ts.exact.p, out->planes_dev,
-                                     out->conf.p, out->idx.p, out->depth.p, cnt + 4));
+        HIP_TRY(dsi::launch_tie_pick(st, n == 2 ? op : 0, ts.cols.p, (int)n_columns, ts.cand.p, (int)n_cand, npix, ts.exact.p, ts.count.p,
+                                     ts.diff.p, out->planes_dev, out->conf.p, out->idx.p, out->depth.p, cnt + 4));
         if (int rc = depth_buffers_ready(out)) return rc;
-        unsigned stats[3] = {0, 0, 0}, plane_bits[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        HIP_TRY(hipMemcpyAsync(stats, cnt + 4, sizeof stats, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(plane_bits, cnt + kTieCounterPassWords, sizeof plane_bits, hipMemcpyDeviceToHost, st));
+        unsigned stats[3] = {0, 0, 0};
+        unsigned* pinned = nullptr;
+        HIP_TRY(ts.host_counters(&pinned));
+        HIP_TRY(hipMemcpyAsync(pinned, cnt, kTieCounterWords * sizeof(unsigned), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        std::memcpy(stats, pinned + 4, sizeof stats);
         info->candidate_planes = 0;
-        for (unsigned wbits : plane_bits) info->candidate_planes += __builtin_popcount(wbits);
+        for (int wd = 0; wd < kTieCounterWords - kTieCounterPassWords; ++wd) info->candidate_planes += __builtin_popcount(pinned[kTieCounterPassWords + wd]);
         float diff = 0.f;
         std::memcpy(&diff, &stats[0], sizeof diff);
         info->max_order_diff = std::max(info->max_order_diff, (double)diff);

@@ -198,9 +198,9 @@ hipError_t launch_mean_square(hipStream_t s, const float* dsi, size_t n, double*
 // cand[<= cap] <- voxel indices (z * npix + p) of every plane whose value is within rel_gap of its column's maximum, for
 // the columns that have >= 2 such planes, a column's run contiguous and ascending in z; counters[0] = voxels (may exceed
 // cap: nothing beyond cap is written), counters[1] = columns.  b == nullptr: the values of `a`; else op(a, b)
-// cols (optional, <= cols_cap entries) <- per near-tie column (first entry of its run in cand, pixel, contenders, 0)
+// cols (<= cols_cap entries) <- per near-tie column (first entry of its run in cand, pixel, contenders, 0).  nz <= 256
 hipError_t launch_tie_candidates(hipStream_t s, const float* a, const float* b, int op, int npix, int nz, float rel_gap,
-                                 unsigned* counters, uint32_t* cand, uint32_t cap, uint4* cols = nullptr, uint32_t cols_cap = 0);
+                                 unsigned* counters, uint32_t* cand, uint32_t cap, uint4* cols, uint32_t cols_cap);
 // desc[c] <- (x | y << 16, z) of voxel vox[c]; plane_bits (optional, 8 zeroed words): bit z <- plane z holds one of them
 hipError_t launch_tie_desc(hipStream_t s, const uint32_t* vox, int n, int nx, int npix, uint2* desc, unsigned* plane_bits);
 // The resolver's event pass, inverted (see k_tie_hits_binned): every vote of the batch that lands on one of the voxels
@@ -214,29 +214,20 @@ hipError_t launch_tie_hits_binned(hipStream_t s, const float2* xy, const float* 
                                   const uint2* desc, int nsv, unsigned rank_base, unsigned pos_bits, unsigned sentinel_rank,
                                   unsigned* seg_counter, unsigned cap_segs, unsigned* flags, unsigned long long* total_hits,
                                   unsigned long long* keys, float* wts);
-// exact[cam * nsv + c], count[...] <- sequential fp32 sum / number of the sorted votes of voxel c of camera cam; stats
-// (optional): [0] = max float bits of |grid_cam[vox[c]] - exact| / max(1, |exact|), [1] = max votes
+// exact[cam * nsv + c], count[...] <- sequential fp32 sum / number of the sorted votes of voxel c of camera cam; diff[...]
+// (optional; needs grid0 (and grid1 for two cameras)) <- |grid_cam[vox[c]] - exact| / max(1, |exact|)
 hipError_t launch_tie_sums2(hipStream_t s, const unsigned long long* keys, const float* wts, unsigned long long n, unsigned pos_bits,
                             const uint32_t* vox, int nsv, int n_cams, const float* grid0, const float* grid1, float* exact,
-                            uint32_t* count, unsigned* stats);
-// per near-tie column: op(exact camera 0, exact camera 1) (op 0: one camera), first maximum, patch; stats[2] += changed pixels
+                            uint32_t* count, float* diff);
+// per near-tie column: op(exact camera 0, exact camera 1) (op 0: one camera), first maximum, patch; stats[0] = max float bits
+// of diff, [1] = max count, [2] += changed pixels
 hipError_t launch_tie_pick(hipStream_t s, int op, const uint4* cols, int n_cols, const uint32_t* vox, int nsv, int npix,
-                           const float* exact, const float* planes, float* conf, uint8_t* idx, float* depth, unsigned* stats);
-int tie_tile_words_of(int nx, int ny);  // 32-bit words of tile bits per plane
-hipError_t launch_tie_mark(hipStream_t s, const uint32_t* sv, int n, uint32_t* bitmap, uint32_t* tiles, int nx, int ny);
-// every vote of the contending planes that lands on a marked voxel: keys[] <- (rank of the voxel among sv) << 32 | position of
-// the vote in the reference's loop over events (packet * 1024 + slot), wts[] <- the bilinear weight the reference adds
-// (cartesian3dgrid.h:261-270).  keys == nullptr: count only
-hipError_t launch_tie_hits(hipStream_t s, const float2* xy, const float* centers, const float* planes, const Geom& g, int np,
-                           const int* zlist, int nzl, const uint32_t* bitmap, const uint32_t* tiles, const uint32_t* sv, int nsv,
-                           unsigned long long* hit_counter, unsigned long long* keys, float* wts, unsigned long long cap);
+                           const float* exact, const uint32_t* count, const float* diff, const float* planes, float* conf,
+                           uint8_t* idx, float* depth, unsigned* stats);
 // (key, weight) pairs sorted by key on the device (rocPRIM radix sort over the low key_bits bits; dsi_tie_sort.hip).
 // tmp == nullptr: *tmp_bytes <- the scratch the sort needs
 hipError_t tie_sort_pairs(hipStream_t s, unsigned long long* keys_in, unsigned long long* keys_out, float* w_in, float* w_out,
                           size_t n, unsigned key_bits, void* tmp, size_t* tmp_bytes);
-// per contending voxel: its sorted votes added one by one in fp32, their number, and the engine's own value grid[sv[c]]
-hipError_t launch_tie_sums(hipStream_t s, const unsigned long long* keys, const float* wts, unsigned long long n,
-                           const uint32_t* sv, int nsv, const float* grid, float* exact, uint32_t* count, float* gpu);
 hipError_t launch_tie_patch(hipStream_t s, const uint32_t* pix, const uint8_t* new_idx, const float* new_conf, int n,
                             const float* planes, float* conf, uint8_t* idx, float* depth);
 

@@ -3632,13 +3632,14 @@ __global__ void k_div_probe(const float* __restrict__ n, const float* __restrict
 // fp32, in event order, rounding after every vote (cartesian3dgrid.h:261-270 inside mapper_emvs_stereo.cpp:197-201).
 // Both are within ~1e-5 of each other, so the arg-max over Z can differ only where a column's two best planes are
 // closer than that.  For those columns the resolver re-sums the contending voxels in the REFERENCE's order:
-//   k_tie_candidates   per pixel: planes whose (fused) value lies within rel_gap of the column's maximum, if >= 2
-//   k_tie_mark         one bit per contending voxel
-//   k_tie_hits         every event x contending plane: the reference's coordinates (IEEE divide), accept test and
-//                      four weights, as k_vote_global computes them; a vote that lands on a marked voxel is recorded
-//                      as (voxel, event order, weight)
-// the host sorts the records by (voxel, event order), adds them up in fp32 one by one, applies the camera fusion and
-// picks the first maximum (cartesian3dgrid.cpp:132-134); k_tie_patch writes the few changed pixels.
+//   k_tie_columns      per pixel: does the column have >= 2 planes within rel_gap of its maximum (one streaming sweep)
+//   k_tie_contenders   wave = such a column, lane = plane: the contending voxels
+//   k_tie_hits_binned  every (packet, contending voxel): the events the plane transfer takes into the voxel's 2 x 2
+//                      neighbourhood, voted with the reference's coordinates (IEEE divide), accept test and weights;
+//                      a vote is recorded as (voxel, event order, weight)
+//   (device sort)      by (camera, voxel, event order)
+//   k_tie_sums2        thread = voxel: its votes added one by one in fp32
+//   k_tie_pick         thread = column: camera fusion, first maximum (cartesian3dgrid.cpp:132-134), patch
 template <int OP>
 __device__ __forceinline__ float tie_value(const float* __restrict__ a, const float* __restrict__ b, size_t i)
 {
@@ -3646,197 +3647,109 @@ __device__ __forceinline__ float tie_value(const float* __restrict__ a, const fl
     return fuse_op<OP>(0.f + a[i], b[i]);  // as k_collapse_max_z_fused / k_fuse2_into compute the fused voxel
 }
 
+// (1) thread = pixel, ONE streaming sweep over the column(s): the largest and second largest (fused) value; a column has
+// >= 2 planes within rel_gap of its maximum iff the second largest is one of them.  The near-tie columns' pixels and maxima go
+// to cols[] (x = pixel, y = float bits of the maximum), slots reserved per workgroup; counters[1] = their number (it keeps
+// counting beyond cols_cap: the host retries with more room).
 template <int OP>
-__global__ __launch_bounds__(256) void k_tie_candidates(const float* __restrict__ a, const float* __restrict__ b, int npix,
-                                                        int nz, float rel_gap, unsigned* __restrict__ counters,
-                                                        uint32_t* __restrict__ cand, uint32_t cap,
-                                                        uint4* __restrict__ cols, uint32_t cols_cap)
+__global__ __launch_bounds__(256) void k_tie_columns(const float* __restrict__ a, const float* __restrict__ b, int npix, int nz,
+                                                     float rel_gap, unsigned* __restrict__ counters, uint4* __restrict__ cols,
+                                                     uint32_t cols_cap)
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= npix) return;
-    float best = tie_value<OP>(a, b, p);
-    for (int k = 1; k < nz; ++k) {
-        const float v = tie_value<OP>(a, b, (size_t)k * npix + p);
-        if (best < v) best = v;
-    }
-    if (!(best > 0.f)) return;  // an empty column is exactly zero in either summation order
-    const float thr = best - rel_gap * best;
-    int cnt = 0;
-    for (int k = 0; k < nz; ++k) cnt += tie_value<OP>(a, b, (size_t)k * npix + p) >= thr ? 1 : 0;
-    if (cnt < 2) return;
-    const unsigned base = atomicAdd(&counters[0], (unsigned)cnt);
-    const unsigned col = atomicAdd(&counters[1], 1u);
-    if (cols && col < cols_cap) cols[col] = make_uint4(base, (unsigned)p, (unsigned)cnt, 0u);  // (the host retries with more room)
-    if ((unsigned long long)base + (unsigned)cnt > cap) return;  // the host sees counters[0] > cap and retries larger
-    int j = 0;
-    for (int k = 0; k < nz; ++k)  // a pixel's contenders: one contiguous run, planes ascending
-        if (tie_value<OP>(a, b, (size_t)k * npix + p) >= thr) cand[base + j++] = (uint32_t)((size_t)k * npix + p);
-}
-
-// tiles: one bit per (plane, 8 x 8 pixel tile) that holds the integer location (xi, yi) of a vote which can reach a
-// contending voxel (x, y): xi in {x - 1, x}, yi in {y - 1, y} -- k_tie_hits looks its four voxels up only for those
-constexpr int kTieTile = 3;  // log2 of the tile side
-__host__ __device__ inline int tie_tiles_x(int nx) { return (nx + (1 << kTieTile) - 1) >> kTieTile; }
-__host__ __device__ inline int tie_tile_words(int nx, int ny)
-{
-    return (tie_tiles_x(nx) * ((ny + (1 << kTieTile) - 1) >> kTieTile) + 31) / 32;
-}
-
-__global__ __launch_bounds__(256) void k_tie_mark(const uint32_t* __restrict__ sv, int n, uint32_t* __restrict__ bitmap,
-                                                  uint32_t* __restrict__ tiles, int nx, int ny)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t v = sv[i];
-    atomicOr(&bitmap[v >> 5], 1u << (v & 31u));
-    if (!tiles) return;
-    const uint32_t npix = (uint32_t)nx * (uint32_t)ny;
-    const int z = (int)(v / npix), p = (int)(v - (uint32_t)z * npix), y = p / nx, x = p - y * nx;
-    const int tx = tie_tiles_x(nx), tw = tie_tile_words(nx, ny);
-    for (int dy = -1; dy <= 0; ++dy)
-        for (int dx = -1; dx <= 0; ++dx) {
-            const int xi = x + dx, yi = y + dy;
-            if (xi < 0 || yi < 0) continue;
-            const int t = (yi >> kTieTile) * tx + (xi >> kTieTile);
-            atomicOr(&tiles[(size_t)z * tw + (t >> 5)], 1u << (t & 31));
-        }
-}
-
-// block = (packet, group of kVgPlanes contending planes); thread t owns events t, t + 256, ... of the packet
-__global__ __launch_bounds__(256) void k_tie_hits(const float2* __restrict__ xy, const float* __restrict__ centers,
-                                                  const float* __restrict__ planes, Geom g, const int* __restrict__ zlist,
-                                                  int nzl, const uint32_t* __restrict__ bitmap,
-                                                  const uint32_t* __restrict__ tiles, int tile_words,
-                                                  const uint32_t* __restrict__ sv, int nsv,
-                                                  unsigned long long* __restrict__ hit_counter,
-                                                  unsigned long long* __restrict__ keys, float* __restrict__ wts,
-                                                  unsigned long long cap)
-{
-    // Output slots: the block walks its (packet, planes) TWICE -- first counting its hits in LDS, then, after ONE global
-    // atomic has reserved its range, writing them (slots within the range from the same LDS counter).  Millions of
-    // atomics on one global address (one per hit, or even one per wave instruction) serialise at the L2 and cost far
-    // more than redoing the arithmetic.
-    __shared__ unsigned s_count;
-    __shared__ unsigned long long s_base;
-    extern __shared__ uint32_t s_tiles[];  // the tile bits of this block's planes (tile_words > 0)
-    const int k = blockIdx.x;
-    const int lbeg = blockIdx.y * kVgPlanes;
-    const int lend = min(nzl, lbeg + kVgPlanes);
-    const float cx_ = centers[3 * k], cy_ = centers[3 * k + 1], cz_ = centers[3 * k + 2];
-    float2 e[4];
+    float best = 0.f, second = -__builtin_inff();
+    if (p < npix) {
+        best = tie_value<OP>(a, b, p);
+        int k = 1;
+        for (; k + 8 <= nz; k += 8) {  // eight planes' loads in flight before the arithmetic (as k_collapse_max_z streams)
+            float va[8], vb[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) e[i] = xy[(size_t)k * kPacket + threadIdx.x + 256 * i];
-    const float xmax = (float)(g.nx - 1), ymax = (float)(g.ny - 1);
-    const size_t plane_sz = (size_t)g.nx * g.ny;
-    const int tiles_x = tie_tiles_x(g.nx);
-    if (threadIdx.x == 0) s_count = 0u;
-    for (int i = threadIdx.x; i < (lend - lbeg) * tile_words; i += 256)
-        s_tiles[i] = tiles[(size_t)zlist[lbeg + i / tile_words] * tile_words + i % tile_words];
+            for (int u = 0; u < 8; ++u) {
+                va[u] = a[(size_t)(k + u) * npix + p];
+                vb[u] = OP == 0 ? 0.f : b[(size_t)(k + u) * npix + p];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float v = OP == 0 ? va[u] : fuse_op<OP>(0.f + va[u], vb[u]);
+                second = best < v ? best : (second < v ? v : second);
+                best = best < v ? v : best;
+            }
+        }
+        for (; k < nz; ++k) {
+            const float v = tie_value<OP>(a, b, (size_t)k * npix + p);
+            second = best < v ? best : (second < v ? v : second);
+            best = best < v ? v : best;
+        }
+    }
+    // (an empty column is exactly zero in either summation order)
+    const bool tie = p < npix && best > 0.f && second >= best - rel_gap * best;
+    __shared__ unsigned s_n, s_base;
+    if (threadIdx.x == 0) s_n = 0u;
     __syncthreads();
-    // bit (l - lbeg) * 4 + i: event i of this thread passed the accept and tile tests on plane l in the first walk; the second
-    // walk redoes only those (a few per cent)
-    static_assert(kVgPlanes * 4 <= 32, "one bit per (plane of the block, event of the thread)");
-    uint32_t live = 0xffffffffu;
-    for (int pass = 0; pass < 2; ++pass) {
-        uint32_t seen = 0u;
-        for (int l = lbeg; l < lend; ++l) {
-            if (!((live >> ((l - lbeg) * 4)) & 0xfu)) continue;
-            const int z = zlist[l];
-            float a, bx, by, d;
-            plane_coefficients(cx_, cy_, cz_, planes[z], g, a, bx, by, d);
+    const unsigned mine = tie ? atomicAdd(&s_n, 1u) : 0u;
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n) s_base = atomicAdd(&counters[1], s_n);
+    __syncthreads();
+    if (tie && s_base + mine < cols_cap) cols[s_base + mine] = make_uint4((unsigned)p, __float_as_uint(best), 0u, 0u);
+}
+
+// (2) WAVE = near-tie column, lane = plane: the contenders (value >= the column's threshold) by ballot -- two load
+// instructions per 64 planes instead of a thread walking its column three times behind dependent loads.  cand[] <- the
+// column's contending voxels (z * npix + p), one contiguous run, planes ascending; cols[j] <- (first entry of the run,
+// pixel, contenders, 0); counters[0] = voxels (keeps counting beyond cap: nothing is written there, the host retries)
+template <int OP>
+__global__ __launch_bounds__(1024) void k_tie_contenders(const float* __restrict__ a, const float* __restrict__ b, int npix, int nz,
+                                                         float rel_gap, unsigned* __restrict__ counters, uint32_t* __restrict__ cand,
+                                                         uint32_t cap, uint4* __restrict__ cols, uint32_t cols_cap)
+{
+    // (a workgroup's 16 columns reserve their runs with ONE global atomic: thousands on one address serialise at ~13 ns apiece)
+    __shared__ unsigned s_n, s_base;
+    const unsigned n_cols = min(counters[1], cols_cap);
+    const int lane = threadIdx.x & 63;
+    for (unsigned j0 = blockIdx.x * 16u; j0 < n_cols; j0 += gridDim.x * 16u) {
+        const unsigned j = j0 + (threadIdx.x >> 6);
+        const bool live = j < n_cols;  // (wave-uniform)
+        if (threadIdx.x == 0) s_n = 0u;
+        __syncthreads();
+        unsigned long long mask[4] = {0ull, 0ull, 0ull, 0ull};  // dimZ <= 256 (main.cpp:156)
+        unsigned cnt = 0u, p = 0u, off = 0u;
+        if (live) {
+            const uint4 col = cols[j];
+            p = col.x;
+            const float best = __uint_as_float(col.y), thr = best - rel_gap * best;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (!((live >> ((l - lbeg) * 4 + i)) & 1u)) continue;
-                const float X = (e[i].x * a + bx) / d;  // mapper_emvs_stereo.cpp:194-195
-                const float Y = (e[i].y * a + by) / d;
-                if (!(X >= 0.f && Y >= 0.f && X < xmax && Y < ymax)) continue;  // cartesian3dgrid.h:255-259 (see vote_global)
-                const int xi = (int)X, yi = (int)Y;
-                if (tile_words) {  // a tile without a bit holds no vote that reaches a contending voxel
-                    const int t = (yi >> kTieTile) * tiles_x + (xi >> kTieTile);
-                    if (!((s_tiles[(l - lbeg) * tile_words + (t >> 5)] >> (t & 31)) & 1u)) continue;
-                }
-                seen |= 1u << ((l - lbeg) * 4 + i);
-                const float fx = X - (float)xi, fy = Y - (float)yi, fx1 = 1.f - fx, fy1 = 1.f - fy;
-                const float w[4] = {fx1 * fy1, fx * fy1, fx1 * fy, fx * fy};  // :261-270
-                const uint32_t v0 = (uint32_t)((size_t)z * plane_sz + (size_t)yi * g.nx + xi);
-                const uint32_t v[4] = {v0, v0 + 1u, v0 + (uint32_t)g.nx, v0 + (uint32_t)g.nx + 1u};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (!((bitmap[v[c] >> 5] >> (v[c] & 31u)) & 1u)) continue;
-                    const unsigned my = atomicAdd(&s_count, 1u);  // (LDS)
-                    if (pass == 0 || !keys) continue;
-                    const unsigned long long slot = s_base + my;
-                    if (slot >= cap) continue;
-                    int lo = 0, hi = nsv;  // the voxel's rank among the contenders (sorted, unique)
-                    while (lo < hi) {
-                        const int mid = (lo + hi) >> 1;
-                        if (sv[mid] < v[c])
-                            lo = mid + 1;
-                        else
-                            hi = mid;
-                    }
-                    // key = (voxel's rank, position of the vote in the reference's loop over events): sorting by it puts a
-                    // voxel's votes in one run, in the order the reference adds them
-                    keys[slot] = ((unsigned long long)lo << 32) | ((unsigned long long)k * kPacket + (unsigned)(threadIdx.x + 256 * i));
-                    wts[slot] = w[c];
+                const int z = i * 64 + lane;
+                if (i * 64 < nz) {
+                    const bool in = z < nz && tie_value<OP>(a, b, (size_t)z * npix + p) >= thr;
+                    mask[i] = __ballot(in);
+                    cnt += (unsigned)__popcll(mask[i]);
                 }
             }
+            if (lane == 0) off = atomicAdd(&s_n, cnt);  // (LDS)
+            off = (unsigned)__builtin_amdgcn_readfirstlane((int)off);
         }
-        live = seen;
         __syncthreads();
-        if (pass == 0) {
-            if (threadIdx.x == 0) {
-                s_base = s_count ? atomicAdd(hit_counter, (unsigned long long)s_count) : 0ull;
-                s_count = 0u;
+        if (threadIdx.x == 0 && s_n) s_base = atomicAdd(&counters[0], s_n);
+        __syncthreads();
+        if (live) {
+            const unsigned base = s_base + off;
+            if (lane == 0) cols[j] = make_uint4(base, p, cnt, 0u);
+            if ((unsigned long long)base + cnt <= cap) {
+                unsigned before = 0u;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int z = i * 64 + lane;
+                    if ((mask[i] >> lane) & 1ull) {
+                        const unsigned at = before + (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(mask[i] >> 32),
+                                                                                          __builtin_amdgcn_mbcnt_lo((unsigned)mask[i], 0u));
+                        cand[base + at] = (uint32_t)((size_t)z * npix + p);
+                    }
+                    before += (unsigned)__popcll(mask[i]);
+                }
             }
-            __syncthreads();
-            if (!keys) break;  // counting only
         }
     }
-}
-
-// thread = contending voxel: its run of the sorted votes added one by one in fp32 -- resetGrid (mapper_emvs_stereo.cpp:145),
-// then "grid[i] += w" per vote in event order (cartesian3dgrid.h:261-270); gpu[] <- the engine's own value of the voxel
-__global__ __launch_bounds__(64) void k_tie_sums(const unsigned long long* __restrict__ keys, const float* __restrict__ wts,
-                                                 unsigned long long n, const uint32_t* __restrict__ sv, int nsv,
-                                                 const float* __restrict__ grid, float* __restrict__ exact,
-                                                 uint32_t* __restrict__ count, float* __restrict__ gpu)
-{
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= nsv) return;
-    unsigned long long lo = 0, hi = n;  // first vote of voxel c
-    const unsigned long long want = (unsigned long long)c << 32;
-    while (lo < hi) {
-        const unsigned long long mid = (lo + hi) >> 1;
-        if (keys[mid] < want)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    const unsigned long long first = lo;
-    hi = n;  // first vote of the next voxel: the run's length is known before the additions, so their loads pipeline
-    const unsigned long long next = (unsigned long long)(c + 1) << 32;
-    while (lo < hi) {
-        const unsigned long long mid = (lo + hi) >> 1;
-        if (keys[mid] < next)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    const unsigned long long last = lo;
-    float sum = 0.f;
-    unsigned long long i = first;
-    for (; i + 8 <= last; i += 8) {
-        float w8[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) w8[j] = wts[i + j];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sum += w8[j];  // one by one, in order (no reassociation: -ffp-contract=off, no fast-math)
-    }
-    for (; i < last; ++i) sum += wts[i];
-    exact[c] = sum;
-    count[c] = (uint32_t)(last - first);
-    gpu[c] = grid[sv[c]];
 }
 
 __global__ __launch_bounds__(256) void k_tie_patch(const uint32_t* __restrict__ pix, const uint8_t* __restrict__ new_idx,
@@ -3853,8 +3766,8 @@ __global__ __launch_bounds__(256) void k_tie_patch(const uint32_t* __restrict__ 
 }
 
 // ---- the resolver's event pass, INVERTED: (packet, contending voxel) pairs instead of (event, contending plane) pairs ----
-// k_tie_hits above walks every event over every contending plane (1 G event-planes per configs[1] camera, two IEEE
-// divides each) to find the ~0.7 % of them that reach a contending voxel.  This kernel turns the loop around: a block
+// Walking every event over every contending plane (1 G event-planes per configs[1] camera, two IEEE divides each: round
+// 4's k_tie_hits, 4.9 ms) finds the ~0.7 % of them that reach a contending voxel.  This kernel turns the loop around: a block
 // takes a packet, bins its 1024 z0 locations by 2-D tile in LDS (counting sort), and every thread asks, for one
 // contending voxel (x, y, z) at a time, WHICH z0 locations the transfer of mapper_emvs_stereo.cpp:177-195 can take into
 // the 2 x 2 integer locations whose bilinear vote touches that voxel: X = (x0 a + bx) / d is affine in x0, so the
@@ -3869,14 +3782,14 @@ __global__ __launch_bounds__(256) void k_tie_patch(const uint32_t* __restrict__ 
 // (packet * 1024 + slot); rank = rank_base + index of the voxel in `desc`.  Slots: a block owns SEGMENTS of kTieSeg
 // records; a hit takes the next position of its block's virtual cursor (one LDS atomic), the hit that opens a segment
 // reserves it with ONE global atomic (7.5 M hits -> ~8 k global atomics; one per hit or per wave instruction
-// serialises at the memory side, see k_tie_hits) and publishes its index in LDS, where the other hits of that segment
+// serialises at the memory side: ~50 ns each, 331 ms at configs[1] in round 4) and publishes its index in LDS, where the other hits of that segment
 // wait for it.  A block pads its last segment with sentinel keys (rank = sentinel_rank, beyond every voxel's), so that
 // the array [0, segments * kTieSeg) can be sorted as it is.
 constexpr int kTieSegShift = 10;
 constexpr int kTieSeg = 1 << kTieSegShift;
-constexpr int kTieMaxSegs = 2048;  // per block: 2 M hits
+constexpr int kTieMaxSegs = 512;  // per block: 512 k hits
 constexpr unsigned kTieSegEmpty = 0xffffffffu;
-constexpr int kTieMaxTiles = 8192;
+constexpr int kTieMaxTiles = 16384;  // tile starts are 16-bit halves of LDS words: 32 KB
 
 struct TiePlane {  // per (packet, plane), in LDS
     float a, bx, by, d;  // mapper_emvs_stereo.cpp:177-182
@@ -3895,7 +3808,7 @@ __host__ __device__ inline TieBinGeom tie_bin_geom(int nx, int ny)
 {
     TieBinGeom b;
     b.margin = 32;
-    for (b.shift = 3;; ++b.shift) {
+    for (b.shift = 2;; ++b.shift) {
         b.tx_n = (nx + 2 * b.margin + (1 << b.shift) - 1) >> b.shift;
         b.ty_n = (ny + 2 * b.margin + (1 << b.shift) - 1) >> b.shift;
         if (b.tx_n * b.ty_n <= kTieMaxTiles) break;
@@ -3924,13 +3837,14 @@ __device__ __forceinline__ void tie_emit(const TieOut& o, unsigned long long key
 {
     const unsigned vp = atomicAdd(o.s_vpos, 1u);  // (LDS)
     const unsigned j = vp >> kTieSegShift, off = vp & (unsigned)(kTieSeg - 1);
-    if (j >= (unsigned)kTieMaxSegs) {
-        atomicOr(o.flags, 1u);
+    if (j >= (unsigned)kTieMaxSegs) {  // (one global atomic per event of this kind, not per hit: they serialise)
+        if (vp == (unsigned)kTieMaxSegs * (unsigned)kTieSeg) atomicOr(o.flags, 1u);
         return;
     }
     // step 1, all lanes of the wave that hit: the lane that opens a segment reserves and publishes it ...
     if (off == 0u) {
         const unsigned b = atomicAdd(o.seg_counter, 1u);
+        if (b >= o.cap_segs) atomicOr(o.flags, 2u);
         __hip_atomic_store(&o.s_seg[j], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     // ... step 2: everybody reads it.  A lane can only wait here for a lane of ANOTHER wave (one of its own wave has
@@ -3938,20 +3852,46 @@ __device__ __forceinline__ void tie_emit(const TieOut& o, unsigned long long key
     unsigned b;
     while ((b = __hip_atomic_load(&o.s_seg[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == kTieSegEmpty)
         __builtin_amdgcn_s_sleep(1);
-    if (b >= o.cap_segs) {
-        atomicOr(o.flags, 2u);
-        return;
-    }
+    if (b >= o.cap_segs) return;  // (flagged by the lane that opened the segment; the host repeats the pass with more room)
     const size_t at = ((size_t)b << kTieSegShift) + off;
     o.keys[at] = key;
     o.wts[at] = w;
 }
 
-// dynamic LDS: rec_x[1024] rec_y[1024] (f32) | rec_slot[1024] (u32) | tile_start[tiles + 1] (u32) | TiePlane[nz] |
-// seg[kTieMaxSegs] (u32)
+constexpr int kTieQueue = 256;  // queued (voxel, record) pairs per wave
+
+// The exact vote of record r of packet k on voxel c: the reference's coordinates (mapper_emvs_stereo.cpp:194-195), accept test
+// (cartesian3dgrid.h:255-259, see vote_global) and the bilinear weight of the corner the voxel is (:261-270)
+__device__ __forceinline__ void tie_vote_pair(const TieOut& out, const uint2* __restrict__ desc, const TiePlane* __restrict__ tp,
+                                              const float* __restrict__ rec_x, const float* __restrict__ rec_y,
+                                              const unsigned* __restrict__ rec_slot, int c, unsigned r, int k, unsigned rank_base,
+                                              unsigned pos_bits, float xmax, float ymax)
+{
+    const uint2 dsc = desc[c];
+    const int vx = (int)(dsc.x & 0xffffu), vy = (int)(dsc.x >> 16), vz = (int)dsc.y;
+    const float a = tp[vz].a, bx = tp[vz].bx, by = tp[vz].by, d = tp[vz].d;
+    const float x0 = rec_x[r], y0 = rec_y[r];
+    const float X = (x0 * a + bx) / d;
+    const float Y = (y0 * a + by) / d;
+    if (!(X >= 0.f && Y >= 0.f && X < xmax && Y < ymax)) return;
+    const int xi = (int)X, yi = (int)Y;
+    const unsigned dx = (unsigned)(vx - xi), dy = (unsigned)(vy - yi);
+    if (dx > 1u || dy > 1u) return;
+    const float fx = X - (float)xi, fy = Y - (float)yi, fx1 = 1.f - fx, fy1 = 1.f - fy;
+    const float w = (dx ? fx : fx1) * (dy ? fy : fy1);  // fx1*fy1, fx*fy1, fx1*fy, fx*fy
+    tie_emit(out, ((unsigned long long)(rank_base + (unsigned)c) << pos_bits) | ((unsigned long long)k * kPacket + rec_slot[r]), w);
+}
+
+// dynamic LDS: rec_x[1024] rec_y[1024] (f32) | rec_slot[1024] (u32) | tile starts, tiles + 1 of them as the 16-bit halves
+// of (tiles + 2) / 2 words | TiePlane[nz] | seg[kTieMaxSegs] (u32)
+__host__ __device__ inline int tie_tile_words(int tiles) { return (tiles + 2) / 2; }
 __host__ __device__ inline size_t tie_hits_lds_bytes(int tiles, int nz)
 {
-    return (size_t)kPacket * 12 + (size_t)(tiles + 1) * 4 + (size_t)nz * sizeof(TiePlane) + (size_t)kTieMaxSegs * 4;
+    return (size_t)kPacket * 12 + (size_t)tie_tile_words(tiles) * 4 + (size_t)nz * sizeof(TiePlane) + (size_t)kTieMaxSegs * 4;
+}
+__device__ __forceinline__ unsigned tie_tile_start(const unsigned* __restrict__ tw, int t)
+{
+    return (tw[t >> 1] >> ((t & 1) << 4)) & 0xffffu;
 }
 
 __global__ __launch_bounds__(256) void k_tie_hits_binned(const float2* __restrict__ xy, const float* __restrict__ centers,
@@ -3966,12 +3906,16 @@ __global__ __launch_bounds__(256) void k_tie_hits_binned(const float2* __restric
     extern __shared__ unsigned char s_raw[];
     __shared__ unsigned s_vpos;
     __shared__ unsigned s_wave_tot[4];
+    __shared__ unsigned s_q[4][kTieQueue];  // per wave: (voxel - v_beg) << 10 | record, pairs that passed the box test
+    __shared__ unsigned s_qn[4];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x < 4) s_qn[threadIdx.x] = 0u;
     float* rec_x = reinterpret_cast<float*>(s_raw);
     float* rec_y = rec_x + kPacket;
     unsigned* rec_slot = reinterpret_cast<unsigned*>(rec_y + kPacket);
-    const int tiles = bg.tx_n * bg.ty_n;
-    unsigned* tstart = rec_slot + kPacket;  // [tiles + 1]
-    TiePlane* tp = reinterpret_cast<TiePlane*>(tstart + tiles + 1);
+    const int tiles = bg.tx_n * bg.ty_n, twords = tie_tile_words(tiles);
+    unsigned* tstart = rec_slot + kPacket;  // tile t: half (t & 1) of word t >> 1; entry `tiles` = the packet's records
+    TiePlane* tp = reinterpret_cast<TiePlane*>(tstart + twords);
     unsigned* s_seg = reinterpret_cast<unsigned*>(tp + g.nz);
     const int tid = threadIdx.x;
     const float inv_tile = 1.f / (float)(1 << bg.shift);
@@ -3980,9 +3924,12 @@ __global__ __launch_bounds__(256) void k_tie_hits_binned(const float2* __restric
     if (tid == 0) s_vpos = 0u;
     for (int i = tid; i < kTieMaxSegs; i += 256) s_seg[i] = kTieSegEmpty;
 
+    // this block's share of the voxels (blockIdx.y): few packets (a 50 ms window: ~490) do not fill the chip by themselves
+    const int v_per = (nsv + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int v_beg = (int)blockIdx.y * v_per, v_end = min(nsv, v_beg + v_per);
     for (int k = blockIdx.x; k < np; k += gridDim.x) {
         __syncthreads();  // the previous packet's voxel loop has left the tables
-        for (int i = tid; i <= tiles; i += 256) tstart[i] = 0u;
+        for (int i = tid; i < twords; i += 256) tstart[i] = 0u;
         {
             const float cx_ = centers[3 * k], cy_ = centers[3 * k + 1], cz_ = centers[3 * k + 2];
             for (int z = tid; z < g.nz; z += 256) {
@@ -4021,15 +3968,19 @@ __global__ __launch_bounds__(256) void k_tie_hits_binned(const float2* __restric
             tile[i] = ok ? tie_tile_coord(e[i].y, bg.margin, inv_tile, bg.ty_n) * bg.tx_n +
                                tie_tile_coord(e[i].x, bg.margin, inv_tile, bg.tx_n)
                          : -1;
-            off[i] = ok ? atomicAdd(&tstart[tile[i]], 1u) : 0u;  // (LDS)
+            // (LDS; a packet holds 1024 events: a half word cannot carry into its neighbour)
+            off[i] = ok ? (atomicAdd(&tstart[tile[i] >> 1], 1u << ((tile[i] & 1) << 4)) >> ((tile[i] & 1) << 4)) & 0xffffu : 0u;
         }
         __syncthreads();
         // exclusive scan of the tile counts -> tile starts (thread t owns a contiguous stretch of tiles)
         {
-            const int per = (tiles + 1 + 255) / 256;
-            const int t0 = tid * per, t1 = min(tiles + 1, t0 + per);
+            const int per = (twords + 255) / 256;
+            const int t0 = tid * per, t1 = min(twords, t0 + per);
             unsigned sum = 0u;
-            for (int t = t0; t < t1; ++t) sum += tstart[t];
+            for (int t = t0; t < t1; ++t) {
+                const unsigned c = tstart[t];
+                sum += (c & 0xffffu) + (c >> 16);
+            }
             unsigned incl = sum;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
@@ -4041,52 +3992,69 @@ __global__ __launch_bounds__(256) void k_tie_hits_binned(const float2* __restric
             unsigned base = incl - sum;
             for (int w = 0; w < (tid >> 6); ++w) base += s_wave_tot[w];
             for (int t = t0; t < t1; ++t) {
-                const unsigned c = tstart[t];
-                tstart[t] = base;
-                base += c;
+                const unsigned c = tstart[t], lo_n = c & 0xffffu;
+                tstart[t] = base | ((base + lo_n) << 16);
+                base += lo_n + (c >> 16);
             }
         }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (tile[i] >= 0) {
-                const unsigned r = tstart[tile[i]] + off[i];
+                const unsigned r = tie_tile_start(tstart, tile[i]) + off[i];
                 rec_x[r] = e[i].x;
                 rec_y[r] = e[i].y;
                 rec_slot[r] = (unsigned)(tid + 256 * i);
             }
         __syncthreads();
-        const unsigned n_rec = tstart[tiles];
-        // every contending voxel against this packet
-        for (int c = tid; c < nsv; c += 256) {
-            const uint2 dsc = desc[c];
-            const int vx = (int)(dsc.x & 0xffffu), vy = (int)(dsc.x >> 16), vz = (int)dsc.y;
-            const TiePlane P = tp[vz];
-            if (P.hw < 0.f) continue;
-            const float cx0 = (float)vx * P.ia + P.qx, cy0 = (float)vy * P.ia + P.qy;
-            const float xlo = cx0 - P.hw, xhi = cx0 + P.hw, ylo = cy0 - P.hw, yhi = cy0 + P.hw;
-            const int txlo = tie_tile_coord(xlo, bg.margin, inv_tile, bg.tx_n), txhi = tie_tile_coord(xhi, bg.margin, inv_tile, bg.tx_n);
-            const int tylo = tie_tile_coord(ylo, bg.margin, inv_tile, bg.ty_n), tyhi = tie_tile_coord(yhi, bg.margin, inv_tile, bg.ty_n);
-            const unsigned long long key_hi = (unsigned long long)(rank_base + (unsigned)c) << pos_bits;
-            for (int ty = tylo; ty <= tyhi; ++ty) {
-                const unsigned rb = tstart[ty * bg.tx_n + txlo], re = tstart[ty * bg.tx_n + txhi + 1];
-                for (unsigned r = rb; r < re; ++r) {
-                    const float x0 = rec_x[r], y0 = rec_y[r];
-                    // the exact pre-image test (the tiles are coarser); never true for NaN bounds -- there are none: ia, q, hw finite or hw = inf
-                    if (!(x0 >= xlo && x0 <= xhi && y0 >= ylo && y0 <= yhi)) continue;
-                    const float X = (x0 * P.a + P.bx) / P.d;  // mapper_emvs_stereo.cpp:194-195
-                    const float Y = (y0 * P.a + P.by) / P.d;
-                    if (!(X >= 0.f && Y >= 0.f && X < xmax && Y < ymax)) continue;  // cartesian3dgrid.h:255-259 (see vote_global)
-                    const int xi = (int)X, yi = (int)Y;
-                    const unsigned dx = (unsigned)(vx - xi), dy = (unsigned)(vy - yi);
-                    if (dx > 1u || dy > 1u) continue;
-                    const float fx = X - (float)xi, fy = Y - (float)yi, fx1 = 1.f - fx, fy1 = 1.f - fy;
-                    const float w = (dx ? fx : fx1) * (dy ? fy : fy1);  // :261-270: fx1*fy1, fx*fy1, fx1*fy, fx*fy
-                    tie_emit(out, key_hi | ((unsigned long long)k * kPacket + rec_slot[r]), w);
+        // Every contending voxel of this block against this packet.  A thread scans the records of its voxel's tiles
+        // against the exact pre-image box; the ~10 % of (voxel, record) pairs that pass are QUEUED (per wave, in LDS) and
+        // voted 64 at a time with all lanes busy -- voted where they are found, the two IEEE divisions, the weights and
+        // the output slot would run for the few lanes that have a hit while the rest of the wave waits.
+        for (int c0 = v_beg; c0 < v_end; c0 += 256) {
+            const int c = c0 + tid;
+            if (c < v_end) {
+                const uint2 dsc = desc[c];
+                const int vx = (int)(dsc.x & 0xffffu), vy = (int)(dsc.x >> 16), vz = (int)dsc.y;
+                const float hw = tp[vz].hw;
+                if (hw >= 0.f) {
+                    const float ia = tp[vz].ia, qx = tp[vz].qx, qy = tp[vz].qy;
+                    const float cx0 = (float)vx * ia + qx, cy0 = (float)vy * ia + qy;
+                    const float xlo = cx0 - hw, xhi = cx0 + hw, ylo = cy0 - hw, yhi = cy0 + hw;
+                    const int txlo = tie_tile_coord(xlo, bg.margin, inv_tile, bg.tx_n), txhi = tie_tile_coord(xhi, bg.margin, inv_tile, bg.tx_n);
+                    const int tylo = tie_tile_coord(ylo, bg.margin, inv_tile, bg.ty_n), tyhi = tie_tile_coord(yhi, bg.margin, inv_tile, bg.ty_n);
+                    for (int ty = tylo; ty <= tyhi; ++ty) {
+                        const unsigned rb = tie_tile_start(tstart, ty * bg.tx_n + txlo), re = tie_tile_start(tstart, ty * bg.tx_n + txhi + 1);
+                        for (unsigned r = rb; r < re; ++r) {
+                            const float x0 = rec_x[r], y0 = rec_y[r];
+                            // the exact pre-image test (the tiles are coarser); the bounds are never NaN: ia, q finite, hw finite or +inf
+                            if (!(x0 >= xlo && x0 <= xhi && y0 >= ylo && y0 <= yhi)) continue;
+                            const unsigned pos = atomicAdd(&s_qn[wv], 1u);  // (LDS)
+                            if (pos < (unsigned)kTieQueue)
+                                s_q[wv][pos] = ((unsigned)(c - v_beg) << 10) | r;
+                            else  // a full queue (a burst of events on one pixel): vote in place
+                                tie_vote_pair(out, desc, tp, rec_x, rec_y, rec_slot, c, r, k, rank_base, pos_bits, xmax, ymax);
+                        }
+                    }
                 }
             }
+            // (the wave is whole again) full batches of the queue
+            unsigned n = min(*(volatile unsigned*)&s_qn[wv], (unsigned)kTieQueue);
+            while (n >= 64u) {
+                n -= 64u;
+                const unsigned e = *(volatile unsigned*)&s_q[wv][n + (unsigned)lane];
+                tie_vote_pair(out, desc, tp, rec_x, rec_y, rec_slot, v_beg + (int)(e >> 10), e & 1023u, k, rank_base, pos_bits, xmax, ymax);
+            }
+            if (lane == 0) *(volatile unsigned*)&s_qn[wv] = n;
         }
-        (void)n_rec;
+        {  // the rest of the queue: its entries point into this packet's records
+            const unsigned n = min(*(volatile unsigned*)&s_qn[wv], (unsigned)kTieQueue);
+            if ((unsigned)lane < n) {
+                const unsigned e = *(volatile unsigned*)&s_q[wv][lane];
+                tie_vote_pair(out, desc, tp, rec_x, rec_y, rec_slot, v_beg + (int)(e >> 10), e & 1023u, k, rank_base, pos_bits, xmax, ymax);
+            }
+            if (lane == 0) *(volatile unsigned*)&s_qn[wv] = 0u;
+        }
     }
     __syncthreads();
     // pad the last segment with sentinels; report the block's hits
@@ -4105,71 +4073,88 @@ __global__ __launch_bounds__(256) void k_tie_hits_binned(const float2* __restric
 }
 
 // desc[c] = (x | y << 16, z) of voxel vox[c] = z * npix + y * nx + x
-// plane_bits (optional, 8 words): bit z set for every plane that holds one of the voxels
+// plane_bits (optional, 8 zeroed words): bit z <- plane z holds one of the voxels (statistics; collected per workgroup in LDS)
 __global__ __launch_bounds__(256) void k_tie_desc(const uint32_t* __restrict__ vox, int n, int nx, int npix, uint2* __restrict__ desc,
                                                   unsigned* __restrict__ plane_bits)
 {
+    __shared__ unsigned s_bits[8];
+    if (threadIdx.x < 8) s_bits[threadIdx.x] = 0u;
+    __syncthreads();
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n) return;
-    const uint32_t v = vox[c];
-    const uint32_t z = v / (uint32_t)npix, p = v - z * (uint32_t)npix, y = p / (uint32_t)nx, x = p - y * (uint32_t)nx;
-    desc[c] = make_uint2(x | (y << 16), z);
-    if (plane_bits && z < 256u && !((plane_bits[z >> 5] >> (z & 31u)) & 1u)) atomicOr(&plane_bits[z >> 5], 1u << (z & 31u));
+    if (c < n) {
+        const uint32_t v = vox[c];
+        const uint32_t z = v / (uint32_t)npix, p = v - z * (uint32_t)npix, y = p / (uint32_t)nx, x = p - y * (uint32_t)nx;
+        desc[c] = make_uint2(x | (y << 16), z);
+        if (plane_bits && z < 256u && !((s_bits[z >> 5] >> (z & 31u)) & 1u)) atomicOr(&s_bits[z >> 5], 1u << (z & 31u));
+    }
+    __syncthreads();
+    if (plane_bits && threadIdx.x < 8 && s_bits[threadIdx.x] && (s_bits[threadIdx.x] & ~plane_bits[threadIdx.x]))
+        atomicOr(&plane_bits[threadIdx.x], s_bits[threadIdx.x]);
 }
 
-// thread = (camera, contending voxel): its run of the sorted votes added one by one in fp32 -- resetGrid
+// WAVE = (camera, contending voxel): its run of the sorted votes added one by one in fp32 -- resetGrid
 // (mapper_emvs_stereo.cpp:145), then "grid[i] += w" per vote in event order (cartesian3dgrid.h:261-270).  Virtual voxel
-// r = camera * nsv + c; keys = r << pos_bits | event position, sorted.  stats[0] = max over the voxels of the float bits of
-// |engine value - reference-order value| / max(1, |reference-order value|), stats[1] = max votes of a voxel
-__global__ __launch_bounds__(64) void k_tie_sums2(const unsigned long long* __restrict__ keys, const float* __restrict__ wts,
-                                                  unsigned long long n, unsigned pos_bits, const uint32_t* __restrict__ vox,
-                                                  int nsv, int n_cams, const float* __restrict__ grid0,
-                                                  const float* __restrict__ grid1, float* __restrict__ exact,
-                                                  uint32_t* __restrict__ count, unsigned* __restrict__ stats)
+// r = camera * nsv + c; keys = r << pos_bits | event position, sorted.  The wave loads 64 consecutive weights with one
+// coalesced instruction (the next 64 are in flight meanwhile) and adds them in order, each broadcast from its lane
+// (v_readlane) -- the chain of dependent additions is the same in every lane.  (One THREAD per voxel reads 64 different
+// cache lines per instruction and spends ~110 clocks per addition of the longest run: 354 us at configs[1], now ~40.)
+// diff[r] (optional) = |engine value - reference-order value| / max(1, |reference-order value|)
+__global__ __launch_bounds__(256) void k_tie_sums2(const unsigned long long* __restrict__ keys, const float* __restrict__ wts,
+                                                   unsigned long long n, unsigned pos_bits, const uint32_t* __restrict__ vox,
+                                                   int nsv, int n_cams, const float* __restrict__ grid0,
+                                                   const float* __restrict__ grid1, float* __restrict__ exact,
+                                                   uint32_t* __restrict__ count, float* __restrict__ diff)
 {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nsv * n_cams) return;
-    unsigned long long lo = 0, hi = n;  // first vote of virtual voxel r
-    const unsigned long long want = (unsigned long long)r << pos_bits;
-    while (lo < hi) {
-        const unsigned long long mid = (lo + hi) >> 1;
-        if (keys[mid] < want)
-            lo = mid + 1;
-        else
-            hi = mid;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= nsv * n_cams) return;  // (wave-uniform)
+    // [first, last) = the run of keys with rank r, by a 64-ary search: every step the 64 lanes probe 64 evenly spaced keys
+    // of the remaining range (4 dependent loads for 16 M keys, where a binary search makes 24)
+    unsigned long long bound[2];
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const unsigned long long want = (unsigned long long)(r + side) << pos_bits;  // first key >= want
+        unsigned long long lo = 0, hi = n;  // the answer lies in [lo, hi]
+        while (hi - lo > 0) {
+            const unsigned long long span = hi - lo, step = (span + 63) / 64;
+            const unsigned long long at = lo + (unsigned long long)lane * step;  // probes lo, lo + step, ...
+            const bool below = at < hi && keys[at] < want;                       // keys[at] < want: the answer is beyond `at`
+            const unsigned long long m = __ballot(below);
+            const int nb = __popcll(m);  // probes 0 .. nb - 1 are below (the keys are sorted)
+            if (nb == 0) {
+                hi = lo;
+                break;
+            }
+            const unsigned long long last_below = lo + (unsigned long long)(nb - 1) * step;
+            lo = last_below + 1;
+            const unsigned long long first_not = lo + step - 1;  // = probe nb, if there is one
+            hi = first_not < hi ? first_not : hi;
+        }
+        bound[side] = lo;
     }
-    const unsigned long long first = lo;
-    hi = n;  // first vote of the next one: the run's length is known before the additions, so their loads pipeline
-    const unsigned long long next = (unsigned long long)(r + 1) << pos_bits;
-    while (lo < hi) {
-        const unsigned long long mid = (lo + hi) >> 1;
-        if (keys[mid] < next)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    const unsigned long long last = lo;
+    const unsigned long long first = bound[0], last = bound[1];
     float sum = 0.f;
-    unsigned long long i = first;
-    for (; i + 8 <= last; i += 8) {
-        float w8[8];
+    float w = first + (unsigned)lane < last ? wts[first + (unsigned)lane] : 0.f;
+    for (unsigned long long base = first; base < last; base += 64) {
+        const float cur = w;
+        const unsigned long long nb = base + 64 + (unsigned)lane;
+        w = nb < last ? wts[nb] : 0.f;  // the next batch, in flight during this one's additions
+        if (last - base >= 64) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) w8[j] = wts[i + j];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sum += w8[j];  // one by one, in order (no reassociation: -ffp-contract=off, no fast-math)
+            for (int i = 0; i < 64; ++i) sum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur), i));
+        } else {
+            const int cnt = (int)(last - base);
+            for (int i = 0; i < cnt; ++i) sum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur), i));
+        }  // one by one, in order (no reassociation: -ffp-contract=off, no fast-math)
     }
-    for (; i < last; ++i) sum += wts[i];
+    if (lane != 0) return;
     exact[r] = sum;
     count[r] = (uint32_t)(last - first);
-    if (stats) {
+    if (diff) {  // |engine value - reference-order value| / max(1, |reference-order value|): k_tie_pick takes the maximum
         const int cam = r / nsv;
         const float* grid = cam == 0 ? grid0 : grid1;
-        if (grid) {
-            const float have = grid[vox[r - cam * nsv]];
-            const float diff = fabsf(have - sum) / fmaxf(1.f, fabsf(sum));
-            atomicMax(&stats[0], __float_as_uint(diff));  // non-negative floats order like their bits (NaN: above everything)
-        }
-        atomicMax(&stats[1], (unsigned)(last - first));
+        const float have = grid[vox[r - cam * nsv]];
+        diff[r] = fabsf(have - sum) / fmaxf(1.f, fabsf(sum));
     }
 }
 
@@ -4180,27 +4165,50 @@ __global__ __launch_bounds__(64) void k_tie_sums2(const unsigned long long* __re
 template <int OP>
 __global__ __launch_bounds__(256) void k_tie_pick(const uint4* __restrict__ cols, int n_cols, const uint32_t* __restrict__ vox,
                                                   int nsv, int npix, const float* __restrict__ exact,
+                                                  const uint32_t* __restrict__ count, const float* __restrict__ diff,
                                                   const float* __restrict__ planes, float* __restrict__ conf,
                                                   uint8_t* __restrict__ idx, float* __restrict__ depth,
                                                   unsigned* __restrict__ stats)
 {
+    // stats[0] = max float bits of diff[], stats[1] = max votes of a voxel, stats[2] += changed pixels: one global atomic each
+    // per WORKGROUP (thousands on one address serialise at ~50 ns apiece)
+    __shared__ unsigned s_stats[3];
+    if (threadIdx.x < 3) s_stats[threadIdx.x] = 0u;
+    __syncthreads();
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_cols) return;
-    const uint4 col = cols[j];
-    float best = 0.f;
-    int best_z = -1;
-    for (unsigned i = col.x; i < col.x + col.z; ++i) {
-        const float v = OP == 0 ? exact[i] : fuse_op<OP>(0.f + exact[i], exact[(size_t)nsv + i]);
-        if (best_z < 0 || best < v) {
-            best = v;
-            best_z = (int)(vox[i] / (uint32_t)npix);
+    if (j < n_cols) {
+        const uint4 col = cols[j];
+        float best = 0.f;
+        int best_z = -1;
+        unsigned dmax = 0u, cmax = 0u;
+        for (unsigned i = col.x; i < col.x + col.z; ++i) {
+            const float v = OP == 0 ? exact[i] : fuse_op<OP>(0.f + exact[i], exact[(size_t)nsv + i]);
+            if (best_z < 0 || best < v) {
+                best = v;
+                best_z = (int)(vox[i] / (uint32_t)npix);
+            }
+            // (non-negative floats order like their bits; a NaN ranks above everything and fails the premise)
+            dmax = max(dmax, __float_as_uint(diff[i]));
+            cmax = max(cmax, count[i]);
+            if (OP != 0) {
+                dmax = max(dmax, __float_as_uint(diff[(size_t)nsv + i]));
+                cmax = max(cmax, count[(size_t)nsv + i]);
+            }
         }
+        const uint32_t p = col.y;
+        if (idx[p] != (uint8_t)best_z) atomicAdd(&s_stats[2], 1u);
+        conf[p] = best;
+        idx[p] = (uint8_t)best_z;
+        depth[p] = planes[best_z];
+        atomicMax(&s_stats[0], dmax);
+        atomicMax(&s_stats[1], cmax);
     }
-    const uint32_t p = col.y;
-    if (idx[p] != (uint8_t)best_z) atomicAdd(&stats[2], 1u);
-    conf[p] = best;
-    idx[p] = (uint8_t)best_z;
-    depth[p] = planes[best_z];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_stats[0]) atomicMax(&stats[0], s_stats[0]);
+        if (s_stats[1]) atomicMax(&stats[1], s_stats[1]);
+        if (s_stats[2]) atomicAdd(&stats[2], s_stats[2]);
+    }
 }
 
 int grid_for(size_t work_items, int block, int max_blocks = 256 * 8)
@@ -4835,10 +4843,13 @@ hipError_t launch_div_probe(hipStream_t s, const float* n, const float* d, size_
 hipError_t launch_tie_candidates(hipStream_t s, const float* a, const float* b, int op, int npix, int nz, float rel_gap,
                                  unsigned* counters, uint32_t* cand, uint32_t cap, uint4* cols, uint32_t cols_cap)
 {
+    if (nz > 256) return hipErrorInvalidValue;
     const dim3 grid((npix + 255) / 256), block(256);
-#define DSI_TIE_CAND(OPV)                                                                                                   \
-    case OPV:                                                                                                               \
-        hipLaunchKernelGGL(k_tie_candidates<OPV>, grid, block, 0, s, a, b, npix, nz, rel_gap, counters, cand, cap, cols, cols_cap); \
+    const dim3 grid2((unsigned)std::min<size_t>(512, ((size_t)cols_cap + 15) / 16)), block2(1024);
+#define DSI_TIE_CAND(OPV)                                                                                                           \
+    case OPV:                                                                                                                       \
+        hipLaunchKernelGGL(k_tie_columns<OPV>, grid, block, 0, s, a, b, npix, nz, rel_gap, counters, cols, cols_cap);                \
+        hipLaunchKernelGGL(k_tie_contenders<OPV>, grid2, block2, 0, s, a, b, npix, nz, rel_gap, counters, cand, cap, cols, cols_cap); \
         break;
     switch (b ? op : 0) {
         DSI_TIE_CAND(0) DSI_TIE_CAND(1) DSI_TIE_CAND(2) DSI_TIE_CAND(3) DSI_TIE_CAND(4) DSI_TIE_CAND(5) DSI_TIE_CAND(6)
@@ -4870,65 +4881,40 @@ hipError_t launch_tie_hits_binned(hipStream_t s, const float2* xy, const float* 
     // blocks take packets in turn (the order of the hits does not matter: they are sorted); as many as fit the chip
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, max_dynamic_lds() / lds));
     const int blocks = std::min(np, 256 * per_cu);
-    hipLaunchKernelGGL(k_tie_hits_binned, dim3(blocks), dim3(256), lds, s, xy, centers, planes, g, np, desc, nsv, rank_base, pos_bits,
+    // ... and when the packets alone do not (a 50 ms window), the voxels are dealt over blockIdx.y (each share bins the packet again)
+    int vshares = std::max(1, std::min(std::min(16, (nsv + 1023) / 1024), (256 * per_cu) / blocks));
+    vshares = std::max(vshares, (nsv + (1 << 22) - 1) >> 22);  // (a queue entry holds the voxel's index within its share in 22 bits)
+    hipLaunchKernelGGL(k_tie_hits_binned, dim3(blocks, vshares), dim3(256), lds, s, xy, centers, planes, g, np, desc, nsv, rank_base, pos_bits,
                        sentinel_rank, bg, seg_counter, cap_segs, flags, total_hits, keys, wts);
     return hipExtGetLastError();
 }
 
 hipError_t launch_tie_sums2(hipStream_t s, const unsigned long long* keys, const float* wts, unsigned long long n, unsigned pos_bits,
                             const uint32_t* vox, int nsv, int n_cams, const float* grid0, const float* grid1, float* exact,
-                            uint32_t* count, unsigned* stats)
+                            uint32_t* count, float* diff)
 {
     if (nsv <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_tie_sums2, dim3((nsv * n_cams + 63) / 64), dim3(64), 0, s, keys, wts, n, pos_bits, vox, nsv, n_cams, grid0,
-                       grid1, exact, count, stats);
+    hipLaunchKernelGGL(k_tie_sums2, dim3((nsv * n_cams + 3) / 4), dim3(256), 0, s, keys, wts, n, pos_bits, vox, nsv, n_cams, grid0,
+                       grid1, exact, count, diff);
     return hipExtGetLastError();
 }
 
 hipError_t launch_tie_pick(hipStream_t s, int op, const uint4* cols, int n_cols, const uint32_t* vox, int nsv, int npix,
-                           const float* exact, const float* planes, float* conf, uint8_t* idx, float* depth, unsigned* stats)
+                           const float* exact, const uint32_t* count, const float* diff, const float* planes, float* conf,
+                           uint8_t* idx, float* depth, unsigned* stats)
 {
     if (n_cols <= 0) return hipSuccess;
     const dim3 grid((n_cols + 255) / 256), block(256);
 #define DSI_TIE_PICK(OPV)                                                                                                        \
     case OPV:                                                                                                                    \
-        hipLaunchKernelGGL(k_tie_pick<OPV>, grid, block, 0, s, cols, n_cols, vox, nsv, npix, exact, planes, conf, idx, depth, stats); \
+        hipLaunchKernelGGL(k_tie_pick<OPV>, grid, block, 0, s, cols, n_cols, vox, nsv, npix, exact, count, diff, planes, conf, idx,   \
+                           depth, stats);                                                                                        \
         break;
     switch (op) {
         DSI_TIE_PICK(0) DSI_TIE_PICK(1) DSI_TIE_PICK(2) DSI_TIE_PICK(3) DSI_TIE_PICK(4) DSI_TIE_PICK(5) DSI_TIE_PICK(6)
     default: return hipErrorInvalidValue;
     }
 #undef DSI_TIE_PICK
-    return hipExtGetLastError();
-}
-
-int tie_tile_words_of(int nx, int ny) { return tie_tile_words(nx, ny); }
-
-hipError_t launch_tie_mark(hipStream_t s, const uint32_t* sv, int n, uint32_t* bitmap, uint32_t* tiles, int nx, int ny)
-{
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_tie_mark, dim3((n + 255) / 256), dim3(256), 0, s, sv, n, bitmap, tiles, nx, ny);
-    return hipExtGetLastError();
-}
-
-hipError_t launch_tie_hits(hipStream_t s, const float2* xy, const float* centers, const float* planes, const Geom& g, int np,
-                           const int* zlist, int nzl, const uint32_t* bitmap, const uint32_t* tiles, const uint32_t* sv, int nsv,
-                           unsigned long long* hit_counter, unsigned long long* keys, float* wts, unsigned long long cap)
-{
-    if (np <= 0 || nzl <= 0) return hipSuccess;
-    // the tile bits of a block's planes sit in LDS; images too large for that (> 4 M pixels) go without the tile test
-    int tw = tiles ? tie_tile_words(g.nx, g.ny) : 0;
-    if ((size_t)tw * kVgPlanes * sizeof(uint32_t) > 48 * 1024) tw = 0;
-    hipLaunchKernelGGL(k_tie_hits, dim3(np, (nzl + kVgPlanes - 1) / kVgPlanes), dim3(256), (size_t)tw * kVgPlanes * sizeof(uint32_t), s,
-                       xy, centers, planes, g, zlist, nzl, bitmap, tiles, tw, sv, nsv, hit_counter, keys, wts, cap);
-    return hipExtGetLastError();
-}
-
-hipError_t launch_tie_sums(hipStream_t s, const unsigned long long* keys, const float* wts, unsigned long long n,
-                           const uint32_t* sv, int nsv, const float* grid, float* exact, uint32_t* count, float* gpu)
-{
-    if (nsv <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_tie_sums, dim3((nsv + 63) / 64), dim3(64), 0, s, keys, wts, n, sv, nsv, grid, exact, count, gpu);
     return hipExtGetLastError();
 }
 

@@ -403,7 +403,7 @@ class WindowStream:
             else:
                 pk = E.packetize(events[c][2], trajectories[c], T_rv_w)
                 if pk is None:                      # evaluateDSI returns false: < 1024 events (:71-75)
-                    if not self.fused_vote:
+                    if not self.fused_vote and not self.exact_ties:
                         mappers[c].dsi_.resetGrid()
                         continue
                     pk = (np.zeros(0, np.uint32), np.zeros((0, 12), np.float32))   # a batch without packets
@@ -418,8 +418,10 @@ class WindowStream:
             all_batches.append(b)
             if self.fused_vote:
                 fused_batches.append(b)
-            else:
+            elif b.n_packets:
                 mappers[c].evaluateDSI_batch(b)
+            else:                                   # a batch without packets: evaluateDSI resets the DSI and returns false;
+                mappers[c].dsi_.resetGrid()         # the resolver takes the batch as it is -- no votes from this camera
             self.voted += b.n_packets * E.PACKET_SIZE
         if self.fused_vote:
             self.extract[slot].computeDepthMapOfEvents(mappers, fused_batches, self.fusion_method)
@@ -429,7 +431,7 @@ class WindowStream:
         else:
             self.extract[slot].computeDepthMapOfFusion(mappers[0].dsi_, mappers[1].dsi_,
                                                        self.fusion_method)
-        if self.exact_ties and len(all_batches) == 2:
+        if self.exact_ties:
             self.last_resolve = self.extract[slot].resolveNearTies(mappers, all_batches, self.fusion_method)
         for b in own:
             b.close()                               # the block returns to the pool once its readers are done

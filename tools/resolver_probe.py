@@ -1,6 +1,7 @@
 """The exact tie resolver (dsi_mapper_resolve_near_ties) at BASELINE configs[1]'s size, three calls in a row: the first
 allocates the scratch it keeps, the others show the cost in a stream of steps.  Run on the GPU box, e.g. under
-rocprofv3 --kernel-trace --stats for the per-kernel split (k_tie_hits, the sort, k_tie_sums)."""
+rocprofv3 --kernel-trace --stats for the per-kernel split (k_tie_columns, k_tie_contenders, k_tie_hits_binned, the sort, k_tie_sums2, k_tie_pick;
+tools/trace_timeline.py prints the dispatches of one call)."""
 import sys, time
 sys.path.insert(0, ".")
 import numpy as np
