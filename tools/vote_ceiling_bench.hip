@@ -1,0 +1,335 @@
+// Ceiling replica of the banded voting kernels: the SAME per-record work -- two gathers (a 12-byte
+// record, a 20-byte coefficient set), the plane transfer of mapper_emvs_stereo.cpp:194-195 with the residual-corrected
+// divide, the accept test, the four bilinear weights in Q.31 and four ds_add_u64 into a band of LDS -- at the SAME
+// waves per CU and band size, with everything else taken away: no run bookkeeping, no passes, no cuts, no barriers, no
+// flush, no work-item draw, every lane always busy, cells uniformly random over the band.  Its rate is what the
+// instruction mix can reach on this chip at this occupancy; the product kernels are measured against it
+// ("replica").  Variants answer VERDICT r04 item 5 as well: what 2 paired 64-bit atomics (two 32-bit cells per
+// atomic) or 4 x 32-bit atomics per record would buy if exactness were given up.
+//
+//   shape      band cells          workgroups x waves per CU   product kernel it bounds
+//   headline   27 rows x 346       2 x 16                      k_vote_bands_packed<1024, 7>, configs[1]
+//   wide       18 rows x 1024      1 x 16                      k_vote_bands_vfill<1024, 5>, 1024 x 1024 x 256
+//   window     39 rows x 512       1 x 16                      k_vote_fuse_argmax, 512 x 512 x 200 (a voting phase)
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/vote_ceiling_bench.hip -o tools/vote_ceiling_bench
+#include <hip/hip_runtime.h>
+
+#include "../dvs_mcemvs_amd/csrc/dsi_vote_asm.h"
+
+#include <cstdint>
+#include <cstdio>
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+struct Rec {
+    float x, y;
+    uint32_t m;
+};
+struct Coef {
+    float a, bx, by, d, r;
+};
+
+__device__ __forceinline__ float div_rc(float n, float d, float r)
+{
+    float q = n * r;
+    float e = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(-d, q, n);
+    return __builtin_fmaf(e, r, q);
+}
+
+__device__ __forceinline__ int floor_to_int(float x)
+{
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+// ATOMICS: 0 none (the vector work alone), 1 4 x ds_add_u64 (the product), 2 2 x ds_add_u64 on pairs of 32-bit cells,
+// 3 4 x ds_add_u32, 4 atomics only (no arithmetic: cells from a counter)
+// LOADS: 0 records / coefficients synthesised in registers, 1 gathered from global memory like the product does
+template <int ATOMICS, int LOADS>
+__global__ __launch_bounds__(1024) void k_replica(const Rec* __restrict__ recs, const Coef* __restrict__ coefs, int n_recs, int n_coefs,
+                                                  int nx, int rows, int batches, unsigned long long* __restrict__ sink)
+{
+    extern __shared__ unsigned char raw[];
+    unsigned long long* band = reinterpret_cast<unsigned long long*>(raw);
+    const int cells = nx * rows;
+    for (int i = threadIdx.x; i < cells; i += blockDim.x) band[i] = 0ull;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = (blockIdx.x * (blockDim.x >> 6)) + (threadIdx.x >> 6);
+    uint32_t s = (uint32_t)(wave * 64 + lane) * 2654435761u + 12345u;
+    const float fnx = (float)(nx - 2), frows = (float)(rows - 2);
+    unsigned long long keep = 0ull;
+    size_t at = ((size_t)wave * 64 * 97) % (size_t)(n_recs - 64);
+    Rec e{};
+    Coef c{};
+    if (LOADS) {
+        e = recs[at + lane];
+        c = coefs[(wave * 7 + lane / 5) % n_coefs];
+    }
+    for (int b = 0; b < batches; ++b) {
+        Rec en{};
+        Coef cn{};
+        if (LOADS) {  // the next batch's gathers in flight during this batch's votes (the product keeps two to three sets)
+            at += 64;
+            if (at >= (size_t)(n_recs - 64)) at -= (size_t)(n_recs - 64);
+            en = recs[at + lane];
+            cn = coefs[(wave * 7 + b * 3 + lane / 5) % n_coefs];  // ~13 runs per batch, like 19-record runs
+        } else {
+            s = s * 1664525u + 1013904223u;
+            e.x = (float)(s >> 8) * (1.f / 16777216.f) * fnx;
+            s = s * 1664525u + 1013904223u;
+            e.y = (float)(s >> 8) * (1.f / 16777216.f) * frows;
+            e.m = 1u;
+            c.a = 1.f; c.bx = 0.f; c.by = 0.f; c.d = 1.f; c.r = 1.f;
+        }
+        if (ATOMICS == 4) {
+            s = s * 1664525u + 1013904223u;
+            const int cell = (int)((s >> 8) % (uint32_t)(cells - nx - 2));
+            __hip_atomic_fetch_add(&band[cell], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&band[cell + 1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&band[cell + nx], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&band[cell + nx + 1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            // the product's arithmetic (vote_record<false> + vote4 of dsi_kernels.hip)
+            const float nxv = e.x * c.a + c.bx;
+            const float nyv = e.y * c.a + c.by;
+            const float X = div_rc(nxv, c.d, c.r), Y = div_rc(nyv, c.d, c.r);
+            const int xi = floor_to_int(X), yi = floor_to_int(Y);
+            const int sgn = xi | (nx - 2 - xi) | yi | (rows - 2 - yi);
+            if (sgn >= 0) {
+                const float fx = __builtin_amdgcn_fractf(X), fy = __builtin_amdgcn_fractf(Y);
+                const float fx1 = 1.f - fx, fy1 = 1.f - fy;
+                const float fxs = fx * 2147483648.f, fx1s = fx1 * 2147483648.f;
+                const uint32_t w00 = (uint32_t)(fx1s * fy1), w01 = (uint32_t)(fxs * fy1), w10 = (uint32_t)(fx1s * fy), w11 = (uint32_t)(fxs * fy);
+                const int cell = yi * nx + xi;
+                if (ATOMICS == 1) {
+                    __hip_atomic_fetch_add(&band[cell], (unsigned long long)w00 * e.m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&band[cell + 1], (unsigned long long)w01 * e.m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&band[cell + nx], (unsigned long long)w10 * e.m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&band[cell + nx + 1], (unsigned long long)w11 * e.m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else if (ATOMICS == 2) {
+                    // two 32-bit cells (x, x + 1) per 64-bit atomic; twin arrays for even / odd x, here: the same band bytes,
+                    // 8-byte slot (cell >> 1) of the row pair -- the address statistics of the scheme
+                    const unsigned long long lo = ((unsigned long long)((w01 >> 12) * e.m) << 32) | ((w00 >> 12) * e.m);
+                    const unsigned long long hi = ((unsigned long long)((w11 >> 12) * e.m) << 32) | ((w10 >> 12) * e.m);
+                    __hip_atomic_fetch_add(&band[cell], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&band[cell + nx], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else if (ATOMICS == 3) {
+                    uint32_t* b32 = reinterpret_cast<uint32_t*>(band);
+                    __hip_atomic_fetch_add(&b32[cell], (w00 >> 12) * e.m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&b32[cell + 1], (w01 >> 12) * e.m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&b32[cell + nx], (w10 >> 12) * e.m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&b32[cell + nx + 1], (w11 >> 12) * e.m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                    keep += (unsigned long long)w00 * e.m + w01 + w10 + w11 + (unsigned)cell;
+                }
+            }
+        }
+        if (LOADS) {
+            e = en;
+            c = cn;
+        }
+    }
+    __syncthreads();
+    if (keep == 0x123456789ull || (threadIdx.x == 0 && blockIdx.x == 0)) sink[0] = band[threadIdx.x] + keep;
+}
+
+// The replica proper: the product's own hand-scheduled GATHER and VOTE (dsi_vote_asm.h), two register sets like
+// packed_stream_asm -- gathers of batch k + 1 in flight while batch k votes --, and NOTHING between them: the lanes'
+// record indices advance by a constant.  runs: how many packets a batch's 64 lanes come from (1: long runs, the headline
+// shape; 4: ~16-record runs, wide grids) -- that many coefficient sets and record segments per gather.
+// Coefficient table: 32 bytes per packet (a, bx, by, d | r, pad); records: 12 bytes, 1024 per packet.
+template <int RUNS>
+__global__ __launch_bounds__(1024) void k_replica_asm(const Rec* __restrict__ recs, const uint4* __restrict__ coef4, int rec_mask, int nx,
+                                                      int rows, int batches, unsigned long long* __restrict__ sink)
+{
+    extern __shared__ unsigned char raw[];
+    unsigned long long* band = reinterpret_cast<unsigned long long*>(raw);
+    const int cells = nx * rows;
+    for (int i = threadIdx.x; i < cells; i += blockDim.x) band[i] = 0ull;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = (blockIdx.x * (blockDim.x >> 6)) + (threadIdx.x >> 6);
+    // lane -> record: RUNS segments of 64 / RUNS consecutive records, one packet (1024 records) apart
+    const int per = 64 / RUNS;
+    const int lane_off = (lane / per) * 1024 + (lane % per);
+    const int s_base = __builtin_amdgcn_readfirstlane((wave * 1543 * 64) & rec_mask);
+    const int s_step = __builtin_amdgcn_readfirstlane(per);
+    const int s_mask = __builtin_amdgcn_readfirstlane(rec_mask);
+    const int s_n = __builtin_amdgcn_readfirstlane(batches / 2);
+    const int s_nx8 = __builtin_amdgcn_readfirstlane(nx * 8);
+    const int s_cbase = __builtin_amdgcn_readfirstlane((int)(uintptr_t)band);
+    const int s_nxm2 = __builtin_amdgcn_readfirstlane(nx - 2);
+    const int s_Li = __builtin_amdgcn_readfirstlane(0);
+    const int s_Uim1 = __builtin_amdgcn_readfirstlane(rows - 2);
+    asm volatile(
+        "s_mov_b32 s40, %2\n\t"                // running base
+        "s_mov_b32 s41, %5\n\t"                // batch pairs left
+        "v_add_u32 v40, s40, %15\n\t"
+        "v_and_b32 v40, %4, v40\n\t"
+        DSI_ASM_GATHER("v[42:44]", "v[46:49]", "v45")
+        "Lloop%=:\n\t"
+        "s_add_i32 s40, s40, %3\n\t"
+        "v_add_u32 v40, s40, %15\n\t"
+        "v_and_b32 v40, %4, v40\n\t"
+        DSI_ASM_GATHER("v[50:52]", "v[54:57]", "v53")
+        "s_waitcnt vmcnt(3)\n\t"
+        DSI_ASM_VOTE("v42", "v43", "v44", "v46", "v47", "v48", "v49", "v45")
+        "s_add_i32 s40, s40, %3\n\t"
+        "v_add_u32 v40, s40, %15\n\t"
+        "v_and_b32 v40, %4, v40\n\t"
+        DSI_ASM_GATHER("v[42:44]", "v[46:49]", "v45")
+        "s_waitcnt vmcnt(3)\n\t"
+        DSI_ASM_VOTE("v50", "v51", "v52", "v54", "v55", "v56", "v57", "v53")
+        "s_sub_i32 s41, s41, 1\n\t"
+        "s_cmp_lg_u32 s41, 0\n\t"
+        "s_cbranch_scc1 Lloop%=\n\t"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)"
+        :
+        : "s"(recs), "s"(coef4), "s"(s_base), "s"(s_step), "s"(s_mask), "s"(s_n), "s"(0), "s"(0), "s"(0), "s"(s_nx8), "s"(s_cbase),
+          "s"(s_nxm2), "s"(s_Li), "s"(s_Uim1), "s"(0), "v"(lane_off)
+        : "memory", "scc", "vcc", "s40", "s41", "s50", "v36", "v37", "v38", "v39", "v40", "v42", "v43", "v44", "v45", "v46", "v47",
+          "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x == 0) sink[0] = band[5];
+}
+
+struct Shape {
+    const char* name;
+    int nx, rows, wgs_per_cu;
+    double product_frac;  // the product kernel's measured fraction of the conflict-free LDS-atomic roof (round 4)
+    const char* product;
+};
+
+template <int ATOMICS, int LOADS>
+double run(const Shape& sh, const Rec* recs, const Coef* coefs, int n_recs, int n_coefs, unsigned long long* sink, int cus, int batches)
+{
+    const size_t lds = (size_t)sh.nx * sh.rows * 8;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_replica<ATOMICS, LOADS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int blocks = cus * sh.wgs_per_cu;
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    hipLaunchKernelGGL((k_replica<ATOMICS, LOADS>), dim3(blocks), dim3(1024), lds, 0, recs, coefs, n_recs, n_coefs, sh.nx, sh.rows, batches / 8, sink);
+    (void)hipDeviceSynchronize();
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(a);
+        hipLaunchKernelGGL((k_replica<ATOMICS, LOADS>), dim3(blocks), dim3(1024), lds, 0, recs, coefs, n_recs, n_coefs, sh.nx, sh.rows, batches, sink);
+        (void)hipEventRecord(b);
+        (void)hipEventSynchronize(b);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, a, b);
+        if (ms < best) best = ms;
+    }
+    if (hipError_t e = hipGetLastError()) std::printf("ERR %s\n", hipGetErrorString(e));
+    // batches per second over the chip -> "adds per second" in the product's accounting (4 per record, 64 records per batch)
+    const double wave_batches = (double)blocks * 16.0 * batches;
+    return wave_batches * 64.0 * 4.0 / (best * 1e-3);
+}
+
+template <int RUNS>
+double run_asm(const Shape& sh, const Rec* recs, const uint4* coef4, int rec_mask, unsigned long long* sink, int cus, int batches)
+{
+    const size_t lds = (size_t)sh.nx * sh.rows * 8;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_replica_asm<RUNS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int blocks = cus * sh.wgs_per_cu;
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+    hipLaunchKernelGGL((k_replica_asm<RUNS>), dim3(blocks), dim3(1024), lds, 0, recs, coef4, rec_mask, sh.nx, sh.rows, batches / 8, sink);
+    (void)hipDeviceSynchronize();
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(a);
+        hipLaunchKernelGGL((k_replica_asm<RUNS>), dim3(blocks), dim3(1024), lds, 0, recs, coef4, rec_mask, sh.nx, sh.rows, batches, sink);
+        (void)hipEventRecord(b);
+        (void)hipEventSynchronize(b);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, a, b);
+        if (ms < best) best = ms;
+    }
+    if (hipError_t e = hipGetLastError()) std::printf("ERR %s\n", hipGetErrorString(e));
+    return (double)blocks * 16.0 * (batches / 2 * 2) * 64.0 * 4.0 / (best * 1e-3);
+}
+
+int main(int argc, char** argv)
+{
+    int batches = argc > 1 ? std::atoi(argv[1]) : 4000;
+    hipDeviceProp_t prop;
+    (void)hipGetDeviceProperties(&prop, 0);
+    const int cus = prop.multiProcessorCount;
+    const double roof = (double)cus * 64.0 * 2.4e9 / 6.2;  // conflict-free ds_add_u64, the roof bench.py prices against
+    const int n_recs = 1 << 16, n_coefs = 4096;  // 768 KB of records: L2-resident (the product re-reads a band's records plane after plane: 86 % L2 hits)
+    std::vector<Rec> hr(n_recs);
+    std::vector<Coef> hc(n_coefs);
+    uint32_t s = 777u;
+    auto rnd = [&]() {
+        s = s * 1664525u + 1013904223u;
+        return (float)(s >> 8) * (1.f / 16777216.f);
+    };
+    Rec* recs;
+    Coef* coefs;
+    uint4* coef4;  // the product's table layout: 32 bytes per packet
+    unsigned long long* sink;
+    const int n_packets = n_recs / 1024 + 8;
+    (void)hipMalloc(&coef4, (size_t)n_packets * 32);
+    (void)hipMalloc(&recs, (n_recs + 8 * 1024) * sizeof(Rec));
+    (void)hipMalloc(&coefs, n_coefs * sizeof(Coef));
+    (void)hipMalloc(&sink, 64);
+    const Shape shapes[3] = {{"headline 27x346, 2 WG/CU (32 waves)", 346, 27, 2, 0.51, "k_vote_bands_packed<1024,7> 0.51 (0.455 uniform pixels)"},
+                             {"wide 18x1024, 1 WG/CU (16 waves)", 1024, 18, 1, 0.355, "k_vote_bands_vfill<1024,5> 0.355 (10 M events), 0.258 (2 M)"},
+                             {"window 39x512, 1 WG/CU (16 waves)", 512, 39, 1, 0.228, "k_vote_fuse_argmax 0.228 whole kernel (a voting phase alone: ~0.37)"}};
+    std::printf("CUs %d; roof = conflict-free ds_add_u64 at 2.4 GHz = %.3f T adds/s; %d batches per wave\n", cus, roof * 1e-12, batches);
+    for (const Shape& sh : shapes) {
+        // records uniformly random over the band, coefficients of an almost-identity transfer (alpha in 0.9 .. 1.1 leaves the
+        // cells uniformly random; the accept test passes for ~all)
+        for (auto& r : hr) {
+            r.x = 1.f + rnd() * (float)(sh.nx - 4);
+            r.y = 1.f + rnd() * (float)(sh.rows - 4);
+            r.m = 1u;
+        }
+        for (auto& c : hc) {
+            c.a = 1.f;
+            c.bx = rnd() - 0.5f;
+            c.by = rnd() - 0.5f;
+            c.d = 1.f;
+            c.r = 1.f / c.d;
+        }
+        (void)hipMemcpy(recs, hr.data(), n_recs * sizeof(Rec), hipMemcpyHostToDevice);
+        (void)hipMemcpy(recs + n_recs, hr.data(), 8 * 1024 * sizeof(Rec), hipMemcpyHostToDevice);  // (segments a packet apart run past the mask)
+        {
+            std::vector<float> t((size_t)n_packets * 8, 0.f);
+            for (int k = 0; k < n_packets; ++k) {
+                const Coef& c = hc[k % n_coefs];
+                float* q = &t[(size_t)k * 8];
+                q[0] = c.a; q[1] = c.bx; q[2] = c.by; q[3] = c.d; q[4] = c.r;
+            }
+            (void)hipMemcpy(coef4, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice);
+        }
+        (void)hipMemcpy(coefs, hc.data(), n_coefs * sizeof(Coef), hipMemcpyHostToDevice);
+        std::printf("\n== %s   [product: %s]\n", sh.name, sh.product);
+        struct Row {
+            const char* what;
+            double rate;
+        } rows[] = {
+            {"atomics only: 4 ds_add_u64 on random cells", run<4, 0>(sh, recs, coefs, n_recs, n_coefs, sink, cus, batches)},
+            {"vector work only (transfer, test, weights), no atomics, no loads", run<0, 0>(sh, recs, coefs, n_recs, n_coefs, sink, cus, batches)},
+            {"vector work + gathers, no atomics", run<0, 1>(sh, recs, coefs, n_recs, n_coefs, sink, cus, batches)},
+            {"compiled replica: gathers + vector work + 4 ds_add_u64", run<1, 1>(sh, recs, coefs, n_recs, n_coefs, sink, cus, batches)},
+            {"  the same without the gathers", run<1, 0>(sh, recs, coefs, n_recs, n_coefs, sink, cus, batches)},
+            {"REPLICA, hand-scheduled (the product's GATHER + VOTE, 1 run per batch)", run_asm<1>(sh, recs, coef4, n_recs - 1, sink, cus, batches)},
+            {"REPLICA, hand-scheduled, 4 runs per batch (wide grids)", run_asm<4>(sh, recs, coef4, n_recs - 1, sink, cus, batches)},
+            {"variant: 2 ds_add_u64 on pairs of 32-bit cells (+ gathers)", run<2, 1>(sh, recs, coefs, n_recs, n_coefs, sink, cus, batches)},
+            {"variant: 4 ds_add_u32 (+ gathers)", run<3, 1>(sh, recs, coefs, n_recs, n_coefs, sink, cus, batches)},
+        };
+        const double replica = std::max(rows[3].rate, std::max(rows[5].rate, rows[6].rate));
+        for (const Row& r : rows)
+            std::printf("  %-66s %7.3f T adds/s  = %.3f of the roof\n", r.what, r.rate * 1e-12, r.rate / roof);
+        std::printf("  -> product / replica = %.2f\n", sh.product_frac * roof / replica);
+    }
+    return 0;
+}
