@@ -102,6 +102,11 @@ def parse():
                          "sort / coefficient tables and the first workgroups of its voting kernel start on the CUs camera c's "
                          "persistent voting kernel has already left (its workgroups fill a CU's LDS, so nothing else runs "
                          "beside them)")
+    ap.add_argument("--tile", type=int, default=1,
+                    help="cameras4: the events of every camera are --events / --tile generated events, repeated --tile times "
+                         "with the rig moved on between the repeats (different poses: different votes) -- how BASELINE "
+                         "configs[4]'s 100 M events per camera are built in seconds of host time (--events 100000000 --tile 10), "
+                         "like tests/test_gpu_parity.py::test_configs4_end_to_end_at_full_size does")
     ap.add_argument("--clock-ramp", type=int, default=None,
                     help="untimed steps run BEFORE the --warmup steps to bring the GPU's clocks up after the idle stretch in "
                          "which the host generated the inputs (default: ~0.25 s worth: 100 stereo steps, 600 windows, 40 "
@@ -209,8 +214,7 @@ def stream_kernels(d, ctx):
     nvox = nx * ny * nz
     for name, fn, nbytes in (("dsi_fuse", lambda: a.harmonicMeanTwoGrids(b), 12.0 * nvox),
                              ("dsi_fuse_into", lambda: m.dsi_.setToFusionOf(a, b, d.FUSE_HM), 12.0 * nvox),
-                             ("nary_accumulate_log", lambda: a.accumulate(b, d.ACC_LOG_SUM), 12.0 * nvox),
-                             ("argmax", lambda: m.computeDepthMap(a), (4.0 * nz + 9.0) * nx * ny)):
+                             ("nary_accumulate_log", lambda: a.accumulate(b, d.ACC_LOG_SUM), 12.0 * nvox)):
         fn()
         ctx.timer_start()
         for _ in range(reps):
@@ -234,6 +238,22 @@ def stream_kernels(d, ctx):
         ms = ctx.timer_stop() / reps
         out[name] = {"ms": ms, "GBps": nbytes / (ms * 1e-3) / 1e9,
                      "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+    # arg-max: ONE volume (210 MB) fits the 256 MiB Infinity Cache, so re-reading it measures the cache (round 4 did:
+    # 5.8 TB/s); here four different volumes take turns (840 MB between two reads of the same one)
+    turn = {"i": 0}
+
+    def argmax_next():
+        m.computeDepthMap(c4[turn["i"] & 3])
+        turn["i"] += 1
+    for _ in range(4):
+        argmax_next()
+    ctx.timer_start()
+    for _ in range(reps + 2):
+        argmax_next()
+    ms = ctx.timer_stop() / (reps + 2)
+    nbytes = (4.0 * nz + 9.0) * nx * ny
+    out["argmax"] = {"ms": ms, "GBps": nbytes / (ms * 1e-3) / 1e9, "frac_of_hbm_peak": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "note": "four 210 MB volumes in turn: served from HBM, not from the Infinity Cache"}
     out["grid"] = "%dx%dx%d (%.0f MB per volume)" % (nx, ny, nz, 4.0 * nvox / 1e6)
     for o in [m] + c4:
         o.close()
@@ -431,14 +451,20 @@ def other_workloads():
     default run carries them too.  Run after this process has released the GPU."""
     import subprocess
     res = {}
-    for name in ("windows", "cameras4"):
-        cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--no-cpu", "--no-host-fed", "--no-extra"]
+    runs = (("windows", ["--workload", "windows"]), ("cameras4", ["--workload", "cameras4"]),
+            # BASELINE configs[4] at ITS OWN size on one GPU: 4 x 99,993,600 events, 1024 x 1024 x 256, GM tree + arg-max
+            ("cameras4_full", ["--workload", "cameras4", "--events", "100000000", "--tile", "10", "--steps", "3", "--warmup", "1",
+                               "--clock-ramp", "1"]))
+    for name, flags in runs:
+        # (the windows line carries its host-fed rates: Python from pageable / page-locked arrays, C++ from std::vector<Event>)
+        cmd = [sys.executable, os.path.abspath(__file__)] + flags + ["--no-cpu", "--no-extra"] + ([] if name == "windows" else ["--no-host-fed"])
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
             line = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1]
             j = json.loads(line)
             res[name] = {k: j.get(k) for k in ("value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline",
-                                                 "step_ms", "windows_per_s", "x_real_time", "timed_region_s")}
+                                                 "step_ms", "windows_per_s", "x_real_time", "timed_region_s",
+                                                 "device_memory", "input_gen_s", "host_fed")}
         except Exception as e:                                  # report, do not fail the headline
             res[name] = {"error": str(e)[:300]}
     return res
@@ -619,7 +645,8 @@ def main():
 
     else:
         # ---- configs[4] shape: 4 cameras, n-ary GM; N > 1: plane sharding ----
-        rig = syn.stereo_rig(args.events, width=nx, height=ny, t0=10.0, duration=0.5, seed=1234, n_cams=4,
+        tile = max(1, args.tile)
+        rig = syn.stereo_rig(args.events // tile, width=nx, height=ny, t0=10.0, duration=0.5, seed=1234, n_cams=4,
                              n_points=args.points)
         shape = d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0)
         begin, count = dd.plane_ranges(nz, world)[rank]
@@ -630,8 +657,20 @@ def main():
             cc = cam_ctxs[c % len(cam_ctxs)]
             m = tune(d.MapperEMVS(cc, rig["cam"], shape, plane_range=(begin, count)))
             first, Rt = d.packetize(rig["events"][c][2], rig["trajectories"][c], rig["T_rv_w"])
-            batches.append(d.EventBatch(cc, rig["events"][c][0], rig["events"][c][1], Rt, first))
-            voted += first.shape[0] * d.PACKET_SIZE
+            ex, ey = rig["events"][c][0], rig["events"][c][1]
+            if tile > 1:
+                # the same pixels seen from a rig that has moved on: `tile` different stretches of the trajectory
+                n = first.shape[0] * d.PACKET_SIZE
+                assert np.array_equal(first, np.arange(first.shape[0], dtype=np.uint32) * d.PACKET_SIZE)
+                rts = []
+                for i in range(tile):
+                    r_ = Rt.copy()
+                    r_[:, 9] += 0.02 * i
+                    r_[:, 11] += 0.01 * i
+                    rts.append(r_)
+                ex, ey, Rt, first = np.tile(ex[:n], tile), np.tile(ey[:n], tile), np.concatenate(rts), None
+            batches.append(d.EventBatch(cc, ex, ey, Rt, first))
+            voted += batches[-1].n_packets * d.PACKET_SIZE
             mappers.append(m)
         vote_mappers = mappers
         extra["batch0"] = batches[0]
@@ -692,6 +731,20 @@ def main():
     # clock ramp (untimed, before the contract's W warm-up steps): the GPU idled for seconds while the host generated the
     # inputs, and the first launches after an idle stretch run 1-2 % slow (measured: stereo 2.623 -> 2.589 ms per step,
     # windows 0.451 -> 0.443, cameras4 6.51 -> 6.37 with a long warm-up); a stream of real windows never idles
+    # ... and the same K steps timed WITHOUT it first (after the W warm-up steps only, the contract's letter), reported
+    # beside `value` as value_no_ramp
+    no_ramp = None
+    if args.clock_ramp > 0 and world == 1:
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t_nr = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        t_nr = time.perf_counter() - t_nr
+        no_ramp = {"value": voted_per_step * args.steps / t_nr / 1e6, "ms_per_step": 1e3 * t_nr / args.steps,
+                   "note": "the same K steps after the W warm-up steps only, before the clock-ramp steps"}
     t_ramp = time.perf_counter()
     for i in range(args.clock_ramp):
         step()
@@ -874,6 +927,7 @@ def main():
                 for cx, cy, _ in cams_:
                     cx.close()
                     cy.close()
+            h2d["cpp_stream"] = cpp_stream_line()
 
         cpu = None
         if not args.no_cpu and world == 1:      # (the CPU baseline is a rank-0, N = 1 figure; at N > 1 the other ranks would only wait for it)
@@ -921,6 +975,8 @@ def main():
             "stream_kernels": streams,
             "gpu_ms_per_step_hip_events": gpu_ms / args.steps,
             "timed_region_s": elapsed,
+            "value_no_ramp": no_ramp["value"] if no_ramp else None,
+            "no_ramp": no_ramp,
             "clock_ramp": {"steps": args.clock_ramp, "seconds": t_ramp,
                            "note": "untimed steps before the warm-up steps: brings the clocks up after the idle input generation"},
             "host_fed": h2d, "roofline": roofline, "cpu_baseline": cpu, "input_gen_s": t_gen,
@@ -930,6 +986,7 @@ def main():
             if step_ms.shape[0] else None,
             "parity": parity,
             "sensitivity": sensitivity,
+            "device_memory": device_memory(),
         }
         if others:
             out["other_workloads_pending"] = True
@@ -965,6 +1022,40 @@ def main():
         sys.stdout.flush()
         print(json.dumps(out))
         sys.stdout.flush()
+
+
+def cpp_stream_line():
+    """The same stream through the C++ adapter (dsi::full_sequence_depth_maps, include/dsi_process.hpp) fed from
+    std::vector<dsi::Event> -- 24-byte structs in pageable memory, like the reference holds its events
+    (main.cpp:177-302): tools/window_stream_bench in its own process, after this one's work."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "window_stream_bench")
+    if not os.path.exists(exe):
+        return {"error": "tools/window_stream_bench is not built (__graft_entry__.build())"}
+    try:
+        r = subprocess.run([exe, "4.0"], capture_output=True, text=True, timeout=300)
+        rows = [json.loads(ln[5:]) for ln in r.stdout.splitlines() if ln.startswith("JSON ")]
+        if not rows:
+            return {"error": (r.stdout + r.stderr)[-300:]}
+        return {"by_depth": rows, "source": "std::vector<dsi::Event> (24-byte structs, pageable), host threads turn a window into the "
+                "engine's arrays in page-locked staging; 2 x 500 k events per 50 ms window, 512x512x200; steady state"}
+    except Exception as e:
+        return {"error": str(e)[:300]}
+
+
+def device_memory():
+    """Bytes of HBM in use on the current device at the end of the timed region (hipMemGetInfo: everything the engine
+    holds -- the allocations only grow --, plus the runtime's own few hundred MB)."""
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        free_b, total_b = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        if hip.hipMemGetInfo(ctypes.byref(free_b), ctypes.byref(total_b)) != 0:
+            return None
+        return {"used_GB": (total_b.value - free_b.value) / 1e9, "total_GB": total_b.value / 1e9,
+                "source": "hipMemGetInfo after the timed region (grow-only allocations: the high-water mark)"}
+    except OSError:
+        return None
 
 
 def info_nz(mapper):

@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
 #include <string>
@@ -107,6 +108,13 @@ struct dsi_context {
     double* ms_accum = nullptr;    // device scalar for mean-square
     // Event batches are uploaded on their own stream so that the upload of the next batch (camera,
     // window) overlaps the voting of the current one; "ready" / "freed" events order the two streams.
+    // ONE upload stream per device, shared by its contexts (uploads share the PCIe link anyway): the runtime maps
+    // streams onto four hardware queues by default, and a pipeline of windows -- one context per window in flight --
+    // that gave every context two streams of its own had its uploads queue behind another window's kernel
+    // (profiles/r04_cpp_window_stream.txt: 0.41 ms per window waiting for uploads).
+    hipStream_t upload_stream = nullptr;
+    // device -> host copies of depth maps that must not wait for later work of the compute stream
+    // (dsi_mapper_fetch_depth_map[_async]); created on first use
     hipStream_t copy_stream = nullptr;
     // Released event-batch blocks, reused by the next dsi_batch_create on this context: a stream of
     // windows then costs no hipMalloc / hipFree (hipFree synchronises the device).
@@ -124,6 +132,47 @@ struct dsi_context {
     // context refuses to go while any is alive (destroying it first was a use-after-free in their destroy)
     std::atomic<int> children{0};
 };
+
+// the per-device upload stream (see dsi_context::upload_stream)
+struct SharedUpload {
+    hipStream_t stream = nullptr;
+    int refs = 0;
+};
+std::mutex g_upload_mu;
+std::map<int, SharedUpload> g_upload;
+
+hipError_t upload_stream_acquire(int device, hipStream_t* out)
+{
+    std::lock_guard<std::mutex> lock(g_upload_mu);
+    SharedUpload& u = g_upload[device];
+    if (!u.stream)
+        if (hipError_t e = hipStreamCreateWithFlags(&u.stream, hipStreamNonBlocking)) return e;
+    ++u.refs;
+    *out = u.stream;
+    return hipSuccess;
+}
+
+void upload_stream_release(int device)
+{
+    std::lock_guard<std::mutex> lock(g_upload_mu);
+    auto it = g_upload.find(device);
+    if (it == g_upload.end()) return;
+    if (--it->second.refs <= 0) {
+        if (it->second.stream) {
+            (void)hipStreamSynchronize(it->second.stream);
+            (void)hipStreamDestroy(it->second.stream);
+        }
+        g_upload.erase(it);
+    }
+}
+
+hipError_t copy_stream_of(dsi_context* ctx, hipStream_t* out)
+{
+    if (!ctx->copy_stream)
+        if (hipError_t e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking)) return e;
+    *out = ctx->copy_stream;
+    return hipSuccess;
+}
 
 bool pool_take(dsi_context* ctx, size_t bytes, dsi_context::PoolBlock* out)
 {
@@ -584,13 +633,17 @@ int depth_buffers_ready(dsi_mapper* m)
     return DSI_OK;
 }
 
-// device -> host copies of the depth map on the copy stream (see dsi_mapper::ev_depth_ready)
-int depth_buffers_fetch(dsi_mapper* m, float* depth_host, float* conf_host, uint8_t* idx_host, bool wait)
+// device -> host copies of the depth map: on the context's copy stream behind the arg-max only (see
+// dsi_mapper::ev_depth_ready), or -- in_order -- on the compute stream behind whatever it holds
+int depth_buffers_fetch(dsi_mapper* m, float* depth_host, float* conf_host, uint8_t* idx_host, bool wait, bool in_order = false)
 {
     dsi_context* ctx = m->ctx;
-    hipStream_t cs = ctx->copy_stream;
+    hipStream_t cs = ctx->stream;
     const size_t npix = (size_t)m->geom.nx * m->geom.ny;
-    HIP_TRY(hipStreamWaitEvent(cs, m->ev_depth_ready, 0));
+    if (!in_order) {
+        HIP_TRY(copy_stream_of(ctx, &cs));
+        HIP_TRY(hipStreamWaitEvent(cs, m->ev_depth_ready, 0));
+    }
     if (depth_host) HIP_TRY(hipMemcpyAsync(depth_host, m->depth.p, npix * sizeof(float), hipMemcpyDeviceToHost, cs));
     if (conf_host) HIP_TRY(hipMemcpyAsync(conf_host, m->conf.p, npix * sizeof(float), hipMemcpyDeviceToHost, cs));
     if (idx_host) HIP_TRY(hipMemcpyAsync(idx_host, m->idx.p, npix, hipMemcpyDeviceToHost, cs));
@@ -760,7 +813,7 @@ int dsi_context_create(int device_id, dsi_context_t** out)
     REQUIRE(ctx, DSI_ERR_INVALID, "out of host memory");
     ctx->device = device_id;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = upload_stream_acquire(device_id, &ctx->upload_stream);
     if (e == hipSuccess) e = hipEventCreate(&ctx->t0);
     if (e == hipSuccess) e = hipEventCreate(&ctx->t1);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&ctx->ms_accum), sizeof(double));
@@ -781,6 +834,11 @@ int dsi_context_destroy(dsi_context_t* ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    if (ctx->upload_stream) {
+        (void)hipStreamSynchronize(ctx->upload_stream);
+        upload_stream_release(ctx->device);
+        ctx->upload_stream = nullptr;
+    }
     for (auto& blk : ctx->batch_pool) {
         (void)hipFree(blk.p);
         (void)hipEventDestroy(blk.freed);
@@ -1193,7 +1251,7 @@ int dsi_mapper_destroy(dsi_mapper_t* m)
         (void)hipEventDestroy(m->ev_vote_done);
     }
     if (m->ev_depth_ready) {
-        (void)hipStreamSynchronize(m->ctx->copy_stream);
+        if (m->ctx->copy_stream) (void)hipStreamSynchronize(m->ctx->copy_stream);
         (void)hipEventDestroy(m->ev_depth_ready);
         (void)hipEventDestroy(m->ev_depth_read);
     }
@@ -1351,7 +1409,7 @@ static int batch_create(dsi_context_t* ctx, const uint16_t* x, const uint16_t* y
     b->first = packet_first ? reinterpret_cast<uint32_t*>(base + rt_bytes) : nullptr;
     b->x = reinterpret_cast<uint16_t*>(base + rt_bytes + first_bytes);
     b->y = reinterpret_cast<uint16_t*>(base + rt_bytes + first_bytes + ev_bytes);
-    hipStream_t cs = ctx->copy_stream;
+    hipStream_t cs = ctx->upload_stream;
     hipError_t e = hipEventCreateWithFlags(&b->ready, hipEventDisableTiming);
     // the block's previous reader (a kernel on the compute stream) must be done before we overwrite it
     if (e == hipSuccess) e = hipStreamWaitEvent(cs, b->block.freed, 0);
@@ -2054,6 +2112,14 @@ int dsi_mapper_fetch_depth_map_async(dsi_mapper_t* m, float* depth_host, float* 
     REQUIRE(m->depth_valid, DSI_ERR_INVALID, "no depth map has been computed since the last vote");
     if (int rc = set_device(m->ctx)) return rc;
     return depth_buffers_fetch(m, depth_host, conf_host, idx_host, /*wait=*/false);
+}
+
+int dsi_mapper_fetch_depth_map_in_order(dsi_mapper_t* m, float* depth_host, float* conf_host, uint8_t* idx_host)
+{
+    REQUIRE(m, DSI_ERR_INVALID, "mapper is null");
+    REQUIRE(m->depth_valid, DSI_ERR_INVALID, "no depth map has been computed since the last vote");
+    if (int rc = set_device(m->ctx)) return rc;
+    return depth_buffers_fetch(m, depth_host, conf_host, idx_host, /*wait=*/false, /*in_order=*/true);
 }
 
 int dsi_mapper_fetch_wait(dsi_mapper_t* m)

@@ -158,6 +158,7 @@ def load_library():
         "dsi_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(vp)]),
         "dsi_host_free": (C.c_int, [vp]),
         "dsi_mapper_fetch_depth_map_async": (C.c_int, [vp, f32p, f32p, u8p]),
+        "dsi_mapper_fetch_depth_map_in_order": (C.c_int, [vp, f32p, f32p, u8p]),
         "dsi_mapper_fetch_wait": (C.c_int, [vp]),
         "dsi_batch_num_packets": (C.c_size_t, [vp]),
         "dsi_mapper_evaluate_batch": (C.c_int, [vp, vp]),
@@ -999,10 +1000,24 @@ class MapperEMVS:
     def fetchWait(self):
         _check(load_library().dsi_mapper_fetch_wait(self._h))
 
-    def fetchDepthMap(self):
+    def fetchDepthMapInOrder(self, depth, conf, idx):
+        """Like fetchDepthMapAsync, but on the context's COMPUTE stream behind whatever it holds (no second stream per
+        context: for pipelines with one context per window in flight); valid after fetchWait()."""
+        _check(load_library().dsi_mapper_fetch_depth_map_in_order(
+            self._h, None if depth is None else _ptr(depth, C.c_float),
+            None if conf is None else _ptr(conf, C.c_float), None if idx is None else _ptr(idx, C.c_uint8)))
+
+    def fetchDepthMap(self, in_order=False):
+        """(depth, confidence, indices) on the host (synchronises).  in_order: the copies go on the compute stream (see
+        fetchDepthMapInOrder) instead of the context's copy stream."""
         depth = np.empty((self.dimY, self.dimX), np.float32)
         conf = np.empty((self.dimY, self.dimX), np.float32)
         idx = np.empty((self.dimY, self.dimX), np.uint8)
+        if in_order:
+            self.fetchDepthMapInOrder(depth, conf, idx)
+            self.fetchWait()                       # (pageable destinations: the runtime has copied by then)
+            _check(load_library().dsi_context_synchronize(self.ctx._h))
+            return depth, conf, idx
         _check(load_library().dsi_mapper_fetch_depth_map(self._h, _ptr(depth, C.c_float),
                                                          _ptr(conf, C.c_float), _ptr(idx, C.c_uint8)))
         return depth, conf, idx

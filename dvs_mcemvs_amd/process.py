@@ -446,7 +446,9 @@ class WindowStream:
         window's arg-max was produced."""
         if options_depth_map is not None:
             return self.extract[slot].filterDepthMap(options_depth_map)
-        return self.extract[slot].fetchDepthMap()
+        # (every slot has its own context when the stream is concurrent: the copies follow the window's kernels on its
+        #  compute stream -- one stream per window in flight, plus the device's shared upload stream)
+        return self.extract[slot].fetchDepthMap(in_order=self.concurrent)
 
     def fused_grid(self, slot):
         return self.fused[slot]

@@ -382,6 +382,12 @@ DSI_API int dsi_mapper_fetch_depth_map(dsi_mapper_t *m, float *depth_host, float
  * dsi_host_alloc) are valid after dsi_mapper_fetch_wait */
 DSI_API int dsi_mapper_fetch_depth_map_async(dsi_mapper_t *m, float *depth_host, float *conf_host,
                                              uint8_t *idx_host);
+/* the same copies queued on the context's COMPUTE stream, in order behind whatever it already holds -- for pipelines that
+ * give every window in flight its own context (main.cpp:177 as a stream: include/dsi_process.hpp full_sequence_depth_maps)
+ * and fetch right after the window's kernels: no second stream per context (the runtime maps streams onto four hardware
+ * queues by default; contexts with two streams each made windows' uploads and copies queue behind other windows' kernels).
+ * Valid after dsi_mapper_fetch_wait, like the _async form. */
+DSI_API int dsi_mapper_fetch_depth_map_in_order(dsi_mapper_t *m, float *depth_host, float *conf_host, uint8_t *idx_host);
 DSI_API int dsi_mapper_fetch_wait(dsi_mapper_t *m);
 
 /* Plane sharding (one DSI too big or too slow for one GPU): every rank's mapper owns a

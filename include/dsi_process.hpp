@@ -489,7 +489,7 @@ inline size_t full_sequence_depth_maps(const std::vector<int>& devices, const Pi
     for (double interval_start = start_time_s; interval_start + duration <= stop_time_s; interval_start += out_skip)
         starts.push_back(interval_start);
     const size_t n_windows = starts.size();
-    constexpr int kPrepSplit = 2;  // host threads per camera (a window's 500 k 24-byte events take one core 0.4-0.7 ms)
+    constexpr int kPrepSplit = 4;  // host threads per camera (a window's 500 k 24-byte events take one core 0.4-0.7 ms)
     WindowPrepWorker workers[2 * kPrepSplit];
     // prepare(i): window i's interval, reference view and event ranges, then the preparation threads fill the slot's
     // INPUT staging.  That staging was last read by the uploads of the window the slot holds (window i - depth), which
@@ -563,8 +563,9 @@ inline size_t full_sequence_depth_maps(const std::vector<int>& devices, const Pi
                                          &s.batch[c]));
         }
         check(dsi_mapper_depth_map_of_events(s.out.handle(), ms, s.batch, 2, fusion_method));
-        check(dsi_mapper_fetch_depth_map_async(s.out.handle(), static_cast<float*>(s.host[0]), static_cast<float*>(s.host[1]),
-                                               static_cast<uint8_t*>(s.host[2])));
+        // (behind the window's kernels on its context's stream: ONE stream per window in flight + the device's upload stream)
+        check(dsi_mapper_fetch_depth_map_in_order(s.out.handle(), static_cast<float*>(s.host[0]), static_cast<float*>(s.host[1]),
+                                                  static_cast<uint8_t*>(s.host[2])));
         s.busy = true;
         st.submit_ms += since(t0);
     };

@@ -3,9 +3,9 @@
 // 2 x ~500 k events (10 Mevents/s per camera), sensor 640 x 480, DSI 512 x 512 x 200, harmonic-mean fusion --
 // fed from std::vector<dsi::Event> in pageable host memory, like the reference holds them.  Prints ms per window
 // for 1, 2 and 3 windows in flight.
-// build (on the GPU box, rpath = the box's copy of the repo):
+// build (__graft_entry__.build() does it; the rpath is relative to the binary):
 //   g++ -std=c++17 -O2 -pthread tools/window_stream_bench.cpp -Iinclude -Ldvs_mcemvs_amd -ldsi_engine
-//       -Wl,-rpath,$PWD/dvs_mcemvs_amd -Wl,-rpath,/opt/rocm/lib -o tools/window_stream_bench
+//       '-Wl,-rpath,$ORIGIN/../dvs_mcemvs_amd' -Wl,-rpath,/opt/rocm/lib -o tools/window_stream_bench
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -107,6 +107,12 @@ int main(int argc, char** argv)
                     std::printf("depth %d: %zu windows, %.3f ms per window in steady state (%.0f windows/s, %.1f x real time); whole call "
                                 "%.1f ms; %.0f events per window, checksum %.6g\n", depth, nw, steady, 1e3 / steady,
                                 duration * 1e3 / steady, ms, (double)ev_sum / (double)nw, checksum);
+                if (rep == 1)  // one machine-readable line per depth (bench.py: host_fed.cpp_stream)
+                    std::printf("JSON {\"depth\": %d, \"windows\": %zu, \"ms_per_window\": %.4f, \"windows_per_s\": %.1f, \"x_real_time\": %.2f, "
+                                "\"wait_prepare_ms\": %.4f, \"wait_gpu_ms\": %.4f, \"wait_upload_ms\": %.4f, \"deliver_ms\": %.4f, \"submit_ms\": %.4f}\n",
+                                depth, nw, steady, 1e3 / steady, duration * 1e3 / steady, stats.wait_prepare_ms / (double)nw,
+                                stats.wait_gpu_ms / (double)nw, stats.wait_upload_ms / (double)nw, stats.deliver_ms / (double)nw,
+                                stats.submit_ms / (double)nw);
                 if (rep == 1)
                     std::printf("         calling thread per window: wait for the preparation threads %.3f, wait for the GPU %.3f + %.3f (uploads), deliver %.3f, "
                                 "submit %.3f ms (whole call %.1f ms)\n", stats.wait_prepare_ms / (double)nw, stats.wait_gpu_ms / (double)nw,
