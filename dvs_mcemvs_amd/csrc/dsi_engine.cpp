@@ -643,6 +643,29 @@ int depth_buffers_fetch(dsi_mapper* m, float* depth_host, float* conf_host, uint
     if (!in_order) {
         HIP_TRY(copy_stream_of(ctx, &cs));
         HIP_TRY(hipStreamWaitEvent(cs, m->ev_depth_ready, 0));
+    } else {
+        // destinations in mapped page-locked memory (dsi_host_alloc): the CUs store the maps there, no copy engine involved
+        // (a device -> host copy queued behind this window's kernel would hold up the next window's uploads)
+        auto mapped = [](void* host, void** dev) {
+            *dev = nullptr;
+            if (!host) return true;
+            hipPointerAttribute_t attr{};
+            if (hipPointerGetAttributes(&attr, host) != hipSuccess) {
+                (void)hipGetLastError();  // (an ordinary pointer: not an error of ours)
+                return false;
+            }
+            if (attr.type != hipMemoryTypeHost) return false;
+            return hipHostGetDevicePointer(dev, host, 0) == hipSuccess && *dev;
+        };
+        void *dd = nullptr, *dc = nullptr, *di = nullptr;
+        if (mapped(depth_host, &dd) && mapped(conf_host, &dc) && mapped(idx_host, &di) && npix % 4 == 0) {
+            HIP_TRY(dsi::launch_store_depth_map(cs, m->depth.p, m->conf.p, m->idx.p, npix, static_cast<float*>(dd),
+                                                static_cast<float*>(dc), static_cast<uint8_t*>(di)));
+            HIP_TRY(hipEventRecord(m->ev_depth_read, cs));
+            m->depth_read_pending = true;
+            if (wait) HIP_TRY(hipEventSynchronize(m->ev_depth_read));
+            return DSI_OK;
+        }
     }
     if (depth_host) HIP_TRY(hipMemcpyAsync(depth_host, m->depth.p, npix * sizeof(float), hipMemcpyDeviceToHost, cs));
     if (conf_host) HIP_TRY(hipMemcpyAsync(conf_host, m->conf.p, npix * sizeof(float), hipMemcpyDeviceToHost, cs));
@@ -1382,11 +1405,16 @@ static int batch_create(dsi_context_t* ctx, const uint16_t* x, const uint16_t* y
     REQUIRE(n_packets == 0 || Rt, DSI_ERR_INVALID, "null pose array");
     REQUIRE(n_events < ((size_t)1 << 32), DSI_ERR_INVALID, "at most 2^32-1 events per batch");
     REQUIRE(n_packets < ((size_t)1 << 21), DSI_ERR_INVALID, "too many packets in one batch");
+    bool regular = true;  // packet k starts at event k * 1024 (no pose look-up failed, mapper_emvs_stereo.cpp:95-99)
     for (size_t k = 0; k < n_packets; ++k) {
         const size_t first = packet_first ? packet_first[k] : k * dsi::kPacket;
         REQUIRE(first + dsi::kPacket <= n_events, DSI_ERR_INVALID,
                 "packet %zu [%zu, %zu) exceeds the %zu events given", k, first, first + dsi::kPacket, n_events);
+        regular = regular && first == k * dsi::kPacket;
     }
+    // ... then the table is implied and does not travel: the runtime moves a copy of a few KB with a shader, which waits for
+    // a free CU behind a persistent voting kernel and held up a window's other uploads by 0.2 ms (profiles/r05_cpp_window_stream_timeline.txt)
+    if (regular) packet_first = nullptr;
     if (int rc = set_device(ctx)) return rc;
     dsi_batch* b = new (std::nothrow) dsi_batch();
     REQUIRE(b, DSI_ERR_INVALID, "out of host memory");

@@ -176,6 +176,9 @@ hipError_t launch_fuse_hm_n(hipStream_t s, float* a, const float* g, size_t n, i
 hipError_t launch_accumulate(hipStream_t s, float* acc, const float* g, size_t n, int mode);
 hipError_t launch_finalize(hipStream_t s, float* acc, size_t n, int mode, int n_maps);
 hipError_t launch_fill(hipStream_t s, float* a, size_t n, float v);
+// the depth map's arrays stored by a kernel into mapped page-locked host memory (device-side addresses; any may be null)
+hipError_t launch_store_depth_map(hipStream_t s, const float* depth, const float* conf, const uint8_t* idx, size_t npix,
+                                  float* depth_host_dev, float* conf_host_dev, uint8_t* idx_host_dev);
 hipError_t launch_fuse_n(hipStream_t s, float* dst, const float* const* srcs, int n_src, size_t n, int mode);
 hipError_t launch_pack_argmax(hipStream_t s, const float* conf, const uint8_t* idx, int n, int plane_begin,
                               unsigned long long* keys, int combine = 0);

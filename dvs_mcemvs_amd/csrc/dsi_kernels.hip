@@ -4669,6 +4669,38 @@ __global__ __launch_bounds__(256) void k_fill(float* __restrict__ a, size_t n, f
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) a[i] = v;
 }
 
+// depth map -> page-locked host memory by the CUs (the three arrays of a fetch in one launch): see launch_store_depth_map
+__global__ __launch_bounds__(256) void k_store_depth_map(const float* __restrict__ depth, const float* __restrict__ conf,
+                                                         const uint8_t* __restrict__ idx, size_t npix, float* __restrict__ depth_h,
+                                                         float* __restrict__ conf_h, uint8_t* __restrict__ idx_h)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += stride) {
+        if (depth_h) depth_h[i] = depth[i];
+        if (conf_h) conf_h[i] = conf[i];
+    }
+    if (idx_h) {
+        const size_t n4 = npix / 4;  // (hipMalloc'ed and hipHostMalloc'ed arrays: 4-byte aligned)
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(idx);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(idx_h);
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+        if (blockIdx.x == 0 && threadIdx.x < npix - 4 * n4) idx_h[4 * n4 + threadIdx.x] = idx[4 * n4 + threadIdx.x];
+    }
+}
+
+// A device -> host copy queued on an SDMA engine BEHIND a kernel holds up every later copy of that engine -- the next
+// window's uploads waited for the current window's kernel (profiles/r05_cpp_window_stream_timeline.txt).  A kernel that
+// stores the maps into mapped page-locked memory keeps the copy engines free for the uploads.
+hipError_t launch_store_depth_map(hipStream_t s, const float* depth, const float* conf, const uint8_t* idx, size_t npix,
+                                  float* depth_host_dev, float* conf_host_dev, uint8_t* idx_host_dev)
+{
+    if (!npix) return hipSuccess;
+    // (PCIe-bound: a few CUs do, the others are the next window's)
+    hipLaunchKernelGGL(k_store_depth_map, dim3(grid_for(npix, 256, 64)), dim3(256), 0, s, depth, conf, idx, npix, depth_host_dev,
+                       conf_host_dev, idx_host_dev);
+    return hipExtGetLastError();
+}
+
 hipError_t launch_fill(hipStream_t s, float* a, size_t n, float v)
 {
     hipLaunchKernelGGL(k_fill, dim3(grid_for(n, 256)), dim3(256), 0, s, a, n, v);
