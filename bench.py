@@ -132,7 +132,15 @@ def make_comm(d, dd, ctx, D):
     other collective backend."""
     if D.world == 1:
         return dd.engine_allreduce(None), None, "none (1 rank)"
-    uid = D.broadcast(d.Comm.unique_id() if D.rank == 0 else None)
+    uid, uid_err = None, ""
+    if D.rank == 0:
+        try:
+            uid = d.Comm.unique_id()
+        except d.DsiError as e:          # librccl missing / broken: every rank must learn it, or the others wait in the broadcast
+            uid_err = str(e)
+    uid, uid_err = D.broadcast((uid, uid_err))
+    if uid is None:
+        raise SystemExit("bench.py: rank 0 could not create the RCCL unique id (%s); there is no other collective backend" % uid_err)
     try:
         comm = d.Comm(ctx, uid, D.world, D.rank)
         ok, err = 1, ""
@@ -964,6 +972,7 @@ def main():
                        "launched_by": ("a launcher (RANK / WORLD_SIZE in the environment)" if not D.spawned else
                                        "bench.py itself (dvs_mcemvs_amd.launch.spawn_ranks), one process per GPU")
                        if world > 1 else "single process"},
+            "launch_env": launch.environment_report() if world > 1 else None,
             "rccl_ranks": rccl[0] if rccl else 1,
             "ranks": ranks,
             "collective": collective_block,

@@ -35,15 +35,42 @@ def launched_by_a_launcher(env=None):
     return "WORLD_SIZE" in env and "RANK" in env
 
 
+# Two settings the ranks get unless the caller's environment already has them -- guesses until an 8-GPU node has run
+# (RCCL with more than one rank never has, in any round): whatever the environment says wins, DSI_LAUNCH_NO_ENV_DEFAULTS=1
+# sets neither, and bench.py prints what the ranks actually ran with (environment_report) in its JSON line.
+ENV_DEFAULTS = {
+    # the host driver only supports dmabuf IPC (without it RCCL fails with hipIpcGetMemHandle: invalid argument)
+    "HSA_ENABLE_IPC_MODE_LEGACY": "0",
+    # one node: RCCL's bootstrap sockets on the loopback interface (the container's hostname may not resolve)
+    "NCCL_SOCKET_IFNAME": "lo",
+}
+NO_DEFAULTS_ENV = "DSI_LAUNCH_NO_ENV_DEFAULTS"
+
+
+def apply_env_defaults(env):
+    if env.get(NO_DEFAULTS_ENV) == "1":
+        return env
+    for k, v in ENV_DEFAULTS.items():
+        env.setdefault(k, v)
+    return env
+
+
+def environment_report(env=None):
+    """What a rank runs with for the settings above: value and whether it is this module's default."""
+    env = os.environ if env is None else env
+    rep = {}
+    for k, v in ENV_DEFAULTS.items():
+        have = env.get(k)
+        rep[k] = {"value": have, "is_launch_default": have == v and env.get(NO_DEFAULTS_ENV) != "1"}
+    rep["defaults_disabled"] = env.get(NO_DEFAULTS_ENV) == "1"
+    return rep
+
+
 def rank_environment(base, rank, world, port):
     env = dict(base)
     env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
                 "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), SPAWNED_ENV: "1"})
-    # the host driver only supports dmabuf IPC (without it RCCL fails with hipIpcGetMemHandle: invalid argument)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    # one node: RCCL's bootstrap sockets on the loopback interface (the container's hostname may not resolve)
-    env.setdefault("NCCL_SOCKET_IFNAME", "lo")
-    return env
+    return apply_env_defaults(env)
 
 
 def spawn_ranks(world, argv, n_devices=None, env=None, timeout=None, poll_s=0.05, out=None, err=None):
@@ -120,9 +147,10 @@ class Dist:
         if self.world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-            if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
-                os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            if os.environ.get(NO_DEFAULTS_ENV) != "1":
+                if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+                    os.environ.setdefault("NCCL_SOCKET_IFNAME", ENV_DEFAULTS["NCCL_SOCKET_IFNAME"])
+                os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", ENV_DEFAULTS["HSA_ENABLE_IPC_MODE_LEGACY"])
             import torch
             import torch.distributed as dist
             self.torch, self.dist = torch, dist
