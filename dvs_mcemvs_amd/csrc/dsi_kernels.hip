@@ -4407,12 +4407,21 @@ static hipError_t launch_vote_fuse_argmax_t(hipStream_t s, const FusedCameras& c
         if (bp.experiment != 300 && bp.lds_bytes * 2 <= max_dynamic_lds() && (size_t)(bp.band_rows + 2) * g.nx <= (size_t)HALF * 1024) {
             const void* kern2 = reinterpret_cast<const void*>(&k_vote_fuse_argmax_2cu<MAPPING, HALF>);
             if (hipError_t e = allow_dynamic_lds(kern2, bp.lds_bytes)) return e;
+            // ... only if the runtime agrees that two fit (static LDS and the allocation granularity also count: a band just
+            // under half the LDS would otherwise run its 2 x grid of half-size assignments in two serialised waves)
+            int resident = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, kern2, 1024, bp.lds_bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                resident = 0;
+            }
+            if (resident < 2) goto one_per_cu;
             // (the balanced partition, an experiments-flavour option, is laid out for one workgroup per CU: not used here)
             hipLaunchKernelGGL((k_vote_fuse_argmax_2cu<MAPPING, HALF>), dim3(2 * blocks), dim3(1024), bp.lds_bytes, s, cams, g, bp, op,
                                nullptr, keys, trace);
             return hipExtGetLastError();
         }
     }
+one_per_cu:
     const void* kern = reinterpret_cast<const void*>(&k_vote_fuse_argmax<MAPPING, CELLS>);
     if (hipError_t e = allow_dynamic_lds(kern, bp.lds_bytes)) return e;
     hipLaunchKernelGGL((k_vote_fuse_argmax<MAPPING, CELLS>), dim3(blocks), dim3(1024), bp.lds_bytes, s, cams, g, bp, op, splits, keys, trace);

@@ -311,7 +311,9 @@ class Context:
                         o.close()
                     except Exception:
                         pass
-            load_library().dsi_context_destroy(self._h)
+            # (the C side refuses while children are alive: that would be a permanent leak of the stream, the pool and
+            #  the scratch -- raise, and keep the handle so that a later close() can succeed)
+            _check(load_library().dsi_context_destroy(self._h))
             self._h = C.c_void_p()
 
     def __del__(self):

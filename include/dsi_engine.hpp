@@ -154,7 +154,12 @@ inline bool inpaint_depth_cell_indices(const ImgT& /*filtered u8*/, const ImgT& 
 class Context {
 public:
     explicit Context(int device = 0) { check(dsi_context_create(device, &h_)); }
-    ~Context() { dsi_context_destroy(h_); }
+    ~Context()
+    {
+        // the C side refuses (and destroys nothing) while grids, mappers or batches of this context are alive: a wrong
+        // destruction order would be a silent, permanent leak of the stream, the pool and the scratch -- say so
+        if (dsi_context_destroy(h_) != DSI_OK) std::fprintf(stderr, "dsi::Context: NOT destroyed: %s\n", dsi_last_error());
+    }
     Context(const Context&) = delete;
     Context& operator=(const Context&) = delete;
     dsi_context_t* handle() const { return h_; }

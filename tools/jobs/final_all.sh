@@ -1,11 +1,11 @@
 # end-of-round job: re-stamp traffic.json on the final kernel source (tools/profile_round.sh), the workloads' traces, then
 # the -m gpu suite, smoke() and the driver's bench command
 cd $GRAFT_REPO_ROOT
-R=${1:-r04}
+R=${1:-r05}
 bash tools/profile_round.sh $R > gpurun_out/profile_round_$R.log 2>&1
 tail -2 gpurun_out/profile_round_$R.log
 cp gpurun_out/profiles_$R/traffic.json profiles/traffic.json
-bash tools/profile_workloads.sh $R windows cameras4 1024 > gpurun_out/profile_workloads_$R.log 2>&1
+bash tools/profile_workloads.sh $R windows cameras4 cameras4_full 1024 > gpurun_out/profile_workloads_$R.log 2>&1
 export TMPDIR=/tmp; mkdir -p gpurun_out/tr
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/tr -o t -- python $GRAFT_REPO_ROOT/bench.py --no-cpu --no-host-fed --no-extra --no-sensitivity --steps 50 --warmup 5 > $GRAFT_REPO_ROOT/gpurun_out/${R}_trace_bench.log 2>&1)
 python tools/rocpd_summary.py gpurun_out/tr/*.db > gpurun_out/${R}_kernel_trace_stats_timed_only.txt 2>&1; rm -rf gpurun_out/tr
