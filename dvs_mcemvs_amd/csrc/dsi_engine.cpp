@@ -2004,7 +2004,7 @@ int dsi_mapper_resolve_near_ties(dsi_mapper_t* out, dsi_mapper_t* const* mappers
         for (int wd = 0; wd < kTieCounterWords - kTieCounterPassWords; ++wd) info->candidate_planes += __builtin_popcount(pinned[kTieCounterPassWords + wd]);
         float diff = 0.f;
         std::memcpy(&diff, &stats[0], sizeof diff);
-        info->max_order_diff = std::max(info->max_order_diff, (double)diff);
+        info->max_order_diff = (double)diff;  // (of the last pass: what its premise is checked with)
         info->max_rel_bound = stats[1] > 1 ? (double)(stats[1] - 1) * 5.9604644775390625e-8 : 0.0;
         info->changed_pixels += (int)stats[2];
         info->premise_ok = (8.0 * (double)diff < (double)rel_gap) ? 1 : 0;  // (false for a NaN difference, too)

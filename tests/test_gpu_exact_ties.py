@@ -135,6 +135,71 @@ def process_nary(fused, ms, batches, acc):
     return proc.exact_depth_map_nary(fused, ms, batches, acc)
 
 
+def test_resolver_checks_its_premise_and_widens_the_gap(ctx):
+    """the gap is a premise (the rigorous per-voxel bound (votes - 1) * 2^-24 can exceed it), so the call measures
+    the difference between the two summation orders on the voxels it re-sums and repeats the pass with a 4 x wider gap while
+    8 * max_order_diff >= rel_gap.  Forced here by asking for a gap of 4 x the measured difference: one widening, then ok."""
+    nx, ny, nz = 96, 72, 32
+    rig = syn.stereo_rig(150_000, width=nx, height=ny, duration=0.3, seed=8, n_points=700)
+    shape = d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0)
+    batches = _batches(ctx, rig, 2)
+    ms = [d.MapperEMVS(ctx, rig["cam"], shape) for _ in range(2)]
+    for m, b in zip(ms, batches):
+        m.evaluateDSI_batch(b)
+    out = d.MapperEMVS(ctx, rig["cam"], shape)
+    out.computeDepthMapOfFusion(ms[0].dsi_, ms[1].dsi_, d.FUSE_HM)
+    first = out.resolveNearTies(ms, batches, d.FUSE_HM)
+    assert first["premise_ok"] == 1 and first["gap_widenings"] == 0
+    diff = first["max_order_diff"]
+    if diff <= 0:
+        pytest.skip("the two summation orders agree exactly on this input")
+    out.computeDepthMapOfFusion(ms[0].dsi_, ms[1].dsi_, d.FUSE_HM)
+    ref, _ = _oracle_fused(rig, 2, d.FUSE_HM, (nx, ny, nz))
+    _, ridx = orc.collapse_max_z(ref)
+    _, _, idx = out.fetchDepthMap()
+    assert np.array_equal(idx, ridx), first
+    asked = 4.0 * diff
+    forced = out.resolveNearTies(ms, batches, d.FUSE_HM, rel_gap=asked)
+    # (a narrower gap re-sums fewer voxels and may measure a smaller difference: the mechanics are what is asserted)
+    assert 0 <= forced["gap_widenings"] <= 3
+    assert forced["rel_gap"] == pytest.approx(asked * 4 ** forced["gap_widenings"], rel=1e-5)
+    assert forced["premise_ok"] == int(8 * forced["max_order_diff"] < forced["rel_gap"]), forced
+    if forced["max_order_diff"] >= 0.99 * diff:
+        assert forced["gap_widenings"] >= 1, forced
+    # a gap that three widenings cannot bring above 8 x the difference: reported, not hidden
+    out.computeDepthMapOfFusion(ms[0].dsi_, ms[1].dsi_, d.FUSE_HM)
+    hopeless = out.resolveNearTies(ms, batches, d.FUSE_HM, rel_gap=diff / 64.0)
+    if hopeless["candidate_voxels"]:
+        assert hopeless["gap_widenings"] == 3 and hopeless["premise_ok"] == 0, hopeless
+    for o in ms + [out] + batches:
+        o.close()
+
+
+def test_in_order_fetch_gives_the_same_depth_map(ctx):
+    """dsi_mapper_fetch_depth_map_in_order (the maps stored by a kernel into mapped page-locked memory on the compute stream,
+    or copied there when the destination is pageable) = dsi_mapper_fetch_depth_map."""
+    nx, ny, nz = 96, 72, 32
+    rig = syn.stereo_rig(40_000, width=nx, height=ny, duration=0.2, seed=4, n_points=500)
+    shape = d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0)
+    b = _batches(ctx, rig, 1)[0]
+    m = d.MapperEMVS(ctx, rig["cam"], shape)
+    m.evaluateDSI_batch(b)
+    m.computeDepthMap()
+    want = m.fetchDepthMap()
+    got = m.fetchDepthMap(in_order=True)                       # pageable destinations
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    pins = [d.PinnedArray((ny, nx), t) for t in (np.float32, np.float32, np.uint8)]
+    for p in pins:
+        p.a[...] = 0
+    m.fetchDepthMapInOrder(*[p.a for p in pins])               # mapped page-locked destinations: k_store_depth_map
+    m.fetchWait()
+    for p, w in zip(pins, want):
+        assert np.array_equal(p.a, w)
+    for o in pins + [m, b]:
+        o.close()
+
+
 def test_resolver_argument_checks(ctx):
     rig = syn.stereo_rig(5_000, width=64, height=48, duration=0.1, seed=1)
     shape = d.ShapeDSI(0, 0, 8, 4.0, 100.0, 0.0)
