@@ -195,3 +195,38 @@ def test_resolver_building_blocks(ctx):
         m.exactVoxels(batch, [nx * ny * nz])
     m.close()
     batch.close()
+
+
+def test_exact_voxels_on_degenerate_plane_transfers(ctx):
+    """The inverted event pass of the resolver (k_tie_hits_binned) asks, per packet and voxel, which z0 locations the plane
+    transfer can take into the voxel's neighbourhood -- the pre-image of an affine map.  Where the map degenerates the
+    pass must fall back, not guess: camera centre ON a plane (a = 0: every event lands on one location), z0 - Cz = 0
+    (d = 0: no finite coordinate), a centre between planes (negative slope on some), far behind everything, NaN.  EVERY
+    voxel of the DSI, re-summed in the reference's order, equals the oracle's DSI bit for bit."""
+    nx, ny, nz = 40, 30, 6
+    cam = (nx, ny, 30.0, 30.0, 20.0, 15.0)
+    shape = d.ShapeDSI(0, 0, nz, 1.0, 4.0, 0.0)
+    m = d.MapperEMVS(ctx, cam, shape)
+    planes = m.raw_depths_vec_
+    centers = np.array([(0, 0, 0), (0.2, -0.1, planes[2]), (0.1, 0.1, planes[0]), (0.0, 0.0, planes[3] + 0.01),
+                        (5.0, -7.0, 100.0), (np.nan, 0.0, 0.0), (0.3, 0.2, -0.5), (-0.4, 0.1, 0.2)], np.float32)
+    npk = centers.shape[0]
+    Rt = np.zeros((npk, 12), np.float32)
+    Rt[:, 0] = Rt[:, 4] = Rt[:, 8] = 1.0
+    Rt[:, 9:12] = -centers                      # C = -R^T t (mapper_emvs_stereo.cpp:108)
+    rng = np.random.default_rng(5)
+    x = rng.integers(0, nx, npk * 1024).astype(np.uint16)
+    y = rng.integers(0, ny, npk * 1024).astype(np.uint16)
+    x[:64] = 7                                  # a burst on one pixel: more hits per (voxel, packet) than a wave queues
+    y[:64] = 9
+    batch = d.EventBatch(ctx, x, y, Rt)
+    r = OracleMapper(cam, dimZ=nz, min_depth=1.0, max_depth=4.0)
+    first = np.arange(npk, dtype=np.uint32) * 1024
+    r.evaluate_packets(x, y, first, Rt)
+    ref = r.dsi
+    vox = np.arange(nx * ny * nz, dtype=np.uint32)
+    values, votes = m.exactVoxels(batch, vox)
+    assert np.array_equal(values, ref.reshape(-1)), "%d voxels differ" % int((values != ref.reshape(-1)).sum())
+    assert votes.sum() > 4 * 1024   # (zero-weight votes count: integer coordinates give weight-0 corners)
+    m.close()
+    batch.close()
