@@ -386,7 +386,7 @@ inline size_t full_sequence_depth_maps(const std::vector<int>& devices, const Pi
                                        const LinearTrajectory& trajectory1, const std::vector<Event>& events0,
                                        const std::vector<Event>& events1, double start_time_s, double stop_time_s,
                                        double duration, double out_skip, bool forward_looking, int fusion_method,
-                                       OnWindow&& on_window, int depth = 3, double rv_pos = 0.0,
+                                       OnWindow&& on_window, int depth = 2, double rv_pos = 0.0,
                                        const EMVS::OptionsDepthMap* options_depth_map = nullptr,
                                        WindowStreamStats* stats = nullptr)
 {
@@ -614,7 +614,7 @@ inline size_t full_sequence_depth_maps(int device, const PinholeCameraModel& cam
                                        const LinearTrajectory& trajectory1, const std::vector<Event>& events0,
                                        const std::vector<Event>& events1, double start_time_s, double stop_time_s,
                                        double duration, double out_skip, bool forward_looking, int fusion_method,
-                                       OnWindow&& on_window, int depth = 3, double rv_pos = 0.0,
+                                       OnWindow&& on_window, int depth = 2, double rv_pos = 0.0,
                                        const EMVS::OptionsDepthMap* options_depth_map = nullptr,
                                        WindowStreamStats* stats = nullptr)
 {
