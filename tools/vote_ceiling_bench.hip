@@ -138,6 +138,52 @@ __global__ __launch_bounds__(1024) void k_replica(const Rec* __restrict__ recs, 
     if (keep == 0x123456789ull || (threadIdx.x == 0 && blockIdx.x == 0)) sink[0] = band[threadIdx.x] + keep;
 }
 
+// A wave-level fast path for batches whose multiplicities are all 1 (87-99 % of the records): the four v_mad_u64_u32 go, two
+// v_mov_b32 zero the high halves.  Measurement only.
+#define DSI_ASM_VOTE_M1(EX, EY, EM, KA, KBX, KBY, KD, KR)                                             \
+    "v_mul_f32 v58, " EX ", " KA "\n\t"                                                             \
+    "v_mul_f32 v59, " EY ", " KA "\n\t"                                                             \
+    "v_add_f32 v58, v58, " KBX "\n\t"     /* x0*a + bx */                                           \
+    "v_add_f32 v59, v59, " KBY "\n\t"     /* y0*a + by */                                           \
+    "v_mul_f32 v60, v58, " KR "\n\t"      /* div_rc: q = n*r */                                     \
+    "v_mul_f32 v61, v59, " KR "\n\t"                                                                \
+    "v_fma_f32 v62, -" KD ", v60, v58\n\t"                                                          \
+    "v_fma_f32 v63, -" KD ", v61, v59\n\t"                                                          \
+    "v_fma_f32 v60, v62, " KR ", v60\n\t"                                                           \
+    "v_fma_f32 v61, v63, " KR ", v61\n\t"                                                           \
+    "v_fma_f32 v62, -" KD ", v60, v58\n\t"                                                          \
+    "v_fma_f32 v63, -" KD ", v61, v59\n\t"                                                          \
+    "v_fma_f32 v60, v62, " KR ", v60\n\t" /* X */                                                   \
+    "v_fma_f32 v61, v63, " KR ", v61\n\t" /* Y */                                                   \
+    "v_cvt_flr_i32_f32 v58, v60\n\t"      /* xi */                                                  \
+    "v_cvt_flr_i32_f32 v59, v61\n\t"      /* yi */                                                  \
+    "v_subrev_u32 v63, %12, v59\n\t"      /* yi-Li */                                               \
+    "v_cmpx_ge_u32 vcc, %11, v58\n\t"     /* exec &= 0 <= xi <= nx-2       (unsigned compare) */    \
+    "v_cmpx_ge_u32 vcc, %13, v63\n\t"     /* exec &= 0 <= yi-Li <= Ui-1-Li (unsigned compare) */    \
+    "v_fract_f32 v60, v60\n\t"            /* fx (X >= 0 here) */                                    \
+    "v_fract_f32 v61, v61\n\t"            /* fy */                                                  \
+    "v_lshl_add_u32 v58, v58, 3, %10\n\t"                                                           \
+    "v_mad_i32_i24 v59, v59, %9, v58\n\t" /* LDS byte address of voxel (xi, yi) */                  \
+    "v_sub_f32 v63, 1.0, v61\n\t"         /* 1-fy */                                                \
+    "v_mul_f32 v60, 0x4f000000, v60\n\t"  /* fx * 2^31 */                                           \
+    "v_sub_f32 v62, 0x4f000000, v60\n\t"  /* 2^31 - fx*2^31 == fl(1-fx) * 2^31 (power-of-two scale) */ \
+    "v_mul_f32 v36, v62, v63\n\t"                                                                   \
+    "v_mul_f32 v37, v60, v63\n\t"                                                                   \
+    "v_mul_f32 v38, v62, v61\n\t"                                                                   \
+    "v_mul_f32 v39, v60, v61\n\t"                                                                   \
+    "v_mov_b32 v63, 0\n\t"              /* (1-fy, fy are spent) high halves of the two 64-bit operands */ \
+    "v_mov_b32 v61, 0\n\t"                                                                         \
+    "v_cvt_u32_f32 v62, v36\n\t"                                                                   \
+    "ds_add_u64 v59, v[62:63]\n\t"                                                                 \
+    "v_cvt_u32_f32 v60, v37\n\t"                                                                   \
+    "ds_add_u64 v59, v[60:61] offset:8\n\t"                                                        \
+    "v_add_u32 v58, %9, v59\n\t"                                                                   \
+    "v_cvt_u32_f32 v62, v38\n\t"                                                                   \
+    "ds_add_u64 v58, v[62:63]\n\t"                                                                 \
+    "v_cvt_u32_f32 v60, v39\n\t"                                                                   \
+    "ds_add_u64 v58, v[60:61] offset:8\n\t"                                                        \
+    "s_mov_b64 exec, -1\n\t"
+
 // VERDICT r04 item 5, priced before building it: the VOTE with TWO atomics per record -- one ds_add_u64 updates the pair of
 // 32-bit cells (x, x + 1) of a row (weights in Q.20 instead of Q.31: 32-bit cells hold 4,096 full votes between spills).
 // The same instruction stream as DSI_ASM_VOTE up to the four products; then 4 v_cvt_u32_f32, 4 v_mul_lo_u32 (multiplicity)
@@ -192,7 +238,7 @@ __global__ __launch_bounds__(1024) void k_replica(const Rec* __restrict__ recs, 
 // record indices advance by a constant.  runs: how many packets a batch's 64 lanes come from (1: long runs, the headline
 // shape; 4: ~16-record runs, wide grids) -- that many coefficient sets and record segments per gather.
 // Coefficient table: 32 bytes per packet (a, bx, by, d | r, pad); records: 12 bytes, 1024 per packet.
-template <int RUNS, bool PAIRED>
+template <int RUNS, int PAIRED>
 __global__ __launch_bounds__(1024) void k_replica_asm(const Rec* __restrict__ recs, const uint4* __restrict__ coef4, int rec_mask, int nx,
                                                       int rows, int batches, unsigned long long* __restrict__ sink)
 {
@@ -214,7 +260,7 @@ __global__ __launch_bounds__(1024) void k_replica_asm(const Rec* __restrict__ re
     const int s_nxm2 = __builtin_amdgcn_readfirstlane(nx - 2);
     const int s_Li = __builtin_amdgcn_readfirstlane(0);
     const int s_Uim1 = __builtin_amdgcn_readfirstlane(rows - 2);
-    if (!PAIRED) {
+    if (PAIRED == 0) {
     asm volatile(
         "s_mov_b32 s40, %2\n\t"                // running base
         "s_mov_b32 s41, %5\n\t"                // batch pairs left
@@ -243,7 +289,7 @@ __global__ __launch_bounds__(1024) void k_replica_asm(const Rec* __restrict__ re
           "s"(s_nxm2), "s"(s_Li), "s"(s_Uim1), "s"(0), "v"(lane_off)
         : "memory", "scc", "vcc", "s40", "s41", "s50", "v36", "v37", "v38", "v39", "v40", "v42", "v43", "v44", "v45", "v46", "v47",
           "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
-    } else {
+    } else if (PAIRED == 1) {
     asm volatile(
         "s_mov_b32 s40, %2\n\t"                // running base
         "s_mov_b32 s41, %5\n\t"                // batch pairs left
@@ -263,6 +309,35 @@ __global__ __launch_bounds__(1024) void k_replica_asm(const Rec* __restrict__ re
         DSI_ASM_GATHER("v[42:44]", "v[46:49]", "v45")
         "s_waitcnt vmcnt(3)\n\t"
         DSI_ASM_VOTE_PAIRED("v50", "v51", "v52", "v54", "v55", "v56", "v57", "v53")
+        "s_sub_i32 s41, s41, 1\n\t"
+        "s_cmp_lg_u32 s41, 0\n\t"
+        "s_cbranch_scc1 Lloop%=\n\t"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)"
+        :
+        : "s"(recs), "s"(coef4), "s"(s_base), "s"(s_step), "s"(s_mask), "s"(s_n), "s"(0), "s"(0), "s"(0), "s"(s_nx8), "s"(s_cbase),
+          "s"(s_nxm2), "s"(s_Li), "s"(s_Uim1), "s"(0), "v"(lane_off)
+        : "memory", "scc", "vcc", "s40", "s41", "s50", "v36", "v37", "v38", "v39", "v40", "v42", "v43", "v44", "v45", "v46", "v47",
+          "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+    } else {
+    asm volatile(
+        "s_mov_b32 s40, %2\n\t"                // running base
+        "s_mov_b32 s41, %5\n\t"                // batch pairs left
+        "v_add_u32 v40, s40, %15\n\t"
+        "v_and_b32 v40, %4, v40\n\t"
+        DSI_ASM_GATHER("v[42:44]", "v[46:49]", "v45")
+        "Lloop%=:\n\t"
+        "s_add_i32 s40, s40, %3\n\t"
+        "v_add_u32 v40, s40, %15\n\t"
+        "v_and_b32 v40, %4, v40\n\t"
+        DSI_ASM_GATHER("v[50:52]", "v[54:57]", "v53")
+        "s_waitcnt vmcnt(3)\n\t"
+        DSI_ASM_VOTE_M1("v42", "v43", "v44", "v46", "v47", "v48", "v49", "v45")
+        "s_add_i32 s40, s40, %3\n\t"
+        "v_add_u32 v40, s40, %15\n\t"
+        "v_and_b32 v40, %4, v40\n\t"
+        DSI_ASM_GATHER("v[42:44]", "v[46:49]", "v45")
+        "s_waitcnt vmcnt(3)\n\t"
+        DSI_ASM_VOTE_M1("v50", "v51", "v52", "v54", "v55", "v56", "v57", "v53")
         "s_sub_i32 s41, s41, 1\n\t"
         "s_cmp_lg_u32 s41, 0\n\t"
         "s_cbranch_scc1 Lloop%=\n\t"
@@ -311,7 +386,7 @@ double run(const Shape& sh, const Rec* recs, const Coef* coefs, int n_recs, int 
     return wave_batches * 64.0 * 4.0 / (best * 1e-3);
 }
 
-template <int RUNS, bool PAIRED>
+template <int RUNS, int PAIRED>
 double run_asm(const Shape& sh, const Rec* recs, const uint4* coef4, int rec_mask, unsigned long long* sink, int cus, int batches)
 {
     const size_t lds = (size_t)sh.nx * sh.rows * 8;
@@ -401,10 +476,11 @@ int main(int argc, char** argv)
             {"vector work + gathers, no atomics", run<0, 1>(sh, recs, coefs, n_recs, n_coefs, sink, cus, batches)},
             {"compiled replica: gathers + vector work + 4 ds_add_u64", run<1, 1>(sh, recs, coefs, n_recs, n_coefs, sink, cus, batches)},
             {"  the same without the gathers", run<1, 0>(sh, recs, coefs, n_recs, n_coefs, sink, cus, batches)},
-            {"REPLICA, hand-scheduled (the product's GATHER + VOTE, 1 run per batch)", run_asm<1, false>(sh, recs, coef4, n_recs - 1, sink, cus, batches)},
-            {"REPLICA, hand-scheduled, 4 runs per batch (wide grids)", run_asm<4, false>(sh, recs, coef4, n_recs - 1, sink, cus, batches)},
-            {"hand-scheduled, 2 ds_add_u64 on pairs of 32-bit cells, 1 run per batch", run_asm<1, true>(sh, recs, coef4, n_recs - 1, sink, cus, batches)},
-            {"hand-scheduled, 2 ds_add_u64 on pairs of 32-bit cells, 4 runs per batch", run_asm<4, true>(sh, recs, coef4, n_recs - 1, sink, cus, batches)},
+            {"REPLICA, hand-scheduled (the product's GATHER + VOTE, 1 run per batch)", run_asm<1, 0>(sh, recs, coef4, n_recs - 1, sink, cus, batches)},
+            {"REPLICA, hand-scheduled, 4 runs per batch (wide grids)", run_asm<4, 0>(sh, recs, coef4, n_recs - 1, sink, cus, batches)},
+            {"hand-scheduled, multiplicity-1 fast path (no v_mad_u64_u32), 1 run per batch", run_asm<1, 2>(sh, recs, coef4, n_recs - 1, sink, cus, batches)},
+            {"hand-scheduled, 2 ds_add_u64 on pairs of 32-bit cells, 1 run per batch", run_asm<1, 1>(sh, recs, coef4, n_recs - 1, sink, cus, batches)},
+            {"hand-scheduled, 2 ds_add_u64 on pairs of 32-bit cells, 4 runs per batch", run_asm<4, 1>(sh, recs, coef4, n_recs - 1, sink, cus, batches)},
             {"compiled variant: 2 ds_add_u64 on pairs of 32-bit cells (+ gathers)", run<2, 1>(sh, recs, coefs, n_recs, n_coefs, sink, cus, batches)},
             {"compiled variant: 4 ds_add_u32 (+ gathers)", run<3, 1>(sh, recs, coefs, n_recs, n_coefs, sink, cus, batches)},
         };
