@@ -184,6 +184,91 @@ __global__ __launch_bounds__(1024) void k_replica(const Rec* __restrict__ recs, 
     "ds_add_u64 v58, v[60:61] offset:8\n\t"                                                        \
     "s_mov_b64 exec, -1\n\t"
 
+// A 64-bit cell IS a low and a high 32-bit word.  ds_add_u64 moves 512 bytes per wave instruction and costs 11.2 clocks on
+// random cells; ds_add_u32 6.5.  SPLIT vote: the weight (Q.24 instead of Q.31, so that the low word wraps once per 256
+// full votes and not once per two) is added to the LOW word with ds_add_rtn_u32; the returned old value tells whether
+// the add wrapped (old + W < 2^32 ?), and the rare carries (~1 lane in 1,000) are added to the HIGH word by a masked
+// ds_add_u32 one batch later, when the returns have long arrived.  Same memory layout, same exact 64-bit integer sums, no
+// overflow to guard: only the weight quantum changes.  State of the previous batch: v20-v23 returned old values, v24-v27
+// weights, v28 / v29 the two row addresses, s[52:53] its accepted lanes; v34 = 1.
+#define DSI_ASM_VOTE_SPLIT(EX, EY, EM, KA, KBX, KBY, KD, KR, L)                                    \
+    "v_mul_f32 v58, " EX ", " KA "\n\t"                                                             \
+    "v_mul_f32 v59, " EY ", " KA "\n\t"                                                             \
+    "v_add_f32 v58, v58, " KBX "\n\t"                                                               \
+    "v_add_f32 v59, v59, " KBY "\n\t"                                                               \
+    "v_mul_f32 v60, v58, " KR "\n\t"                                                                \
+    "v_mul_f32 v61, v59, " KR "\n\t"                                                                \
+    "v_fma_f32 v62, -" KD ", v60, v58\n\t"                                                          \
+    "v_fma_f32 v63, -" KD ", v61, v59\n\t"                                                          \
+    "v_fma_f32 v60, v62, " KR ", v60\n\t"                                                           \
+    "v_fma_f32 v61, v63, " KR ", v61\n\t"                                                           \
+    "v_fma_f32 v62, -" KD ", v60, v58\n\t"                                                          \
+    "v_fma_f32 v63, -" KD ", v61, v59\n\t"                                                          \
+    "v_fma_f32 v60, v62, " KR ", v60\n\t"                                                           \
+    "v_fma_f32 v61, v63, " KR ", v61\n\t"                                                           \
+    "v_cvt_flr_i32_f32 v58, v60\n\t"                                                                \
+    "v_cvt_flr_i32_f32 v59, v61\n\t"                                                                \
+    "v_subrev_u32 v63, %12, v59\n\t"                                                                \
+    "v_cmpx_ge_u32 vcc, %11, v58\n\t"                                                               \
+    "v_cmpx_ge_u32 vcc, %13, v63\n\t"                                                               \
+    "v_fract_f32 v60, v60\n\t"                                                                      \
+    "v_fract_f32 v61, v61\n\t"                                                                      \
+    "v_lshl_add_u32 v58, v58, 3, %10\n\t"                                                           \
+    "v_sub_f32 v63, 1.0, v61\n\t"                                                                   \
+    "v_mul_f32 v60, 0x4b800000, v60\n\t"  /* fx * 2^24 */                                           \
+    "v_sub_f32 v62, 0x4b800000, v60\n\t"                                                            \
+    "v_mul_f32 v36, v62, v63\n\t"                                                                   \
+    "v_mul_f32 v37, v60, v63\n\t"                                                                   \
+    "v_mul_f32 v38, v62, v61\n\t"                                                                   \
+    "v_mul_f32 v39, v60, v61\n\t"                                                                   \
+    "v_cvt_u32_f32 v36, v36\n\t"                                                                    \
+    "v_cvt_u32_f32 v37, v37\n\t"                                                                    \
+    "v_cvt_u32_f32 v38, v38\n\t"                                                                    \
+    "v_cvt_u32_f32 v39, v39\n\t"                                                                    \
+    "v_mad_i32_i24 v59, v59, %9, v58\n\t" /* LDS byte address of voxel (xi, yi) */                  \
+    "s_mov_b64 s[56:57], exec\n\t"                                                                  \
+    "s_mov_b64 exec, -1\n\t"                                                                        \
+    /* the previous batch's carries (its returns arrived during the arithmetic above); fast path: one OR-ed mask */ \
+    "s_waitcnt lgkmcnt(0)\n\t"                                                                      \
+    "v_add_co_u32 v20, vcc, v20, v24\n\t"                                                           \
+    "s_mov_b64 s[60:61], vcc\n\t"                                                                   \
+    "v_add_co_u32 v21, vcc, v21, v25\n\t"                                                           \
+    "s_or_b64 s[60:61], s[60:61], vcc\n\t"                                                          \
+    "v_add_co_u32 v22, vcc, v22, v26\n\t"                                                           \
+    "s_or_b64 s[60:61], s[60:61], vcc\n\t"                                                          \
+    "v_add_co_u32 v23, vcc, v23, v27\n\t"                                                           \
+    "s_or_b64 s[60:61], s[60:61], vcc\n\t"                                                          \
+    "s_and_b64 s[60:61], s[60:61], s[52:53]\n\t"                                                    \
+    "s_cbranch_scc0 Lnocarry" L "%=\n\t"                                                            \
+    "s_mov_b64 s[62:63], exec\n\t"      /* (v20-v23 now hold old + W: wrapped <=> sum < W) */       \
+    "s_mov_b64 exec, s[52:53]\n\t"                                                                  \
+    "v_cmpx_lt_u32 vcc, v20, v24\n\t"                                                               \
+    "ds_add_u32 v28, v34 offset:4\n\t"                                                              \
+    "s_mov_b64 exec, s[52:53]\n\t"                                                                  \
+    "v_cmpx_lt_u32 vcc, v21, v25\n\t"                                                               \
+    "ds_add_u32 v28, v34 offset:12\n\t"                                                             \
+    "s_mov_b64 exec, s[52:53]\n\t"                                                                  \
+    "v_cmpx_lt_u32 vcc, v22, v26\n\t"                                                               \
+    "ds_add_u32 v29, v34 offset:4\n\t"                                                              \
+    "s_mov_b64 exec, s[52:53]\n\t"                                                                  \
+    "v_cmpx_lt_u32 vcc, v23, v27\n\t"                                                               \
+    "ds_add_u32 v29, v34 offset:12\n\t"                                                             \
+    "s_mov_b64 exec, s[62:63]\n"                                                                     \
+    "Lnocarry" L "%=:\n\t"                                                                          \
+    "s_mov_b64 exec, s[56:57]\n\t"                                                                  \
+    "v_mov_b32 v28, v59\n\t"                                                                        \
+    "v_mul_lo_u32 v24, v36, " EM "\n\t"                                                             \
+    "ds_add_rtn_u32 v20, v28, v24\n\t"                                                              \
+    "v_mul_lo_u32 v25, v37, " EM "\n\t"                                                             \
+    "ds_add_rtn_u32 v21, v28, v25 offset:8\n\t"                                                     \
+    "v_add_u32 v29, %9, v28\n\t"                                                                    \
+    "v_mul_lo_u32 v26, v38, " EM "\n\t"                                                             \
+    "ds_add_rtn_u32 v22, v29, v26\n\t"                                                              \
+    "v_mul_lo_u32 v27, v39, " EM "\n\t"                                                             \
+    "ds_add_rtn_u32 v23, v29, v27 offset:8\n\t"                                                     \
+    "s_mov_b64 s[52:53], exec\n\t"                                                                  \
+    "s_mov_b64 exec, -1\n\t"
+
 // VERDICT r04 item 5, priced before building it: the VOTE with TWO atomics per record -- one ds_add_u64 updates the pair of
 // 32-bit cells (x, x + 1) of a row (weights in Q.20 instead of Q.31: 32-bit cells hold 4,096 full votes between spills).
 // The same instruction stream as DSI_ASM_VOTE up to the four products; then 4 v_cvt_u32_f32, 4 v_mul_lo_u32 (multiplicity)
@@ -318,7 +403,7 @@ __global__ __launch_bounds__(1024) void k_replica_asm(const Rec* __restrict__ re
           "s"(s_nxm2), "s"(s_Li), "s"(s_Uim1), "s"(0), "v"(lane_off)
         : "memory", "scc", "vcc", "s40", "s41", "s50", "v36", "v37", "v38", "v39", "v40", "v42", "v43", "v44", "v45", "v46", "v47",
           "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
-    } else {
+    } else if (PAIRED == 2) {
     asm volatile(
         "s_mov_b32 s40, %2\n\t"                // running base
         "s_mov_b32 s41, %5\n\t"                // batch pairs left
@@ -347,6 +432,37 @@ __global__ __launch_bounds__(1024) void k_replica_asm(const Rec* __restrict__ re
           "s"(s_nxm2), "s"(s_Li), "s"(s_Uim1), "s"(0), "v"(lane_off)
         : "memory", "scc", "vcc", "s40", "s41", "s50", "v36", "v37", "v38", "v39", "v40", "v42", "v43", "v44", "v45", "v46", "v47",
           "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+    } else {
+    asm volatile(
+        "s_mov_b64 s[52:53], 0\n\t"
+        "v_mov_b32 v34, 1\n\t"
+        "s_mov_b32 s40, %2\n\t"                // running base
+        "s_mov_b32 s41, %5\n\t"                // batch pairs left
+        "v_add_u32 v40, s40, %15\n\t"
+        "v_and_b32 v40, %4, v40\n\t"
+        DSI_ASM_GATHER("v[42:44]", "v[46:49]", "v45")
+        "Lloop%=:\n\t"
+        "s_add_i32 s40, s40, %3\n\t"
+        "v_add_u32 v40, s40, %15\n\t"
+        "v_and_b32 v40, %4, v40\n\t"
+        DSI_ASM_GATHER("v[50:52]", "v[54:57]", "v53")
+        "s_waitcnt vmcnt(3)\n\t"
+        DSI_ASM_VOTE_SPLIT("v42", "v43", "v44", "v46", "v47", "v48", "v49", "v45", "a")
+        "s_add_i32 s40, s40, %3\n\t"
+        "v_add_u32 v40, s40, %15\n\t"
+        "v_and_b32 v40, %4, v40\n\t"
+        DSI_ASM_GATHER("v[42:44]", "v[46:49]", "v45")
+        "s_waitcnt vmcnt(3)\n\t"
+        DSI_ASM_VOTE_SPLIT("v50", "v51", "v52", "v54", "v55", "v56", "v57", "v53", "b")
+        "s_sub_i32 s41, s41, 1\n\t"
+        "s_cmp_lg_u32 s41, 0\n\t"
+        "s_cbranch_scc1 Lloop%=\n\t"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)"
+        :
+        : "s"(recs), "s"(coef4), "s"(s_base), "s"(s_step), "s"(s_mask), "s"(s_n), "s"(0), "s"(0), "s"(0), "s"(s_nx8), "s"(s_cbase),
+          "s"(s_nxm2), "s"(s_Li), "s"(s_Uim1), "s"(0), "v"(lane_off)
+        : "memory", "scc", "vcc", "s40", "s41", "s50", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v34", "v36", "v37", "v38", "v39", "v40", "v42", "v43", "v44", "v45", "v46", "v47",
+          "v48", "v49", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v34", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63");
     }
     __syncthreads();
     if (threadIdx.x == 0 && blockIdx.x == 0) sink[0] = band[5];
@@ -479,6 +595,8 @@ int main(int argc, char** argv)
             {"REPLICA, hand-scheduled (the product's GATHER + VOTE, 1 run per batch)", run_asm<1, 0>(sh, recs, coef4, n_recs - 1, sink, cus, batches)},
             {"REPLICA, hand-scheduled, 4 runs per batch (wide grids)", run_asm<4, 0>(sh, recs, coef4, n_recs - 1, sink, cus, batches)},
             {"hand-scheduled, multiplicity-1 fast path (no v_mad_u64_u32), 1 run per batch", run_asm<1, 2>(sh, recs, coef4, n_recs - 1, sink, cus, batches)},
+            {"hand-scheduled, SPLIT vote: 4 ds_add_rtn_u32 + deferred carries (Q.24), 1 run per batch", run_asm<1, 3>(sh, recs, coef4, n_recs - 1, sink, cus, batches)},
+            {"hand-scheduled, SPLIT vote, 4 runs per batch", run_asm<4, 3>(sh, recs, coef4, n_recs - 1, sink, cus, batches)},
             {"hand-scheduled, 2 ds_add_u64 on pairs of 32-bit cells, 1 run per batch", run_asm<1, 1>(sh, recs, coef4, n_recs - 1, sink, cus, batches)},
             {"hand-scheduled, 2 ds_add_u64 on pairs of 32-bit cells, 4 runs per batch", run_asm<4, 1>(sh, recs, coef4, n_recs - 1, sink, cus, batches)},
             {"compiled variant: 2 ds_add_u64 on pairs of 32-bit cells (+ gathers)", run<2, 1>(sh, recs, coefs, n_recs, n_coefs, sink, cus, batches)},
