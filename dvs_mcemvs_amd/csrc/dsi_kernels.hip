@@ -3806,7 +3806,7 @@ __device__ __forceinline__ void tie_emit(const TieOut& o, unsigned long long key
     o.wts[at] = w;
 }
 
-constexpr int kTieQueue = 256;  // queued (voxel, record) pairs per wave
+constexpr int kTieQueue = 128;  // queued (voxel, record) pairs per wave
 
 // The exact vote of record r of packet k on voxel c: the reference's coordinates (mapper_emvs_stereo.cpp:194-195), accept test
 // (cartesian3dgrid.h:255-259, see vote_global) and the bilinear weight of the corner the voxel is (:261-270)
@@ -3842,7 +3842,8 @@ __device__ __forceinline__ unsigned tie_tile_start(const unsigned* __restrict__ 
     return (tw[t >> 1] >> ((t & 1) << 4)) & 0xffffu;
 }
 
-__global__ __launch_bounds__(256) void k_tie_hits_binned(const float2* __restrict__ xy, const float* __restrict__ centers,
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tie_hits_binned(const float2* __restrict__ xy, const float* __restrict__ centers,
                                                          const float* __restrict__ planes, Geom g, int np,
                                                          const uint2* __restrict__ desc, int nsv, unsigned rank_base,
                                                          unsigned pos_bits, unsigned sentinel_rank, TieBinGeom bg,
@@ -3853,11 +3854,12 @@ __global__ __launch_bounds__(256) void k_tie_hits_binned(const float2* __restric
 {
     extern __shared__ unsigned char s_raw[];
     __shared__ unsigned s_vpos;
-    __shared__ unsigned s_wave_tot[4];
-    __shared__ unsigned s_q[4][kTieQueue];  // per wave: (voxel - v_beg) << 10 | record, pairs that passed the box test
-    __shared__ unsigned s_qn[4];
+    __shared__ unsigned s_wave_tot[BLOCK / 64];
+    constexpr int PER = kPacket / BLOCK;  // events of a packet per thread
+    __shared__ unsigned s_q[BLOCK / 64][kTieQueue];  // per wave: (voxel - v_beg) << 10 | record, pairs that passed the box test
+    __shared__ unsigned s_qn[BLOCK / 64];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (threadIdx.x < 4) s_qn[threadIdx.x] = 0u;
+    if (threadIdx.x < BLOCK / 64) s_qn[threadIdx.x] = 0u;
     float* rec_x = reinterpret_cast<float*>(s_raw);
     float* rec_y = rec_x + kPacket;
     unsigned* rec_slot = reinterpret_cast<unsigned*>(rec_y + kPacket);
@@ -3870,17 +3872,17 @@ __global__ __launch_bounds__(256) void k_tie_hits_binned(const float2* __restric
     const float xmax = (float)(g.nx - 1), ymax = (float)(g.ny - 1);
     TieOut out{&s_vpos, s_seg, seg_counter, flags, cap_segs, keys, wts};
     if (tid == 0) s_vpos = 0u;
-    for (int i = tid; i < kTieMaxSegs; i += 256) s_seg[i] = kTieSegEmpty;
+    for (int i = tid; i < kTieMaxSegs; i += BLOCK) s_seg[i] = kTieSegEmpty;
 
     // this block's share of the voxels (blockIdx.y): few packets (a 50 ms window: ~490) do not fill the chip by themselves
     const int v_per = (nsv + (int)gridDim.y - 1) / (int)gridDim.y;
     const int v_beg = (int)blockIdx.y * v_per, v_end = min(nsv, v_beg + v_per);
     for (int k = blockIdx.x; k < np; k += gridDim.x) {
         __syncthreads();  // the previous packet's voxel loop has left the tables
-        for (int i = tid; i < twords; i += 256) tstart[i] = 0u;
+        for (int i = tid; i < twords; i += BLOCK) tstart[i] = 0u;
         {
             const float cx_ = centers[3 * k], cy_ = centers[3 * k + 1], cz_ = centers[3 * k + 2];
-            for (int z = tid; z < g.nz; z += 256) {
+            for (int z = tid; z < g.nz; z += BLOCK) {
                 TiePlane P;
                 plane_coefficients(cx_, cy_, cz_, planes[z], g, P.a, P.bx, P.by, P.d);
                 P.ia = P.d / P.a;
@@ -3904,14 +3906,14 @@ __global__ __launch_bounds__(256) void k_tie_hits_binned(const float2* __restric
             }
         }
         // the packet's z0 locations, counted per tile; a non-finite location votes on no plane
-        float2 e[4];
-        int tile[4];
-        unsigned off[4];
+        float2 e[PER];
+        int tile[PER];
+        unsigned off[PER];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) e[i] = xy[(size_t)k * kPacket + tid + 256 * i];
+        for (int i = 0; i < PER; ++i) e[i] = xy[(size_t)k * kPacket + tid + BLOCK * i];
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < PER; ++i) {
             const bool ok = __builtin_isfinite(e[i].x) && __builtin_isfinite(e[i].y);
             tile[i] = ok ? tie_tile_coord(e[i].y, bg.margin, inv_tile, bg.ty_n) * bg.tx_n +
                                tie_tile_coord(e[i].x, bg.margin, inv_tile, bg.tx_n)
@@ -3922,7 +3924,7 @@ __global__ __launch_bounds__(256) void k_tie_hits_binned(const float2* __restric
         __syncthreads();
         // exclusive scan of the tile counts -> tile starts (thread t owns a contiguous stretch of tiles)
         {
-            const int per = (twords + 255) / 256;
+            const int per = (twords + BLOCK - 1) / BLOCK;
             const int t0 = tid * per, t1 = min(twords, t0 + per);
             unsigned sum = 0u;
             for (int t = t0; t < t1; ++t) {
@@ -3947,19 +3949,19 @@ __global__ __launch_bounds__(256) void k_tie_hits_binned(const float2* __restric
         }
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < PER; ++i)
             if (tile[i] >= 0) {
                 const unsigned r = tie_tile_start(tstart, tile[i]) + off[i];
                 rec_x[r] = e[i].x;
                 rec_y[r] = e[i].y;
-                rec_slot[r] = (unsigned)(tid + 256 * i);
+                rec_slot[r] = (unsigned)(tid + BLOCK * i);
             }
         __syncthreads();
         // Every contending voxel of this block against this packet.  A thread scans the records of its voxel's tiles
         // against the exact pre-image box; the ~10 % of (voxel, record) pairs that pass are QUEUED (per wave, in LDS) and
         // voted 64 at a time with all lanes busy -- voted where they are found, the two IEEE divisions, the weights and
         // the output slot would run for the few lanes that have a hit while the rest of the wave waits.
-        for (int c0 = v_beg; c0 < v_end; c0 += 256) {
+        for (int c0 = v_beg; c0 < v_end; c0 += BLOCK) {
             const int c = c0 + tid;
             if (c < v_end) {
                 const uint2 dsc = desc[c];
@@ -4012,7 +4014,7 @@ __global__ __launch_bounds__(256) void k_tie_hits_binned(const float2* __restric
         const unsigned b = s_seg[j];
         const unsigned first = total - (j << kTieSegShift);  // records of the last segment in use: 1 .. kTieSeg
         if (b != kTieSegEmpty && b < cap_segs)
-            for (unsigned o = first + (unsigned)tid; o < (unsigned)kTieSeg; o += 256u) {
+            for (unsigned o = first + (unsigned)tid; o < (unsigned)kTieSeg; o += (unsigned)BLOCK) {
                 keys[((size_t)b << kTieSegShift) + o] = (unsigned long long)sentinel_rank << pos_bits;
                 wts[((size_t)b << kTieSegShift) + o] = 0.f;
             }
@@ -4866,14 +4868,15 @@ hipError_t launch_tie_hits_binned(hipStream_t s, const float2* xy, const float* 
     const TieBinGeom bg = tie_bin_geom(g.nx, g.ny);
     const size_t lds = tie_hits_lds_bytes(bg.tx_n * bg.ty_n, g.nz);
     if (lds > max_dynamic_lds() || g.nx > 0xffff || g.ny > 0xffff) return hipErrorInvalidValue;
-    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(k_tie_hits_binned), lds)) return e;
+    constexpr int kHitsBlock = 512;  // 8 waves per block, <= 64 VGPRs: up to 32 waves per CU next to four blocks' LDS
+    if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(k_tie_hits_binned<kHitsBlock>), lds)) return e;
     // blocks take packets in turn (the order of the hits does not matter: they are sorted); as many as fit the chip
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, max_dynamic_lds() / lds));
     const int blocks = std::min(np, 256 * per_cu);
     // ... and when the packets alone do not (a 50 ms window), the voxels are dealt over blockIdx.y (each share bins the packet again)
     int vshares = std::max(1, std::min(std::min(16, (nsv + 1023) / 1024), (256 * per_cu) / blocks));
     vshares = std::max(vshares, (nsv + (1 << 22) - 1) >> 22);  // (a queue entry holds the voxel's index within its share in 22 bits)
-    hipLaunchKernelGGL(k_tie_hits_binned, dim3(blocks, vshares), dim3(256), lds, s, xy, centers, planes, g, np, desc, nsv, rank_base, pos_bits,
+    hipLaunchKernelGGL(k_tie_hits_binned<kHitsBlock>, dim3(blocks, vshares), dim3(kHitsBlock), lds, s, xy, centers, planes, g, np, desc, nsv, rank_base, pos_bits,
                        sentinel_rank, bg, seg_counter, cap_segs, flags, total_hits, keys, wts);
     return hipExtGetLastError();
 }
