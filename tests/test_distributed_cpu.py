@@ -184,3 +184,21 @@ def test_bench_refuses_more_ranks_than_devices(built):
     assert r.returncode == 2, r.stderr[-2000:]
     assert "refusing to run a smaller job" in r.stderr and ("%d GPU device" % n_dev) in r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_launch_env_defaults_yield_to_the_environment_and_are_reported():
+    """launch.py's two environment defaults are guesses until an 8-GPU node has run -- the caller's
+    environment wins, DSI_LAUNCH_NO_ENV_DEFAULTS=1 sets neither, and environment_report says what a rank runs with."""
+    from dvs_mcemvs_amd import launch
+    env = launch.rank_environment({}, 1, 4, 29999)
+    assert env["RANK"] == "1" and env["WORLD_SIZE"] == "4" and env["MASTER_ADDR"] == "127.0.0.1"
+    assert env["NCCL_SOCKET_IFNAME"] == "lo" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    rep = launch.environment_report(env)
+    assert rep["NCCL_SOCKET_IFNAME"] == {"value": "lo", "is_launch_default": True} and not rep["defaults_disabled"]
+    env = launch.rank_environment({"NCCL_SOCKET_IFNAME": "eth0"}, 0, 2, 29999)
+    assert env["NCCL_SOCKET_IFNAME"] == "eth0"
+    assert launch.environment_report(env)["NCCL_SOCKET_IFNAME"] == {"value": "eth0", "is_launch_default": False}
+    env = launch.rank_environment({launch.NO_DEFAULTS_ENV: "1"}, 0, 2, 29999)
+    assert "NCCL_SOCKET_IFNAME" not in env and "HSA_ENABLE_IPC_MODE_LEGACY" not in env
+    rep = launch.environment_report(env)
+    assert rep["defaults_disabled"] and rep["HSA_ENABLE_IPC_MODE_LEGACY"]["value"] is None
