@@ -325,7 +325,8 @@ __global__ __launch_bounds__(1024) void k_replica(const Rec* __restrict__ recs, 
 // Coefficient table: 32 bytes per packet (a, bx, by, d | r, pad); records: 12 bytes, 1024 per packet.
 template <int RUNS, int PAIRED>
 __global__ __launch_bounds__(1024) void k_replica_asm(const Rec* __restrict__ recs, const uint4* __restrict__ coef4, int rec_mask, int nx,
-                                                      int rows, int batches, unsigned long long* __restrict__ sink)
+                                                      int rows, int batches, unsigned long long* __restrict__ sink,
+                                                      const uint4* __restrict__ coef4b = nullptr)
 {
     extern __shared__ unsigned char raw[];
     unsigned long long* band = reinterpret_cast<unsigned long long*>(raw);
@@ -345,7 +346,50 @@ __global__ __launch_bounds__(1024) void k_replica_asm(const Rec* __restrict__ re
     const int s_nxm2 = __builtin_amdgcn_readfirstlane(nx - 2);
     const int s_Li = __builtin_amdgcn_readfirstlane(0);
     const int s_Uim1 = __builtin_amdgcn_readfirstlane(rows - 2);
-    if (PAIRED == 0) {
+    if (PAIRED == 4) {
+    // TWO planes per gathered record (priced): one record gather, two coefficient sets (plane z from %1,
+    // plane z + 1 from %6), two votes; the second table's by puts its votes into the other half of the band
+#define DSI_ASM_GATHER2(EV, CA, CR, CA2, CR2)                                                      \
+    "v_mul_lo_u32 v58, v40, 12\n\t"                                                                \
+    "v_lshrrev_b32 v59, 5, v40\n\t"                                                                \
+    "v_and_b32 v59, 0x7ffffe0, v59\n\t"                                                            \
+    "global_load_dwordx3 " EV ", v58, %0\n\t"                                                      \
+    "global_load_dwordx4 " CA ", v59, %1\n\t"                                                      \
+    "global_load_dword " CR ", v59, %1 offset:16\n\t"                                              \
+    "global_load_dwordx4 " CA2 ", v59, %6\n\t"                                                     \
+    "global_load_dword " CR2 ", v59, %6 offset:16\n\t"
+    asm volatile(
+        "s_mov_b32 s40, %2\n\t"
+        "s_mov_b32 s41, %5\n\t"
+        "v_add_u32 v40, s40, %15\n\t"
+        "v_and_b32 v40, %4, v40\n\t"
+        DSI_ASM_GATHER2("v[42:44]", "v[46:49]", "v45", "v[20:23]", "v24")
+        "Lloop%=:\n\t"
+        "s_add_i32 s40, s40, %3\n\t"
+        "v_add_u32 v40, s40, %15\n\t"
+        "v_and_b32 v40, %4, v40\n\t"
+        DSI_ASM_GATHER2("v[50:52]", "v[54:57]", "v53", "v[26:29]", "v30")
+        "s_waitcnt vmcnt(5)\n\t"
+        DSI_ASM_VOTE("v42", "v43", "v44", "v46", "v47", "v48", "v49", "v45")
+        DSI_ASM_VOTE("v42", "v43", "v44", "v20", "v21", "v22", "v23", "v24")
+        "s_add_i32 s40, s40, %3\n\t"
+        "v_add_u32 v40, s40, %15\n\t"
+        "v_and_b32 v40, %4, v40\n\t"
+        DSI_ASM_GATHER2("v[42:44]", "v[46:49]", "v45", "v[20:23]", "v24")
+        "s_waitcnt vmcnt(5)\n\t"
+        DSI_ASM_VOTE("v50", "v51", "v52", "v54", "v55", "v56", "v57", "v53")
+        DSI_ASM_VOTE("v50", "v51", "v52", "v26", "v27", "v28", "v29", "v30")
+        "s_sub_i32 s41, s41, 1\n\t"
+        "s_cmp_lg_u32 s41, 0\n\t"
+        "s_cbranch_scc1 Lloop%=\n\t"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)"
+        :
+        : "s"(recs), "s"(coef4), "s"(s_base), "s"(s_step), "s"(s_mask), "s"(s_n), "s"(coef4b), "s"(0), "s"(0), "s"(s_nx8), "s"(s_cbase),
+          "s"(s_nxm2), "s"(s_Li), "s"(s_Uim1), "s"(0), "v"(lane_off)
+        : "memory", "scc", "vcc", "s40", "s41", "s50", "v20", "v21", "v22", "v23", "v24", "v26", "v27", "v28", "v29", "v30", "v36", "v37",
+          "v38", "v39", "v40", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56",
+          "v57", "v58", "v59", "v60", "v61", "v62", "v63");
+    } else if (PAIRED == 0) {
     asm volatile(
         "s_mov_b32 s40, %2\n\t"                // running base
         "s_mov_b32 s41, %5\n\t"                // batch pairs left
@@ -503,7 +547,8 @@ double run(const Shape& sh, const Rec* recs, const Coef* coefs, int n_recs, int 
 }
 
 template <int RUNS, int PAIRED>
-double run_asm(const Shape& sh, const Rec* recs, const uint4* coef4, int rec_mask, unsigned long long* sink, int cus, int batches)
+double run_asm(const Shape& sh, const Rec* recs, const uint4* coef4, int rec_mask, unsigned long long* sink, int cus, int batches,
+               const uint4* coef4b = nullptr)
 {
     const size_t lds = (size_t)sh.nx * sh.rows * 8;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_replica_asm<RUNS, PAIRED>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -511,12 +556,12 @@ double run_asm(const Shape& sh, const Rec* recs, const uint4* coef4, int rec_mas
     hipEvent_t a, b;
     (void)hipEventCreate(&a);
     (void)hipEventCreate(&b);
-    hipLaunchKernelGGL((k_replica_asm<RUNS, PAIRED>), dim3(blocks), dim3(1024), lds, 0, recs, coef4, rec_mask, sh.nx, sh.rows, batches / 8, sink);
+    hipLaunchKernelGGL((k_replica_asm<RUNS, PAIRED>), dim3(blocks), dim3(1024), lds, 0, recs, coef4, rec_mask, sh.nx, sh.rows, batches / 8, sink, coef4b);
     (void)hipDeviceSynchronize();
     float best = 1e30f;
     for (int rep = 0; rep < 3; ++rep) {
         (void)hipEventRecord(a);
-        hipLaunchKernelGGL((k_replica_asm<RUNS, PAIRED>), dim3(blocks), dim3(1024), lds, 0, recs, coef4, rec_mask, sh.nx, sh.rows, batches, sink);
+        hipLaunchKernelGGL((k_replica_asm<RUNS, PAIRED>), dim3(blocks), dim3(1024), lds, 0, recs, coef4, rec_mask, sh.nx, sh.rows, batches, sink, coef4b);
         (void)hipEventRecord(b);
         (void)hipEventSynchronize(b);
         float ms = 0;
@@ -524,7 +569,7 @@ double run_asm(const Shape& sh, const Rec* recs, const uint4* coef4, int rec_mas
         if (ms < best) best = ms;
     }
     if (hipError_t e = hipGetLastError()) std::printf("ERR %s\n", hipGetErrorString(e));
-    return (double)blocks * 16.0 * (batches / 2 * 2) * 64.0 * 4.0 / (best * 1e-3);
+    return (double)blocks * 16.0 * (batches / 2 * 2) * 64.0 * 4.0 * (PAIRED == 4 ? 2.0 : 1.0) / (best * 1e-3);
 }
 
 int main(int argc, char** argv)
@@ -548,6 +593,9 @@ int main(int argc, char** argv)
     unsigned long long* sink;
     const int n_packets = n_recs / 1024 + 8;
     (void)hipMalloc(&coef4, (size_t)n_packets * 32);
+    uint4 *coef4_h1, *coef4_h2;
+    (void)hipMalloc(&coef4_h1, (size_t)n_packets * 32);
+    (void)hipMalloc(&coef4_h2, (size_t)n_packets * 32);
     (void)hipMalloc(&recs, (n_recs + 8 * 1024) * sizeof(Rec));
     (void)hipMalloc(&coefs, n_coefs * sizeof(Coef));
     (void)hipMalloc(&sink, 64);
@@ -580,6 +628,14 @@ int main(int argc, char** argv)
                 q[0] = c.a; q[1] = c.bx; q[2] = c.by; q[3] = c.d; q[4] = c.r;
             }
             (void)hipMemcpy(coef4, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice);
+            // two-plane variant: a = 0.5 (Y in the upper half of the band for table 1, the lower half for table 2)
+            for (int k = 0; k < n_packets; ++k) {
+                float* q = &t[(size_t)k * 8];
+                q[0] = 0.5f;
+            }
+            (void)hipMemcpy(coef4_h1, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice);
+            for (int k = 0; k < n_packets; ++k) t[(size_t)k * 8 + 2] += (float)(sh.rows / 2 - 1);
+            (void)hipMemcpy(coef4_h2, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice);
         }
         (void)hipMemcpy(coefs, hc.data(), n_coefs * sizeof(Coef), hipMemcpyHostToDevice);
         std::printf("\n== %s   [product: %s]\n", sh.name, sh.product);
@@ -594,6 +650,8 @@ int main(int argc, char** argv)
             {"  the same without the gathers", run<1, 0>(sh, recs, coefs, n_recs, n_coefs, sink, cus, batches)},
             {"REPLICA, hand-scheduled (the product's GATHER + VOTE, 1 run per batch)", run_asm<1, 0>(sh, recs, coef4, n_recs - 1, sink, cus, batches)},
             {"REPLICA, hand-scheduled, 4 runs per batch (wide grids)", run_asm<4, 0>(sh, recs, coef4, n_recs - 1, sink, cus, batches)},
+            {"hand-scheduled, TWO planes per gathered record (2 votes per gather), 1 run per batch", run_asm<1, 4>(sh, recs, coef4_h1, n_recs - 1, sink, cus, batches, coef4_h2)},
+            {"hand-scheduled, TWO planes per gathered record, 4 runs per batch", run_asm<4, 4>(sh, recs, coef4_h1, n_recs - 1, sink, cus, batches, coef4_h2)},
             {"hand-scheduled, multiplicity-1 fast path (no v_mad_u64_u32), 1 run per batch", run_asm<1, 2>(sh, recs, coef4, n_recs - 1, sink, cus, batches)},
             {"hand-scheduled, SPLIT vote: 4 ds_add_rtn_u32 + deferred carries (Q.24), 1 run per batch", run_asm<1, 3>(sh, recs, coef4, n_recs - 1, sink, cus, batches)},
             {"hand-scheduled, SPLIT vote, 4 runs per batch", run_asm<4, 3>(sh, recs, coef4, n_recs - 1, sink, cus, batches)},
