@@ -626,7 +626,9 @@ int depth_buffers_ready(dsi_mapper* m)
 {
     if (!m->ev_depth_ready) {
         HIP_TRY(hipEventCreateWithFlags(&m->ev_depth_ready, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&m->ev_depth_read, hipEventDisableTiming));
+        // (the in-order fetch STORES the maps into mapped host memory from a kernel: the event that says "read" must
+        //  release those stores to the system, or the host may see stale maps in non-coherent pinned memory -- ADVICE r05)
+        HIP_TRY(hipEventCreateWithFlags(&m->ev_depth_read, hipEventDisableTiming | hipEventReleaseToSystem));
     }
     HIP_TRY(hipEventRecord(m->ev_depth_ready, m->ctx->stream));
     m->depth_valid = true;
@@ -658,7 +660,9 @@ int depth_buffers_fetch(dsi_mapper* m, float* depth_host, float* conf_host, uint
             return hipHostGetDevicePointer(dev, host, 0) == hipSuccess && *dev;
         };
         void *dd = nullptr, *dc = nullptr, *di = nullptr;
-        if (mapped(depth_host, &dd) && mapped(conf_host, &dc) && mapped(idx_host, &di) && npix % 4 == 0) {
+        // (the kernel stores the index map as 32-bit words: an interior, misaligned idx_host takes the copy path below)
+        if (mapped(depth_host, &dd) && mapped(conf_host, &dc) && mapped(idx_host, &di) && npix % 4 == 0 &&
+            reinterpret_cast<uintptr_t>(di) % 4 == 0) {
             HIP_TRY(dsi::launch_store_depth_map(cs, m->depth.p, m->conf.p, m->idx.p, npix, static_cast<float*>(dd),
                                                 static_cast<float*>(dc), static_cast<uint8_t*>(di)));
             HIP_TRY(hipEventRecord(m->ev_depth_read, cs));
@@ -1485,7 +1489,9 @@ int dsi_host_alloc(size_t bytes, void** out)
     REQUIRE(out, DSI_ERR_INVALID, "out is null");
     *out = nullptr;
     REQUIRE(bytes > 0, DSI_ERR_INVALID, "bytes must be > 0");
-    HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocPortable));
+    // coherent + mapped whatever HIP_HOST_COHERENT says: kernels store depth maps into these blocks
+    // (dsi_mapper_fetch_depth_map_in_order) and the host reads them after an event
+    HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent));
     return DSI_OK;
 }
 
@@ -1818,9 +1824,10 @@ unsigned bits_for(unsigned long long values)  // bits that hold 0 .. values - 1
 // |grid value - reference-order value| and of the votes per voxel into ts.counters.  Host round trips: ONE read of two
 // counters (how many records to sort).
 static int tie_exact_values_dev(TieScratch& ts, hipStream_t st, dsi_mapper* const* ms, const dsi_batch* const* bs, int n, int nsv,
-                                bool grid_stats, long long* votes)
+                                bool grid_stats, long long* votes, bool* table_overflow = nullptr)
 {
     *votes = 0;
+    if (table_overflow) *table_overflow = false;
     if (nsv <= 0) return DSI_OK;
     const dsi::Geom& g0 = ms[0]->geom;
     const int npix = g0.nx * g0.ny;
@@ -1876,7 +1883,12 @@ static int tie_exact_values_dev(TieScratch& ts, hipStream_t st, dsi_mapper* cons
         host_cnt[1] = pinned[3];
         host_cnt[2] = pinned[8];
         host_cnt[3] = pinned[9];
-        REQUIRE(!(host_cnt[1] & 1u), DSI_ERR_INVALID, "a workgroup recorded more than 2 M votes: too many voxels asked for");
+        if ((host_cnt[1] & 1u) && table_overflow) {  // (a WIDENED pass of the resolver: the caller keeps the last good pass)
+            *table_overflow = true;
+            return DSI_OK;
+        }
+        REQUIRE(!(host_cnt[1] & 1u), DSI_ERR_INVALID, "a workgroup recorded more than %d k votes: too many voxels asked for",
+                dsi::tie_block_capacity_records() >> 10);
         if (!(host_cnt[1] & 2u)) break;
         REQUIRE(attempt == 0, DSI_ERR_INVALID, "the vote count changed between two passes");
         cap = (size_t)host_cnt[0] * seg;
@@ -1970,7 +1982,11 @@ int dsi_mapper_resolve_near_ties(dsi_mapper_t* out, dsi_mapper_t* const* mappers
     // not assumed: max_order_diff is measured on the re-summed voxels (the column maxima of the near-tie columns, among
     // them the most-voted voxels of the volume), and a pass that finds it above rel_gap / 8 is repeated with a gap four
     // times as wide (at most three times); premise_ok tells whether the last pass held it.
+    // A WIDENED pass can ask for orders of magnitude more voxels than the first; if it overflows a workgroup's segment
+    // table (or the 32-bit bookkeeping) the call does not fail: it keeps the last completed pass's patch and statistics
+    // and returns DSI_OK with premise_ok = 0 -- "the caller decides", as the header says.
     for (int widenings = 0;; ++widenings) {
+        const dsi_resolve_info_t last_good = *info;
         info->rel_gap = rel_gap;
         info->gap_widenings = widenings;
         // 1. the contending voxels (device lists)
@@ -1986,7 +2002,16 @@ int dsi_mapper_resolve_near_ties(dsi_mapper_t* out, dsi_mapper_t* const* mappers
         long long votes = 0;
         dsi_mapper* ms[2] = {mappers[0], n == 2 ? mappers[1] : nullptr};
         const dsi_batch* bs[2] = {batches[0], n == 2 ? batches[1] : nullptr};
-        if (int rc = tie_exact_values_dev(ts, st, ms, bs, n, (int)n_cand, /*grid_stats=*/true, &votes)) return rc;
+        bool overflow = false;
+        if (int rc = tie_exact_values_dev(ts, st, ms, bs, n, (int)n_cand, /*grid_stats=*/true, &votes, widenings > 0 ? &overflow : nullptr)) {
+            if (widenings == 0) return rc;
+            overflow = true;  // (too many voxels x events for the sort key, > 2^33 votes: the same verdict)
+            g_last_error.clear();
+        }
+        if (overflow) {
+            *info = last_good;  // (premise_ok = 0 there: that is why this pass was tried)
+            return finish();
+        }
         info->votes = votes;
         // 4. fuse, first maximum per column, patch (device)
         if (int rc = depth_buffers_acquire(out)) return rc;
@@ -2023,6 +2048,7 @@ int dsi_grid_near_tie_voxels(dsi_mapper_t* scratch, dsi_grid_t* g, float rel_gap
     if (!(rel_gap > 0.f)) rel_gap = 2.5e-4f;
     REQUIRE(rel_gap < 0.5f, DSI_ERR_INVALID, "rel_gap %g is not a rounding-sized gap", (double)rel_gap);
     REQUIRE(g->n < ((size_t)1 << 32), DSI_ERR_INVALID, "voxels are addressed with 32 bits");
+    REQUIRE(g->nz <= 256, DSI_ERR_SHAPE, "the near-tie search holds a column's planes in four 64-bit masks: dimZ %d > 256", g->nz);
     if (int rc = set_device(g->ctx)) return rc;
     unsigned n_cand = 0, cols = 0;
     if (int rc = tie_candidates_dev(scratch->tie, g->ctx->stream, g->data, nullptr, 0, g->nx * g->ny, g->nz, rel_gap, &n_cand, &cols)) return rc;

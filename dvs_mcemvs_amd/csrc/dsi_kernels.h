@@ -213,6 +213,7 @@ hipError_t launch_tie_desc(hipStream_t s, const uint32_t* vox, int n, int nx, in
 // flags bit 0: a block overflowed its segment table); unused tails hold sentinel keys sentinel_rank << pos_bits.  Several
 // launches (cameras) may append to the same arrays.  *total_hits += the real votes
 int tie_segment_records();
+int tie_block_capacity_records();  // votes one workgroup of the pass can record
 hipError_t launch_tie_hits_binned(hipStream_t s, const float2* xy, const float* centers, const float* planes, const Geom& g, int np,
                                   const uint2* desc, int nsv, unsigned rank_base, unsigned pos_bits, unsigned sentinel_rank,
                                   unsigned* seg_counter, unsigned cap_segs, unsigned* flags, unsigned long long* total_hits,

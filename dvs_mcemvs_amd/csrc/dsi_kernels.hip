@@ -4202,6 +4202,32 @@ static hipError_t allow_dynamic_lds(const void* kern, size_t bytes)
     return hipSuccess;
 }
 
+// hipOccupancyMaxActiveBlocksPerMultiprocessor, remembered per (kernel, device, block, dynamic LDS): a runtime query has
+// no place on the path of every launch.  0 when the runtime cannot tell.
+static int resident_blocks_cached(const void* kern, int block, size_t lds_bytes)
+{
+    struct Entry {
+        const void* kern;
+        int device, block;
+        size_t bytes;
+        int resident;
+    };
+    static std::mutex mu;
+    static std::vector<Entry> table;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    std::lock_guard<std::mutex> lock(mu);
+    for (const Entry& t : table)
+        if (t.kern == kern && t.device == dev && t.block == block && t.bytes == lds_bytes) return t.resident;
+    int resident = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, kern, block, lds_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        resident = 0;
+    }
+    table.push_back({kern, dev, block, lds_bytes, resident});
+    return resident;
+}
+
 hipError_t launch_packet_geometry(hipStream_t s, const float* Rt, int np, const Geom& g,
                                   float* centers, float* H)
 {
@@ -4411,12 +4437,8 @@ static hipError_t launch_vote_fuse_argmax_t(hipStream_t s, const FusedCameras& c
             if (hipError_t e = allow_dynamic_lds(kern2, bp.lds_bytes)) return e;
             // ... only if the runtime agrees that two fit (static LDS and the allocation granularity also count: a band just
             // under half the LDS would otherwise run its 2 x grid of half-size assignments in two serialised waves)
-            int resident = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, kern2, 1024, bp.lds_bytes) != hipSuccess) {
-                (void)hipGetLastError();
-                resident = 0;
-            }
-            if (resident < 2) goto one_per_cu;
+            // (the answer depends on (kernel, device, LDS bytes) only: asked once, not on every window -- ADVICE r05)
+            if (resident_blocks_cached(kern2, 1024, bp.lds_bytes) < 2) goto one_per_cu;
             // (the balanced partition, an experiments-flavour option, is laid out for one workgroup per CU: not used here)
             hipLaunchKernelGGL((k_vote_fuse_argmax_2cu<MAPPING, HALF>), dim3(2 * blocks), dim3(1024), bp.lds_bytes, s, cams, g, bp, op,
                                nullptr, keys, trace);
@@ -4858,6 +4880,7 @@ hipError_t launch_tie_desc(hipStream_t s, const uint32_t* vox, int n, int nx, in
 }
 
 int tie_segment_records() { return kTieSeg; }
+int tie_block_capacity_records() { return kTieMaxSegs * kTieSeg; }
 
 hipError_t launch_tie_hits_binned(hipStream_t s, const float2* xy, const float* centers, const float* planes, const Geom& g, int np,
                                   const uint2* desc, int nsv, unsigned rank_base, unsigned pos_bits, unsigned sentinel_rank,

@@ -466,15 +466,18 @@ DSI_API int dsi_mapper_depth_map_from_keys(dsi_mapper_t *m);
  * checks it: max_order_diff is the largest |engine value - reference-order value| / max(1, value) over the voxels it
  * re-summed -- the column maxima of the near-tie columns, the most-voted voxels of the volume among them.  If it reaches
  * rel_gap / 8 the pass is repeated with a four times wider gap (gap_widenings, at most 3); premise_ok = 0 when even the
- * last pass did not hold it: the call still returns DSI_OK, the caller decides.  Optional and off the throughput path
- * (elapsed_ms).  Synchronises. */
+ * last pass did not hold it: the call still returns DSI_OK, the caller decides.  A WIDENED pass that asks for more votes
+ * than the pass can record (a workgroup's segment table, the sort key) does not turn into an error either: the last
+ * completed pass's patch and statistics stand, premise_ok = 0.  Optional and off the throughput path (elapsed_ms).
+ * Synchronises. */
 typedef struct {
     float rel_gap;          /* in (0 = 2.5e-4); out: the gap of the last pass (wider than asked for after gap_widenings) */
     int near_tie_pixels;    /* out: columns with >= 2 contending planes */
     int candidate_voxels;   /*      contending voxels re-summed (per camera) */
     int candidate_planes;   /*      distinct planes among them */
     long long votes;        /*      votes re-summed, all cameras */
-    int changed_pixels;     /*      pixels whose plane index changed */
+    int changed_pixels;     /*      pixels whose plane index a pass changed, SUMMED over the passes (a widened pass counts against
+                                    the already patched map: with gap_widenings > 0 a pixel can be counted more than once) */
     double max_rel_bound;   /*      see above */
     double max_order_diff;  /*      see above */
     float elapsed_ms;       /*      wall time of the call */
@@ -492,7 +495,7 @@ DSI_API int dsi_mapper_resolve_near_ties(dsi_mapper_t *out, dsi_mapper_t *const 
  *  - dsi_grid_near_tie_voxels: the voxels (z * dimY * dimX + y * dimX + x) of g within rel_gap of their column's
  *    maximum, for the columns that have >= 2 of them; a column's run contiguous, planes ascending.  *n_voxels may
  *    exceed capacity (then nothing beyond capacity was written: call again with more room).  scratch: any mapper of
- *    g's context and shape (its resolver scratch is used).
+ *    g's context and shape (its resolver scratch is used).  dimZ <= 256 (main.cpp:156), else DSI_ERR_SHAPE.
  *  - dsi_mapper_exact_voxels: values[i] <- the value voxel voxels[i] of the DSI of (m, batch) has when its votes are
  *    added in fp32 in event order (resetGrid, then += per vote: mapper_emvs_stereo.cpp:145, :197-201,
  *    cartesian3dgrid.h:261-270); votes[i] (optional) <- their number.  m's grid is not touched.  voxels: any order,

@@ -84,6 +84,13 @@ class NumpyMapper:
     def computeDepthMapFromKeys(self):
         self.conf, self.idx = dd.unpack_argmax_keys(self.keys)
 
+    def computeDepthMapReduceScattered(self, acc, comm, mode, n_maps):
+        """MapperEMVS.computeDepthMapReduceScattered with the two nccl calls replaced by the host-staged transport
+        (comm = (world, rank)): what EnginePipelinedTemporalFusion(scattered=...) calls once per round."""
+        world, rank = comm
+        dd.host_staged_depth_map_reduce_scattered(self, acc, world, rank, mode, n_maps)
+        self.rounds.append((self.conf.copy(), self.idx.copy()))
+
 
 def job_temporal(D, out_dir, mode):
     rig = syn.stereo_rig(9000, width=40, height=30, duration=0.3, seed=17)
@@ -156,6 +163,29 @@ def job_scattered(D, out_dir, nz):
     np.savez(os.path.join(out_dir, "scattered_rank%d.npz" % D.rank), conf=m.conf, idx=m.idx)
 
 
+def job_pipelined_scattered(D, out_dir, nz):
+    """EnginePipelinedTemporalFusion with scattered= (the reduce-scatter form of the round's collective) over a stream
+    of rounds: world 3 with dimZ 8 gives q = 2 owned planes per rank and 2 tail planes every rank finalizes."""
+    rng = np.random.default_rng(77)                      # same stream on every rank
+    rounds = [rng.uniform(0, 3, (D.world, nz, 6, 5)).astype(np.float32) for _ in range(4)]
+    for r in rounds:
+        r[:, :, 0, 0] = 0.0                              # an all-zero column: index 0 on every rank
+    m = NumpyMapper()
+    m.rounds = []
+
+    def slot():
+        g = NumpyGrid(5, 6, nz)
+        return (g, g)
+    pipe = dd.EnginePipelinedTemporalFusion(NullContext(), NullContext(), (5, 6, nz), E.ACC_INV_SUM, D.world, None,
+                                            scattered=(m, (D.world, D.rank)), make_slot=slot)
+    for r in rounds:
+        pipe.submit(r[D.rank])
+    pipe.drain()
+    assert len(m.rounds) == 4 and pipe.k == 4
+    np.savez(os.path.join(out_dir, "pipe_scattered_rank%d.npz" % D.rank), conf=np.stack([c for c, _ in m.rounds]),
+             idx=np.stack([i for _, i in m.rounds]))
+
+
 def main():
     job, out_dir = sys.argv[1], sys.argv[2]
     D = launch.Dist()
@@ -167,6 +197,8 @@ def main():
         job_planes(D, out_dir)
     elif job == "scattered":
         job_scattered(D, out_dir, int(sys.argv[3]))
+    elif job == "pipelined_scattered":
+        job_pipelined_scattered(D, out_dir, int(sys.argv[3]))
     else:
         raise SystemExit("unknown job %r" % job)
     D.close()

@@ -150,6 +150,29 @@ def test_reduce_scattered_depth_map_on_stand_in_grids(tmp_path, world, nz):
         assert np.allclose(z["conf"], conf, rtol=1e-6)
 
 
+@pytest.mark.parametrize("world,nz", [(3, 8), (2, 5)])
+def test_pipelined_temporal_fusion_with_the_reduce_scatter_collective(tmp_path, world, nz):
+    """EnginePipelinedTemporalFusion(scattered=...) over four rounds -- the class `bench.py --temporal-collective
+    reduce_scatter` drives -- equals the single-process temporal HM + arg-max of every round on every rank.  World 3
+    with dimZ 8: two owned planes per rank plus two tail planes (process2.cpp:211-242 across ranks)."""
+    from oracle import oracle as orc
+    rc, out, err = run_ranks(world, "pipelined_scattered", tmp_path, [str(nz)])
+    assert rc == 0, err[-3000:]
+    rng = np.random.default_rng(77)
+    rounds = [rng.uniform(0, 3, (world, nz, 6, 5)).astype(np.float32) for _ in range(4)]
+    got = [np.load(tmp_path / ("pipe_scattered_rank%d.npz" % r)) for r in range(world)]
+    for k, slices in enumerate(rounds):
+        slices[:, :, 0, 0] = 0.0
+        acc = np.zeros((nz, 6, 5), np.float32)
+        for s in slices:
+            acc = orc.accumulate(acc, s, 1)
+        conf, idx = orc.collapse_max_z(orc.finalize(acc, 1, world))
+        for r in range(world):
+            assert np.array_equal(got[r]["idx"][k], idx), (k, r)
+            assert np.allclose(got[r]["conf"][k], conf, rtol=1e-6), (k, r)
+        assert idx[0, 0] == 0
+
+
 def test_launcher_refuses_a_smaller_job_and_reports_a_failed_rank(tmp_path):
     """`bench.py --gpus N` on a node with fewer than N devices must fail, not run fewer ranks; a rank that dies
     takes the job down with its status."""

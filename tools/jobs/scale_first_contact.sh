@@ -3,7 +3,11 @@
 # any round -- every lease so far had one GPU.  This script is what to run on the first node that has more:
 #   1. the two tests that turn such a run into a CORRECTNESS run of the collectives,
 #   2. bench.py --gpus {1,2,4,8} for the three workloads (stereo with both forms of the temporal collective),
-#   3. a table: ranks RCCL itself reports, the collective's bus bandwidth alone, whole-job rate, scaling efficiency.
+#   3. a table: ranks RCCL itself reports, the collective's bus bandwidth alone, whole-job rate, scaling efficiency,
+#   4. ONE record per workload in the shape of the driver's SCALE_rNN.json ($OUT/SCALE_<workload>.json and all of them
+#      in $OUT/SCALE_first_contact.json): per N the bench line, rccl_ranks, value, efficiency = value_N / (N x value_1),
+#      collective.busbw_GBps, plus the verdict of the collectives' correctness tests -- a curve, not a log
+#      (VERDICT r05 item 6).
 # On a one-GPU box it exits 0 after printing the expected refusals (bench.py exits 2 for N > devices: no smaller job).
 # Usage: bash tools/jobs/scale_first_contact.sh [out_dir] [max_gpus]      (DSI_LAUNCH_NO_ENV_DEFAULTS=1 or
 #        NCCL_SOCKET_IFNAME=... / HSA_ENABLE_IPC_MODE_LEGACY=... in the environment override launch.py's two defaults;
@@ -25,7 +29,9 @@ echo "== devices visible: $NDEV"
 echo "== 1. collectives over every device (correctness: all-reduce sum / min / max, sharded and reduce-scattered arg-max)"
 python -m pytest tests/test_gpu_multirank.py -m gpu -q -x -k "every_device or bench_gpus_2 or communicator" \
     > "$OUT/tests.txt" 2>&1
-echo "   pytest exit $? : $(grep -E 'passed|failed|error' "$OUT/tests.txt" | tail -1)"
+TESTS_RC=$?
+echo "   pytest exit $TESTS_RC : $(grep -E 'passed|failed|error' "$OUT/tests.txt" | tail -1)"
+echo "$TESTS_RC" > "$OUT/tests.rc"
 
 run_line() {   # name, gpus, extra flags...
     local name=$1 n=$2
@@ -81,5 +87,39 @@ for name, by_n in rows.items():
                                                             ("%.1f" % coll["busbw_GBps"]) if coll.get("busbw_GBps") else "-", eff))
         if n > 1 and j.get("launch_env"):
             print("    launch_env:", json.dumps(j["launch_env"]))
+
+# 4. the records
+try:
+    tests_rc = int(open(os.path.join(out, "tests.rc")).read().strip())
+except Exception:
+    tests_rc = None
+tests_tail = [ln.strip() for ln in open(os.path.join(out, "tests.txt")).read().splitlines() if ln.strip()][-1:] if os.path.exists(os.path.join(out, "tests.txt")) else []
+try:
+    ndev = int(open(os.path.join(out, "devices.txt")).read().split()[-1])
+except Exception:
+    ndev = None
+records = {}
+for name, by_n in rows.items():
+    base_name = "stereo_allreduce" if name.startswith("stereo") else name
+    base = rows.get(base_name, {}).get(1)
+    runs = []
+    for n in sorted(by_n):
+        j = by_n[n]
+        coll = j.get("collective") or {}
+        runs.append({"n_gpus": n, "rccl_ranks": j.get("rccl_ranks"), "value": j["value"], "unit": j["unit"],
+                     "ms_per_step": j["ms_per_step"], "scaling": j.get("scaling"),
+                     "efficiency": (j["value"] / (n * base["value"])) if base and base.get("value") else None,
+                     "collective": {"bytes": coll.get("bytes"), "ms_alone": coll.get("ms_alone"), "busbw_GBps": coll.get("busbw_GBps")},
+                     "parsed": j})
+    records[name] = {"skipped": False, "metric": runs[0]["parsed"].get("metric") if runs else None, "workload": name,
+                     "devices_visible": ndev, "runs": runs,
+                     "collectives_test": {"name": "tests/test_gpu_multirank.py -k 'every_device or bench_gpus_2 or communicator'",
+                                          "rc": tests_rc, "passed": tests_rc == 0, "summary": tests_tail[0] if tests_tail else None},
+                     "rccl_with_more_than_one_rank": any((r["rccl_ranks"] or 0) > 1 for r in runs)}
+    with open(os.path.join(out, "SCALE_%s.json" % name), "w") as f:
+        json.dump(records[name], f, indent=1)
+with open(os.path.join(out, "SCALE_first_contact.json"), "w") as f:
+    json.dump(records, f, indent=1)
+print("records:", ", ".join("SCALE_%s.json" % k for k in records), "+ SCALE_first_contact.json")
 PY
 echo "== done: lines and logs in $OUT"
