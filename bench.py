@@ -69,6 +69,9 @@ def parse():
                     help="lane mapping: -1 auto, 0 per-packet waves, 1 packed (hand-scheduled), 2 packet groups, "
                          "3 packed (compiled), 4 groups (hand-scheduled), 5 packed + vector fill, 6 = 5 compiled, 7 = 1 with dealt passes")
     ap.add_argument("--pass-lg", type=int, default=0, help="tuning: log2 of the packets per pass of the voting streams (0 = automatic)")
+    ap.add_argument("--inline-cuts", type=int, default=-1,
+                    help="tuning (lane mappings 5 / 6): packets per call from which the voting kernel derives its runs itself "
+                         "instead of reading a cut table (-1 = the engine's default 8192, 0 = always)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-host-fed", action="store_true",
                     help="skip the host-fed (PCIe-inclusive) measurements and the 512x512x200 stream-kernel timings "
@@ -524,6 +527,8 @@ def main():
         m.set_vote_algo(args.algo)
         m.set_band_params(*args.band)
         m.set_packed_lanes(args.packed)
+        if args.inline_cuts >= 0:
+            m.set_inline_cuts(args.inline_cuts)
         if args.pass_lg:
             from dvs_mcemvs_amd import engine as eng
             if not eng.experiments_requested():

@@ -305,6 +305,8 @@ struct dsi_mapper {
     DevBuf<dsi::EvRec> sxy;
     DevBuf<unsigned long long> seam;  // [chunks][nz][bands][2][nx]: 64-bit sums of each band's first row and of the row below it
     DevBuf<uint32_t> nvalid, cuts, gcuts;
+    size_t cuts_inline_min_packets = 8192;   // vote_device: from this many packets on the vector fill derives its cuts itself
+    bool info_cuts_inline = false;           // the last banded vote did
     DevBuf<uint8_t> spk;
     DevBuf<uint16_t> rowstart;
     DevBuf<dsi::PlaneCoef> coef;
@@ -748,7 +750,19 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
     HIP_TRY(m->nvalid.reserve(np + (size_t)geom.nz + 8));  // + one "needs IEEE divide" word per plane + 8 work counters
     HIP_TRY(m->rowstart.reserve(np * (size_t)(geom.ny + 2 * bp.row_pad + 3) + 2));  // (+ slack: k_plane_coef copies 32-bit words)
     HIP_TRY(m->coef.reserve(np * geom.nz + 1));       // + the dummy record's "coefficients"
-    HIP_TRY(m->cuts.reserve(np * geom.nz * bp.bands));
+    // Wide grids with many packets (the vector fill): no cut table -- at 1024 x 1024 x 256 with 100 M events it is 6.1 GB per
+    // camera and 3.9 ms to write -- but the packets' row tables transposed (u16 [ny + 2 pad + 3][stride], 0.6 GB there), from
+    // which the voting kernel's passes derive their runs (BandPlan::cuts_inline).  Below ~8 k packets the table stays: a work
+    // item is then short and the two dependent look-ups at its start would show.
+    bp.rs_stride = (int)((np + 63) / 64 * 64);
+    // (the voting kernel addresses the transposed table with 32-bit byte offsets)
+    const bool rs_fits = (size_t)(geom.ny + 2 * bp.row_pad + 3) * (size_t)bp.rs_stride * 2 < ((size_t)1 << 32);
+    bp.cuts_inline = ((bp.packed == 5 || bp.packed == 6) && np >= (size_t)m->cuts_inline_min_packets && rs_fits) ? 1 : 0;
+    if (bp.cuts_inline)
+        HIP_TRY(m->cuts.reserve(((size_t)(geom.ny + 2 * bp.row_pad + 3) * (size_t)bp.rs_stride + 1) / 2));  // (u16 entries in u32 words)
+    else
+        HIP_TRY(m->cuts.reserve(np * geom.nz * bp.bands));
+    m->info_cuts_inline = bp.cuts_inline != 0;
     HIP_TRY(m->seam.reserve((size_t)bp.chunks * geom.nz * bp.bands * 2 * geom.nx));
     const bool direct = (bp.chunks == 1 && !accumulate);
     bp.raw_out = direct ? 0 : 1;
@@ -1377,6 +1391,13 @@ int dsi_mapper_set_packed_lanes(dsi_mapper_t* m, int mode)
     REQUIRE(m, DSI_ERR_INVALID, "mapper is null");
     REQUIRE(mode >= -1 && mode <= 7, DSI_ERR_INVALID, "mode must be -1 (auto) or 0..7");
     m->want_packed = mode;
+    return DSI_OK;
+}
+
+int dsi_mapper_set_inline_cuts(dsi_mapper_t* m, long long min_packets)
+{
+    REQUIRE(m, DSI_ERR_INVALID, "mapper is null");
+    m->cuts_inline_min_packets = min_packets < 0 ? (size_t)8192 : (size_t)min_packets;
     return DSI_OK;
 }
 
@@ -2369,6 +2390,7 @@ DSI_API int dsi_test_run_length_total(dsi_mapper_t* m, unsigned long long* total
     REQUIRE(m && total && entries, DSI_ERR_INVALID, "null argument");
     if (int rc = set_device(m->ctx)) return rc;
     size_t units = m->info.n_packets;
+    REQUIRE(!m->info_cuts_inline, DSI_ERR_INVALID, "the last vote derived its runs in the kernel: there is no cut table to add up");
     const uint32_t* src = m->cuts.p;
     if (m->info.packed == 2 || m->info.packed == 4) {  // grouped mapping: one run per group of packets
         units = (m->info.n_packets + m->info.group_packets - 1) / m->info.group_packets;

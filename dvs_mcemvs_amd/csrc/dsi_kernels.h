@@ -16,11 +16,14 @@ constexpr int kPacket = 1024;  // mapper_emvs_stereo.hpp:152
 struct PlaneCoef {
     float a, bx, by, d;
     float r;         // RN(1/d) for the residual-corrected division
-    uint32_t flags;  // kCoefSkip / kCoefSlow
-    uint32_t pad0, pad1;
+    uint32_t flags;  // kCoefSkip / kCoefSlow / kCoefInvertible; bits 16-31: the inline cuts' widening in 1/256 rows
+    float d_a, by_a;  // the inverse of the row transfer, y0 = Y * d_a - by_a (d / a, by / a): a band's rows -> the packet's
+                      // z0 rows -> its run of records.  k_plane_coef turns them into the cut table; with
+                      // BandPlan::cuts_inline the vector-fill stream does, per pass, from the transposed row table
 };
 constexpr uint32_t kCoefSkip = 1u;  // no event of this (packet, plane) can be accepted
 constexpr uint32_t kCoefSlow = 2u;  // use the IEEE divide and the whole packet
+constexpr uint32_t kCoefInvertible = 4u;  // d_a / by_a are usable by the inline cuts (else the run is the whole packet)
 
 // One entry of a grouped packet: an event's z0 location and how many events of the packet
 // share exactly that location (identical raw pixel in one 1024-event packet: hot pixels,
@@ -61,6 +64,11 @@ struct BandPlan {
     int halo;           // 1: a band also takes the events of the row above its first owned row and keeps a halo row
                         // on either side in LDS ((band_rows + 2) rows; k_vote_fuse_argmax), 0: carry row ((band_rows + 1))
     int experiment;     // DSI_EXPERIMENT (timing experiments only, results are wrong): 1 no votes, 2 no flush
+    int cuts_inline;    // mappings 5 / 6 with many packets: NO cut table (bands x planes x packets words: 6.1 GB per camera at
+                        // 1024 x 1024 x 256 with 100 M events, 3.9 ms to write); the voting kernel's `cuts` argument is then the
+                        // TRANSPOSED row table u16 [ny + 2 row_pad + 3][rs_stride] (k_transpose_rowstart) and every pass
+                        // derives its packets' runs from it and from PlaneCoef::d_a / by_a
+    int rs_stride;      // cuts_inline: packets per row of the transposed table (a multiple of 64)
 };
 
 // distance in voxels between the partial volumes of consecutive packet chunks: the volume size

@@ -508,6 +508,36 @@ __device__ __host__ __forceinline__ bool grouped(int packed) { return packed == 
 //     best; wider tiles for longer write segments were slower).
 constexpr int kCoefTilePackets = 16;
 
+// The z0 row bins a band's rows come from: band rows [r0 - halo, min(r1, ny - 1)] -> y0 = Y * d_a - by_a (fp32; its rounding,
+// <= 4e-7 of |y0| + |by/a|, disappears in the widening) -> entries of the packet's row table: the run is
+// [rs[*bin_lo], rs[*bin_hi]).  false: a NaN bound -- the run is the whole packet.  ONE function for k_plane_coef's cut
+// table and for the vector fill's inline cuts (BandPlan::cuts_inline), so that both take the same runs.
+__device__ __forceinline__ bool band_row_bins(float d_a, float by_a, float L, float U, int ny, int pad, int* bin_lo, int* bin_hi)
+{
+    const float ya = L * d_a - by_a, yb = U * d_a - by_a;
+    float ymin = fminf(ya, yb), ymax = fmaxf(ya, yb);
+    if (!(ya == ya && yb == yb)) return false;
+    // the fp32 forward map (mul, add, divide) is within a few ulps of the real
+    // one: in y0 units that is ~2^-22 * (|y0| + |by/a|); widen by 80x that
+    const float m = 2e-5f * (fmaxf(fabsf(ymin), fabsf(ymax)) + fabsf(by_a));
+    ymin -= m;
+    ymax += m;
+    const float fa = fminf(fmaxf(__builtin_floorf(ymin), (float)(-pad - 1)), (float)(ny + pad));
+    const float fb = fminf(fmaxf(__builtin_floorf(ymax), (float)(-pad - 1)), (float)(ny + pad));
+    *bin_lo = (int)fa + pad + 1;  // events in bins below bin(fa)
+    *bin_hi = (int)fb + pad + 2;  // events in bins up to and including bin(fb)
+    return true;
+}
+// (the band's accepted Y interval: accepted iff 0 <= Y < ny-1; the band needs floor(Y) in [r0, r1-1]; bp.halo: the fused
+//  kernel's bands also take the events of the row above their first)
+__device__ __forceinline__ void band_y_interval(int j, const Geom& g, const BandPlan& bp, float* L, float* U)
+{
+    const int r0 = j * bp.band_rows;
+    const int r1 = min(g.ny, r0 + bp.band_rows);
+    *L = (float)(r0 - bp.halo) - 0.01f;
+    *U = (float)min(r1, g.ny - 1) + 0.01f;
+}
+
 template <bool STAGED>
 __device__ __forceinline__ void plane_coef_body(const unsigned bid, const float* __restrict__ centers,
                                                 const float* __restrict__ planes,
@@ -534,7 +564,7 @@ __device__ __forceinline__ void plane_coef_body(const unsigned bid, const float*
     const int z = (int)(tile / (unsigned)tiles_p) * planes_per_block + (int)(threadIdx.x >> 4);
     const int pad = bp.row_pad;
     const int nb = g.ny + 2 * pad + 2;
-    if (STAGED) {
+    if (STAGED && !(bp.cuts_inline && !pair_work)) {
         // the tile's tables are one contiguous piece of rowstart, 4-byte aligned (k0 is even); the
         // last 32-bit word may reach one element past the piece (the buffer has that slack)
         const int count = min(kCoefTilePackets, np - k0) * (nb + 1);
@@ -553,7 +583,6 @@ __device__ __forceinline__ void plane_coef_body(const unsigned bid, const float*
     plane_coefficients(centers[3 * kq], centers[3 * kq + 1], centers[3 * kq + 2], planes[zq], g, c.a,
                        c.bx, c.by, c.d);
     c.r = 1.f / c.d;
-    c.pad0 = c.pad1 = 0;
     const uint32_t nvraw = !valid ? 0u : (grouped(bp.packed) ? 1u : nvalid[kq]);
     const int nv = (int)(nvraw & 0x7fffffffu);
     const bool big_events = (nvraw >> 31) != 0;
@@ -568,12 +597,6 @@ __device__ __forceinline__ void plane_coef_body(const unsigned bid, const float*
     const bool slow = !dead && (!(ad >= 0x1p-40f && ad <= 0x1p40f) /* incl. d = +-inf */ ||
                                 big_events || fabsf(c.a) > 0x1p40f || fabsf(c.bx) > 0x1p40f ||
                                 fabsf(c.by) > 0x1p40f);
-    c.flags = dead ? kCoefSkip : (slow ? kCoefSlow : 0u);
-    if (valid) coef[tid] = c;
-    if (slow) atomicOr(&nvalid[np + zq], 1u);  // (slow implies valid: nv > 0)
-
-    const uint16_t* rs = STAGED ? s_rowstart + (size_t)(threadIdx.x & 15) * (nb + 1)
-                                : rowstart + (grouped(bp.packed) ? 0 : (size_t)kq * (nb + 1));
     // y0 = (Y*d - by)/a inverts the transfer; unusable when the map is (nearly) constant or
     // the inversion is ill-conditioned -- then the whole packet is the (superset) run
     const double a = (double)c.a, d = (double)c.d, by = (double)c.by;
@@ -583,32 +606,37 @@ __device__ __forceinline__ void plane_coef_body(const unsigned bid, const float*
     // widening below, and 2 x bands x planes x packets double-precision chains were what the kernel
     // spent its time on
     const float by_a = (float)(by * inv_a), d_a = (float)(d * inv_a);
+    // The inline cuts (BandPlan::cuts_inline) widen every band's interval by ONE bound per (packet, plane), M >= the
+    // 2e-5 * (|y0| + |by/a|) of band_row_bins for every band (|y0| <= (ny + 1) |d/a| + |by/a|), in 1/256 rows in the high half of
+    // flags; they only trust d_a / by_a where every band's y0 stays far inside the int32 range of v_cvt_flr_i32_f32.
+    const float margin = 2e-5f * ((float)(g.ny + 1) * fabsf(d_a) + 2.f * fabsf(by_a));
+    const bool inline_ok = invertible && fabsf(d_a) <= 1e4f && fabsf(by_a) <= 1e8f && margin <= 200.f;
+    const uint32_t margin_q = inline_ok ? (uint32_t)__builtin_ceilf(margin * 256.f) + 1u : 0u;
+    c.flags = (dead ? kCoefSkip : (slow ? kCoefSlow : 0u)) | (inline_ok ? kCoefInvertible : 0u) | (margin_q << 16);
+    c.d_a = d_a;
+    c.by_a = by_a;
+    if (valid) coef[tid] = c;
+    if (slow) atomicOr(&nvalid[np + zq], 1u);  // (slow implies valid: nv > 0)
+    // no cut table: the voting kernel's passes derive their runs themselves (BandPlan::cuts_inline)
+    if (bp.cuts_inline && !pair_work) return;
+
+    const uint16_t* rs = STAGED ? s_rowstart + (size_t)(threadIdx.x & 15) * (nb + 1)
+                                : rowstart + (grouped(bp.packed) ? 0 : (size_t)kq * (nb + 1));
     for (int j = 0; j < bp.bands; ++j) {
         uint32_t lo = 0, hi = 0;
         if (!dead) {
             hi = (uint32_t)nv;
             if (invertible) {
-                const int r0 = j * bp.band_rows;
-                const int r1 = min(g.ny, r0 + bp.band_rows);
-                // accepted iff 0 <= Y < ny-1; the band needs floor(Y) in [r0, r1-1]
-                // (bp.halo: the fused kernel's bands also take the events of the row above their first)
-                const float L = (float)(r0 - bp.halo) - 0.01f, U = (float)min(r1, g.ny - 1) + 0.01f;
-                const float ya = L * d_a - by_a, yb = U * d_a - by_a;
-                float ymin = fminf(ya, yb), ymax = fmaxf(ya, yb);
-                if (ya == ya && yb == yb) {  // not NaN
-                    // the fp32 forward map (mul, add, divide) is within a few ulps of the real
-                    // one: in y0 units that is ~2^-22 * (|y0| + |by/a|); widen by 80x that
-                    const float m = 2e-5f * (fmaxf(fabsf(ymin), fabsf(ymax)) + fabsf(by_a));
-                    ymin -= m;
-                    ymax += m;
-                    const float fa = fminf(fmaxf(__builtin_floorf(ymin), (float)(-pad - 1)), (float)(g.ny + pad));
-                    const float fb = fminf(fmaxf(__builtin_floorf(ymax), (float)(-pad - 1)), (float)(g.ny + pad));
+                float L, U;
+                band_y_interval(j, g, bp, &L, &U);
+                int bin_lo, bin_hi;
+                if (band_row_bins(d_a, by_a, L, U, g.ny, pad, &bin_lo, &bin_hi)) {  // not NaN
                     if (grouped(bp.packed)) {  // grouped mapping: row bins, resolved per group later
-                        lo = (uint32_t)((int)fa + pad + 1);
-                        hi = (uint32_t)((int)fb + pad + 2);
+                        lo = (uint32_t)bin_lo;
+                        hi = (uint32_t)bin_hi;
                     } else {
-                        lo = rs[(int)fa + pad + 1];   // events in bins below bin(fa)
-                        hi = rs[(int)fb + pad + 2];   // events in bins up to and including bin(fb)
+                        lo = rs[bin_lo];
+                        hi = rs[bin_hi];
                     }
                 } else if (grouped(bp.packed)) {
                     lo = 0;
@@ -623,7 +651,7 @@ __device__ __forceinline__ void plane_coef_body(const unsigned bid, const float*
             lo = 0xffffu;  // dead packet: contributes no rows
             hi = 0;
         }
-        if (valid) cuts[((size_t)j * g.nz + zq) * np + kq] = lo | (hi << 16);  // 16 bits each
+        if (valid && !bp.cuts_inline) cuts[((size_t)j * g.nz + zq) * np + kq] = lo | (hi << 16);  // 16 bits each
         if (pair_work) {
             // records of this (band, plane) over the 16 packets of the tile (lanes 16 i .. 16 i + 15 of a wave
             // share the plane): a row reduction, then one atomic per (band, plane, tile)
@@ -666,6 +694,31 @@ __global__ __launch_bounds__(1024) void k_plane_coef_multi(PrepCameras cams, Ban
     }
     const PrepCamera& pc = cams.cam[c];
     plane_coef_body<STAGED>(bid, pc.raw.centers, pc.planes, pc.rowstart, pc.nvalid, pc.np, pc.raw.g, bp, pc.coef, pc.cuts, pc.pair_work);
+}
+
+// (2b) BandPlan::cuts_inline: the packets' row tables TRANSPOSED -- rsT[bin][packet], rows of `stride` packets -- so
+//      that a pass of the vector fill (lane = packet, 64 consecutive packets whose poses are microseconds apart: their
+//      bins for one band and plane differ by a row or two) reads its two entries per packet from one or two 128-byte
+//      pieces.  64 packets x 64 bins per block through LDS.
+__global__ __launch_bounds__(256) void k_transpose_rowstart(const uint16_t* __restrict__ rs, int np, int nb1, int stride,
+                                                            uint16_t* __restrict__ rsT)
+{
+    __shared__ uint16_t tile[64][66];
+    const int p0 = (int)blockIdx.x * 64, b0 = (int)blockIdx.y * 64;
+    {
+        const int bin = b0 + (int)(threadIdx.x & 63);
+        for (int i = (int)(threadIdx.x >> 6); i < 64; i += 4) {
+            const int p = p0 + i;
+            tile[i][threadIdx.x & 63] = (p < np && bin < nb1) ? rs[(size_t)p * nb1 + bin] : (uint16_t)0;
+        }
+    }
+    __syncthreads();
+    const int p = p0 + (int)(threadIdx.x & 63);
+    if (p >= stride) return;
+    for (int i = (int)(threadIdx.x >> 6); i < 64; i += 4) {
+        const int bin = b0 + i;
+        if (bin < nb1) rsT[(size_t)bin * stride + p] = tile[threadIdx.x & 63][i];
+    }
 }
 
 // (3) the voting kernel.  Work item = (packet chunk c, band j, plane z): the band's
@@ -1189,6 +1242,62 @@ __device__ __forceinline__ int wave_incl_scan(int v, int /*lane*/)
     return s;
 }
 
+// BandPlan::cuts_inline: what a pass of the vector fill needs to find its packets' runs without a cut table.  Per item
+// (band, plane): the band's Y interval; per packet two steps -- (1) the second half of its PlaneCoef {r, flags, d_a, by_a},
+// (2) two entries of the transposed row table.  The streams issue (1) two stretches and (2) one stretch ahead of the votes.
+struct InlineCuts {
+    const uint16_t* rsT;  // nullptr: cut table
+    uint32_t stride2;     // BYTES per row of rsT (the whole table is < 4 GB: vote_device)
+    int nb;               // last entry of a packet's table: all its records
+    int pad;
+    float L, U;
+};
+
+__device__ __forceinline__ InlineCuts inline_cuts_of(const uint32_t* cuts, const Geom& g, const BandPlan& bp, int j)
+{
+    InlineCuts ic{};
+    if (!bp.cuts_inline) return ic;
+    ic.rsT = reinterpret_cast<const uint16_t*>(cuts);
+    ic.stride2 = 2u * (uint32_t)bp.rs_stride;
+    ic.pad = bp.row_pad;
+    ic.nb = g.ny + 2 * bp.row_pad + 2;
+    band_y_interval(j, g, bp, &ic.L, &ic.U);
+    return ic;
+}
+
+// step 2 for the packet at byte column p2 (= 2 * packet; a valid packet of the plane): the byte offsets of its two table
+// entries.  c1 = {r, flags | margin << 16, d_a, by_a}.  A vector instruction here is paid 1,500 times per wave and work
+// item at configs[4]'s size, beside ~50 per batch of votes: the bins are band_row_bins' with the widening taken from the
+// packet's own bound (PlaneCoef::flags >> 16, 1/256 rows: >= every band's), fused multiply-adds, one v_cvt_flr each and
+// the clamps on integers -- a superset of that superset; the vote re-tests every event exactly.
+__device__ __forceinline__ void inline_cut_entries(const InlineCuts& ic, uint4 c1, uint32_t p2, uint32_t* at_lo, uint32_t* at_hi)
+{
+    const float d_a = __uint_as_float(c1.z), by_a = __uint_as_float(c1.w);
+    const float M = (float)(c1.y >> 16) * (1.f / 256.f);
+    const float ya = __builtin_fmaf(ic.L, d_a, -by_a), yb = __builtin_fmaf(ic.U, d_a, -by_a);  // (finite: kCoefInvertible's range)
+    const int lo = floor_to_int(fminf(ya, yb) - M) + (ic.pad + 1);  // events in bins below bin(floor(ymin))
+    const int hi = floor_to_int(fmaxf(ya, yb) + M) + (ic.pad + 2);  // events in bins up to and including bin(floor(ymax))
+    int bin_lo = min(max(lo, 0), ic.nb - 1), bin_hi = min(max(hi, 1), ic.nb);
+    if (!(c1.y & kCoefInvertible)) {  // entry 0 is 0, entry nb the packet's records: the whole packet
+        bin_lo = 0;
+        bin_hi = ic.nb;
+    }
+    *at_lo = (uint32_t)bin_lo * ic.stride2 + p2;
+    *at_hi = (uint32_t)bin_hi * ic.stride2 + p2;
+}
+
+__device__ __forceinline__ uint32_t inline_cut_load(const InlineCuts& ic, uint32_t byte_offset)
+{
+    return *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(ic.rsT) + byte_offset);
+}
+
+// the cut word lo | hi << 16 of what the two loads returned (k_plane_coef's rules: a dead pair has no run, hi >= lo)
+__device__ __forceinline__ uint32_t inline_cut_word(uint32_t flags, uint32_t lo, uint32_t hi)
+{
+    if (flags & kCoefSkip) return 0u;
+    return lo | (max(hi, lo) << 16);
+}
+
 template <bool SLOW>
 __device__ __forceinline__ void vfill_stream(const EvRec* __restrict__ sxy,
                                              const uint4* __restrict__ coef4,
@@ -1197,7 +1306,7 @@ __device__ __forceinline__ void vfill_stream(const EvRec* __restrict__ sxy,
                                              unsigned long long* __restrict__ scratch /* 64 words of this wave */,
                                              int p_first, int p_end, int lg_pass, int stride,
                                              int lane, int nx, int Li, int Ui, int row_base,
-                                             uint32_t dummy_eo)
+                                             uint32_t dummy_eo, const InlineCuts& ic)
 {
     if (Ui - 1 < Li) return;  // the band accepts no row
     const int pass = 1 << lg_pass;
@@ -1245,7 +1354,16 @@ __device__ __forceinline__ void vfill_stream(const EvRec* __restrict__ sxy,
             if (pass_base >= p_end) return false;
             const int p = pass_base + lane;
             uint32_t cu = 0;
-            if (lane < pass && p < p_end) cu = cutz[p];
+            if (lane < pass && p < p_end) {
+                if (ic.rsT) {  // (this compiled stream is the A/B twin and the IEEE-divide planes' path: no prefetch)
+                    const uint4 c1 = coef4[2 * (size_t)p + 1];
+                    uint32_t at_lo, at_hi;
+                    inline_cut_entries(ic, c1, 2u * (uint32_t)p, &at_lo, &at_hi);
+                    cu = inline_cut_word(c1.y, inline_cut_load(ic, at_lo), inline_cut_load(ic, at_hi));
+                } else {
+                    cu = cutz[p];
+                }
+            }
             const int lo = (int)(cu & 0xffffu), hi = (int)(cu >> 16);
             len = max(hi - lo, 0);
             incl = wave_incl_scan(len, lane);
@@ -1838,7 +1956,7 @@ __device__ __forceinline__ void vfill_stream_asm(const EvRec* __restrict__ sxy,
                                                  int p_first, int p_end, int lg_pass, int stride,
                                                  int lane, int nx, int Li, int Ui, int row_base,
                                                  uint32_t dummy_eo, int variant, int p_begin_of_wg,
-                                                 int* __restrict__ pass_counter)
+                                                 int* __restrict__ pass_counter, const InlineCuts& ic)
 {
     if (Ui - 1 < Li) return;  // the band accepts no row (the unsigned range test needs Ui-1-Li >= 0)
     const int pass = 1 << lg_pass;
@@ -1874,16 +1992,60 @@ __device__ __forceinline__ void vfill_stream_asm(const EvRec* __restrict__ sxy,
     auto packet_of = [&](int u) { return p_begin + u * half + lane; };
     const int u0 = 2 * ((p_first - p_begin) / pass);  // this wave's first stretch: a whole pass
     uint32_t cu_next = 0;
-    if (u0 < n_units && lane < pass && packet_of(u0) < p_end) cu_next = cutz[packet_of(u0)];
+    // BandPlan::cuts_inline (ic.rsT): no cut table.  The runs of a stretch come in two dependent steps -- the packets'
+    // {flags, d_a, by_a}, then two entries of the transposed row table -- so stretches are drawn TWO ahead: while stretch
+    // u is voted, step 2 of stretch u' (the next) and step 1 of stretch u'' (the one after) are in flight.
+    const bool inl = ic.rsT != nullptr;
+    uint4 c1_next = make_uint4(0u, 0u, 0u, 0u);   // step 1 of the stretch after this one
+    uint32_t e_lo = 0, e_hi = 0, e_flags = kCoefSkip;  // step 2 of this stretch (arrives during the previous one)
+    int u_after = n_units, t_after = 2;
+    bool valid_next = false;
+    auto lanes_of = [&](int u, int t) { return u < n_units && lane < t * half && packet_of(u) < p_end; };
+    auto step2 = [&](uint4 c1, int p, bool valid) {
+        e_flags = kCoefSkip;
+        e_lo = e_hi = 0;
+        if (valid) {
+            uint32_t at_lo, at_hi;
+            inline_cut_entries(ic, c1, 2u * (uint32_t)p, &at_lo, &at_hi);
+            e_flags = c1.y;
+            e_lo = inline_cut_load(ic, at_lo);
+            e_hi = inline_cut_load(ic, at_hi);
+        }
+    };
     int take = 2, tn = 2;
+    if (inl) {
+        const bool v0 = lanes_of(u0, 2);
+        uint4 c1 = make_uint4(0u, 0u, 0u, 0u);
+        if (v0) c1 = coef4[2 * (size_t)packet_of(u0) + 1];
+        u_after = draw(t_after);                     // the second stretch
+        valid_next = lanes_of(u_after, t_after);
+        if (valid_next) c1_next = coef4[2 * (size_t)packet_of(u_after) + 1];
+        step2(c1, packet_of(u0), v0);                // (waits for the first stretch's step 1: once per item and wave)
+    } else if (u0 < n_units && lane < pass && packet_of(u0) < p_end) {
+        cu_next = cutz[packet_of(u0)];
+    }
     for (int u = u0, un; u < n_units; u = un, take = tn) {
         const int p = packet_of(u);
-        const uint32_t cu = cu_next;
+        uint32_t cu;
         (void)take;  // (lanes beyond the stretch loaded no cut word: length 0)
-        // the next stretch is drawn now and its cut words travel while this one is voted
-        un = draw(tn);
-        cu_next = 0;
-        if (un < n_units && lane < tn * half && packet_of(un) < p_end) cu_next = cutz[packet_of(un)];
+        if (inl) {
+            cu = inline_cut_word(e_flags, e_lo, e_hi);   // this stretch's entries (requested one stretch ago)
+            un = u_after;
+            tn = t_after;
+            const uint4 c1 = c1_next;                    // the next stretch's step 1 (requested one stretch ago) ...
+            const bool vn = valid_next;
+            u_after = draw(t_after);                     // ... the stretch after it is drawn now, its step 1 requested ...
+            valid_next = lanes_of(u_after, t_after);
+            c1_next = make_uint4(0u, 0u, 0u, 0u);
+            if (valid_next) c1_next = coef4[2 * (size_t)packet_of(u_after) + 1];
+            step2(c1, packet_of(un), vn);                // ... and the next stretch's entries
+        } else {
+            cu = cu_next;
+            // the next stretch is drawn now and its cut words travel while this one is voted
+            un = draw(tn);
+            cu_next = 0;
+            if (un < n_units && lane < tn * half && packet_of(un) < p_end) cu_next = cutz[packet_of(un)];
+        }
         const int lo = (int)(cu & 0xffffu), hi = (int)(cu >> 16);
         const int len = max(hi - lo, 0);
         const int incl = wave_incl_scan(len, lane);
@@ -2110,7 +2272,8 @@ __device__ __forceinline__ void stream_item(const EvRec* __restrict__ sxy, const
     if (bp.pass_lg > 0) lg_group = bp.pass_lg;
     const int group = 1 << lg_group;
     const uint4* __restrict__ coef4 = reinterpret_cast<const uint4*>(coef) + 2 * (size_t)z * np;
-    const uint32_t* __restrict__ cutz = cuts + ((size_t)j * g.nz + z) * np;
+    // (bp.cuts_inline: `cuts` is the transposed row table, there is no table row of this item)
+    const uint32_t* __restrict__ cutz = bp.cuts_inline ? cuts : cuts + ((size_t)j * g.nz + z) * np;
     // record np * 1024 is a dummy with multiplicity 0 (k_sort_packets) for the lanes a short last
     // batch does not reach; "its" coefficients are whatever follows the plane's table
     const uint32_t dummy_eo = (uint32_t)np * (uint32_t)kPacket;
@@ -2126,15 +2289,16 @@ __device__ __forceinline__ void stream_item(const EvRec* __restrict__ sxy, const
         const int pass = 1 << lg_pass;
         unsigned long long* scratch =
             reinterpret_cast<unsigned long long*>(band_bytes + bp.scratch_offset) + wave * kVfillScratchWords;
+        const InlineCuts ic = inline_cuts_of(cuts, g, bp, j);  // (ic.rsT != nullptr: `cuts` is the transposed row table)
         if (slow_any[z] != 0)
             vfill_stream<true>(sxy, coef4, cutz, band_bytes, scratch, p_begin + wave * pass, p_end, lg_pass,
-                               kWaves * pass, lane, nx, Li, Ui, row_base, dummy_eo);
+                               kWaves * pass, lane, nx, Li, Ui, row_base, dummy_eo, ic);
         else if constexpr (MAPPING == 6)
             vfill_stream<false>(sxy, coef4, cutz, band_bytes, scratch, p_begin + wave * pass, p_end, lg_pass,
-                                kWaves * pass, lane, nx, Li, Ui, row_base, dummy_eo);
+                                kWaves * pass, lane, nx, Li, Ui, row_base, dummy_eo, ic);
         else
             vfill_stream_asm(sxy, coef4, cutz, band_bytes, scratch, p_begin + wave * pass, p_end, lg_pass,
-                             kWaves * pass, lane, nx, Li, Ui, row_base, dummy_eo, TWO_SETS ? 3 : bp.experiment, p_begin, s_pass);
+                             kWaves * pass, lane, nx, Li, Ui, row_base, dummy_eo, TWO_SETS ? 3 : bp.experiment, p_begin, s_pass, ic);
     } else {
         // MAPPING 3 is the compiled stream on the fast path too (A/B testing)
         if (slow_any[z] != 0)
@@ -4288,6 +4452,18 @@ hipError_t launch_plane_coef(hipStream_t s, const float* centers, const float* p
     if (np <= 0) return hipSuccess;
     const unsigned tiles_p = (unsigned)((np + kCoefTilePackets - 1) / kCoefTilePackets);
     const size_t table_bytes = ((size_t)kCoefTilePackets * (size_t)(g.ny + 2 * bp.row_pad + 3) * sizeof(uint16_t) + 7) & ~(size_t)7;
+    if (bp.cuts_inline) {
+        // coefficients only (16 packets x 16 planes per block, no row tables staged), then the row tables transposed:
+        // `cuts` is that table, u16 [ny + 2 row_pad + 3][bp.rs_stride]
+        if (grouped(bp.packed) || bp.rs_stride < np || (bp.rs_stride & 63)) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_plane_coef<false>, dim3((tiles_p * (unsigned)((g.nz + 15) / 16) + 63u) & ~63u), dim3(256), 0, s, centers,
+                           planes, rowstart, nvalid, np, g, bp, coef, cuts);
+        if (hipError_t e = hipExtGetLastError()) return e;
+        const int nb1 = g.ny + 2 * bp.row_pad + 3;
+        hipLaunchKernelGGL(k_transpose_rowstart, dim3((unsigned)(bp.rs_stride / 64), (unsigned)((nb1 + 63) / 64)), dim3(256), 0, s,
+                           rowstart, np, nb1, bp.rs_stride, reinterpret_cast<uint16_t*>(cuts));
+        return hipExtGetLastError();
+    }
     if (!grouped(bp.packed) && table_bytes <= max_dynamic_lds()) {
         // 16 packets x 64 planes per block: the tables are loaded nz / 64 times
         if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_plane_coef<true>), table_bytes)) return e;

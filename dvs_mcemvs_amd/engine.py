@@ -148,6 +148,7 @@ def load_library():
         "dsi_mapper_set_vote_algo": (C.c_int, [vp, C.c_int]),
         "dsi_mapper_set_band_params": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
         "dsi_mapper_set_packed_lanes": (C.c_int, [vp, C.c_int]),
+        "dsi_mapper_set_inline_cuts": (C.c_int, [vp, C.c_longlong]),
         "dsi_mapper_fill_voxel_grid": (C.c_int, [vp, f32p, f32p, C.c_size_t]),
         "dsi_batch_create": (C.c_int, [vp, u16p, u16p, C.c_size_t, u32p, f32p, C.c_size_t,
                                        C.POINTER(vp)]),
@@ -790,6 +791,11 @@ class MapperEMVS:
 
     def set_packed_lanes(self, mode=-1):
         _check(load_library().dsi_mapper_set_packed_lanes(self._h, int(mode)))
+
+    def set_inline_cuts(self, min_packets=-1):
+        """Lane mappings 5 / 6: from how many packets per call on the voting kernel derives the packets' runs itself
+        instead of reading a cut table (-1 = default 8192, 0 = always)."""
+        _check(load_library().dsi_mapper_set_inline_cuts(self._h, int(min_packets)))
 
     def last_vote_info(self):
         info = _VoteInfo()

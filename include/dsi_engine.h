@@ -39,7 +39,7 @@ extern "C" {
 #define DSI_API
 #endif
 
-#define DSI_ENGINE_ABI_VERSION 8
+#define DSI_ENGINE_ABI_VERSION 9
 #define DSI_PACKET_SIZE 1024 /* mapper_emvs_stereo.hpp:152 packet_size_ */
 
 typedef enum {
@@ -275,6 +275,12 @@ DSI_API int dsi_mapper_set_band_params(dsi_mapper_t *m, int band_rows, int chunk
  * 7 = mapping 1 with DEALT passes: the waves of a workgroup draw their passes from a counter instead of taking
  *     every 16th one (the automatic choice wherever mapping 1 used to be chosen). */
 DSI_API int dsi_mapper_set_packed_lanes(dsi_mapper_t *m, int mode);
+/* Lane mappings 5 / 6 (wide grids) read, per (band, plane, packet), the run of the packet's records the band must look
+ * at.  As a table that is bands x planes x packets words -- 6.1 GB per camera at 1024 x 1024 x 256 with 100 M events, 3.9 ms to
+ * write -- so from min_packets packets per call on the voting kernel derives the runs itself, per pass, from the
+ * packets' transposed row tables (the same runs: fillVoxelGrid's loop mapper_emvs_stereo.cpp:168-203 visits the same
+ * events either way, and the DSI is bit-identical).  min_packets < 0 = the default (8192), 0 = always, a huge value = never. */
+DSI_API int dsi_mapper_set_inline_cuts(dsi_mapper_t *m, long long min_packets);
 
 /* MapperEMVS::fillVoxelGrid(event_locations_z0, camera_centers)
  * (mapper_emvs_stereo.cpp:151-205) -- the exact-parity test point.  xy_z0: 2 floats

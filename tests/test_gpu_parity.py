@@ -42,7 +42,7 @@ def random_packets(rng, n_packets, nx, ny, spread=0.3, cz_spread=0.5):
 
 
 def make_mapper(ctx, cam, nz, dmin, dmax, algo, dimX=0, dimY=0, fov=0.0, lut=None, inverse=False,
-                band=None, packed=None):
+                band=None, packed=None, inline_cuts=None):
     m = d.MapperEMVS(ctx, cam, d.ShapeDSI(dimX, dimY, nz, dmin, dmax, fov), lut=lut,
                      inverse_depth=inverse)
     m.set_vote_algo(algo)
@@ -50,6 +50,8 @@ def make_mapper(ctx, cam, nz, dmin, dmax, algo, dimX=0, dimY=0, fov=0.0, lut=Non
         m.set_band_params(*band)
     if packed is not None:
         m.set_packed_lanes(packed)
+    if inline_cuts is not None:
+        m.set_inline_cuts(inline_cuts)
     return m
 
 
@@ -802,6 +804,38 @@ def test_both_lane_mappings_match_oracle(ctx, shape, band, packed):
     m.close()
 
 
+@pytest.mark.parametrize("packed", [5, 6])
+@pytest.mark.parametrize("n_packets", [1, 70, 700, 2500])
+def test_inline_cuts_equal_the_cut_table_bit_for_bit(ctx, packed, n_packets):
+    """Round 6: from 16 k packets on the vector-fill mapping derives every pass's runs in the voting kernel (two entries
+    of the packets' transposed row tables per packet and pass) instead of reading k_plane_coef's cut table -- 6.1 GB per
+    camera at configs[4]'s size.  Forced on here at small sizes: same DSI bit for bit, and the oracle's
+    (mapper_emvs_stereo.cpp:168-203 visits the same events either way).  Dead packets, one-row packets, d = 0 and
+    IEEE-divide planes included; 2,500 packets = many dealt stretches per wave."""
+    nx, ny, nz = 160, 120, 9
+    rng = np.random.default_rng(4100 + n_packets)
+    cam = (nx, ny, 0.8 * nx, 0.8 * nx, 0.5 * nx, 0.5 * ny)
+    xy, centers = random_packets(rng, n_packets, nx, ny)
+    if n_packets > 12:
+        xy[5 * 1024:6 * 1024] = np.nan
+        xy[7 * 1024:8 * 1024, 1] = 3.25
+        centers[11] = (0.0, 0.0, 1e30)
+    got = []
+    for inline in (None, 0):
+        m = make_mapper(ctx, cam, nz, 1.0, 6.5, d.VOTE_LDS_BANDS, band=(9, 1, 1024), packed=packed, inline_cuts=inline)
+        if n_packets > 12 and inline is None:
+            centers[9] = (0.1, 0.1, m.raw_depths_vec_[0])
+        m.fillVoxelGrid(xy, centers)
+        assert m.last_vote_info()["packed"] == packed
+        got.append(m.dsi_.download())
+        if inline is None and n_packets <= 700:
+            ref = orc.fill_voxel_grid(xy, centers, m.raw_depths_vec_, np.array(m.virtual_cam_, np.float32), nx, ny)
+            assert_dsi_close(got[0], ref)
+        m.close()
+    assert np.array_equal(got[0], got[1])
+    assert got[0].any()
+
+
 @pytest.mark.parametrize("packed", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("n_pixels", [1, 7, 300, 5000])
 def test_duplicate_events_in_a_packet(ctx, packed, n_pixels):
@@ -894,8 +928,9 @@ def test_hand_scheduled_loops_equal_the_compiled_loop_bit_for_bit(ctx, seed):
     # every voxel is fl(exact 64-bit sum) whatever the lane mapping, band height or packet chunking (round 3: the
     # chunks' partial volumes are raw 64-bit sums), so ALL seven mappings give the same bits -- the grouped
     # mappings 2 / 4 too, although they cut the packets into chunks at other places
-    for packed in (3, 1, 7, 0, 5, 6, 2, 4):
-        m = make_mapper(ctx, cam, nz, 0.8, m_max, d.VOTE_LDS_BANDS, band=band, packed=packed)
+    # (5 / 6 twice: with the cut table and with the runs derived in the kernel from the transposed row tables, round 6)
+    for packed, inline in ((3, None), (1, None), (7, None), (0, None), (5, None), (6, None), (2, None), (4, None), (5, 0), (6, 0)):
+        m = make_mapper(ctx, cam, nz, 0.8, m_max, d.VOTE_LDS_BANDS, band=band, packed=packed, inline_cuts=inline)
         m.fillVoxelGrid(xy, centers)
         got = m.dsi_.download()
         m.close()
