@@ -538,6 +538,8 @@ bool plan_fused(const dsi_mapper* m, size_t n_packets_max, dsi::BandPlan* bp)
 #ifdef DSI_TIMING_EXPERIMENTS
     if (const char* e = std::getenv("DSI_FUSED_2CU"))  // 0: a small band still runs one workgroup per CU (A/B)
         if (std::atoi(e) == 0) bp->experiment = 300;
+    if (const char* e = std::getenv("DSI_FUSED_DEFER"))  // 0: camera 1's fusion + arg-max inside its read-back, as before round 6 (A/B)
+        if (std::atoi(e) == 0) bp->experiment = 301;
 #endif
     return true;
 }

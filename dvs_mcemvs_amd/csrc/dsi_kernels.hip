@@ -2498,11 +2498,31 @@ struct FusedBest {
 // anyway -- so that the CELLS / 2 LDS reads of a half are in flight together: with a branch per cell every
 // read was waited for on its own, and the read-back took 3 us per phase (tools/fused_trace.py).
 // MODE: what a phase does with the band it has just voted
-enum { FUSED_KEEP = 0,   // camera 0 of several: keep the values
+enum { FUSED_READ1 = 5,  // camera 1 of 2, round 6: read back, clear and convert only -- values kept in vb; the fusion op and the
+                         // running arg-max (the VALU-bound two thirds of that read-back) are DEFERRED to fused_deferred_argmax,
+                         // which every wave runs at the end of ITS OWN next voting stream, while the other waves still vote
+       FUSED_KEEP = 0,   // camera 0 of several: keep the values
        FUSED_MID = 1,    // camera 1 of 3: the two-camera op, result kept (process1.cpp:126-158)
        FUSED_LAST2 = 2,  // camera 1 of 2: the two-camera op, then the running arg-max
        FUSED_LAST1 = 3,  // the only camera: arg-max of its own values
        FUSED_LAST3 = 4 };// camera 2 of 3: the third-camera op (process1.cpp:169-191: 1 min, 2 HM with n = 3, 6 max), arg-max
+// the deferred half of camera 1's read-back (two cameras): process1.cpp:126-158 on the values of both cameras, then the
+// running first maximum (cartesian3dgrid.cpp:132-134) -- registers only, no LDS, no barrier
+template <int CELLS, int OP>
+__device__ __forceinline__ void fused_deferred_argmax(const float* __restrict__ va, const float* __restrict__ vb,
+                                                      FusedBest<CELLS>& fb, int z)
+{
+#pragma unroll
+    for (int kk = 0; kk < CELLS; ++kk) {
+        const float f = fuse_op<OP>(0.f + va[kk], vb[kk]);
+        const bool better = fb.best[kk] < f;
+        fb.best[kk] = better ? f : fb.best[kk];
+        const int sh = (kk & 3) * 8;
+        const uint32_t with_z = (fb.idx4[kk >> 2] & ~(0xffu << sh)) | ((uint32_t)z << sh);
+        fb.idx4[kk >> 2] = better ? with_z : fb.idx4[kk >> 2];
+    }
+}
+
 template <int CELLS, int OP, int MODE>
 __device__ __forceinline__ void fused_consume(acc_t* __restrict__ band, int nx, int n_own, int rows_lds,
                                               float* __restrict__ va, FusedBest<CELLS>& fb, int z)
@@ -2513,8 +2533,10 @@ __device__ __forceinline__ void fused_consume(acc_t* __restrict__ band, int nx, 
     //  the voting loops, which name 40 physical registers themselves)
     int t = (int)threadIdx.x;
     asm volatile("" : "+v"(t));
-    constexpr int HALF = CELLS / 2;
-    static_assert(CELLS % 2 == 0, "two halves");
+    // cells read back together.  With camera 1's values parked in a second register array (DEFER) the kernel has ~20
+    // registers fewer for the reads in flight: quarters instead of halves there
+    constexpr int HALF = (MODE == FUSED_READ1 || (MODE == FUSED_KEEP && CELLS % 4 == 0 && CELLS == 20)) ? CELLS / 4 : CELLS / 2;
+    static_assert(CELLS % 2 == 0 && CELLS % HALF == 0, "whole parts");
 #pragma unroll
     for (int h = 0; h < CELLS; h += HALF) {
         acc_t raw[HALF];
@@ -2536,7 +2558,7 @@ __device__ __forceinline__ void fused_consume(acc_t* __restrict__ band, int nx, 
             const float v = big ? (float)((double)raw[k] * kFixInv)
                                 : (float)(__longlong_as_double((long long)(raw[k] | 0x4140000000000000ull)) - 2097152.0);
             const int kk = h + k;
-            if (MODE == FUSED_KEEP) {
+            if (MODE == FUSED_KEEP || MODE == FUSED_READ1) {
                 va[kk] = v;
             } else if (MODE == FUSED_MID) {
                 va[kk] = fuse_op<OP>(0.f + va[kk], v);
@@ -2561,7 +2583,12 @@ __device__ __forceinline__ void fused_consume(acc_t* __restrict__ band, int nx, 
     }
 }
 
-template <int MAPPING, int CELLS>
+// DEFER (round 6, the one-workgroup-per-CU kernel with the packed stream): with two cameras, camera 1's read-back only
+// reads, clears and converts (FUSED_READ1); its fusion op and arg-max update -- ~60 % of that read-back's vector
+// instructions, the IEEE division of the harmonic mean among them -- are run by every wave at the end of its NEXT voting
+// stream, i.e. in the time it would otherwise wait at the phase barrier for the slowest wave (the waves of a phase end
+// up to one pass = 2-4 us apart), while the others still vote.  Same values, same order per cell: same bits.
+template <int MAPPING, int CELLS, bool DEFER = false>
 __device__ __forceinline__ void vote_fuse_argmax_body(const FusedCameras& cams, const Geom& g, const BandPlan& bp, int op,
                                                       const uint32_t* __restrict__ splits,
                                                       unsigned long long* __restrict__ keys,
@@ -2615,7 +2642,21 @@ __device__ __forceinline__ void vote_fuse_argmax_body(const FusedCameras& cams, 
         return o;
     };
     float va[CELLS];
+    float vb[DEFER ? CELLS : 1];  // DEFER: camera 1's values of the pair whose arg-max update is pending
+    int pend_z = -1;              // its plane (wave-uniform); -1: nothing pending
     FusedBest<CELLS> fb;
+    auto run_pending = [&]() {
+        if (!DEFER || pend_z < 0) return;
+        switch (op) {
+        case 1: fused_deferred_argmax<CELLS, 1>(va, vb, fb, pend_z); break;
+        case 2: fused_deferred_argmax<CELLS, 2>(va, vb, fb, pend_z); break;
+        case 3: fused_deferred_argmax<CELLS, 3>(va, vb, fb, pend_z); break;
+        case 4: fused_deferred_argmax<CELLS, 4>(va, vb, fb, pend_z); break;
+        case 5: fused_deferred_argmax<CELLS, 5>(va, vb, fb, pend_z); break;
+        default: fused_deferred_argmax<CELLS, 6>(va, vb, fb, pend_z); break;
+        }
+        pend_z = -1;
+    };
     int cur_j = -1, r0 = 0, r1 = 0, n_own = 0;
     // the cut words of this wave's first pass of phase (pair q, camera c) -- see packed_stream_asm_dealt
     constexpr bool kPrefetchCuts = MAPPING == 1;
@@ -2649,6 +2690,7 @@ __device__ __forceinline__ void vote_fuse_argmax_body(const FusedCameras& cams, 
     for (int q = q_begin; q < q_end; ++q) {
         const int j = q / g.nz, z = q - j * g.nz;
         if (j != cur_j) {
+            run_pending();  // (the last pair of the band that ends here)
             if (cur_j >= 0) emit();
             cur_j = j;
             r0 = j * bp.band_rows;
@@ -2662,8 +2704,10 @@ __device__ __forceinline__ void vote_fuse_argmax_body(const FusedCameras& cams, 
         const int rows_lds = r1 - r0 + 2;
         // events with floor(Y) in [r0 - 1, r1 - 1] (and in [0, ny - 2], cartesian3dgrid.h:255-259)
         const int Li = max(r0 - 1, 0), Ui = min(r1, g.ny - 1);
+        // (the DEFER instantiation is launched for two cameras only: the other camera counts' read-backs are not in it)
+        const int n_cams = DEFER ? 2 : cams.n;
 #pragma nounroll
-        for (int c = 0; c < cams.n; ++c) {
+        for (int c = 0; c < n_cams; ++c) {
             const FusedCamera cam = camera(c);
 #ifdef DSI_TIMING_EXPERIMENTS
             // development aid (experiments flavour only, dsi_test_fused_trace_*): 100 MHz time stamps per (workgroup,
@@ -2683,15 +2727,23 @@ __device__ __forceinline__ void vote_fuse_argmax_body(const FusedCameras& cams, 
             stream_item<BLOCK, MAPPING, true, true>(cam.sxy, cam.coef, cam.cuts, cam.slow_any, cam.np, g, bp, j, z, 0, cam.np,
                                         reinterpret_cast<char*>(band), Li, Ui, r0 - 1, &s_pass, cuts_now);
             // the next phase's first cut words travel during this phase's barrier and read-back
-            if (c + 1 < cams.n)
+            if (c + 1 < n_cams)
                 cuts_next = first_cuts_of(q, c + 1);
             else if (q + 1 < q_end)
                 cuts_next = first_cuts_of(q + 1, 0);
+            run_pending();  // the previous pair's fusion + arg-max update, while the other waves finish their passes
             DSI_FUSED_STAMP(1);
             __syncthreads();
             if (threadIdx.x == 0) s_pass = kPass0;
-            const bool last = c == cams.n - 1;
-            if (!last) {
+            const bool last = c == n_cams - 1;
+            if constexpr (DEFER) {
+                if (!last) {
+                    fused_consume<CELLS, 1, FUSED_KEEP>(band, nx, n_own, rows_lds, va, fb, z);
+                } else {
+                    fused_consume<CELLS, 1, FUSED_READ1>(band, nx, n_own, rows_lds, vb, fb, z);
+                    pend_z = z;
+                }
+            } else if (!last) {
                 if (c == 0) {
                     fused_consume<CELLS, 1, FUSED_KEEP>(band, nx, n_own, rows_lds, va, fb, z);
                 } else {  // camera 1 of 3: only the ops whose third step exists get here (1, 2, 6)
@@ -2724,18 +2776,19 @@ __device__ __forceinline__ void vote_fuse_argmax_body(const FusedCameras& cams, 
             DSI_FUSED_STAMP(3);
         }
     }
+    run_pending();
     emit();
 #undef DSI_FUSED_STAMP
 }
 
 // one workgroup per CU: the band takes (almost) the whole LDS, up to 128 VGPRs
-template <int MAPPING, int CELLS>
+template <int MAPPING, int CELLS, bool DEFER = false>
 __global__ __launch_bounds__(1024) void k_vote_fuse_argmax(FusedCameras cams, Geom g, BandPlan bp, int op,
                                                            const uint32_t* __restrict__ splits,
                                                            unsigned long long* __restrict__ keys,
                                                            unsigned long long* __restrict__ trace)
 {
-    vote_fuse_argmax_body<MAPPING, CELLS>(cams, g, bp, op, splits, keys, trace);
+    vote_fuse_argmax_body<MAPPING, CELLS, DEFER>(cams, g, bp, op, splits, keys, trace);
 }
 
 // TWO workgroups per CU (round 4): bands of at most half the LDS, half the cells per thread, <= 64 VGPRs -- while one
@@ -4622,6 +4675,17 @@ static hipError_t launch_vote_fuse_argmax_t(hipStream_t s, const FusedCameras& c
         }
     }
 one_per_cu:
+    if constexpr (MAPPING == 1) {
+        // two cameras, the packed stream: the instantiation that defers camera 1's fusion + arg-max update into the waits
+        // of the next phase (vote_fuse_argmax_body, DEFER).  bp.experiment 301 (experiments flavour): off, for A/B runs
+        if (cams.n == 2 && bp.experiment != 301) {
+            const void* kern_d = reinterpret_cast<const void*>(&k_vote_fuse_argmax<MAPPING, CELLS, true>);
+            if (hipError_t e = allow_dynamic_lds(kern_d, bp.lds_bytes)) return e;
+            hipLaunchKernelGGL((k_vote_fuse_argmax<MAPPING, CELLS, true>), dim3(blocks), dim3(1024), bp.lds_bytes, s, cams, g, bp, op, splits,
+                               keys, trace);
+            return hipExtGetLastError();
+        }
+    }
     const void* kern = reinterpret_cast<const void*>(&k_vote_fuse_argmax<MAPPING, CELLS>);
     if (hipError_t e = allow_dynamic_lds(kern, bp.lds_bytes)) return e;
     hipLaunchKernelGGL((k_vote_fuse_argmax<MAPPING, CELLS>), dim3(blocks), dim3(1024), bp.lds_bytes, s, cams, g, bp, op, splits, keys, trace);

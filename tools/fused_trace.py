@@ -76,10 +76,19 @@ for w in np.nonzero(wg_valid)[0]:
                    s[:, 3].max() - s[:, 2].max(),         # closing barrier
                    s[:, 3].max() - start))
 ph = np.array(ph)
+par = []          # (phases alternate camera 0 / camera 1 with two cameras: the same table per camera)
+for w in np.nonzero(wg_valid)[0]:
+    for p in range(64):
+        if valid[w, p].all():
+            par.append(p & 1)
+par = np.array(par)
 names = ["start skew", "first wave done", "median wave done", "mean wave done", "last wave done", "barrier+consume", "closing barrier", "phase total"]
 for k, nm in enumerate(names):
     print("%-18s mean %7.2f us   p10 %7.2f   p90 %7.2f" % (nm, ph[:, k].mean(), np.percentile(ph[:, k], 10), np.percentile(ph[:, k], 90)))
 print("phases: %d; sum of phase totals / workgroups = %.1f us" % (len(ph), ph[:, 7].sum() / wg_valid.sum()))
+for c in (0, 1):
+    sel = par == c
+    print("camera %d phases: " % c + ", ".join("%s %.2f" % (nm, ph[sel, k].mean()) for k, nm in enumerate(names)))
 fin = np.where(wg_valid, t[..., 3].max(axis=(1, 2)) - t0, np.nan)
 sta = np.where(wg_valid, np.where(valid, t[..., 0], np.inf).min(axis=(1, 2)) - t0, np.nan)
 for x in range(8):
