@@ -363,8 +363,10 @@ float virtual_focal(float cam_fx, float fov_deg, int dim_x)
 bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
 {
     const dsi::Geom& g = m->geom;
-    const size_t row_bytes = (size_t)g.nx * sizeof(unsigned long long);  // Q33.31 LDS accumulators
-    const int block_threads = m->want_block > 0 ? m->want_block : 1024;
+    // Q33.31 LDS accumulators, one per cell -- or, lane mapping 8 (opt-in, never chosen automatically), rows of paired 32-bit
+    // cells: 2 * ((nx >> 1) + 1) words of 8 bytes
+    const size_t row_bytes = (size_t)(m->want_packed == 8 ? dsi::paired_row_words_host(g.nx) : g.nx) * sizeof(unsigned long long);
+    const int block_threads = m->want_packed == 8 ? 1024 : (m->want_block > 0 ? m->want_block : 1024);
     // Lane mapping and workgroups per CU, by the records of a packet a band sees (its run):
     // rows + 1 of Ny rows see 1024 * (rows + 1) / Ny events of a packet.
     //  * TWO 1024-thread workgroups per CU (32 waves; half the LDS each) with the packed mapping and its
@@ -437,7 +439,7 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
     // 0.232 -> 0.222 ms).  With two per CU the hardware dispatcher already overlaps them and the item
     // loop only adds a barrier and an atomic (346x260x100: 1.175 ms plain, 1.204 ms persistent).
     const bool two_per_cu = bp->lds_bytes * 2 <= dsi::max_dynamic_lds() && bp->block_threads <= 1024;
-    bp->persistent = ((bp->packed == 1 || bp->packed == 3 || bp->packed == 5 || bp->packed == 6 || bp->packed == 7) && !two_per_cu) ? 1 : 0;
+    bp->persistent = ((bp->packed == 1 || bp->packed == 3 || bp->packed == 5 || bp->packed == 6 || bp->packed == 7 || bp->packed == 8) && !two_per_cu) ? 1 : 0;
     bp->experiment = 0;
     bp->pass_lg = (m->want_pass_lg >= 1 && m->want_pass_lg <= 6) ? m->want_pass_lg : 0;  // test hook dsi_test_pass_lg
 #ifdef DSI_TIMING_EXPERIMENTS
@@ -732,6 +734,7 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
     // beyond 2^32 / 12 records (349,525 packets = 358 M events in ONE call) use the compiled loops
     if ((np + 1) * dsi::kPacket * sizeof(dsi::EvRec) > 0xffffffffull) {
         if (bp.packed == 1 || bp.packed == 7) bp.packed = 3;
+        if (bp.packed == 8) return fail(DSI_ERR_INVALID, "lane mapping 8 (paired cells) addresses records with 32 bits: %zu packets are too many", np);
         if (bp.packed == 4) bp.packed = 2;
         if (bp.packed == 5) bp.packed = 6;
     }
@@ -749,7 +752,7 @@ int vote_device(dsi_mapper* m, const float2* xy, const float* centers, size_t np
         return vote_done(m);
     }
     HIP_TRY(m->sxy.reserve(np * dsi::kPacket + 1));  // + the multiplicity-0 dummy record
-    HIP_TRY(m->nvalid.reserve(np + (size_t)geom.nz + 8));  // + one "needs IEEE divide" word per plane + 8 work counters
+    HIP_TRY(m->nvalid.reserve(np + (size_t)geom.nz + 9));  // + one "needs IEEE divide" word per plane + 8 work counters + the paired cells' overflow word
     HIP_TRY(m->rowstart.reserve(np * (size_t)(geom.ny + 2 * bp.row_pad + 3) + 2));  // (+ slack: k_plane_coef copies 32-bit words)
     HIP_TRY(m->coef.reserve(np * geom.nz + 1));       // + the dummy record's "coefficients"
     // Wide grids with many packets (the vector fill): no cut table -- at 1024 x 1024 x 256 with 100 M events it is 6.1 GB per
@@ -1391,8 +1394,21 @@ int dsi_mapper_set_band_params(dsi_mapper_t* m, int band_rows, int chunks, int b
 int dsi_mapper_set_packed_lanes(dsi_mapper_t* m, int mode)
 {
     REQUIRE(m, DSI_ERR_INVALID, "mapper is null");
-    REQUIRE(mode >= -1 && mode <= 7, DSI_ERR_INVALID, "mode must be -1 (auto) or 0..7");
+    REQUIRE(mode >= -1 && mode <= 8, DSI_ERR_INVALID, "mode must be -1 (auto) or 0..8");
     m->want_packed = mode;
+    return DSI_OK;
+}
+
+int dsi_mapper_paired_overflow(dsi_mapper_t* m, int* overflowed)
+{
+    REQUIRE(m && overflowed, DSI_ERR_INVALID, "null argument");
+    *overflowed = 0;
+    if (m->info.algo != DSI_VOTE_LDS_BANDS || m->info.packed != 8 || m->info.n_packets == 0) return DSI_OK;
+    if (int rc = set_device(m->ctx)) return rc;
+    uint32_t word = 0;
+    HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+    HIP_TRY(hipMemcpy(&word, m->nvalid.p + m->info.n_packets + (size_t)m->geom.nz + 8, sizeof word, hipMemcpyDeviceToHost));
+    *overflowed = word != 0u ? 1 : 0;
     return DSI_OK;
 }
 
@@ -1760,7 +1776,7 @@ int dsi_mapper_depth_map_of_events(dsi_mapper_t* out, dsi_mapper_t* const* mappe
         // the per-camera tables of the banded vote, built for bands with halo rows
         HIP_TRY(m->centers.reserve(std::max<size_t>(np, 1) * 3));
         HIP_TRY(m->sxy.reserve(np * dsi::kPacket + 1));
-        HIP_TRY(m->nvalid.reserve(np + (size_t)geom.nz + 8));
+        HIP_TRY(m->nvalid.reserve(np + (size_t)geom.nz + 9));
         HIP_TRY(m->rowstart.reserve(np * (size_t)(geom.ny + 2 * bp.row_pad + 3) + 2));
         HIP_TRY(m->coef.reserve(np * geom.nz + 1));
         HIP_TRY(m->cuts.reserve(std::max<size_t>(np * geom.nz * bp.bands, 64)));

@@ -51,7 +51,8 @@ struct BandPlan {
     int block_threads;  // 256 / 512 / 1024
     int packed;         // lane mapping: 0 k_vote_bands, 1 k_vote_bands_packed (asm), 2 k_vote_groups,
                         // 3 k_vote_bands_packed (compiled loop), 4 k_vote_groups (asm),
-                        // 5 k_vote_bands_packed with the vector fill (wide grids), 6 the same all compiled
+                        // 5 k_vote_bands_packed with the vector fill (wide grids), 6 the same all compiled,
+                        // 7 mapping 1 with dealt passes, 8 mapping 7 on PAIRED 32-bit Q.19 cells (opt-in: not the exact sums)
     int group_packets;  // mapping 2: packets sorted together (power of two <= 32)
     int row_pad;        // z0 rows binned over [-row_pad, ny + row_pad) by k_sort_packets
     int pass_lg;        // packed mappings: log2(packets a wave takes per pass); 0 = automatic
@@ -70,6 +71,9 @@ struct BandPlan {
                         // derives its packets' runs from it and from PlaneCoef::d_a / by_a
     int rs_stride;      // cuts_inline: packets per row of the transposed table (a multiple of 64)
 };
+
+// lane mapping 8: 8-byte words per band row of paired 32-bit cells (dsi_vote_asm.h)
+inline int paired_row_words_host(int nx) { return 2 * ((nx >> 1) + 1); }
 
 // distance in voxels between the partial volumes of consecutive packet chunks: the volume size
 // rounded up to 4 voxels, so that every partial volume starts 16-byte aligned

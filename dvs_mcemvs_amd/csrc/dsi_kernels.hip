@@ -313,8 +313,8 @@ __device__ __forceinline__ void sort_packets_body(const int k, const float2* __r
     // nvalid[np + z]: "plane z has a coefficient set that needs the IEEE divide", set by
     // k_plane_coef (next kernel on the stream), read by the packed voting kernel
     if (k == 0) {
-        // (+ 8 work counters of the persistent voting kernel behind the per-plane flags)
-        for (int i = threadIdx.x; i < nz + 8; i += 256) nvalid[np + i] = 0;
+        // (+ 8 work counters of the persistent voting kernel behind the per-plane flags, + lane mapping 8's overflow word)
+        for (int i = threadIdx.x; i < nz + 9; i += 256) nvalid[np + i] = 0;
         // (+ the records per (band, plane) pair that k_plane_coef counts for the fused kernel's partition)
         if (pair_work)
             for (int i = threadIdx.x; i < n_pairs; i += 256) pair_work[i] = 0;
@@ -774,6 +774,50 @@ __device__ __forceinline__ void vote4(acc_t* __restrict__ band, int idx, int nx,
     __hip_atomic_fetch_add(cell + nx + 1, (acc_t)(unsigned int)(fxs * fy) * m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// ---- lane mapping 8: PAIRED 32-bit cells (dsi_vote_asm.h, DSI_ASM_VOTE_PAIRED19) ----
+constexpr int kPairedFracBits = 19;                       // Q.19 weights, rounded
+constexpr uint32_t kPairedGuard = 0x80000000u;            // a sub-cell at or above this is reported (4,096 full votes)
+__host__ __device__ inline int paired_row_words(int nx) { return 2 * ((nx >> 1) + 1); }  // 8-byte words per band row
+
+__device__ __forceinline__ uint32_t cvt_rpi(float x)  // floor(x + 0.5), the instruction the hand-scheduled vote uses
+{
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return (uint32_t)r;
+}
+
+// the compiled twin of DSI_ASM_VOTE_PAIRED19's tail (the IEEE-divide planes of mapping 8 use it): same operations, same bits
+__device__ __forceinline__ void vote_paired(char* __restrict__ band_bytes, int xi, int yi, int row_bytes, int cbase, float fx,
+                                            float fy, uint32_t m)
+{
+    const float fy1 = 1.f - fy;
+    const float S = 524288.f * (float)m;  // m * 2^19, exact (m <= 1024)
+    const float fxs = S * fx, fx1s = S - fxs;
+    const uint32_t w00 = cvt_rpi(fx1s * fy1), w10 = cvt_rpi(fxs * fy1);
+    const uint32_t w01 = cvt_rpi(fx1s * fy), w11 = cvt_rpi(fxs * fy);
+    acc_t* word = reinterpret_cast<acc_t*>(band_bytes + (__mul24(yi, row_bytes) + (((xi >> 1) << 3) + cbase) + (xi & 1) * (row_bytes >> 1)));
+    __hip_atomic_fetch_add(word, (acc_t)w00 | ((acc_t)w10 << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    acc_t* below = reinterpret_cast<acc_t*>(reinterpret_cast<char*>(word) + row_bytes);
+    __hip_atomic_fetch_add(below, (acc_t)w01 | ((acc_t)w11 << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// the raw sum of cell x of a paired row, as the Q33.31 value the exact mappings hold (so that seam rows, partial volumes
+// and the one rounding to fp32 are theirs); *guard |= a sub-cell reached kPairedGuard
+__device__ __forceinline__ acc_t paired_cell(const uint2* __restrict__ row, int rw, int x, uint32_t* guard)
+{
+    const int k = x >> 1;
+    uint32_t a, b;
+    if (x & 1) {
+        a = row[k].y;        // votes at xi = x - 1 (even): W_k's upper cell
+        b = row[rw + k].x;   // votes at xi = x (odd):      V_k's lower cell
+    } else {
+        a = row[k].x;                            // votes at xi = x (even): W_k's lower cell
+        b = k > 0 ? row[rw + k - 1].y : 0u;      // votes at xi = x - 1 (odd): V_(k-1)'s upper cell
+    }
+    *guard |= (a | b) & kPairedGuard;
+    return ((acc_t)a + (acc_t)b) << (31 - kPairedFracBits);
+}
+
 // owned rows of the band -> fp32 volume (a linear, coalesced copy).  A vote of an event in the band's
 // last owned row also lands in the row below, which is the next band's first row: that "carry" row,
 // and the next band's own sums for its first row (its "head"), leave the CU as the raw 64-bit
@@ -861,6 +905,39 @@ __device__ __forceinline__ void flush_band_and_clear(acc_t* __restrict__ band, i
                                                      size_t off, int raw, acc_t* __restrict__ seam_j, int j, int bands)
 {
     flush_band_t<BLOCK, true>(band, nx, n_out, out, off, raw, seam_j, j, bands);
+}
+
+// flush_band_t for a band of PAIRED cells (lane mapping 8): a cell's two parts are added, scaled to Q33.31 and leave the CU the
+// way the exact sums do.  n_rows owned rows + the carry row; the band is always cleared (persistent or not, it is cheap).
+// overflow: one word, set when a sub-cell reached the guard (2^31: half its capacity) -- the caller re-runs in an exact mode.
+template <int BLOCK>
+__device__ __forceinline__ void flush_band_paired(acc_t* __restrict__ band, int nx, int n_rows, void* __restrict__ out, size_t off,
+                                                  int raw, acc_t* __restrict__ seam_j, int j, int bands,
+                                                  uint32_t* __restrict__ overflow)
+{
+    const int rw = (nx >> 1) + 1;
+    const uint2* __restrict__ words = reinterpret_cast<const uint2*>(band);
+    float* __restrict__ dstf = reinterpret_cast<float*>(out) + off;
+    acc_t* __restrict__ dstr = reinterpret_cast<acc_t*>(out) + off;
+    const int head = j >= 1 ? nx : 0;  // cells that go to the seam buffer instead of the volume
+    const int n_out = n_rows * nx;
+    uint32_t guard = 0u;
+    for (int i = threadIdx.x; i < n_out + nx; i += BLOCK) {  // (the last nx: the carry row)
+        const int r = i / nx, x = i - r * nx;
+        const acc_t v = paired_cell(words + (size_t)r * 2 * rw, rw, x, &guard);
+        if (i >= n_out) {
+            if (j < bands - 1) seam_j[nx + (i - n_out)] = v;
+        } else if (i < head)
+            seam_j[i] = v;
+        else if (raw)
+            dstr[i] = v;
+        else
+            dstf[i] = fix_to_float(v);
+    }
+    if (__builtin_amdgcn_ballot_w64(guard != 0u) != 0ull && (threadIdx.x & 63) == 0) atomicOr(overflow, 1u);
+    __syncthreads();  // every cell has been read
+    const int all_words = (n_rows + 1) * 2 * rw;
+    for (int i = threadIdx.x; i < all_words; i += BLOCK) band[i] = 0;
 }
 
 template <int BLOCK>
@@ -996,14 +1073,14 @@ __device__ __forceinline__ int floor_to_int(float x)
 // floor/fract, three-operand integer ops, compares, v_cndmask, 24-bit and 64-bit multiplies)
 // ~0.95, and v_pk_*_f32 0.95 (no gain over two scalar ops).  The loop below is bound by VALU
 // issue, so it is written to need few instructions of the second kind.
-template <bool SLOW>
+template <bool SLOW, bool PAIRED = false>
 __device__ __forceinline__ void packed_stream(const EvRec* __restrict__ sxy,
                                               const uint4* __restrict__ coef4,
                                               const uint32_t* __restrict__ cutz,
                                               char* __restrict__ band_bytes, int p_first,
                                               int p_end, int lg_group, int stride, int lane,
                                               int nx, int Li, int Ui, int row_base,
-                                              uint32_t dummy_eo)
+                                              uint32_t dummy_eo, int row_bytes = 0)
 {
     // ---- the run stream (all wave-uniform).  The wave owns packets i = 0 .. n_my-1:
     //      packet i is p_first + (i >> lg_group) * stride + (i & (group-1)); it contributes the
@@ -1151,8 +1228,12 @@ __device__ __forceinline__ void packed_stream(const EvRec* __restrict__ sxy,
         if (sgn >= 0) {
             // accepted => X, Y >= 0, where v_fract is exactly X - floor(X)
             const float fx = __builtin_amdgcn_fractf(X), fy = __builtin_amdgcn_fractf(Y);
-            acc_t* cell = reinterpret_cast<acc_t*>(band_bytes + (__mul24(yi, nx8) + ((xi << 3) + cbase)));
-            vote4(cell, 0, nx, fx, fy, __float_as_uint(ev.z));  // cartesian3dgrid.h:261-270
+            if (PAIRED) {  // lane mapping 8: two atomics on paired 32-bit cells
+                vote_paired(band_bytes, xi, yi, row_bytes, -row_base * row_bytes, fx, fy, __float_as_uint(ev.z));
+            } else {
+                acc_t* cell = reinterpret_cast<acc_t*>(band_bytes + (__mul24(yi, nx8) + ((xi << 3) + cbase)));
+                vote4(cell, 0, nx, fx, fy, __float_as_uint(ev.z));  // cartesian3dgrid.h:261-270
+            }
         }
     };
 
@@ -1665,11 +1746,56 @@ __device__ __forceinline__ void packed_stream_asm(const EvRec* sxy, const uint4*
 
 // passes of `1 << lg_group` packets of [p_begin, p_end); wave `wave` of `n_waves`; pass_counter: LDS word set
 // to 2 * n_waves before the workgroup's waves enter
+// (the whole stream as one asm statement; VOTE = DSI_ASM_VOTE or, lane mapping 8, DSI_ASM_VOTE_PAIRED19)
+#define DSI_DEALT_STREAM_ASM(VOTE)                                                                                      \
+    asm volatile(                                                                                                       \
+        "s_mov_b32 s42, 0\n\t"                                                                                          \
+        "s_mov_b32 s54, 0\n\t"                                                                                          \
+        "s_mov_b32 s40, 0\n\t"                                                                                          \
+        "s_mov_b32 s41, 0\n\t"                                                                                          \
+        "s_mov_b32 s43, 0\n\t"                                                                                          \
+        "s_mov_b32 s55, %18\n\t"             /* the first pass: the wave's index ... */                                 \
+        "v_mov_b32 v34, %19\n\t"             /* ... the second: n_waves further */                                      \
+        "v_mov_b32 v40, 0\n\t"                                                                                          \
+        "v_mov_b32 v41, 0\n\t"                                                                                          \
+        "s_mov_b32 s50, 0\n\t"                                                                                          \
+        "v_mov_b32 v35, %20\n\t"             /* the first pass's cut words (already here) */                            \
+        DSI_ASM_FILL_DEAL("s47", "a")                                                                                   \
+        DSI_ASM_GATHER("v[42:44]", "v[46:49]", "v45")                                                                   \
+        "s_cmp_eq_u32 s47, 0\n\t"                                                                                       \
+        "s_cbranch_scc1 Lend%=\n"                                                                                       \
+        "Lloop%=:\n\t"                                                                                                  \
+        DSI_ASM_FILL_DEAL("s48", "b")                                                                                   \
+        DSI_ASM_GATHER("v[50:52]", "v[54:57]", "v53")                                                                   \
+        "s_waitcnt vmcnt(3)\n\t"                                                                                        \
+        VOTE("v42", "v43", "v44", "v46", "v47", "v48", "v49", "v45")                                                    \
+        "s_cmp_eq_u32 s48, 0\n\t"                                                                                       \
+        "s_cbranch_scc1 Lend%=\n\t"                                                                                     \
+        DSI_ASM_FILL_DEAL("s47", "c")                                                                                   \
+        DSI_ASM_GATHER("v[42:44]", "v[46:49]", "v45")                                                                   \
+        "s_waitcnt vmcnt(3)\n\t"                                                                                        \
+        VOTE("v50", "v51", "v52", "v54", "v55", "v56", "v57", "v53")                                                    \
+        "s_cmp_lg_u32 s47, 0\n\t"                                                                                       \
+        "s_cbranch_scc1 Lloop%=\n"                                                                                      \
+        "Lend%=:\n\t"                                                                                                   \
+        "s_waitcnt vmcnt(0) lgkmcnt(0)"                                                                                 \
+        :                                                                                                               \
+        : "s"(sxy), "s"(coef4), "s"(cutz), "s"(s_npass), "s"(s_group), "s"(s_p_begin), "s"(s_p_end),                    \
+          "s"(s_lg), "s"(s_p_last), "s"(s_nx8), "s"(s_cbase), "s"(s_nxm2), "s"(s_Li), "s"(s_Uim1),                      \
+          "s"(s_dummy), "v"(lane), "v"(ctr_addr), "v"(1), "s"(s_first), "v"(wave + n_waves), "v"(first_cuts), "s"(s_halfb) \
+        : "memory", "scc", "vcc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s50", "s53", "s54", "s55", \
+          "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48",     \
+          "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61",                   \
+          "v62", "v63")
+
+// PAIRED (lane mapping 8): the band's rows are rows of paired 32-bit cells (dsi_vote_asm.h), row_bytes = 16 * rw apart
+template <bool PAIRED = false>
 __device__ __forceinline__ void packed_stream_asm_dealt(const EvRec* sxy, const uint4* coef4,
                                                         const uint32_t* cutz, char* band_bytes,
                                                         int p_begin, int p_end, int lg_group, int wave, int n_waves,
                                                         int lane, int nx, int Li, int Ui, int row_base,
-                                                        uint32_t dummy_eo, int* pass_counter, uint32_t first_cuts)
+                                                        uint32_t dummy_eo, int* pass_counter, uint32_t first_cuts,
+                                                        int row_bytes = 0)
 {
     // first_cuts: the cut words of the wave's first pass, lane l = packet p_begin + wave * group + l (clamped to
     // p_end - 1), loaded by the caller -- in the fused kernel BEFORE the previous phase's barrier and read-back,
@@ -1677,60 +1803,27 @@ __device__ __forceinline__ void packed_stream_asm_dealt(const EvRec* sxy, const 
     const int group = 1 << lg_group;
     int npass = (p_end - p_begin + group - 1) >> lg_group;
     if (Ui - 1 < Li) npass = 0;  // no acceptable row (the unsigned range test needs Ui-1-Li >= 0)
+    if (!PAIRED) row_bytes = nx * 8;
     const int s_npass = __builtin_amdgcn_readfirstlane(npass);
     const int s_group = __builtin_amdgcn_readfirstlane(group);
     const int s_p_begin = __builtin_amdgcn_readfirstlane(p_begin);
     const int s_p_end = __builtin_amdgcn_readfirstlane(p_end);
     const int s_lg = __builtin_amdgcn_readfirstlane(lg_group);
     const int s_p_last = __builtin_amdgcn_readfirstlane(p_end - 1);
-    const int s_nx8 = __builtin_amdgcn_readfirstlane(nx * 8);
+    const int s_nx8 = __builtin_amdgcn_readfirstlane(row_bytes);
     const int lds_base = (int)(uintptr_t)band_bytes;  // LDS byte offset of the band
-    const int s_cbase = __builtin_amdgcn_readfirstlane(lds_base - row_base * nx * 8);
+    const int s_cbase = __builtin_amdgcn_readfirstlane(lds_base - row_base * row_bytes);
     const int s_nxm2 = __builtin_amdgcn_readfirstlane(nx - 2);
     const int s_Li = __builtin_amdgcn_readfirstlane(Li);
     const int s_Uim1 = __builtin_amdgcn_readfirstlane(Ui - 1 - Li);
     const uint32_t s_dummy = __builtin_amdgcn_readfirstlane(dummy_eo);
     const int ctr_addr = (int)(uintptr_t)pass_counter;
     const int s_first = __builtin_amdgcn_readfirstlane(wave);
-    asm volatile(
-        "s_mov_b32 s42, 0\n\t"
-        "s_mov_b32 s54, 0\n\t"
-        "s_mov_b32 s40, 0\n\t"
-        "s_mov_b32 s41, 0\n\t"
-        "s_mov_b32 s43, 0\n\t"
-        "s_mov_b32 s55, %18\n\t"             // the first pass: the wave's index ...
-        "v_mov_b32 v34, %19\n\t"             // ... the second: n_waves further
-        "v_mov_b32 v40, 0\n\t"
-        "v_mov_b32 v41, 0\n\t"
-        "s_mov_b32 s50, 0\n\t"
-        "v_mov_b32 v35, %20\n\t"             // the first pass's cut words (already here)
-        DSI_ASM_FILL_DEAL("s47", "a")
-        DSI_ASM_GATHER("v[42:44]", "v[46:49]", "v45")
-        "s_cmp_eq_u32 s47, 0\n\t"
-        "s_cbranch_scc1 Lend%=\n"
-        "Lloop%=:\n\t"
-        DSI_ASM_FILL_DEAL("s48", "b")
-        DSI_ASM_GATHER("v[50:52]", "v[54:57]", "v53")
-        "s_waitcnt vmcnt(3)\n\t"
-        DSI_ASM_VOTE("v42", "v43", "v44", "v46", "v47", "v48", "v49", "v45")
-        "s_cmp_eq_u32 s48, 0\n\t"
-        "s_cbranch_scc1 Lend%=\n\t"
-        DSI_ASM_FILL_DEAL("s47", "c")
-        DSI_ASM_GATHER("v[42:44]", "v[46:49]", "v45")
-        "s_waitcnt vmcnt(3)\n\t"
-        DSI_ASM_VOTE("v50", "v51", "v52", "v54", "v55", "v56", "v57", "v53")
-        "s_cmp_lg_u32 s47, 0\n\t"
-        "s_cbranch_scc1 Lloop%=\n"
-        "Lend%=:\n\t"
-        "s_waitcnt vmcnt(0) lgkmcnt(0)"
-        :
-        : "s"(sxy), "s"(coef4), "s"(cutz), "s"(s_npass), "s"(s_group), "s"(s_p_begin), "s"(s_p_end),
-          "s"(s_lg), "s"(s_p_last), "s"(s_nx8), "s"(s_cbase), "s"(s_nxm2), "s"(s_Li), "s"(s_Uim1),
-          "s"(s_dummy), "v"(lane), "v"(ctr_addr), "v"(1), "s"(s_first), "v"(wave + n_waves), "v"(first_cuts)
-        : "memory", "scc", "vcc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s50", "s53", "s54", "s55",
-          "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48",
-          "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61",
-          "v62", "v63");
+    const int s_halfb = __builtin_amdgcn_readfirstlane(row_bytes >> 1);  // (PAIRED: byte offset of a row's V words)
+    if constexpr (PAIRED)
+        DSI_DEALT_STREAM_ASM(DSI_ASM_VOTE_PAIRED19);
+    else
+        DSI_DEALT_STREAM_ASM(DSI_ASM_VOTE);
 }
 
 // ---- lane mapping 5, hand-scheduled: the batches of one range (<= 64 batches = 4096 slots) of a
@@ -2302,11 +2395,19 @@ __device__ __forceinline__ void stream_item(const EvRec* __restrict__ sxy, const
     } else {
         // MAPPING 3 is the compiled stream on the fast path too (A/B testing)
         if (slow_any[z] != 0)
-            packed_stream<true>(sxy, coef4, cutz, band_bytes, p_begin + wave * group, p_end, lg_group,
-                                kWaves * group, lane, nx, Li, Ui, row_base, dummy_eo);
+            packed_stream<true, MAPPING == 8>(sxy, coef4, cutz, band_bytes, p_begin + wave * group, p_end, lg_group,
+                                              kWaves * group, lane, nx, Li, Ui, row_base, dummy_eo, paired_row_words(nx) * 8);
         else if constexpr (MAPPING == 3)
             packed_stream<false>(sxy, coef4, cutz, band_bytes, p_begin + wave * group, p_end, lg_group,
                                  kWaves * group, lane, nx, Li, Ui, row_base, dummy_eo);
+        else if constexpr (MAPPING == 8) {  // mapping 7's stream on paired 32-bit cells (opt-in, NOT the exact sums)
+            int lg = (p_end - p_begin) >= kWaves * 16 ? 3 : 2;
+            while (lg < 5 && (p_end - p_begin) >= ((kWaves * 16) << (lg + 1))) ++lg;
+            if (bp.pass_lg > 0) lg = bp.pass_lg;
+            first_cuts = p_end > p_begin ? cutz[min(p_begin + (wave << lg) + lane, p_end - 1)] : 0u;
+            packed_stream_asm_dealt<true>(sxy, coef4, cutz, band_bytes, p_begin, p_end, lg, wave, kWaves, lane, nx, Li, Ui, row_base,
+                                          dummy_eo, s_pass, first_cuts, paired_row_words(nx) * 8);
+        }
         else if constexpr (DEAL || MAPPING == 7) {
             // (*s_pass = 2 * kWaves, set by the item's set-up.)  Packets per pass: enough passes per wave for the dealing
             // to balance the waves (>= ~16), few enough switches (each costs a wait for the wave's outstanding LDS
@@ -2358,8 +2459,10 @@ __device__ __forceinline__ void vote_bands_packed_body(const EvRec* __restrict__
     // counter per class, so the load stays balanced like the hardware's own dispatch.
     const int cls = blockIdx.x & 7;
     __shared__ int s_next;  // persistent: the item AFTER the current one, drawn while the current one is voted
+    constexpr bool kPaired = MAPPING == 8;
+    const int row_words = kPaired ? paired_row_words(nx) : nx;  // 8-byte words per band row
     if (work_counters) {
-        const int all_cells = (bp.band_rows + 1) * nx;
+        const int all_cells = (bp.band_rows + 1) * row_words;
         for (int i = threadIdx.x; i < all_cells; i += BLOCK) band[i] = 0;
         if (threadIdx.x == 0) {
             s_item = (int)atomicAdd(&work_counters[cls], 1u) * 8 + cls;
@@ -2386,7 +2489,7 @@ __device__ __forceinline__ void vote_bands_packed_body(const EvRec* __restrict__
     const int c = q / bp.bands, j = q % bp.bands;
     const int r0 = j * bp.band_rows;
     const int r1 = min(g.ny, r0 + bp.band_rows);
-    const int cells = (r1 - r0 + 1) * nx;  // owned rows + the carry row
+    const int cells = (r1 - r0 + 1) * row_words;  // owned rows + the carry row
     if (!work_counters) {
         for (int i = threadIdx.x; i < cells; i += BLOCK) band[i] = 0;
         if (threadIdx.x == 0) s_pass = 2 * (BLOCK / kWave);
@@ -2402,12 +2505,19 @@ __device__ __forceinline__ void vote_bands_packed_body(const EvRec* __restrict__
 
     const size_t vol = partial_stride((size_t)g.nx * g.ny * g.nz);
     const size_t off = (size_t)c * vol + ((size_t)z * g.ny + r0) * nx;
+    if constexpr (kPaired) {
+        // (the overflow word sits behind the per-plane flags and the 8 work counters: zeroed by the sort kernel)
+        flush_band_paired<BLOCK>(band, nx, r1 - r0, out, off, bp.raw_out, seam_rows(seam, c, z, j, g, bp), j, bp.bands,
+                                 const_cast<uint32_t*>(slow_any) + g.nz + 8);
+        if (!work_counters) break;
+    } else {
     if (!work_counters) {
         flush_band<BLOCK>(band, nx, (r1 - r0) * nx, out, off, bp.raw_out, seam_rows(seam, c, z, j, g, bp), j, bp.bands);
         break;
     }
     if (bp.experiment != 2)  // (2: timing experiment without the flush)
         flush_band_and_clear<BLOCK>(band, nx, (r1 - r0) * nx, out, off, bp.raw_out, seam_rows(seam, c, z, j, g, bp), j, bp.bands);
+    }
     if (threadIdx.x == 0) {  // (every thread read s_item before the stream's barrier; s_pass is idle between the barriers)
         s_item = s_next;
         s_pass = 2 * (BLOCK / kWave);
@@ -4578,6 +4688,9 @@ static hipError_t launch_vote_bands_b(hipStream_t s, const EvRec* sxy, const Pla
     case 5: return launch_vote_bands_t<BLOCK, 5>(s, sxy, coef, cuts, slow_any, np, g, bp, out, seam);
     case 6: return launch_vote_bands_t<BLOCK, 6>(s, sxy, coef, cuts, slow_any, np, g, bp, out, seam);
     case 7: return launch_vote_bands_t<BLOCK, 7>(s, sxy, coef, cuts, slow_any, np, g, bp, out, seam);
+    case 8:
+        if constexpr (BLOCK == 1024) return launch_vote_bands_t<BLOCK, 8>(s, sxy, coef, cuts, slow_any, np, g, bp, out, seam);
+        return hipErrorInvalidValue;  // (the paired cells exist for 1024-thread workgroups only)
     default: return hipErrorInvalidValue;
     }
 }

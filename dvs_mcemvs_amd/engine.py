@@ -149,6 +149,7 @@ def load_library():
         "dsi_mapper_set_band_params": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
         "dsi_mapper_set_packed_lanes": (C.c_int, [vp, C.c_int]),
         "dsi_mapper_set_inline_cuts": (C.c_int, [vp, C.c_longlong]),
+        "dsi_mapper_paired_overflow": (C.c_int, [vp, C.POINTER(C.c_int)]),
         "dsi_mapper_fill_voxel_grid": (C.c_int, [vp, f32p, f32p, C.c_size_t]),
         "dsi_batch_create": (C.c_int, [vp, u16p, u16p, C.c_size_t, u32p, f32p, C.c_size_t,
                                        C.POINTER(vp)]),
@@ -791,6 +792,13 @@ class MapperEMVS:
 
     def set_packed_lanes(self, mode=-1):
         _check(load_library().dsi_mapper_set_packed_lanes(self._h, int(mode)))
+
+    def paired_overflow(self):
+        """Lane mapping 8 (paired 32-bit cells): did a cell of the last vote reach half its capacity?  (Then vote again
+        with an exact mapping.)"""
+        flag = C.c_int(0)
+        _check(load_library().dsi_mapper_paired_overflow(self._h, C.byref(flag)))
+        return bool(flag.value)
 
     def set_inline_cuts(self, min_packets=-1):
         """Lane mappings 5 / 6: from how many packets per call on the voting kernel derives the packets' runs itself

@@ -273,8 +273,19 @@ DSI_API int dsi_mapper_set_band_params(dsi_mapper_t *m, int band_rows, int chunk
  *     bookkeeping (short runs: wide grids), hand-scheduled batches,
  * 6 = mapping 5 all compiled, for A/B tests,
  * 7 = mapping 1 with DEALT passes: the waves of a workgroup draw their passes from a counter instead of taking
- *     every 16th one (the automatic choice wherever mapping 1 used to be chosen). */
+ *     every 16th one (the automatic choice wherever mapping 1 used to be chosen),
+ * 8 = OPT-IN, never chosen automatically: mapping 7 on PAIRED 32-bit cells -- one 64-bit LDS atomic updates the two cells
+ *     (x, x + 1) of a row, a vote is two atomics instead of four (the voting kernels are bound by the LDS atomic unit).
+ *     The price is the numerical contract: the weights of cartesian3dgrid.h:261-270 are added as ROUNDED Q.19 integers
+ *     (error <= 2^-20 per vote, about that of the reference's own fp32 "+=") instead of the exact Q33.31 sums every other
+ *     mapping keeps, the DSI is no longer bit-identical to theirs, and a 32-bit cell holds 8,192 full votes per work
+ *     item: the voting kernel reports any cell that reached HALF of that (dsi_mapper_paired_overflow), in which case the
+ *     caller repeats the call with another mapping.  1024-thread workgroups, the evaluate / fillVoxelGrid path only. */
 DSI_API int dsi_mapper_set_packed_lanes(dsi_mapper_t *m, int mode);
+/* lane mapping 8: *overflowed <- 1 if a paired cell of the last vote reached 2^31 (4,096 full votes: half its capacity;
+ * beyond 8,192 a cell wraps, so a set flag means "the DSI may be wrong, vote again with an exact mapping").  0 for every
+ * other mapping.  Synchronises. */
+DSI_API int dsi_mapper_paired_overflow(dsi_mapper_t *m, int *overflowed);
 /* Lane mappings 5 / 6 (wide grids) read, per (band, plane, packet), the run of the packet's records the band must look
  * at.  As a table that is bands x planes x packets words -- 6.1 GB per camera at 1024 x 1024 x 256 with 100 M events, 3.9 ms to
  * write -- so from min_packets packets per call on the voting kernel derives the runs itself, per pass, from the

@@ -804,6 +804,104 @@ def test_both_lane_mappings_match_oracle(ctx, shape, band, packed):
     m.close()
 
 
+@pytest.mark.parametrize("shape,band", [((64, 48, 16), None), ((346, 260, 12), (26, 4, 1024)), ((346, 260, 12), None),
+                                        ((131, 97, 7), (5, 3, 1024)), ((70, 48, 9), (48, 2, 1024)), ((41, 30, 6), (9, 1, 1024))])
+def test_paired_cells_mapping_matches_oracle(ctx, shape, band):
+    """Lane mapping 8 (round 6, opt-in): two LDS atomics per vote on paired 32-bit cells, ROUNDED Q.19 weights instead of the
+    exact Q33.31 sums -- NOT bit-identical to the other mappings, but inside the tolerance every DSI is held to
+    (|gpu - cpu| <= 1e-4 max(1, |cpu|), cartesian3dgrid.h:261-270 summed in fp32 by the reference), odd and even widths,
+    several chunks (raw partial volumes), dead packets, one-row packets, d = 0 and IEEE-divide planes; no cell near its
+    capacity."""
+    nx, ny, nz = shape
+    rng = np.random.default_rng(300 + nx)
+    cam = (nx, ny, 0.8 * nx, 0.8 * nx, 0.5 * nx, 0.5 * ny)
+    m = make_mapper(ctx, cam, nz, 1.0, 6.5, d.VOTE_LDS_BANDS, band=band, packed=8)
+    xy, centers = random_packets(rng, 70, nx, ny)
+    xy[5 * 1024:6 * 1024] = np.nan
+    xy[7 * 1024:8 * 1024, 1] = 3.25
+    centers[9] = (0.1, 0.1, m.raw_depths_vec_[0])
+    centers[11] = (0.0, 0.0, 1e30)
+    ref = orc.fill_voxel_grid(xy, centers, m.raw_depths_vec_, np.array(m.virtual_cam_, np.float32), nx, ny)
+    m.fillVoxelGrid(xy, centers)
+    assert m.last_vote_info()["packed"] == 8
+    got = m.dsi_.download()
+    assert_dsi_close(got, ref)
+    assert not m.paired_overflow()
+    # against the exact mapping: the difference is the weights' rounding, <= 2^-20 per vote (votes <= value / smallest weight...)
+    m7 = make_mapper(ctx, cam, nz, 1.0, 6.5, d.VOTE_LDS_BANDS, band=band, packed=7)
+    m7.fillVoxelGrid(xy, centers)
+    exact = m7.dsi_.download()
+    assert np.abs(got.astype(np.float64) - exact).max() <= 2.0 ** -20 * 70 * 1024   # (a loose, rigorous bound)
+    assert np.abs(got.astype(np.float64) - exact).max() <= 1e-4
+    # the second call accumulates (fillVoxelGrid adds to the grid: raw partial volumes): still inside the tolerance
+    m.fillVoxelGrid(xy, centers)
+    assert_dsi_close(m.dsi_.download(), 2.0 * ref.astype(np.float64))
+    m.close()
+    m7.close()
+
+
+def test_paired_cells_report_a_cell_at_half_capacity(ctx):
+    """Identity pose, every event on the integer location (2, 3): all votes are one full weight on ONE paired cell.  3,072
+    of them are summed exactly; 5,120 exceed 2^31 in Q.19 (half the cell's capacity): dsi_mapper_paired_overflow says so."""
+    nx, ny, nz = 32, 24, 5
+    for n_packets, expect in ((3, False), (5, True)):
+        # (ONE packet chunk: a cell's capacity is per work item, and small grids are cut into as many chunks as packets)
+        m = make_mapper(ctx, (nx, ny, 25.0, 25.0, 16.0, 12.0), nz, 1.0, 3.0, d.VOTE_LDS_BANDS, band=(0, 1, 1024), packed=8)
+        xy = np.zeros((n_packets * 1024, 2), np.float32)
+        xy[:] = (2.0, 3.0)
+        m.fillVoxelGrid(xy, np.zeros((n_packets, 3), np.float32))
+        assert m.paired_overflow() is expect
+        if not expect:
+            got = m.dsi_.download()
+            # (X, Y are the integers only up to the transfer's fp32 rounding on some planes: a weight of 1 - 2^-22)
+            assert np.allclose(got[:, 3, 2], 1024.0 * n_packets, rtol=1e-6) and got.sum() == pytest.approx(1024.0 * n_packets * nz, rel=1e-6)
+        m.close()
+    # an exact mapping never reports
+    m = make_mapper(ctx, (nx, ny, 25.0, 25.0, 16.0, 12.0), nz, 1.0, 3.0, d.VOTE_LDS_BANDS, packed=7)
+    m.fillVoxelGrid(xy, np.zeros((5, 3), np.float32))
+    assert not m.paired_overflow() and np.allclose(m.dsi_.download()[:, 3, 2], 5120.0, rtol=1e-6)
+    m.close()
+
+
+def test_paired_cells_at_configs1_full_size(ctx):
+    """BASELINE configs[1] with the opt-in paired cells: every voxel of both camera DSIs within 1e-4 of
+    the CPU oracle, no cell at half capacity, the HM-fused volume within 3e-4, and -- with the exact tie resolver, which
+    re-sums the contending voxels in the reference's order whatever built the DSIs -- the oracle's index map on every pixel."""
+    rig = syn.stereo_rig(10_000_000, seed=1234)
+    cam = rig["cam"]
+    gpu, cpu, batches = [], [], []
+    for c in range(2):
+        m = make_mapper(ctx, cam, 100, 4.0, 200.0, d.VOTE_LDS_BANDS, packed=8)
+        first, Rt = d.packetize(rig["events"][c][2], rig["trajectories"][c], rig["T_rv_w"])
+        b = d.EventBatch(ctx, rig["events"][c][0], rig["events"][c][1], Rt, first)
+        m.evaluateDSI_batch(b)
+        assert m.last_vote_info()["packed"] == 8 and not m.paired_overflow()
+        r = OracleMapper(cam, dimZ=100, min_depth=4.0, max_depth=200.0)
+        assert r.evaluateDSI(rig["events"][c], rig["trajectories"][c], rig["T_rv_w"])
+        got = m.dsi_.download()
+        assert_dsi_close(got, r.dsi)
+        err = np.abs(got.astype(np.float64) - r.dsi) / np.maximum(1.0, np.abs(r.dsi))
+        print("paired cells, camera %d: max rel err %.3g, busiest voxel %.1f" % (c, err.max(), r.dsi.max()))
+        gpu.append(m)
+        cpu.append(r)
+        batches.append(b)
+    fused = d.Grid3D(ctx, 346, 260, 100)
+    fused.setToFusionOf(gpu[0].dsi_, gpu[1].dsi_, d.FUSE_HM)
+    ref = orc.fuse2(cpu[0].dsi.copy(), cpu[1].dsi, 2)
+    assert_dsi_close(fused.download(), ref, tol=3 * DSI_TOL)
+    gpu[0].computeDepthMap(fused)
+    idx = gpu[0].fetchDepthMap()[2]
+    rep = argmax_report(idx, ref, 3 * DSI_TOL)
+    assert rep["violations"] == 0, rep
+    res = gpu[0].resolveNearTies(gpu, batches, d.FUSE_HM)
+    idx = gpu[0].fetchDepthMap()[2]
+    print("paired cells + resolver: %r; without: %r" % (res, rep))
+    assert res["premise_ok"]
+    assert np.array_equal(idx, ref.argmax(axis=0))
+    for o in gpu + batches + [fused]:
+        o.close()
+
+
 @pytest.mark.parametrize("packed", [5, 6])
 @pytest.mark.parametrize("n_packets", [1, 70, 700, 2500])
 def test_inline_cuts_equal_the_cut_table_bit_for_bit(ctx, packed, n_packets):
