@@ -763,8 +763,15 @@ def main():
         shape = d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0)
         begin, count = dd.plane_ranges(nz, world)[rank]
         mappers, batches, voted = [], [], 0
+        # --fused-vote: the four cameras through ONE kernel that votes, fuses (GM tree) and keeps the running arg-max: no DSI
+        # is written (dsi_mapper_depth_map_of_events_n; one GPU, the tree form, one context)
+        # Default: on up to 4 M events per camera (4 x 2 M: 6.04 vs 6.24 ms per step), off beyond -- the DSI-less kernel votes the two
+        # seam rows of every band twice (14-row bands at 1024 wide: +14 % votes), which at 100 M events per camera costs far more
+        # than the 4 GiB of DSI traffic it saves
+        want_fused4 = args.fused_vote if args.fused_vote is not None else args.events <= 4_000_000
+        fused4 = bool(want_fused4) and world == 1 and args.gm == "tree" and not args.materialize_fused and args.algo in (0, 2)
         # cameras dealt over one or two contexts of this GPU (the arg-max / fusion waits for both and releases them)
-        cam_ctxs = [ctx] + [d.Context(D.local_rank) for _ in range(max(0, min(4, args.camera_streams) - 1))]
+        cam_ctxs = [ctx] + [d.Context(D.local_rank) for _ in range(0 if fused4 else max(0, min(4, args.camera_streams) - 1))]
         for c in range(4):
             cc = cam_ctxs[c % len(cam_ctxs)]
             m = tune(d.MapperEMVS(cc, rig["cam"], shape, plane_range=(begin, count)))
@@ -790,7 +797,17 @@ def main():
         closers += mappers + batches + [fused] + cam_ctxs[1:]
         gm_mode = d.ACC_GM_TREE if args.gm == "tree" else d.ACC_LOG_SUM
 
+        if fused4:
+            out_mapper = tune(d.MapperEMVS(ctx, rig["cam"], shape))
+            closers.append(out_mapper)
+            vote_mappers = [out_mapper]           # (the fused kernel reads its knobs and its timer from the OUTPUT mapper)
+            extra["fused_vote"] = True
+            extra["last_mappers"], extra["last_window"] = mappers, batches
+
         def step():
+            if fused4:
+                out_mapper.computeDepthMapOfEventsN(mappers, batches)
+                return
             for c in range(4):
                 mappers[c].evaluateDSI_batch(batches[c])
             if comm is None and not args.materialize_fused:
@@ -811,7 +828,7 @@ def main():
             for cc in cam_ctxs:
                 cc.synchronize()
 
-        if len(cam_ctxs) > 1:
+        if len(cam_ctxs) > 1 and not fused4:
             # an event pair around a kernel also times its wait for the other stream's workgroups to leave the CUs: the
             # dominant kernel's duration is measured on un-overlapped steps after the timed region (like the windows)
             extra["concurrent"] = True
@@ -828,11 +845,13 @@ def main():
         workload = ("4-camera synthetic rig, %d events/cam, %dx%dx%d DSI, n-ary geometric-mean camera fusion (%s) + arg-max%s"
                     % (args.events, nx, ny, nz,
                        "tree of the reference's 2-ary sqrt(a*b)" if args.gm == "tree" else "exp(mean(log))",
-                       (" (fused DSI written)" if args.materialize_fused else " in one kernel (fused DSI not written)")
+                       (" (fused DSI written)" if args.materialize_fused else
+                        " -- ONE kernel votes the four cameras band by band in LDS, fuses them and keeps the running arg-max: no DSI "
+                        "is written" if fused4 else " in one kernel (fused DSI not written)")
                        if world == 1 else ", planes sharded over %d GPUs" % world) +
                     ("; cameras dealt over %d streams" % len(cam_ctxs) if len(cam_ctxs) > 1 else ""))
         parallelism, scaling = ("1 GPU" if world == 1 else "plane-shard x%d" % world), "strong"
-        ev_per_launch = voted / 4.0
+        ev_per_launch = voted if fused4 else voted / 4.0
     t_gen = time.time() - t_gen
 
     def barrier():

@@ -500,7 +500,7 @@ bool plan_bands(const dsi_mapper* m, size_t n_packets, dsi::BandPlan* bp)
 // Band decomposition of the fused vote -> camera fusion -> arg-max kernel (k_vote_fuse_argmax): one
 // 1024-thread workgroup per CU, the band as tall as the LDS (and the per-thread register arrays) allow,
 // a halo row on either side of the owned rows instead of a carry row, one chunk.
-bool plan_fused(const dsi_mapper* m, size_t n_packets_max, dsi::BandPlan* bp)
+bool plan_fused(const dsi_mapper* m, size_t n_packets_max, dsi::BandPlan* bp, int n_cameras = 2)
 {
     const dsi::Geom& g = m->geom;
     const size_t row_bytes = (size_t)g.nx * sizeof(unsigned long long);
@@ -508,14 +508,14 @@ bool plan_fused(const dsi_mapper* m, size_t n_packets_max, dsi::BandPlan* bp)
     int packed = m->want_packed;
     if (!(packed == 1 || packed == 3 || packed == 5 || packed == 6)) {
         // the rule of plan_bands for one workgroup per CU: vector fill below ~72 records per (packet, band)
-        const long rows_full = (long)std::min(dsi::max_dynamic_lds() / row_bytes, dsi::fused_max_cells(1) / (size_t)g.nx);
+        const long rows_full = (long)std::min(dsi::max_dynamic_lds() / row_bytes, dsi::fused_max_cells(1, n_cameras) / (size_t)g.nx);
         packed = 1024L * rows_full / g.ny < 72 ? 5 : 1;
     }
     // the hand-scheduled loops address records with 32-bit byte offsets (see vote_device)
     if ((n_packets_max + 1) * dsi::kPacket * sizeof(dsi::EvRec) > 0xffffffffull) packed = packed == 1 ? 3 : (packed == 5 ? 6 : packed);
     const size_t scratch_bytes = (packed == 5 || packed == 6) ? (size_t)(1024 / 64) * dsi::kVfillScratchWords * 8 : 0;
     const long max_rows_total =
-        (long)std::min((dsi::max_dynamic_lds() - scratch_bytes) / row_bytes, dsi::fused_max_cells(packed) / (size_t)g.nx);
+        (long)std::min((dsi::max_dynamic_lds() - scratch_bytes) / row_bytes, dsi::fused_max_cells(packed, n_cameras) / (size_t)g.nx);
     if (max_rows_total < 3) return false;
     long max_owned = max_rows_total - 2;  // + the two halo rows
     if (m->want_band_rows > 0) max_owned = std::min<long>(max_owned, m->want_band_rows);
@@ -1736,12 +1736,31 @@ int dsi_mapper_depth_map_of_fusion_n(dsi_mapper_t* m, const dsi_grid_t* const* s
     return depth_buffers_ready(m);
 }
 
+static int depth_map_of_events_impl(dsi_mapper_t* out, dsi_mapper_t* const* mappers, const dsi_batch_t* const* batches, int n,
+                                    int op, bool gm_tree4);
+
 int dsi_mapper_depth_map_of_events(dsi_mapper_t* out, dsi_mapper_t* const* mappers, const dsi_batch_t* const* batches, int n,
                                    int op)
 {
     REQUIRE(out && mappers && batches, DSI_ERR_INVALID, "null argument");
-    REQUIRE(n >= 1 && n <= dsi::kFusedMaxCameras, DSI_ERR_INVALID, "1, 2 or 3 cameras (got %d)", n);
+    REQUIRE(n >= 1 && n <= 3, DSI_ERR_INVALID, "1, 2 or 3 cameras (got %d)", n);
     REQUIRE(n == 1 || (op >= 1 && op <= 6), DSI_ERR_BAD_OP, "improper fusion method %d (expected 1..6)", op);
+    return depth_map_of_events_impl(out, mappers, batches, n, op, false);
+}
+
+int dsi_mapper_depth_map_of_events_n(dsi_mapper_t* out, dsi_mapper_t* const* mappers, const dsi_batch_t* const* batches, int n,
+                                     int mode)
+{
+    REQUIRE(out && mappers && batches, DSI_ERR_INVALID, "null argument");
+    REQUIRE(mode == DSI_ACC_GM_TREE, DSI_ERR_BAD_OP, "the DSI-less n-camera path fuses by the geometric-mean tree (DSI_ACC_GM_TREE); got mode %d", mode);
+    REQUIRE(n == 2 || n == 4, DSI_ERR_INVALID, "the geometric-mean tree takes 2 or 4 cameras here (got %d)", n);
+    // (two cameras: the tree IS the reference's 2-ary op, cartesian3dgrid.h:150-156)
+    return depth_map_of_events_impl(out, mappers, batches, n, DSI_FUSE_GM, n == 4);
+}
+
+static int depth_map_of_events_impl(dsi_mapper_t* out, dsi_mapper_t* const* mappers, const dsi_batch_t* const* batches, int n,
+                                    int op, bool gm_tree4)
+{
     dsi_context* ctx = out->ctx;
     size_t np_max = 0;
     for (int i = 0; i < n; ++i) {
@@ -1754,14 +1773,14 @@ int dsi_mapper_depth_map_of_events(dsi_mapper_t* out, dsi_mapper_t* const* mappe
     }
     // process1.cpp:169-191: the third camera enters only through min (1), harmonicMeanTwoGrids(g, 3) (2) and max (6);
     // "case 3: break; case 4: break; case 5: break;" -- its DSI is built and then ignored, so it is not built here
-    if (n == 3 && (op == 3 || op == 4 || op == 5)) n = 2;
+    if (n == 3 && !gm_tree4 && (op == 3 || op == 4 || op == 5)) n = 2;
     for (int i = 0; i < n; ++i) np_max = std::max(np_max, batches[i]->n_packets);
     REQUIRE(out->geom.nz <= 256, DSI_ERR_INVALID, "arg-max indices are u8: dimZ must be <= 256 (got %d)", out->geom.nz);
     if (int rc = set_device(ctx)) return rc;
     dsi::BandPlan bp{};
     // every knob of this path (lane mapping, band height, the kernel timer, the experiments flavour's pass size, partition
     // cost and tracing) is read from ONE object, the output mapper; the vote info is recorded on it and on the cameras
-    REQUIRE(plan_fused(out, np_max, &bp), DSI_ERR_INVALID, "grid rows of %d floats do not fit the fused kernel", out->geom.nx);
+    REQUIRE(plan_fused(out, np_max, &bp, n), DSI_ERR_INVALID, "grid rows of %d floats do not fit the fused kernel", out->geom.nx);
     const dsi::Geom& geom = mappers[0]->geom;
     hipStream_t st = ctx->stream;
     dsi::FusedCameras cams{};

@@ -129,11 +129,12 @@ struct FusedCamera {
     const uint32_t* slow_any;
     int np;
 };
-constexpr int kFusedMaxCameras = 3;
+constexpr int kFusedMaxCameras = 4;
 struct FusedCameras {
     FusedCamera cam[kFusedMaxCameras];
-    int n;  // 1 (vote -> arg-max), 2 (vote x 2 -> op -> arg-max) or 3 (process1.cpp:169-191: the trinocular rig --
-            // op 1 min, 2 harmonicMeanTwoGrids(g, 3), 6 max of the two-camera result and camera 2)
+    int n;  // 1 (vote -> arg-max), 2 (vote x 2 -> op -> arg-max), 3 (process1.cpp:169-191: the trinocular rig --
+            // op 1 min, 2 harmonicMeanTwoGrids(g, 3), 6 max of the two-camera result and camera 2) or 4 (round 6: the
+            // balanced tree of the reference's 2-ary geometric mean, cartesian3dgrid.h:150-156 -- DSI_ACC_GM_TREE)
 };
 // LAYOUT LOCK: k_vote_fuse_argmax reads cam[c] with scalar loads straight from the kernel-argument segment
 // (__builtin_amdgcn_kernarg_segment_ptr), which holds because (i) `cams` is the kernel's FIRST parameter, so cam[0]
@@ -176,7 +177,7 @@ int fused_max_pairs();
 // launch_unpack_argmax.  splits: optional balanced partition of the (band-major) pair list, one entry
 // per workgroup + 1 (fused_grid_blocks() workgroups)
 int fused_grid_blocks();
-size_t fused_max_cells(int mapping);  // (band_rows + 2) * nx may not exceed this
+size_t fused_max_cells(int mapping, int n_cameras = 2);  // (band_rows + 2) * nx may not exceed this (four cameras: 16 cells per thread)
 hipError_t launch_vote_fuse_argmax(hipStream_t s, const FusedCameras& cams, const Geom& g, const BandPlan& bp, int op,
                                    const uint32_t* splits, unsigned long long* keys, unsigned long long* trace = nullptr);
 size_t fused_trace_words();  // trace: [workgroup][64 phases][16 waves][4 stamps] of 100 MHz ticks, or nullptr

@@ -677,21 +677,22 @@ __global__ __launch_bounds__(1024) void k_plane_coef(const float* __restrict__ c
     plane_coef_body<STAGED>(blockIdx.x, centers, planes, rowstart, nvalid, np, g, bp, coef, cuts, nullptr);
 }
 
-// the coefficient / cut tables of up to three cameras in one launch; camera 1's blocks start at blocks0, camera 2's
-// blocks1 further
+// the coefficient / cut tables of up to four cameras in one launch; camera c's blocks follow camera c - 1's
+struct PrepBlocks {
+    unsigned n[kFusedMaxCameras];  // blocks of camera c
+};
+
 template <bool STAGED>
-__global__ __launch_bounds__(1024) void k_plane_coef_multi(PrepCameras cams, BandPlan bp, unsigned blocks0, unsigned blocks1)
+__global__ __launch_bounds__(1024) void k_plane_coef_multi(PrepCameras cams, BandPlan bp, PrepBlocks blocks)
 {
     unsigned bid = blockIdx.x;
     int c = 0;
-    if (cams.n > 1 && bid >= blocks0) {
-        bid -= blocks0;
-        c = 1;
-        if (cams.n > 2 && bid >= blocks1) {
-            bid -= blocks1;
-            c = 2;
+#pragma unroll
+    for (int k = 0; k < kFusedMaxCameras - 1; ++k)
+        if (c == k && cams.n > k + 1 && bid >= blocks.n[k]) {
+            bid -= blocks.n[k];
+            c = k + 1;
         }
-    }
     const PrepCamera& pc = cams.cam[c];
     plane_coef_body<STAGED>(bid, pc.raw.centers, pc.planes, pc.rowstart, pc.nvalid, pc.np, pc.raw.g, bp, pc.coef, pc.cuts, pc.pair_work);
 }
@@ -744,6 +745,7 @@ using acc_t = unsigned long long;
 // thread.  20 cover the whole LDS (160 KB of 8-byte cells); the vector-fill mappings leave fewer registers: 16.
 constexpr int kFusedTracePhases = 64;
 __host__ __device__ constexpr int fused_cells_per_thread(int mapping) { return (mapping == 5 || mapping == 6) ? 16 : 20; }
+constexpr int kFusedCellsFourCameras = 16;  // four cameras keep TWO fp32 arrays per thread beside the running maxima
 constexpr int kFusedCellsTwoPerCu = 10;  // k_vote_fuse_argmax_2cu: half the LDS per workgroup = 10 x 1024 cells
 constexpr float kFixScale = 2147483648.f;      // 2^31
 constexpr double kFixInv = 1.0 / 2147483648.0;  // 2^-31
@@ -2608,7 +2610,8 @@ struct FusedBest {
 // anyway -- so that the CELLS / 2 LDS reads of a half are in flight together: with a branch per cell every
 // read was waited for on its own, and the read-back took 3 us per phase (tools/fused_trace.py).
 // MODE: what a phase does with the band it has just voted
-enum { FUSED_READ1 = 5,  // camera 1 of 2, round 6: read back, clear and convert only -- values kept in vb; the fusion op and the
+enum { FUSED_LAST4 = 6,  // camera 3 of 4: sqrt(sqrt(c0 c1) * sqrt(c2 c3)) -- the GM tree's root (cartesian3dgrid.h:150-156), arg-max
+       FUSED_READ1 = 5,  // camera 1 of 2, round 6: read back, clear and convert only -- values kept in vb; the fusion op and the
                          // running arg-max (the VALU-bound two thirds of that read-back) are DEFERRED to fused_deferred_argmax,
                          // which every wave runs at the end of ITS OWN next voting stream, while the other waves still vote
        FUSED_KEEP = 0,   // camera 0 of several: keep the values
@@ -2635,7 +2638,8 @@ __device__ __forceinline__ void fused_deferred_argmax(const float* __restrict__ 
 
 template <int CELLS, int OP, int MODE>
 __device__ __forceinline__ void fused_consume(acc_t* __restrict__ band, int nx, int n_own, int rows_lds,
-                                              float* __restrict__ va, FusedBest<CELLS>& fb, int z)
+                                              float* __restrict__ va, FusedBest<CELLS>& fb, int z,
+                                              const float* __restrict__ vpair = nullptr /* FUSED_LAST4: cameras 2's values */)
 {
     acc_t* own = band + nx;
     // (the thread index is re-read behind an opaque barrier so that the compiler recomputes the 20 cell
@@ -2675,8 +2679,10 @@ __device__ __forceinline__ void fused_consume(acc_t* __restrict__ band, int nx, 
             } else {
                 // process1.cpp:126-158: fused = 0; fused += dsi0; fused.<op>TwoGrids(dsi1)
                 // process1.cpp:169-191: fused.minTwoGrids / harmonicMeanTwoGrids(dsi2, 3) / maxTwoGrids(dsi2)
+                // (FUSED_LAST4: gm_tree<4> of k_fuse_gm_tree -- t0 = va = sqrt(c0 c1), t1 = sqrt(c2 c3), sqrt(t0 t1))
                 const float f = MODE == FUSED_LAST2   ? fuse_op<OP>(0.f + va[kk], v)
                                 : MODE == FUSED_LAST3 ? (OP == 2 ? harmonic_mean_n(va[kk], v, 3.f, 2.f) : fuse_op<OP>(va[kk], v))
+                                : MODE == FUSED_LAST4 ? fuse_op<3>(va[kk], fuse_op<3>(vpair[kk], v))
                                                       : v;
                 const bool better = fb.best[kk] < f;  // strict: the first maximum wins (cartesian3dgrid.cpp:132-134)
                 fb.best[kk] = better ? f : fb.best[kk];
@@ -2698,7 +2704,10 @@ __device__ __forceinline__ void fused_consume(acc_t* __restrict__ band, int nx, 
 // instructions, the IEEE division of the harmonic mean among them -- are run by every wave at the end of its NEXT voting
 // stream, i.e. in the time it would otherwise wait at the phase barrier for the slowest wave (the waves of a phase end
 // up to one pass = 2-4 us apart), while the others still vote.  Same values, same order per cell: same bits.
-template <int MAPPING, int CELLS, bool DEFER = false>
+// FOUR (round 6): four cameras fused by the balanced tree of the reference's 2-ary geometric mean (DSI_ACC_GM_TREE,
+// cartesian3dgrid.h:150-156 applied pairwise: BASELINE configs[4]) -- camera 0 kept, camera 1 folded into it, camera 2 kept in
+// a second register array, camera 3 closes both pairs and the root; same bits as k_collapse_max_z_gm_tree<4> on the four DSIs.
+template <int MAPPING, int CELLS, bool DEFER = false, bool FOUR = false>
 __device__ __forceinline__ void vote_fuse_argmax_body(const FusedCameras& cams, const Geom& g, const BandPlan& bp, int op,
                                                       const uint32_t* __restrict__ splits,
                                                       unsigned long long* __restrict__ keys,
@@ -2752,7 +2761,8 @@ __device__ __forceinline__ void vote_fuse_argmax_body(const FusedCameras& cams, 
         return o;
     };
     float va[CELLS];
-    float vb[DEFER ? CELLS : 1];  // DEFER: camera 1's values of the pair whose arg-max update is pending
+    static_assert(!(DEFER && FOUR), "one use of the second register array");
+    float vb[(DEFER || FOUR) ? CELLS : 1];  // DEFER: camera 1's values of the pair whose arg-max update is pending; FOUR: camera 2's
     int pend_z = -1;              // its plane (wave-uniform); -1: nothing pending
     FusedBest<CELLS> fb;
     auto run_pending = [&]() {
@@ -2815,7 +2825,7 @@ __device__ __forceinline__ void vote_fuse_argmax_body(const FusedCameras& cams, 
         // events with floor(Y) in [r0 - 1, r1 - 1] (and in [0, ny - 2], cartesian3dgrid.h:255-259)
         const int Li = max(r0 - 1, 0), Ui = min(r1, g.ny - 1);
         // (the DEFER instantiation is launched for two cameras only: the other camera counts' read-backs are not in it)
-        const int n_cams = DEFER ? 2 : cams.n;
+        const int n_cams = DEFER ? 2 : (FOUR ? 4 : cams.n);
 #pragma nounroll
         for (int c = 0; c < n_cams; ++c) {
             const FusedCamera cam = camera(c);
@@ -2846,7 +2856,16 @@ __device__ __forceinline__ void vote_fuse_argmax_body(const FusedCameras& cams, 
             __syncthreads();
             if (threadIdx.x == 0) s_pass = kPass0;
             const bool last = c == n_cams - 1;
-            if constexpr (DEFER) {
+            if constexpr (FOUR) {
+                if (c == 0)
+                    fused_consume<CELLS, 3, FUSED_KEEP>(band, nx, n_own, rows_lds, va, fb, z);
+                else if (c == 1)
+                    fused_consume<CELLS, 3, FUSED_MID>(band, nx, n_own, rows_lds, va, fb, z);
+                else if (c == 2)
+                    fused_consume<CELLS, 3, FUSED_KEEP>(band, nx, n_own, rows_lds, vb, fb, z);
+                else
+                    fused_consume<CELLS, 3, FUSED_LAST4>(band, nx, n_own, rows_lds, va, fb, z, vb);
+            } else if constexpr (DEFER) {
                 if (!last) {
                     fused_consume<CELLS, 1, FUSED_KEEP>(band, nx, n_own, rows_lds, va, fb, z);
                 } else {
@@ -2892,13 +2911,13 @@ __device__ __forceinline__ void vote_fuse_argmax_body(const FusedCameras& cams, 
 }
 
 // one workgroup per CU: the band takes (almost) the whole LDS, up to 128 VGPRs
-template <int MAPPING, int CELLS, bool DEFER = false>
+template <int MAPPING, int CELLS, bool DEFER = false, bool FOUR = false>
 __global__ __launch_bounds__(1024) void k_vote_fuse_argmax(FusedCameras cams, Geom g, BandPlan bp, int op,
                                                            const uint32_t* __restrict__ splits,
                                                            unsigned long long* __restrict__ keys,
                                                            unsigned long long* __restrict__ trace)
 {
-    vote_fuse_argmax_body<MAPPING, CELLS, DEFER>(cams, g, bp, op, splits, keys, trace);
+    vote_fuse_argmax_body<MAPPING, CELLS, DEFER, FOUR>(cams, g, bp, op, splits, keys, trace);
 }
 
 // TWO workgroups per CU (round 4): bands of at most half the LDS, half the cells per thread, <= 64 VGPRs -- while one
@@ -4739,17 +4758,18 @@ hipError_t launch_prepare_cameras(hipStream_t s, const PrepCameraArgs* args, int
     const size_t table_bytes = ((size_t)kCoefTilePackets * (size_t)(g.ny + 2 * bp.row_pad + 3) * sizeof(uint16_t) + 7) & ~(size_t)7;
     const bool staged = table_bytes <= max_dynamic_lds();
     const unsigned zdiv = staged ? 64u : 16u;
-    unsigned blocks[kFusedMaxCameras] = {0, 0, 0};
+    PrepBlocks pb{};
+    unsigned total_blocks = 0;
     for (int c = 0; c < cams.n; ++c) {
         const unsigned tiles_p = (unsigned)((cams.cam[c].np + kCoefTilePackets - 1) / kCoefTilePackets);
-        blocks[c] = (tiles_p * (((unsigned)g.nz + zdiv - 1) / zdiv) + 63u) & ~63u;
+        pb.n[c] = (tiles_p * (((unsigned)g.nz + zdiv - 1) / zdiv) + 63u) & ~63u;
+        total_blocks += pb.n[c];
     }
     if (staged) {
         if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_plane_coef_multi<true>), table_bytes)) return e;
-        hipLaunchKernelGGL(k_plane_coef_multi<true>, dim3(blocks[0] + blocks[1] + blocks[2]), dim3(1024), table_bytes, s, cams, bp, blocks[0],
-                           blocks[1]);
+        hipLaunchKernelGGL(k_plane_coef_multi<true>, dim3(total_blocks), dim3(1024), table_bytes, s, cams, bp, pb);
     } else {
-        hipLaunchKernelGGL(k_plane_coef_multi<false>, dim3(blocks[0] + blocks[1] + blocks[2]), dim3(256), 0, s, cams, bp, blocks[0], blocks[1]);
+        hipLaunchKernelGGL(k_plane_coef_multi<false>, dim3(total_blocks), dim3(256), 0, s, cams, bp, pb);
     }
     return hipExtGetLastError();
 }
@@ -4770,6 +4790,17 @@ static hipError_t launch_vote_fuse_argmax_t(hipStream_t s, const FusedCameras& c
 {
     constexpr int CELLS = fused_cells_per_thread(MAPPING);
     if ((size_t)(bp.band_rows + 2) * g.nx > (size_t)CELLS * 1024) return hipErrorInvalidValue;
+    if (cams.n == 4) {
+        // four cameras: the geometric-mean tree only (op 3), one workgroup per CU, a second register array per thread -- 16
+        // cells per thread in every mapping (plan_fused cuts the bands accordingly)
+        constexpr int CELLS4 = kFusedCellsFourCameras;
+        if (op != 3 || (size_t)(bp.band_rows + 2) * g.nx > (size_t)CELLS4 * 1024) return hipErrorInvalidValue;
+        const void* kern4 = reinterpret_cast<const void*>(&k_vote_fuse_argmax<MAPPING, CELLS4, false, true>);
+        if (hipError_t e = allow_dynamic_lds(kern4, bp.lds_bytes)) return e;
+        hipLaunchKernelGGL((k_vote_fuse_argmax<MAPPING, CELLS4, false, true>), dim3(blocks), dim3(1024), bp.lds_bytes, s, cams, g, bp, op,
+                           splits, keys, trace);
+        return hipExtGetLastError();
+    }
     if constexpr (MAPPING == 1 || MAPPING == 3) {
         // a band of at most half the LDS and half the cells: two workgroups per CU, the variant with <= 64 VGPRs
         constexpr int HALF = kFusedCellsTwoPerCu;
@@ -4805,7 +4836,10 @@ one_per_cu:
     return hipExtGetLastError();
 }
 
-size_t fused_max_cells(int mapping) { return (size_t)fused_cells_per_thread(mapping) * 1024; }
+size_t fused_max_cells(int mapping, int n_cameras)
+{
+    return (size_t)(n_cameras == 4 ? std::min(kFusedCellsFourCameras, fused_cells_per_thread(mapping)) : fused_cells_per_thread(mapping)) * 1024;
+}
 
 size_t fused_trace_words() { return (size_t)2 * fused_grid_blocks() * kFusedTracePhases * 16 * 4; }  // (two workgroups per CU at most)
 

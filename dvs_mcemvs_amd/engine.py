@@ -176,6 +176,7 @@ def load_library():
         "dsi_mapper_depth_map_of_fusion": (C.c_int, [vp, vp, vp, C.c_int]),
         "dsi_mapper_depth_map_of_fusion_n": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_int]),
         "dsi_mapper_depth_map_of_events": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int]),
+        "dsi_mapper_depth_map_of_events_n": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int]),
         "dsi_mapper_get_depth_map_from_dsi": (C.c_int, [vp, vp, C.POINTER(_DepthMapOptions), f32p, f32p,
                                                        u8p, u8p]),
         "dsi_mapper_filter_depth_map": (C.c_int, [vp, C.POINTER(_DepthMapOptions), f32p, f32p, u8p, u8p]),
@@ -926,6 +927,15 @@ class MapperEMVS:
         hm = (C.c_void_p * len(mappers))(*[m._h for m in mappers])
         hb = (C.c_void_p * len(batches))(*[b._h for b in batches])
         _check(load_library().dsi_mapper_depth_map_of_events(self._h, hm, hb, len(mappers), int(fusion_method)))
+
+    def computeDepthMapOfEventsN(self, mappers, batches, mode=None):
+        """Depth map of four (or two) cameras' events fused by the geometric-mean tree (ACC_GM_TREE) without building their
+        DSIs (dsi_mapper_depth_map_of_events_n): bit-identical to evaluateDSI_batch on every mapper +
+        computeDepthMapOfFusionN([m.dsi_ ...], ACC_GM_TREE).  Results in THIS mapper's depth-map buffers."""
+        hm = (C.c_void_p * len(mappers))(*[m._h for m in mappers])
+        hb = (C.c_void_p * len(batches))(*[b._h for b in batches])
+        _check(load_library().dsi_mapper_depth_map_of_events_n(self._h, hm, hb, len(mappers),
+                                                               int(ACC_GM_TREE if mode is None else mode)))
 
     def resolveNearTies(self, mappers, batches, fusion_method=FUSE_HM, rel_gap=0.0):
         """Exact tie resolver (dsi_mapper_resolve_near_ties): after the mappers' DSIs were built from `batches`

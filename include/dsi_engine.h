@@ -393,6 +393,16 @@ DSI_API int dsi_mapper_depth_map_of_fusion_n(dsi_mapper_t *m, const dsi_grid_t *
  * returned false, mapper_emvs_stereo.cpp:71-75).  Asynchronous on the context's stream. */
 DSI_API int dsi_mapper_depth_map_of_events(dsi_mapper_t *out, dsi_mapper_t *const *mappers,
                                            const dsi_batch_t *const *batches, int n, int op);
+/* The same for the n-camera rigs the reference's process_1 has no switch for (BASELINE configs[4]: four cameras,
+ * geometric mean): bit for bit what
+ *     for c in 0..n-1: dsi_mapper_evaluate_batch(mappers[c], batches[c]);
+ *     dsi_mapper_depth_map_of_fusion_n(out, {grid(mappers[c])}, n, mode)
+ * leaves in out's depth-map buffers, by the one kernel that votes, fuses and keeps the running arg-max -- no DSI written
+ * (at 1024 x 1024 x 256: 4 GiB not written and not read back).  mode = DSI_ACC_GM_TREE, the balanced tree of
+ * Grid3D::geometricMeanTwoGrids (cartesian3dgrid.h:150-156): sqrt(sqrt(c0 c1) sqrt(c2 c3)); n = 4, or 2 (where the tree IS
+ * the reference's 2-ary op).  Everything else as dsi_mapper_depth_map_of_events. */
+DSI_API int dsi_mapper_depth_map_of_events_n(dsi_mapper_t *out, dsi_mapper_t *const *mappers,
+                                             const dsi_batch_t *const *batches, int n, int mode);
 DSI_API int dsi_mapper_fetch_depth_map(dsi_mapper_t *m, float *depth_host, float *conf_host, uint8_t *idx_host);
 /* the same without waiting: the copies are queued (on the context's copy stream, behind the arg-max
  * only -- not behind later work of the compute stream); the outputs (page-locked memory from
