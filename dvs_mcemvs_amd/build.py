@@ -14,7 +14,7 @@ OUT = os.path.join(HERE, "libdsi_engine.so")
 # the EXPERIMENTS flavour (-DDSI_TIMING_EXPERIMENTS: environment knobs + dsi_test_* hooks, some of which corrupt the
 # DSIs on purpose) is a DIFFERENT file, loaded only by an explicit opt-in (engine.load_library: DSI_ENGINE_EXPERIMENTS=1)
 OUT_EXPERIMENTS = os.path.join(HERE, "libdsi_engine_experiments.so")
-SOURCES = ["dsi_kernels.hip", "dsi_tie_sort.hip", "dsi_engine.cpp"]
+SOURCES = ["dsi_kernels.hip", "dsi_engine.cpp"]
 HEADERS = ["dsi_kernels.h", "dsi_vote_asm.h", "dsi_host.hpp", os.path.join("..", "..", "include", "dsi_engine.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
          "-fvisibility=hidden", "-Wall", "-Wextra", "-Wno-unused-parameter", "-x", "hip"]

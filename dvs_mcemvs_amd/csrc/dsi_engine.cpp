@@ -232,16 +232,16 @@ struct dsi_batch {
 
 // grow-only device scratch of the exact tie resolver (dsi_mapper_resolve_near_ties), owned by the output mapper
 struct TieScratch {
-    DevBuf<uint32_t> cand, count;
+    DevBuf<uint32_t> cand, count, rank_count, rank_start, rank_cursor;
     DevBuf<uint2> desc;
     DevBuf<uint4> cols;
     // 32-bit words: [0] contending voxels, [1] near-tie columns (k_tie_candidates); [2] output segments handed out,
-    // [3] overflow flags (k_tie_hits_binned); [4] max order difference (float bits), [5] max votes of a voxel (k_tie_sums2);
+    // [3] overflow flags (k_tie_hits_binned); [4] max order difference (float bits), [5] max votes of a voxel (k_tie_pick);
     // [6] changed pixels (k_tie_pick); [8..9] one 64-bit word: real votes recorded; [16..23] planes with a contender (k_tie_desc)
     DevBuf<unsigned long long> counters;
     DevBuf<unsigned long long> keys, keys2;
-    DevBuf<float> w, w2, exact, diff;
-    DevBuf<char> tmp;
+    DevBuf<float> w, exact, diff;
+    DevBuf<char> tmp;  // dsi_mapper_patch_depth_map: the new indices
     unsigned* host = nullptr;  // page-locked copy of the counters: the three reads of a call are plain DMAs
     hipError_t host_counters(unsigned** out)
     {
@@ -255,7 +255,8 @@ struct TieScratch {
         if (host) (void)hipHostFree(host);
         host = nullptr;
         cand.release(); count.release(); desc.release(); cols.release(); counters.release();
-        keys.release(); keys2.release(); w.release(); w2.release(); exact.release(); diff.release(); tmp.release();
+        keys.release(); keys2.release(); w.release(); exact.release(); diff.release(); tmp.release();
+        rank_count.release(); rank_start.release(); rank_cursor.release();
     }
 };
 
@@ -1923,7 +1924,6 @@ static int tie_exact_values_dev(TieScratch& ts, hipStream_t st, dsi_mapper* cons
         HIP_TRY(ts.keys.reserve(cap));
         HIP_TRY(ts.keys2.reserve(cap));
         HIP_TRY(ts.w.reserve(cap));
-        HIP_TRY(ts.w2.reserve(cap));
         const unsigned cap_segs = (unsigned)std::min<size_t>(ts.keys.cap / seg, 0x7fffffffu);
         HIP_TRY(hipMemsetAsync(cnt + 2, 0, (kTieCounterPassWords - 2) * sizeof(unsigned), st));
         for (int c = 0; c < n; ++c) {
@@ -1956,20 +1956,17 @@ static int tie_exact_values_dev(TieScratch& ts, hipStream_t st, dsi_mapper* cons
     std::memcpy(&real_votes, host_cnt + 2, sizeof real_votes);
     *votes = (long long)real_votes;
     const size_t n_rec = (size_t)host_cnt[0] * seg;  // with the sentinel tails of the blocks' last segments
-    const unsigned long long* keys_sorted = nullptr;
-    const float* w_sorted = nullptr;
-    if (n_rec) {
-        size_t tmp_bytes = 0;
-        HIP_TRY(dsi::tie_sort_pairs(st, ts.keys.p, ts.keys2.p, ts.w.p, ts.w2.p, n_rec, pos_bits + rank_bits, nullptr, &tmp_bytes));
-        HIP_TRY(ts.tmp.reserve(tmp_bytes));
-        HIP_TRY(dsi::tie_sort_pairs(st, ts.keys.p, ts.keys2.p, ts.w.p, ts.w2.p, n_rec, pos_bits + rank_bits, ts.tmp.p, &tmp_bytes));
-        keys_sorted = ts.keys2.p;
-        w_sorted = ts.w2.p;
-    }
+    // the votes partitioned by (camera, voxel), each voxel's run put in event order in LDS and added one by one (round 6: no
+    // device-wide sort, no library call)
+    REQUIRE(pos_bits <= 32 && n_rec < ((size_t)1 << 32), DSI_ERR_INVALID, "%zu votes to re-sum: too many voxels asked for", n_rec);
     if (grid_stats) HIP_TRY(ts.diff.reserve((size_t)n * nsv));
-    HIP_TRY(dsi::launch_tie_sums2(st, keys_sorted, w_sorted, n_rec, pos_bits, ts.cand.p, nsv, n, grid_stats ? ms[0]->grid->data : nullptr,
-                                  grid_stats && n > 1 ? ms[1]->grid->data : nullptr, ts.exact.p, ts.count.p,
-                                  grid_stats ? ts.diff.p : nullptr));
+    HIP_TRY(ts.rank_count.reserve((size_t)n * nsv));
+    HIP_TRY(ts.rank_start.reserve((size_t)n * nsv + 1));
+    HIP_TRY(ts.rank_cursor.reserve((size_t)n * nsv));
+    HIP_TRY(dsi::launch_tie_partition_sums(st, ts.keys.p, ts.w.p, n_rec, pos_bits, ts.rank_count.p, ts.rank_start.p, ts.rank_cursor.p,
+                                           ts.keys2.p, ts.cand.p, nsv, n, grid_stats ? ms[0]->grid->data : nullptr,
+                                           grid_stats && n > 1 ? ms[1]->grid->data : nullptr, ts.exact.p, ts.count.p,
+                                           grid_stats ? ts.diff.p : nullptr));
     return DSI_OK;
 }
 

@@ -231,20 +231,20 @@ hipError_t launch_tie_hits_binned(hipStream_t s, const float2* xy, const float* 
                                   const uint2* desc, int nsv, unsigned rank_base, unsigned pos_bits, unsigned sentinel_rank,
                                   unsigned* seg_counter, unsigned cap_segs, unsigned* flags, unsigned long long* total_hits,
                                   unsigned long long* keys, float* wts);
-// exact[cam * nsv + c], count[...] <- sequential fp32 sum / number of the sorted votes of voxel c of camera cam; diff[...]
-// (optional; needs grid0 (and grid1 for two cameras)) <- |grid_cam[vox[c]] - exact| / max(1, |exact|)
-hipError_t launch_tie_sums2(hipStream_t s, const unsigned long long* keys, const float* wts, unsigned long long n, unsigned pos_bits,
-                            const uint32_t* vox, int nsv, int n_cams, const float* grid0, const float* grid1, float* exact,
-                            uint32_t* count, float* diff);
 // per near-tie column: op(exact camera 0, exact camera 1) (op 0: one camera), first maximum, patch; stats[0] = max float bits
 // of diff, [1] = max count, [2] += changed pixels
 hipError_t launch_tie_pick(hipStream_t s, int op, const uint4* cols, int n_cols, const uint32_t* vox, int nsv, int npix,
                            const float* exact, const uint32_t* count, const float* diff, const float* planes, float* conf,
                            uint8_t* idx, float* depth, unsigned* stats);
-// (key, weight) pairs sorted by key on the device (rocPRIM radix sort over the low key_bits bits; dsi_tie_sort.hip).
-// tmp == nullptr: *tmp_bytes <- the scratch the sort needs
-hipError_t tie_sort_pairs(hipStream_t s, unsigned long long* keys_in, unsigned long long* keys_out, float* w_in, float* w_out,
-                          size_t n, unsigned key_bits, void* tmp, size_t* tmp_bytes);
+// round 6, instead of a device-wide sort: the recorded votes partitioned by rank (camera * nsv + voxel) into runs[], each run
+// ordered by event position in LDS and added one by one in fp32.  counts / cursor: n_cams * nsv words, starts: one more (scratch);
+// runs: n_rec words; wts is consumed (it receives the weights in event order).  exact[cam * nsv + c], count[...] <- sequential fp32
+// sum / number of the votes of voxel c of camera cam; diff[...] (optional; needs grid0 (and grid1 for two cameras)) <-
+// |grid_cam[vox[c]] - exact| / max(1, |exact|).  No library call.
+hipError_t launch_tie_partition_sums(hipStream_t s, const unsigned long long* keys, const float* wts, unsigned long long n_rec,
+                                     unsigned pos_bits, uint32_t* counts, uint32_t* starts, uint32_t* cursor, unsigned long long* runs,
+                                     const uint32_t* vox, int nsv, int n_cams, const float* grid0, const float* grid1, float* exact,
+                                     uint32_t* count, float* diff);
 hipError_t launch_tie_patch(hipStream_t s, const uint32_t* pix, const uint8_t* new_idx, const float* new_conf, int n,
                             const float* planes, float* conf, uint8_t* idx, float* depth);
 

@@ -3931,8 +3931,7 @@ __global__ void k_div_probe(const float* __restrict__ n, const float* __restrict
 //   k_tie_hits_binned  every (packet, contending voxel): the events the plane transfer takes into the voxel's 2 x 2
 //                      neighbourhood, voted with the reference's coordinates (IEEE divide), accept test and weights;
 //                      a vote is recorded as (voxel, event order, weight)
-//   (device sort)      by (camera, voxel, event order)
-//   k_tie_sums2        thread = voxel: its votes added one by one in fp32
+//   (partition by voxel, per-voxel order in LDS, one-by-one fp32 sums: k_tie_partition, k_tie_sort_runs, k_tie_add_runs below)
 //   k_tie_pick         thread = column: camera fusion, first maximum (cartesian3dgrid.cpp:132-134), patch
 template <int OP>
 __device__ __forceinline__ float tie_value(const float* __restrict__ a, const float* __restrict__ b, size_t i)
@@ -4388,65 +4387,296 @@ __global__ __launch_bounds__(256) void k_tie_desc(const uint32_t* __restrict__ v
         atomicOr(&plane_bits[threadIdx.x], s_bits[threadIdx.x]);
 }
 
-// WAVE = (camera, contending voxel): its run of the sorted votes added one by one in fp32 -- resetGrid
-// (mapper_emvs_stereo.cpp:145), then "grid[i] += w" per vote in event order (cartesian3dgrid.h:261-270).  Virtual voxel
-// r = camera * nsv + c; keys = r << pos_bits | event position, sorted.  The wave loads 64 consecutive weights with one
-// coalesced instruction (the next 64 are in flight meanwhile) and adds them in order, each broadcast from its lane
-// (v_readlane) -- the chain of dependent additions is the same in every lane.  (One THREAD per voxel reads 64 different
-// cache lines per instruction and spends ~110 clocks per addition of the longest run: 354 us at configs[1], now ~40.)
-// diff[r] (optional) = |engine value - reference-order value| / max(1, |reference-order value|)
-__global__ __launch_bounds__(256) void k_tie_sums2(const unsigned long long* __restrict__ keys, const float* __restrict__ wts,
-                                                   unsigned long long n, unsigned pos_bits, const uint32_t* __restrict__ vox,
-                                                   int nsv, int n_cams, const float* __restrict__ grid0,
-                                                   const float* __restrict__ grid1, float* __restrict__ exact,
-                                                   uint32_t* __restrict__ count, float* __restrict__ diff)
+// ---- round 6: the recorded votes PARTITIONED by (camera, voxel) and ordered per voxel in LDS, instead of one device-wide
+// radix sort of 38-bit keys (rocPRIM: 5 passes over 15.7 M pairs, 0.74 ms at configs[1] -- the last library call of the engine).
+// Nothing needs the votes of DIFFERENT voxels in any order, and a voxel has a few thousand of them:
+//   k_tie_partition<false>   votes per rank r = camera * nsv + voxel (a workgroup counts its stretch in LDS first: one global
+//                            atomic per (workgroup, rank), not per vote -- same-address atomics serialise at the memory side)
+//   k_tie_scan               exclusive prefix -> where each rank's run begins
+//   k_tie_partition<true>    every vote into its rank's run, as ONE 64-bit word (event position << 32 | weight bits), in any order
+//   k_tie_sort_runs          workgroup = rank: the run put in event order in LDS (a bucket sort by event position: tie_block_sort),
+//                            its weights written back in that order.  Runs beyond 4,096 votes (configs[4]: ~30 k in a voxel)
+//                            go through the same LDS in windows of event positions.
+//   k_tie_add_runs           wave = rank: the weights added one by one in fp32 -- resetGrid (mapper_emvs_stereo.cpp:145),
+//                            "grid[i] += w" per vote in event order (cartesian3dgrid.h:261-270)
+constexpr int kTiePartLdsRanks = 30720;  // 120 KB of counters
+constexpr int kTieRunLds = 4096;         // words of a wave's sorting buffer (32 KB)
+
+template <bool SCATTER>
+__global__ __launch_bounds__(1024) void k_tie_partition(const unsigned long long* __restrict__ keys, const float* __restrict__ wts,
+                                                        unsigned long long n_rec, unsigned long long per_block, unsigned pos_bits,
+                                                        unsigned n_ranks, int use_lds, uint32_t* __restrict__ counts_or_cursor,
+                                                        const uint32_t* __restrict__ starts, unsigned long long* __restrict__ runs)
+{
+    extern __shared__ uint32_t s_rank[];  // use_lds: n_ranks counters, then (SCATTER) the next free slot of each rank's run
+    const unsigned long long b0 = (unsigned long long)blockIdx.x * per_block, b1 = min(n_rec, b0 + per_block);
+    if (b0 >= b1) return;
+    const unsigned long long pos_mask = (1ull << pos_bits) - 1ull;
+    if (!use_lds) {  // too many ranks for the LDS: one global atomic per vote (they spread over that many addresses)
+        for (unsigned long long i = b0 + threadIdx.x; i < b1; i += 1024) {
+            const unsigned long long key = keys[i];
+            const unsigned r = (unsigned)(key >> pos_bits);
+            if (r >= n_ranks) continue;  // (the sentinel tails of the blocks' last segments)
+            const uint32_t at = atomicAdd(&counts_or_cursor[r], 1u);
+            if (SCATTER) runs[(size_t)starts[r] + at] = ((key & pos_mask) << 32) | (unsigned long long)__float_as_uint(wts[i]);
+        }
+        return;
+    }
+    for (unsigned r = threadIdx.x; r < n_ranks; r += 1024) s_rank[r] = 0u;
+    __syncthreads();
+    for (unsigned long long i = b0 + threadIdx.x; i < b1; i += 1024) {
+        const unsigned r = (unsigned)(keys[i] >> pos_bits);
+        if (r < n_ranks) atomicAdd(&s_rank[r], 1u);  // (LDS)
+    }
+    __syncthreads();
+    for (unsigned r = threadIdx.x; r < n_ranks; r += 1024) {
+        const uint32_t c = s_rank[r];
+        if (!c) continue;
+        const uint32_t at = atomicAdd(&counts_or_cursor[r], c);
+        if (SCATTER) s_rank[r] = starts[r] + at;
+    }
+    if (!SCATTER) return;
+    __syncthreads();
+    for (unsigned long long i = b0 + threadIdx.x; i < b1; i += 1024) {
+        const unsigned long long key = keys[i];
+        const unsigned r = (unsigned)(key >> pos_bits);
+        if (r >= n_ranks) continue;
+        const uint32_t slot = atomicAdd(&s_rank[r], 1u);  // (LDS)
+        runs[slot] = ((key & pos_mask) << 32) | (unsigned long long)__float_as_uint(wts[i]);
+    }
+}
+
+// starts[r] = votes of the ranks below r (starts[n_ranks] = all of them); cursor[r] = 0.  One workgroup.
+__global__ __launch_bounds__(1024) void k_tie_scan(const uint32_t* __restrict__ counts, unsigned n_ranks, uint32_t* __restrict__ starts,
+                                                   uint32_t* __restrict__ cursor)
+{
+    __shared__ uint32_t wave_tot[16];
+    const unsigned per = (n_ranks + 1023u) / 1024u;
+    const unsigned r0 = min(n_ranks, threadIdx.x * per), r1 = min(n_ranks, r0 + per);
+    uint32_t local = 0;
+    for (unsigned r = r0; r < r1; ++r) local += counts[r];
+    uint32_t incl = local;
+    const int lane = threadIdx.x & 63;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wave_tot[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t base = incl - local, total = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < (int)(threadIdx.x >> 6)) base += wave_tot[w];
+        total += wave_tot[w];
+    }
+    for (unsigned r = r0; r < r1; ++r) {
+        starts[r] = base;
+        base += counts[r];
+        cursor[r] = 0u;
+    }
+    if (threadIdx.x == 0) starts[n_ranks] = total;
+}
+
+// The n <= kTieRunLds words of a run (any order; event position << 32 | weight bits) -> ascending in tmp[0 .. n), by the whole
+// workgroup (256 threads).  The words are dealt to nb >= n buckets of equal position width (one LDS atomic each: count and
+// rank in the bucket), the bucket starts are a prefix sum, every word goes to its bucket's stretch, and inside a bucket every
+// word finds its place by counting the smaller ones.  ~6 passes over the run instead of a 66-stage bitonic network (which cost
+// 2 ms at configs[1] with a wave per run).  A burst -- all events of ONE packet on a voxel -- is one bucket of 1,024 words:
+// 1,024 reads per word, spread over the workgroup: slow, correct, rare.
+template <int CAP>
+__device__ __forceinline__ void tie_block_sort(const unsigned long long* __restrict__ src, int n,
+                                               unsigned long long* __restrict__ tmp, uint32_t* __restrict__ bcnt, uint32_t* __restrict__ wave_tot)
+{
+    constexpr int T = 256, PER = CAP / T;
+    const int tid = (int)threadIdx.x;
+    int nb = 64;
+    while (nb < n) nb <<= 1;
+    for (int i = tid; i < nb; i += T) bcnt[i] = 0u;
+    unsigned long long key[PER];
+    uint32_t rank[PER], bucket[PER];
+    // the run's own span of event positions (a voxel is voted while the camera looks past it: its votes sit in a stretch of
+    // the stream, and buckets over the WHOLE stream would put them into a few): min and max over the workgroup
+    uint32_t pmin = 0xffffffffu, pmax = 0u;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = tid + k * T;
+        if (i < n) {
+            key[k] = src[i];
+            const uint32_t p = (uint32_t)(key[k] >> 32);
+            pmin = min(pmin, p);
+            pmax = max(pmax, p);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        pmin = min(pmin, (uint32_t)__shfl_xor((int)pmin, off, 64));
+        pmax = max(pmax, (uint32_t)__shfl_xor((int)pmax, off, 64));
+    }
+    if ((tid & 63) == 0) {
+        wave_tot[tid >> 6] = pmin;
+        wave_tot[4 + (tid >> 6)] = pmax;
+    }
+    __syncthreads();
+    pmin = min(min(wave_tot[0], wave_tot[1]), min(wave_tot[2], wave_tot[3]));
+    pmax = max(max(wave_tot[4], wave_tot[5]), max(wave_tot[6], wave_tot[7]));
+    // bucket = floor((p - pmin) * scale), scale a little below nb / (span + 1): monotone in p, < nb
+    const float scale = (float)nb / ((float)(pmax - pmin) + 1.f) * 0.99999f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = tid + k * T;
+        if (i < n) {
+            const uint32_t p = (uint32_t)(key[k] >> 32);
+            bucket[k] = min((uint32_t)((float)(p - pmin) * scale), (uint32_t)(nb - 1));
+            rank[k] = atomicAdd(&bcnt[bucket[k]], 1u);  // (LDS)
+        }
+    }
+    __syncthreads();
+    // exclusive prefix of the bucket counts, in place (thread t owns a contiguous stretch of nb / 256 buckets)
+    {
+        const int per = max(1, nb / T), b0 = tid * per, b1 = min(nb, b0 + per);
+        uint32_t local = 0;
+        for (int b = b0; b < b1; ++b) local += bcnt[b];
+        uint32_t incl = local;
+        const int lane = tid & 63;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) wave_tot[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t base = incl - local;
+        for (int w = 0; w < (tid >> 6); ++w) base += wave_tot[w];
+        // the stretch's buckets with several words are ordered below by this thread: remember (start, count) in place as
+        // start | count << 16 (n <= 4096: 13 bits each)
+        for (int b = b0; b < b1; ++b) {
+            const uint32_t c = bcnt[b];
+            bcnt[b] = base | (c << 16);
+            base += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = tid + k * T;
+        if (i < n) tmp[(bcnt[bucket[k]] & 0xffffu) + rank[k]] = key[k];
+    }
+    __syncthreads();
+    // order inside the buckets: every word counts the smaller words of its bucket (a voxel is voted while the camera looks
+    // past it, so its votes CLUSTER in time: buckets of tens of words are the rule, and a serial sort of a bucket by one
+    // thread made this kernel 0.6 ms; counted by their own threads, a bucket of c words costs c reads per word, in parallel)
+    uint32_t final_at[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = tid + k * T;
+        if (i < n) {
+            const uint32_t e = bcnt[bucket[k]], c = e >> 16, s0 = e & 0xffffu;
+            uint32_t smaller = 0;
+            if (c > 1u)
+                for (uint32_t q = 0; q < c; ++q) smaller += tmp[s0 + q] < key[k] ? 1u : 0u;  // (positions are unique within a voxel)
+            final_at[k] = s0 + smaller;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = tid + k * T;
+        if (i < n) tmp[final_at[k]] = key[k];
+    }
+    __syncthreads();
+}
+
+// workgroup = rank: its run in event order -> sorted_w[starts[r] .. + counts[r]) (the weights only, 4 bytes per vote); all 256
+// threads work all the time -- the one-by-one additions, which only one wave can do, are k_tie_add_runs' (with them in here three
+// waves of four held 48 KB of LDS idle for ~5 us per run: 0.42 ms at configs[1])
+// CAP: the runs of (CAP / 2, CAP] votes (CAP = 1024: of up to 1,024; CAP = kTieRunLds: also the longer ones, in windows) -- a
+// workgroup of the wrong class leaves at once; three launches, so that the many short runs do not each hold 48 KB of LDS
+template <int CAP>
+__global__ __launch_bounds__(256) void k_tie_sort_runs(const unsigned long long* __restrict__ runs, const uint32_t* __restrict__ starts,
+                                                       const uint32_t* __restrict__ counts, unsigned pos_bits, int n_ranks,
+                                                       float* __restrict__ sorted_w)
+{
+    __shared__ unsigned long long tmp[CAP];
+    __shared__ uint32_t bcnt[CAP];
+    __shared__ uint32_t wave_tot[8];
+    __shared__ uint32_t s_n;
+    const int r = (int)blockIdx.x, tid = (int)threadIdx.x;
+    if (r >= n_ranks) return;
+    const uint32_t first = starts[r], cnt = counts[r];
+    if (cnt == 0u || cnt <= (uint32_t)(CAP == 1024 ? 0 : CAP / 2) || (CAP != kTieRunLds && cnt > (uint32_t)CAP)) return;
+    if (cnt <= (uint32_t)CAP) {
+        tie_block_sort<CAP>(runs + first, (int)cnt, tmp, bcnt, wave_tot);
+        for (uint32_t i = (uint32_t)tid; i < cnt; i += 256) sorted_w[(size_t)first + i] = __uint_as_float((uint32_t)tmp[i]);
+        return;
+    }
+    // Longer runs (configs[4]: ~30 k votes in a voxel): windows [lo, lo + 2^span_bits) of event positions; the run is scanned
+    // once per window, the window's votes compacted into the upper half of tmp (the window is aimed at CAP / 4 votes), sorted
+    // into the lower half and appended.  Positions are unique within a voxel: a window of one position holds one vote at most.
+    unsigned span_bits = pos_bits;
+    while (span_bits > 0 && ((unsigned long long)cnt >> (pos_bits - span_bits)) > (unsigned long long)(CAP / 4)) --span_bits;
+    unsigned long long lo = 0;
+    const unsigned long long pos_range = 1ull << pos_bits;
+    unsigned long long* stage = tmp + CAP / 2;
+    uint32_t done = 0;
+    while (lo < pos_range) {
+        const unsigned long long hi = lo + (1ull << span_bits);
+        if (tid == 0) s_n = 0u;
+        __syncthreads();
+        for (uint32_t i0 = 0; i0 < cnt; i0 += 256) {
+            const uint32_t i = i0 + (uint32_t)tid;
+            const unsigned long long key = i < cnt ? runs[(size_t)first + i] : ~0ull;
+            const unsigned long long p = key >> 32;
+            if (i < cnt && p >= lo && p < hi) {
+                const uint32_t at = atomicAdd(&s_n, 1u);  // (LDS; order is irrelevant here)
+                if (at < (uint32_t)(CAP / 2)) stage[at] = key;
+            }
+        }
+        __syncthreads();
+        const uint32_t n = s_n;
+        if (n > (uint32_t)(CAP / 2)) {  // denser than expected here: a narrower window
+            --span_bits;
+            __syncthreads();
+            continue;
+        }
+        if (n) {
+            tie_block_sort<CAP>(stage, (int)n, tmp, bcnt, wave_tot);
+            for (uint32_t i = (uint32_t)tid; i < n; i += 256) sorted_w[(size_t)first + done + i] = __uint_as_float((uint32_t)tmp[i]);
+            done += n;
+        }
+        __syncthreads();
+        lo = hi;
+        if (n < (uint32_t)(CAP / 16) && span_bits < pos_bits && (lo & ((1ull << (span_bits + 1)) - 1ull)) == 0ull) ++span_bits;
+    }
+}
+
+// WAVE = (camera, contending voxel): its weights, in event order by now, added one by one in fp32 -- resetGrid
+// (mapper_emvs_stereo.cpp:145), then "grid[i] += w" per vote (cartesian3dgrid.h:261-270).  64 consecutive weights per coalesced
+// load (the next 64 in flight meanwhile), each broadcast from its lane (v_readlane): the chain of dependent additions is the
+// same in every lane.  diff[r] (optional) = |engine value - reference-order value| / max(1, |reference-order value|)
+__global__ __launch_bounds__(256) void k_tie_add_runs(const float* __restrict__ sorted_w, const uint32_t* __restrict__ starts,
+                                                      const uint32_t* __restrict__ counts, const uint32_t* __restrict__ vox, int nsv,
+                                                      int n_cams, const float* __restrict__ grid0, const float* __restrict__ grid1,
+                                                      float* __restrict__ exact, uint32_t* __restrict__ count, float* __restrict__ diff)
 {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (r >= nsv * n_cams) return;  // (wave-uniform)
-    // [first, last) = the run of keys with rank r, by a 64-ary search: every step the 64 lanes probe 64 evenly spaced keys
-    // of the remaining range (4 dependent loads for 16 M keys, where a binary search makes 24)
-    unsigned long long bound[2];
-#pragma unroll
-    for (int side = 0; side < 2; ++side) {
-        const unsigned long long want = (unsigned long long)(r + side) << pos_bits;  // first key >= want
-        unsigned long long lo = 0, hi = n;  // the answer lies in [lo, hi]
-        while (hi - lo > 0) {
-            const unsigned long long span = hi - lo, step = (span + 63) / 64;
-            const unsigned long long at = lo + (unsigned long long)lane * step;  // probes lo, lo + step, ...
-            const bool below = at < hi && keys[at] < want;                       // keys[at] < want: the answer is beyond `at`
-            const unsigned long long m = __ballot(below);
-            const int nb = __popcll(m);  // probes 0 .. nb - 1 are below (the keys are sorted)
-            if (nb == 0) {
-                hi = lo;
-                break;
-            }
-            const unsigned long long last_below = lo + (unsigned long long)(nb - 1) * step;
-            lo = last_below + 1;
-            const unsigned long long first_not = lo + step - 1;  // = probe nb, if there is one
-            hi = first_not < hi ? first_not : hi;
-        }
-        bound[side] = lo;
-    }
-    const unsigned long long first = bound[0], last = bound[1];
+    const unsigned long long first = starts[r], last = first + counts[r];
     float sum = 0.f;
-    float w = first + (unsigned)lane < last ? wts[first + (unsigned)lane] : 0.f;
+    float w = first + (unsigned)lane < last ? sorted_w[first + (unsigned)lane] : 0.f;
     for (unsigned long long base = first; base < last; base += 64) {
         const float cur = w;
         const unsigned long long nb = base + 64 + (unsigned)lane;
-        w = nb < last ? wts[nb] : 0.f;  // the next batch, in flight during this one's additions
+        w = nb < last ? sorted_w[nb] : 0.f;  // the next batch, in flight during this one's additions
         if (last - base >= 64) {
 #pragma unroll
             for (int i = 0; i < 64; ++i) sum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur), i));
         } else {
-            const int cnt = (int)(last - base);
-            for (int i = 0; i < cnt; ++i) sum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur), i));
+            const int c = (int)(last - base);
+            for (int i = 0; i < c; ++i) sum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur), i));
         }  // one by one, in order (no reassociation: -ffp-contract=off, no fast-math)
     }
     if (lane != 0) return;
     exact[r] = sum;
-    count[r] = (uint32_t)(last - first);
-    if (diff) {  // |engine value - reference-order value| / max(1, |reference-order value|): k_tie_pick takes the maximum
+    count[r] = counts[r];
+    if (diff) {
         const int cam = r / nsv;
         const float* grid = cam == 0 ? grid0 : grid1;
         const float have = grid[vox[r - cam * nsv]];
@@ -5291,13 +5521,54 @@ hipError_t launch_tie_hits_binned(hipStream_t s, const float2* xy, const float* 
     return hipExtGetLastError();
 }
 
-hipError_t launch_tie_sums2(hipStream_t s, const unsigned long long* keys, const float* wts, unsigned long long n, unsigned pos_bits,
-                            const uint32_t* vox, int nsv, int n_cams, const float* grid0, const float* grid1, float* exact,
-                            uint32_t* count, float* diff)
+
+// the recorded votes [0, n_rec) partitioned by rank into runs[starts[r] .. starts[r] + counts[r]) (any order inside a run;
+// a word = event position << 32 | weight bits), then exact[] / count[] / diff[] (dsi_kernels.h).  n_ranks =
+// n_cams * nsv; counts, cursor: n_ranks words, starts: n_ranks + 1 (scratch).  pos_bits <= 32, n_rec < 2^32.
+hipError_t launch_tie_partition_sums(hipStream_t s, const unsigned long long* keys, const float* wts, unsigned long long n_rec,
+                                     unsigned pos_bits, uint32_t* counts, uint32_t* starts, uint32_t* cursor, unsigned long long* runs,
+                                     const uint32_t* vox, int nsv, int n_cams, const float* grid0, const float* grid1, float* exact,
+                                     uint32_t* count, float* diff)
 {
-    if (nsv <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_tie_sums2, dim3((nsv * n_cams + 3) / 4), dim3(256), 0, s, keys, wts, n, pos_bits, vox, nsv, n_cams, grid0,
-                       grid1, exact, count, diff);
+    const unsigned n_ranks = (unsigned)nsv * (unsigned)n_cams;
+    if (n_ranks == 0) return hipSuccess;
+    if (pos_bits > 32u || n_rec >= (1ull << 32)) return hipErrorInvalidValue;
+    if (hipError_t e = hipMemsetAsync(counts, 0, (size_t)n_ranks * sizeof(uint32_t), s)) return e;
+    if (n_rec) {
+        const int use_lds = n_ranks <= (unsigned)kTiePartLdsRanks ? 1 : 0;
+        const size_t lds = use_lds ? (size_t)n_ranks * sizeof(uint32_t) : 0;
+        // stretches of >= 8 k votes, at most two workgroups per CU's worth of them: a workgroup pays ~n_ranks LDS words and
+        // up to n_ranks global atomics per stretch
+        const unsigned long long per = std::max<unsigned long long>(8192ull, (n_rec + 255ull) / 256ull);
+        const unsigned blocks = (unsigned)((n_rec + per - 1) / per);
+        if (use_lds) {
+            if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_tie_partition<false>), lds)) return e;
+            if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_tie_partition<true>), lds)) return e;
+        }
+        hipLaunchKernelGGL(k_tie_partition<false>, dim3(blocks), dim3(1024), lds, s, keys, wts, n_rec, per, pos_bits, n_ranks, use_lds,
+                           counts, (const uint32_t*)nullptr, (unsigned long long*)nullptr);
+        if (hipError_t e = hipExtGetLastError()) return e;
+        hipLaunchKernelGGL(k_tie_scan, dim3(1), dim3(1024), 0, s, counts, n_ranks, starts, cursor);
+        if (hipError_t e = hipExtGetLastError()) return e;
+        hipLaunchKernelGGL(k_tie_partition<true>, dim3(blocks), dim3(1024), lds, s, keys, wts, n_rec, per, pos_bits, n_ranks, use_lds,
+                           cursor, (const uint32_t*)starts, runs);
+        if (hipError_t e = hipExtGetLastError()) return e;
+    } else {
+        hipLaunchKernelGGL(k_tie_scan, dim3(1), dim3(1024), 0, s, counts, n_ranks, starts, cursor);
+        if (hipError_t e = hipExtGetLastError()) return e;
+    }
+    // (the unsorted weights have been consumed by the scatter: their array receives the weights in event order)
+    float* sorted_w = const_cast<float*>(wts);
+    if (n_rec) {
+        hipLaunchKernelGGL(k_tie_sort_runs<1024>, dim3(n_ranks), dim3(256), 0, s, runs, starts, counts, pos_bits, (int)n_ranks, sorted_w);
+        if (hipError_t e = hipExtGetLastError()) return e;
+        hipLaunchKernelGGL(k_tie_sort_runs<2048>, dim3(n_ranks), dim3(256), 0, s, runs, starts, counts, pos_bits, (int)n_ranks, sorted_w);
+        if (hipError_t e = hipExtGetLastError()) return e;
+        hipLaunchKernelGGL(k_tie_sort_runs<kTieRunLds>, dim3(n_ranks), dim3(256), 0, s, runs, starts, counts, pos_bits, (int)n_ranks, sorted_w);
+        if (hipError_t e = hipExtGetLastError()) return e;
+    }
+    hipLaunchKernelGGL(k_tie_add_runs, dim3((n_ranks + 3) / 4), dim3(256), 0, s, sorted_w, starts, counts, vox, nsv, n_cams, grid0, grid1,
+                       exact, count, diff);
     return hipExtGetLastError();
 }
 

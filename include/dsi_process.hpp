@@ -91,14 +91,19 @@ inline dsi::Transformation process_1(const LinearTrajectory& trajectory0, const 
 // getDepthMapFromDSI's arg-max): the same result as process_1(...) + mapper_fused.getDepthMapFromDSI(depth_map,
 // confidence_map, depth_cell_indices), bit for bit, but through ONE kernel that votes the cameras band by band in LDS,
 // fuses them per voxel and keeps the running arg-max on the CU (dsi_mapper_depth_map_of_events): no DSI is written.
-// The mappers supply the cameras' geometry and scratch; their dsi_ members are NOT updated.  n cameras (1..3).
+// The mappers supply the cameras' geometry and scratch; their dsi_ members are NOT updated.  n cameras (1..3); n = 4 (round
+// 6): the synthetic four-camera rig of BASELINE configs[4], for which process_1 has no switch -- fusion_method must be 3
+// (geometric mean) and the cameras are fused by the balanced tree of Grid3D::geometricMeanTwoGrids
+// (cartesian3dgrid.h:150-156; dsi_mapper_depth_map_of_events_n, DSI_ACC_GM_TREE).
 inline dsi::Transformation process_1_depth_map_n(const LinearTrajectory* const* trs, const std::vector<dsi::Event>* const* evs,
                                                  EMVS::MapperEMVS* const* mappers, int n, EMVS::MapperEMVS& mapper_out, double ts,
                                                  int fusion_method, dsi::Image<float>& depth_map,
                                                  dsi::Image<float>& confidence_map, dsi::Image<uint8_t>& depth_cell_indices,
                                                  double rv_pos = 0.0)
 {
-    if (n < 1 || n > 3) throw dsi::Error(DSI_ERR_INVALID, "process_1_depth_map: 1 to 3 cameras");
+    if (n < 1 || n > 4) throw dsi::Error(DSI_ERR_INVALID, "process_1_depth_map: 1 to 4 cameras");
+    if (n == 4 && fusion_method != DSI_FUSE_GM)
+        throw dsi::Error(DSI_ERR_BAD_OP, "process_1_depth_map: four cameras are fused by the geometric-mean tree (fusion_method 3)");
     dsi::Transformation T_w_l;
     if (!trs[0]->getPoseAt(ts, T_w_l)) throw dsi::Error(DSI_ERR_INVALID, "no pose at the reference timestamp");
     dsi::Transformation baseline;
@@ -106,8 +111,8 @@ inline dsi::Transformation process_1_depth_map_n(const LinearTrajectory* const* 
     const dsi::Transformation T_rv_w = dsi::inverse(T_w_l * baseline);  // process1.cpp:56-68
     double T7[7];
     T_rv_w.to7(T7);
-    dsi_mapper_t* ms[3] = {nullptr, nullptr, nullptr};
-    dsi_batch_t* bs[3] = {nullptr, nullptr, nullptr};
+    dsi_mapper_t* ms[4] = {nullptr, nullptr, nullptr, nullptr};
+    dsi_batch_t* bs[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<uint16_t> xs, ys;
     std::vector<uint32_t> first;
     std::vector<float> Rt;
@@ -131,7 +136,10 @@ inline dsi::Transformation process_1_depth_map_n(const LinearTrajectory* const* 
             else dsi::check(rc);
             dsi::check(dsi_batch_create(ctx, xs.data(), ys.data(), ne, first.data(), Rt.data(), np, &bs[c]));
         }
-        dsi::check(dsi_mapper_depth_map_of_events(mapper_out.handle(), ms, bs, n, fusion_method));
+        if (n == 4)
+            dsi::check(dsi_mapper_depth_map_of_events_n(mapper_out.handle(), ms, bs, n, DSI_ACC_GM_TREE));
+        else
+            dsi::check(dsi_mapper_depth_map_of_events(mapper_out.handle(), ms, bs, n, fusion_method));
         int nx, ny, nz;
         mapper_out.dsi_.getDimensions(&nx, &ny, &nz);
         depth_map = dsi::Image<float>(ny, nx);

@@ -302,6 +302,40 @@ int main()
                     }
                 }
             }
+            // four cameras (BASELINE configs[4]'s rig; process_1 has no switch for it): the DSI-less kernel with the geometric-mean
+            // tree == evaluateDSI x 4 + the tree inside the arg-max kernel (dsi_mapper_depth_map_of_fusion_n), bit for bit
+            {
+                const std::vector<dsi::Event> ev2(events1.begin() + (long)(events1.size() / 2), events1.end());
+                const std::vector<dsi::Event> ev3(events0.begin() + (long)(events0.size() / 3), events0.end());
+                EMVS::MapperEMVS mapper3(ctx, cam, dsi_shape), out4(ctx, cam, dsi_shape);
+                const LinearTrajectory* trs[4] = {&trajectory0, &trajectory1, &trajectory1, &trajectory0};
+                const std::vector<dsi::Event>* evs[4] = {&events0, &events1, &ev2, &ev3};
+                EMVS::MapperEMVS* ms4[4] = {&mapper0, &mapper1, &mapper2, &mapper3};
+                dsi::Image<float> d4, c4;
+                dsi::Image<uint8_t> i4;
+                const dsi::Transformation T4 = process_1_depth_map_n(trs, evs, ms4, 4, out4, 0.5, DSI_FUSE_GM, d4, c4, i4);
+                const dsi_grid_t* gs[4];
+                for (int c = 0; c < 4; ++c) {
+                    ms4[c]->evaluateDSI(*evs[c], *trs[c], T4);
+                    gs[c] = ms4[c]->dsi_.handle();
+                }
+                dsi::check(dsi_mapper_depth_map_of_fusion_n(mapper_fused.handle(), gs, 4, DSI_ACC_GM_TREE));
+                dsi::Image<float> d5(d4.rows, d4.cols), c5(d4.rows, d4.cols);
+                dsi::Image<uint8_t> i5(d4.rows, d4.cols);
+                dsi::check(dsi_mapper_fetch_depth_map(mapper_fused.handle(), d5.data.data(), c5.data.data(), i5.data.data()));
+                bool any = false;
+                for (float v : c4.data) any = any || v > 0.f;
+                if (d4.data != d5.data || c4.data != c5.data || i4.data != i5.data || !any) {
+                    std::printf("four-camera process_1_depth_map_n differs from evaluateDSI x 4 + the GM tree\n");
+                    return 68;
+                }
+                try {
+                    process_1_depth_map_n(trs, evs, ms4, 4, out4, 0.5, DSI_FUSE_HM, d4, c4, i4);
+                    return 69;
+                } catch (const dsi::Error& e) {
+                    if (e.code != DSI_ERR_BAD_OP) return 69;
+                }
+            }
             try {
                 process_1(trajectory0, trajectory1, trajectory1, events0, events1, none, mapper_fused, mapper0,
                           mapper1, mapper2, 0.5, 9);
