@@ -78,6 +78,11 @@ def test_vote_kernels_do_not_spill(tmp_path):
             assert val("vgpr_count") <= 64 and val("private_segment_fixed_size") <= 128, name
             continue
         assert val("vgpr_spill_count") == 0 and val("private_segment_fixed_size") == 0, name
+        if "k_tie_sort_runs" in name:
+            # a thread keeps up to 16 (key, bucket, rank, final slot) of its run in registers; the LDS (12 / 24 / 48 KB per
+            # 256-thread workgroup), not the registers, bounds the occupancy of these kernels
+            assert val("vgpr_count") <= 128, name
+            continue
         assert val("vgpr_count") <= 64, name
     assert tie >= 10
     # the hand-scheduled loops are in there and keep their waits
