@@ -2072,9 +2072,9 @@ int dsi_mapper_resolve_near_ties(dsi_mapper_t* out, dsi_mapper_t* const* mappers
         if (int rc = depth_buffers_acquire(out)) return rc;
         unsigned* cnt = reinterpret_cast<unsigned*>(ts.counters.p);
         HIP_TRY(dsi::launch_tie_pick(st, n == 2 ? op : 0, ts.cols.p, (int)n_columns, ts.cand.p, (int)n_cand, npix, ts.exact.p, ts.count.p,
-                                     ts.diff.p, out->planes_dev, out->conf.p, out->idx.p, out->depth.p, cnt + 4));
+                                     ts.diff.p, out->planes_dev, out->conf.p, out->idx.p, out->depth.p, cnt + 4, rel_gap));
         if (int rc = depth_buffers_ready(out)) return rc;
-        unsigned stats[3] = {0, 0, 0};
+        unsigned stats[4] = {0, 0, 0, 0};
         unsigned* pinned = nullptr;
         HIP_TRY(ts.host_counters(&pinned));
         HIP_TRY(hipMemcpyAsync(pinned, cnt, kTieCounterWords * sizeof(unsigned), hipMemcpyDeviceToHost, st));
@@ -2087,6 +2087,7 @@ int dsi_mapper_resolve_near_ties(dsi_mapper_t* out, dsi_mapper_t* const* mappers
         info->max_order_diff = (double)diff;  // (of the last pass: what its premise is checked with)
         info->max_rel_bound = stats[1] > 1 ? (double)(stats[1] - 1) * 5.9604644775390625e-8 : 0.0;
         info->changed_pixels += (int)stats[2];
+        info->columns_bounded = (int)stats[3];
         info->premise_ok = (8.0 * (double)diff < (double)rel_gap) ? 1 : 0;  // (false for a NaN difference, too)
         if (info->premise_ok || widenings == 3 || rel_gap * 4.f >= 0.5f) return finish();
         rel_gap *= 4.f;

@@ -232,10 +232,10 @@ hipError_t launch_tie_hits_binned(hipStream_t s, const float2* xy, const float* 
                                   unsigned* seg_counter, unsigned cap_segs, unsigned* flags, unsigned long long* total_hits,
                                   unsigned long long* keys, float* wts);
 // per near-tie column: op(exact camera 0, exact camera 1) (op 0: one camera), first maximum, patch; stats[0] = max float bits
-// of diff, [1] = max count, [2] += changed pixels
+// of diff, [1] = max count, [2] += changed pixels, [3] += columns whose gap covers their own contenders' worst-case bound
 hipError_t launch_tie_pick(hipStream_t s, int op, const uint4* cols, int n_cols, const uint32_t* vox, int nsv, int npix,
                            const float* exact, const uint32_t* count, const float* diff, const float* planes, float* conf,
-                           uint8_t* idx, float* depth, unsigned* stats);
+                           uint8_t* idx, float* depth, unsigned* stats, float rel_gap);
 // round 6, instead of a device-wide sort: the recorded votes partitioned by rank (camera * nsv + voxel) into runs[], each run
 // ordered by event position in LDS and added one by one in fp32.  counts / cursor: n_cams * nsv words, starts: one more (scratch);
 // runs: n_rec words; wts is consumed (it receives the weights in event order).  exact[cam * nsv + c], count[...] <- sequential fp32

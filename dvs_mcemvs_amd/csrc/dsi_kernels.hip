@@ -4694,12 +4694,13 @@ __global__ __launch_bounds__(256) void k_tie_pick(const uint4* __restrict__ cols
                                                   const uint32_t* __restrict__ count, const float* __restrict__ diff,
                                                   const float* __restrict__ planes, float* __restrict__ conf,
                                                   uint8_t* __restrict__ idx, float* __restrict__ depth,
-                                                  unsigned* __restrict__ stats)
+                                                  unsigned* __restrict__ stats, float rel_gap)
 {
-    // stats[0] = max float bits of diff[], stats[1] = max votes of a voxel, stats[2] += changed pixels: one global atomic each
-    // per WORKGROUP (thousands on one address serialise at ~50 ns apiece)
-    __shared__ unsigned s_stats[3];
-    if (threadIdx.x < 3) s_stats[threadIdx.x] = 0u;
+    // stats[0] = max float bits of diff[], stats[1] = max votes of a voxel, stats[2] += changed pixels, stats[3] += columns whose
+    // gap exceeds the worst-case reordering bound of their own most-voted contender (see below): one global atomic each per
+    // WORKGROUP (thousands on one address serialise at ~50 ns apiece)
+    __shared__ unsigned s_stats[4];
+    if (threadIdx.x < 4) s_stats[threadIdx.x] = 0u;
     __syncthreads();
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < n_cols) {
@@ -4728,12 +4729,21 @@ __global__ __launch_bounds__(256) void k_tie_pick(const uint4* __restrict__ cols
         depth[p] = planes[best_z];
         atomicMax(&s_stats[0], dmax);
         atomicMax(&s_stats[1], cmax);
+        // The column's own worst case: a value summed in fp32 from n positive votes is within (n - 1) 2^-24 of the exact sum
+        // (relative), the engine's value within 2^-24 + n 2^-31; the 2-ary op adds a few ulps.  With n = the most votes any of the
+        // column's CONTENDERS has (either camera), a plane outside the gap could overtake the engine's best only if its error and
+        // the best's together exceeded the gap: gap >= 2 (n 2^-24 + 2^-22) rules that out for planes with no more votes than n.
+        // (Planes outside the gap with MORE votes than every contender are not covered: their counts are not known.  A
+        // statistic beside the measured premise check, not a proof.)
+        const float bound = 2.f * ((float)cmax * 5.9604644775390625e-8f + 2.384185791015625e-7f);
+        if (rel_gap >= bound) atomicAdd(&s_stats[3], 1u);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         if (s_stats[0]) atomicMax(&stats[0], s_stats[0]);
         if (s_stats[1]) atomicMax(&stats[1], s_stats[1]);
         if (s_stats[2]) atomicAdd(&stats[2], s_stats[2]);
+        if (s_stats[3]) atomicAdd(&stats[3], s_stats[3]);
     }
 }
 
@@ -5574,14 +5584,14 @@ hipError_t launch_tie_partition_sums(hipStream_t s, const unsigned long long* ke
 
 hipError_t launch_tie_pick(hipStream_t s, int op, const uint4* cols, int n_cols, const uint32_t* vox, int nsv, int npix,
                            const float* exact, const uint32_t* count, const float* diff, const float* planes, float* conf,
-                           uint8_t* idx, float* depth, unsigned* stats)
+                           uint8_t* idx, float* depth, unsigned* stats, float rel_gap)
 {
     if (n_cols <= 0) return hipSuccess;
     const dim3 grid((n_cols + 255) / 256), block(256);
 #define DSI_TIE_PICK(OPV)                                                                                                        \
     case OPV:                                                                                                                    \
         hipLaunchKernelGGL(k_tie_pick<OPV>, grid, block, 0, s, cols, n_cols, vox, nsv, npix, exact, count, diff, planes, conf, idx,   \
-                           depth, stats);                                                                                        \
+                           depth, stats, rel_gap);                                                                               \
         break;
     switch (op) {
         DSI_TIE_PICK(0) DSI_TIE_PICK(1) DSI_TIE_PICK(2) DSI_TIE_PICK(3) DSI_TIE_PICK(4) DSI_TIE_PICK(5) DSI_TIE_PICK(6)

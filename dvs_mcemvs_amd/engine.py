@@ -61,7 +61,7 @@ class _ResolveInfo(C.Structure):
     _fields_ = [("rel_gap", C.c_float), ("near_tie_pixels", C.c_int), ("candidate_voxels", C.c_int),
                 ("candidate_planes", C.c_int), ("votes", C.c_longlong), ("changed_pixels", C.c_int),
                 ("max_rel_bound", C.c_double), ("max_order_diff", C.c_double), ("elapsed_ms", C.c_float),
-                ("gap_widenings", C.c_int), ("premise_ok", C.c_int)]
+                ("gap_widenings", C.c_int), ("premise_ok", C.c_int), ("columns_bounded", C.c_int)]
 
 
 class _VoteInfo(C.Structure):

@@ -511,6 +511,11 @@ typedef struct {
     int gap_widenings;      /*      passes repeated with a 4 x wider gap because max_order_diff reached rel_gap / 8 (0..3) */
     int premise_ok;         /*      1: 8 * max_order_diff < rel_gap held in the last pass.  0: it did not even at the widest gap
                                     tried -- the index map is then NOT known to equal the reference's */
+    int columns_bounded;    /*      near-tie columns (of the last pass) whose gap also covers the WORST-CASE reordering error of
+                                    their own most-voted contender, 2 ((votes) 2^-24 + 2^-22): for those no plane with at most
+                                    that many votes can have been left out wrongly.  (Planes outside the gap with more votes than
+                                    every contender are not covered -- the engine keeps no per-voxel vote counts --, so this is a
+                                    statistic beside premise_ok, not a proof.) */
 } dsi_resolve_info_t;
 DSI_API int dsi_mapper_resolve_near_ties(dsi_mapper_t *out, dsi_mapper_t *const *mappers,
                                          const dsi_batch_t *const *batches, int n, int op, dsi_resolve_info_t *info);
