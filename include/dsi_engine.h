@@ -278,7 +278,9 @@ DSI_API int dsi_mapper_set_band_params(dsi_mapper_t *m, int band_rows, int chunk
  *     (x, x + 1) of a row, a vote is two atomics instead of four (the voting kernels are bound by the LDS atomic unit).
  *     The price is the numerical contract: the weights of cartesian3dgrid.h:261-270 are added as ROUNDED Q.19 integers
  *     (error <= 2^-20 per vote, about that of the reference's own fp32 "+=") instead of the exact Q33.31 sums every other
- *     mapping keeps, the DSI is no longer bit-identical to theirs, and a 32-bit cell holds 8,192 full votes per work
+ *     mapping keeps -- a record whose weight on a cell is below 2^-20 adds nothing, so bursts of events on one sub-pixel
+ *     location can lose up to 2^-20 per record on the neighbouring cells --, the DSI is no longer bit-identical to
+ *     theirs, and a 32-bit cell holds 8,192 full votes per work
  *     item: the voting kernel reports any cell that reached HALF of that (dsi_mapper_paired_overflow), in which case the
  *     caller repeats the call with another mapping.  1024-thread workgroups, the evaluate / fillVoxelGrid path only. */
 DSI_API int dsi_mapper_set_packed_lanes(dsi_mapper_t *m, int mode);
