@@ -2,7 +2,7 @@
 # Per-round profiles of every workload (on the GPU box): rocprofv3 kernel trace + stats of the timed steps, PMC counters in their own
 # passes (never combined with other trace domains), for the default bench (configs[1]), the configs[2] window stream
 # (one stream, so that per-kernel durations are not inflated by the overlap of consecutive windows), the configs[4]
-# shape and the 1024x1024x256 stereo shape.   tools/profile_workloads.sh r04 [stereo windows windows_two_streams cameras4 cameras4_full 1024]  ->  gpurun_out/profiles_r04_*/
+# shape and the 1024x1024x256 stereo shape.   tools/profile_workloads.sh r04 [stereo windows windows_two_streams cameras4 cameras4_unfused cameras4_full 1024]  ->  gpurun_out/profiles_r04_*/
 set -u
 cd "$(dirname "$0")/.."
 R=${1:-r04}
@@ -34,8 +34,10 @@ want stereo && one ${R}_stereo "--no-host-fed --steps 50 --warmup 5" "--no-sensi
 want stereo && python tools/make_traffic_json.py gpurun_out/profiles_${R}_stereo/pmc_counters.txt 512 512 200 > gpurun_out/profiles_${R}_stereo/traffic.json
 want windows && one ${R}_windows "--workload windows --serial-windows --no-host-fed --steps 50 --warmup 5" "--workload windows --serial-windows --no-host-fed --steps 3 --warmup 1" "$SQ1" "$SQ2" "$SQ3" "FETCH_SIZE" "WRITE_SIZE"
 want windows_two_streams && one ${R}_windows_two_streams "--workload windows --no-host-fed --steps 50 --warmup 5" "" 
-want cameras4 && one ${R}_cameras4 "--workload cameras4 --camera-streams 1 --no-host-fed --steps 10 --warmup 2" "--workload cameras4 --camera-streams 1 --no-host-fed --steps 3 --warmup 1 --clock-ramp 0" "$SQ1" "$SQ3"
-# BASELINE configs[4] at its own size (4 x 100 M events): the kernel trace of the bench's cameras4_full sub-run
-want cameras4_full && one ${R}_cameras4_full "--workload cameras4 --events 100000000 --tile 10 --camera-streams 1 --no-host-fed --steps 3 --warmup 1 --clock-ramp 1" ""
+want cameras4 && one ${R}_cameras4 "--workload cameras4 --camera-streams 1 --no-host-fed --steps 10 --warmup 2" "--workload cameras4 --camera-streams 1 --no-host-fed --steps 3 --warmup 1 --clock-ramp 0" "$SQ1" "$SQ2" "$SQ3" "FETCH_SIZE" "WRITE_SIZE"
+# the same shape through the banded kernels with the DSIs written (the round-5 path of this workload), for comparison
+want cameras4_unfused && one ${R}_cameras4_unfused "--workload cameras4 --no-fused-vote --camera-streams 1 --no-host-fed --steps 10 --warmup 2" "--workload cameras4 --no-fused-vote --camera-streams 1 --no-host-fed --steps 3 --warmup 1 --clock-ramp 0" "$SQ1" "$SQ2"
+# BASELINE configs[4] at its own size (4 x 100 M events): the kernel trace of the bench's cameras4_full sub-run + its counters
+want cameras4_full && one ${R}_cameras4_full "--workload cameras4 --events 100000000 --tile 10 --camera-streams 1 --no-host-fed --steps 3 --warmup 1 --clock-ramp 1" "--workload cameras4 --events 100000000 --tile 10 --camera-streams 1 --no-host-fed --steps 1 --warmup 1 --clock-ramp 0" "$SQ1" "$SQ2" "FETCH_SIZE" "WRITE_SIZE"
 want 1024 && one ${R}_1024 "--dims 1024 1024 256 --events 10000000 --no-host-fed --steps 10 --warmup 2" "--dims 1024 1024 256 --events 10000000 --no-host-fed --steps 3 --warmup 1" "$SQ1" "$SQ2" "$SQ3"
 ls -la gpurun_out/profiles_${R}_*
