@@ -538,11 +538,14 @@ bool plan_fused(const dsi_mapper* m, size_t n_packets_max, dsi::BandPlan* bp, in
     bp->persistent = 0;
     bp->halo = 1;
     bp->experiment = 0;
+    bp->interleave = -1;  // decided by the caller from the cameras' packet counts (depth_map_of_events_impl)
 #ifdef DSI_TIMING_EXPERIMENTS
     if (const char* e = std::getenv("DSI_FUSED_2CU"))  // 0: a small band still runs one workgroup per CU (A/B)
         if (std::atoi(e) == 0) bp->experiment = 300;
     if (const char* e = std::getenv("DSI_FUSED_DEFER"))  // 0: camera 1's fusion + arg-max inside its read-back, as before round 6 (A/B)
         if (std::atoi(e) == 0) bp->experiment = 301;
+    if (const char* e = std::getenv("DSI_FUSED_INTERLEAVE"))  // A/B: 0 contiguous pieces, 1 pairs in turn
+        bp->interleave = std::atoi(e) != 0 ? 1 : 0;
 #endif
     return true;
 }
@@ -1782,6 +1785,18 @@ static int depth_map_of_events_impl(dsi_mapper_t* out, dsi_mapper_t* const* mapp
     // every knob of this path (lane mapping, band height, the kernel timer, the experiments flavour's pass size, partition
     // cost and tracing) is read from ONE object, the output mapper; the vote info is recorded on it and on the cameras
     REQUIRE(plan_fused(out, np_max, &bp, n), DSI_ERR_INVALID, "grid rows of %d floats do not fit the fused kernel", out->geom.nx);
+    if (bp.interleave < 0) {
+        // Which pairs a workgroup takes: a contiguous piece of its XCD's stretch, or every 32nd pair (all 32 workgroups of an
+        // XCD on consecutive planes of ONE band).  With contiguous pieces an XCD works on bands / 8 + 1 bands at once; when
+        // their records (all cameras') exceed its 4 MB of L2 every phase re-reads its band from the Infinity Cache -- four
+        // cameras x 2 M events at 1024 x 1024 x 256: 13 MB, 4.6 TB/s; in turn: 6.10 -> 5.76 ms per step.  A 50 ms stereo window
+        // (2.5 MB) measures the same either way and keeps the contiguous pieces (one band change per workgroup).
+        double records_bytes = 0.0;
+        for (int i = 0; i < n; ++i) records_bytes += (double)batches[i]->n_packets * dsi::kPacket * sizeof(dsi::EvRec);
+        const double band_bytes = records_bytes * (double)(bp.band_rows + 2) / (double)std::max(1, out->geom.ny);
+        const int at_once = std::min(32, bp.bands / 8 + 1);
+        bp.interleave = band_bytes * at_once > 3.0e6 ? 1 : 0;
+    }
     const dsi::Geom& geom = mappers[0]->geom;
     hipStream_t st = ctx->stream;
     dsi::FusedCameras cams{};

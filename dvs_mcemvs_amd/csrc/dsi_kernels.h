@@ -65,6 +65,7 @@ struct BandPlan {
     int halo;           // 1: a band also takes the events of the row above its first owned row and keeps a halo row
                         // on either side in LDS ((band_rows + 2) rows; k_vote_fuse_argmax), 0: carry row ((band_rows + 1))
     int experiment;     // DSI_EXPERIMENT (timing experiments only, results are wrong): 1 no votes, 2 no flush
+    int interleave;     // k_vote_fuse_argmax: an XCD's workgroups take the pairs of its stretch in turn (see the kernel)
     int cuts_inline;    // mappings 5 / 6 with many packets: NO cut table (bands x planes x packets words: 6.1 GB per camera at
                         // 1024 x 1024 x 256 with 100 M events, 3.9 ms to write); the voting kernel's `cuts` argument is then the
                         // TRANSPOSED row table u16 [ny + 2 row_pad + 3][rs_stride] (k_transpose_rowstart) and every pass

@@ -426,6 +426,34 @@ def test_fused_four_cameras_geometric_mean_tree(ctx, packed, shape, band_rows):
         o.close()
 
 
+@pytest.mark.parametrize("n_cams", [2, 4])
+def test_fused_kernel_with_the_pairs_taken_in_turn(ctx, n_cams):
+    """Round 6: when the bands an XCD works on at once hold more records than its L2 (here 4 / 2 cameras x 1.2 M events at
+    512 x 512 x 24: 5 bands x 1.8 / 0.9 MB), the XCD's workgroups take the (band, plane) pairs of its stretch IN TURN -- all 32 on
+    consecutive planes of one band -- instead of a contiguous piece each.  Which workgroup votes a pair changes no bit:
+    the depth map is that of evaluateDSI x n + the fusion inside the arg-max."""
+    nx, ny, nz = 512, 512, 24
+    rig = syn.stereo_rig(1_200_000, width=nx, height=ny, duration=0.3, seed=91, n_points=4000, n_cams=4)
+    sh = d.ShapeDSI(0, 0, nz, 4.0, 150.0, 0.0)
+    batches = rig_batches(ctx, rig, n_cams)
+    ref_m = [d.MapperEMVS(ctx, rig["cam"], sh) for _ in range(n_cams)]
+    fus_m = [d.MapperEMVS(ctx, rig["cam"], sh) for _ in range(n_cams + 1)]
+    for m, b in zip(ref_m, batches):
+        m.evaluateDSI_batch(b)
+    if n_cams == 4:
+        ref_m[0].computeDepthMapOfFusionN([m.dsi_ for m in ref_m], d.ACC_GM_TREE)
+        fus_m[-1].computeDepthMapOfEventsN(fus_m[:4], batches)
+    else:
+        ref_m[0].computeDepthMapOfFusion(ref_m[0].dsi_, ref_m[1].dsi_, d.FUSE_HM)
+        fus_m[-1].computeDepthMapOfEvents(fus_m[:2], batches, d.FUSE_HM)
+    want, got = ref_m[0].fetchDepthMap(), fus_m[-1].fetchDepthMap()
+    for g, w, name in zip(got, want, ("depth", "confidence", "index")):
+        assert np.array_equal(g, w), "%s differs at %d pixels" % (name, (g != w).sum())
+    assert want[1].max() > 0.5
+    for o in ref_m + fus_m + batches:
+        o.close()
+
+
 @pytest.mark.parametrize("packed", [-1, 3, 5])
 def test_fused_three_cameras_follow_process_1(ctx, packed):
     """The trinocular rig (EVIMO2; process1.cpp:105-117, :169-191): fused = op(dsi0, dsi1), then min /
