@@ -544,8 +544,8 @@ bool plan_fused(const dsi_mapper* m, size_t n_packets_max, dsi::BandPlan* bp, in
         if (std::atoi(e) == 0) bp->experiment = 300;
     if (const char* e = std::getenv("DSI_FUSED_DEFER"))  // 0: camera 1's fusion + arg-max inside its read-back, as before round 6 (A/B)
         if (std::atoi(e) == 0) bp->experiment = 301;
-    if (const char* e = std::getenv("DSI_FUSED_INTERLEAVE"))  // A/B: 0 contiguous pieces, 1 pairs in turn
-        bp->interleave = std::atoi(e) != 0 ? 1 : 0;
+    if (const char* e = std::getenv("DSI_FUSED_INTERLEAVE"))  // A/B: 0 contiguous pieces, 1 pairs in turn, 2 pairs drawn
+        bp->interleave = std::min(2, std::max(0, std::atoi(e)));
 #endif
     return true;
 }
@@ -1786,16 +1786,19 @@ static int depth_map_of_events_impl(dsi_mapper_t* out, dsi_mapper_t* const* mapp
     // cost and tracing) is read from ONE object, the output mapper; the vote info is recorded on it and on the cameras
     REQUIRE(plan_fused(out, np_max, &bp, n), DSI_ERR_INVALID, "grid rows of %d floats do not fit the fused kernel", out->geom.nx);
     if (bp.interleave < 0) {
-        // Which pairs a workgroup takes: a contiguous piece of its XCD's stretch, or every 32nd pair (all 32 workgroups of an
-        // XCD on consecutive planes of ONE band).  With contiguous pieces an XCD works on bands / 8 + 1 bands at once; when
-        // their records (all cameras') exceed its 4 MB of L2 every phase re-reads its band from the Infinity Cache -- four
-        // cameras x 2 M events at 1024 x 1024 x 256: 13 MB, 4.6 TB/s; in turn: 6.10 -> 5.76 ms per step.  A 50 ms stereo window
-        // (2.5 MB) measures the same either way and keeps the contiguous pieces (one band change per workgroup).
+        // Which pairs a workgroup takes: a contiguous piece of its XCD's stretch (0), or -- all 32 workgroups of an XCD on
+        // consecutive planes of ONE band -- every 32nd pair (1) / the next pair drawn from the XCD's counter (2).  With
+        // contiguous pieces an XCD works on bands / 8 + 1 bands at once; when their records (all cameras') exceed its 4 MB of
+        // L2 every phase re-reads its band from the Infinity Cache -- four cameras x 2 M events at 1024 x 1024 x 256: 13 MB,
+        // 4.6 TB/s; in turn: 6.10 -> 5.76 ms per step (kernel 5.89 -> 5.55), drawn: 5.50 (a workgroup's 74 pairs differ in
+        // cost; the draw is one atomic per pair).  A 50 ms stereo window (2.5 MB) measures the same all three ways -- its
+        // kernel lasts ceil(2800 pairs / 256 workgroups) = 11 pairs of equal cost however they are dealt -- and keeps the
+        // contiguous pieces (one band change per workgroup).
         double records_bytes = 0.0;
         for (int i = 0; i < n; ++i) records_bytes += (double)batches[i]->n_packets * dsi::kPacket * sizeof(dsi::EvRec);
         const double band_bytes = records_bytes * (double)(bp.band_rows + 2) / (double)std::max(1, out->geom.ny);
         const int at_once = std::min(32, bp.bands / 8 + 1);
-        bp.interleave = band_bytes * at_once > 3.0e6 ? 1 : 0;
+        bp.interleave = band_bytes * at_once > 3.0e6 ? 2 : 0;
     }
     const dsi::Geom& geom = mappers[0]->geom;
     hipStream_t st = ctx->stream;
@@ -1858,8 +1861,8 @@ static int depth_map_of_events_impl(dsi_mapper_t* out, dsi_mapper_t* const* mapp
     if (int rc = depth_buffers_acquire(out)) return rc;
     // one key per pixel, zero before the kernel: zeroed once when (re)allocated, then by every unpack
     // (or after a call that failed between the voting kernel and the unpack)
-    if (out->fused_keys.cap < npix || out->fused_keys_dirty) {
-        HIP_TRY(out->fused_keys.reserve(npix));
+    if (out->fused_keys.cap < npix + dsi::kFusedKeyTail || out->fused_keys_dirty) {
+        HIP_TRY(out->fused_keys.reserve(npix + dsi::kFusedKeyTail));  // (+ the pair-dealing counters)
         HIP_TRY(hipMemsetAsync(out->fused_keys.p, 0, out->fused_keys.cap * sizeof(unsigned long long), st));
     }
     out->fused_keys_dirty = true;

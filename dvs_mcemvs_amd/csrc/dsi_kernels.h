@@ -65,7 +65,8 @@ struct BandPlan {
     int halo;           // 1: a band also takes the events of the row above its first owned row and keeps a halo row
                         // on either side in LDS ((band_rows + 2) rows; k_vote_fuse_argmax), 0: carry row ((band_rows + 1))
     int experiment;     // DSI_EXPERIMENT (timing experiments only, results are wrong): 1 no votes, 2 no flush
-    int interleave;     // k_vote_fuse_argmax: an XCD's workgroups take the pairs of its stretch in turn (see the kernel)
+    int interleave;     // k_vote_fuse_argmax: 1 an XCD's workgroups take the pairs of its stretch in turn, 2 they DRAW them from
+                        // the XCD's counter behind the keys (and from the other XCDs' once theirs is dry); see the kernel
     int cuts_inline;    // mappings 5 / 6 with many packets: NO cut table (bands x planes x packets words: 6.1 GB per camera at
                         // 1024 x 1024 x 256 with 100 M events, 3.9 ms to write); the voting kernel's `cuts` argument is then the
                         // TRANSPOSED row table u16 [ny + 2 row_pad + 3][rs_stride] (k_transpose_rowstart) and every pass
@@ -196,7 +197,9 @@ hipError_t launch_store_depth_map(hipStream_t s, const float* depth, const float
 hipError_t launch_fuse_n(hipStream_t s, float* dst, const float* const* srcs, int n_src, size_t n, int mode);
 hipError_t launch_pack_argmax(hipStream_t s, const float* conf, const uint8_t* idx, int n, int plane_begin,
                               unsigned long long* keys, int combine = 0);
-// clear != 0: the keys are zeroed as they are read (the fused vote kernel needs them zero before it runs)
+// clear != 0: the keys are zeroed as they are read (the fused vote kernel needs them zero before it runs) -- and so are the
+// kFusedKeyTail 64-bit words BEHIND the n keys, which such a buffer must have: the fused kernel's pair-dealing counters
+constexpr int kFusedKeyTail = 8;
 hipError_t launch_unpack_argmax(hipStream_t s, unsigned long long* keys, int n, const float* planes_full,
                                 float* conf, uint8_t* idx, float* depth, int clear = 0);
 hipError_t launch_collapse_max_z(hipStream_t s, const float* dsi, int nx, int ny, int nz,

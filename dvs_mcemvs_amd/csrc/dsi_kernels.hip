@@ -2707,7 +2707,7 @@ __device__ __forceinline__ void fused_consume(acc_t* __restrict__ band, int nx, 
 // FOUR (round 6): four cameras fused by the balanced tree of the reference's 2-ary geometric mean (DSI_ACC_GM_TREE,
 // cartesian3dgrid.h:150-156 applied pairwise: BASELINE configs[4]) -- camera 0 kept, camera 1 folded into it, camera 2 kept in
 // a second register array, camera 3 closes both pairs and the root; same bits as k_collapse_max_z_gm_tree<4> on the four DSIs.
-template <int MAPPING, int CELLS, bool DEFER = false, bool FOUR = false>
+template <int MAPPING, int CELLS, bool DEFER = false, bool FOUR = false, bool DEAL = true>
 __device__ __forceinline__ void vote_fuse_argmax_body(const FusedCameras& cams, const Geom& g, const BandPlan& bp, int op,
                                                       const uint32_t* __restrict__ splits,
                                                       unsigned long long* __restrict__ keys,
@@ -2725,6 +2725,17 @@ __device__ __forceinline__ void vote_fuse_argmax_body(const FusedCameras& cams, 
     // k_fused_splits has balanced the partition by the records each pair holds.
     const int P = bp.bands * g.nz;
     int q_begin, q_end, q_step = 1;
+    // DEALT (bp.interleave == 2, round 6): as "in turn", but only a workgroup's FIRST pair is fixed; every further pair is drawn
+    // from its XCD's counter (one global atomic per pair, by thread 0, while the other waves finish camera 0's stream), and a
+    // workgroup whose XCD has run dry draws from the next XCD's counter.  The pairs a workgroup meets still ascend within a
+    // stretch (few band changes), the workgroups of an XCD still share one band's records at a time, and the kernel no
+    // longer lasts as long as the workgroup whose FIXED share was the slowest (span / mean busy time 1.11 with fixed
+    // shares: the dense middle bands are slow per record).  Which workgroup votes a pair changes no bit.
+    // Counters: 8 words behind the keys, zero at launch (k_unpack_argmax re-zeroes them with the keys).
+    // (DEAL = false: the two-workgroups-per-CU kernel, at 64 registers, takes its pairs in turn instead)
+    const bool dealt = DEAL && !splits && bp.interleave == 2;
+    __shared__ int s_next_q[2];
+    __shared__ int s_deal_tries;
     if (splits) {
         // rank = position of this workgroup in XCD-major order: XCD x still covers one contiguous stretch
         const int rank = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
@@ -2733,7 +2744,10 @@ __device__ __forceinline__ void vote_fuse_argmax_body(const FusedCameras& cams, 
     } else {
         const int x = blockIdx.x & 7, l = blockIdx.x >> 3, per = gridDim.x >> 3;
         const int lo = (int)(((long long)P * x) / 8), hi = (int)(((long long)P * (x + 1)) / 8);
-        if (bp.interleave) {
+        if (dealt) {
+            q_begin = lo + l;
+            q_end = hi;
+        } else if (bp.interleave) {
             // the XCD's workgroups take the pairs of its stretch in turn: 32 workgroups on 32 consecutive planes of ONE band at a
             // time, so that the band's records (all cameras') stay in that XCD's L2 while they are read once per plane --
             // with contiguous pieces 32 workgroups work on ~9 bands at once at 1024 x 1024 x 256 (four cameras x 375 KB each:
@@ -2751,9 +2765,13 @@ __device__ __forceinline__ void vote_fuse_argmax_body(const FusedCameras& cams, 
     {
         const int all_cells = (bp.band_rows + 2) * nx;
         for (int i = threadIdx.x; i < all_cells; i += BLOCK) band[i] = 0;
-        if (threadIdx.x == 0) s_pass = kPass0;
+        if (threadIdx.x == 0) {
+            s_pass = kPass0;
+            s_deal_tries = 0;
+        }
     }
     __syncthreads();
+    if (dealt) q_end = P;  // (a drawn pair may lie in another XCD's stretch; "none" is beyond every pair)
 
     // The cameras' table is read where it lies, in the kernel-argument segment, with scalar loads at the (uniform)
     // camera index: indexing the by-value array dynamically made the compiler keep all three cameras' pointers in
@@ -2818,8 +2836,10 @@ __device__ __forceinline__ void vote_fuse_argmax_body(const FusedCameras& cams, 
             }
         }
     };
-    for (int q = q_begin; q < q_end; q += q_step) {
+    int it = 0;  // pairs this workgroup has begun
+    for (int q = q_begin; q < q_end; ++it) {
         const int j = q / g.nz, z = q - j * g.nz;
+        int q_next = q + q_step;  // (DEALT: read from s_next_q behind the last phase's first barrier)
         if (j != cur_j) {
             run_pending();  // (the last pair of the band that ends here)
             if (cur_j >= 0) emit();
@@ -2845,7 +2865,7 @@ __device__ __forceinline__ void vote_fuse_argmax_body(const FusedCameras& cams, 
             // phase, wave): stream begins, stream ends, after the barrier + the read-back / clear, after the closing barrier
             int tr = -1;  // (wave-uniform: lives in a scalar register)
             if (trace) {
-                const int phase = ((q - q_begin) / q_step) * cams.n + c;
+                const int phase = it * cams.n + c;
                 if (phase < kFusedTracePhases)
                     tr = __builtin_amdgcn_readfirstlane((((int)blockIdx.x * kFusedTracePhases + phase) * (BLOCK / kWave) + (int)(threadIdx.x / kWave)) * 4);
             }
@@ -2858,15 +2878,44 @@ __device__ __forceinline__ void vote_fuse_argmax_body(const FusedCameras& cams, 
             stream_item<BLOCK, MAPPING, true, true>(cam.sxy, cam.coef, cam.cuts, cam.slow_any, cam.np, g, bp, j, z, 0, cam.np,
                                         reinterpret_cast<char*>(band), Li, Ui, r0 - 1, &s_pass, cuts_now);
             // the next phase's first cut words travel during this phase's barrier and read-back
+            const bool last = c == n_cams - 1;
             if (c + 1 < n_cams)
                 cuts_next = first_cuts_of(q, c + 1);
-            else if (q + q_step < q_end)
+            else if (!dealt && q + q_step < q_end)
                 cuts_next = first_cuts_of(q + q_step, 0);
             run_pending();  // the previous pair's fusion + arg-max update, while the other waves finish their passes
+            if (dealt && c == 0 && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0) {
+                // the next pair of this workgroup: its XCD's counter first, then the other XCDs' in turn (the first `per`
+                // pairs of every stretch are the workgroups' fixed first pairs).  Wave 0, scalar code but for the atomic.
+                // (P < 2^24: at most 2^16 rows -- 16-bit row tables -- and 256 planes -- 8-bit plane indices in the keys)
+                const int xcd = (int)(blockIdx.x & 7), per = (int)(gridDim.x >> 3);
+                unsigned* const ctr = reinterpret_cast<unsigned*>(keys + (size_t)g.nx * g.ny);
+                int tries = __builtin_amdgcn_readfirstlane(s_deal_tries);  // XCDs this workgroup has found dry
+                int nq = 0x7fffffff;
+                while (tries < 8) {
+                    const int xx = (xcd + tries) & 7;
+                    unsigned got = 0u;
+                    if ((threadIdx.x & 63) == 0) got = atomicAdd(&ctr[xx], 1u);
+                    const int cand = (P * xx) / 8 + per + (int)__builtin_amdgcn_readfirstlane(got);
+                    if (cand < (P * (xx + 1)) / 8) {
+                        nq = cand;
+                        break;
+                    }
+                    ++tries;
+                }
+                if ((threadIdx.x & 63) == 0) {
+                    s_deal_tries = tries;
+                    s_next_q[it & 1] = nq;
+                }
+            }
             DSI_FUSED_STAMP(1);
             __syncthreads();
             if (threadIdx.x == 0) s_pass = kPass0;
-            const bool last = c == n_cams - 1;
+            if (dealt && last) {
+                // (written before the first barrier of this pair's camera-0 phase; slot it & 1 is next written two pairs on)
+                q_next = __builtin_amdgcn_readfirstlane(s_next_q[it & 1]);
+                if (q_next < P) cuts_next = first_cuts_of(q_next, 0);
+            }
             if constexpr (FOUR) {
                 if (c == 0)
                     fused_consume<CELLS, 3, FUSED_KEEP>(band, nx, n_own, rows_lds, va, fb, z);
@@ -2915,6 +2964,7 @@ __device__ __forceinline__ void vote_fuse_argmax_body(const FusedCameras& cams, 
             __syncthreads();
             DSI_FUSED_STAMP(3);
         }
+        q = q_next;
     }
     run_pending();
     emit();
@@ -2939,7 +2989,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     FusedCameras cams, Geom g, BandPlan bp, int op, const uint32_t* __restrict__ splits,
     unsigned long long* __restrict__ keys, unsigned long long* __restrict__ trace)
 {
-    vote_fuse_argmax_body<MAPPING, CELLS>(cams, g, bp, op, splits, keys, trace);
+    vote_fuse_argmax_body<MAPPING, CELLS, false, false, false>(cams, g, bp, op, splits, keys, trace);
 }
 
 // Balanced partition of the (band-major) pair list for the fused kernel: pair q costs work0[q] + work1[q]
@@ -5283,6 +5333,8 @@ __global__ __launch_bounds__(256) void k_unpack_argmax(unsigned long long* __res
                                                        float* __restrict__ depth, int clear)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // (clear: the buffer is the fused kernel's -- n keys + kFusedKeyTail words, the tail = its pair-dealing counters)
+    if (clear && i < 2 * kFusedKeyTail) reinterpret_cast<unsigned*>(keys + n)[i] = 0u;
     if (i >= n) return;
     const unsigned long long k = keys[i];
     if (clear) keys[i] = 0ull;  // ready for the next fused vote (saves a memset launch per window)

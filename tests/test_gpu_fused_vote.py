@@ -430,8 +430,10 @@ def test_fused_four_cameras_geometric_mean_tree(ctx, packed, shape, band_rows):
 def test_fused_kernel_with_the_pairs_taken_in_turn(ctx, n_cams):
     """Round 6: when the bands an XCD works on at once hold more records than its L2 (here 4 / 2 cameras x 1.2 M events at
     512 x 512 x 24: 5 bands x 1.8 / 0.9 MB), the XCD's workgroups take the (band, plane) pairs of its stretch IN TURN -- all 32 on
-    consecutive planes of one band -- instead of a contiguous piece each.  Which workgroup votes a pair changes no bit:
-    the depth map is that of evaluateDSI x n + the fusion inside the arg-max."""
+    consecutive planes of one band -- instead of a contiguous piece each: the first pair fixed, every further pair DRAWN from
+    the XCD's counter behind the arg-max keys (and from the other XCDs' once that one is dry).  Which workgroup votes a
+    pair changes no bit: the depth map is that of evaluateDSI x n + the fusion inside the arg-max.  Called twice: the
+    counters must be zero again for the second call (k_unpack_argmax clears them with the keys)."""
     nx, ny, nz = 512, 512, 24
     rig = syn.stereo_rig(1_200_000, width=nx, height=ny, duration=0.3, seed=91, n_points=4000, n_cams=4)
     sh = d.ShapeDSI(0, 0, nz, 4.0, 150.0, 0.0)
@@ -446,9 +448,16 @@ def test_fused_kernel_with_the_pairs_taken_in_turn(ctx, n_cams):
     else:
         ref_m[0].computeDepthMapOfFusion(ref_m[0].dsi_, ref_m[1].dsi_, d.FUSE_HM)
         fus_m[-1].computeDepthMapOfEvents(fus_m[:2], batches, d.FUSE_HM)
-    want, got = ref_m[0].fetchDepthMap(), fus_m[-1].fetchDepthMap()
-    for g, w, name in zip(got, want, ("depth", "confidence", "index")):
-        assert np.array_equal(g, w), "%s differs at %d pixels" % (name, (g != w).sum())
+    want = ref_m[0].fetchDepthMap()
+    for call in range(2):
+        if call:
+            if n_cams == 4:
+                fus_m[-1].computeDepthMapOfEventsN(fus_m[:4], batches)
+            else:
+                fus_m[-1].computeDepthMapOfEvents(fus_m[:2], batches, d.FUSE_HM)
+        got = fus_m[-1].fetchDepthMap()
+        for g, w, name in zip(got, want, ("depth", "confidence", "index")):
+            assert np.array_equal(g, w), "call %d: %s differs at %d pixels" % (call, name, (g != w).sum())
     assert want[1].max() > 0.5
     for o in ref_m + fus_m + batches:
         o.close()
