@@ -1980,7 +1980,7 @@ static int tie_exact_values_dev(TieScratch& ts, hipStream_t st, dsi_mapper* cons
     if (grid_stats) HIP_TRY(ts.diff.reserve((size_t)n * nsv));
     HIP_TRY(ts.rank_count.reserve((size_t)n * nsv));
     HIP_TRY(ts.rank_start.reserve((size_t)n * nsv + 1));
-    HIP_TRY(ts.rank_cursor.reserve((size_t)n * nsv));
+    HIP_TRY(ts.rank_cursor.reserve(dsi::tie_partition_cursor_words((size_t)n * nsv)));
     HIP_TRY(dsi::launch_tie_partition_sums(st, ts.keys.p, ts.w.p, n_rec, pos_bits, ts.rank_count.p, ts.rank_start.p, ts.rank_cursor.p,
                                            ts.keys2.p, ts.cand.p, nsv, n, grid_stats ? ms[0]->grid->data : nullptr,
                                            grid_stats && n > 1 ? ms[1]->grid->data : nullptr, ts.exact.p, ts.count.p,

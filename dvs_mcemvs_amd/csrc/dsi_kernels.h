@@ -245,6 +245,8 @@ hipError_t launch_tie_pick(hipStream_t s, int op, const uint4* cols, int n_cols,
 // runs: n_rec words; wts is consumed (it receives the weights in event order).  exact[cam * nsv + c], count[...] <- sequential fp32
 // sum / number of the votes of voxel c of camera cam; diff[...] (optional; needs grid0 (and grid1 for two cameras)) <-
 // |grid_cam[vox[c]] - exact| / max(1, |exact|).  No library call.
+// cursor: tie_partition_cursor_words(n_ranks) words (the per-stretch table of the LDS path, or one cursor per rank)
+size_t tie_partition_cursor_words(size_t n_ranks);
 hipError_t launch_tie_partition_sums(hipStream_t s, const unsigned long long* keys, const float* wts, unsigned long long n_rec,
                                      unsigned pos_bits, uint32_t* counts, uint32_t* starts, uint32_t* cursor, unsigned long long* runs,
                                      const uint32_t* vox, int nsv, int n_cams, const float* grid0, const float* grid1, float* exact,

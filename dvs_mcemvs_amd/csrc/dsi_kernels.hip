@@ -4461,6 +4461,7 @@ __global__ __launch_bounds__(256) void k_tie_desc(const uint32_t* __restrict__ v
 //   k_tie_add_runs           wave = rank: the weights added one by one in fp32 -- resetGrid (mapper_emvs_stereo.cpp:145),
 //                            "grid[i] += w" per vote in event order (cartesian3dgrid.h:261-270)
 constexpr int kTiePartLdsRanks = 30720;  // 120 KB of counters
+constexpr unsigned long long kTiePartStretches = 256ull;  // stretches of the recorded votes per partition launch (at most)
 constexpr int kTieRunLds = 4096;         // words of a wave's sorting buffer (32 KB)
 
 template <bool SCATTER>
@@ -4483,27 +4484,47 @@ __global__ __launch_bounds__(1024) void k_tie_partition(const unsigned long long
         }
         return;
     }
-    for (unsigned r = threadIdx.x; r < n_ranks; r += 1024) s_rank[r] = 0u;
-    __syncthreads();
-    for (unsigned long long i = b0 + threadIdx.x; i < b1; i += 1024) {
-        const unsigned r = (unsigned)(keys[i] >> pos_bits);
-        if (r < n_ranks) atomicAdd(&s_rank[r], 1u);  // (LDS)
+    if (SCATTER) {
+        // where this stretch's votes of rank r go: the run's start + the votes of r in the stretches before this one
+        // (k_tie_colscan turned the table of counts into these offsets)
+        const uint32_t* const before = counts_or_cursor + (size_t)blockIdx.x * n_ranks;
+        for (unsigned r = threadIdx.x; r < n_ranks; r += 1024) s_rank[r] = starts[r] + before[r];
+    } else {
+        for (unsigned r = threadIdx.x; r < n_ranks; r += 1024) s_rank[r] = 0u;
+        __syncthreads();
+        for (unsigned long long i = b0 + threadIdx.x; i < b1; i += 1024) {
+            const unsigned r = (unsigned)(keys[i] >> pos_bits);
+            if (r < n_ranks) atomicAdd(&s_rank[r], 1u);  // (LDS)
+        }
     }
     __syncthreads();
-    for (unsigned r = threadIdx.x; r < n_ranks; r += 1024) {
-        const uint32_t c = s_rank[r];
-        if (!c) continue;
-        const uint32_t at = atomicAdd(&counts_or_cursor[r], c);
-        if (SCATTER) s_rank[r] = starts[r] + at;
+    if (!SCATTER) {  // this stretch's row of the table [stretch][rank] (launch_tie_partition_sums)
+        uint32_t* const row = counts_or_cursor + (size_t)blockIdx.x * n_ranks;
+        for (unsigned r = threadIdx.x; r < n_ranks; r += 1024) row[r] = s_rank[r];
+        return;
     }
-    if (!SCATTER) return;
-    __syncthreads();
-    for (unsigned long long i = b0 + threadIdx.x; i < b1; i += 1024) {
-        const unsigned long long key = keys[i];
-        const unsigned r = (unsigned)(key >> pos_bits);
-        if (r >= n_ranks) continue;
-        const uint32_t slot = atomicAdd(&s_rank[r], 1u);  // (LDS)
-        runs[slot] = ((key & pos_mask) << 32) | (unsigned long long)__float_as_uint(wts[i]);
+    // Four records per thread and turn, their loads in flight together.  What this launch costs is its 8-byte stores: a
+    // stretch holds ~5 votes per rank, so nearly every store is its own partial-line write into a 125 MB array (0.24 ms at
+    // configs[1] = 65 G stores/s; the counting launch reads the same keys in 0.04 ms).  Measured: one record per turn 0.287,
+    // four 0.277, without the returning atomics on the runs' cursors (the table) 0.240 ms; 512 / 1,024 stretches 0.287 / 0.265.
+    constexpr int U = 4;
+    for (unsigned long long i0 = b0 + threadIdx.x; i0 < b1; i0 += 1024ull * U) {
+        unsigned long long key[U];
+        float w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned long long i = i0 + 1024ull * u;
+            const bool in = i < b1;
+            key[u] = in ? keys[i] : ~0ull;  // (rank bits all ones: >= n_ranks)
+            w[u] = in ? wts[i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned r = (unsigned)(key[u] >> pos_bits);
+            if (r >= n_ranks) continue;
+            const uint32_t slot = atomicAdd(&s_rank[r], 1u);  // (LDS)
+            runs[slot] = ((key[u] & pos_mask) << 32) | (unsigned long long)__float_as_uint(w[u]);
+        }
     }
 }
 
@@ -4532,9 +4553,36 @@ __global__ __launch_bounds__(1024) void k_tie_scan(const uint32_t* __restrict__ 
     for (unsigned r = r0; r < r1; ++r) {
         starts[r] = base;
         base += counts[r];
-        cursor[r] = 0u;
+        if (cursor) cursor[r] = 0u;
     }
     if (threadIdx.x == 0) starts[n_ranks] = total;
+}
+
+// table[b][r] = votes of rank r in stretch b  ->  votes of rank r in the stretches BEFORE b; counts[r] = all of them.
+// Thread = rank (consecutive threads read consecutive words of a row); eight rows' loads in flight.
+__global__ __launch_bounds__(64) void k_tie_colscan(uint32_t* __restrict__ table, unsigned n_ranks, unsigned n_stretches,
+                                                    uint32_t* __restrict__ counts)
+{
+    const unsigned r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_ranks) return;
+    uint32_t running = 0u;
+    unsigned b = 0;
+    for (; b + 8 <= n_stretches; b += 8) {
+        uint32_t c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c[u] = table[(size_t)(b + u) * n_ranks + r];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            table[(size_t)(b + u) * n_ranks + r] = running;
+            running += c[u];
+        }
+    }
+    for (; b < n_stretches; ++b) {
+        const uint32_t c = table[(size_t)b * n_ranks + r];
+        table[(size_t)b * n_ranks + r] = running;
+        running += c;
+    }
+    counts[r] = running;
 }
 
 // The n <= kTieRunLds words of a run (any order; event position << 32 | weight bits) -> ascending in tmp[0 .. n), by the whole
@@ -5598,6 +5646,11 @@ hipError_t launch_tie_hits_binned(hipStream_t s, const float2* xy, const float* 
 // the recorded votes [0, n_rec) partitioned by rank into runs[starts[r] .. starts[r] + counts[r]) (any order inside a run;
 // a word = event position << 32 | weight bits), then exact[] / count[] / diff[] (dsi_kernels.h).  n_ranks =
 // n_cams * nsv; counts, cursor: n_ranks words, starts: n_ranks + 1 (scratch).  pos_bits <= 32, n_rec < 2^32.
+size_t tie_partition_cursor_words(size_t n_ranks)
+{
+    return n_ranks <= (size_t)kTiePartLdsRanks ? n_ranks * (size_t)kTiePartStretches : n_ranks;
+}
+
 hipError_t launch_tie_partition_sums(hipStream_t s, const unsigned long long* keys, const float* wts, unsigned long long n_rec,
                                      unsigned pos_bits, uint32_t* counts, uint32_t* starts, uint32_t* cursor, unsigned long long* runs,
                                      const uint32_t* vox, int nsv, int n_cams, const float* grid0, const float* grid1, float* exact,
@@ -5610,18 +5663,26 @@ hipError_t launch_tie_partition_sums(hipStream_t s, const unsigned long long* ke
     if (n_rec) {
         const int use_lds = n_ranks <= (unsigned)kTiePartLdsRanks ? 1 : 0;
         const size_t lds = use_lds ? (size_t)n_ranks * sizeof(uint32_t) : 0;
-        // stretches of >= 8 k votes, at most two workgroups per CU's worth of them: a workgroup pays ~n_ranks LDS words and
-        // up to n_ranks global atomics per stretch
-        const unsigned long long per = std::max<unsigned long long>(8192ull, (n_rec + 255ull) / 256ull);
+        // stretches of >= 8 k votes, at most kTiePartStretches of them (one workgroup per CU's worth): a workgroup pays
+        // ~n_ranks LDS words per stretch.  LDS path: NO global atomic -- the counting launch leaves its counts in a table
+        // [stretch][rank] (`cursor`: tie_partition_cursor_words), k_tie_colscan turns a rank's column into the offsets of
+        // the stretches inside its run (17 us), the scattering launch reads its row instead of counting again (with one
+        // returning atomic per (stretch, rank) on the runs' cursors -- 256 workgroups walking the ranks in the same order --
+        // the scatter took 0.277 ms at configs[1]; now 0.240)
+        const unsigned long long per = std::max<unsigned long long>(8192ull, (n_rec + kTiePartStretches - 1ull) / kTiePartStretches);
         const unsigned blocks = (unsigned)((n_rec + per - 1) / per);
         if (use_lds) {
             if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_tie_partition<false>), lds)) return e;
             if (hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(&k_tie_partition<true>), lds)) return e;
         }
         hipLaunchKernelGGL(k_tie_partition<false>, dim3(blocks), dim3(1024), lds, s, keys, wts, n_rec, per, pos_bits, n_ranks, use_lds,
-                           counts, (const uint32_t*)nullptr, (unsigned long long*)nullptr);
+                           use_lds ? cursor : counts, (const uint32_t*)nullptr, (unsigned long long*)nullptr);
         if (hipError_t e = hipExtGetLastError()) return e;
-        hipLaunchKernelGGL(k_tie_scan, dim3(1), dim3(1024), 0, s, counts, n_ranks, starts, cursor);
+        if (use_lds) {
+            hipLaunchKernelGGL(k_tie_colscan, dim3((n_ranks + 63) / 64), dim3(64), 0, s, cursor, n_ranks, blocks, counts);
+            if (hipError_t e = hipExtGetLastError()) return e;
+        }
+        hipLaunchKernelGGL(k_tie_scan, dim3(1), dim3(1024), 0, s, counts, n_ranks, starts, use_lds ? (uint32_t*)nullptr : cursor);
         if (hipError_t e = hipExtGetLastError()) return e;
         hipLaunchKernelGGL(k_tie_partition<true>, dim3(blocks), dim3(1024), lds, s, keys, wts, n_rec, per, pos_bits, n_ranks, use_lds,
                            cursor, (const uint32_t*)starts, runs);
