@@ -4755,34 +4755,84 @@ __global__ __launch_bounds__(256) void k_tie_sort_runs(const unsigned long long*
     }
 }
 
-// WAVE = (camera, contending voxel): its weights, in event order by now, added one by one in fp32 -- resetGrid
-// (mapper_emvs_stereo.cpp:145), then "grid[i] += w" per vote (cartesian3dgrid.h:261-270).  64 consecutive weights per coalesced
-// load (the next 64 in flight meanwhile), each broadcast from its lane (v_readlane): the chain of dependent additions is the
-// same in every lane.  diff[r] (optional) = |engine value - reference-order value| / max(1, |reference-order value|)
+// ROW of 16 lanes = (camera, contending voxel): its weights, in event order by now, added one by one in fp32 -- resetGrid
+// (mapper_emvs_stereo.cpp:145), then "grid[i] += w" per vote (cartesian3dgrid.h:261-270).  A row loads 4 x 16 consecutive weights
+// (the next 64 in flight meanwhile) and its lane 0 adds them in order, lane j's weight reaching it through the
+// add's own DPP operand (row_shl:j): ONE vector instruction per vote step, and the four rows of a wave walk four runs with it.
+// (Round 6, first version: a wave per run, v_readlane + v_add per vote -- 2.3 instructions per vote, 34 M per call at
+// configs[1], 0.12 ms with eight such waves sharing a SIMD.)  A row whose run has ended, and the lanes behind a run's last
+// weight, add +0: x + 0 = x for every x this sum can hold (weights >= 0, denormals kept), so padding changes no bit.
+// diff[r] (optional) = |engine value - reference-order value| / max(1, |reference-order value|)
+#define DSI_TIE_ADD16(SUM, W)                                                             \
+    asm volatile("s_nop 4\n\t" /* (W / EXEC may have been written by the vector unit just before: DPP read hazards) */ \
+                 "v_add_f32 %0, %1, %0\n\t"                                                \
+                 "v_add_f32_dpp %0, %1, %0 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"       \
+                 "v_add_f32_dpp %0, %1, %0 row_shl:2 row_mask:0xf bank_mask:0xf\n\t"       \
+                 "v_add_f32_dpp %0, %1, %0 row_shl:3 row_mask:0xf bank_mask:0xf\n\t"       \
+                 "v_add_f32_dpp %0, %1, %0 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"       \
+                 "v_add_f32_dpp %0, %1, %0 row_shl:5 row_mask:0xf bank_mask:0xf\n\t"       \
+                 "v_add_f32_dpp %0, %1, %0 row_shl:6 row_mask:0xf bank_mask:0xf\n\t"       \
+                 "v_add_f32_dpp %0, %1, %0 row_shl:7 row_mask:0xf bank_mask:0xf\n\t"       \
+                 "v_add_f32_dpp %0, %1, %0 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"       \
+                 "v_add_f32_dpp %0, %1, %0 row_shl:9 row_mask:0xf bank_mask:0xf\n\t"       \
+                 "v_add_f32_dpp %0, %1, %0 row_shl:10 row_mask:0xf bank_mask:0xf\n\t"      \
+                 "v_add_f32_dpp %0, %1, %0 row_shl:11 row_mask:0xf bank_mask:0xf\n\t"      \
+                 "v_add_f32_dpp %0, %1, %0 row_shl:12 row_mask:0xf bank_mask:0xf\n\t"      \
+                 "v_add_f32_dpp %0, %1, %0 row_shl:13 row_mask:0xf bank_mask:0xf\n\t"      \
+                 "v_add_f32_dpp %0, %1, %0 row_shl:14 row_mask:0xf bank_mask:0xf\n\t"      \
+                 "v_add_f32_dpp %0, %1, %0 row_shl:15 row_mask:0xf bank_mask:0xf"            \
+                 : "+v"(SUM)                                                               \
+                 : "v"(W))
+
 __global__ __launch_bounds__(256) void k_tie_add_runs(const float* __restrict__ sorted_w, const uint32_t* __restrict__ starts,
                                                       const uint32_t* __restrict__ counts, const uint32_t* __restrict__ vox, int nsv,
                                                       int n_cams, const float* __restrict__ grid0, const float* __restrict__ grid1,
                                                       float* __restrict__ exact, uint32_t* __restrict__ count, float* __restrict__ diff)
 {
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (r >= nsv * n_cams) return;  // (wave-uniform)
-    const unsigned long long first = starts[r], last = first + counts[r];
-    float sum = 0.f;
-    float w = first + (unsigned)lane < last ? sorted_w[first + (unsigned)lane] : 0.f;
-    for (unsigned long long base = first; base < last; base += 64) {
-        const float cur = w;
-        const unsigned long long nb = base + 64 + (unsigned)lane;
-        w = nb < last ? sorted_w[nb] : 0.f;  // the next batch, in flight during this one's additions
-        if (last - base >= 64) {
+    const int n_ranks = nsv * n_cams;
+    const int r = blockIdx.x * 16 + (int)(threadIdx.x >> 4);  // this row's run
+    const unsigned j = threadIdx.x & 15u;                      // lane within the row
+    const bool have_run = r < n_ranks;
+    const unsigned long long first = have_run ? starts[r] : 0ull, last = have_run ? first + counts[r] : 0ull;
+    float sum = 0.f;  // (only lane 0 of the row holds the run's sum)
+    // 64 weights per row and turn: lane j holds weights base + 16 c + j, c = 0..3.  The loads are UNCONDITIONAL (a lane past its
+    // run's end reads weight 0 of the array and keeps +0 instead): with a branch around them the compiler has to wait for
+    // every load in flight before the additions, the next turn's included
+    auto fetch = [&](unsigned long long at, float (&w)[4]) {
 #pragma unroll
-            for (int i = 0; i < 64; ++i) sum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur), i));
-        } else {
-            const int c = (int)(last - base);
-            for (int i = 0; i < c; ++i) sum += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur), i));
-        }  // one by one, in order (no reassociation: -ffp-contract=off, no fast-math)
+        for (int c = 0; c < 4; ++c) {
+            const unsigned long long i = at + 16u * (unsigned)c + j;
+            const float v = sorted_w[i < last ? i : 0ull];
+            w[c] = i < last ? v : 0.f;
+        }
+    };
+    if (__builtin_amdgcn_ballot_w64(first < last) == 0ull) {  // (no run with a vote in this wave: the array may be empty)
+        if (j == 0 && have_run) {
+            exact[r] = 0.f;
+            count[r] = 0u;
+            if (diff) {
+                const int cam = r / nsv;
+                diff[r] = fabsf((cam == 0 ? grid0 : grid1)[vox[r - cam * nsv]]);
+            }
+        }
+        return;
     }
-    if (lane != 0) return;
+    float w[4];
+    fetch(first, w);
+    unsigned long long base = first;
+    while (__builtin_amdgcn_ballot_w64(base < last) != 0ull) {  // (wave-uniform: until the longest of the four runs is through)
+        float cur[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cur[c] = w[c];
+        fetch(base + 64, w);  // the next 64, in flight during these additions
+        // one by one, in order (no reassociation; lanes and rows past their run's end add +0)
+        DSI_TIE_ADD16(sum, cur[0]);
+        DSI_TIE_ADD16(sum, cur[1]);
+        DSI_TIE_ADD16(sum, cur[2]);
+        DSI_TIE_ADD16(sum, cur[3]);
+        base += 64;
+    }
+    if (j != 0 || !have_run) return;
     exact[r] = sum;
     count[r] = counts[r];
     if (diff) {
@@ -4792,6 +4842,7 @@ __global__ __launch_bounds__(256) void k_tie_add_runs(const float* __restrict__ 
         diff[r] = fabsf(have - sum) / fmaxf(1.f, fabsf(sum));
     }
 }
+#undef DSI_TIE_ADD16
 
 // thread = near-tie column: camera fusion of the reference-order values (fuse_op, what k_fuse2_into computes), first
 // maximum over the column's contending planes (std::max_element, cartesian3dgrid.cpp:132-134), patch of the depth map
@@ -5701,7 +5752,7 @@ hipError_t launch_tie_partition_sums(hipStream_t s, const unsigned long long* ke
         hipLaunchKernelGGL(k_tie_sort_runs<kTieRunLds>, dim3(n_ranks), dim3(256), 0, s, runs, starts, counts, pos_bits, (int)n_ranks, sorted_w);
         if (hipError_t e = hipExtGetLastError()) return e;
     }
-    hipLaunchKernelGGL(k_tie_add_runs, dim3((n_ranks + 3) / 4), dim3(256), 0, s, sorted_w, starts, counts, vox, nsv, n_cams, grid0, grid1,
+    hipLaunchKernelGGL(k_tie_add_runs, dim3((n_ranks + 15) / 16), dim3(256), 0, s, sorted_w, starts, counts, vox, nsv, n_cams, grid0, grid1,
                        exact, count, diff);
     return hipExtGetLastError();
 }
