@@ -1927,11 +1927,10 @@ static int tie_exact_values_dev(TieScratch& ts, hipStream_t st, dsi_mapper* cons
         const size_t np = bs[c]->n_packets;
         if (!np) continue;
         HIP_TRY(m->H.reserve(np * 9));
-        HIP_TRY(m->xy.reserve(np * dsi::kPacket));
         HIP_TRY(m->centers.reserve(np * 3));
         if (bs[c]->ready) HIP_TRY(hipStreamWaitEvent(st, bs[c]->ready, 0));
+        // (the events' z0 locations are computed by the event pass itself, packet by packet: no z0 array)
         HIP_TRY(dsi::launch_packet_geometry(st, bs[c]->Rt, (int)np, m->geom, m->centers.p, m->H.p));
-        HIP_TRY(dsi::launch_warp_z0(st, bs[c]->x, bs[c]->y, bs[c]->first, (int)np, m->H.p, m->lut_dev, m->sensor_w, m->sensor_h, m->xy.p));
     }
     // ONE pass per camera into the scratch already held (4 M records to begin with); a pass that runs out of segments only
     // counts what it would have needed, and everything is repeated once with that much room
@@ -1947,7 +1946,8 @@ static int tie_exact_values_dev(TieScratch& ts, hipStream_t st, dsi_mapper* cons
         for (int c = 0; c < n; ++c) {
             dsi_mapper* m = ms[c];
             if (!bs[c]->n_packets) continue;
-            HIP_TRY(dsi::launch_tie_hits_binned(st, m->xy.p, m->centers.p, m->planes_dev, m->geom, (int)bs[c]->n_packets, ts.desc.p, nsv,
+            HIP_TRY(dsi::launch_tie_hits_binned(st, bs[c]->x, bs[c]->y, bs[c]->first, m->H.p, m->lut_dev, m->sensor_w, m->sensor_h,
+                                                m->centers.p, m->planes_dev, m->geom, (int)bs[c]->n_packets, ts.desc.p, nsv,
                                                 (unsigned)c * (unsigned)nsv, pos_bits, sentinel, cnt + 2, cap_segs, cnt + 3,
                                                 ts.counters.p + 4, ts.keys.p, ts.w.p));
         }

@@ -231,8 +231,9 @@ hipError_t launch_tie_desc(hipStream_t s, const uint32_t* vox, int n, int nx, in
 // launches (cameras) may append to the same arrays.  *total_hits += the real votes
 int tie_segment_records();
 int tie_block_capacity_records();  // votes one workgroup of the pass can record
-hipError_t launch_tie_hits_binned(hipStream_t s, const float2* xy, const float* centers, const float* planes, const Geom& g, int np,
-                                  const uint2* desc, int nsv, unsigned rank_base, unsigned pos_bits, unsigned sentinel_rank,
+hipError_t launch_tie_hits_binned(hipStream_t s, const uint16_t* ex, const uint16_t* ey, const uint32_t* packet_first, const float* H,
+                                  const float2* lut, int sensor_w, int sensor_h, const float* centers, const float* planes, const Geom& g,
+                                  int np, const uint2* desc, int nsv, unsigned rank_base, unsigned pos_bits, unsigned sentinel_rank,
                                   unsigned* seg_counter, unsigned cap_segs, unsigned* flags, unsigned long long* total_hits,
                                   unsigned long long* keys, float* wts);
 // per near-tie column: op(exact camera 0, exact camera 1) (op 0: one camera), first maximum, patch; stats[0] = max float bits

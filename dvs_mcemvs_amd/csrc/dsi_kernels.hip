@@ -4177,6 +4177,15 @@ __device__ __forceinline__ int tie_tile_coord(float v, int margin, float inv_til
     return (int)fminf(fmaxf(t, 0.f), (float)(n_tiles - 1));
 }
 
+struct TieEvents {  // the raw events of a camera's batch + what stage A needs per packet
+    const uint16_t* x;
+    const uint16_t* y;
+    const uint32_t* first;  // first event of packet k (nullptr: k * 1024)
+    const float* H;         // [np][9] (k_packet_geometry)
+    const float2* lut;
+    int sensor_w, sensor_h;
+};
+
 struct TieOut {
     unsigned* s_vpos;          // LDS: the block's virtual cursor
     unsigned* s_seg;           // LDS: segment table [kTieMaxSegs]
@@ -4249,7 +4258,7 @@ __device__ __forceinline__ unsigned tie_tile_start(const unsigned* __restrict__ 
 }
 
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tie_hits_binned(const float2* __restrict__ xy, const float* __restrict__ centers,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tie_hits_binned(TieEvents ev, const float* __restrict__ centers,
                                                          const float* __restrict__ planes, Geom g, int np,
                                                          const uint2* __restrict__ desc, int nsv, unsigned rank_base,
                                                          unsigned pos_bits, unsigned sentinel_rank, TieBinGeom bg,
@@ -4315,8 +4324,19 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         float2 e[PER];
         int tile[PER];
         unsigned off[PER];
+        {
+            // stage A of the packet's events here (mapper_emvs_stereo.cpp:129-142, the function k_warp_z0 applies: same bits)
+            // instead of a z0 array written and read back per call (80 MB and 28 us per camera at configs[1])
+            const size_t first = ev.first ? (size_t)ev.first[k] : (size_t)k * kPacket;
+            float hh[9];
 #pragma unroll
-        for (int i = 0; i < PER; ++i) e[i] = xy[(size_t)k * kPacket + tid + BLOCK * i];
+            for (int i = 0; i < 9; ++i) hh[i] = ev.H[9 * (size_t)k + i];
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const size_t at = first + (size_t)(tid + BLOCK * i);
+                e[i] = warp_event_z0(ev.x[at], ev.y[at], hh, ev.lut, ev.sensor_w, ev.sensor_h);
+            }
+        }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
@@ -5671,11 +5691,13 @@ hipError_t launch_tie_desc(hipStream_t s, const uint32_t* vox, int n, int nx, in
 int tie_segment_records() { return kTieSeg; }
 int tie_block_capacity_records() { return kTieMaxSegs * kTieSeg; }
 
-hipError_t launch_tie_hits_binned(hipStream_t s, const float2* xy, const float* centers, const float* planes, const Geom& g, int np,
-                                  const uint2* desc, int nsv, unsigned rank_base, unsigned pos_bits, unsigned sentinel_rank,
+hipError_t launch_tie_hits_binned(hipStream_t s, const uint16_t* ex, const uint16_t* ey, const uint32_t* packet_first, const float* H,
+                                  const float2* lut, int sensor_w, int sensor_h, const float* centers, const float* planes, const Geom& g,
+                                  int np, const uint2* desc, int nsv, unsigned rank_base, unsigned pos_bits, unsigned sentinel_rank,
                                   unsigned* seg_counter, unsigned cap_segs, unsigned* flags, unsigned long long* total_hits,
                                   unsigned long long* keys, float* wts)
 {
+    const TieEvents ev{ex, ey, packet_first, H, lut, sensor_w, sensor_h};
     if (np <= 0 || nsv <= 0) return hipSuccess;
     const TieBinGeom bg = tie_bin_geom(g.nx, g.ny);
     const size_t lds = tie_hits_lds_bytes(bg.tx_n * bg.ty_n, g.nz);
@@ -5688,7 +5710,7 @@ hipError_t launch_tie_hits_binned(hipStream_t s, const float2* xy, const float* 
     // ... and when the packets alone do not (a 50 ms window), the voxels are dealt over blockIdx.y (each share bins the packet again)
     int vshares = std::max(1, std::min(std::min(16, (nsv + 1023) / 1024), (256 * per_cu) / blocks));
     vshares = std::max(vshares, (nsv + (1 << 22) - 1) >> 22);  // (a queue entry holds the voxel's index within its share in 22 bits)
-    hipLaunchKernelGGL(k_tie_hits_binned<kHitsBlock>, dim3(blocks, vshares), dim3(kHitsBlock), lds, s, xy, centers, planes, g, np, desc, nsv, rank_base, pos_bits,
+    hipLaunchKernelGGL(k_tie_hits_binned<kHitsBlock>, dim3(blocks, vshares), dim3(kHitsBlock), lds, s, ev, centers, planes, g, np, desc, nsv, rank_base, pos_bits,
                        sentinel_rank, bg, seg_counter, cap_segs, flags, total_hits, keys, wts);
     return hipExtGetLastError();
 }
