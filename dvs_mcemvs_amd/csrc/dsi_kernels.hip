@@ -4606,16 +4606,16 @@ __global__ __launch_bounds__(64) void k_tie_colscan(uint32_t* __restrict__ table
 }
 
 // The n <= kTieRunLds words of a run (any order; event position << 32 | weight bits) -> ascending in tmp[0 .. n), by the whole
-// workgroup (256 threads).  The words are dealt to nb >= n buckets of equal position width (one LDS atomic each: count and
+// workgroup (T threads).  The words are dealt to nb >= n buckets of equal position width (one LDS atomic each: count and
 // rank in the bucket), the bucket starts are a prefix sum, every word goes to its bucket's stretch, and inside a bucket every
 // word finds its place by counting the smaller ones.  ~6 passes over the run instead of a 66-stage bitonic network (which cost
 // 2 ms at configs[1] with a wave per run).  A burst -- all events of ONE packet on a voxel -- is one bucket of 1,024 words:
 // 1,024 reads per word, spread over the workgroup: slow, correct, rare.
-template <int CAP>
+template <int CAP, int T>
 __device__ __forceinline__ void tie_block_sort(const unsigned long long* __restrict__ src, int n,
                                                unsigned long long* __restrict__ tmp, uint32_t* __restrict__ bcnt, uint32_t* __restrict__ wave_tot)
 {
-    constexpr int T = 256, PER = CAP / T;
+    constexpr int PER = CAP / T, W = T / 64;  // (wave_tot: 2 * W words)
     const int tid = (int)threadIdx.x;
     int nb = 64;
     while (nb < n) nb <<= 1;
@@ -4641,11 +4641,14 @@ __device__ __forceinline__ void tie_block_sort(const unsigned long long* __restr
     }
     if ((tid & 63) == 0) {
         wave_tot[tid >> 6] = pmin;
-        wave_tot[4 + (tid >> 6)] = pmax;
+        wave_tot[W + (tid >> 6)] = pmax;
     }
     __syncthreads();
-    pmin = min(min(wave_tot[0], wave_tot[1]), min(wave_tot[2], wave_tot[3]));
-    pmax = max(max(wave_tot[4], wave_tot[5]), max(wave_tot[6], wave_tot[7]));
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+        pmin = min(pmin, wave_tot[w]);
+        pmax = max(pmax, wave_tot[W + w]);
+    }  // (wave_tot is written again by the prefix sum below, behind the next barrier)
     // bucket = floor((p - pmin) * scale), scale a little below nb / (span + 1): monotone in p, < nb
     const float scale = (float)nb / ((float)(pmax - pmin) + 1.f) * 0.99999f;
 #pragma unroll
@@ -4712,27 +4715,29 @@ __device__ __forceinline__ void tie_block_sort(const unsigned long long* __restr
     __syncthreads();
 }
 
-// workgroup = rank: its run in event order -> sorted_w[starts[r] .. + counts[r]) (the weights only, 4 bytes per vote); all 256
+// workgroup = rank: its run in event order -> sorted_w[starts[r] .. + counts[r]) (the weights only, 4 bytes per vote); all T
 // threads work all the time -- the one-by-one additions, which only one wave can do, are k_tie_add_runs' (with them in here three
 // waves of four held 48 KB of LDS idle for ~5 us per run: 0.42 ms at configs[1])
 // CAP: the runs of (CAP / 2, CAP] votes (CAP = 1024: of up to 1,024; CAP = kTieRunLds: also the longer ones, in windows) -- a
 // workgroup of the wrong class leaves at once; three launches, so that the many short runs do not each hold 48 KB of LDS
-template <int CAP>
-__global__ __launch_bounds__(256) void k_tie_sort_runs(const unsigned long long* __restrict__ runs, const uint32_t* __restrict__ starts,
+// T threads: 256, and 512 for the longest class -- its 48 KB of LDS allow three workgroups per CU whatever their size, so twice the
+// threads sort a run in about half the time (k_tie_sort_runs<4096>: 0.152 -> see DESIGN 4.6)
+template <int CAP, int T = (CAP > 2048 ? 512 : 256)>
+__global__ __launch_bounds__(T) void k_tie_sort_runs(const unsigned long long* __restrict__ runs, const uint32_t* __restrict__ starts,
                                                        const uint32_t* __restrict__ counts, unsigned pos_bits, int n_ranks,
                                                        float* __restrict__ sorted_w)
 {
     __shared__ unsigned long long tmp[CAP];
     __shared__ uint32_t bcnt[CAP];
-    __shared__ uint32_t wave_tot[8];
+    __shared__ uint32_t wave_tot[2 * (T / 64)];
     __shared__ uint32_t s_n;
     const int r = (int)blockIdx.x, tid = (int)threadIdx.x;
     if (r >= n_ranks) return;
     const uint32_t first = starts[r], cnt = counts[r];
     if (cnt == 0u || cnt <= (uint32_t)(CAP == 1024 ? 0 : CAP / 2) || (CAP != kTieRunLds && cnt > (uint32_t)CAP)) return;
     if (cnt <= (uint32_t)CAP) {
-        tie_block_sort<CAP>(runs + first, (int)cnt, tmp, bcnt, wave_tot);
-        for (uint32_t i = (uint32_t)tid; i < cnt; i += 256) sorted_w[(size_t)first + i] = __uint_as_float((uint32_t)tmp[i]);
+        tie_block_sort<CAP, T>(runs + first, (int)cnt, tmp, bcnt, wave_tot);
+        for (uint32_t i = (uint32_t)tid; i < cnt; i += T) sorted_w[(size_t)first + i] = __uint_as_float((uint32_t)tmp[i]);
         return;
     }
     // Longer runs (configs[4]: ~30 k votes in a voxel): windows [lo, lo + 2^span_bits) of event positions; the run is scanned
@@ -4748,7 +4753,7 @@ __global__ __launch_bounds__(256) void k_tie_sort_runs(const unsigned long long*
         const unsigned long long hi = lo + (1ull << span_bits);
         if (tid == 0) s_n = 0u;
         __syncthreads();
-        for (uint32_t i0 = 0; i0 < cnt; i0 += 256) {
+        for (uint32_t i0 = 0; i0 < cnt; i0 += T) {
             const uint32_t i = i0 + (uint32_t)tid;
             const unsigned long long key = i < cnt ? runs[(size_t)first + i] : ~0ull;
             const unsigned long long p = key >> 32;
@@ -4765,8 +4770,8 @@ __global__ __launch_bounds__(256) void k_tie_sort_runs(const unsigned long long*
             continue;
         }
         if (n) {
-            tie_block_sort<CAP>(stage, (int)n, tmp, bcnt, wave_tot);
-            for (uint32_t i = (uint32_t)tid; i < n; i += 256) sorted_w[(size_t)first + done + i] = __uint_as_float((uint32_t)tmp[i]);
+            tie_block_sort<CAP, T>(stage, (int)n, tmp, bcnt, wave_tot);
+            for (uint32_t i = (uint32_t)tid; i < n; i += T) sorted_w[(size_t)first + done + i] = __uint_as_float((uint32_t)tmp[i]);
             done += n;
         }
         __syncthreads();
@@ -5771,7 +5776,7 @@ hipError_t launch_tie_partition_sums(hipStream_t s, const unsigned long long* ke
         if (hipError_t e = hipExtGetLastError()) return e;
         hipLaunchKernelGGL(k_tie_sort_runs<2048>, dim3(n_ranks), dim3(256), 0, s, runs, starts, counts, pos_bits, (int)n_ranks, sorted_w);
         if (hipError_t e = hipExtGetLastError()) return e;
-        hipLaunchKernelGGL(k_tie_sort_runs<kTieRunLds>, dim3(n_ranks), dim3(256), 0, s, runs, starts, counts, pos_bits, (int)n_ranks, sorted_w);
+        hipLaunchKernelGGL(k_tie_sort_runs<kTieRunLds>, dim3(n_ranks), dim3(512), 0, s, runs, starts, counts, pos_bits, (int)n_ranks, sorted_w);
         if (hipError_t e = hipExtGetLastError()) return e;
     }
     hipLaunchKernelGGL(k_tie_add_runs, dim3((n_ranks + 15) / 16), dim3(256), 0, s, sorted_w, starts, counts, vox, nsv, n_cams, grid0, grid1,
