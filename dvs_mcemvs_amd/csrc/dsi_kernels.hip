@@ -4145,7 +4145,7 @@ constexpr int kTieMaxSegs = 512;  // per block: 512 k hits
 constexpr unsigned kTieSegEmpty = 0xffffffffu;
 constexpr int kTieMaxTiles = 16384;  // tile starts are 16-bit halves of LDS words: 32 KB
 
-struct TiePlane {  // per (packet, plane), in LDS
+struct alignas(16) TiePlane {  // per (packet, plane), in LDS
     float a, bx, by, d;  // mapper_emvs_stereo.cpp:177-182
     float ia, qx, qy;    // z0 location of integer X: x0 = X * ia + qx (ia = d / a, qx = -bx / a), same for y
     float hw;            // half width of the pre-image of [X - 1, X + 1) in z0 pixels, rounding included; < 0: no votes;
@@ -4247,14 +4247,17 @@ __device__ __forceinline__ void tie_vote_pair(const TieOut& out, const uint2* __
 
 // dynamic LDS: rec_x[1024] rec_y[1024] (f32) | rec_slot[1024] (u32) | tile starts, tiles + 1 of them as the 16-bit halves
 // of (tiles + 2) / 2 words | TiePlane[nz] | seg[kTieMaxSegs] (u32)
-__host__ __device__ inline int tie_tile_words(int tiles) { return (tiles + 2) / 2; }
+// (a multiple of four words, so that the TiePlane table behind them is 16-byte aligned: one ds_read_b128 per look-up)
+__host__ __device__ inline int tie_tile_words(int tiles) { return ((tiles + 2) / 2 + 3) & ~3; }
 __host__ __device__ inline size_t tie_hits_lds_bytes(int tiles, int nz)
 {
     return (size_t)kPacket * 12 + (size_t)tie_tile_words(tiles) * 4 + (size_t)nz * sizeof(TiePlane) + (size_t)kTieMaxSegs * 4;
 }
 __device__ __forceinline__ unsigned tie_tile_start(const unsigned* __restrict__ tw, int t)
 {
-    return (tw[t >> 1] >> ((t & 1) << 4)) & 0xffffu;
+    // half (t & 1) of word t >> 1 = 16-bit element t (little endian): ONE ds_read_u16 instead of a word read + shift + mask --
+    // four of these per (voxel, packet) pair, 54 M pairs per camera
+    return reinterpret_cast<const uint16_t*>(tw)[t];
 }
 
 template <int BLOCK>
@@ -4267,7 +4270,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                                                          unsigned long long* __restrict__ total_hits,
                                                          unsigned long long* __restrict__ keys, float* __restrict__ wts)
 {
-    extern __shared__ unsigned char s_raw[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     __shared__ unsigned s_vpos;
     __shared__ unsigned s_wave_tot[BLOCK / 64];
     constexpr int PER = kPacket / BLOCK;  // events of a packet per thread
@@ -4280,7 +4283,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     unsigned* rec_slot = reinterpret_cast<unsigned*>(rec_y + kPacket);
     const int tiles = bg.tx_n * bg.ty_n, twords = tie_tile_words(tiles);
     unsigned* tstart = rec_slot + kPacket;  // tile t: half (t & 1) of word t >> 1; entry `tiles` = the packet's records
-    TiePlane* tp = reinterpret_cast<TiePlane*>(tstart + twords);
+    TiePlane* tp = reinterpret_cast<TiePlane*>(__builtin_assume_aligned(tstart + twords, 16));  // (kPacket * 12 + 4 * twords: 16 | both)
     unsigned* s_seg = reinterpret_cast<unsigned*>(tp + g.nz);
     const int tid = threadIdx.x;
     const float inv_tile = 1.f / (float)(1 << bg.shift);
@@ -4387,18 +4390,26 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         // against the exact pre-image box; the ~10 % of (voxel, record) pairs that pass are QUEUED (per wave, in LDS) and
         // voted 64 at a time with all lanes busy -- voted where they are found, the two IEEE divisions, the weights and
         // the output slot would run for the few lanes that have a hit while the rest of the wave waits.
+        // (a voxel's descriptor is loaded one turn ahead: read where it is used, its two words -- the plane first, for the
+        //  early exit -- were two dependent L2 round trips per turn, in a loop whose waves are parked 69 % of the time)
+        uint2 dsc_next = make_uint2(0u, 0u);
+        if (v_beg + tid < v_end) dsc_next = desc[v_beg + tid];
         for (int c0 = v_beg; c0 < v_end; c0 += BLOCK) {
             const int c = c0 + tid;
+            const uint2 dsc = dsc_next;
+            if (c + BLOCK < v_end) dsc_next = desc[c + BLOCK];
             if (c < v_end) {
-                const uint2 dsc = desc[c];
                 const int vx = (int)(dsc.x & 0xffffu), vy = (int)(dsc.x >> 16), vz = (int)dsc.y;
-                const float hw = tp[vz].hw;
+                const float4 look = *reinterpret_cast<const float4*>(&tp[vz].ia);  // ia, qx, qy, hw
+                const float hw = look.w;
                 if (hw >= 0.f) {
-                    const float ia = tp[vz].ia, qx = tp[vz].qx, qy = tp[vz].qy;
+                    const float ia = look.x, qx = look.y, qy = look.z;
                     const float cx0 = (float)vx * ia + qx, cy0 = (float)vy * ia + qy;
                     const float xlo = cx0 - hw, xhi = cx0 + hw, ylo = cy0 - hw, yhi = cy0 + hw;
                     const int txlo = tie_tile_coord(xlo, bg.margin, inv_tile, bg.tx_n), txhi = tie_tile_coord(xhi, bg.margin, inv_tile, bg.tx_n);
                     const int tylo = tie_tile_coord(ylo, bg.margin, inv_tile, bg.ty_n), tyhi = tie_tile_coord(yhi, bg.margin, inv_tile, bg.ty_n);
+                    // (measured and dropped: both tile rows' starts read together and one loop over the records of both --
+                    //  313 against 304 us)
                     for (int ty = tylo; ty <= tyhi; ++ty) {
                         const unsigned rb = tie_tile_start(tstart, ty * bg.tx_n + txlo), re = tie_tile_start(tstart, ty * bg.tx_n + txhi + 1);
                         for (unsigned r = rb; r < re; ++r) {
