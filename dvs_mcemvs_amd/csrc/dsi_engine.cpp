@@ -1900,8 +1900,26 @@ unsigned bits_for(unsigned long long values)  // bits that hold 0 .. values - 1
 // voxel, event index) and added one by one in fp32 by one thread per (camera, voxel).  grid_stats: also the maxima of
 // |grid value - reference-order value| and of the votes per voxel into ts.counters.  Host round trips: ONE read of two
 // counters (how many records to sort).
+// camera centre + H_z0 of every packet (what the event pass needs besides the raw events).  Depends on no counter: the
+// resolver queues it BEFORE it waits for the number of contending voxels, so that the launches behind that wait are not
+// held up by it (the dispatch timeline showed ~40 us of idle stream between the wait and the first event pass)
+static int tie_packet_geometry(hipStream_t st, dsi_mapper* const* ms, const dsi_batch* const* bs, int n)
+{
+    for (int c = 0; c < n; ++c) {
+        dsi_mapper* m = ms[c];
+        const size_t np = bs[c]->n_packets;
+        if (!np) continue;
+        HIP_TRY(m->H.reserve(np * 9));
+        HIP_TRY(m->centers.reserve(np * 3));
+        if (bs[c]->ready) HIP_TRY(hipStreamWaitEvent(st, bs[c]->ready, 0));
+        // (the events' z0 locations are computed by the event pass itself, packet by packet: no z0 array)
+        HIP_TRY(dsi::launch_packet_geometry(st, bs[c]->Rt, (int)np, m->geom, m->centers.p, m->H.p));
+    }
+    return DSI_OK;
+}
+
 static int tie_exact_values_dev(TieScratch& ts, hipStream_t st, dsi_mapper* const* ms, const dsi_batch* const* bs, int n, int nsv,
-                                bool grid_stats, long long* votes, bool* table_overflow = nullptr)
+                                bool grid_stats, long long* votes, bool* table_overflow = nullptr, bool geometry_ready = false)
 {
     *votes = 0;
     if (table_overflow) *table_overflow = false;
@@ -1922,16 +1940,8 @@ static int tie_exact_values_dev(TieScratch& ts, hipStream_t st, dsi_mapper* cons
     unsigned* cnt = reinterpret_cast<unsigned*>(ts.counters.p);
     HIP_TRY(hipMemsetAsync(cnt + kTieCounterPassWords, 0, (kTieCounterWords - kTieCounterPassWords) * sizeof(unsigned), st));
     HIP_TRY(dsi::launch_tie_desc(st, ts.cand.p, nsv, g0.nx, npix, ts.desc.p, cnt + kTieCounterPassWords));
-    for (int c = 0; c < n; ++c) {
-        dsi_mapper* m = ms[c];
-        const size_t np = bs[c]->n_packets;
-        if (!np) continue;
-        HIP_TRY(m->H.reserve(np * 9));
-        HIP_TRY(m->centers.reserve(np * 3));
-        if (bs[c]->ready) HIP_TRY(hipStreamWaitEvent(st, bs[c]->ready, 0));
-        // (the events' z0 locations are computed by the event pass itself, packet by packet: no z0 array)
-        HIP_TRY(dsi::launch_packet_geometry(st, bs[c]->Rt, (int)np, m->geom, m->centers.p, m->H.p));
-    }
+    if (!geometry_ready)
+        if (int rc = tie_packet_geometry(st, ms, bs, n)) return rc;
     // ONE pass per camera into the scratch already held (4 M records to begin with); a pass that runs out of segments only
     // counts what it would have needed, and everything is repeated once with that much room
     size_t cap = std::max<size_t>(ts.keys.cap, (size_t)1 << 22);
@@ -2058,6 +2068,11 @@ int dsi_mapper_resolve_near_ties(dsi_mapper_t* out, dsi_mapper_t* const* mappers
     // A WIDENED pass can ask for orders of magnitude more voxels than the first; if it overflows a workgroup's segment
     // table (or the 32-bit bookkeeping) the call does not fail: it keeps the last completed pass's patch and statistics
     // and returns DSI_OK with premise_ok = 0 -- "the caller decides", as the header says.
+    {
+        dsi_mapper* ms0[2] = {mappers[0], n == 2 ? mappers[1] : nullptr};
+        const dsi_batch* bs0[2] = {batches[0], n == 2 ? batches[1] : nullptr};
+        if (int rc = tie_packet_geometry(st, ms0, bs0, n)) return rc;  // (queued ahead of the first wait below)
+    }
     for (int widenings = 0;; ++widenings) {
         const dsi_resolve_info_t last_good = *info;
         info->rel_gap = rel_gap;
@@ -2076,7 +2091,8 @@ int dsi_mapper_resolve_near_ties(dsi_mapper_t* out, dsi_mapper_t* const* mappers
         dsi_mapper* ms[2] = {mappers[0], n == 2 ? mappers[1] : nullptr};
         const dsi_batch* bs[2] = {batches[0], n == 2 ? batches[1] : nullptr};
         bool overflow = false;
-        if (int rc = tie_exact_values_dev(ts, st, ms, bs, n, (int)n_cand, /*grid_stats=*/true, &votes, widenings > 0 ? &overflow : nullptr)) {
+        if (int rc = tie_exact_values_dev(ts, st, ms, bs, n, (int)n_cand, /*grid_stats=*/true, &votes, widenings > 0 ? &overflow : nullptr,
+                                          /*geometry_ready=*/true)) {
             if (widenings == 0) return rc;
             overflow = true;  // (too many voxels x events for the sort key, > 2^33 votes: the same verdict)
             g_last_error.clear();
