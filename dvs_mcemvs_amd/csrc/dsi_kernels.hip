@@ -4412,11 +4412,18 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                     //  313 against 304 us)
                     for (int ty = tylo; ty <= tyhi; ++ty) {
                         const unsigned rb = tie_tile_start(tstart, ty * bg.tx_n + txlo), re = tie_tile_start(tstart, ty * bg.tx_n + txhi + 1);
-                        for (unsigned r = rb; r < re; ++r) {
-                            const float x0 = rec_x[r], y0 = rec_y[r];
-                            // the exact pre-image test (the tiles are coarser); the bounds are never NaN: ia, q finite, hw finite or +inf
-                            if (!(x0 >= xlo && x0 <= xhi && y0 >= ylo && y0 <= yhi)) continue;
+                        // (the loop variable is the record's LDS address itself: no index -> address step per record)
+                        for (const float* px = rec_x + rb; px < rec_x + re; ++px) {
+                            const float x0 = px[0], y0 = px[kPacket];  // (rec_y = rec_x + kPacket)
+                            // the pre-image test proper (the tiles are coarser), as max(|x0 - cx0|, |y0 - cy0|) <= hw: two
+                            // subtractions, one maximum with |.| operands and ONE comparison, where four comparisons against
+                            // xlo / xhi / ylo / yhi took four compares + three scalar mask operations -- in the loop whose trip count
+                            // is the longest lane's, i.e. where most of this kernel's instructions are.  The subtraction's own
+                            // rounding (<= 2^-24 hw) moves the cut by 1e-7 hw; hw carries 16 times the bound it needs (above).
+                            // Never NaN: records are finite, ia and q finite, hw finite or +inf.
+                            if (!(fmaxf(fabsf(x0 - cx0), fabsf(y0 - cy0)) <= hw)) continue;
                             const unsigned pos = atomicAdd(&s_qn[wv], 1u);  // (LDS)
+                            const unsigned r = (unsigned)(px - rec_x);
                             if (pos < (unsigned)kTieQueue)
                                 s_q[wv][pos] = ((unsigned)(c - v_beg) << 10) | r;
                             else  // a full queue (a burst of events on one pixel): vote in place
