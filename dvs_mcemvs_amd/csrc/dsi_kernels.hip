@@ -17,6 +17,8 @@
 #include "dsi_vote_asm.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <mutex>
 #include <vector>
@@ -4150,6 +4152,8 @@ struct alignas(16) TiePlane {  // per (packet, plane), in LDS
     float ia, qx, qy;    // z0 location of integer X: x0 = X * ia + qx (ia = d / a, qx = -bx / a), same for y
     float hw;            // half width of the pre-image of [X - 1, X + 1) in z0 pixels, rounding included; < 0: no votes;
                          // +inf (with ia = qx = qy = 0): scan the whole packet
+    float c_lo, c_hi;    // tile of the box's edges: floor(fma(centre, 1 / tile, c_lo | c_hi)), c = (margin -+ hw) / tile
+    float pad_[2];
 };
 
 struct TieBinGeom {
@@ -4320,6 +4324,12 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                     P.ia = P.qx = P.qy = 0.f;
                     P.hw = __builtin_inff();
                 }
+                // (widened by 1e-3 tile: the fused multiply-add, these constants' own roundings and the two roundings of a
+                //  record's tile (tie_tile_coord) are each below 3e-5 tile wherever a tile index is not clamped, so a record
+                //  with edge <= x has tile(edge) <= tile(x) whatever |ia| is; hw = +inf: -inf / +inf -- the clamps take the row)
+                P.c_lo = ((float)bg.margin - P.hw) * inv_tile - 1e-3f;
+                P.c_hi = ((float)bg.margin + P.hw) * inv_tile + 1e-3f;
+                P.pad_[0] = P.pad_[1] = 0.f;
                 tp[z] = P;
             }
         }
@@ -4404,10 +4414,17 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) v
                 const float hw = look.w;
                 if (hw >= 0.f) {
                     const float ia = look.x, qx = look.y, qy = look.z;
-                    const float cx0 = (float)vx * ia + qx, cy0 = (float)vy * ia + qy;
-                    const float xlo = cx0 - hw, xhi = cx0 + hw, ylo = cy0 - hw, yhi = cy0 + hw;
-                    const int txlo = tie_tile_coord(xlo, bg.margin, inv_tile, bg.tx_n), txhi = tie_tile_coord(xhi, bg.margin, inv_tile, bg.tx_n);
-                    const int tylo = tie_tile_coord(ylo, bg.margin, inv_tile, bg.ty_n), tyhi = tie_tile_coord(yhi, bg.margin, inv_tile, bg.ty_n);
+                    // the box's tiles from the centre with ONE fused multiply-add per edge and per-plane constants (this is the
+                    // superset filter, not the reference's arithmetic; its roundings are covered by the constants' widening,
+                    // see where they are made): 18 vector instructions per (voxel, packet) instead of the 32 of
+                    // centre -+ hw, (edge + margin) / tile, floor, two clamps (same box: 305 -> 296 us per camera)
+                    const float cx0 = __builtin_fmaf((float)vx, ia, qx), cy0 = __builtin_fmaf((float)vy, ia, qy);
+                    const float2 cc = *reinterpret_cast<const float2*>(&tp[vz].c_lo);
+                    const float fx_n = (float)(bg.tx_n - 1), fy_n = (float)(bg.ty_n - 1);
+                    const int txlo = (int)__builtin_amdgcn_fmed3f(__builtin_floorf(__builtin_fmaf(cx0, inv_tile, cc.x)), 0.f, fx_n);
+                    const int txhi = (int)__builtin_amdgcn_fmed3f(__builtin_floorf(__builtin_fmaf(cx0, inv_tile, cc.y)), 0.f, fx_n);
+                    const int tylo = (int)__builtin_amdgcn_fmed3f(__builtin_floorf(__builtin_fmaf(cy0, inv_tile, cc.x)), 0.f, fy_n);
+                    const int tyhi = (int)__builtin_amdgcn_fmed3f(__builtin_floorf(__builtin_fmaf(cy0, inv_tile, cc.y)), 0.f, fy_n);
                     // (measured and dropped: both tile rows' starts read together and one loop over the records of both --
                     //  313 against 304 us)
                     for (int ty = tylo; ty <= tyhi; ++ty) {
@@ -4738,9 +4755,10 @@ __device__ __forceinline__ void tie_block_sort(const unsigned long long* __restr
 // waves of four held 48 KB of LDS idle for ~5 us per run: 0.42 ms at configs[1])
 // CAP: the runs of (CAP / 2, CAP] votes (CAP = 1024: of up to 1,024; CAP = kTieRunLds: also the longer ones, in windows) -- a
 // workgroup of the wrong class leaves at once; three launches, so that the many short runs do not each hold 48 KB of LDS
-// T threads: 256, and 512 for the longest class -- its 48 KB of LDS allow three workgroups per CU whatever their size, so twice the
-// threads sort a run in about half the time (k_tie_sort_runs<4096>: 0.152 -> see DESIGN 4.6)
-template <int CAP, int T = (CAP > 2048 ? 512 : 256)>
+// T threads: 256 for the shortest class, 512 for the others -- the longest's 48 KB of LDS allow three workgroups per CU whatever
+// their size, so twice the threads sort a run in about two thirds of the time (same-box: k_tie_sort_runs<4096> 152 -> 99 us with
+// 512 threads, 106 with 1,024; <2048> 30.8 -> 28.5 us)
+template <int CAP, int T = (CAP > 1024 ? 512 : 256)>
 __global__ __launch_bounds__(T) void k_tie_sort_runs(const unsigned long long* __restrict__ runs, const uint32_t* __restrict__ starts,
                                                        const uint32_t* __restrict__ counts, unsigned pos_bits, int n_ranks,
                                                        float* __restrict__ sorted_w)
@@ -5792,7 +5810,7 @@ hipError_t launch_tie_partition_sums(hipStream_t s, const unsigned long long* ke
     if (n_rec) {
         hipLaunchKernelGGL(k_tie_sort_runs<1024>, dim3(n_ranks), dim3(256), 0, s, runs, starts, counts, pos_bits, (int)n_ranks, sorted_w);
         if (hipError_t e = hipExtGetLastError()) return e;
-        hipLaunchKernelGGL(k_tie_sort_runs<2048>, dim3(n_ranks), dim3(256), 0, s, runs, starts, counts, pos_bits, (int)n_ranks, sorted_w);
+        hipLaunchKernelGGL(k_tie_sort_runs<2048>, dim3(n_ranks), dim3(512), 0, s, runs, starts, counts, pos_bits, (int)n_ranks, sorted_w);
         if (hipError_t e = hipExtGetLastError()) return e;
         hipLaunchKernelGGL(k_tie_sort_runs<kTieRunLds>, dim3(n_ranks), dim3(512), 0, s, runs, starts, counts, pos_bits, (int)n_ranks, sorted_w);
         if (hipError_t e = hipExtGetLastError()) return e;
