@@ -36,6 +36,35 @@ def _oracle_fused(rig, n, op, dims, lut=None, inverse=False, depths=(4.0, 200.0)
     return ref, r.planes
 
 
+@pytest.mark.parametrize("rel_gap,min_ranks", [(0.05, 3_000), (0.45, 31_000)])
+def test_resolver_with_very_many_contenders(ctx, rel_gap, min_ranks):
+    """A gap far beyond rounding size makes (nearly) every voxel of a column a contender: tens of thousands of (camera, voxel)
+    ranks.  Below 30,720 ranks the recorded votes are partitioned through the per-stretch table in LDS (round 6: counting
+    launch -> k_tie_colscan -> scattering launch, no global atomic), above it with one global atomic per vote; short and empty
+    runs, runs that are not a multiple of the addition kernel's 64 weights per turn, and rows of a wave whose runs end at
+    different turns all occur.  Whatever the gap, re-summing MORE voxels in the reference's order must give the oracle's map."""
+    nx, ny, nz = 64, 48, 24
+    rig = syn.stereo_rig(60_000, width=nx, height=ny, duration=0.3, seed=77, n_points=500)
+    shape = d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0)
+    batches = _batches(ctx, rig, 2)
+    ms = [d.MapperEMVS(ctx, rig["cam"], shape) for _ in range(2)]
+    for m, b in zip(ms, batches):
+        m.evaluateDSI_batch(b)
+    out = d.MapperEMVS(ctx, rig["cam"], shape)
+    out.computeDepthMapOfFusion(ms[0].dsi_, ms[1].dsi_, d.FUSE_HM)
+    ref, planes = _oracle_fused(rig, 2, d.FUSE_HM, (nx, ny, nz))
+    rconf, ridx = orc.collapse_max_z(ref)
+    info = out.resolveNearTies(ms, batches, d.FUSE_HM, rel_gap=rel_gap)
+    depth, conf, idx = out.fetchDepthMap()
+    assert 2 * info["candidate_voxels"] >= min_ranks, info
+    assert info["gap_widenings"] == 0 and info["premise_ok"] == 1, info
+    assert np.array_equal(idx, ridx), "%d pixels differ; %r" % ((idx != ridx).sum(), info)
+    assert np.array_equal(depth, planes[ridx])
+    assert np.allclose(conf, rconf, rtol=1e-4, atol=1e-6)
+    for o in ms + [out] + batches:
+        o.close()
+
+
 @pytest.mark.parametrize("n_cams,op", [(1, 0), (2, d.FUSE_HM), (2, d.FUSE_MIN), (2, d.FUSE_GM), (2, d.FUSE_AM),
                                        (2, d.FUSE_RMS), (2, d.FUSE_MAX)])
 @pytest.mark.parametrize("events", [12_000, 150_000])
