@@ -242,6 +242,10 @@ struct TieScratch {
     DevBuf<unsigned long long> keys, keys2;
     DevBuf<float> w, exact, diff;
     DevBuf<char> tmp;  // dsi_mapper_patch_depth_map: the new indices
+    DevBuf<uint32_t> votes[2];  // dsi_mapper_prove_near_ties: the cameras' vote counters per integer location
+    bool votes_valid[2] = {false, false};
+    DevBuf<uint2> unproven;     // ... and the columns it could not prove (pixel, float bits of the gap the column needs)
+    size_t n_unproven = 0;
     unsigned* host = nullptr;  // page-locked copy of the counters: the three reads of a call are plain DMAs
     hipError_t host_counters(unsigned** out)
     {
@@ -255,6 +259,7 @@ struct TieScratch {
         if (host) (void)hipHostFree(host);
         host = nullptr;
         cand.release(); count.release(); desc.release(); cols.release(); counters.release();
+        votes[0].release(); votes[1].release(); unproven.release();
         keys.release(); keys2.release(); w.release(); exact.release(); diff.release(); tmp.release();
         rank_count.release(); rank_start.release(); rank_cursor.release();
     }
@@ -2126,6 +2131,107 @@ int dsi_mapper_resolve_near_ties(dsi_mapper_t* out, dsi_mapper_t* const* mappers
         if (info->premise_ok || widenings == 3 || rel_gap * 4.f >= 0.5f) return finish();
         rel_gap *= 4.f;
     }
+}
+
+int dsi_mapper_prove_near_ties(dsi_mapper_t* out, dsi_mapper_t* const* mappers, const dsi_batch_t* const* batches, int n, int op,
+                               dsi_prove_info_t* info)
+{
+    REQUIRE(out && mappers && batches && info, DSI_ERR_INVALID, "null argument");
+    REQUIRE(n == 1 || n == 2, DSI_ERR_INVALID, "1 or 2 cameras (got %d)", n);
+    REQUIRE(n == 1 || (op >= 1 && op <= 6), DSI_ERR_BAD_OP, "improper fusion method %d (expected 1..6)", op);
+    const float rel_gap = info->rel_gap > 0.f ? info->rel_gap : 2.5e-4f;
+    REQUIRE(rel_gap < 0.5f, DSI_ERR_INVALID, "rel_gap %g is not a rounding-sized gap", (double)rel_gap);
+    dsi_context* ctx = out->ctx;
+    for (int i = 0; i < n; ++i) {
+        REQUIRE(mappers[i] && batches[i], DSI_ERR_INVALID, "camera %d: null mapper or batch", i);
+        REQUIRE(mappers[i]->ctx == ctx && batches[i]->ctx == ctx, DSI_ERR_CONTEXT,
+                "mappers, batches and the output mapper must share one context");
+        REQUIRE(same_shape(out->grid, mappers[i]->grid), DSI_ERR_SHAPE, "camera %d: DSI shape differs from the output mapper's", i);
+    }
+    REQUIRE(n == 1 || mappers[0] != mappers[1], DSI_ERR_INVALID, "the cameras need distinct mappers");
+    const dsi::Geom& g0 = out->geom;
+    const size_t nvox = (size_t)g0.nx * g0.ny * g0.nz;
+    if (int rc = set_device(ctx)) return rc;
+    hipStream_t st = ctx->stream;
+    const auto t_begin = std::chrono::steady_clock::now();
+    *info = dsi_prove_info_t{};
+    info->rel_gap = rel_gap;
+    TieScratch& ts = out->tie;
+    dsi_mapper* ms[2] = {mappers[0], n == 2 ? mappers[1] : nullptr};
+    const dsi_batch* bs[2] = {batches[0], n == 2 ? batches[1] : nullptr};
+    if (int rc = tie_packet_geometry(st, ms, bs, n)) return rc;
+    ts.votes_valid[0] = ts.votes_valid[1] = false;
+    for (int c = 0; c < n; ++c) {
+        HIP_TRY(ts.votes[c].reserve(nvox));
+        HIP_TRY(hipMemsetAsync(ts.votes[c].p, 0, nvox * sizeof(uint32_t), st));
+        dsi_mapper* m = ms[c];
+        if (!bs[c]->n_packets) continue;
+        HIP_TRY(dsi::launch_count_votes(st, bs[c]->x, bs[c]->y, bs[c]->first, m->H.p, m->lut_dev, m->sensor_w, m->sensor_h, m->centers.p,
+                                        m->planes_dev, m->geom, (int)bs[c]->n_packets, ts.votes[c].p));
+    }
+    HIP_TRY(ts.counters.reserve(kTieCounterWords / 2));
+    unsigned* cnt = reinterpret_cast<unsigned*>(ts.counters.p);
+    HIP_TRY(hipMemsetAsync(cnt, 0, 5 * sizeof(unsigned), st));
+    HIP_TRY(ts.unproven.reserve((size_t)g0.nx * g0.ny));
+    ts.n_unproven = 0;
+    HIP_TRY(dsi::launch_tie_prove(st, ms[0]->grid->data, n == 2 ? ms[1]->grid->data : nullptr, ts.votes[0].p, n == 2 ? ts.votes[1].p : nullptr,
+                                  op, g0.nx, g0.ny, g0.nz, rel_gap, cnt, ts.unproven.p));
+    unsigned* pinned = nullptr;
+    HIP_TRY(ts.host_counters(&pinned));
+    HIP_TRY(hipMemcpyAsync(pinned, cnt, 5 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int c = 0; c < n; ++c) ts.votes_valid[c] = true;
+    ts.n_unproven = pinned[4];
+    info->columns = (long long)g0.nx * g0.ny;
+    info->columns_proven = pinned[0];
+    info->columns_unproven = pinned[1];
+    float need = 0.f;
+    std::memcpy(&need, &pinned[2], sizeof need);
+    info->gap_needed = pinned[1] ? (double)need : 0.0;
+    info->max_votes = pinned[3];
+    info->elapsed_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    return DSI_OK;
+}
+
+int dsi_mapper_proof_unproven(dsi_mapper_t* out, uint32_t* pixels, float* gaps, size_t capacity, size_t* n)
+{
+    REQUIRE(out && n && (capacity == 0 || pixels), DSI_ERR_INVALID, "null argument");
+    TieScratch& ts = out->tie;
+    REQUIRE(ts.votes_valid[0], DSI_ERR_INVALID, "no proof has run on this mapper");
+    *n = ts.n_unproven;
+    const size_t take = std::min(capacity, ts.n_unproven);
+    if (!take) return DSI_OK;
+    if (int rc = set_device(out->ctx)) return rc;
+    std::vector<uint2> host(take);
+    HIP_TRY(hipMemcpyAsync(host.data(), ts.unproven.p, take * sizeof(uint2), hipMemcpyDeviceToHost, out->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(out->ctx->stream));
+    for (size_t i = 0; i < take; ++i) {
+        pixels[i] = host[i].x;
+        if (gaps) std::memcpy(&gaps[i], &host[i].y, sizeof(float));
+    }
+    return DSI_OK;
+}
+
+int dsi_mapper_proof_votes(dsi_mapper_t* out, int camera, const uint32_t* voxels, size_t n, uint32_t* votes)
+{
+    REQUIRE(out && (n == 0 || (voxels && votes)), DSI_ERR_INVALID, "null argument");
+    REQUIRE(camera == 0 || camera == 1, DSI_ERR_INVALID, "camera %d (0 or 1)", camera);
+    const dsi::Geom& g0 = out->geom;
+    const size_t nvox = (size_t)g0.nx * g0.ny * g0.nz;
+    TieScratch& ts = out->tie;
+    REQUIRE(ts.votes[camera].cap >= nvox && ts.votes_valid[camera], DSI_ERR_INVALID, "no proof has counted camera %d's votes on this mapper", camera);
+    REQUIRE(n < ((size_t)1 << 31), DSI_ERR_INVALID, "too many voxels");
+    for (size_t i = 0; i < n; ++i) REQUIRE(voxels[i] < nvox, DSI_ERR_INVALID, "voxel %zu (%u) is outside the grid", i, voxels[i]);
+    if (n == 0) return DSI_OK;
+    if (int rc = set_device(out->ctx)) return rc;
+    hipStream_t st = out->ctx->stream;
+    HIP_TRY(ts.cand.reserve(n));
+    HIP_TRY(ts.count.reserve(n));
+    HIP_TRY(hipMemcpyAsync(ts.cand.p, voxels, n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    HIP_TRY(dsi::launch_tie_votes_of(st, ts.votes[camera].p, ts.cand.p, (int)n, g0.nx, g0.ny, ts.count.p));
+    HIP_TRY(hipMemcpyAsync(votes, ts.count.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));  // (pageable host arrays)
+    return DSI_OK;
 }
 
 int dsi_grid_near_tie_voxels(dsi_mapper_t* scratch, dsi_grid_t* g, float rel_gap, uint32_t* voxels, size_t capacity,

@@ -246,6 +246,17 @@ hipError_t launch_tie_pick(hipStream_t s, int op, const uint4* cols, int n_cols,
 // runs: n_rec words; wts is consumed (it receives the weights in event order).  exact[cam * nsv + c], count[...] <- sequential fp32
 // sum / number of the votes of voxel c of camera cam; diff[...] (optional; needs grid0 (and grid1 for two cameras)) <-
 // |grid_cam[vox[c]] - exact| / max(1, |exact|).  No library call.
+// the resolver's premise as a per-column proof (dsi_mapper_prove_near_ties): H (nz * ny * nx zeroed words) <- the reference's
+// votes per INTEGER location (a voxel's votes: the four locations whose 2 x 2 footprint holds it); then, per column, every plane
+// below best - rel_gap * best against the maximum's plane with rigorous bounds of both reference values.  stats5 (zeroed):
+// columns proven, columns not, float bits of the rel_gap that would take the offending planes in, most votes in a voxel,
+// entries of unproven[] (pixel, float bits of the gap that column needs)
+hipError_t launch_count_votes(hipStream_t s, const uint16_t* ex, const uint16_t* ey, const uint32_t* packet_first, const float* H9,
+                              const float2* lut, int sensor_w, int sensor_h, const float* centers, const float* planes, const Geom& g,
+                              int np, uint32_t* H);
+hipError_t launch_tie_votes_of(hipStream_t s, const uint32_t* H, const uint32_t* vox, int n, int nx, int ny, uint32_t* votes);
+hipError_t launch_tie_prove(hipStream_t s, const float* a, const float* b, const uint32_t* Ha, const uint32_t* Hb, int op, int nx,
+                            int ny, int nz, float rel_gap, unsigned* stats5, uint2* unproven /* nx * ny entries, or nullptr */);
 // cursor: tie_partition_cursor_words(n_ranks) words (the per-stretch table of the LDS path, or one cursor per rank)
 size_t tie_partition_cursor_words(size_t n_ranks);
 hipError_t launch_tie_partition_sums(hipStream_t s, const unsigned long long* keys, const float* wts, unsigned long long n_rec,

@@ -5703,6 +5703,220 @@ hipError_t launch_div_probe(hipStream_t s, const float* n, const float* d, size_
     return hipExtGetLastError();  // status of THIS launch (hipGetLastError is sticky across calls)
 }
 
+// ---- the resolver's premise as a per-column PROOF (dsi_mapper_prove_near_ties) ----
+// The resolver re-sums the planes within rel_gap of a column's maximum and trusts that no plane outside can win under the
+// reference's arithmetic.  That is provable once the number n of votes of every voxel is known: the reference adds a voxel's n
+// non-negative weights one by one in fp32, so its value R lies within gamma_(n-1) = (n-1) u / (1 - (n-1) u), u = 2^-24, of their
+// real sum (the standard bound for recursive summation), and the engine's value E is that sum with every weight rounded to 2^-31
+// and ONE rounding to fp32.  The engine keeps no counts; this pass makes them:
+//   k_count_votes   H[z][yi][xi] += 1 for every vote the reference casts (transfer with the IEEE divide, accept test of
+//                   cartesian3dgrid.h:255-259) -- the integer location (xi, yi) of the vote's 2 x 2 footprint; a voxel's n is
+//                   the sum of the four H cells whose footprint contains it.  Global atomics on a u32 volume: a verification
+//                   pass, not a product kernel (~1 G atomics per camera at configs[1]).
+//   k_tie_prove     thread = column: the engine's first maximum, the resolver's threshold, and for every plane BELOW the
+//                   threshold an upper bound of its reference value against a lower bound of the maximum's.
+// block = (packet, group of kVgPlanes planes); thread t owns events t, t + 256, ... of the packet (as k_vote_global)
+__global__ __launch_bounds__(256) void k_count_votes(TieEvents ev, const float* __restrict__ centers, const float* __restrict__ planes,
+                                                     Geom g, uint32_t* __restrict__ H)
+{
+    const int k = blockIdx.x;
+    const int zbeg = blockIdx.y * kVgPlanes, zend = min(g.nz, zbeg + kVgPlanes);
+    const float cx_ = centers[3 * k], cy_ = centers[3 * k + 1], cz_ = centers[3 * k + 2];
+    const size_t first = ev.first ? (size_t)ev.first[k] : (size_t)k * kPacket;
+    float hh[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) hh[i] = ev.H[9 * (size_t)k + i];
+    float2 e[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const size_t at = first + threadIdx.x + 256 * i;
+        e[i] = warp_event_z0(ev.x[at], ev.y[at], hh, ev.lut, ev.sensor_w, ev.sensor_h);  // mapper_emvs_stereo.cpp:129-142
+    }
+    const float xmax = (float)(g.nx - 1), ymax = (float)(g.ny - 1);
+    const size_t plane_sz = (size_t)g.nx * g.ny;
+    for (int z = zbeg; z < zend; ++z) {
+        float a, bx, by, d;
+        plane_coefficients(cx_, cy_, cz_, planes[z], g, a, bx, by, d);
+        uint32_t* plane = H + (size_t)z * plane_sz;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float X = (e[i].x * a + bx) / d;  // :194
+            const float Y = (e[i].y * a + by) / d;  // :195
+            if (X >= 0.f && Y >= 0.f && X < xmax && Y < ymax) atomicAdd(plane + (size_t)(int)Y * g.nx + (int)X, 1u);  // (see vote_global)
+        }
+    }
+}
+
+hipError_t launch_count_votes(hipStream_t s, const uint16_t* ex, const uint16_t* ey, const uint32_t* packet_first, const float* H9,
+                              const float2* lut, int sensor_w, int sensor_h, const float* centers, const float* planes, const Geom& g,
+                              int np, uint32_t* H)
+{
+    if (np <= 0) return hipSuccess;
+    const TieEvents ev{ex, ey, packet_first, H9, lut, sensor_w, sensor_h};
+    hipLaunchKernelGGL(k_count_votes, dim3(np, (g.nz + kVgPlanes - 1) / kVgPlanes), dim3(256), 0, s, ev, centers, planes, g, H);
+    return hipExtGetLastError();
+}
+
+// [lo, hi] of the value the REFERENCE holds in a voxel whose engine value is E (exact sum of the weights rounded to 2^-31, rounded
+// once to fp32) and which received n votes.  n u >= 1/2: no bound (hi = +inf).
+__device__ __forceinline__ void tie_reference_interval(float E, uint32_t n, double* lo, double* hi)
+{
+    if (n == 0u) {  // no vote: exactly zero in either arithmetic
+        *lo = *hi = 0.0;
+        return;
+    }
+    const double u = 5.9604644775390625e-8, q = (double)n * 2.3283064365386963e-10;  // 2^-24; n 2^-32 (the weights' rounding)
+    const double nu = (double)(n - 1u) * u;
+    if (!(nu < 0.5)) {
+        *lo = 0.0;
+        *hi = __builtin_inf();
+        return;
+    }
+    const double gamma = nu / (1.0 - nu);
+    const double w_hi = (double)E * (1.0 + 2.0 * u) + q, w_lo = fmax(0.0, (double)E * (1.0 - 2.0 * u) - q);  // the weights' real sum
+    *hi = w_hi * (1.0 + gamma);
+    *lo = fmax(0.0, w_lo * (1.0 - gamma));
+    // E > 0 means the rounded weights sum to at least 2^-31, so ONE weight is at least 2^-32 -- and a sequential fp32 sum of
+    // non-negative terms is never below any of them (fl(s + w) >= max(s, w)): the reference's value is not zero either.  Without
+    // this floor a column whose maximum is a handful of tiny weights could not even exclude its all-zero planes.
+    if (E > 0.f) *lo = fmax(*lo, 1.1641532182693481e-10);  // 2^-33
+}
+
+// the fusion op as a real function (monotone non-decreasing in both arguments on [0, inf)); the fp32 chains of fuse_op stay
+// within 8 u of it (at most five roundings)
+template <int OP>
+__device__ __forceinline__ double tie_fuse_real(double a, double g)
+{
+    if (OP == 0) return a;
+    if (OP == 1) return fmin(a, g);
+    if (OP == 2) return 2.0 * a * g / (a + g + (double)0.1f);
+    if (OP == 3) return sqrt(a * g);
+    if (OP == 4) return 0.5 * (a + g);
+    if (OP == 5) return sqrt(0.5 * (a * a + g * g));
+    return fmax(a, g);
+}
+
+__device__ __forceinline__ uint32_t tie_votes_of(const uint32_t* __restrict__ Hz, int x, int y, int nx)
+{
+    // the votes whose 2 x 2 footprint (xi .. xi + 1, yi .. yi + 1) contains (x, y): integer locations (x - 1 .. x, y - 1 .. y)
+    uint32_t n = Hz[(size_t)y * nx + x];
+    if (x > 0) n += Hz[(size_t)y * nx + x - 1];
+    if (y > 0) n += Hz[(size_t)(y - 1) * nx + x];
+    if (x > 0 && y > 0) n += Hz[(size_t)(y - 1) * nx + x - 1];
+    return n;
+}
+
+// stats: [0] columns proven, [1] columns with a plane below the threshold that the bounds cannot exclude, [2] float bits of the
+// largest (maximum - value) / maximum among those planes (the rel_gap that would have taken them all in), [3] most votes in a voxel,
+// [4] entries of unproven[] (pixel, float bits of the gap the column needs)
+template <int OP>
+__global__ __launch_bounds__(256) void k_tie_prove(const float* __restrict__ a, const float* __restrict__ b,
+                                                   const uint32_t* __restrict__ Ha, const uint32_t* __restrict__ Hb, int nx, int ny,
+                                                   int nz, float rel_gap, unsigned* __restrict__ stats, uint2* __restrict__ unproven)
+{
+    __shared__ unsigned s_stats[4];
+    if (threadIdx.x < 4) s_stats[threadIdx.x] = 0u;
+    __syncthreads();
+    const int npix = nx * ny;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < npix) {
+        const int y = p / nx, x = p - y * nx;
+        // the engine's arg-max: first maximum of the fused exact values (k_collapse_max_z_fused / k_tie_columns)
+        float best = tie_value<OP>(a, b, p);
+        int zbest = 0;
+        for (int z = 1; z < nz; ++z) {
+            const float v = tie_value<OP>(a, b, (size_t)z * npix + p);
+            if (best < v) {
+                best = v;
+                zbest = z;
+            }
+        }
+        bool proven = true;
+        float need = 0.f;
+        unsigned most = 0u;
+        if (best > 0.f) {  // (an empty column is exactly zero in either summation order)
+            const float thr = best - rel_gap * best;  // k_tie_columns / k_tie_contenders
+            const double c8 = 8.0 * 5.9604644775390625e-8;
+            double lo0, hi0, lo1 = 0.0, hi1 = 0.0;
+            {
+                const size_t i = (size_t)zbest * npix + p;
+                const uint32_t n0 = tie_votes_of(Ha + (size_t)zbest * npix, x, y, nx);
+                tie_reference_interval(a[i], n0, &lo0, &hi0);
+                most = n0;
+                if (OP != 0) {
+                    const uint32_t n1 = tie_votes_of(Hb + (size_t)zbest * npix, x, y, nx);
+                    tie_reference_interval(b[i], n1, &lo1, &hi1);
+                    most = max(most, n1);
+                }
+            }
+            const double winner_lo = tie_fuse_real<OP>(lo0, lo1) * (1.0 - c8);
+            for (int z = 0; z < nz; ++z) {
+                const size_t i = (size_t)z * npix + p;
+                const float v = tie_value<OP>(a, b, i);
+                if (v >= thr) continue;  // within the gap: re-summed in the reference's order by the resolver (or the maximum itself)
+                const uint32_t n0 = tie_votes_of(Ha + (size_t)z * npix, x, y, nx);
+                double l0, h0, l1 = 0.0, h1 = 0.0;
+                tie_reference_interval(a[i], n0, &l0, &h0);
+                most = max(most, n0);
+                if (OP != 0) {
+                    const uint32_t n1 = tie_votes_of(Hb + (size_t)z * npix, x, y, nx);
+                    tie_reference_interval(b[i], n1, &l1, &h1);
+                    most = max(most, n1);
+                }
+                const double upper = tie_fuse_real<OP>(h0, h1) * (1.0 + c8);
+                if (!(upper < winner_lo)) {  // cannot be excluded (strictly below: an equal value at a lower plane would win)
+                    proven = false;
+                    need = fmaxf(need, (best - v) / best);
+                }
+            }
+        }
+        atomicAdd(&s_stats[proven ? 0 : 1], 1u);
+        if (!proven) {
+            atomicMax(&s_stats[2], __float_as_uint(need));  // (non-negative floats order like their bits)
+            // the column and the gap it needs, for callers that treat the few hard columns one by one (room for every pixel)
+            if (unproven) unproven[atomicAdd(&stats[4], 1u)] = make_uint2((unsigned)p, __float_as_uint(need));
+        }
+        atomicMax(&s_stats[3], most);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 && s_stats[threadIdx.x]) atomicAdd(&stats[threadIdx.x], s_stats[threadIdx.x]);
+    if (threadIdx.x >= 2 && threadIdx.x < 4 && s_stats[threadIdx.x]) atomicMax(&stats[threadIdx.x], s_stats[threadIdx.x]);
+}
+
+// votes[i] <- the votes of voxel vox[i] (z * ny * nx + y * nx + x) according to the counters H (tie_votes_of)
+__global__ __launch_bounds__(256) void k_tie_votes_of(const uint32_t* __restrict__ H, const uint32_t* __restrict__ vox, int n, int nx, int ny,
+                                                      uint32_t* __restrict__ votes)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v = vox[i], npix = (uint32_t)nx * (uint32_t)ny;
+    const uint32_t z = v / npix, p = v - z * npix, y = p / (uint32_t)nx, x = p - y * (uint32_t)nx;
+    votes[i] = tie_votes_of(H + (size_t)z * npix, (int)x, (int)y, nx);
+}
+
+hipError_t launch_tie_votes_of(hipStream_t s, const uint32_t* H, const uint32_t* vox, int n, int nx, int ny, uint32_t* votes)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_tie_votes_of, dim3((n + 255) / 256), dim3(256), 0, s, H, vox, n, nx, ny, votes);
+    return hipExtGetLastError();
+}
+
+hipError_t launch_tie_prove(hipStream_t s, const float* a, const float* b, const uint32_t* Ha, const uint32_t* Hb, int op, int nx,
+                            int ny, int nz, float rel_gap, unsigned* stats4, uint2* unproven)
+{
+    const dim3 grid((nx * ny + 255) / 256), block(256);
+#define DSI_TIE_PROVE(OPV)                                                                                      \
+    case OPV:                                                                                                   \
+        hipLaunchKernelGGL(k_tie_prove<OPV>, grid, block, 0, s, a, b, Ha, Hb, nx, ny, nz, rel_gap, stats4, unproven); \
+        break;
+    switch (b ? op : 0) {
+        DSI_TIE_PROVE(0) DSI_TIE_PROVE(1) DSI_TIE_PROVE(2) DSI_TIE_PROVE(3) DSI_TIE_PROVE(4) DSI_TIE_PROVE(5) DSI_TIE_PROVE(6)
+    default: return hipErrorInvalidValue;
+    }
+#undef DSI_TIE_PROVE
+    return hipExtGetLastError();
+}
+
 hipError_t launch_tie_candidates(hipStream_t s, const float* a, const float* b, int op, int npix, int nz, float rel_gap,
                                  unsigned* counters, uint32_t* cand, uint32_t cap, uint4* cols, uint32_t cols_cap)
 {

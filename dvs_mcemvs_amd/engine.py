@@ -57,6 +57,12 @@ class _ScatterPlan(C.Structure):
                 ("tail_count", C.c_int)]
 
 
+class _ProveInfo(C.Structure):
+    _fields_ = [("rel_gap", C.c_float), ("columns", C.c_longlong), ("columns_proven", C.c_longlong),
+                ("columns_unproven", C.c_longlong), ("gap_needed", C.c_double), ("max_votes", C.c_longlong),
+                ("elapsed_ms", C.c_float), ("columns_resolved_fully", C.c_longlong)]
+
+
 class _ResolveInfo(C.Structure):
     _fields_ = [("rel_gap", C.c_float), ("near_tie_pixels", C.c_int), ("candidate_voxels", C.c_int),
                 ("candidate_planes", C.c_int), ("votes", C.c_longlong), ("changed_pixels", C.c_int),
@@ -207,6 +213,9 @@ def load_library():
         "dsi_mapper_depth_map_from_keys": (C.c_int, [vp]),
         "dsi_mapper_resolve_near_ties": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int,
                                                   C.POINTER(_ResolveInfo)]),
+        "dsi_mapper_prove_near_ties": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.POINTER(_ProveInfo)]),
+        "dsi_mapper_proof_votes": (C.c_int, [vp, C.c_int, u32p, C.c_size_t, u32p]),
+        "dsi_mapper_proof_unproven": (C.c_int, [vp, u32p, f32p, C.c_size_t, szp]),
         "dsi_grid_near_tie_voxels": (C.c_int, [vp, vp, C.c_float, u32p, C.c_size_t, szp, szp]),
         "dsi_mapper_exact_voxels": (C.c_int, [vp, vp, u32p, C.c_size_t, f32p, u32p]),
         "dsi_reference_fuse2": (C.c_int, [C.c_int, f32p, f32p, C.c_size_t, f32p]),
@@ -949,6 +958,38 @@ class MapperEMVS:
         info.rel_gap = float(rel_gap)
         _check(load_library().dsi_mapper_resolve_near_ties(self._h, hm, hb, n, int(fusion_method), C.byref(info)))
         return {k: getattr(info, k) for k, _ in _ResolveInfo._fields_}
+
+    def proveNearTies(self, mappers, batches, fusion_method=FUSE_HM, rel_gap=0.0):
+        """The resolver's premise as a per-column proof (dsi_mapper_prove_near_ties; a verification pass): counts the votes of
+        every voxel of the mappers' DSIs (built from `batches`) and checks, with rigorous bounds of the reference's fp32
+        event-order sums, that in every column no plane outside `rel_gap` of the maximum can be the reference's first
+        maximum.  Returns {columns, columns_proven, columns_unproven, gap_needed, max_votes, elapsed_ms, rel_gap}."""
+        n = len(mappers)
+        hm = (C.c_void_p * n)(*[m._h for m in mappers])
+        hb = (C.c_void_p * n)(*[b._h for b in batches])
+        info = _ProveInfo()
+        info.rel_gap = float(rel_gap)
+        _check(load_library().dsi_mapper_prove_near_ties(self._h, hm, hb, n, int(fusion_method), C.byref(info)))
+        return {k: getattr(info, k) for k, _ in _ProveInfo._fields_}
+
+    def proofUnproven(self):
+        """dsi_mapper_proof_unproven: (pixels uint32[n], gaps float32[n]) -- the columns the last proveNearTies could not
+        prove and the rel_gap each of them alone would need."""
+        n = C.c_size_t(0)
+        lib = load_library()
+        _check(lib.dsi_mapper_proof_unproven(self._h, None, None, 0, C.byref(n)))
+        pixels, gaps = np.empty(n.value, np.uint32), np.empty(n.value, np.float32)
+        if n.value:
+            _check(lib.dsi_mapper_proof_unproven(self._h, _ptr(pixels, C.c_uint32), _ptr(gaps, C.c_float), n.value, C.byref(n)))
+        return pixels, gaps
+
+    def proofVotes(self, camera, voxels):
+        """dsi_mapper_proof_votes: the votes of the listed voxels of camera 0 / 1 as the last proveNearTies counted them."""
+        voxels = _arr(voxels, np.uint32)
+        votes = np.empty(voxels.shape, np.uint32)
+        _check(load_library().dsi_mapper_proof_votes(self._h, int(camera), _ptr(voxels, C.c_uint32), voxels.size,
+                                                     _ptr(votes, C.c_uint32)))
+        return votes
 
     def nearTieVoxels(self, grid=None, rel_gap=0.0):
         """dsi_grid_near_tie_voxels of `grid` (default: this mapper's DSI): the voxels (linear indices z*Ny*Nx + y*Nx + x)

@@ -263,6 +263,50 @@ def _first_maxima(vox, values, npix):
     return pix_of[starts].astype(np.uint32), z_of[j].astype(np.uint8), values[j].astype(np.float32)
 
 
+def resolve_columns_fully(mapper_fused, mappers, batches, fusion_method, pixels):
+    """ALL planes of the listed columns (pixels y * dimX + x) re-summed per camera in the reference's order
+    (MapperEMVS.exactVoxels), fused with the reference's scalar op (engine.reference_fuse2; one camera: as they are), the first
+    maximum taken (cartesian3dgrid.cpp:132-134) and the depth map of mapper_fused patched: these columns are then the
+    reference's by construction, whatever their values.  For the FEW columns a proof cannot settle -- it costs
+    planes x columns voxels.  Returns the number of pixels whose plane changed."""
+    pixels = np.unique(np.asarray(pixels, np.uint32))
+    if not pixels.size:
+        return 0
+    nx, ny, nz = mapper_fused.dsi_.getDimensions()
+    npix = nx * ny
+    vox = (pixels[:, None].astype(np.uint64) + np.arange(nz, dtype=np.uint64)[None, :] * npix).reshape(-1).astype(np.uint32)
+    vals = [m.exactVoxels(b, vox)[0] for m, b in zip(mappers, batches)]   # (pixel-major, planes ascending)
+    final = vals[0] if len(mappers) == 1 else E.reference_fuse2(fusion_method, vals[0], vals[1])
+    pix, new_idx, new_conf = _first_maxima(vox, final, npix)
+    idx0 = mapper_fused.fetchDepthMap()[2].reshape(-1)[pix]
+    mapper_fused.patchDepthMap(pix, new_idx, new_conf)
+    return int((idx0 != new_idx).sum())
+
+
+def resolve_near_ties_proven(mapper_fused, mappers, batches, fusion_method=E.FUSE_HM, rel_gap=0.0, max_gap=4e-3,
+                             max_full_columns=4096):
+    """MapperEMVS.resolveNearTies in PROVEN mode (ABI 10): resolve, then MapperEMVS.proveNearTies -- every voxel's votes counted,
+    the reference's fp32 event-order sums bounded from the counts.  Columns whose bounds reach beyond the gap: if a gap of at
+    most `max_gap` covers some of them the resolver runs again with it (and the proof again); the columns that remain -- maxima
+    made of a handful of tiny weights, where the engine's 2^-31 weight grid is as coarse as the values -- are re-summed on ALL
+    their planes (resolve_columns_fully; at most `max_full_columns`, else they stay unproven).  Returns (resolver info, proof
+    info); proof["columns_unproven"] - proof["columns_resolved_fully"] == 0 means the index map is the reference's on every
+    pixel by proof.  The proof passes are verification passes (global-atomic vote counts): not for a timed loop."""
+    info = mapper_fused.resolveNearTies(mappers, batches, fusion_method, rel_gap=rel_gap)
+    proof = mapper_fused.proveNearTies(mappers, batches, fusion_method, rel_gap=info["rel_gap"])
+    if proof["columns_unproven"]:
+        pix, gaps = mapper_fused.proofUnproven()
+        moderate = gaps[gaps.astype(np.float64) * 1.05 <= max_gap]
+        if moderate.size:
+            info = mapper_fused.resolveNearTies(mappers, batches, fusion_method, rel_gap=float(moderate.max()) * 1.05)
+            proof = mapper_fused.proveNearTies(mappers, batches, fusion_method, rel_gap=info["rel_gap"])
+            pix = mapper_fused.proofUnproven()[0] if proof["columns_unproven"] else pix[:0]
+        if pix.size and pix.size <= max_full_columns:
+            resolve_columns_fully(mapper_fused, mappers, batches, fusion_method, pix)
+            proof["columns_resolved_fully"] = int(pix.size)
+    return info, proof
+
+
 def exact_depth_map_nary(mapper_fused, mappers, batches, mode, rel_gap=0.0, fused_grid=None):
     """The n-camera counterpart of MapperEMVS.resolveNearTies (BASELINE configs[4]): mapper_fused.dsi_ holds
     setToFusionOfN([m.dsi_ for m in mappers], mode) of the DSIs the mappers built from `batches`, and mapper_fused

@@ -39,7 +39,7 @@ extern "C" {
 #define DSI_API
 #endif
 
-#define DSI_ENGINE_ABI_VERSION 9
+#define DSI_ENGINE_ABI_VERSION 10
 #define DSI_PACKET_SIZE 1024 /* mapper_emvs_stereo.hpp:152 packet_size_ */
 
 typedef enum {
@@ -521,6 +521,47 @@ typedef struct {
 } dsi_resolve_info_t;
 DSI_API int dsi_mapper_resolve_near_ties(dsi_mapper_t *out, dsi_mapper_t *const *mappers,
                                          const dsi_batch_t *const *batches, int n, int op, dsi_resolve_info_t *info);
+
+/* The resolver's premise as a PROOF, column by column (ABI 10) -- a verification pass, not part of a step.
+ * dsi_mapper_resolve_near_ties re-sums the planes within rel_gap of a column's maximum in the reference's order and trusts
+ * that no plane outside that gap can win under the reference's arithmetic; it checks this on the voxels it re-sums
+ * (premise_ok), not on the others.  This call closes the gap: it COUNTS the votes of every voxel of every camera (the
+ * transfer of mapper_emvs_stereo.cpp:177-195 with the IEEE divide and the accept test of cartesian3dgrid.h:255-259, one
+ * global atomic per vote on a dimZ x dimY x dimX volume of 32-bit counters per camera), and then bounds, per voxel, the
+ * value the reference holds there: its n non-negative weights added one by one in fp32 stay within
+ * (n - 1) u / (1 - (n - 1) u), u = 2^-24, of their real sum (recursive summation), the engine's value is that sum with
+ * every weight rounded to 2^-31 and one rounding to fp32, and the camera fusion (cartesian3dgrid.h:108-190) is monotone
+ * with at most five roundings.  A column is PROVEN when every plane below best - rel_gap * best has an upper bound
+ * strictly below the lower bound of the maximum's plane: then the reference's first maximum (cartesian3dgrid.cpp:132-134)
+ * is among the planes the resolver re-sums exactly, and the resolved index is the reference's.
+ *   mappers / batches / n / op: as for dsi_mapper_resolve_near_ties (the cameras' DSIs voted from these batches);
+ *   out: any mapper of their shape and context (its scratch holds the counters; its depth map is not touched).
+ * gap_needed: the smallest rel_gap that would have taken every offending plane into the re-summed set (0 when all columns
+ * are proven); resolving again with a gap a little above it and proving again then proves every column. */
+typedef struct {
+    float rel_gap;              /* in: the gap the resolver ran with (0: its default, 2.5e-4) */
+    long long columns;          /* pixels examined: all of them */
+    long long columns_proven;
+    long long columns_unproven;
+    double gap_needed;
+    long long max_votes;        /* most votes in one voxel of one camera */
+    float elapsed_ms;
+    long long columns_resolved_fully; /* 0 from this call; the proven-mode helpers (process_1_exact_depth_map, process.py) count
+                                         here the unproven columns they then re-summed on ALL planes (dsi_mapper_exact_voxels +
+                                         dsi_reference_fuse2 + dsi_mapper_patch_depth_map): exact by construction */
+} dsi_prove_info_t;
+DSI_API int dsi_mapper_prove_near_ties(dsi_mapper_t *out, dsi_mapper_t *const *mappers,
+                                       const dsi_batch_t *const *batches, int n, int op, dsi_prove_info_t *info);
+/* votes[i] <- the number of votes voxel voxels[i] (z * dimY * dimX + y * dimX + x) of camera `camera` (0 or 1) received
+ * according to the counters the LAST dsi_mapper_prove_near_ties on `out` made (what its bounds were computed from; the
+ * same number dsi_mapper_exact_voxels reports from the resolver's own event pass). */
+DSI_API int dsi_mapper_proof_votes(dsi_mapper_t *out, int camera, const uint32_t *voxels, size_t n, uint32_t *votes);
+/* The columns the LAST dsi_mapper_prove_near_ties on `out` could not prove: pixels[i] = y * dimX + x, gaps[i] (optional) = the
+ * rel_gap that column alone would need (1 = down to its all-but-zero planes: a column whose maximum is a handful of tiny
+ * weights, where the engine's 2^-31 weight grid is as coarse as the values).  *n may exceed capacity (nothing is written
+ * beyond it).  Few and hard columns are cheaper to re-sum on ALL their planes (dsi_mapper_exact_voxels) than to widen the
+ * gap of every column for. */
+DSI_API int dsi_mapper_proof_unproven(dsi_mapper_t *out, uint32_t *pixels, float *gaps, size_t capacity, size_t *n);
 
 /* The resolver's building blocks, for fusion topologies it does not cover itself (Alg. 2's camera-then-time fusion,
  * process2.cpp:98-249; n cameras): find the near-tie columns of ANY grid, get the reference-order value of ANY list of

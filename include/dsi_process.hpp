@@ -155,6 +155,37 @@ inline dsi::Transformation process_1_depth_map_n(const LinearTrajectory* const* 
     return T_rv_w;
 }
 
+// ALL planes of the listed columns (pixels y * dimX + x) re-summed per camera in the reference's order
+// (dsi_mapper_exact_voxels), fused with the reference's scalar op (dsi_reference_fuse2; one camera: as they are), the first
+// maximum taken (cartesian3dgrid.cpp:132-134) and out's depth map patched: those columns are then the reference's by
+// construction.  For the FEW columns dsi_mapper_prove_near_ties cannot settle (planes x columns voxels per camera).
+inline void resolve_columns_fully(dsi_mapper_t* out, dsi_mapper_t* const* ms, dsi_batch_t* const* bs, int n, int fusion_method,
+                                  const std::vector<uint32_t>& pixels, int nx, int ny, int nz)
+{
+    if (pixels.empty()) return;
+    const size_t npix = (size_t)nx * ny, ncol = pixels.size();
+    std::vector<uint32_t> vox(ncol * (size_t)nz);
+    for (size_t i = 0; i < ncol; ++i)
+        for (int z = 0; z < nz; ++z) vox[i * (size_t)nz + (size_t)z] = (uint32_t)((size_t)z * npix + pixels[i]);
+    std::vector<float> val[2], fused(vox.size());
+    for (int c = 0; c < n; ++c) {
+        val[c].resize(vox.size());
+        dsi::check(dsi_mapper_exact_voxels(ms[c], bs[c], vox.data(), vox.size(), val[c].data(), nullptr));
+    }
+    if (n == 2) dsi::check(dsi_reference_fuse2(fusion_method, val[0].data(), val[1].data(), vox.size(), fused.data()));
+    else fused = val[0];
+    std::vector<uint8_t> idx(ncol);
+    std::vector<float> conf(ncol);
+    for (size_t i = 0; i < ncol; ++i) {
+        size_t best = 0;
+        for (size_t z = 1; z < (size_t)nz; ++z)
+            if (fused[i * (size_t)nz + best] < fused[i * (size_t)nz + z]) best = z;  // the first maximum
+        idx[i] = (uint8_t)best;
+        conf[i] = fused[i * (size_t)nz + best];
+    }
+    dsi::check(dsi_mapper_patch_depth_map(out, pixels.data(), idx.data(), conf.data(), ncol));
+}
+
 // Alg. 1 + the arg-max of getDepthMapFromDSI with the EXACT TIE RESOLVER (dsi_mapper_resolve_near_ties): what
 // process_1(...) + mapper_fused.getDepthMapFromDSI(depth_map, confidence_map, depth_cell_indices) gives, except that the
 // plane index map equals the CPU reference's on EVERY pixel: the engine sums a voxel's votes exactly and rounds once, the
@@ -162,13 +193,19 @@ inline dsi::Transformation process_1_depth_map_n(const LinearTrajectory* const* 
 // (cartesian3dgrid.cpp:132-134) can differ where a column's best planes are closer than that rounding; those columns'
 // contending voxels are re-summed in the reference's order.  Two cameras; the camera DSIs and the fused DSI are written
 // (mapper0.dsi_, mapper1.dsi_, mapper_fused.dsi_) like process_1 does.  info (optional): the resolver's statistics.
+// proof (optional, ABI 10): PROVEN mode -- after the resolver, dsi_mapper_prove_near_ties counts every voxel's votes and checks
+// with rigorous bounds of the reference's fp32 event-order sums that no plane outside the re-summed gap can be the reference's
+// first maximum; where columns' bounds ask for a moderately wider gap the resolver runs again with it (and the proof again);
+// the columns that remain (maxima made of a handful of tiny weights) are re-summed on ALL their planes (resolve_columns_fully).
+// *proof holds the last pass: columns_unproven - columns_resolved_fully == 0 means the index map is the reference's on every
+// pixel BY PROOF.  A verification pass (two global-atomic vote counts): tens of milliseconds at 10 M events per camera.
 inline dsi::Transformation process_1_exact_depth_map(const LinearTrajectory& trajectory0, const LinearTrajectory& trajectory1,
                                                      const std::vector<dsi::Event>& events0, const std::vector<dsi::Event>& events1,
                                                      EMVS::MapperEMVS& mapper_fused, EMVS::MapperEMVS& mapper0,
                                                      EMVS::MapperEMVS& mapper1, double ts, int fusion_method,
                                                      dsi::Image<float>& depth_map, dsi::Image<float>& confidence_map,
                                                      dsi::Image<uint8_t>& depth_cell_indices, dsi_resolve_info_t* info = nullptr,
-                                                     double rv_pos = 0.0)
+                                                     double rv_pos = 0.0, dsi_prove_info_t* proof = nullptr)
 {
     dsi::Transformation T_w_l;
     if (!trajectory0.getPoseAt(ts, T_w_l)) throw dsi::Error(DSI_ERR_INVALID, "no pose at the reference timestamp");
@@ -212,7 +249,48 @@ inline dsi::Transformation process_1_exact_depth_map(const LinearTrajectory& tra
         dsi::fuseTwoGrids(mapper_fused.dsi_, mapper1.dsi_, fusion_method, "Improper fusion method selected");
         dsi::check(dsi_mapper_depth_map_of(mapper_fused.handle(), mapper_fused.dsi_.handle()));  // :222 -> collapseMaxZSlice
         dsi_resolve_info_t local{};
-        dsi::check(dsi_mapper_resolve_near_ties(mapper_fused.handle(), ms, bs, 2, fusion_method, info ? info : &local));
+        dsi_resolve_info_t* ri = info ? info : &local;
+        dsi::check(dsi_mapper_resolve_near_ties(mapper_fused.handle(), ms, bs, 2, fusion_method, ri));
+        if (proof) {
+            auto prove = [&]() {
+                *proof = dsi_prove_info_t{};
+                proof->rel_gap = ri->rel_gap;  // (the gap the resolver ended with: it may have widened its own)
+                dsi::check(dsi_mapper_prove_near_ties(mapper_fused.handle(), ms, bs, 2, fusion_method, proof));
+            };
+            auto unproven = [&](std::vector<uint32_t>& pix, std::vector<float>& gaps) {
+                size_t m = 0;
+                dsi::check(dsi_mapper_proof_unproven(mapper_fused.handle(), nullptr, nullptr, 0, &m));
+                pix.resize(m);
+                gaps.resize(m);
+                if (m) dsi::check(dsi_mapper_proof_unproven(mapper_fused.handle(), pix.data(), gaps.data(), m, &m));
+            };
+            prove();
+            if (proof->columns_unproven) {
+                // columns whose bounds reach beyond the gap: one more resolver pass if a moderate gap (<= 16 x the default) covers
+                // some of them; what remains -- maxima made of a handful of tiny weights -- is re-summed on ALL its planes
+                std::vector<uint32_t> pix;
+                std::vector<float> gaps;
+                unproven(pix, gaps);
+                const double max_gap = 4e-3;
+                double moderate = 0.0;
+                for (float gp : gaps)
+                    if ((double)gp * 1.05 <= max_gap) moderate = std::max(moderate, (double)gp * 1.05);
+                if (moderate > 0.0) {
+                    *ri = dsi_resolve_info_t{};
+                    ri->rel_gap = (float)moderate;
+                    dsi::check(dsi_mapper_resolve_near_ties(mapper_fused.handle(), ms, bs, 2, fusion_method, ri));
+                    prove();
+                    if (proof->columns_unproven) unproven(pix, gaps);
+                    else pix.clear();
+                }
+                if (!pix.empty() && pix.size() <= 4096) {
+                    int gx, gy, gz;
+                    mapper_fused.dsi_.getDimensions(&gx, &gy, &gz);
+                    resolve_columns_fully(mapper_fused.handle(), ms, bs, 2, fusion_method, pix, gx, gy, gz);
+                    proof->columns_resolved_fully = (long long)pix.size();
+                }
+            }
+        }
         int nx, ny, nz;
         mapper_fused.dsi_.getDimensions(&nx, &ny, &nz);
         depth_map = dsi::Image<float>(ny, nx);

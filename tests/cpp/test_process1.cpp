@@ -283,6 +283,20 @@ int main()
                                 differ, method, rinfo.near_tie_pixels);
                     return 67;
                 }
+                // PROVEN mode (ABI 10): the same map, and every column's premise proven from the counted votes
+                dsi::Image<float> d4, c4;
+                dsi::Image<uint8_t> i4;
+                dsi_resolve_info_t rinfo4{};
+                dsi_prove_info_t proof{};
+                process_1_exact_depth_map(trajectory0, trajectory1, events0, events1, mapper_fused, mapper0, mapper1, 0.5, method, d4,
+                                          c4, i4, &rinfo4, 0.0, &proof);
+                if (i4.data != i3.data || proof.columns != (long long)npix || proof.columns_unproven != proof.columns_resolved_fully ||
+                    proof.columns_proven + proof.columns_unproven != (long long)npix || proof.max_votes <= 0) {
+                    std::printf("proven mode, fusion method %d: %lld of %lld columns proven, %lld re-summed fully (gap %g, needed %g), "
+                                "index maps %s\n", method, proof.columns_proven, proof.columns, proof.columns_resolved_fully,
+                                (double)proof.rel_gap, proof.gap_needed, i4.data == i3.data ? "equal" : "DIFFER");
+                    return 71;
+                }
             }
             // three cameras (process1.cpp:105-117, :169-191): the right camera's second half of events plays camera 2
             {

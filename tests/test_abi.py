@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(built):
     lib = ctypes.CDLL(d.library_path())
     missing = [s for s in syms if not hasattr(lib, s)]
     assert not missing, "not exported: %s" % missing
-    assert lib.dsi_abi_version() == 9
+    assert lib.dsi_abi_version() == 10
     # the Python binding declares a signature for every exported entry point
     L = d.load_library()
     unbound = [s for s in syms if getattr(L, s).argtypes is None]

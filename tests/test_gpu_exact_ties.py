@@ -204,6 +204,87 @@ def test_resolver_checks_its_premise_and_widens_the_gap(ctx):
         o.close()
 
 
+@pytest.mark.parametrize("n_cams,op", [(1, 0), (2, d.FUSE_HM), (2, d.FUSE_MIN), (2, d.FUSE_GM), (2, d.FUSE_AM),
+                                       (2, d.FUSE_RMS), (2, d.FUSE_MAX)])
+def test_the_resolvers_premise_is_proven_column_by_column(ctx, n_cams, op):
+    """dsi_mapper_prove_near_ties (round 6): every voxel's votes are COUNTED, the reference's fp32 event-order sum is bounded
+    from them ((n - 1) u / (1 - (n - 1) u) of the weights' real sum), and a column is proven when no plane below the
+    resolver's threshold can reach the maximum's plane under those bounds.  (1) The counts are the resolver's own -- the
+    inverted event pass reports the same number for any voxel (an independent kernel).  (2) With a gap of rounding size
+    nothing is proven for the contested columns, and gap_needed says how far to widen; (3) resolving with that gap and
+    proving again proves EVERY column, and the resolved map is the oracle's -- now not by comparison alone."""
+    nx, ny, nz = 96, 72, 32
+    rig = syn.stereo_rig(150_000, width=nx, height=ny, duration=0.3, seed=11, n_points=700)
+    shape = d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0)
+    batches = _batches(ctx, rig, n_cams)
+    ms = [d.MapperEMVS(ctx, rig["cam"], shape) for _ in range(n_cams)]
+    for m, b in zip(ms, batches):
+        m.evaluateDSI_batch(b)
+    out = d.MapperEMVS(ctx, rig["cam"], shape)
+    if n_cams == 1:
+        out.computeDepthMap(ms[0].dsi_)
+    else:
+        out.computeDepthMapOfFusion(ms[0].dsi_, ms[1].dsi_, op)
+    tiny = out.proveNearTies(ms, batches, op, rel_gap=1e-7)
+    assert tiny["columns"] == nx * ny and tiny["columns_proven"] + tiny["columns_unproven"] == nx * ny
+    assert tiny["columns_unproven"] > 0 and tiny["gap_needed"] > 1e-7, tiny
+    assert tiny["gap_needed"] < 1e-2, tiny  # rounding-sized: the bounds are not vacuous
+    # (1) the counters against the resolver's event pass, on random voxels and on the heaviest column
+    rng = np.random.default_rng(3)
+    vox = rng.integers(0, nx * ny * nz, 4000).astype(np.uint32)
+    for c in range(n_cams):
+        got = out.proofVotes(c, vox)
+        _, want = ms[c].exactVoxels(batches[c], vox)
+        assert np.array_equal(got, want), "camera %d: %d of %d vote counts differ" % (c, (got != want).sum(), vox.size)
+        assert got.max() > 10
+    # (2) + (3)
+    gap = float(tiny["gap_needed"]) * 1.05 + 1e-9
+    info = out.resolveNearTies(ms, batches, op, rel_gap=gap)
+    assert info["gap_widenings"] == 0
+    proof = out.proveNearTies(ms, batches, op, rel_gap=gap)
+    assert proof["columns_unproven"] == 0 and proof["columns_proven"] == nx * ny and proof["gap_needed"] == 0.0, proof
+    ref, planes = _oracle_fused(rig, n_cams, op, (nx, ny, nz))
+    _, ridx = orc.collapse_max_z(ref)
+    _, _, idx = out.fetchDepthMap()
+    assert np.array_equal(idx, ridx)
+    # a much wider gap stays proven (more planes re-summed, fewer to bound)
+    wide = out.proveNearTies(ms, batches, op, rel_gap=min(0.4, 50 * gap))
+    assert wide["columns_unproven"] == 0
+    for o in ms + [out] + batches:
+        o.close()
+
+
+@pytest.mark.parametrize("events,op", [(12_000, d.FUSE_HM), (12_000, d.FUSE_GM), (150_000, d.FUSE_HM), (150_000, d.FUSE_MIN)])
+def test_proven_mode_settles_every_column(ctx, events, op):
+    """process.resolve_near_ties_proven: resolve, prove; a moderately wider gap for the columns whose bounds ask for one; and the
+    columns no gap of reasonable size settles -- with few events many columns' maxima are a handful of tiny weights, where the
+    engine's 2^-31 weight grid is as coarse as the values -- re-summed on ALL their planes.  Afterwards every column is either
+    proven by bounds or exact by construction, and the map is the oracle's."""
+    nx, ny, nz = 96, 72, 32
+    rig = syn.stereo_rig(events, width=nx, height=ny, duration=0.3, seed=5 + events % 7, n_points=700)
+    shape = d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0)
+    batches = _batches(ctx, rig, 2)
+    ms = [d.MapperEMVS(ctx, rig["cam"], shape) for _ in range(2)]
+    for m, b in zip(ms, batches):
+        m.evaluateDSI_batch(b)
+    out = d.MapperEMVS(ctx, rig["cam"], shape)
+    out.computeDepthMapOfFusion(ms[0].dsi_, ms[1].dsi_, op)
+    info, proof = proc.resolve_near_ties_proven(out, ms, batches, op)
+    assert proof["columns"] == nx * ny and proof["columns_proven"] + proof["columns_unproven"] == nx * ny
+    assert proof["columns_unproven"] == proof["columns_resolved_fully"], (info, proof)
+    ref, planes = _oracle_fused(rig, 2, op, (nx, ny, nz))
+    rconf, ridx = orc.collapse_max_z(ref)
+    depth, conf, idx = out.fetchDepthMap()
+    assert np.array_equal(idx, ridx), "%d pixels differ; %r" % ((idx != ridx).sum(), proof)
+    assert np.array_equal(depth, planes[ridx])
+    if proof["columns_resolved_fully"]:
+        # a fully re-summed column carries the oracle's own confidence, bit for bit
+        pix, _ = out.proofUnproven()
+        assert np.array_equal(conf.reshape(-1)[pix], rconf.reshape(-1)[pix])
+    for o in ms + [out] + batches:
+        o.close()
+
+
 def test_in_order_fetch_gives_the_same_depth_map(ctx):
     """dsi_mapper_fetch_depth_map_in_order (the maps stored by a kernel into mapped page-locked memory on the compute stream,
     or copied there when the destination is pageable) = dsi_mapper_fetch_depth_map."""

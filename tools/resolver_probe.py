@@ -25,3 +25,17 @@ for rep in range(3):
     t = time.perf_counter()
     res = ms[0].resolveNearTies(ms, bs, d.FUSE_HM)
     print("resolver wall %.1f ms" % (1e3 * (time.perf_counter() - t)), res)
+# the premise as a per-column proof (dsi_mapper_prove_near_ties): with the resolver's default gap, then with the gap it asks for
+t = time.perf_counter()
+proof = ms[0].proveNearTies(ms, bs, d.FUSE_HM)
+print("proof wall %.1f ms" % (1e3 * (time.perf_counter() - t)), proof)
+if proof["columns_unproven"]:
+    gap = proof["gap_needed"] * 1.05
+    fused.setToFusionOf(ms[0].dsi_, ms[1].dsi_, d.FUSE_HM)
+    ms[0].computeDepthMap(fused)
+    for rep in range(2):
+        ctx.synchronize()
+        t = time.perf_counter()
+        res = ms[0].resolveNearTies(ms, bs, d.FUSE_HM, rel_gap=gap)
+        print("resolver at the gap the proof needs: wall %.1f ms" % (1e3 * (time.perf_counter() - t)), res)
+    print("proof again", ms[0].proveNearTies(ms, bs, d.FUSE_HM, rel_gap=gap))
