@@ -516,8 +516,9 @@ typedef struct {
     int columns_bounded;    /*      near-tie columns (of the last pass) whose gap also covers the WORST-CASE reordering error of
                                     their own most-voted contender, 2 ((votes) 2^-24 + 2^-22): for those no plane with at most
                                     that many votes can have been left out wrongly.  (Planes outside the gap with more votes than
-                                    every contender are not covered -- the engine keeps no per-voxel vote counts --, so this is a
-                                    statistic beside premise_ok, not a proof.) */
+                                    every contender are not covered -- a step keeps no per-voxel vote counts --, so this is a
+                                    statistic beside premise_ok, not a proof; the proof, with counted votes, is
+                                    dsi_mapper_prove_near_ties below.) */
 } dsi_resolve_info_t;
 DSI_API int dsi_mapper_resolve_near_ties(dsi_mapper_t *out, dsi_mapper_t *const *mappers,
                                          const dsi_batch_t *const *batches, int n, int op, dsi_resolve_info_t *info);
