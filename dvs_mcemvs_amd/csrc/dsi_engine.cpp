@@ -2147,6 +2147,10 @@ int dsi_mapper_prove_near_ties(dsi_mapper_t* out, dsi_mapper_t* const* mappers, 
         REQUIRE(mappers[i]->ctx == ctx && batches[i]->ctx == ctx, DSI_ERR_CONTEXT,
                 "mappers, batches and the output mapper must share one context");
         REQUIRE(same_shape(out->grid, mappers[i]->grid), DSI_ERR_SHAPE, "camera %d: DSI shape differs from the output mapper's", i);
+        // the bounds describe the EXACT sums of the LDS-band mappings (weights truncated to 2^-31, one rounding): a DSI voted
+        // with fp32 global atomics or with the paired 32-bit cells (rounded Q.19 weights) is not one
+        REQUIRE(batches[i]->n_packets == 0 || (mappers[i]->info.algo == DSI_VOTE_LDS_BANDS && mappers[i]->info.packed != 8),
+                DSI_ERR_INVALID, "camera %d: the proof needs a DSI of exact sums (DSI_VOTE_LDS_BANDS, not lane mapping 8)", i);
     }
     REQUIRE(n == 1 || mappers[0] != mappers[1], DSI_ERR_INVALID, "the cameras need distinct mappers");
     const dsi::Geom& g0 = out->geom;

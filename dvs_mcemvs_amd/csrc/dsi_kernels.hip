@@ -5757,15 +5757,18 @@ hipError_t launch_count_votes(hipStream_t s, const uint16_t* ex, const uint16_t*
     return hipExtGetLastError();
 }
 
-// [lo, hi] of the value the REFERENCE holds in a voxel whose engine value is E (exact sum of the weights rounded to 2^-31, rounded
-// once to fp32) and which received n votes.  n u >= 1/2: no bound (hi = +inf).
+// [lo, hi] of the value the REFERENCE holds in a voxel whose engine value is E (exact sum of the weights truncated to the 2^-31
+// grid, rounded once to fp32: the LDS-band mappings other than the paired one) and which received n votes.  n u >= 1/2: no bound
+// (hi = +inf).
 __device__ __forceinline__ void tie_reference_interval(float E, uint32_t n, double* lo, double* hi)
 {
     if (n == 0u) {  // no vote: exactly zero in either arithmetic
         *lo = *hi = 0.0;
         return;
     }
-    const double u = 5.9604644775390625e-8, q = (double)n * 2.3283064365386963e-10;  // 2^-24; n 2^-32 (the weights' rounding)
+    // u = 2^-24; q = n 2^-31: the voting kernels TRUNCATE a weight to the 2^-31 grid (v_cvt_u32_f32), so the sum of the real
+    // weights lies between the engine's integer sum and that sum + n 2^-31 (taken on both sides here)
+    const double u = 5.9604644775390625e-8, q = (double)n * 4.6566128730773926e-10;
     const double nu = (double)(n - 1u) * u;
     if (!(nu < 0.5)) {
         *lo = 0.0;
@@ -5776,7 +5779,7 @@ __device__ __forceinline__ void tie_reference_interval(float E, uint32_t n, doub
     const double w_hi = (double)E * (1.0 + 2.0 * u) + q, w_lo = fmax(0.0, (double)E * (1.0 - 2.0 * u) - q);  // the weights' real sum
     *hi = w_hi * (1.0 + gamma);
     *lo = fmax(0.0, w_lo * (1.0 - gamma));
-    // E > 0 means the rounded weights sum to at least 2^-31, so ONE weight is at least 2^-32 -- and a sequential fp32 sum of
+    // E > 0 means the truncated weights sum to at least 2^-31, so ONE weight is at least 2^-31 -- and a sequential fp32 sum of
     // non-negative terms is never below any of them (fl(s + w) >= max(s, w)): the reference's value is not zero either.  Without
     // this floor a column whose maximum is a handful of tiny weights could not even exclude its all-zero planes.
     if (E > 0.f) *lo = fmax(*lo, 1.1641532182693481e-10);  // 2^-33

@@ -531,8 +531,9 @@ DSI_API int dsi_mapper_resolve_near_ties(dsi_mapper_t *out, dsi_mapper_t *const 
  * global atomic per vote on a dimZ x dimY x dimX volume of 32-bit counters per camera), and then bounds, per voxel, the
  * value the reference holds there: its n non-negative weights added one by one in fp32 stay within
  * (n - 1) u / (1 - (n - 1) u), u = 2^-24, of their real sum (recursive summation), the engine's value is that sum with
- * every weight rounded to 2^-31 and one rounding to fp32, and the camera fusion (cartesian3dgrid.h:108-190) is monotone
- * with at most five roundings.  A column is PROVEN when every plane below best - rel_gap * best has an upper bound
+ * every weight truncated to the 2^-31 grid and one rounding to fp32 (the mappers' DSIs must be such exact sums:
+ * DSI_VOTE_LDS_BANDS, not the paired lane mapping 8 -- DSI_ERR_INVALID otherwise), and the camera fusion
+ * (cartesian3dgrid.h:108-190) is monotone with at most five roundings.  A column is PROVEN when every plane below best - rel_gap * best has an upper bound
  * strictly below the lower bound of the maximum's plane: then the reference's first maximum (cartesian3dgrid.cpp:132-134)
  * is among the planes the resolver re-sums exactly, and the resolved index is the reference's.
  *   mappers / batches / n / op: as for dsi_mapper_resolve_near_ties (the cameras' DSIs voted from these batches);

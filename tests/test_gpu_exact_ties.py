@@ -330,6 +330,26 @@ def test_resolver_argument_checks(ctx):
     other = d.MapperEMVS(ctx, rig["cam"], d.ShapeDSI(0, 0, 9, 4.0, 100.0, 0.0))
     with pytest.raises(d.DsiError):
         out.resolveNearTies([ms[0], other], batches, d.FUSE_HM)
+    # the proof: same argument rules; no list of unproven columns before a proof has run; and a DSI that is not the exact
+    # sums its bounds describe (fp32 global atomics, the paired 32-bit cells) is refused, not "proven"
+    with pytest.raises(d.DsiError):
+        out.proofUnproven()
+    with pytest.raises(d.DsiError):
+        out.proveNearTies(ms, batches, 9)
+    with pytest.raises(d.DsiError):
+        out.proveNearTies([ms[0], other], batches, d.FUSE_HM)
+    assert out.proveNearTies(ms, batches, d.FUSE_HM)["columns"] == 64 * 48
+    with pytest.raises(d.DsiError):
+        out.proofVotes(0, np.array([64 * 48 * 8], np.uint32))      # outside the grid
+    for knob in ("paired", "global"):
+        if knob == "paired":
+            ms[1].set_packed_lanes(8)
+        else:
+            ms[1].set_packed_lanes(-1)
+            ms[1].set_vote_algo(d.VOTE_GLOBAL_ATOMIC)
+        ms[1].evaluateDSI_batch(batches[1])
+        with pytest.raises(d.DsiError):
+            out.proveNearTies(ms, batches, d.FUSE_HM)
     for o in ms + [out, other] + batches:
         o.close()
 
