@@ -254,6 +254,46 @@ def test_the_resolvers_premise_is_proven_column_by_column(ctx, n_cams, op):
         o.close()
 
 
+@pytest.mark.parametrize("events", [12_000, 400_000])
+def test_the_proofs_interval_holds_the_reference_order_value(ctx, events):
+    """The bound k_tie_prove relies on, checked voxel by voxel against values it never sees: for 30,000 random voxels the
+    engine's exact value E (the DSI), the counted votes n (dsi_mapper_proof_votes) and the value R the reference's summation
+    order gives (dsi_mapper_exact_voxels: fp32, event order, an independent kernel).  R must lie in
+    [max(0, E(1 - 2u) - n 2^-31) (1 - g), (E(1 + 2u) + n 2^-31) (1 + g)], g = (n - 1) u / (1 - (n - 1) u), u = 2^-24 -- the
+    interval of tie_reference_interval, restated here in numpy -- and must be positive wherever E is; and the truncation of the
+    weights to the 2^-31 grid is one-sided: the engine's sum never exceeds the reference-order value by more than rounding."""
+    nx, ny, nz = 96, 72, 32
+    rig = syn.stereo_rig(events, width=nx, height=ny, duration=0.3, seed=31, n_points=300)
+    shape = d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0)
+    b = _batches(ctx, rig, 1)[0]
+    m = d.MapperEMVS(ctx, rig["cam"], shape)
+    m.evaluateDSI_batch(b)
+    m.computeDepthMap(m.dsi_)
+    m.proveNearTies([m], [b], 0)
+    rng = np.random.default_rng(8)
+    dsi = m.dsi_.download().reshape(-1)
+    heavy = np.argsort(dsi)[-5000:].astype(np.uint32)                     # the most-voted voxels, where the bound matters
+    vox = np.concatenate([rng.integers(0, dsi.size, 25000).astype(np.uint32), heavy])
+    E = dsi[vox].astype(np.float64)
+    n = m.proofVotes(0, vox).astype(np.float64)
+    R, n2 = m.exactVoxels(b, vox)
+    assert np.array_equal(n2.astype(np.float64), n)
+    R = R.astype(np.float64)
+    u, q = 2.0 ** -24, n * 2.0 ** -31
+    g = np.where(n > 0, (n - 1) * u / (1 - (n - 1) * u), 0.0)
+    hi = (E * (1 + 2 * u) + q) * (1 + g)
+    lo = np.maximum(0.0, E * (1 - 2 * u) - q) * (1 - g)
+    lo = np.where(E > 0, np.maximum(lo, 2.0 ** -33), lo)
+    assert np.all(R <= hi) and np.all(R >= lo), "%d voxels outside their interval" % int(((R > hi) | (R < lo)).sum())
+    assert np.all((n > 0) | ((E == 0) & (R == 0)))
+    assert n.max() > (50 if events < 100_000 else 2000)
+    # how much of the interval the real difference uses: far less than all of it (worst-case bound), but not nothing
+    used = np.abs(R - E) / np.maximum(hi - lo, 1e-300)
+    assert used.max() < 0.5 and used.max() > 1e-4
+    m.close()
+    b.close()
+
+
 @pytest.mark.parametrize("events,op", [(12_000, d.FUSE_HM), (12_000, d.FUSE_GM), (150_000, d.FUSE_HM), (150_000, d.FUSE_MIN)])
 def test_proven_mode_settles_every_column(ctx, events, op):
     """process.resolve_near_ties_proven: resolve, prove; a moderately wider gap for the columns whose bounds ask for one; and the
