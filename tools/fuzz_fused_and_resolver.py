@@ -28,7 +28,7 @@ for seed in range(first, first + count):
         print("FUSED FUZZ FAILURE seed", seed, str(e)[:300])
 print("fused fuzz: %d seeds, %d failures" % (count, bad))
 
-bad2 = 0
+bad2 = bad3 = 0
 for seed in range(first, first + max(1, count // 5)):
     rng = np.random.default_rng(7000 + seed)
     nx, ny, nz = int(rng.integers(16, 160)), int(rng.integers(12, 120)), int(rng.integers(2, 48))
@@ -59,7 +59,19 @@ for seed in range(first, first + max(1, count // 5)):
     if not np.array_equal(idx, ref.argmax(axis=0)):
         bad2 += 1
         print("RESOLVER FUZZ FAILURE seed", seed, (nx, ny, nz), n_cams, op, n_ev, int((idx != ref.argmax(axis=0)).sum()), info)
+    # proven mode on the same problem (round 6): every column proven by bounds or re-summed on all planes, same map; and the
+    # proof must never call a column proven whose resolved plane differs from the oracle's
+    from dvs_mcemvs_amd import process as proc
+    if n_cams == 1:
+        out.computeDepthMap(ms[0].dsi_)
+    else:
+        out.computeDepthMapOfFusion(ms[0].dsi_, ms[1].dsi_, op)
+    info_p, proof = proc.resolve_near_ties_proven(out, ms, batches, op, max_full_columns=10 ** 9)
+    _, _, idx_p = out.fetchDepthMap()
+    if proof["columns_unproven"] != proof["columns_resolved_fully"] or not np.array_equal(idx_p, ref.argmax(axis=0)):
+        bad3 += 1
+        print("PROVEN MODE FUZZ FAILURE seed", seed, (nx, ny, nz), n_cams, op, n_ev, int((idx_p != ref.argmax(axis=0)).sum()), proof)
     for o in ms + [out] + batches:
         o.close()
-print("resolver fuzz: %d seeds, %d failures" % (max(1, count // 5), bad2))
-sys.exit(1 if bad or bad2 else 0)
+print("resolver fuzz: %d seeds, %d failures; proven mode: %d failures" % (max(1, count // 5), bad2, bad3))
+sys.exit(1 if bad or bad2 or bad3 else 0)
