@@ -242,8 +242,8 @@ struct TieScratch {
     DevBuf<unsigned long long> keys, keys2;
     DevBuf<float> w, exact, diff;
     DevBuf<char> tmp;  // dsi_mapper_patch_depth_map: the new indices
-    DevBuf<uint32_t> votes[2];  // dsi_mapper_prove_near_ties: the cameras' vote counters per integer location
-    bool votes_valid[2] = {false, false};
+    DevBuf<uint32_t> votes[8];  // dsi_mapper_prove_near_ties(_n): the cameras' vote counters per integer location
+    bool votes_valid[8] = {false, false, false, false, false, false, false, false};
     DevBuf<uint2> unproven;     // ... and the columns it could not prove (pixel, float bits of the gap the column needs)
     size_t n_unproven = 0;
     unsigned* host = nullptr;  // page-locked copy of the counters: the three reads of a call are plain DMAs
@@ -259,7 +259,8 @@ struct TieScratch {
         if (host) (void)hipHostFree(host);
         host = nullptr;
         cand.release(); count.release(); desc.release(); cols.release(); counters.release();
-        votes[0].release(); votes[1].release(); unproven.release();
+        for (auto& v : votes) v.release();
+        unproven.release();
         keys.release(); keys2.release(); w.release(); exact.release(); diff.release(); tmp.release();
         rank_count.release(); rank_start.release(); rank_cursor.release();
     }
@@ -2164,7 +2165,7 @@ int dsi_mapper_prove_near_ties(dsi_mapper_t* out, dsi_mapper_t* const* mappers, 
     dsi_mapper* ms[2] = {mappers[0], n == 2 ? mappers[1] : nullptr};
     const dsi_batch* bs[2] = {batches[0], n == 2 ? batches[1] : nullptr};
     if (int rc = tie_packet_geometry(st, ms, bs, n)) return rc;
-    ts.votes_valid[0] = ts.votes_valid[1] = false;
+    for (bool& v : ts.votes_valid) v = false;
     for (int c = 0; c < n; ++c) {
         HIP_TRY(ts.votes[c].reserve(nvox));
         HIP_TRY(hipMemsetAsync(ts.votes[c].p, 0, nvox * sizeof(uint32_t), st));
@@ -2180,6 +2181,75 @@ int dsi_mapper_prove_near_ties(dsi_mapper_t* out, dsi_mapper_t* const* mappers, 
     ts.n_unproven = 0;
     HIP_TRY(dsi::launch_tie_prove(st, ms[0]->grid->data, n == 2 ? ms[1]->grid->data : nullptr, ts.votes[0].p, n == 2 ? ts.votes[1].p : nullptr,
                                   op, g0.nx, g0.ny, g0.nz, rel_gap, cnt, ts.unproven.p));
+    unsigned* pinned = nullptr;
+    HIP_TRY(ts.host_counters(&pinned));
+    HIP_TRY(hipMemcpyAsync(pinned, cnt, 5 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int c = 0; c < n; ++c) ts.votes_valid[c] = true;
+    ts.n_unproven = pinned[4];
+    info->columns = (long long)g0.nx * g0.ny;
+    info->columns_proven = pinned[0];
+    info->columns_unproven = pinned[1];
+    float need = 0.f;
+    std::memcpy(&need, &pinned[2], sizeof need);
+    info->gap_needed = pinned[1] ? (double)need : 0.0;
+    info->max_votes = pinned[3];
+    info->elapsed_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    return DSI_OK;
+}
+
+int dsi_mapper_prove_near_ties_n(dsi_mapper_t* out, dsi_grid_t* fused, dsi_mapper_t* const* mappers, const dsi_batch_t* const* batches,
+                                 int n, int mode, dsi_prove_info_t* info)
+{
+    REQUIRE(out && fused && mappers && batches && info, DSI_ERR_INVALID, "null argument");
+    REQUIRE(n >= 1 && n <= 8, DSI_ERR_INVALID, "1 to 8 cameras (got %d)", n);
+    REQUIRE(mode == DSI_ACC_GM_TREE || mode == DSI_ACC_MIN || mode == DSI_ACC_MAX || mode == DSI_ACC_SUM, DSI_ERR_BAD_OP,
+            "mode %d: the proof covers DSI_ACC_GM_TREE, DSI_ACC_MIN, DSI_ACC_MAX and DSI_ACC_SUM", mode);
+    REQUIRE(mode != DSI_ACC_GM_TREE || n == 2 || n == 4 || n == 8, DSI_ERR_BAD_OP, "DSI_ACC_GM_TREE needs 2, 4 or 8 cameras (got %d)", n);
+    const float rel_gap = info->rel_gap > 0.f ? info->rel_gap : 2.5e-4f;
+    REQUIRE(rel_gap < 0.5f, DSI_ERR_INVALID, "rel_gap %g is not a rounding-sized gap", (double)rel_gap);
+    dsi_context* ctx = out->ctx;
+    REQUIRE(fused->ctx == ctx && same_shape(out->grid, fused), DSI_ERR_SHAPE, "the fused grid must have the output mapper's shape and context");
+    for (int i = 0; i < n; ++i) {
+        REQUIRE(mappers[i] && batches[i], DSI_ERR_INVALID, "camera %d: null mapper or batch", i);
+        REQUIRE(mappers[i]->ctx == ctx && batches[i]->ctx == ctx, DSI_ERR_CONTEXT,
+                "mappers, batches and the output mapper must share one context");
+        REQUIRE(same_shape(out->grid, mappers[i]->grid), DSI_ERR_SHAPE, "camera %d: DSI shape differs from the output mapper's", i);
+        REQUIRE(batches[i]->n_packets == 0 || (mappers[i]->info.algo == DSI_VOTE_LDS_BANDS && mappers[i]->info.packed != 8),
+                DSI_ERR_INVALID, "camera %d: the proof needs a DSI of exact sums (DSI_VOTE_LDS_BANDS, not lane mapping 8)", i);
+        for (int k = 0; k < i; ++k) REQUIRE(mappers[i] != mappers[k], DSI_ERR_INVALID, "the cameras need distinct mappers");
+    }
+    const dsi::Geom& g0 = out->geom;
+    const size_t nvox = (size_t)g0.nx * g0.ny * g0.nz;
+    if (int rc = set_device(ctx)) return rc;
+    hipStream_t st = ctx->stream;
+    const auto t_begin = std::chrono::steady_clock::now();
+    *info = dsi_prove_info_t{};
+    info->rel_gap = rel_gap;
+    TieScratch& ts = out->tie;
+    for (bool& v : ts.votes_valid) v = false;
+    const float* e[8] = {};
+    const uint32_t* h[8] = {};
+    for (int c = 0; c < n; ++c) {
+        dsi_mapper* m = mappers[c];
+        const dsi_batch* b = batches[c];
+        dsi_mapper* one_m[1] = {m};
+        const dsi_batch* one_b[1] = {b};
+        if (int rc = tie_packet_geometry(st, one_m, one_b, 1)) return rc;
+        HIP_TRY(ts.votes[c].reserve(nvox));
+        HIP_TRY(hipMemsetAsync(ts.votes[c].p, 0, nvox * sizeof(uint32_t), st));
+        if (b->n_packets)
+            HIP_TRY(dsi::launch_count_votes(st, b->x, b->y, b->first, m->H.p, m->lut_dev, m->sensor_w, m->sensor_h, m->centers.p,
+                                            m->planes_dev, m->geom, (int)b->n_packets, ts.votes[c].p));
+        e[c] = m->grid->data;
+        h[c] = ts.votes[c].p;
+    }
+    HIP_TRY(ts.counters.reserve(kTieCounterWords / 2));
+    unsigned* cnt = reinterpret_cast<unsigned*>(ts.counters.p);
+    HIP_TRY(hipMemsetAsync(cnt, 0, 5 * sizeof(unsigned), st));
+    HIP_TRY(ts.unproven.reserve((size_t)g0.nx * g0.ny));
+    ts.n_unproven = 0;
+    HIP_TRY(dsi::launch_tie_prove_n(st, fused->data, e, h, n, mode, g0.nx, g0.ny, g0.nz, rel_gap, cnt, ts.unproven.p));
     unsigned* pinned = nullptr;
     HIP_TRY(ts.host_counters(&pinned));
     HIP_TRY(hipMemcpyAsync(pinned, cnt, 5 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
@@ -2219,7 +2289,7 @@ int dsi_mapper_proof_unproven(dsi_mapper_t* out, uint32_t* pixels, float* gaps, 
 int dsi_mapper_proof_votes(dsi_mapper_t* out, int camera, const uint32_t* voxels, size_t n, uint32_t* votes)
 {
     REQUIRE(out && (n == 0 || (voxels && votes)), DSI_ERR_INVALID, "null argument");
-    REQUIRE(camera == 0 || camera == 1, DSI_ERR_INVALID, "camera %d (0 or 1)", camera);
+    REQUIRE(camera >= 0 && camera < 8, DSI_ERR_INVALID, "camera %d (0 .. 7)", camera);
     const dsi::Geom& g0 = out->geom;
     const size_t nvox = (size_t)g0.nx * g0.ny * g0.nz;
     TieScratch& ts = out->tie;

@@ -254,6 +254,10 @@ hipError_t launch_tie_pick(hipStream_t s, int op, const uint4* cols, int n_cols,
 hipError_t launch_count_votes(hipStream_t s, const uint16_t* ex, const uint16_t* ey, const uint32_t* packet_first, const float* H9,
                               const float2* lut, int sensor_w, int sensor_h, const float* centers, const float* planes, const Geom& g,
                               int np, uint32_t* H);
+// ... and for n <= 8 cameras fused by an n-ary mode (DSI_ACC_GM_TREE 6 with n = 2, 4, 8; DSI_ACC_MIN 4, DSI_ACC_MAX 5, DSI_ACC_SUM 0):
+// `fused` = the engine's fused grid, whose values decide the near-tie columns and the threshold
+hipError_t launch_tie_prove_n(hipStream_t s, const float* fused, const float* const* e, const uint32_t* const* h, int n, int mode, int nx,
+                              int ny, int nz, float rel_gap, unsigned* stats5, uint2* unproven);
 hipError_t launch_tie_votes_of(hipStream_t s, const uint32_t* H, const uint32_t* vox, int n, int nx, int ny, uint32_t* votes);
 hipError_t launch_tie_prove(hipStream_t s, const float* a, const float* b, const uint32_t* Ha, const uint32_t* Hb, int op, int nx,
                             int ny, int nz, float rel_gap, unsigned* stats5, uint2* unproven /* nx * ny entries, or nullptr */);

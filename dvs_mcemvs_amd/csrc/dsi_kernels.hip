@@ -5904,6 +5904,120 @@ hipError_t launch_tie_votes_of(hipStream_t s, const uint32_t* H, const uint32_t*
     return hipExtGetLastError();
 }
 
+// ---- the same proof for n cameras fused by an n-ary mode (dsi_mapper_prove_near_ties_n: BASELINE configs[4]'s rig) ----
+// fused: the grid the n-ary resolver took its near-tie columns from (dsi_grid_near_tie_voxels: the engine's fused values);
+// e[c] / h[c]: camera c's DSI and vote counters.  MODE: DSI_ACC_GM_TREE (6; n = 2, 4, 8: the balanced tree of the
+// reference's 2-ary sqrt(a * b), cartesian3dgrid.h:150-156), DSI_ACC_MIN (4), DSI_ACC_MAX (5), DSI_ACC_SUM (0: the arithmetic
+// mean).  Every one of them is monotone non-decreasing in each camera's value, with at most 2 n + 2 roundings.
+struct ProveSources {
+    const float* e[8];
+    const uint32_t* h[8];
+    int n;
+};
+
+template <int MODE>
+__device__ __forceinline__ double tie_fuse_real_n(const double* v, int n)
+{
+    if (MODE == 4 || MODE == 5) {
+        double r = v[0];
+        for (int c = 1; c < n; ++c) r = MODE == 4 ? fmin(r, v[c]) : fmax(r, v[c]);
+        return r;
+    }
+    if (MODE == 0) {
+        double r = 0.0;
+        for (int c = 0; c < n; ++c) r += v[c];
+        return r / (double)n;
+    }
+    double t[8];
+    for (int c = 0; c < n; ++c) t[c] = v[c];
+    for (int w = n; w > 1; w >>= 1)
+        for (int c = 0; c < w / 2; ++c) t[c] = sqrt(t[2 * c] * t[2 * c + 1]);
+    return t[0];
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_tie_prove_n(const float* __restrict__ fused, ProveSources src, int nx, int ny, int nz,
+                                                     float rel_gap, unsigned* __restrict__ stats, uint2* __restrict__ unproven)
+{
+    __shared__ unsigned s_stats[4];
+    if (threadIdx.x < 4) s_stats[threadIdx.x] = 0u;
+    __syncthreads();
+    const int npix = nx * ny, n = src.n;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < npix) {
+        const int y = p / nx, x = p - y * nx;
+        float best = fused[p];
+        int zbest = 0;
+        for (int z = 1; z < nz; ++z) {
+            const float v = fused[(size_t)z * npix + p];
+            if (best < v) {
+                best = v;
+                zbest = z;
+            }
+        }
+        bool proven = true;
+        float need = 0.f;
+        unsigned most = 0u;
+        if (best > 0.f) {
+            const float thr = best - rel_gap * best;  // k_tie_columns on the fused grid
+            const double slack = (double)(2 * n + 2) * 5.9604644775390625e-8;
+            double lo[8], hi[8];
+            for (int c = 0; c < n; ++c) {
+                const uint32_t votes = tie_votes_of(src.h[c] + (size_t)zbest * npix, x, y, nx);
+                tie_reference_interval(src.e[c][(size_t)zbest * npix + p], votes, &lo[c], &hi[c]);
+                most = max(most, votes);
+            }
+            const double winner_lo = tie_fuse_real_n<MODE>(lo, n) * (1.0 - slack);
+            for (int z = 0; z < nz; ++z) {
+                const size_t i = (size_t)z * npix + p;
+                const float v = fused[i];
+                if (v >= thr) continue;  // within the gap: re-summed in the reference's order (or the maximum itself)
+                for (int c = 0; c < n; ++c) {
+                    const uint32_t votes = tie_votes_of(src.h[c] + (size_t)z * npix, x, y, nx);
+                    tie_reference_interval(src.e[c][i], votes, &lo[c], &hi[c]);
+                    most = max(most, votes);
+                }
+                const double upper = tie_fuse_real_n<MODE>(hi, n) * (1.0 + slack);
+                if (!(upper < winner_lo)) {
+                    proven = false;
+                    need = fmaxf(need, (best - v) / best);
+                }
+            }
+        }
+        atomicAdd(&s_stats[proven ? 0 : 1], 1u);
+        if (!proven) {
+            atomicMax(&s_stats[2], __float_as_uint(need));
+            if (unproven) unproven[atomicAdd(&stats[4], 1u)] = make_uint2((unsigned)p, __float_as_uint(need));
+        }
+        atomicMax(&s_stats[3], most);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 && s_stats[threadIdx.x]) atomicAdd(&stats[threadIdx.x], s_stats[threadIdx.x]);
+    if (threadIdx.x >= 2 && threadIdx.x < 4 && s_stats[threadIdx.x]) atomicMax(&stats[threadIdx.x], s_stats[threadIdx.x]);
+}
+
+hipError_t launch_tie_prove_n(hipStream_t s, const float* fused, const float* const* e, const uint32_t* const* h, int n, int mode, int nx,
+                              int ny, int nz, float rel_gap, unsigned* stats5, uint2* unproven)
+{
+    if (n < 1 || n > 8) return hipErrorInvalidValue;
+    if (mode == 6 && n != 2 && n != 4 && n != 8) return hipErrorInvalidValue;
+    ProveSources src{};
+    src.n = n;
+    for (int c = 0; c < n; ++c) {
+        src.e[c] = e[c];
+        src.h[c] = h[c];
+    }
+    const dim3 grid((nx * ny + 255) / 256), block(256);
+    switch (mode) {
+    case 0: hipLaunchKernelGGL(k_tie_prove_n<0>, grid, block, 0, s, fused, src, nx, ny, nz, rel_gap, stats5, unproven); break;
+    case 4: hipLaunchKernelGGL(k_tie_prove_n<4>, grid, block, 0, s, fused, src, nx, ny, nz, rel_gap, stats5, unproven); break;
+    case 5: hipLaunchKernelGGL(k_tie_prove_n<5>, grid, block, 0, s, fused, src, nx, ny, nz, rel_gap, stats5, unproven); break;
+    case 6: hipLaunchKernelGGL(k_tie_prove_n<6>, grid, block, 0, s, fused, src, nx, ny, nz, rel_gap, stats5, unproven); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipExtGetLastError();
+}
+
 hipError_t launch_tie_prove(hipStream_t s, const float* a, const float* b, const uint32_t* Ha, const uint32_t* Hb, int op, int nx,
                             int ny, int nz, float rel_gap, unsigned* stats4, uint2* unproven)
 {

@@ -214,6 +214,7 @@ def load_library():
         "dsi_mapper_resolve_near_ties": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int,
                                                   C.POINTER(_ResolveInfo)]),
         "dsi_mapper_prove_near_ties": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.POINTER(_ProveInfo)]),
+        "dsi_mapper_prove_near_ties_n": (C.c_int, [vp, vp, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.POINTER(_ProveInfo)]),
         "dsi_mapper_proof_votes": (C.c_int, [vp, C.c_int, u32p, C.c_size_t, u32p]),
         "dsi_mapper_proof_unproven": (C.c_int, [vp, u32p, f32p, C.c_size_t, szp]),
         "dsi_grid_near_tie_voxels": (C.c_int, [vp, vp, C.c_float, u32p, C.c_size_t, szp, szp]),
@@ -970,6 +971,19 @@ class MapperEMVS:
         info = _ProveInfo()
         info.rel_gap = float(rel_gap)
         _check(load_library().dsi_mapper_prove_near_ties(self._h, hm, hb, n, int(fusion_method), C.byref(info)))
+        return {k: getattr(info, k) for k, _ in _ProveInfo._fields_}
+
+    def proveNearTiesN(self, mappers, batches, mode, fused_grid=None, rel_gap=0.0):
+        """dsi_mapper_prove_near_ties_n: the per-column proof for n <= 8 cameras fused by an n-ary mode (ACC_GM_TREE with
+        2 / 4 / 8 cameras, ACC_MIN, ACC_MAX, ACC_SUM); fused_grid: the grid that holds the fusion (default: this mapper's
+        dsi_), whose values decided the near-tie columns."""
+        n = len(mappers)
+        hm = (C.c_void_p * n)(*[m._h for m in mappers])
+        hb = (C.c_void_p * n)(*[b._h for b in batches])
+        info = _ProveInfo()
+        info.rel_gap = float(rel_gap)
+        g = fused_grid if fused_grid is not None else self.dsi_
+        _check(load_library().dsi_mapper_prove_near_ties_n(self._h, g._h, hm, hb, n, int(mode), C.byref(info)))
         return {k: getattr(info, k) for k, _ in _ProveInfo._fields_}
 
     def proofUnproven(self):

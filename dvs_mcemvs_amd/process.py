@@ -307,6 +307,60 @@ def resolve_near_ties_proven(mapper_fused, mappers, batches, fusion_method=E.FUS
     return info, proof
 
 
+def _fuse_nary_host(vals, mode):
+    """The n-ary camera fusion of reference-order values on the host, with the reference's scalar ops (bit for bit what
+    setToFusionOfN computes on the device)."""
+    n = len(vals)
+    if mode == E.ACC_GM_TREE:
+        if n not in (2, 4, 8):
+            raise E.DsiError(E.ERR_BAD_OP, "ACC_GM_TREE needs 2, 4 or 8 cameras")
+        level = vals
+        while len(level) > 1:       # geometricMeanTwoGrids on pairs, then on the results (cartesian3dgrid.h:150-156)
+            level = [E.reference_fuse2(E.FUSE_GM, level[i], level[i + 1]) for i in range(0, len(level), 2)]
+        return level[0]
+    if mode in (E.ACC_MIN, E.ACC_MAX):
+        final = vals[0]
+        for v in vals[1:]:
+            final = E.reference_fuse2(E.FUSE_MIN if mode == E.ACC_MIN else E.FUSE_MAX, final, v)
+        return final
+    if mode == E.ACC_SUM:
+        acc = np.zeros(vals[0].shape, np.float32)
+        for v in vals:
+            acc = E.reference_accumulate(E.ACC_SUM, acc, v)
+        return E.reference_finalize(E.ACC_SUM, acc, n)
+    raise E.DsiError(E.ERR_BAD_OP, "mode %r has no host restatement" % (mode,))
+
+
+def exact_depth_map_nary_proven(mapper_fused, mappers, batches, mode, rel_gap=0.0, fused_grid=None, max_gap=4e-3,
+                                max_full_columns=4096):
+    """exact_depth_map_nary in PROVEN mode (ABI 10, dsi_mapper_prove_near_ties_n): resolve, prove from counted votes, once
+    more with a moderately wider gap where the bounds ask for it, and the columns no such gap settles re-summed on all their
+    planes.  At BASELINE configs[4]'s size the oracle covers a strip of the image; this covers every column.  Returns
+    (resolver info, proof info): proof["columns_unproven"] == proof["columns_resolved_fully"] means every column is settled."""
+    gap = rel_gap if rel_gap > 0 else 2.5e-4
+    info = exact_depth_map_nary(mapper_fused, mappers, batches, mode, rel_gap=gap, fused_grid=fused_grid)
+    proof = mapper_fused.proveNearTiesN(mappers, batches, mode, fused_grid=fused_grid, rel_gap=gap)
+    if proof["columns_unproven"]:
+        pix, gaps = mapper_fused.proofUnproven()
+        moderate = gaps[gaps.astype(np.float64) * 1.05 <= max_gap]
+        if moderate.size:
+            gap = float(moderate.max()) * 1.05
+            info = exact_depth_map_nary(mapper_fused, mappers, batches, mode, rel_gap=gap, fused_grid=fused_grid)
+            proof = mapper_fused.proveNearTiesN(mappers, batches, mode, fused_grid=fused_grid, rel_gap=gap)
+            pix = mapper_fused.proofUnproven()[0] if proof["columns_unproven"] else pix[:0]
+        if pix.size and pix.size <= max_full_columns:
+            pixels = np.unique(pix)
+            nx, ny, nz = mapper_fused.dsi_.getDimensions()
+            npix = nx * ny
+            vox = (pixels[:, None].astype(np.uint64) + np.arange(nz, dtype=np.uint64)[None, :] * npix).reshape(-1).astype(np.uint32)
+            final = _fuse_nary_host([m.exactVoxels(b, vox)[0] for m, b in zip(mappers, batches)], mode)
+            p2, new_idx, new_conf = _first_maxima(vox, final, npix)
+            mapper_fused.patchDepthMap(p2, new_idx, new_conf)
+            proof["columns_resolved_fully"] = int(pixels.size)
+    info["rel_gap"] = gap
+    return info, proof
+
+
 def exact_depth_map_nary(mapper_fused, mappers, batches, mode, rel_gap=0.0, fused_grid=None):
     """The n-camera counterpart of MapperEMVS.resolveNearTies (BASELINE configs[4]): mapper_fused.dsi_ holds
     setToFusionOfN([m.dsi_ for m in mappers], mode) of the DSIs the mappers built from `batches`, and mapper_fused
@@ -325,24 +379,7 @@ def exact_depth_map_nary(mapper_fused, mappers, batches, mode, rel_gap=0.0, fuse
         v, cnt = m.exactVoxels(b, vox)
         info["votes"] += int(cnt.sum())
         vals.append(v)
-    if mode == E.ACC_GM_TREE:
-        if n not in (2, 4, 8):
-            raise E.DsiError(E.ERR_BAD_OP, "ACC_GM_TREE needs 2, 4 or 8 cameras")
-        level = vals
-        while len(level) > 1:       # geometricMeanTwoGrids on pairs, then on the results (cartesian3dgrid.h:150-156)
-            level = [E.reference_fuse2(E.FUSE_GM, level[i], level[i + 1]) for i in range(0, len(level), 2)]
-        final = level[0]
-    elif mode in (E.ACC_MIN, E.ACC_MAX):
-        final = vals[0]
-        for v in vals[1:]:
-            final = E.reference_fuse2(E.FUSE_MIN if mode == E.ACC_MIN else E.FUSE_MAX, final, v)
-    elif mode == E.ACC_SUM:
-        acc = np.zeros(vox.shape, np.float32)
-        for v in vals:
-            acc = E.reference_accumulate(E.ACC_SUM, acc, v)
-        final = E.reference_finalize(E.ACC_SUM, acc, n)
-    else:
-        raise E.DsiError(E.ERR_BAD_OP, "exact_depth_map_nary: mode %r has no host restatement" % (mode,))
+    final = _fuse_nary_host(vals, mode)
     pix, new_idx, new_conf = _first_maxima(vox, final, nx * ny)
     _, _, idx0 = mapper_fused.fetchDepthMap()
     info["changed_pixels"] = int((idx0.reshape(-1)[pix] != new_idx).sum())

@@ -554,7 +554,14 @@ typedef struct {
 } dsi_prove_info_t;
 DSI_API int dsi_mapper_prove_near_ties(dsi_mapper_t *out, dsi_mapper_t *const *mappers,
                                        const dsi_batch_t *const *batches, int n, int op, dsi_prove_info_t *info);
-/* votes[i] <- the number of votes voxel voxels[i] (z * dimY * dimX + y * dimX + x) of camera `camera` (0 or 1) received
+/* The same proof for n <= 8 cameras fused by an n-ary mode (BASELINE configs[4]'s four-camera rig): fused = the grid that
+ * holds dsi_grid_fuse_n(..., mode) of the mappers' DSIs -- the grid dsi_grid_near_tie_voxels took the near-tie columns from
+ * (process.exact_depth_map_nary / the building blocks re-sum them); mode = DSI_ACC_GM_TREE (n = 2, 4, 8), DSI_ACC_MIN,
+ * DSI_ACC_MAX or DSI_ACC_SUM (the arithmetic mean).  info->rel_gap: the gap those columns were taken with (0: 2.5e-4).
+ * The oracle can only cover a strip of a 1024 x 1024 x 256 volume in reasonable time; this covers every column. */
+DSI_API int dsi_mapper_prove_near_ties_n(dsi_mapper_t *out, dsi_grid_t *fused, dsi_mapper_t *const *mappers,
+                                         const dsi_batch_t *const *batches, int n, int mode, dsi_prove_info_t *info);
+/* votes[i] <- the number of votes voxel voxels[i] (z * dimY * dimX + y * dimX + x) of camera `camera` (0 .. 7) received
  * according to the counters the LAST dsi_mapper_prove_near_ties on `out` made (what its bounds were computed from; the
  * same number dsi_mapper_exact_voxels reports from the resolver's own event pass). */
 DSI_API int dsi_mapper_proof_votes(dsi_mapper_t *out, int camera, const uint32_t *voxels, size_t n, uint32_t *votes);

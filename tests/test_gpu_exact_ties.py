@@ -164,6 +164,47 @@ def process_nary(fused, ms, batches, acc):
     return proc.exact_depth_map_nary(fused, ms, batches, acc)
 
 
+@pytest.mark.parametrize("mode", ["gm_tree", "min", "max", "am"])
+def test_proven_mode_of_four_cameras(ctx, mode):
+    """dsi_mapper_prove_near_ties_n (ABI 10): the per-column proof for configs[4]'s topology.  With a gap of rounding size the
+    contested columns are unproven and gap_needed is rounding-sized; process.exact_depth_map_nary_proven settles every column
+    (wider gap, the hard columns on all planes), and the map is the oracle's.  At configs[4]'s own size the oracle only covers a
+    strip -- there the proof is what covers the rest of the image."""
+    nx, ny, nz = 96, 72, 24
+    rig = syn.stereo_rig(60_000, width=nx, height=ny, duration=0.3, seed=13, n_cams=4, n_points=600)
+    shape = d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0)
+    batches = _batches(ctx, rig, 4)
+    ms = [d.MapperEMVS(ctx, rig["cam"], shape) for _ in range(4)]
+    for m, b in zip(ms, batches):
+        m.evaluateDSI_batch(b)
+    fused = d.MapperEMVS(ctx, rig["cam"], shape)
+    acc = {"gm_tree": d.ACC_GM_TREE, "min": d.ACC_MIN, "max": d.ACC_MAX, "am": d.ACC_SUM}[mode]
+    fused.dsi_.setToFusionOfN([m.dsi_ for m in ms], acc)
+    fused.computeDepthMap()
+    tiny = fused.proveNearTiesN(ms, batches, acc, rel_gap=1e-7)
+    assert tiny["columns"] == nx * ny and tiny["columns_unproven"] > 0 and 1e-7 < tiny["gap_needed"] <= 1.0, tiny
+    for c in range(4):      # the counters of every camera against the resolver's own event pass
+        vox = np.random.default_rng(c).integers(0, nx * ny * nz, 2000).astype(np.uint32)
+        assert np.array_equal(fused.proofVotes(c, vox), ms[c].exactVoxels(batches[c], vox)[1])
+    info, proof = proc.exact_depth_map_nary_proven(fused, ms, batches, acc)
+    assert proof["columns_proven"] + proof["columns_unproven"] == nx * ny
+    assert proof["columns_unproven"] == proof["columns_resolved_fully"], (info, proof)
+    dsis = []
+    for c in range(4):
+        r = OracleMapper(rig["cam"], dimX=nx, dimY=ny, dimZ=nz, min_depth=4.0, max_depth=200.0)
+        assert r.evaluateDSI(rig["events"][c], rig["trajectories"][c], rig["T_rv_w"])
+        dsis.append(r.dsi)
+    ref = orc.fuse_gm_tree(dsis) if mode == "gm_tree" else orc.fuse_nary(dsis, acc)
+    _, _, idx = fused.fetchDepthMap()
+    assert np.array_equal(idx, ref.argmax(axis=0)), "%d pixels differ; %r" % ((idx != ref.argmax(axis=0)).sum(), proof)
+    with pytest.raises(d.DsiError):
+        fused.proveNearTiesN(ms[:3], batches[:3], d.ACC_GM_TREE)       # the tree needs 2, 4 or 8 cameras
+    with pytest.raises(d.DsiError):
+        fused.proveNearTiesN(ms, batches, d.ACC_LOG_SUM)               # exp(mean(log)): no reference counterpart to bound
+    for o in ms + [fused] + batches:
+        o.close()
+
+
 def test_resolver_checks_its_premise_and_widens_the_gap(ctx):
     """the gap is a premise (the rigorous per-voxel bound (votes - 1) * 2^-24 can exceed it), so the call measures
     the difference between the two summation orders on the voxels it re-sums and repeats the pass with a 4 x wider gap while

@@ -755,6 +755,22 @@ def test_configs4_end_to_end_at_full_size(ctx):
     before = int((idx_tree[r0:r0 + rows] != ridx).sum())
     print("configs[4] exact n-ary resolution: %r; on the strip %d pixels differed before" % (info, before))
     assert np.array_equal(idx_exact[r0:r0 + rows], ridx), "%d pixels of the strip differ" % (idx_exact[r0:r0 + rows] != ridx).sum()
+    # (e) beyond the strip: the resolution's premise as a per-column PROOF over the WHOLE image (dsi_mapper_prove_near_ties_n:
+    #     the 4 x 100 M events' votes counted per voxel, the reference's fp32 event-order sums bounded from the counts).  With
+    #     tens of thousands of votes in a voxel the bounds are ~1e-3 wide: the default gap proves 99.2 % of the 1,048,576
+    #     columns (1,040,633; the rest ask for up to 1.8e-3, and settling them means re-summing their 8 M voxels over
+    #     4 x 100 M events -- minutes, in chunks: not in this test).  Asserted: the proof accounts for every column, proves
+    #     the bulk, and a column it calls proven on the strip indeed carries the oracle's plane
+    proof = mappers[0].proveNearTiesN(mappers, batches, d.ACC_GM_TREE, fused_grid=fused)
+    print("configs[4] proof at the default gap: %r" % (proof,))
+    assert proof["columns"] == 1024 * 1024 and proof["columns_proven"] + proof["columns_unproven"] == 1024 * 1024
+    assert proof["max_votes"] > 1000 and proof["columns_proven"] > 0.95 * 1024 * 1024
+    pix, gaps = mappers[0].proofUnproven()
+    assert pix.size == proof["columns_unproven"] and (pix.size == 0 or float(gaps.max()) == pytest.approx(proof["gap_needed"], rel=1e-6))
+    proven_mask = np.ones(1024 * 1024, bool)
+    proven_mask[pix] = False
+    strip_proven = proven_mask.reshape(1024, 1024)[r0:r0 + rows]
+    assert np.array_equal(idx_exact[r0:r0 + rows][strip_proven], ridx[strip_proven])
     for o_ in mappers + batches + [fused]:
         o_.close()
 
