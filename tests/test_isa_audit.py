@@ -78,9 +78,10 @@ def test_vote_kernels_do_not_spill(tmp_path):
             assert val("vgpr_count") <= 64 and val("private_segment_fixed_size") <= 128, name
             continue
         assert val("vgpr_spill_count") == 0 and val("private_segment_fixed_size") == 0, name
-        if "k_tie_sort_runs" in name:
+        if "k_tie_sort_runs" in name or "k_tie_prove" in name:
             # a thread keeps up to 16 (key, bucket, rank, final slot) of its run in registers; the LDS (12 / 24 / 48 KB per
-            # 256-thread workgroup), not the registers, bounds the occupancy of these kernels
+            # 256-thread workgroup), not the registers, bounds the occupancy of these kernels.  (k_tie_prove*: the proof's
+            # per-column interval arithmetic in double precision, up to eight cameras' bounds at once -- a verification pass)
             assert val("vgpr_count") <= 128, name
             continue
         assert val("vgpr_count") <= 64, name
