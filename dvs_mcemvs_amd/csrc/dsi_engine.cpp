@@ -244,6 +244,8 @@ struct TieScratch {
     DevBuf<char> tmp;  // dsi_mapper_patch_depth_map: the new indices
     DevBuf<uint32_t> votes[8];  // dsi_mapper_prove_near_ties(_n): the cameras' vote counters per integer location
     bool votes_valid[8] = {false, false, false, false, false, false, false, false};
+    DevBuf<unsigned> interval_most;  // dsi_mapper_reference_interval: most votes in a voxel since the last dsi_grid_prove_columns
+    bool interval_most_live = false;
     DevBuf<uint2> unproven;     // ... and the columns it could not prove (pixel, float bits of the gap the column needs)
     size_t n_unproven = 0;
     unsigned* host = nullptr;  // page-locked copy of the counters: the three reads of a call are plain DMAs
@@ -260,7 +262,7 @@ struct TieScratch {
         host = nullptr;
         cand.release(); count.release(); desc.release(); cols.release(); counters.release();
         for (auto& v : votes) v.release();
-        unproven.release();
+        unproven.release(); interval_most.release();
         keys.release(); keys2.release(); w.release(); exact.release(); diff.release(); tmp.release();
         rank_count.release(); rank_start.release(); rank_cursor.release();
     }
@@ -2263,6 +2265,87 @@ int dsi_mapper_prove_near_ties_n(dsi_mapper_t* out, dsi_grid_t* fused, dsi_mappe
     std::memcpy(&need, &pinned[2], sizeof need);
     info->gap_needed = pinned[1] ? (double)need : 0.0;
     info->max_votes = pinned[3];
+    info->elapsed_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    return DSI_OK;
+}
+
+int dsi_mapper_reference_interval(dsi_mapper_t* scratch, dsi_mapper_t* m, const dsi_batch_t* batch, dsi_grid_t* lo, dsi_grid_t* hi)
+{
+    REQUIRE(scratch && m && batch && lo && hi, DSI_ERR_INVALID, "null argument");
+    dsi_context* ctx = scratch->ctx;
+    REQUIRE(m->ctx == ctx && batch->ctx == ctx && lo->ctx == ctx && hi->ctx == ctx, DSI_ERR_CONTEXT, "everything must share one context");
+    REQUIRE(same_shape(scratch->grid, m->grid) && same_shape(m->grid, lo) && same_shape(m->grid, hi), DSI_ERR_SHAPE, "shapes differ");
+    REQUIRE(lo != hi && lo != m->grid && hi != m->grid, DSI_ERR_INVALID, "lo, hi and the DSI must be three grids");
+    REQUIRE(batch->n_packets == 0 || (m->info.algo == DSI_VOTE_LDS_BANDS && m->info.packed != 8), DSI_ERR_INVALID,
+            "the bounds need a DSI of exact sums (DSI_VOTE_LDS_BANDS, not lane mapping 8)");
+    const dsi::Geom& g0 = m->geom;
+    const size_t nvox = (size_t)g0.nx * g0.ny * g0.nz;
+    if (int rc = set_device(ctx)) return rc;
+    hipStream_t st = ctx->stream;
+    TieScratch& ts = scratch->tie;
+    dsi_mapper* one_m[1] = {m};
+    const dsi_batch* one_b[1] = {batch};
+    if (int rc = tie_packet_geometry(st, one_m, one_b, 1)) return rc;
+    HIP_TRY(ts.votes[7].reserve(nvox));  // (the last counter volume: the cameras' own of a proof stay valid)
+    ts.votes_valid[7] = false;
+    HIP_TRY(hipMemsetAsync(ts.votes[7].p, 0, nvox * sizeof(uint32_t), st));
+    if (batch->n_packets)
+        HIP_TRY(dsi::launch_count_votes(st, batch->x, batch->y, batch->first, m->H.p, m->lut_dev, m->sensor_w, m->sensor_h, m->centers.p,
+                                        m->planes_dev, m->geom, (int)batch->n_packets, ts.votes[7].p));
+    HIP_TRY(ts.interval_most.reserve(1));
+    if (!ts.interval_most_live) {
+        HIP_TRY(hipMemsetAsync(ts.interval_most.p, 0, sizeof(unsigned), st));
+        ts.interval_most_live = true;
+    }
+    HIP_TRY(dsi::launch_interval_of_counts(st, m->grid->data, ts.votes[7].p, g0.nx, g0.ny, g0.nz, lo->data, hi->data, ts.interval_most.p));
+    return DSI_OK;
+}
+
+int dsi_grid_widen_interval(dsi_grid_t* lo, dsi_grid_t* hi, int roundings)
+{
+    if (int rc = check_pair(lo, hi)) return rc;
+    REQUIRE(lo != hi, DSI_ERR_INVALID, "lo and hi must be two grids");
+    REQUIRE(roundings >= 1 && roundings <= 4096, DSI_ERR_INVALID, "roundings %d (1 .. 4096)", roundings);
+    HIP_TRY(dsi::launch_interval_widen(lo->ctx->stream, lo->data, hi->data, lo->n, roundings));
+    return DSI_OK;
+}
+
+int dsi_grid_prove_columns(dsi_mapper_t* scratch, dsi_grid_t* fused, dsi_grid_t* lo, dsi_grid_t* hi, dsi_prove_info_t* info)
+{
+    REQUIRE(scratch && fused && lo && hi && info, DSI_ERR_INVALID, "null argument");
+    dsi_context* ctx = scratch->ctx;
+    REQUIRE(fused->ctx == ctx && lo->ctx == ctx && hi->ctx == ctx, DSI_ERR_CONTEXT, "everything must share one context");
+    REQUIRE(same_shape(scratch->grid, fused) && same_shape(fused, lo) && same_shape(fused, hi), DSI_ERR_SHAPE, "shapes differ");
+    const float rel_gap = info->rel_gap > 0.f ? info->rel_gap : 2.5e-4f;
+    REQUIRE(rel_gap < 0.5f, DSI_ERR_INVALID, "rel_gap %g is not a rounding-sized gap", (double)rel_gap);
+    if (int rc = set_device(ctx)) return rc;
+    hipStream_t st = ctx->stream;
+    const auto t_begin = std::chrono::steady_clock::now();
+    *info = dsi_prove_info_t{};
+    info->rel_gap = rel_gap;
+    TieScratch& ts = scratch->tie;
+    HIP_TRY(ts.counters.reserve(kTieCounterWords / 2));
+    unsigned* cnt = reinterpret_cast<unsigned*>(ts.counters.p);
+    HIP_TRY(hipMemsetAsync(cnt, 0, 5 * sizeof(unsigned), st));
+    const int npix = fused->nx * fused->ny;
+    HIP_TRY(ts.unproven.reserve((size_t)npix));
+    ts.n_unproven = 0;
+    HIP_TRY(dsi::launch_prove_columns(st, fused->data, lo->data, hi->data, npix, fused->nz, rel_gap, cnt, ts.unproven.p));
+    unsigned* pinned = nullptr;
+    HIP_TRY(ts.host_counters(&pinned));
+    HIP_TRY(hipMemcpyAsync(pinned, cnt, 5 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    if (ts.interval_most_live) HIP_TRY(hipMemcpyAsync(pinned + 8, ts.interval_most.p, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    ts.votes_valid[0] = true;  // (dsi_mapper_proof_unproven asks whether a proof has run)
+    ts.n_unproven = pinned[4];
+    info->columns = npix;
+    info->columns_proven = pinned[0];
+    info->columns_unproven = pinned[1];
+    float need = 0.f;
+    std::memcpy(&need, &pinned[2], sizeof need);
+    info->gap_needed = pinned[1] ? (double)need : 0.0;
+    info->max_votes = ts.interval_most_live ? pinned[8] : 0;
+    ts.interval_most_live = false;  // (the next composition starts its own maximum)
     info->elapsed_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     return DSI_OK;
 }

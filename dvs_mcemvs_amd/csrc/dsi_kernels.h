@@ -254,6 +254,12 @@ hipError_t launch_tie_pick(hipStream_t s, int op, const uint4* cols, int n_cols,
 hipError_t launch_count_votes(hipStream_t s, const uint16_t* ex, const uint16_t* ey, const uint32_t* packet_first, const float* H9,
                               const float2* lut, int sensor_w, int sensor_h, const float* centers, const float* planes, const Geom& g,
                               int np, uint32_t* H);
+// the proof's pieces for any fusion topology: interval grids (lo / hi enclose the reference's value voxel by voxel)
+hipError_t launch_interval_of_counts(hipStream_t s, const float* dsi, const uint32_t* H, int nx, int ny, int nz, float* lo, float* hi,
+                                     unsigned* most /* atomicMax: most votes in a voxel */);
+hipError_t launch_interval_widen(hipStream_t s, float* lo, float* hi, size_t n, int roundings);
+hipError_t launch_prove_columns(hipStream_t s, const float* fused, const float* lo, const float* hi, int npix, int nz, float rel_gap,
+                                unsigned* stats5, uint2* unproven);
 // ... and for n <= 8 cameras fused by an n-ary mode (DSI_ACC_GM_TREE 6 with n = 2, 4, 8; DSI_ACC_MIN 4, DSI_ACC_MAX 5, DSI_ACC_SUM 0):
 // `fused` = the engine's fused grid, whose values decide the near-tie columns and the threshold
 hipError_t launch_tie_prove_n(hipStream_t s, const float* fused, const float* const* e, const uint32_t* const* h, int n, int mode, int nx,

@@ -5904,6 +5904,137 @@ hipError_t launch_tie_votes_of(hipStream_t s, const uint32_t* H, const uint32_t*
     return hipExtGetLastError();
 }
 
+// ---- the proof's pieces for ANY fusion topology (Alg. 2's camera-then-time fusion, process2.cpp:98-249): INTERVAL GRIDS ----
+// lo / hi: two fp32 volumes that enclose, voxel by voxel, the value the reference holds -- made per camera DSI from the
+// counted votes (k_interval_of_counts), carried through the SAME device ops the engine applies to the values (every one of the
+// reference's voxel-wise ops is monotone non-decreasing in its operands, or the decreasing 1 / (0.01 + g) inside the harmonic
+// accumulation whose final n / sum turns it around), widened after every step by that step's roundings (k_interval_widen),
+// and finally compared column by column (k_prove_columns) like k_tie_prove does.
+// (the next fp32 below / above a FINITE f, by its bits: there is no nextafterf on the device)
+__device__ __forceinline__ float next_below(float f)
+{
+    const uint32_t b = __float_as_uint(f);
+    if (f > 0.f) return __uint_as_float(b - 1u);
+    if (f < 0.f) return __uint_as_float(b + 1u);
+    return __uint_as_float(0x80000001u);  // -min denormal
+}
+__device__ __forceinline__ float next_above(float f)
+{
+    const uint32_t b = __float_as_uint(f);
+    if (f > 0.f) return __uint_as_float(b + 1u);  // (max finite -> +inf: a bound that says nothing, correctly)
+    if (f < 0.f) return __uint_as_float(b - 1u);
+    return __uint_as_float(0x00000001u);
+}
+__device__ __forceinline__ float round_down(double v)
+{
+    const float f = (float)v;  // (round to nearest; v = +-inf or NaN pass through)
+    if (f == __builtin_inff() && v < (double)__builtin_inff()) return 3.4028234663852886e38f;  // (a finite v beyond FLT_MAX)
+    return ((double)f > v && f == f && fabsf(f) < __builtin_inff()) ? next_below(f) : f;
+}
+__device__ __forceinline__ float round_up(double v)
+{
+    const float f = (float)v;
+    return ((double)f < v && f == f && fabsf(f) < __builtin_inff()) ? next_above(f) : f;
+}
+
+__global__ __launch_bounds__(256) void k_interval_of_counts(const float* __restrict__ dsi, const uint32_t* __restrict__ H, int nx, int ny,
+                                                            int nz, float* __restrict__ lo, float* __restrict__ hi,
+                                                            unsigned* __restrict__ most)
+{
+    const size_t npix = (size_t)nx * ny, n = npix * nz;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned votes = 0u;
+    if (i < n) {
+        const size_t z = i / npix, p = i - z * npix;
+        const int y = (int)(p / nx), x = (int)(p - (size_t)y * nx);
+        votes = tie_votes_of(H + z * npix, x, y, nx);
+        double l, h;
+        tie_reference_interval(dsi[i], votes, &l, &h);
+        lo[i] = round_down(l);
+        hi[i] = round_up(h);  // (+inf where a voxel has 2^23 votes or more: never proven)
+    }
+    // (most votes in a voxel: one atomic per wave)
+    for (int off = 32; off > 0; off >>= 1) votes = max(votes, (unsigned)__shfl_xor((int)votes, off, 64));
+    if ((threadIdx.x & 63) == 0 && votes) atomicMax(most, votes);
+}
+
+// lo <- lo (1 - k u) rounded down (never below 0), hi <- hi (1 + k u) rounded up: the k roundings of the step just applied
+__global__ __launch_bounds__(256) void k_interval_widen(float* __restrict__ lo, float* __restrict__ hi, size_t n, double ku)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    lo[i] = round_down(fmax(0.0, (double)lo[i] * (1.0 - ku)));
+    hi[i] = round_up((double)hi[i] * (1.0 + ku));
+}
+
+// per column of `fused` (the engine's values: the resolver's threshold comes from them): every plane below
+// best - rel_gap * best must have hi strictly below lo of the maximum's plane.  stats / unproven as k_tie_prove
+__global__ __launch_bounds__(256) void k_prove_columns(const float* __restrict__ fused, const float* __restrict__ lo,
+                                                       const float* __restrict__ hi, int npix, int nz, float rel_gap,
+                                                       unsigned* __restrict__ stats, uint2* __restrict__ unproven)
+{
+    __shared__ unsigned s_stats[3];
+    if (threadIdx.x < 3) s_stats[threadIdx.x] = 0u;
+    __syncthreads();
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < npix) {
+        float best = fused[p];
+        int zbest = 0;
+        for (int z = 1; z < nz; ++z) {
+            const float v = fused[(size_t)z * npix + p];
+            if (best < v) {
+                best = v;
+                zbest = z;
+            }
+        }
+        bool proven = true;
+        float need = 0.f;
+        if (best > 0.f) {
+            const float thr = best - rel_gap * best;
+            const float winner_lo = lo[(size_t)zbest * npix + p];
+            for (int z = 0; z < nz; ++z) {
+                const size_t i = (size_t)z * npix + p;
+                const float v = fused[i];
+                if (v >= thr) continue;
+                if (!(hi[i] < winner_lo)) {
+                    proven = false;
+                    need = fmaxf(need, (best - v) / best);
+                }
+            }
+        }
+        atomicAdd(&s_stats[proven ? 0 : 1], 1u);
+        if (!proven) {
+            atomicMax(&s_stats[2], __float_as_uint(need));
+            if (unproven) unproven[atomicAdd(&stats[4], 1u)] = make_uint2((unsigned)p, __float_as_uint(need));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 && s_stats[threadIdx.x]) atomicAdd(&stats[threadIdx.x], s_stats[threadIdx.x]);
+    if (threadIdx.x == 2 && s_stats[2]) atomicMax(&stats[2], s_stats[2]);
+}
+
+hipError_t launch_interval_of_counts(hipStream_t s, const float* dsi, const uint32_t* H, int nx, int ny, int nz, float* lo, float* hi,
+                                     unsigned* most)
+{
+    const size_t n = (size_t)nx * ny * nz;
+    hipLaunchKernelGGL(k_interval_of_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dsi, H, nx, ny, nz, lo, hi, most);
+    return hipExtGetLastError();
+}
+
+hipError_t launch_interval_widen(hipStream_t s, float* lo, float* hi, size_t n, int roundings)
+{
+    hipLaunchKernelGGL(k_interval_widen, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, lo, hi, n,
+                       (double)roundings * 5.9604644775390625e-8);
+    return hipExtGetLastError();
+}
+
+hipError_t launch_prove_columns(hipStream_t s, const float* fused, const float* lo, const float* hi, int npix, int nz, float rel_gap,
+                                unsigned* stats5, uint2* unproven)
+{
+    hipLaunchKernelGGL(k_prove_columns, dim3((npix + 255) / 256), dim3(256), 0, s, fused, lo, hi, npix, nz, rel_gap, stats5, unproven);
+    return hipExtGetLastError();
+}
+
 // ---- the same proof for n cameras fused by an n-ary mode (dsi_mapper_prove_near_ties_n: BASELINE configs[4]'s rig) ----
 // fused: the grid the n-ary resolver took its near-tie columns from (dsi_grid_near_tie_voxels: the engine's fused values);
 // e[c] / h[c]: camera c's DSI and vote counters.  MODE: DSI_ACC_GM_TREE (6; n = 2, 4, 8: the balanced tree of the

@@ -215,6 +215,9 @@ def load_library():
                                                   C.POINTER(_ResolveInfo)]),
         "dsi_mapper_prove_near_ties": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.POINTER(_ProveInfo)]),
         "dsi_mapper_prove_near_ties_n": (C.c_int, [vp, vp, C.POINTER(vp), C.POINTER(vp), C.c_int, C.c_int, C.POINTER(_ProveInfo)]),
+        "dsi_mapper_reference_interval": (C.c_int, [vp, vp, vp, vp, vp]),
+        "dsi_grid_widen_interval": (C.c_int, [vp, vp, C.c_int]),
+        "dsi_grid_prove_columns": (C.c_int, [vp, vp, vp, vp, C.POINTER(_ProveInfo)]),
         "dsi_mapper_proof_votes": (C.c_int, [vp, C.c_int, u32p, C.c_size_t, u32p]),
         "dsi_mapper_proof_unproven": (C.c_int, [vp, u32p, f32p, C.c_size_t, szp]),
         "dsi_grid_near_tie_voxels": (C.c_int, [vp, vp, C.c_float, u32p, C.c_size_t, szp, szp]),
@@ -452,6 +455,12 @@ def argmax_keys_unpack(keys):
     _check(load_library().dsi_argmax_keys_unpack(_ptr(keys, C.c_uint64), keys.size, _ptr(conf, C.c_float),
                                                  _ptr(idx, C.c_uint8)))
     return conf, idx
+
+
+def widen_interval(lo, hi, roundings):
+    """dsi_grid_widen_interval: lo <- lo (1 - k u) rounded down, hi <- hi (1 + k u) rounded up, u = 2^-24 -- after a grid op
+    that performs k fp32 roundings per voxel was applied to both grids of an interval."""
+    _check(load_library().dsi_grid_widen_interval(lo._h, hi._h, int(roundings)))
 
 
 def reference_fuse2(op, a, g):
@@ -984,6 +993,18 @@ class MapperEMVS:
         info.rel_gap = float(rel_gap)
         g = fused_grid if fused_grid is not None else self.dsi_
         _check(load_library().dsi_mapper_prove_near_ties_n(self._h, g._h, hm, hb, n, int(mode), C.byref(info)))
+        return {k: getattr(info, k) for k, _ in _ProveInfo._fields_}
+
+    def referenceInterval(self, mapper, batch, lo, hi):
+        """dsi_mapper_reference_interval: lo, hi (Grid3D) <- voxel-wise bounds of the value the reference holds in the DSI
+        `mapper` built from `batch` (its votes counted; this mapper lends the scratch)."""
+        _check(load_library().dsi_mapper_reference_interval(self._h, mapper._h, batch._h, lo._h, hi._h))
+
+    def proveColumns(self, fused, lo, hi, rel_gap=0.0):
+        """dsi_grid_prove_columns: every column of `fused` (the engine's values) against the interval grids lo / hi."""
+        info = _ProveInfo()
+        info.rel_gap = float(rel_gap)
+        _check(load_library().dsi_grid_prove_columns(self._h, fused._h, lo._h, hi._h, C.byref(info)))
         return {k: getattr(info, k) for k, _ in _ProveInfo._fields_}
 
     def proofUnproven(self):

@@ -161,7 +161,7 @@ def process_2(ctx, cams, dsi_shape, events, trajectories, num_subintervals, mapp
 
 
 def exact_depth_map_process_2(ctx, cams, dsi_shape, events, trajectories, num_subintervals, mapper_fused, ts,
-                              stereo_fusion, temporal_fusion, luts=(None, None), inverse_depth=False, rel_gap=0.0):
+                              stereo_fusion, temporal_fusion, luts=(None, None), inverse_depth=False, rel_gap=0.0, prove=False):
     """Alg. 2's fused DSI (camera fusion per sub-interval, then temporal fusion; process2.cpp:98-249) and its arg-max
     with the plane index map EQUAL TO THE CPU REFERENCE'S ON EVERY PIXEL (BASELINE configs[3]).  The engine's exact
     vote sums and the reference's fp32, event-ordered sums agree to ~1e-5, so the first-maximum plane can differ in
@@ -174,10 +174,21 @@ def exact_depth_map_process_2(ctx, cams, dsi_shape, events, trajectories, num_su
          order, the first maximum per column (cartesian3dgrid.cpp:132-134), and the few pixels patched.
     mapper_fused.dsi_ holds the fused DSI afterwards, mapper_fused's depth map (fetchDepthMap) the resolved arg-max.
     temporal_fusion 2 (harmonic) or 4 (arithmetic), like the reference (anything else leaves the fused DSI zero).
-    Returns the statistics of the resolution."""
+    Returns the statistics of the resolution.
+    prove=True (ABI 10): the premise of that resolution as a per-column PROOF, for this topology built from INTERVAL GRIDS --
+    every (sub-interval, camera) DSI's votes counted and its reference value bounded (MapperEMVS.referenceInterval), the bounds
+    carried through the same camera fusion / temporal accumulate / finalize as the values (each widened by its roundings;
+    the harmonic accumulation's inverse sums with the directions swapped), MapperEMVS.proveColumns at the end; columns the
+    bounds do not settle are re-summed on all their planes (at most 4,096).  info["proof"] holds the statistics:
+    columns_unproven == columns_resolved_fully means the index map is the reference's on every pixel by proof."""
     mappers = [E.MapperEMVS(ctx, cams[c], dsi_shape, lut=luts[c], inverse_depth=inverse_depth) for c in range(2)]
     dims = mappers[0].dsi_.getDimensions()
     sub = E.Grid3D(ctx, *dims)
+    iv = None
+    if prove and {2: E.ACC_INV_SUM, 4: E.ACC_SUM}.get(int(temporal_fusion)) is not None:
+        iv = {k: E.Grid3D(ctx, *dims) for k in ("lo0", "hi0", "lo1", "hi1", "acc_lo", "acc_hi")}
+        iv["acc_lo"].resetGrid()
+        iv["acc_hi"].resetGrid()
     T_rv_w = reference_view_process2(trajectories[0], ts)
     per = [int(events[c][0].shape[0]) // int(num_subintervals) for c in range(2)]
     mode = {2: E.ACC_INV_SUM, 4: E.ACC_SUM}.get(int(temporal_fusion))
@@ -203,6 +214,29 @@ def exact_depth_map_process_2(ctx, cams, dsi_shape, events, trajectories, num_su
             mapper_fused.dsi_.accumulate(sub, mode)
             if k == num_subintervals - 1:
                 mapper_fused.dsi_.finalize(mode, num_subintervals)
+        if iv is not None:
+            # the sub-interval's bounds: per camera from the counted votes, through the camera fusion (<= 5 roundings), into
+            # the temporal accumulators (3 roundings per step).  The harmonic accumulator holds a SUM OF INVERSES, which falls
+            # where the values rise: the lower values' accumulator bounds that sum from ABOVE, so it is widened upwards
+            for c in range(2):
+                if pair[c].n_packets:
+                    mapper_fused.referenceInterval(mappers[c], pair[c], iv["lo%d" % c], iv["hi%d" % c])
+                else:
+                    iv["lo%d" % c].resetGrid()
+                    iv["hi%d" % c].resetGrid()
+            _fuse_cameras(iv["lo0"], iv["lo1"], stereo_fusion)       # (in place: lo0 <- op(lo0, lo1), like sub above)
+            _fuse_cameras(iv["hi0"], iv["hi1"], stereo_fusion)
+            E.widen_interval(iv["lo0"], iv["hi0"], 8)
+            iv["acc_lo"].accumulate(iv["lo0"], mode)
+            iv["acc_hi"].accumulate(iv["hi0"], mode)
+            if mode == E.ACC_INV_SUM:
+                E.widen_interval(iv["acc_hi"], iv["acc_lo"], 4)      # (swapped: see above)
+            else:
+                E.widen_interval(iv["acc_lo"], iv["acc_hi"], 4)
+            if k == num_subintervals - 1:
+                iv["acc_lo"].finalize(mode, num_subintervals)
+                iv["acc_hi"].finalize(mode, num_subintervals)
+                E.widen_interval(iv["acc_lo"], iv["acc_hi"], 4)
     mapper_fused.computeDepthMap()
     info = {"near_tie_pixels": 0, "candidate_voxels": 0, "votes": 0, "changed_pixels": 0, "max_order_diff": 0.0}
     if mode is not None:
@@ -226,6 +260,24 @@ def exact_depth_map_process_2(ctx, cams, dsi_shape, events, trajectories, num_su
             info["max_order_diff"] = float(np.max(np.abs(fused_now.astype(np.float64) - final) /
                                                   np.maximum(1.0, np.abs(final))))
             mapper_fused.patchDepthMap(pix, new_idx, new_conf)
+    if iv is not None:
+        proof = mapper_fused.proveColumns(mapper_fused.dsi_, iv["acc_lo"], iv["acc_hi"], rel_gap=rel_gap)
+        if 0 < proof["columns_unproven"] <= 4096:
+            # the columns the bounds do not settle: ALL their planes re-summed, in process_2's order, on the host
+            pixels = np.unique(mapper_fused.proofUnproven()[0])
+            nx, ny, nz = dims
+            vox = (pixels[:, None].astype(np.uint64) + np.arange(nz, dtype=np.uint64)[None, :] * (nx * ny)).reshape(-1).astype(np.uint32)
+            acc = np.zeros(vox.shape, np.float32)
+            for k in range(num_subintervals):
+                vals = [mappers[c].exactVoxels(batches[k][c], vox)[0] for c in range(2)]
+                acc = E.reference_accumulate(mode, acc, E.reference_fuse2(stereo_fusion, vals[0], vals[1]))
+            final = E.reference_finalize(mode, acc, num_subintervals)
+            pix, new_idx, new_conf = _first_maxima(vox, final, nx * ny)
+            mapper_fused.patchDepthMap(pix, new_idx, new_conf)
+            proof["columns_resolved_fully"] = int(pixels.size)
+        info["proof"] = proof
+        for g in iv.values():
+            g.close()
     for pair in batches:
         for b in pair:
             b.close()

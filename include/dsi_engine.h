@@ -561,6 +561,25 @@ DSI_API int dsi_mapper_prove_near_ties(dsi_mapper_t *out, dsi_mapper_t *const *m
  * The oracle can only cover a strip of a 1024 x 1024 x 256 volume in reasonable time; this covers every column. */
 DSI_API int dsi_mapper_prove_near_ties_n(dsi_mapper_t *out, dsi_grid_t *fused, dsi_mapper_t *const *mappers,
                                          const dsi_batch_t *const *batches, int n, int mode, dsi_prove_info_t *info);
+/* The proof's pieces for ANY fusion topology (Alg. 2's camera-then-time fusion, process2.cpp:98-249; compositions of your own):
+ * INTERVAL GRIDS.  lo / hi are two grids that enclose, voxel by voxel, the value the reference holds.
+ *  - dsi_mapper_reference_interval: lo, hi <- the bounds of the DSI `m` built from `batch` (its votes counted as in
+ *    dsi_mapper_prove_near_ties; scratch: any mapper of that shape, e.g. the output mapper);
+ *  - carry them through the SAME grid ops the values went through (dsi_grid_fuse2, dsi_grid_accumulate, dsi_grid_finalize,
+ *    dsi_grid_fuse_n ... on lo and on hi separately): the reference's voxel-wise ops are monotone non-decreasing in their
+ *    operands -- except the 1 / (0.01 + g) inside the harmonic accumulation, which the final n / sum turns around, so for
+ *    DSI_ACC_INV_SUM the lower bounds accumulate into the lower result as they are;
+ *  - dsi_grid_widen_interval after every such step with the number of fp32 roundings the step performs per voxel (fuse2: 5;
+ *    accumulate: 3; finalize: 2; an n-ary tree: 2 per level): lo <- lo (1 - k u) rounded down, hi <- hi (1 + k u) rounded up;
+ *  - dsi_grid_prove_columns: `fused` holds the engine's values (the near-tie columns and the threshold come from them);
+ *    a column is proven when every plane below best - rel_gap * best has hi strictly below lo of the maximum's plane.
+ *    info as for dsi_mapper_prove_near_ties (max_votes: from the dsi_mapper_reference_interval calls on `scratch` since its
+ *    last proof); dsi_mapper_proof_unproven lists the columns that are not.
+ * process.exact_depth_map_process_2_proven is Alg. 2 done that way. */
+DSI_API int dsi_mapper_reference_interval(dsi_mapper_t *scratch, dsi_mapper_t *m, const dsi_batch_t *batch, dsi_grid_t *lo,
+                                          dsi_grid_t *hi);
+DSI_API int dsi_grid_widen_interval(dsi_grid_t *lo, dsi_grid_t *hi, int roundings);
+DSI_API int dsi_grid_prove_columns(dsi_mapper_t *scratch, dsi_grid_t *fused, dsi_grid_t *lo, dsi_grid_t *hi, dsi_prove_info_t *info);
 /* votes[i] <- the number of votes voxel voxels[i] (z * dimY * dimX + y * dimX + x) of camera `camera` (0 .. 7) received
  * according to the counters the LAST dsi_mapper_prove_near_ties on `out` made (what its bounds were computed from; the
  * same number dsi_mapper_exact_voxels reports from the resolver's own event pass). */

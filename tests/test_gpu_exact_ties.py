@@ -335,6 +335,56 @@ def test_the_proofs_interval_holds_the_reference_order_value(ctx, events):
     b.close()
 
 
+def test_interval_grids_enclose_the_reference_order_values(ctx):
+    """The interval grids of the general proof (dsi_mapper_reference_interval, dsi_grid_widen_interval): per camera lo <= R <= hi
+    for the reference-order value R of 20,000 voxels (dsi_mapper_exact_voxels); after the camera fusion applied to lo and to hi
+    and widened by its roundings, lo_f <= op(R0, R1) <= hi_f with the reference's scalar op on the host; widening only widens;
+    and dsi_grid_prove_columns on those grids agrees with dsi_mapper_prove_near_ties, which computes the same bounds in double."""
+    from dvs_mcemvs_amd import engine
+    nx, ny, nz = 96, 72, 32
+    rig = syn.stereo_rig(300_000, width=nx, height=ny, duration=0.3, seed=23, n_points=400)
+    shape = d.ShapeDSI(0, 0, nz, 4.0, 200.0, 0.0)
+    batches = _batches(ctx, rig, 2)
+    ms = [d.MapperEMVS(ctx, rig["cam"], shape) for _ in range(2)]
+    for m, b in zip(ms, batches):
+        m.evaluateDSI_batch(b)
+    out = d.MapperEMVS(ctx, rig["cam"], shape)
+    g = {k: d.Grid3D(ctx, nx, ny, nz) for k in ("lo0", "hi0", "lo1", "hi1", "fused")}
+    rng = np.random.default_rng(1)
+    heavy = np.argsort(ms[0].dsi_.download().reshape(-1))[-4000:].astype(np.uint32)
+    vox = np.concatenate([rng.integers(0, nx * ny * nz, 16000).astype(np.uint32), heavy])
+    R = []
+    for c in range(2):
+        out.referenceInterval(ms[c], batches[c], g["lo%d" % c], g["hi%d" % c])
+        r = ms[c].exactVoxels(batches[c], vox)[0]
+        lo, hi = (g[k % c].download().reshape(-1)[vox] for k in ("lo%d", "hi%d"))
+        assert np.all(lo <= r) and np.all(r <= hi), "camera %d: %d voxels outside" % (c, int(((r < lo) | (r > hi)).sum()))
+        assert np.all(lo >= 0) and (hi - lo).max() > 0
+        R.append(r)
+    for op in (d.FUSE_HM, d.FUSE_GM, d.FUSE_MIN, d.FUSE_RMS):
+        lo_f, hi_f = d.Grid3D(ctx, nx, ny, nz), d.Grid3D(ctx, nx, ny, nz)
+        lo_f.setToFusionOf(g["lo0"], g["lo1"], op)
+        hi_f.setToFusionOf(g["hi0"], g["hi1"], op)
+        before = (lo_f.download().copy(), hi_f.download().copy())
+        engine.widen_interval(lo_f, hi_f, 8)
+        lo_w, hi_w = lo_f.download(), hi_f.download()
+        assert np.all(lo_w <= before[0]) and np.all(hi_w >= before[1]) and np.all(lo_w >= 0)
+        rf = engine.reference_fuse2(op, R[0], R[1])
+        assert np.all(lo_w.reshape(-1)[vox] <= rf) and np.all(rf <= hi_w.reshape(-1)[vox]), "op %d" % op
+        # the same columns proven as by the dedicated two-camera proof (same bounds, there in double precision throughout:
+        # the fp32 grids can only be a little wider)
+        g["fused"].setToFusionOf(ms[0].dsi_, ms[1].dsi_, op)
+        general = out.proveColumns(g["fused"], lo_f, hi_f, rel_gap=1e-5)
+        direct = out.proveNearTies(ms, batches, op, rel_gap=1e-5)
+        assert general["columns"] == direct["columns"] == nx * ny
+        assert direct["columns_proven"] >= general["columns_proven"] >= direct["columns_proven"] - 0.02 * nx * ny, (general, direct)
+        assert general["max_votes"] == direct["max_votes"] or general["max_votes"] == 0
+        for o in (lo_f, hi_f):
+            o.close()
+    for o in ms + [out] + batches + list(g.values()):
+        o.close()
+
+
 @pytest.mark.parametrize("events,op", [(12_000, d.FUSE_HM), (12_000, d.FUSE_GM), (150_000, d.FUSE_HM), (150_000, d.FUSE_MIN)])
 def test_proven_mode_settles_every_column(ctx, events, op):
     """process.resolve_near_ties_proven: resolve, prove; a moderately wider gap for the columns whose bounds ask for one; and the

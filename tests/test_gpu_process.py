@@ -117,7 +117,14 @@ def test_configs3_eight_time_slices_at_full_size(ctx):
     # fused DSI, their voxels of all 16 (slice, camera) DSIs re-summed in the reference's order, process_2's scalar
     # ops on the host) the plane index map IS the oracle's on all 89,960 pixels
     exact = d.MapperEMVS(ctx, rig["cam"], shape)
-    info = process.exact_depth_map_process_2(ctx, [rig["cam"]] * 2, shape, rig["events"], rig["trajectories"], 8, exact, ts, 2, 2)
+    info = process.exact_depth_map_process_2(ctx, [rig["cam"]] * 2, shape, rig["events"], rig["trajectories"], 8, exact, ts, 2, 2,
+                                             prove=True)
+    # (prove=True, ABI 10: the resolution's premise proven column by column through interval grids -- all 16 (slice, camera)
+    #  DSIs' votes counted, their bounds carried through the harmonic camera fusion and the harmonic temporal fusion)
+    proof = info.pop("proof")
+    print("configs[3] proof: %r" % (proof,))
+    assert proof["columns"] == 346 * 260 and proof["columns_unproven"] == proof["columns_resolved_fully"], proof
+    assert proof["columns_proven"] > 0.99 * 346 * 260 and proof["max_votes"] > 100
     depth2, conf2, idx2 = exact.fetchDepthMap()
     ridx = ref["fused"].argmax(axis=0)
     print("configs[3] exact: %r; %d pixels differed before" % (info, int((idx != ridx).sum())))
@@ -147,6 +154,37 @@ def test_exact_depth_map_process_2_small(ctx, stereo_fusion, temporal_fusion):
     close(exact.dsi_.download(), ref["fused"])
     if temporal_fusion in (2, 4):
         assert info["near_tie_pixels"] > 0
+    exact.close()
+
+
+@pytest.mark.parametrize("stereo_fusion,temporal_fusion,events", [(2, 2, 30_000), (3, 4, 30_000), (6, 2, 30_000), (2, 2, 400_000),
+                                                                  (1, 4, 400_000)])
+def test_process_2_proven_through_interval_grids(ctx, stereo_fusion, temporal_fusion, events):
+    """Alg. 2's resolution with its premise PROVEN (ABI 10, interval grids): every (sub-interval, camera) DSI's votes counted
+    and bounded, the bounds carried through the camera fusion and the temporal accumulate / finalize like the values, every
+    column either proven or re-summed on all planes; the map is the oracle's process_2 arg-max.  With a gap of rounding size
+    the same bounds leave the contested columns unproven: they are not vacuous."""
+    rig = syn.stereo_rig(events, width=64, height=48, duration=0.3, seed=47, n_points=500)
+    shape = d.ShapeDSI(0, 0, 14, 4.0, 150.0, 0.0)
+    exact = d.MapperEMVS(ctx, rig["cam"], shape)
+    ts = rig["t0"] + 0.15
+    info = process.exact_depth_map_process_2(ctx, [rig["cam"]] * 2, shape, rig["events"], rig["trajectories"], 4, exact, ts,
+                                             stereo_fusion, temporal_fusion, prove=True)
+    proof = info["proof"]
+    assert proof["columns"] == 64 * 48 and proof["columns_proven"] + proof["columns_unproven"] == 64 * 48
+    assert proof["columns_unproven"] == proof["columns_resolved_fully"], proof
+    assert proof["max_votes"] > 5
+    ref = oracle_process_2(lambda: OracleMapper(rig["cam"], dimZ=14, min_depth=4.0, max_depth=150.0),
+                           rig["events"], rig["trajectories"], 4, ts, stereo_fusion, temporal_fusion)
+    depth, conf, idx = exact.fetchDepthMap()
+    assert np.array_equal(idx, ref["fused"].argmax(axis=0)), proof
+    tiny = process.exact_depth_map_process_2(ctx, [rig["cam"]] * 2, shape, rig["events"], rig["trajectories"], 4, exact, ts,
+                                             stereo_fusion, temporal_fusion, rel_gap=1e-7, prove=True)["proof"]
+    assert tiny["columns_unproven"] >= proof["columns_unproven"] - proof["columns_resolved_fully"]
+    if events >= 100_000:
+        # voxels with hundreds of votes: bounds of 1e-5, which a gap of 1e-7 cannot cover -- and most columns settled by bounds
+        assert tiny["columns_unproven"] > 0 and tiny["gap_needed"] > 1e-7, tiny
+        assert proof["columns_proven"] > 0.5 * 64 * 48, proof
     exact.close()
 
 
